@@ -1,0 +1,133 @@
+/* unit_hip.h -- C ABI of libunit_hip.so: the MI355X (gfx950) operator library behind the Faster-R-CNN-C4 hot path of
+ * ubc-vision/UniT.  This is the drop-in boundary: every entry point is `extern "C"`, takes raw
+ * device pointers + explicit shapes/strides + a caller-owned workspace, launches asynchronously on the given
+ * hipStream_t (passed as void*), never allocates, never synchronises, never throws.  Return 0 on success, <0 on
+ * error (unit_last_error() gives the message).  One process per GPU; the library keeps no global mutable state.
+ *
+ * The reference reaches these operators through PyTorch's dispatcher into ATen/cuDNN, Detectron2 `_C` and torchvision;
+ * each declaration cites the UniT call site (path under /root/reference) whose operator it replaces.
+ * dtype codes: 0 = fp32, 1 = bf16.  All activation tensors are NHWC; "ld" arguments are row strides in elements.
+ * Data-dependent sizes (proposal counts, RoI counts, ...) live in device int32 arrays so the step never syncs.
+ */
+#ifndef UNIT_HIP_H
+#define UNIT_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+int unit_version(void);
+const char* unit_last_error(void);
+
+/* ---- a1 preprocess_image: modeling/meta_arch/rcnn.py:257-266 (+ ImageList.from_tensors zero padding) ---- */
+int unit_preprocess_image(const float* img_chw, int C, int H, int W, const float* mean3, const float* std3, float prescale,
+                          void* out_nhwc, int out_dtype, int Hmax, int Wmax, int Cpad, void* stream);
+/* NCHW fp32 <-> NHWC converters for the plugin boundary (reference tensors are NCHW fp32) */
+int unit_nchw_to_nhwc(const float* x, void* y, int dtype, int N, int C, int H, int W, int Cp, void* stream);
+int unit_nhwc_to_nchw(const void* x, int dtype, float* y, int N, int C, int H, int W, int Cp, void* stream);
+int unit_cast(const void* x, int in_dtype, void* y, int out_dtype, long n, void* stream);
+int unit_add_cast(const float* a32, const void* b, void* y, int dtype, long n, void* stream);
+
+/* ---- a2/a3/a9/a10 convolution as implicit GEMM on MFMA: backbone (configs/VOC/VOC-RCNN-101-C4-split1.yaml:6-10 ->
+ * detectron2 build_resnet_backbone), RPN head (modeling/proposal_generator/rpn.py:24), Res5 heads
+ * (modeling/roi_heads/box_head.py:65-80), Linear predictors (modeling/roi_heads/fast_rcnn.py:386-387,
+ * modeling/roi_heads/weak_detector_fast_rcnn.py:150-156).  unit_conv2d_fwd is also the dgrad kernel (flipped,
+ * transposed weights from unit_weight_prep; strided scatter + ReLU-mask epilogue). ---- */
+int unit_conv2d_fwd(const void* x, const void* w, void* y, const float* bias, const void* residual, const void* mask_ref,
+                    int in_dtype, int out_dtype, int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int OH,
+                    int OW, int ldy, int oy_mul, int OHf, int OWf, int relu, int tile_cfg, void* stream);
+size_t unit_conv2d_wgrad_workspace_bytes(int in_dtype, int N, int OH, int OW, int K, int R, int S, int C);
+int unit_conv2d_wgrad(const void* x, const void* dy, float* dw, const float* scale_k, int in_dtype, int N, int H, int W, int C,
+                      int K, int R, int S, int stride, int pad, int OH, int OW, int ldy, int accumulate, void* workspace,
+                      size_t workspace_bytes, void* stream);
+/* FrozenBatchNorm2d fold (detectron2 layers/batch_norm.py, eps 1e-5) and weight re-layout / cast */
+int unit_frozen_bn_fold(const float* w, const float* b, const float* rm, const float* rv, float eps, float* scale, float* shift,
+                        int C, void* stream);
+int unit_weight_prep(const float* w_krsc, const float* scale_k, int K, int R, int S, int C, int Cp, void* w_fwd, void* w_dgrad,
+                     int dtype, void* stream);
+int unit_bias_grad(const void* dy, int dtype, int M, int K, int ld, float* db, int accumulate, void* stream);
+int unit_maxpool3x3s2_fwd(const void* x, void* y, int dtype, int N, int H, int W, int C, void* stream);
+/* Res5BoxHead.forward x.mean(dim=[2,3]): modeling/roi_heads/box_head.py:80 */
+int unit_global_avgpool_fwd(const void* x, void* y, int dtype, int R, int P, int C, void* stream);
+int unit_global_avgpool_bwd_relu(const void* dfeat, const void* out, void* g, int dtype, int R, int P, int C, void* stream);
+
+/* ---- K5 anchors (DefaultAnchorGenerator via modeling/proposal_generator/rpn.py:22) ---- */
+int unit_anchor_grid(float* out, int H, int W, int A, float stride, float offset, const float* cell_dev, void* stream);
+
+/* ---- K6/K7 pairwise IoU + Matcher: modeling/matcher.py:54-120 (and the stock d2 matcher via rpn.py:41, roi_heads.py:563) */
+size_t unit_iou_match_workspace_bytes(int B, int Mcap);
+int unit_iou_match(const float* gt, const int* gt_count, int B, int Mcap, const float* boxes, long box_batch_stride,
+                   const int* box_count, int Ncap, const float* thresholds, const int* labels, int n_thresh,
+                   int allow_low_quality, int64_t* match_idx, int8_t* match_label, float* match_val, void* workspace,
+                   size_t workspace_bytes, void* stream);
+int unit_pairwise_iou(const float* b1, int M, const float* b2, int Nb, float* out, void* stream);
+
+/* ---- K8 subsample_labels with the explicit-permutation contract (detectron2.modeling.sampling via rpn.py:41,
+ * roi_heads.py:563, roi_heads.py:415) ---- */
+int unit_subsample_labels(const void* labels, int labels_are_int64, const int* count, int B, int Ncap, const int* perm, int Pcap,
+                          int num_samples, int max_pos, int bg_label, int8_t* out_labels, int* sampled_idx, int* out_counts,
+                          void* stream);
+
+/* ---- K9 Box2BoxTransform (rpn.py:70, fast_rcnn.py:71, weak_detector_fast_rcnn.py:275) ---- */
+int unit_box_encode(const float* src, const float* tgt, const float* weights4, float* out, int n, void* stream);
+int unit_box_decode(const float* deltas, int ld, int col0, int K, const float* boxes, const float* weights4, float scale_clamp,
+                    float* out, int n, void* stream);
+
+/* ---- K10/K11/a6 find_top_rpn_proposals (detectron2 via rpn.py:48): stable descending sort, decode+clip+filter, NMS */
+size_t unit_sort_workspace_bytes(int B, int n);
+int unit_sort_desc_stable(const float* src, long batch_stride, int ld, int A, int col0, int B, int n, float* out_keys, int* out_idx,
+                          void* workspace, size_t workspace_bytes, void* stream);
+int unit_rpn_decode_select(const float* head, long head_batch_stride, int ld, int A, int delta_col0, const float* anchors,
+                           const int* sorted_idx, const float* sorted_logit, int B, int Ncap, int topk, const float* image_hw_dev,
+                           float scale_clamp, float min_size, float* cand_boxes, float* cand_scores, int* cand_count, void* stream);
+size_t unit_nms_workspace_bytes(int B, int cap);
+int unit_nms(const float* boxes_sorted, const float* scores_sorted, const int* count, int B, int cap, float thresh, int max_keep,
+             int* keep_idx, int* keep_count, float* out_boxes, float* out_scores, void* workspace, size_t workspace_bytes,
+             void* stream);
+
+/* ---- a7 ROIHeads.label_and_sample_proposals plumbing (roi_heads.py:563, :566-572) ---- */
+int unit_append_gt(const float* props, const int* pcount, int Pcap, const float* gt, const int* gcount, int Mcap, int B, float* cat,
+                   int* ccount, void* stream);
+int unit_roi_classes(const int64_t* match_idx, const int8_t* match_label, const int* count, const int64_t* gt_classes,
+                     const int* gcount, int Mcap, int B, int Ncap, int K, int64_t* cls, void* stream);
+int unit_gather_rois(const float* cat, int Ncap, const int* sampled_idx, int S, const int64_t* cls, const int64_t* match_idx,
+                     const float* gt, const int* gcount, int Mcap, int B, float* rois, int* roi_cls, float* roi_gt, void* stream);
+int unit_first_k_rois(const float* props, const int* pcount, int Pcap, int S, int B, int batch_index_offset, float* rois, int* valid,
+                      void* stream);
+
+/* ---- a8 RoIAlign (ROIAlignV2): roi_heads.py:499,511,708 via detectron2 ROIPooler ---- */
+int unit_roi_align_fwd(const void* feat_nhwc, int dtype, int N, int H, int W, int C, const float* rois, const int* roi_count_dev,
+                       int R, int pooled_size, int out_size, int bin_step, float spatial_scale, int sampling_ratio, int aligned,
+                       void* out, void* stream);
+int unit_roi_align_bwd(const void* gout, int dtype, int N, int H, int W, int C, const float* rois, const int* roi_count_dev, int R,
+                       int pooled_size, int out_size, int bin_step, float spatial_scale, int sampling_ratio, int aligned,
+                       float* dfeat_f32, void* stream);
+
+/* ---- a5/a10/a11/a12 fused loss forward+backward kernels ---- */
+int unit_rpn_loss(const float* head, int ld, int A, int dcol0, const int8_t* labels, const int64_t* match_idx, const float* gt_boxes,
+                  int Mcap, const float* anchors, int B, int Ncap, float normalizer, float gscale, float* loss2, void* dhead,
+                  int dhead_dtype, void* stream);
+int unit_sup_scores(const float* delta, int ldd, int dcol0, const float* weak, int ldw, int wcol0, int n_oicr, int ncls,
+                    const unsigned char* novel_mask_dev, const float* extra, int lde, int ecol0, float* out, int ldo, int R,
+                    void* stream);
+int unit_softmax_ce(const float* logits, int ld, int col0, int ncls, const int* labels, const float* weights, int R, float gscale,
+                    float* loss, void* dy, int dy_dtype, int ldd, int dcol0, void* stream);
+int unit_box_reg_loss(const float* bbox, int ld, int col0, int K, const int* labels, const float* rois5, const float* gt_boxes,
+                      const float* weights4, int R, float gscale, float* loss, void* dy, int dy_dtype, int ldd, int dcol0,
+                      void* stream);
+int unit_wsddn_mil(const float* streams, int ld, int ccol0, int dcol0, int K, const int* valid, int S, int B,
+                   const unsigned char* multihot, float cls_temp, float det_temp, float mil_multiplier, float gscale, float* loss,
+                   float* xr_out, void* dy, int dy_dtype, int ldd, int dyc0, int dyd0, void* stream);
+int unit_oicr_targets(const float* src, int ld, int col0, int mode, int K, const float* rois5, const int* valid, int S, int B,
+                      const unsigned char* multihot, float fg_thresh, float bg_thresh, int* labels, float* weights, void* stream);
+int unit_sum_losses(const float* losses, int n, float* out, void* stream);
+
+/* ---- K18 SGD momentum (solver/build.py:110-112) ---- */
+int unit_sgd_momentum(float* p, const float* g, float* buf, long n, float lr, float momentum, float wd, float grad_scale,
+                      int first_step, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

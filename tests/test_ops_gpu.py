@@ -1,0 +1,516 @@
+"""GPU parity tests: every HIP operator (through the C ABI) against the CPU oracle on the same seeded inputs.
+Bar: bit-exact for integer / index outputs; fp32 within the tolerance written next to each check."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import unit_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+def ops():
+    from unit_amd import ops as o
+    return o
+
+
+def g(seed):
+    return torch.Generator().manual_seed(seed)
+
+
+def nhwc(x):  # NCHW -> NHWC
+    return x.permute(0, 2, 3, 1).contiguous()
+
+
+def nchw(x):
+    return x.permute(0, 3, 1, 2).contiguous()
+
+
+def krsc(w):  # [K,C,R,S] -> [K,R,S,C]
+    return w.permute(0, 2, 3, 1).contiguous()
+
+
+def rand_boxes(gen, n, w=1000.0, h=600.0, lo=16, hi=300):
+    x0 = torch.rand(n, generator=gen) * (w - 40)
+    y0 = torch.rand(n, generator=gen) * (h - 40)
+    bw = lo + torch.rand(n, generator=gen) * hi
+    bh = lo + torch.rand(n, generator=gen) * hi
+    return torch.stack([x0, y0, torch.minimum(x0 + bw, torch.tensor(w)), torch.minimum(y0 + bh, torch.tensor(h))], 1)
+
+
+# ------------------------------------------------------------------------------------------- a1
+def test_preprocess(dev):
+    o = ops()
+    gen = g(0)
+    imgs = [torch.rand(3, 37, 53, generator=gen) * 255, torch.rand(3, 41, 47, generator=gen) * 255]
+    mean, std = [103.53, 116.28, 123.675], [1.0, 1.0, 1.0]
+    ref, sizes = orc.preprocess_image(imgs, mean, std)
+    out, sizes2 = o.preprocess_images([i.to(dev) for i in imgs], mean, std, dtype=torch.float32, cpad=8)
+    assert sizes == sizes2
+    got = out.cpu()
+    assert torch.equal(got[..., :3], nhwc(ref))  # fp32 mode is bit-exact
+    assert torch.count_nonzero(got[..., 3:]) == 0
+    std2 = [57.375, 57.12, 58.395]
+    ref2, _ = orc.preprocess_image(imgs, mean, std2, normalize_images=True)
+    out2, _ = o.preprocess_images([i.to(dev) for i in imgs], mean, std2, dtype=torch.float32, normalize_images=True)
+    assert torch.allclose(out2.cpu()[..., :3], nhwc(ref2), rtol=0, atol=1e-6)
+
+
+# ------------------------------------------------------------------------------------------- conv
+CONV_CASES = [
+    # N, H, W, C, K, R, stride, pad
+    (2, 13, 17, 16, 24, 3, 1, 1),
+    (1, 20, 31, 64, 256, 1, 1, 0),
+    (2, 19, 23, 32, 64, 1, 2, 0),
+    (1, 40, 52, 8, 64, 7, 2, 3),      # stem-shaped (C padded 3->8)
+    (1, 38, 63, 128, 75, 1, 1, 0),    # RPN predictor: K=75 -> ldy 80
+    (3, 30, 33, 256, 256, 3, 1, 1),   # many tiles
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_conv_fwd(dev, case, dtype):
+    o = ops()
+    n, h, w, c, k, r, stride, pad = case
+    gen = g(1)
+    x = torch.randn(n, c, h, w, generator=gen)
+    wt = torch.randn(k, c, r, r, generator=gen) * (1.0 / np.sqrt(c * r * r))
+    bias = torch.randn(k, generator=gen)
+    xq, wq = x.to(dtype).float(), wt.to(dtype).float()
+    ref = F.conv2d(xq, wq, bias, stride=stride, padding=pad)
+    res = torch.randn(ref.shape, generator=gen).to(dtype).float()
+    ref_full = F.relu(ref + res)
+    xd, wd = nhwc(x).to(dev).to(dtype), krsc(wt).to(dev).to(dtype)
+    tol = 2e-5 if dtype == torch.float32 else 2e-2
+    for tile in (0, 1, 4):
+        y = o.conv2d(xd, wd, k, r, r, stride, pad, bias=bias.to(dev), out_dtype=torch.float32, tile_cfg=tile)
+        got = nchw(y.cpu()[..., :k])
+        assert torch.allclose(got, ref, rtol=tol, atol=tol * 4), (tile, (got - ref).abs().max())
+    ldy = (k + 3) // 4 * 4
+    resd = torch.zeros(n, ref.shape[2], ref.shape[3], ldy)
+    resd[..., :k] = nhwc(res)
+    y2 = o.conv2d(xd, wd, k, r, r, stride, pad, bias=bias.to(dev), residual=resd.to(dev).to(dtype), relu=True)
+    got2 = nchw(y2.float().cpu()[..., :k])
+    tol2 = tol if dtype == torch.float32 else 4e-2
+    assert torch.allclose(got2, ref_full, rtol=tol2, atol=tol2 * 4)
+
+
+@pytest.mark.parametrize("case", [(2, 13, 17, 16, 24, 3, 1, 1), (1, 20, 31, 64, 128, 1, 1, 0), (2, 19, 23, 32, 64, 1, 2, 0),
+                                  (2, 14, 14, 64, 128, 1, 2, 0)])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_conv_dgrad_wgrad(dev, case, dtype):
+    o = ops()
+    n, h, w, c, k, r, stride, pad = case
+    gen = g(2)
+    x = torch.randn(n, c, h, w, generator=gen).to(dtype).float().requires_grad_(True)
+    wt = (torch.randn(k, c, r, r, generator=gen) / np.sqrt(c * r * r)).to(dtype).float().requires_grad_(True)
+    scale = torch.rand(k, generator=gen) + 0.5
+    y = F.conv2d(x, wt * scale.view(-1, 1, 1, 1), None, stride=stride, padding=pad)
+    dy = torch.randn(y.shape, generator=gen).to(dtype).float()
+    mask_src = torch.randn(x.shape, generator=gen)  # stands for the conv input's pre-activation sign
+    y.backward(dy)
+    dx_ref = x.grad * (mask_src > 0)
+    dw_ref = wt.grad
+    oh, ow = y.shape[2], y.shape[3]
+    wsrc = krsc(wt.detach()).to(dev)
+    w_fwd, w_dg = o.weight_prep(wsrc, scale.to(dev), k, r, r, c, c, dtype)
+    assert torch.allclose(w_fwd.float().cpu(), krsc((wt.detach() * scale.view(-1, 1, 1, 1)).to(dtype).float()), rtol=1e-2 if dtype != torch.float32 else 1e-6, atol=1e-6)
+    dyd = nhwc(dy).to(dev).to(dtype)
+    maskd = nhwc(mask_src).to(dev).to(dtype)
+    if stride == 1:
+        dx = o.conv2d(dyd, w_dg, c, r, r, 1, r - 1 - pad, mask_ref=maskd)
+    else:
+        dx = o.conv2d(dyd, w_dg, c, 1, 1, 1, 0, mask_ref=maskd, scatter=(stride, h, w))
+    tol = 5e-5 if dtype == torch.float32 else 3e-2
+    got = nchw(dx.float().cpu()[..., :c])
+    assert torch.allclose(got, dx_ref, rtol=tol, atol=tol * 4), (got - dx_ref).abs().max()
+    xd = nhwc(x.detach()).to(dev).to(dtype)
+    dw = o.conv2d_wgrad(xd, dyd, k, r, r, stride, pad, scale=scale.to(dev))
+    gotw = dw.cpu().permute(0, 3, 1, 2)
+    tolw = 1e-4 if dtype == torch.float32 else 3e-2
+    assert torch.allclose(gotw, dw_ref, rtol=tolw, atol=tolw * dw_ref.abs().max().item()), (gotw - dw_ref).abs().max()
+    # accumulate=True adds on top
+    dw2 = o.conv2d_wgrad(xd, dyd, k, r, r, stride, pad, scale=scale.to(dev), out=dw.clone(), accumulate=True)
+    assert torch.allclose(dw2.cpu(), 2 * dw.cpu(), rtol=1e-5, atol=1e-6)
+
+
+def test_wgrad_big_m(dev):
+    """M spans many split-M chunks and is not a multiple of the staging step."""
+    o = ops()
+    gen = g(3)
+    n, h, w, c, k = 3, 37, 41, 128, 256
+    x = torch.randn(n, c, h, w, generator=gen).bfloat16().float().requires_grad_(False)
+    dy = torch.randn(n, k, h, w, generator=gen).bfloat16().float()
+    ref = torch.einsum("nkhw,nchw->kc", dy, x)
+    dw = o.conv2d_wgrad(nhwc(x).to(dev).bfloat16(), nhwc(dy).to(dev).bfloat16(), k, 1, 1)
+    got = dw.cpu().view(k, c)
+    assert torch.allclose(got, ref, rtol=2e-2, atol=2e-2 * ref.abs().max().item())
+
+
+def test_pools_bias_misc(dev):
+    o = ops()
+    gen = g(4)
+    x = torch.randn(2, 64, 21, 30, generator=gen)
+    ref = F.max_pool2d(x, 3, 2, 1)
+    got = nchw(o.maxpool3x3s2(nhwc(x).to(dev)).cpu())
+    assert torch.equal(got, ref)
+    r = torch.randn(10, 128, 7, 7, generator=gen)
+    got = o.global_avgpool(nhwc(r).to(dev)).cpu()
+    assert torch.allclose(got, r.mean(dim=[2, 3]), rtol=1e-5, atol=1e-6)
+    df = torch.randn(10, 128, generator=gen)
+    gb = o.global_avgpool_bwd_relu(df.to(dev), nhwc(r).to(dev)).cpu()
+    refb = (df.view(10, 128, 1, 1) / 49.0) * (r > 0)
+    assert torch.allclose(nchw(gb), refb, rtol=1e-6, atol=1e-7)
+    dy = torch.randn(1000, 80, generator=gen)
+    db = o.bias_grad(dy.to(dev), 75).cpu()
+    assert torch.allclose(db, dy[:, :75].sum(0), rtol=1e-4, atol=1e-4)
+    bnw, bnb, rm, rv = [torch.rand(64, generator=gen) + 0.5 for _ in range(4)]
+    sc, sh = o.frozen_bn_fold(bnw.to(dev), bnb.to(dev), rm.to(dev), rv.to(dev))
+    sref = bnw * (rv + 1e-5).rsqrt()
+    assert torch.allclose(sc.cpu(), sref, rtol=1e-6, atol=0) and torch.allclose(sh.cpu(), bnb - rm * sref, rtol=1e-6, atol=1e-6)
+    p, gr, buf = torch.randn(1003, generator=gen), torch.randn(1003, generator=gen), torch.randn(1003, generator=gen)
+    pd, bd = p.clone().to(dev), buf.clone().to(dev)
+    o.sgd_momentum(pd, gr.to(dev), bd, 0.02, 0.9, 1e-4)
+    d = gr + 1e-4 * p
+    b2 = 0.9 * buf + d
+    assert torch.allclose(bd.cpu(), b2, rtol=1e-6, atol=1e-7) and torch.allclose(pd.cpu(), p - 0.02 * b2, rtol=1e-6, atol=1e-7)
+
+
+# ------------------------------------------------------------------------------------------- anchors / matcher / sampling
+def test_anchor_grid(dev):
+    o = ops()
+    ref = orc.grid_anchors(38, 63)
+    got = o.anchor_grid(38, 63, o.cell_anchors().to(dev)).cpu()
+    assert torch.equal(got, ref)
+
+
+def test_iou_match_golden(dev):
+    """HIP matcher vs the vectors produced by the REFERENCE's own modeling/matcher.py (tests/golden/matcher_golden.npz)."""
+    import os
+    o = ops()
+    gold = np.load(os.path.join(os.path.dirname(__file__), "golden", "matcher_golden.npz"))
+    names = sorted({k.split("/")[0] for k in gold.files if k.endswith("/gt")})
+    assert names
+    for name in names:
+        gt, pr = torch.from_numpy(gold[f"{name}/gt"]), torch.from_numpy(gold[f"{name}/pr"])
+        q = torch.from_numpy(gold[f"{name}/q"])
+        got_q = o.pairwise_iou(gt.to(dev), pr.to(dev)).cpu()
+        assert torch.equal(got_q, q), name  # IoU bit-exact
+        for cn, (th, lb, lq) in {"rpn": ([0.3, 0.7], [0, -1, 1], True), "roi": ([0.5], [0, 1], False)}.items():
+            idx, lab, val = o.iou_match(gt[None].to(dev), None, pr.to(dev), None, th, lb, lq)
+            assert np.array_equal(idx[0].cpu().numpy(), gold[f"{name}/{cn}/idx"]), (name, cn)
+            assert np.array_equal(lab[0].cpu().numpy(), gold[f"{name}/{cn}/label"]), (name, cn)
+            assert np.array_equal(val[0].cpu().numpy(), gold[f"{name}/{cn}/val"]), (name, cn)
+
+
+def test_iou_match_batched_counts(dev):
+    o = ops()
+    gen = g(5)
+    anchors = orc.grid_anchors(38, 63)
+    gts = [rand_boxes(gen, 5), rand_boxes(gen, 0), rand_boxes(gen, 17)]
+    mcap = 20
+    gt = torch.zeros(3, mcap, 4)
+    cnt = torch.tensor([len(x) for x in gts], dtype=torch.int32)
+    for i, x in enumerate(gts):
+        gt[i, : len(x)] = x
+    idx, lab, val = o.iou_match(gt.to(dev), cnt.to(dev), anchors.to(dev), None, [0.3, 0.7], [0, -1, 1], True)
+    for i, x in enumerate(gts):
+        ri, rl, rv = orc.iou_match_c(x.numpy(), anchors.numpy(), [0.3, 0.7], [0, -1, 1], True)
+        assert np.array_equal(idx[i].cpu().numpy(), ri) and np.array_equal(lab[i].cpu().numpy(), rl)
+        assert np.array_equal(val[i].cpu().numpy(), rv)
+        m = orc.Matcher(**orc.RPN_MATCHER)
+        ti, tl, tv = m(orc.pairwise_iou(x, anchors))
+        assert np.array_equal(ti.numpy(), ri) and np.array_equal(tl.numpy(), rl)
+
+
+def test_subsample(dev):
+    o = ops()
+    gen = g(6)
+    n = 35910
+    labels = torch.full((2, n), 0, dtype=torch.int8)
+    labels[0, torch.randperm(n, generator=gen)[:300]] = 1
+    labels[0, torch.randperm(n, generator=gen)[:5000]] = -1
+    labels[1, torch.randperm(n, generator=gen)[:40]] = 1
+    perm = torch.stack([torch.randperm(n, generator=gen) for _ in range(2)]).int()
+    out, sidx, counts = o.subsample_labels(labels.to(dev), None, perm.to(dev), 256, 0.5, 0)
+    for i in range(2):
+        pos, neg = orc.subsample_labels(labels[i], 256, 0.5, 0, perm[i].long())
+        ref = torch.full((n,), -1, dtype=torch.int8)
+        ref[pos] = 1
+        ref[neg] = 0
+        assert torch.equal(out[i].cpu(), ref)
+        assert counts[i].tolist() == [len(pos), len(neg)]
+        assert torch.equal(sidx[i].cpu().long()[: len(pos) + len(neg)], torch.cat([pos, neg]))
+    # ROI flavour: int64 classes, bg = K, count < capacity, perm longer than count
+    k = 20
+    cls = torch.randint(0, k + 1, (1, 2100), generator=gen)
+    cls[0, torch.randperm(2100, generator=gen)[:1800]] = k
+    cnt = torch.tensor([1985], dtype=torch.int32)
+    perm = torch.randperm(2100, generator=gen).int()[None]
+    _, sidx, counts = o.subsample_labels(cls.to(dev), cnt.to(dev), perm.to(dev), 512, 0.25, k, want_labels=False)
+    fg, bg = orc.subsample_labels(cls[0, :1985], 512, 0.25, k, perm[0].long())
+    assert counts[0].tolist() == [len(fg), len(bg)]
+    assert torch.equal(sidx[0].cpu().long()[: len(fg) + len(bg)], torch.cat([fg, bg]))
+
+
+def test_box_codec(dev):
+    o = ops()
+    gen = g(7)
+    src, tgt = rand_boxes(gen, 500), rand_boxes(gen, 500)
+    for wts in [(1.0, 1.0, 1.0, 1.0), (10.0, 10.0, 5.0, 5.0)]:
+        ref = orc.get_deltas(src, tgt, wts)
+        got = o.box_encode(src.to(dev), tgt.to(dev), wts).cpu()
+        assert torch.allclose(got, ref, rtol=1e-5, atol=1e-5)   # log() ulp differences only
+        d = torch.randn(500, 80, generator=gen)
+        refd = orc.apply_deltas(d, src, wts)
+        gotd = o.box_decode(d.to(dev), src.to(dev), wts).cpu()
+        assert torch.allclose(gotd, refd, rtol=1e-5, atol=1e-3)
+
+
+# ------------------------------------------------------------------------------------------- sort / nms / proposals
+def test_sort_desc_stable(dev):
+    o = ops()
+    gen = g(8)
+    n = 35910
+    keys = torch.randn(2, n, generator=gen)
+    keys[0, ::7] = keys[0, 0]            # many ties
+    keys[1] = torch.round(keys[1] * 4) / 4
+    k, i = o.sort_desc(keys.to(dev), 2, n)
+    rk, ri = torch.sort(keys, dim=1, descending=True, stable=True)
+    assert torch.equal(i.cpu().long(), ri) and torch.equal(k.cpu(), rk)
+    # strided read (RPN head layout [HW][ld], A anchors per pixel)
+    a, ld = 15, 80
+    head = torch.randn(1, 2394, ld, generator=gen)
+    k2, i2 = o.sort_desc(head.to(dev), 1, 2394 * a, ld=ld, a=a, col0=0)
+    flat = head[0, :, :a].reshape(-1)
+    rk, ri = torch.sort(flat, descending=True, stable=True)
+    assert torch.equal(i2[0].cpu().long(), ri) and torch.equal(k2[0].cpu(), rk)
+
+
+def test_nms_exact(dev):
+    o = ops()
+    gen = g(9)
+    for n, thr, mk in [(1, 0.7, 10), (63, 0.5, 100), (1500, 0.7, 2000), (6000, 0.7, 1000), (12000, 0.7, 2000)]:
+        b = rand_boxes(gen, n, lo=8, hi=200)
+        b[n // 2:] = b[: n - n // 2] + torch.rand(n - n // 2, 4, generator=gen) * 6  # heavy overlaps
+        s = torch.sort(torch.randn(n, generator=gen), descending=True)[0]
+        cap = max(n, 64)
+        bb = torch.zeros(1, cap, 4)
+        bb[0, :n] = b
+        ss = torch.zeros(1, cap)
+        ss[0, :n] = s
+        keep, kc, ob, osc = o.nms(bb.to(dev), ss.to(dev), torch.tensor([n], dtype=torch.int32).to(dev), thr, mk)
+        ref = orc.nms_sorted(b.numpy(), thr)[:mk]
+        assert int(kc[0]) == len(ref), (n, int(kc[0]), len(ref))
+        assert np.array_equal(keep[0, : len(ref)].cpu().numpy(), ref)
+        assert torch.equal(ob[0, : len(ref)].cpu(), b[torch.from_numpy(ref)])
+
+
+def test_rpn_proposals(dev):
+    o = ops()
+    gen = g(10)
+    h, w, a = 38, 63, 15
+    anchors = orc.grid_anchors(h, w)
+    n = anchors.shape[0]
+    logits = torch.randn(2, n, generator=gen)
+    deltas = torch.randn(2, n, 4, generator=gen) * 0.5
+    deltas[0, :10, 2] = 30.0  # exercises the scale clamp
+    sizes = [(600, 1000), (480, 800)]
+    ref = orc.find_top_rpn_proposals(anchors, logits, deltas, sizes, pre_nms_topk=6000, post_nms_topk=1000)
+    head = torch.zeros(2, h * w, 80)
+    head[:, :, :a] = logits.view(2, h * w, a)
+    head[:, :, a:a + 4 * a] = deltas.view(2, h * w, 4 * a)
+    hd = head.to(dev)
+    sk, si = o.sort_desc(hd, 2, n, ld=80, a=a, col0=0)
+    hw = torch.tensor(sizes, dtype=torch.float32).to(dev)
+    cb, cs, cc = o.rpn_decode_select(hd, a, a, anchors.to(dev), si, sk, 6000, hw)
+    keep, kc, ob, osc = o.nms(cb, cs, cc, 0.7, 1000)
+    for i in range(2):
+        rb, rs = ref[i]
+        assert int(kc[i]) == len(rb)
+        assert torch.allclose(ob[i, : len(rb)].cpu(), rb, rtol=1e-5, atol=1e-3)
+        assert torch.equal(osc[i, : len(rb)].cpu(), rs)
+
+
+# ------------------------------------------------------------------------------------------- RoI stage
+def make_rois(gen, r, n_img, w=1000.0, h=600.0):
+    b = rand_boxes(gen, r, w, h, lo=2, hi=500)
+    b[0] = torch.tensor([10.0, 10.0, 10.0, 10.0])          # zero-area RoI -> grid 0 -> output 0
+    b[1] = torch.tensor([-40.0, -30.0, 90.0, 70.0])        # partly outside the map
+    b[2] = torch.tensor([900.0, 500.0, 1100.0, 700.0])
+    bi = torch.randint(0, n_img, (r, 1), generator=gen).float()
+    return torch.cat([bi, b], 1)
+
+
+@pytest.mark.parametrize("c", [32, 1024])
+def test_roi_align_fwd_bwd(dev, c):
+    o = ops()
+    gen = g(11)
+    n, h, w, r = 2, 38, 63, 48
+    feat = torch.randn(n, c, h, w, generator=gen)
+    rois = make_rois(gen, r, n)
+    ref = orc.roi_align_forward(feat.numpy(), rois.numpy())
+    got = o.roi_align(nhwc(feat).to(dev), rois.to(dev)).cpu()
+    assert np.array_equal(nchw(got).numpy(), ref)   # fp32 mode: bit-exact (same op order, no FMA contraction)
+    # strided mode == every other bin of the full mode
+    got_s = o.roi_align(nhwc(feat).to(dev), rois.to(dev), pooled_size=14, out_size=7, bin_step=2).cpu()
+    assert torch.equal(got_s, got[:, ::2, ::2, :])
+    # bf16 storage
+    got_b = o.roi_align(nhwc(feat).to(dev).bfloat16(), rois.to(dev)).float().cpu()
+    refb = orc.roi_align_forward(feat.bfloat16().float().numpy(), rois.numpy())
+    assert np.allclose(nchw(got_b).numpy(), refb, rtol=1e-2, atol=1e-2)
+    # backward (atomics: order differs -> tolerance vs the fp64-accumulated oracle)
+    gout = torch.randn(r, c, 14, 14, generator=gen)
+    refd = orc.roi_align_backward(gout.numpy(), (n, c, h, w), rois.numpy())
+    gotd = o.roi_align_bwd(nhwc(gout).to(dev), (n, h, w, c), rois.to(dev)).cpu()
+    assert np.allclose(nchw(gotd).numpy(), refd, rtol=1e-4, atol=1e-4)
+    gs = gout[:, :, ::2, ::2].contiguous()
+    gfull = torch.zeros_like(gout)
+    gfull[:, :, ::2, ::2] = gs
+    refs = orc.roi_align_backward(gfull.numpy(), (n, c, h, w), rois.numpy())
+    gots = o.roi_align_bwd(nhwc(gs).to(dev), (n, h, w, c), rois.to(dev), pooled_size=14, bin_step=2).cpu()
+    assert np.allclose(nchw(gots).numpy(), refs, rtol=1e-4, atol=1e-4)
+
+
+def test_roi_sampling_pipeline(dev):
+    """a7: append GT -> IoU/match[0.5] -> classes -> subsample(512,25%) -> gather, vs oracle.label_and_sample_proposals."""
+    o = ops()
+    gen = g(12)
+    k = 20
+    b = 2
+    pcap, mcap = 600, 8
+    props = [rand_boxes(gen, 500), rand_boxes(gen, 130)]
+    gts = [rand_boxes(gen, 5), rand_boxes(gen, 3)]
+    for i in range(b):
+        props[i][:40] = gts[i][torch.randint(0, len(gts[i]), (40,), generator=gen)] + torch.rand(40, 4, generator=gen) * 10
+    gcls = [torch.randint(0, k, (len(x),), generator=gen) for x in gts]
+    perms = [torch.randperm(pcap + mcap, generator=gen) for _ in range(b)]
+    ref = orc.label_and_sample_proposals([(p, torch.zeros(len(p))) for p in props], gts, gcls, perms, k, 128, 0.25)
+    pt = torch.zeros(b, pcap, 4); gt = torch.zeros(b, mcap, 4); gc = torch.zeros(b, mcap, dtype=torch.int64)
+    for i in range(b):
+        pt[i, : len(props[i])] = props[i]; gt[i, : len(gts[i])] = gts[i]; gc[i, : len(gts[i])] = gcls[i]
+    pc = torch.tensor([len(p) for p in props], dtype=torch.int32).to(dev)
+    gcount = torch.tensor([len(x) for x in gts], dtype=torch.int32).to(dev)
+    cat, cc = o.append_gt(pt.to(dev), pc, gt.to(dev), gcount)
+    idx, lab, _ = o.iou_match(gt.to(dev), gcount, cat, cc, [0.5], [0, 1], False)
+    cls = o.roi_classes(idx, lab, cc, gc.to(dev), gcount, k)
+    perm = torch.stack(perms).int().to(dev)
+    _, sidx, counts = o.subsample_labels(cls, cc, perm, 128, 0.25, k, want_labels=False)
+    rois, rcls, rgt = o.gather_rois(cat, sidx, cls, idx, gt.to(dev), gcount)
+    for i in range(b):
+        r = ref[i]
+        m = len(r["boxes"])
+        assert int(counts[i].sum()) == m
+        sl = slice(i * 128, i * 128 + m)
+        assert torch.equal(rois[sl, 1:].cpu(), r["boxes"]) and torch.all(rois[sl, 0].cpu() == i)
+        assert torch.equal(rcls[sl].cpu().long(), r["gt_classes"])
+        assert torch.equal(rgt[sl].cpu(), r["gt_boxes"])
+        assert torch.all(rcls[i * 128 + m: (i + 1) * 128].cpu() == -1)
+
+
+# ------------------------------------------------------------------------------------------- losses
+def test_rpn_loss(dev):
+    o = ops()
+    gen = g(13)
+    h, w, a = 12, 17, 15
+    anchors = orc.grid_anchors(h, w)
+    n = anchors.shape[0]
+    gts = [rand_boxes(gen, 4, 272, 192, 16, 100), rand_boxes(gen, 2, 272, 192, 16, 100)]
+    perms = [torch.randperm(n, generator=gen) for _ in range(2)]
+    logits = torch.randn(2, n, generator=gen, requires_grad=True)
+    deltas = (torch.randn(2, n, 4, generator=gen) * 0.3).requires_grad_(True)
+    gl, gb = orc.label_and_sample_anchors(anchors, gts, perms, 64, 0.5)
+    ref = orc.rpn_losses(anchors, logits, gl, deltas, gb, batch_size_per_image=64)
+    (ref["loss_rpn_cls"] + ref["loss_rpn_loc"]).backward()
+    mcap = 6
+    gt = torch.zeros(2, mcap, 4)
+    for i, x in enumerate(gts):
+        gt[i, : len(x)] = x
+    gcount = torch.tensor([4, 2], dtype=torch.int32).to(dev)
+    idx, lab, _ = o.iou_match(gt.to(dev), gcount, anchors.to(dev), None, [0.3, 0.7], [0, -1, 1], True)
+    perm = torch.stack(perms).int().to(dev)
+    out_labels, _, _ = o.subsample_labels(lab, None, perm, 64, 0.5, 0, want_idx=False)
+    assert torch.equal(out_labels.cpu(), torch.stack(gl))
+    head = torch.zeros(2, h * w, 80)
+    head[:, :, :a] = logits.detach().view(2, h * w, a)
+    head[:, :, a:5 * a] = deltas.detach().view(2, h * w, 4 * a)
+    loss2, dhead = o.rpn_loss(head.to(dev), a, a, out_labels, idx, gt.to(dev), anchors.to(dev), 64 * 2, torch.float32)
+    assert torch.allclose(loss2.cpu(), torch.stack([ref["loss_rpn_cls"], ref["loss_rpn_loc"]]).detach(), rtol=1e-5, atol=1e-6)
+    dh = dhead.cpu()
+    assert torch.allclose(dh[:, :, :a].reshape(2, n), logits.grad, rtol=1e-5, atol=1e-7)
+    assert torch.allclose(dh[:, :, a:5 * a].reshape(2, n, 4), deltas.grad, rtol=1e-5, atol=1e-7)
+    assert torch.count_nonzero(dh[:, :, 5 * a:]) == 0
+
+
+def test_box_head_losses(dev):
+    o = ops()
+    gen = g(14)
+    r, k = 300, 20
+    novel = orc.VOC_NOVEL_SPLIT1
+    delta = torch.randn(r, 104, generator=gen)
+    weak = torch.randn(r, 3 * (k + 1), generator=gen)
+    labels = torch.randint(0, k + 1, (r,), generator=gen)
+    labels[labels < k] = torch.tensor(orc.VOC_BASE_SPLIT1)[torch.randint(0, 15, ((labels < k).sum().item(),), generator=gen)]
+    labels_dev = labels.clone().int()
+    labels_dev[-7:] = -1            # empty RoI slots are ignored
+    valid = labels_dev >= 0
+    ds = delta[:, : k + 1].clone().requires_grad_(True)
+    db = delta[:, k + 1: k + 1 + 4 * k].clone().requires_grad_(True)
+    scores = ds + torch.mean(torch.stack([weak[:, i * (k + 1):(i + 1) * (k + 1)] for i in range(3)], 0), 0)
+    scores = scores.index_fill(1, torch.tensor(novel), -float("inf"))
+    props, gtb = rand_boxes(gen, r), rand_boxes(gen, r)
+    ref = orc.fast_rcnn_losses(scores[valid], db[valid], props[valid], gtb[valid], labels[valid])
+    (ref["loss_cls"] + ref["loss_box_reg"]).backward()
+    mask = torch.zeros(k, dtype=torch.uint8)
+    mask[novel] = 1
+    sc = o.sup_scores(delta.to(dev), 0, weak.to(dev), 0, 3, k + 1, mask.to(dev))
+    assert torch.equal(sc.cpu()[valid], scores.detach()[valid])
+    dy = torch.full((r, 104), 7.0).to(dev)
+    l1 = o.softmax_ce(sc, 0, k + 1, labels_dev.to(dev), dy=dy, dcol0=0)
+    rois5 = torch.cat([torch.zeros(r, 1), props], 1)
+    l2 = o.box_reg_loss(delta.to(dev), k + 1, k, labels_dev.to(dev), rois5.to(dev), gtb.to(dev), (10.0, 10.0, 5.0, 5.0), dy=dy, dcol0=k + 1)
+    assert abs(l1.item() - ref["loss_cls"].item()) < 1e-5 and abs(l2.item() - ref["loss_box_reg"].item()) < 1e-5
+    dyc = dy.cpu()
+    assert torch.allclose(dyc[:, : k + 1], ds.grad, rtol=1e-4, atol=1e-7)
+    assert torch.allclose(dyc[:, k + 1: k + 1 + 4 * k], db.grad, rtol=1e-5, atol=1e-8)
+
+
+def test_weak_losses(dev):
+    o = ops()
+    gen = g(15)
+    k, s, b = 20, 64, 2
+    x = torch.randn(b * s, 104, generator=gen)
+    cs = (x[:, :k] / 1.0).clone().requires_grad_(True)
+    ds = (x[:, k:2 * k]).clone().requires_grad_(True)
+    oicr = [x[:, 2 * k + i * (k + 1): 2 * k + (i + 1) * (k + 1)].clone().requires_grad_(True) for i in range(3)]
+    boxes = [rand_boxes(gen, s), rand_boxes(gen, s)]
+    targets = [torch.tensor([3, 7, 7, 12]), torch.tensor([0])]
+    ref = orc.weak_losses(cs, ds / 2.0, oicr, boxes, targets, mil_multiplier=1.0)
+    sum(ref.values()).backward()
+    multihot = torch.zeros(b, k, dtype=torch.uint8)
+    multihot[0, [3, 7, 12]] = 1
+    multihot[1, 0] = 1
+    rois5 = torch.cat([torch.cat([torch.full((s, 1), float(i)), boxes[i]], 1) for i in range(b)]).to(dev)
+    valid = torch.zeros(b * s, dtype=torch.int32).to(dev)
+    xd = x.to(dev)
+    dy = torch.zeros(b * s, 104).to(dev)
+    loss_mil, xr = o.wsddn_mil(xd, 0, k, k, valid, s, b, multihot.to(dev), 1.0, 2.0, 1.0, dy=dy, dyc0=0, dyd0=k)
+    assert abs(loss_mil.item() - ref["loss_im_cls"].item()) < 1e-5
+    assert torch.allclose(dy.cpu()[:, :k], cs.grad, rtol=1e-3, atol=1e-7)
+    assert torch.allclose(dy.cpu()[:, k:2 * k], ds.grad, rtol=1e-3, atol=1e-7)
+    for it in range(3):
+        if it == 0:
+            lab, wts = o.oicr_targets(xr, 0, 0, k, rois5, valid, s, b, multihot.to(dev))
+        else:
+            lab, wts = o.oicr_targets(xd, 2 * k + (it - 1) * (k + 1), 1, k, rois5, valid, s, b, multihot.to(dev))
+        indices = [0, s, 2 * s]
+        probs = xr.cpu() if it == 0 else torch.softmax(oicr[it - 1].detach(), -1)
+        rl, rw = orc.oicr_targets(boxes, probs, [torch.unique(t) for t in targets], indices)
+        assert torch.equal(lab.cpu().long(), rl)
+        assert torch.allclose(wts.cpu(), rw, rtol=1e-5, atol=1e-8)
+        c0 = 2 * k + it * (k + 1)
+        l = o.softmax_ce(xd, c0, k + 1, lab, weights=wts, dy=dy, dcol0=c0)
+        assert abs(l.item() - ref[f"loss_oicr_{it + 1}"].item()) < 1e-5
+        assert torch.allclose(dy.cpu()[:, c0:c0 + k + 1], oicr[it].grad, rtol=1e-4, atol=1e-8)

@@ -1,0 +1,68 @@
+"""ctypes binding of libunit_hip.so. Signatures are parsed from include/unit_hip.h so the Python side can never
+drift from the C ABI. The product path fails loudly if the library is missing: there is no CPU fallback."""
+import ctypes
+import os
+import re
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+HEADER = os.path.join(os.path.dirname(HERE), "include", "unit_hip.h")
+LIB_PATH = os.path.join(HERE, "_build", "libunit_hip.so")
+
+_CT = {
+    "int": ctypes.c_int, "long": ctypes.c_long, "float": ctypes.c_float, "size_t": ctypes.c_size_t,
+}
+
+
+def parse_header(path=HEADER):
+    """-> {name: (restype, [argtypes])} for every prototype in the header."""
+    txt = open(path).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    txt = re.sub(r"#.*", "", txt)
+    protos = {}
+    for m in re.finditer(r"([A-Za-z_][\w\s\*]*?)\b(unit_\w+)\s*\(([^;{}]*)\)\s*;", txt):
+        ret, name, args = m.group(1).strip(), m.group(2), m.group(3).strip()
+        if "*" in ret:
+            restype = ctypes.c_char_p if "char" in ret else ctypes.c_void_p
+        else:
+            restype = _CT[ret.split()[-1]]
+        argtypes = []
+        if args and args != "void":
+            for a in args.split(","):
+                a = a.strip()
+                if "*" in a:
+                    argtypes.append(ctypes.c_void_p)
+                else:
+                    ty = a.split()[-2] if len(a.split()) >= 2 else a
+                    argtypes.append(_CT[ty])
+        protos[name] = (restype, argtypes)
+    return protos
+
+
+class UnitLibError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def lib():
+    """Loads libunit_hip.so (building it is __graft_entry__.build()'s / unit_amd.build's job)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise UnitLibError(
+                f"{LIB_PATH} not found: the HIP extension is required (no CPU fallback). "
+                "Run `python -m unit_amd.build` or `python -c 'import __graft_entry__ as g; g.build()'`.")
+        l = ctypes.CDLL(LIB_PATH)
+        for name, (restype, argtypes) in parse_header().items():
+            fn = getattr(l, name)  # AttributeError if the .so does not export a declared symbol
+            fn.restype = restype
+            fn.argtypes = argtypes
+        _lib = l
+    return _lib
+
+
+def check(status, what=""):
+    if status != 0:
+        msg = lib().unit_last_error()
+        raise UnitLibError(f"{what} failed with status {status}: {msg.decode() if msg else ''}")

@@ -1,0 +1,250 @@
+// conv_wgrad.hip -- weight gradient of the NHWC implicit-GEMM convolution on CDNA4 MFMA (gfx950).
+//
+//   dW[n][k] = sum_m dy[m][n] * im2col(x)[m][k]        n = out channel, k = (r,s,c), m = output pixel
+// Both operands are contraction(m)-major in memory, so the MFMA fragments (8 consecutive m per lane) are produced by
+// the CDNA4 transposing LDS read ds_read_b64_tr_b16 from row-major [m][k] / [m][n] LDS tiles (bf16); the fp32 parity
+// path uses v_mfma_f32_16x16x4_f32 whose one-float-per-lane operands are plain ds_read_b32.
+//   MFMA A (rows) = im2col(x)^T [k][m],  MFMA B (cols) = dy [m][n]  -> lane holds 4 consecutive k of one n: 16-B stores
+// The m-range is split across workgroups (split-M); partial fp32 slabs go to the workspace and unit_wgrad_reduce sums
+// them in a fixed order (bit-reproducible), applies the FrozenBN scale[n] fold and writes / accumulates dW [K][R][S][C].
+#include "common.h"
+
+struct WgradArgs {
+  const void* x; const void* dy; float* partial;
+  int N, H, W, C;
+  int K, R, S, stride, pad;
+  int OH, OW;
+  int ldy;     // dy row stride (elements)
+  int Kgemm, M;
+  int tiles_k, tiles_n, splits, m_per_split;
+  unsigned x_bytes, dy_bytes;
+};
+
+template <typename TI> struct WgCfg;
+template <> struct WgCfg<bf16_t> { static constexpr int ROWB = 288, MS = 64, EPC = 8; };   // 128 elems * 2 B + 32 pad
+template <> struct WgCfg<float>  { static constexpr int ROWB = 576, MS = 32, EPC = 4; };   // 128 elems * 4 B + 64 pad
+
+// fragment fetch: returns the per-lane operand for k-substep `sub` (bf16: 32 m-rows; fp32: 16 m-rows = 4 MFMAs)
+template <typename TI> struct WgFrag;
+template <> struct WgFrag<bf16_t> {
+  typedef bf16x8 frag_t;
+  // lane l: g = l>>4, i = l&15 = 4q+p ; reads rows (32*sub + 16h + 4g + q), cols col0 + 4p..4p+3 ; element j=4h+q' of
+  // lane i <-> m-row 32*sub + 16h + 4g + q', column col0 + i.  (same m permutation for both operands)
+  static __device__ __forceinline__ frag_t load(const char* tile, int sub, int col0, int lane) {
+    int g = lane >> 4, i = lane & 15, q = i >> 2, pq = i & 3;
+    const char* a0 = tile + (32 * sub + 4 * g + q) * 288 + (col0 + 4 * pq) * 2;
+    s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a0));
+    s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a0 + 16 * 288));
+    typedef __attribute__((ext_vector_type(8))) short s16x8;
+    s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8, v);
+  }
+  static __device__ __forceinline__ void mma(const frag_t& a, const frag_t& b, f32x4& acc) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc, 0, 0, 0);
+  }
+};
+template <> struct WgFrag<float> {
+  typedef f32x4 frag_t;   // 4 consecutive MFMA k-steps: element e <-> m-row 16*sub + 4e + (l>>4)
+  static __device__ __forceinline__ frag_t load(const char* tile, int sub, int col0, int lane) {
+    int g = lane >> 4, i = lane & 15;
+    f32x4 v;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = *reinterpret_cast<const float*>(tile + (16 * sub + 4 * e + g) * 576 + (col0 + i) * 4);
+    return v;
+  }
+  static __device__ __forceinline__ void mma(const frag_t& a, const frag_t& b, f32x4& acc) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[e], b[e], acc, 0, 0, 0);
+  }
+};
+
+template <typename TI>
+__global__ void __launch_bounds__(256, 2) conv_wgrad_kernel(WgradArgs p) {
+  typedef WgCfg<TI> Cfg;
+  constexpr int ROWB = Cfg::ROWB, MS = Cfg::MS, EPC = Cfg::EPC;
+  constexpr int BK = 128, BN = 128;
+  constexpr int CPR = 128 / EPC;                // 16-B chunks per tile row (16 bf16 / 32 fp32)
+  constexpr int NL = MS * CPR / 256;            // chunks per thread per operand per step (4)
+  constexpr int TILE_BYTES = MS * ROWB;
+  constexpr int SUBS = 2;                       // MFMA sub-steps per staged tile (bf16: 2x32 rows, fp32: 2x16 rows)
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  int bid = blockIdx.x;
+  int tile_k = bid % p.tiles_k; int t = bid / p.tiles_k;
+  int tile_n = t % p.tiles_n; int split = t / p.tiles_n;
+  int k0 = tile_k * BK, n0 = tile_n * BN;
+  int m_begin = split * p.m_per_split, m_end = min(p.M, m_begin + p.m_per_split);
+
+  const TI* __restrict__ X = (const TI*)p.x;
+  const TI* __restrict__ DY = (const TI*)p.dy;
+  __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc(const_cast<TI*>(X), 0, (int)p.x_bytes, 0x00020000);
+  __amdgpu_buffer_rsrc_t rsD = __builtin_amdgcn_make_buffer_rsrc(const_cast<TI*>(DY), 0, (int)p.dy_bytes, 0x00020000);
+  constexpr unsigned OOB = 0xFFFFFFF0u;
+
+  int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  int wk = wid >> 1, wn = wid & 1;
+  int lc = tid % CPR, lr = tid / CPR;           // chunk column and first row of this thread
+  constexpr int RSTEP = 256 / CPR;              // row step between this thread's chunks (16 bf16 / 8 fp32)
+  // this thread's k-chunk is fixed for the whole kernel: decompose once
+  int kk = k0 + lc * EPC;
+  bool k_ok = kk < p.Kgemm;
+  int rs = kk / p.C, ch = kk - rs * p.C, kr = rs / p.S, ksx = rs - kr * p.S;
+  int nn = n0 + lc * EPC;
+  bool n_ok = nn < p.K;   // K multiple of EPC assumed for full chunks; partial chunk columns are masked in the epilogue
+  bool pointwise = (p.R == 1 && p.S == 1 && p.stride == 1 && p.pad == 0);
+
+  i32x4 rx[NL], rd[NL];
+  auto gload = [&](int mstep) {
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+      int m = mstep + lr + RSTEP * i;
+      bool mok = m < m_end;
+      unsigned xoff;
+      bool ok = mok && k_ok;
+      if (pointwise) xoff = ((unsigned)m * (unsigned)p.C + (unsigned)ch) * (unsigned)sizeof(TI);
+      else {
+        int ow = m % p.OW; int tt = m / p.OW; int oh = tt % p.OH; int n = tt / p.OH;
+        int ih = oh * p.stride - p.pad + kr, iw = ow * p.stride - p.pad + ksx;
+        ok = ok && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
+        xoff = ((unsigned)n * (unsigned)(p.H * p.W * p.C) + (unsigned)((ih * p.W + iw) * p.C + ch)) * (unsigned)sizeof(TI);
+      }
+      rx[i] = __builtin_amdgcn_raw_buffer_load_b128(rsX, ok ? xoff : OOB, 0, 0);
+      unsigned doff = ((unsigned)m * (unsigned)p.ldy + (unsigned)nn) * (unsigned)sizeof(TI);
+      rd[i] = __builtin_amdgcn_raw_buffer_load_b128(rsD, (mok && n_ok) ? doff : OOB, 0, 0);
+    }
+  };
+  auto lstore = [&](int buf) {
+    char* bx = smem + buf * 2 * TILE_BYTES;
+    char* bd = bx + TILE_BYTES;
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+      int row = lr + RSTEP * i;
+      *reinterpret_cast<i32x4*>(bx + row * ROWB + lc * 16) = rx[i];
+      *reinterpret_cast<i32x4*>(bd + row * ROWB + lc * 16) = rd[i];
+    }
+  };
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  int nsteps = (m_end - m_begin + MS - 1) / MS;
+  if (nsteps > 0) {
+    gload(m_begin);
+    lstore(0);
+  }
+  __syncthreads();
+  for (int st = 0; st < nsteps; ++st) {
+    int buf = st & 1;
+    if (st + 1 < nsteps) gload(m_begin + (st + 1) * MS);
+    const char* bx = smem + buf * 2 * TILE_BYTES;
+    const char* bd = bx + TILE_BYTES;
+#pragma unroll
+    for (int sub = 0; sub < SUBS; ++sub) {
+      typename WgFrag<TI>::frag_t fa[4], fb[4];
+#pragma unroll
+      for (int a = 0; a < 4; ++a) fa[a] = WgFrag<TI>::load(bx, sub, wk * 64 + a * 16, lane);
+#pragma unroll
+      for (int b = 0; b < 4; ++b) fb[b] = WgFrag<TI>::load(bd, sub, wn * 64 + b * 16, lane);
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) WgFrag<TI>::mma(fa[a], fb[b], acc[a][b]);
+    }
+    if (st + 1 < nsteps) lstore(buf ^ 1);
+    __syncthreads();
+  }
+
+  // epilogue: D[row = k][col = n] -> partial[split][n][k..k+3]
+  float* out = p.partial + (size_t)split * p.K * p.Kgemm;
+  int fq = lane >> 4, fr = lane & 15;
+#pragma unroll
+  for (int b = 0; b < 4; ++b) {
+    int n = n0 + wn * 64 + b * 16 + fr;
+    if (n >= p.K) continue;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      int k = k0 + wk * 64 + a * 16 + fq * 4;
+      if (k >= p.Kgemm) continue;
+      *reinterpret_cast<f32x4*>(out + (size_t)n * p.Kgemm + k) = acc[a][b];
+    }
+  }
+}
+
+// dW[n][k] = (accumulate ? dW : 0) + scale[n] * sum_s partial[s][n][k]     (fixed summation order)
+__global__ void wgrad_reduce_kernel(const float* __restrict__ partial, int splits, long KK, int Kgemm, const float* __restrict__ scale,
+                                    float* __restrict__ dw, int accumulate) {
+  long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  if (i >= KK) return;
+  f32x4 s = *reinterpret_cast<const f32x4*>(partial + i);
+  for (int sp = 1; sp < splits; ++sp) {
+    f32x4 v = *reinterpret_cast<const f32x4*>(partial + (size_t)sp * KK + i);
+    s += v;
+  }
+  if (scale) { float sc = scale[i / Kgemm]; s *= sc; }
+  if (accumulate) s += *reinterpret_cast<const f32x4*>(dw + i);
+  *reinterpret_cast<f32x4*>(dw + i) = s;
+}
+
+static int choose_splits(int M, int tiles, int ms) {
+  int want = (512 + tiles - 1) / tiles;
+  int maxs = (M + 4 * ms - 1) / (4 * ms);   // at least 4 staged steps per split
+  if (maxs < 1) maxs = 1;
+  int s = want < maxs ? want : maxs;
+  if (s < 1) s = 1;
+  if (s > 64) s = 64;
+  return s;
+}
+
+extern "C" size_t unit_conv2d_wgrad_workspace_bytes(int in_dtype, int N, int OH, int OW, int K, int R, int S, int C) {
+  long M = (long)N * OH * OW;
+  int Kgemm = R * S * C;
+  int tiles = cdiv(Kgemm, 128) * cdiv(K, 128);
+  int splits = choose_splits((int)M, tiles, in_dtype == UNIT_BF16 ? 64 : 32);
+  return (size_t)splits * K * Kgemm * sizeof(float);
+}
+
+// x [N,H,W,C], dy [M][ldy] (pixels of the conv's OUTPUT grid, row-major), dw fp32 [K][R][S][C].
+extern "C" int unit_conv2d_wgrad(const void* x, const void* dy, float* dw, const float* scale_k, int in_dtype, int N,
+                                 int H, int W, int C, int K, int R, int S, int stride, int pad, int OH, int OW, int ldy,
+                                 int accumulate, void* workspace, size_t workspace_bytes, void* stream) {
+  int epc = in_dtype == UNIT_BF16 ? 8 : 4;
+  UNIT_CHECK_ARG(C % epc == 0 && K % epc == 0 && ldy % epc == 0, "wgrad: C, K, ldy must be multiples of 8 (bf16) / 4 (fp32)");
+  UNIT_CHECK_ARG(((uintptr_t)x % 16 == 0) && ((uintptr_t)dy % 16 == 0) && ((uintptr_t)dw % 16 == 0), "wgrad: 16B alignment");
+  WgradArgs a;
+  a.x = x; a.dy = dy; a.partial = (float*)workspace;
+  a.N = N; a.H = H; a.W = W; a.C = C; a.K = K; a.R = R; a.S = S; a.stride = stride; a.pad = pad; a.OH = OH; a.OW = OW;
+  a.ldy = ldy; a.Kgemm = R * S * C; a.M = N * OH * OW;
+  UNIT_CHECK_ARG(a.Kgemm % 4 == 0, "wgrad: R*S*C % 4 != 0");
+  size_t esz = in_dtype == UNIT_BF16 ? 2 : 4;
+  size_t xb = (size_t)N * H * W * C * esz, db = (size_t)a.M * ldy * esz;
+  UNIT_CHECK_ARG(xb < 0xFFFFFFF0ull && db < 0xFFFFFFF0ull, "wgrad: operand larger than 4 GiB");
+  a.x_bytes = (unsigned)xb; a.dy_bytes = (unsigned)db;
+  a.tiles_k = cdiv(a.Kgemm, 128); a.tiles_n = cdiv(K, 128);
+  int ms = in_dtype == UNIT_BF16 ? 64 : 32;
+  a.splits = choose_splits(a.M, a.tiles_k * a.tiles_n, ms);
+  int mps = cdiv(a.M > 0 ? a.M : 1, a.splits);
+  a.m_per_split = cdiv(mps, ms) * ms;
+  size_t need = (size_t)a.splits * K * a.Kgemm * sizeof(float);
+  if (workspace_bytes < need) { unit_set_error("wgrad: workspace too small"); return UNIT_ERR_WORKSPACE; }
+  hipStream_t st = (hipStream_t)stream;
+  int grid = a.tiles_k * a.tiles_n * a.splits;
+  if (in_dtype == UNIT_BF16) {
+    size_t lds = (size_t)2 * 2 * WgCfg<bf16_t>::MS * WgCfg<bf16_t>::ROWB;
+    static bool set1 = false;
+    if (!set1) { (void)hipFuncSetAttribute((const void*)conv_wgrad_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); set1 = true; }
+    conv_wgrad_kernel<bf16_t><<<grid, 256, lds, st>>>(a);
+  } else {
+    size_t lds = (size_t)2 * 2 * WgCfg<float>::MS * WgCfg<float>::ROWB;
+    static bool set2 = false;
+    if (!set2) { (void)hipFuncSetAttribute((const void*)conv_wgrad_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); set2 = true; }
+    conv_wgrad_kernel<float><<<grid, 256, lds, st>>>(a);
+  }
+  UNIT_LAUNCH_CHECK();
+  long KK = (long)K * a.Kgemm;
+  wgrad_reduce_kernel<<<cdiv(KK / 4, 256), 256, 0, st>>>(a.partial, a.splits, KK, a.Kgemm, scale_k, dw, accumulate);
+  UNIT_LAUNCH_CHECK();
+  return UNIT_OK;
+}

@@ -1,0 +1,349 @@
+// elementwise.hip -- HBM-bound helper kernels of the Faster-R-CNN-C4 hot path (NHWC, 16 B / lane).
+//   preprocess (a1), maxpool 3x3 s2 (a2 stem), global avg-pool fwd/bwd (a9), weight prep (FrozenBN fold +
+//   bf16 cast + dgrad re-layout), bias grad, SGD momentum (K18), small fills/casts.
+#include "common.h"
+
+static thread_local char g_err[512] = "";
+extern "C" void unit_set_error(const char* msg) { strncpy(g_err, msg ? msg : "", sizeof(g_err) - 1); }
+extern "C" const char* unit_last_error(void) { return g_err; }
+extern "C" int unit_version(void) { return 100; }
+
+// ---------------------------------------------------------------------------------------------------
+// a1  preprocess_image: modeling/meta_arch/rcnn.py:257-266 -- (x[*prescale] - mean) / std, zero pad to
+// (Hmax,Wmax), CHW fp32 -> one image slot of an NHWC batch with channels padded to Cpad (pad channels = 0).
+// ---------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void preprocess_kernel(const float* __restrict__ img, int C, int H, int W, f32x4 mean, f32x4 stdv,
+                                  float prescale, T* __restrict__ out, int Hmax, int Wmax, int Cpad) {
+  int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= Hmax * Wmax) return;
+  int y = idx / Wmax, x = idx - y * Wmax;
+  T* o = out + (size_t)idx * Cpad;
+  bool in = (y < H) && (x < W);
+  for (int c = 0; c < Cpad; ++c) {
+    float v = 0.f;
+    if (in && c < C) {
+      float p = img[((size_t)c * H + y) * W + x];
+      if (prescale != 1.0f) p = p / prescale;  // normalize_images: x/255.0 (rcnn.py:262-263); prescale = divisor
+      v = (p - mean[c]) / stdv[c];
+    }
+    o[c] = (T)v;
+  }
+}
+
+extern "C" int unit_preprocess_image(const float* img_chw, int C, int H, int W, const float* mean3,
+                                     const float* std3, float prescale, void* out_nhwc, int out_dtype,
+                                     int Hmax, int Wmax, int Cpad, void* stream) {
+  UNIT_CHECK_ARG(C <= 4 && Cpad >= C && H <= Hmax && W <= Wmax, "preprocess: bad shape");
+  f32x4 m = {0, 0, 0, 0}, s = {1, 1, 1, 1};
+  for (int c = 0; c < C; ++c) { m[c] = mean3[c]; s[c] = std3[c]; }
+  int n = Hmax * Wmax;
+  hipStream_t st = (hipStream_t)stream;
+  if (out_dtype == UNIT_BF16)
+    preprocess_kernel<bf16_t><<<cdiv(n, 256), 256, 0, st>>>(img_chw, C, H, W, m, s, prescale, (bf16_t*)out_nhwc, Hmax, Wmax, Cpad);
+  else
+    preprocess_kernel<float><<<cdiv(n, 256), 256, 0, st>>>(img_chw, C, H, W, m, s, prescale, (float*)out_nhwc, Hmax, Wmax, Cpad);
+  UNIT_LAUNCH_CHECK();
+  return UNIT_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// a2  stem max_pool2d(k3,s2,p1) NHWC, 8 channels per lane (no backward: FREEZE_AT=2 freezes stem+res2)
+// ---------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void maxpool3x3s2_kernel(const T* __restrict__ x, T* __restrict__ y, int N, int H, int W, int C,
+                                    int OH, int OW) {
+  int c8n = C / 8;
+  long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  long total = (long)N * OH * OW * c8n;
+  if (idx >= total) return;
+  int c8 = idx % c8n; long p = idx / c8n;
+  int ow = p % OW; p /= OW;
+  int oh = p % OH; int n = p / OH;
+  float m[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) m[i] = -INFINITY;
+  for (int dy = 0; dy < 3; ++dy) {
+    int iy = oh * 2 - 1 + dy;
+    if (iy < 0 || iy >= H) continue;
+    for (int dx = 0; dx < 3; ++dx) {
+      int ix = ow * 2 - 1 + dx;
+      if (ix < 0 || ix >= W) continue;
+      float v[8];
+      Vec8<T>::load(x + (((size_t)n * H + iy) * W + ix) * C + c8 * 8, v);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) m[i] = fmaxf(m[i], v[i]);
+    }
+  }
+  Vec8<T>::store(y + (((size_t)n * OH + oh) * OW + ow) * C + c8 * 8, m);
+}
+
+extern "C" int unit_maxpool3x3s2_fwd(const void* x, void* y, int dtype, int N, int H, int W, int C, void* stream) {
+  UNIT_CHECK_ARG(C % 8 == 0, "maxpool: C % 8 != 0");
+  int OH = (H + 2 - 3) / 2 + 1, OW = (W + 2 - 3) / 2 + 1;
+  long total = (long)N * OH * OW * (C / 8);
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == UNIT_BF16)
+    maxpool3x3s2_kernel<bf16_t><<<cdiv(total, 256), 256, 0, st>>>((const bf16_t*)x, (bf16_t*)y, N, H, W, C, OH, OW);
+  else
+    maxpool3x3s2_kernel<float><<<cdiv(total, 256), 256, 0, st>>>((const float*)x, (float*)y, N, H, W, C, OH, OW);
+  UNIT_LAUNCH_CHECK();
+  return UNIT_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// a9  Res5BoxHead x.mean(dim=[2,3]) : modeling/roi_heads/box_head.py:80.  [R][P][C] -> [R][C] (fp32 accumulate)
+// backward fused with the ReLU mask of the last res5 block: g[r,p,c] = (out[r,p,c] > 0) ? dfeat[r,c]/P : 0
+// ---------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void avgpool_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, int R, int P, int C) {
+  int c8n = C / 8;
+  long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long)R * c8n) return;
+  int c8 = idx % c8n; int r = idx / c8n;
+  float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  for (int p = 0; p < P; ++p) {
+    float v[8];
+    Vec8<T>::load(x + ((size_t)r * P + p) * C + c8 * 8, v);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[i] += v[i];
+  }
+  float inv = (float)P;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) acc[i] = acc[i] / inv;
+  Vec8<T>::store(y + (size_t)r * C + c8 * 8, acc);
+}
+
+template <typename T>
+__global__ void avgpool_bwd_mask_kernel(const T* __restrict__ dfeat, const T* __restrict__ out, T* __restrict__ g,
+                                        int R, int P, int C) {
+  int c8n = C / 8;
+  long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long)R * P * c8n) return;
+  int c8 = idx % c8n; long rp = idx / c8n; int r = rp / P;
+  float d[8], o[8];
+  Vec8<T>::load(dfeat + (size_t)r * C + c8 * 8, d);
+  Vec8<T>::load(out + (size_t)rp * C + c8 * 8, o);
+  float inv = (float)P;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) d[i] = o[i] > 0.f ? d[i] / inv : 0.f;
+  Vec8<T>::store(g + (size_t)rp * C + c8 * 8, d);
+}
+
+extern "C" int unit_global_avgpool_fwd(const void* x, void* y, int dtype, int R, int P, int C, void* stream) {
+  UNIT_CHECK_ARG(C % 8 == 0, "avgpool: C % 8 != 0");
+  long total = (long)R * (C / 8);
+  hipStream_t st = (hipStream_t)stream;
+  if (total == 0) return UNIT_OK;
+  if (dtype == UNIT_BF16) avgpool_fwd_kernel<bf16_t><<<cdiv(total, 256), 256, 0, st>>>((const bf16_t*)x, (bf16_t*)y, R, P, C);
+  else avgpool_fwd_kernel<float><<<cdiv(total, 256), 256, 0, st>>>((const float*)x, (float*)y, R, P, C);
+  UNIT_LAUNCH_CHECK();
+  return UNIT_OK;
+}
+
+extern "C" int unit_global_avgpool_bwd_relu(const void* dfeat, const void* out, void* g, int dtype, int R, int P,
+                                            int C, void* stream) {
+  UNIT_CHECK_ARG(C % 8 == 0, "avgpool: C % 8 != 0");
+  long total = (long)R * P * (C / 8);
+  hipStream_t st = (hipStream_t)stream;
+  if (total == 0) return UNIT_OK;
+  if (dtype == UNIT_BF16) avgpool_bwd_mask_kernel<bf16_t><<<cdiv(total, 256), 256, 0, st>>>((const bf16_t*)dfeat, (const bf16_t*)out, (bf16_t*)g, R, P, C);
+  else avgpool_bwd_mask_kernel<float><<<cdiv(total, 256), 256, 0, st>>>((const float*)dfeat, (const float*)out, (float*)g, R, P, C);
+  UNIT_LAUNCH_CHECK();
+  return UNIT_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Weight prep: master weights fp32 [K][R][S][C] (= channels_last view of the reference's [K,C,R,S] tensor),
+// FrozenBN scale folded (scale[k] = bn.weight * rsqrt(var+eps)) ->
+//   w_fwd  [K][R][S][Cp]            (Cp >= C, zero padded)  -- forward implicit-GEMM B operand
+//   w_dgrad[C][R][S][K]  with (r,s) flipped                -- dgrad = forward conv of dy with this tensor
+// ---------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void weight_prep_kernel(const float* __restrict__ w, const float* __restrict__ scale, int K, int R, int S,
+                                   int C, int Cp, T* __restrict__ wf, T* __restrict__ wd) {
+  long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  long total = (long)K * R * S * Cp;
+  if (idx >= total) return;
+  int c = idx % Cp; long t = idx / Cp;
+  int s = t % S; t /= S;
+  int r = t % R; int k = t / R;
+  float v = 0.f;
+  if (c < C) {
+    v = w[(((size_t)k * R + r) * S + s) * C + c];
+    if (scale) v = v * scale[k];
+  }
+  if (wf) wf[idx] = (T)v;
+  if (wd && c < C) wd[(((size_t)c * R + (R - 1 - r)) * S + (S - 1 - s)) * K + k] = (T)v;
+}
+
+extern "C" int unit_weight_prep(const float* w_krsc, const float* scale_k, int K, int R, int S, int C, int Cp,
+                                void* w_fwd, void* w_dgrad, int dtype, void* stream) {
+  UNIT_CHECK_ARG(Cp >= C, "weight_prep: Cp < C");
+  long total = (long)K * R * S * Cp;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == UNIT_BF16)
+    weight_prep_kernel<bf16_t><<<cdiv(total, 256), 256, 0, st>>>(w_krsc, scale_k, K, R, S, C, Cp, (bf16_t*)w_fwd, (bf16_t*)w_dgrad);
+  else
+    weight_prep_kernel<float><<<cdiv(total, 256), 256, 0, st>>>(w_krsc, scale_k, K, R, S, C, Cp, (float*)w_fwd, (float*)w_dgrad);
+  UNIT_LAUNCH_CHECK();
+  return UNIT_OK;
+}
+
+// FrozenBN -> (scale, shift):  detectron2 FrozenBatchNorm2d eps=1e-5
+__global__ void frozen_bn_fold_kernel(const float* w, const float* b, const float* rm, const float* rv, float eps,
+                                      float* scale, float* shift, int C) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= C) return;
+  float s = w[i] * (1.0f / sqrtf(rv[i] + eps));
+  scale[i] = s;
+  shift[i] = b[i] - rm[i] * s;
+}
+extern "C" int unit_frozen_bn_fold(const float* w, const float* b, const float* rm, const float* rv, float eps,
+                                   float* scale, float* shift, int C, void* stream) {
+  frozen_bn_fold_kernel<<<cdiv(C, 256), 256, 0, (hipStream_t)stream>>>(w, b, rm, rv, eps, scale, shift, C);
+  UNIT_LAUNCH_CHECK();
+  return UNIT_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// bias grad: db[k] (+)= sum_m dy[m][k]   (dy [M][ld], columns [0,K))
+// ---------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void bias_grad_kernel(const T* __restrict__ dy, int M, int K, int ld, float* __restrict__ db, int rows_per_block) {
+  int k = blockIdx.x * blockDim.x + threadIdx.x;
+  int m0 = blockIdx.y * rows_per_block;
+  if (k >= K) return;
+  int m1 = min(M, m0 + rows_per_block);
+  float acc = 0.f;
+  for (int m = m0; m < m1; ++m) acc += (float)dy[(size_t)m * ld + k];
+  atomicAdd(db + k, acc);
+}
+extern "C" int unit_bias_grad(const void* dy, int dtype, int M, int K, int ld, float* db, int accumulate, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  if (!accumulate) hipMemsetAsync(db, 0, sizeof(float) * K, st);
+  if (M == 0) return UNIT_OK;
+  int rpb = 256;
+  dim3 grid(cdiv(K, 64), cdiv(M, rpb));
+  if (dtype == UNIT_BF16) bias_grad_kernel<bf16_t><<<grid, 64, 0, st>>>((const bf16_t*)dy, M, K, ld, db, rpb);
+  else bias_grad_kernel<float><<<grid, 64, 0, st>>>((const float*)dy, M, K, ld, db, rpb);
+  UNIT_LAUNCH_CHECK();
+  return UNIT_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// K18  SGD momentum on flat fp32 buffers (torch.optim.SGD semantics: solver/build.py:110-112):
+//   g = grad + wd*p ; buf = momentum*buf + g ; p -= lr*buf        (first step: buf = g, via buf init 0 + momentum*0)
+// ---------------------------------------------------------------------------------------------------
+__global__ void sgd_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ buf, long n,
+                           float lr, float momentum, float wd, float grad_scale, int first) {
+  long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  if (i >= n) return;
+  if (i + 4 <= n) {
+    f32x4 pv = *reinterpret_cast<f32x4*>(p + i), gv = *reinterpret_cast<const f32x4*>(g + i);
+    f32x4 bv = *reinterpret_cast<f32x4*>(buf + i);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float d = gv[j] * grad_scale + wd * pv[j];
+      float b = first ? d : momentum * bv[j] + d;
+      bv[j] = b; pv[j] = pv[j] - lr * b;
+    }
+    *reinterpret_cast<f32x4*>(p + i) = pv; *reinterpret_cast<f32x4*>(buf + i) = bv;
+  } else {
+    for (long j = i; j < n; ++j) {
+      float d = g[j] * grad_scale + wd * p[j];
+      float b = first ? d : momentum * buf[j] + d;
+      buf[j] = b; p[j] = p[j] - lr * b;
+    }
+  }
+}
+extern "C" int unit_sgd_momentum(float* p, const float* g, float* buf, long n, float lr, float momentum, float wd,
+                                 float grad_scale, int first_step, void* stream) {
+  if (n == 0) return UNIT_OK;
+  UNIT_CHECK_ARG(((uintptr_t)p % 16 == 0) && ((uintptr_t)g % 16 == 0) && ((uintptr_t)buf % 16 == 0), "sgd: 16B alignment");
+  sgd_kernel<<<cdiv(cdiv(n, 4), 256), 256, 0, (hipStream_t)stream>>>(p, g, buf, n, lr, momentum, wd, grad_scale, first_step);
+  UNIT_LAUNCH_CHECK();
+  return UNIT_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// small helpers: y = cast(a32 [+ b]) ; used to merge the fp32 RoIAlign-backward accumulator with the RPN dgrad
+// ---------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void add_cast_kernel(const float* __restrict__ a32, const T* __restrict__ b, T* __restrict__ y, long n8) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n8) return;
+  float a[8], bb[8];
+  Vec8<float>::load(a32 + i * 8, a);
+  if (b) {
+    Vec8<T>::load(b + i * 8, bb);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) a[j] += bb[j];
+  }
+  Vec8<T>::store(y + i * 8, a);
+}
+extern "C" int unit_add_cast(const float* a32, const void* b, void* y, int dtype, long n, void* stream) {
+  UNIT_CHECK_ARG(n % 8 == 0, "add_cast: n % 8 != 0");
+  if (n == 0) return UNIT_OK;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == UNIT_BF16) add_cast_kernel<bf16_t><<<cdiv(n / 8, 256), 256, 0, st>>>(a32, (const bf16_t*)b, (bf16_t*)y, n / 8);
+  else add_cast_kernel<float><<<cdiv(n / 8, 256), 256, 0, st>>>(a32, (const float*)b, (float*)y, n / 8);
+  UNIT_LAUNCH_CHECK();
+  return UNIT_OK;
+}
+
+// y[i] = cast(x[i])  between fp32 and bf16 (either direction)
+template <typename TI, typename TO>
+__global__ void cast_kernel(const TI* __restrict__ x, TO* __restrict__ y, long n) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) y[i] = (TO)(float)x[i];
+}
+extern "C" int unit_cast(const void* x, int in_dtype, void* y, int out_dtype, long n, void* stream) {
+  if (n == 0) return UNIT_OK;
+  hipStream_t st = (hipStream_t)stream;
+  int g = cdiv(n, 256);
+  if (in_dtype == UNIT_F32 && out_dtype == UNIT_BF16) cast_kernel<float, bf16_t><<<g, 256, 0, st>>>((const float*)x, (bf16_t*)y, n);
+  else if (in_dtype == UNIT_BF16 && out_dtype == UNIT_F32) cast_kernel<bf16_t, float><<<g, 256, 0, st>>>((const bf16_t*)x, (float*)y, n);
+  else if (in_dtype == UNIT_F32 && out_dtype == UNIT_F32) cast_kernel<float, float><<<g, 256, 0, st>>>((const float*)x, (float*)y, n);
+  else cast_kernel<bf16_t, bf16_t><<<g, 256, 0, st>>>((const bf16_t*)x, (bf16_t*)y, n);
+  UNIT_LAUNCH_CHECK();
+  return UNIT_OK;
+}
+
+// NCHW fp32 <-> NHWC (T) layout conversion for the plugin boundary (reference tensors are NCHW fp32).
+template <typename T>
+__global__ void nchw_to_nhwc_kernel(const float* __restrict__ x, T* __restrict__ y, int N, int C, int H, int W, int Cp) {
+  long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  long total = (long)N * H * W * Cp;
+  if (idx >= total) return;
+  int c = idx % Cp; long p = idx / Cp;
+  int w = p % W; p /= W; int h = p % H; int n = p / H;
+  y[idx] = (T)(c < C ? x[(((size_t)n * C + c) * H + h) * W + w] : 0.f);
+}
+template <typename T>
+__global__ void nhwc_to_nchw_kernel(const T* __restrict__ x, float* __restrict__ y, int N, int C, int H, int W, int Cp) {
+  long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  long total = (long)N * C * H * W;
+  if (idx >= total) return;
+  int w = idx % W; long p = idx / W;
+  int h = p % H; p /= H; int c = p % C; int n = p / C;
+  y[idx] = (float)x[(((size_t)n * H + h) * W + w) * Cp + c];
+}
+extern "C" int unit_nchw_to_nhwc(const float* x, void* y, int dtype, int N, int C, int H, int W, int Cp, void* stream) {
+  long total = (long)N * H * W * Cp;
+  if (total == 0) return UNIT_OK;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == UNIT_BF16) nchw_to_nhwc_kernel<bf16_t><<<cdiv(total, 256), 256, 0, st>>>(x, (bf16_t*)y, N, C, H, W, Cp);
+  else nchw_to_nhwc_kernel<float><<<cdiv(total, 256), 256, 0, st>>>(x, (float*)y, N, C, H, W, Cp);
+  UNIT_LAUNCH_CHECK();
+  return UNIT_OK;
+}
+extern "C" int unit_nhwc_to_nchw(const void* x, int dtype, float* y, int N, int C, int H, int W, int Cp, void* stream) {
+  long total = (long)N * C * H * W;
+  if (total == 0) return UNIT_OK;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == UNIT_BF16) nhwc_to_nchw_kernel<bf16_t><<<cdiv(total, 256), 256, 0, st>>>((const bf16_t*)x, y, N, C, H, W, Cp);
+  else nhwc_to_nchw_kernel<float><<<cdiv(total, 256), 256, 0, st>>>((const float*)x, y, N, C, H, W, Cp);
+  UNIT_LAUNCH_CHECK();
+  return UNIT_OK;
+}

@@ -1,0 +1,228 @@
+// sort_nms.hip -- stable descending sort of RPN objectness (K10) and NMS (K11), latency-bound integer work.
+#include "common.h"
+
+// ---------------------------------------------------------------------------------------------------
+// K10  logits.sort(descending=True) (find_top_rpn_proposals via rpn.py:48).
+// One 1024-thread workgroup per image: LSD radix sort, 4-bit digits, 8 passes, stable (ties keep ascending
+// original index, like torch's stable CPU sort).  keys are read from a strided matrix: key(i) =
+// src[b*bstride + (i / A) * ld + col0 + (i % A)]  (NHWC RPN head output) -- pass A=1, ld=1 for a flat vector.
+// workspace: 2 * B * n * (4+4) bytes (ping-pong keys + idx).
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned desc_key(float f) {
+  unsigned u = __float_as_uint(f);
+  unsigned asc = (u & 0x80000000u) ? ~u : (u | 0x80000000u);  // ascending-order key
+  return ~asc;                                                 // descending
+}
+__device__ __forceinline__ float key_to_float(unsigned k) {
+  unsigned asc = ~k;
+  unsigned u = (asc & 0x80000000u) ? (asc & 0x7fffffffu) : ~asc;
+  return __uint_as_float(u);
+}
+
+#define SORT_THREADS 1024
+__global__ void __launch_bounds__(SORT_THREADS) radix_sort_kernel(const float* __restrict__ src, long bstride, int ld, int A, int col0,
+                                                          int n, unsigned* __restrict__ kbuf, int* __restrict__ ibuf,
+                                                          float* __restrict__ out_keys, int* __restrict__ out_idx) {
+  __shared__ unsigned short hist[16 * SORT_THREADS];  // [digit][thread]
+  __shared__ int wsum[17];
+  int b = blockIdx.x;
+  unsigned* k0 = kbuf + (size_t)b * 2 * n; unsigned* k1 = k0 + n;
+  int* i0 = ibuf + (size_t)b * 2 * n; int* i1 = i0 + n;
+  int tid = threadIdx.x;
+  int chunk = (n + SORT_THREADS - 1) / SORT_THREADS;
+  int s = tid * chunk, e = min(n, s + chunk);
+  for (int i = tid; i < n; i += SORT_THREADS) {
+    int pix = i / A, a = i - pix * A;
+    k0[i] = desc_key(src[(size_t)b * bstride + (size_t)pix * ld + col0 + a]);
+    i0[i] = i;
+  }
+  __syncthreads();
+  for (int pass = 0; pass < 8; ++pass) {
+    int shift = pass * 4;
+    unsigned short cnt[16];
+#pragma unroll
+    for (int d = 0; d < 16; ++d) cnt[d] = 0;
+    for (int i = s; i < e; ++i) {
+      unsigned d = (k0[i] >> shift) & 15u;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) cnt[q] += (d == (unsigned)q) ? 1 : 0;
+    }
+#pragma unroll
+    for (int d = 0; d < 16; ++d) hist[d * SORT_THREADS + tid] = cnt[d];
+    __syncthreads();
+    // exclusive scan over the 16*1024 counters in (digit, thread) order; thread t owns entries [16t, 16t+16)
+    int loc[16]; int sum = 0;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) { loc[j] = sum; sum += hist[tid * 16 + j]; }
+    int lane = tid & 63, wid = tid >> 6;
+    int inc = sum;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { int t = __shfl_up(inc, o, 64); if (lane >= o) inc += t; }
+    if (lane == 63) wsum[wid] = inc;
+    __syncthreads();
+    if (tid == 0) { int run = 0; for (int w = 0; w < SORT_THREADS / 64; ++w) { int t = wsum[w]; wsum[w] = run; run += t; } }
+    __syncthreads();
+    int base = wsum[wid] + inc - sum;
+    // overwrite hist with exclusive prefixes (as int would overflow u16: keep in registers, re-layout through LDS ints)
+    __syncthreads();
+    int* pref = reinterpret_cast<int*>(hist);  // 16*1024 u16 = 32 KB = 8192 ints: not enough for 16384 ints -> two halves
+    // scatter positions for this thread's digits are needed by thread tid for digit d: entry index d*1024+tid, owned by
+    // thread (d*1024+tid)/16. Exchange through LDS in two halves of 8 digits.
+    int mypos[16];
+    for (int half = 0; half < 2; ++half) {
+      // owner thread t holds entries [16t,16t+16) i.e. digits d = (16t)/1024 .. ; entries of digits [8*half, 8*half+8) are
+      // owned by threads [512*half, 512*half+512).
+      if ((tid >> 9) == half) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) pref[(tid & 511) * 16 + j] = base + loc[j];
+      }
+      __syncthreads();
+#pragma unroll
+      for (int dd = 0; dd < 8; ++dd) mypos[half * 8 + dd] = pref[dd * SORT_THREADS + tid];
+      __syncthreads();
+    }
+    for (int i = s; i < e; ++i) {
+      unsigned k = k0[i]; unsigned d = (k >> shift) & 15u;
+      int p = 0;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) if (d == (unsigned)q) { p = mypos[q]; mypos[q] = p + 1; }
+      k1[p] = k; i1[p] = i0[i];
+    }
+    __syncthreads();
+    unsigned* tk = k0; k0 = k1; k1 = tk;
+    int* ti = i0; i0 = i1; i1 = ti;
+  }
+  for (int i = tid; i < n; i += SORT_THREADS) {
+    out_keys[(size_t)b * n + i] = key_to_float(k0[i]);
+    out_idx[(size_t)b * n + i] = i0[i];
+  }
+}
+
+extern "C" size_t unit_sort_workspace_bytes(int B, int n) { return (size_t)B * 2 * n * 8; }
+
+extern "C" int unit_sort_desc_stable(const float* src, long batch_stride, int ld, int A, int col0, int B, int n,
+                                     float* out_keys, int* out_idx, void* workspace, size_t workspace_bytes, void* stream) {
+  UNIT_CHECK_ARG(n <= 64 * SORT_THREADS, "sort: n too large for the single-workgroup sorter (<= 65536)");
+  if (workspace_bytes < unit_sort_workspace_bytes(B, n)) { unit_set_error("sort: workspace too small"); return UNIT_ERR_WORKSPACE; }
+  if (B == 0 || n == 0) return UNIT_OK;
+  unsigned* kbuf = (unsigned*)workspace;
+  int* ibuf = (int*)((char*)workspace + (size_t)B * 2 * n * 4);
+  radix_sort_kernel<<<B, SORT_THREADS, 0, (hipStream_t)stream>>>(src, batch_stride, ld, A, col0, n, kbuf, ibuf, out_keys, out_idx);
+  UNIT_LAUNCH_CHECK();
+  return UNIT_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// K11  NMS (torchvision.ops.nms semantics): boxes sorted by descending score; box j is suppressed
+// iff an already-kept i<j has IoU(i,j) > thresh (strict); IoU = inter / (area_i + area_j - inter), no +1.
+//  (1) nms_mask_kernel: 64x64 tiles of the upper triangle -> bitmask[i][j/64]
+//  (2) nms_scan_kernel: one 256-thread workgroup per image; thread t owns word t of the "removed" bitmap;
+//      wave 0 resolves each 64-box chunk serially from the diagonal words, all threads then OR in the rows of the
+//      boxes kept in that chunk.  Stops after max_keep boxes.  Emits kept boxes/scores (gathered) + indices.
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool nms_suppress(const f32x4 a, const f32x4 b, float thresh) {
+  float xx1 = fmaxf(a[0], b[0]), yy1 = fmaxf(a[1], b[1]);
+  float xx2 = fminf(a[2], b[2]), yy2 = fminf(a[3], b[3]);
+  float w = fmaxf(0.0f, xx2 - xx1), h = fmaxf(0.0f, yy2 - yy1);
+  float inter = w * h;
+  float areaa = (a[2] - a[0]) * (a[3] - a[1]);
+  float areab = (b[2] - b[0]) * (b[3] - b[1]);
+  return inter / (areaa + areab - inter) > thresh;
+}
+
+__global__ void nms_mask_kernel(const float* __restrict__ boxes, const int* __restrict__ count, int cap, int nw,
+                                float thresh, unsigned long long* __restrict__ mask) {
+  int b = blockIdx.z;
+  int n = count ? min(count[b], cap) : cap;
+  int rb = blockIdx.y, cb = blockIdx.x;
+  if (cb < rb) return;
+  if (rb * 64 >= n || cb * 64 >= n) return;
+  __shared__ f32x4 cbox[64];
+  const float* bx = boxes + (size_t)b * cap * 4;
+  int cj = cb * 64 + threadIdx.x;
+  if (cj < n) cbox[threadIdx.x] = *reinterpret_cast<const f32x4*>(bx + 4 * (size_t)cj);
+  __syncthreads();
+  int i = rb * 64 + threadIdx.x;
+  if (i >= n) return;
+  f32x4 me = *reinterpret_cast<const f32x4*>(bx + 4 * (size_t)i);
+  unsigned long long bits = 0;
+  int jn = min(64, n - cb * 64);
+  int j0 = (rb == cb) ? threadIdx.x + 1 : 0;
+  for (int j = j0; j < jn; ++j)
+    if (nms_suppress(me, cbox[j], thresh)) bits |= 1ull << j;
+  mask[((size_t)b * cap + i) * nw + cb] = bits;
+}
+
+#define NMS_SCAN_THREADS 256
+__global__ void __launch_bounds__(NMS_SCAN_THREADS) nms_scan_kernel(const float* __restrict__ boxes, const float* __restrict__ scores,
+                                                            const int* __restrict__ count, int cap, int nw,
+                                                            const unsigned long long* __restrict__ mask, int max_keep,
+                                                            int* __restrict__ keep_idx, int* __restrict__ keep_count,
+                                                            float* __restrict__ out_boxes, float* __restrict__ out_scores) {
+  __shared__ unsigned long long s_cur, s_kept;
+  __shared__ int s_nkept;
+  int b = blockIdx.x;
+  int n = count ? min(count[b], cap) : cap;
+  const unsigned long long* mk = mask + (size_t)b * cap * nw;
+  int tid = threadIdx.x;
+  unsigned long long removed = 0;  // word `tid` of the removed bitmap
+  int nkept = 0;
+  if (tid == 0) s_nkept = 0;
+  int nchunks = (n + 63) / 64;
+  for (int c = 0; c < nchunks; ++c) {
+    if (tid == c) s_cur = removed;
+    __syncthreads();
+    if (tid < 64) {
+      int i = c * 64 + tid;
+      unsigned long long diag = (i < n) ? mk[(size_t)i * nw + c] : 0ull;
+      unsigned long long cur = s_cur, kept = 0;
+      int cnt = s_nkept;
+      int lim = min(64, n - c * 64);
+      for (int j = 0; j < lim; ++j) {
+        unsigned long long dj = __shfl(diag, j, 64);
+        if (!((cur >> j) & 1ull) && cnt < max_keep) { kept |= 1ull << j; cur |= dj; cnt++; }
+      }
+      if (tid == 0) { s_kept = kept; s_nkept = cnt; }
+      // emit this chunk's kept boxes in order
+      if ((kept >> tid) & 1ull) {
+        int rank = nkept + __popcll(kept & ((1ull << tid) - 1ull));
+        size_t o = (size_t)b * max_keep + rank;
+        keep_idx[o] = i;
+        if (out_boxes) *reinterpret_cast<f32x4*>(out_boxes + 4 * o) = *reinterpret_cast<const f32x4*>(boxes + ((size_t)b * cap + i) * 4);
+        if (out_scores) out_scores[o] = scores[(size_t)b * cap + i];
+      }
+    }
+    __syncthreads();
+    unsigned long long kept = s_kept;
+    nkept = s_nkept;
+    if (nkept >= max_keep) break;
+    if (tid < nw && tid > c) {
+      while (kept) {
+        int j = __ffsll((long long)kept) - 1;
+        kept &= kept - 1;
+        removed |= mk[(size_t)(c * 64 + j) * nw + tid];
+      }
+    }
+  }
+  if (tid == 0) keep_count[b] = nkept;
+}
+
+extern "C" size_t unit_nms_workspace_bytes(int B, int cap) { return (size_t)B * cap * ((cap + 63) / 64) * 8; }
+
+extern "C" int unit_nms(const float* boxes_sorted, const float* scores_sorted, const int* count, int B, int cap,
+                        float thresh, int max_keep, int* keep_idx, int* keep_count, float* out_boxes, float* out_scores,
+                        void* workspace, size_t workspace_bytes, void* stream) {
+  int nw = (cap + 63) / 64;
+  UNIT_CHECK_ARG(nw <= NMS_SCAN_THREADS, "nms: more than 16384 candidates per image");
+  if (workspace_bytes < unit_nms_workspace_bytes(B, cap)) { unit_set_error("nms: workspace too small"); return UNIT_ERR_WORKSPACE; }
+  if (B == 0) return UNIT_OK;
+  hipStream_t st = (hipStream_t)stream;
+  if (cap > 0) {
+    nms_mask_kernel<<<dim3(nw, nw, B), 64, 0, st>>>(boxes_sorted, count, cap, nw, thresh, (unsigned long long*)workspace);
+    UNIT_LAUNCH_CHECK();
+  }
+  nms_scan_kernel<<<B, NMS_SCAN_THREADS, 0, st>>>(boxes_sorted, scores_sorted, count, cap, nw, (const unsigned long long*)workspace,
+                                                  max_keep, keep_idx, keep_count, out_boxes, out_scores);
+  UNIT_LAUNCH_CHECK();
+  return UNIT_OK;
+}

@@ -1,0 +1,436 @@
+"""Functional Python wrappers over the libunit_hip.so C ABI (include/unit_hip.h).
+
+PyTorch is used here only as plumbing: device memory (torch.empty on the ROCm device), the current HIP stream and
+dtype bookkeeping. Every arithmetic step is one of the hand-written HIP kernels; there is no CPU / eager fallback --
+a missing extension or a CPU tensor raises.
+"""
+import ctypes
+import math
+
+import torch
+
+from ._lib import check, lib
+
+F32, BF16 = 0, 1
+SCALE_CLAMP = math.log(1000.0 / 16)  # Box2BoxTransform scale_clamp (detectron2 default)
+
+
+def dt(dtype):
+    if dtype == torch.float32:
+        return F32
+    if dtype == torch.bfloat16:
+        return BF16
+    raise TypeError(f"unsupported dtype {dtype}")
+
+
+def _p(t):
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError("unit_amd ops need tensors on the ROCm device (no CPU fallback)")
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def _s():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+_WS = {}
+
+
+def workspace(nbytes, device, slot=0):
+    key = (device, slot)
+    w = _WS.get(key)
+    if w is None or w.numel() < nbytes:
+        w = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
+        _WS[key] = w
+    return w
+
+
+# ------------------------------------------------------------------------------------------------ a1
+def preprocess_images(images, pixel_mean, pixel_std, dtype=torch.bfloat16, cpad=8, normalize_images=False, out=None):
+    """images: list of CHW fp32 device tensors (0..255). -> ([N,Hmax,Wmax,cpad] NHWC, [(h,w)...])  rcnn.py:257-266"""
+    sizes = [(int(x.shape[-2]), int(x.shape[-1])) for x in images]
+    hm, wm = max(s[0] for s in sizes), max(s[1] for s in sizes)
+    n = len(images)
+    if out is None:
+        out = torch.empty((n, hm, wm, cpad), dtype=dtype, device=images[0].device)
+    mean = (ctypes.c_float * 3)(*[float(v) for v in pixel_mean])
+    std = (ctypes.c_float * 3)(*[float(v) for v in pixel_std])
+    for i, x in enumerate(images):
+        x = x.contiguous()
+        if x.dtype != torch.float32:
+            raise TypeError("preprocess_images expects fp32 CHW images")
+        check(lib().unit_preprocess_image(_p(x), x.shape[0], sizes[i][0], sizes[i][1], mean, std,
+                                          255.0 if normalize_images else 1.0, _p(out[i]), dt(dtype), hm, wm, cpad, _s()),
+              "unit_preprocess_image")
+    return out, sizes
+
+
+def nchw_to_nhwc(x, dtype=torch.bfloat16, cpad=None):
+    n, c, h, w = x.shape
+    cp = cpad or c
+    y = torch.empty((n, h, w, cp), dtype=dtype, device=x.device)
+    check(lib().unit_nchw_to_nhwc(_p(x.contiguous().float()), _p(y), dt(dtype), n, c, h, w, cp, _s()), "nchw_to_nhwc")
+    return y
+
+
+def nhwc_to_nchw(x, c=None):
+    n, h, w, cp = x.shape
+    c = c or cp
+    y = torch.empty((n, c, h, w), dtype=torch.float32, device=x.device)
+    check(lib().unit_nhwc_to_nchw(_p(x.contiguous()), dt(x.dtype), _p(y), n, c, h, w, cp, _s()), "nhwc_to_nchw")
+    return y
+
+
+def cast(x, dtype):
+    y = torch.empty(x.shape, dtype=dtype, device=x.device)
+    check(lib().unit_cast(_p(x.contiguous()), dt(x.dtype), _p(y), dt(dtype), x.numel(), _s()), "cast")
+    return y
+
+
+def add_cast(a32, b, dtype):
+    y = torch.empty(a32.shape, dtype=dtype, device=a32.device)
+    check(lib().unit_add_cast(_p(a32), _p(b), _p(y), dt(dtype), a32.numel(), _s()), "add_cast")
+    return y
+
+
+# ------------------------------------------------------------------------------------------------ conv
+def conv_out_size(h, w, r, s, stride, pad):
+    return (h + 2 * pad - r) // stride + 1, (w + 2 * pad - s) // stride + 1
+
+
+def conv2d(x, w, k, r, s, stride=1, pad=0, bias=None, residual=None, mask_ref=None, relu=False, out_dtype=None,
+           out=None, ldy=None, scatter=None, tile_cfg=0):
+    """x [N,H,W,C] NHWC ; w [k][r][s][C] (same dtype). Returns y [N,OH,OW,ldy] (or writes the strided scatter target).
+    scatter = (oy_mul, OHf, OWf): output pixel (n,oh,ow) lands at (n, oh*oy_mul, ow*oy_mul) of `out` [N,OHf,OWf,ldy]."""
+    n, h, wd, c = x.shape
+    oh, ow = conv_out_size(h, wd, r, s, stride, pad)
+    out_dtype = out_dtype or x.dtype
+    ldy = ldy or ((k + 3) // 4 * 4)
+    if scatter is None:
+        oy_mul, ohf, owf = 1, oh, ow
+    else:
+        oy_mul, ohf, owf = scatter
+    if out is None:
+        if scatter is not None:
+            out = torch.zeros((n, ohf, owf, ldy), dtype=out_dtype, device=x.device)
+        else:
+            out = torch.empty((n, ohf, owf, ldy), dtype=out_dtype, device=x.device)
+    check(lib().unit_conv2d_fwd(_p(x), _p(w), _p(out), _p(bias), _p(residual), _p(mask_ref), dt(x.dtype), dt(out_dtype),
+                                n, h, wd, c, k, r, s, stride, pad, oh, ow, ldy, oy_mul, ohf, owf, int(relu), tile_cfg, _s()),
+          "unit_conv2d_fwd")
+    return out
+
+
+def conv2d_wgrad(x, dy, k, r, s, stride=1, pad=0, scale=None, out=None, accumulate=False, ldy=None):
+    """x [N,H,W,C], dy [N,OH,OW,ldy] -> dw fp32 [k,r,s,C] (scale[k] folded)."""
+    n, h, wd, c = x.shape
+    oh, ow = conv_out_size(h, wd, r, s, stride, pad)
+    ldy = ldy or dy.shape[-1]
+    if out is None:
+        out = torch.empty((k, r, s, c), dtype=torch.float32, device=x.device)
+    nbytes = lib().unit_conv2d_wgrad_workspace_bytes(dt(x.dtype), n, oh, ow, k, r, s, c)
+    ws = workspace(nbytes, x.device)
+    check(lib().unit_conv2d_wgrad(_p(x), _p(dy), _p(out), _p(scale), dt(x.dtype), n, h, wd, c, k, r, s, stride, pad, oh, ow,
+                                  ldy, int(accumulate), _p(ws), ws.numel(), _s()), "unit_conv2d_wgrad")
+    return out
+
+
+def frozen_bn_fold(weight, bias, running_mean, running_var, eps=1e-5):
+    c = weight.numel()
+    scale = torch.empty(c, dtype=torch.float32, device=weight.device)
+    shift = torch.empty(c, dtype=torch.float32, device=weight.device)
+    check(lib().unit_frozen_bn_fold(_p(weight), _p(bias), _p(running_mean), _p(running_var), eps, _p(scale), _p(shift), c, _s()),
+          "frozen_bn_fold")
+    return scale, shift
+
+
+def weight_prep(w_krsc, scale, k, r, s, c, cp, dtype, want_dgrad=True, w_fwd=None, w_dgrad=None):
+    """w_krsc: fp32 storage in [k][r][s][c] order (channels_last view of the [k,c,r,s] parameter)."""
+    dev = w_krsc.device
+    if w_fwd is None:
+        w_fwd = torch.empty((k, r, s, cp), dtype=dtype, device=dev)
+    if want_dgrad and w_dgrad is None:
+        w_dgrad = torch.empty((c, r, s, k), dtype=dtype, device=dev)
+    check(lib().unit_weight_prep(_p(w_krsc), _p(scale), k, r, s, c, cp, _p(w_fwd), _p(w_dgrad) if want_dgrad else None,
+                                 dt(dtype), _s()), "weight_prep")
+    return w_fwd, w_dgrad
+
+
+def bias_grad(dy2d, k, out=None, accumulate=False):
+    m, ld = dy2d.shape
+    if out is None:
+        out = torch.empty(k, dtype=torch.float32, device=dy2d.device)
+    check(lib().unit_bias_grad(_p(dy2d), dt(dy2d.dtype), m, k, ld, _p(out), int(accumulate), _s()), "bias_grad")
+    return out
+
+
+def maxpool3x3s2(x):
+    n, h, w, c = x.shape
+    oh, ow = (h + 2 - 3) // 2 + 1, (w + 2 - 3) // 2 + 1
+    y = torch.empty((n, oh, ow, c), dtype=x.dtype, device=x.device)
+    check(lib().unit_maxpool3x3s2_fwd(_p(x), _p(y), dt(x.dtype), n, h, w, c, _s()), "maxpool")
+    return y
+
+
+def global_avgpool(x):
+    """[R,PH,PW,C] -> [R,C]"""
+    r, ph, pw, c = x.shape
+    y = torch.empty((r, c), dtype=x.dtype, device=x.device)
+    check(lib().unit_global_avgpool_fwd(_p(x), _p(y), dt(x.dtype), r, ph * pw, c, _s()), "avgpool_fwd")
+    return y
+
+
+def global_avgpool_bwd_relu(dfeat, out):
+    r, ph, pw, c = out.shape
+    g = torch.empty_like(out)
+    check(lib().unit_global_avgpool_bwd_relu(_p(dfeat), _p(out), _p(g), dt(out.dtype), r, ph * pw, c, _s()), "avgpool_bwd")
+    return g
+
+
+# ------------------------------------------------------------------------------------------------ boxes
+def cell_anchors(sizes=(32, 64, 128, 256, 512), ratios=(0.5, 1.0, 2.0)):
+    """DefaultAnchorGenerator.generate_cell_anchors: python double math, then fp32."""
+    out = []
+    for size in sizes:
+        area = size ** 2.0
+        for r in ratios:
+            w = math.sqrt(area / r)
+            h = r * w
+            out.append([-w / 2.0, -h / 2.0, w / 2.0, h / 2.0])
+    return torch.tensor(out, dtype=torch.float32)
+
+
+def anchor_grid(h, w, cell, stride=16, offset=0.0):
+    a = cell.shape[0]
+    out = torch.empty((h * w * a, 4), dtype=torch.float32, device=cell.device)
+    check(lib().unit_anchor_grid(_p(out), h, w, a, float(stride), float(offset), _p(cell), _s()), "anchor_grid")
+    return out
+
+
+def iou_match(gt, gt_count, boxes, box_count, thresholds, labels, allow_low_quality, want_vals=True):
+    """gt [B,Mcap,4]; boxes [Ncap,4] (shared) or [B,Ncap,4]; counts: device int32 [B] or None."""
+    b, mcap = gt.shape[0], gt.shape[1]
+    shared = boxes.dim() == 2
+    ncap = boxes.shape[-2]
+    dev = gt.device
+    idx = torch.empty((b, ncap), dtype=torch.int64, device=dev)
+    lab = torch.empty((b, ncap), dtype=torch.int8, device=dev)
+    val = torch.empty((b, ncap), dtype=torch.float32, device=dev) if want_vals else None
+    th = (ctypes.c_float * len(thresholds))(*thresholds)
+    lb = (ctypes.c_int * len(labels))(*labels)
+    nb = lib().unit_iou_match_workspace_bytes(b, mcap)
+    ws = workspace(nb, dev)
+    check(lib().unit_iou_match(_p(gt), _p(gt_count), b, mcap, _p(boxes), 0 if shared else ncap * 4, _p(box_count), ncap,
+                               th, lb, len(thresholds), int(allow_low_quality), _p(idx), _p(lab), _p(val), _p(ws), ws.numel(),
+                               _s()), "iou_match")
+    return idx, lab, val
+
+
+def pairwise_iou(b1, b2):
+    out = torch.empty((b1.shape[0], b2.shape[0]), dtype=torch.float32, device=b1.device)
+    check(lib().unit_pairwise_iou(_p(b1), b1.shape[0], _p(b2), b2.shape[0], _p(out), _s()), "pairwise_iou")
+    return out
+
+
+def subsample_labels(labels, count, perm, num_samples, positive_fraction, bg_label, want_labels=True, want_idx=True):
+    """labels [B,Ncap] int8|int64 ; perm [B,Pcap] int32 -> (out_labels int8 [B,Ncap], sampled_idx int32 [B,S], counts [B,2])"""
+    b, ncap = labels.shape
+    dev = labels.device
+    out_labels = torch.empty((b, ncap), dtype=torch.int8, device=dev) if want_labels else None
+    sidx = torch.empty((b, num_samples), dtype=torch.int32, device=dev) if want_idx else None
+    counts = torch.empty((b, 2), dtype=torch.int32, device=dev)
+    max_pos = int(num_samples * positive_fraction)
+    check(lib().unit_subsample_labels(_p(labels), int(labels.dtype == torch.int64), _p(count), b, ncap, _p(perm), perm.shape[1],
+                                      num_samples, max_pos, bg_label, _p(out_labels), _p(sidx), _p(counts), _s()),
+          "subsample_labels")
+    return out_labels, sidx, counts
+
+
+def box_encode(src, tgt, weights):
+    out = torch.empty_like(src)
+    w = (ctypes.c_float * 4)(*weights)
+    check(lib().unit_box_encode(_p(src), _p(tgt), w, _p(out), src.shape[0], _s()), "box_encode")
+    return out
+
+
+def box_decode(deltas, boxes, weights, k=None, col0=0):
+    n, ld = deltas.shape
+    k = k or (ld - col0) // 4
+    out = torch.empty((n, k * 4), dtype=torch.float32, device=deltas.device)
+    w = (ctypes.c_float * 4)(*weights)
+    check(lib().unit_box_decode(_p(deltas), ld, col0, k, _p(boxes), w, SCALE_CLAMP, _p(out), n, _s()), "box_decode")
+    return out
+
+
+def sort_desc(src, b, n, ld=1, a=1, col0=0, batch_stride=None):
+    """stable descending sort of n keys per batch row; keys read as src[b*bstride + (i//a)*ld + col0 + i%a]."""
+    dev = src.device
+    keys = torch.empty((b, n), dtype=torch.float32, device=dev)
+    idx = torch.empty((b, n), dtype=torch.int32, device=dev)
+    if batch_stride is None:
+        batch_stride = (n // a) * ld
+    nb = lib().unit_sort_workspace_bytes(b, n)
+    ws = workspace(nb, dev)
+    check(lib().unit_sort_desc_stable(_p(src), batch_stride, ld, a, col0, b, n, _p(keys), _p(idx), _p(ws), ws.numel(), _s()),
+          "sort_desc_stable")
+    return keys, idx
+
+
+def rpn_decode_select(head, a, delta_col0, anchors, sorted_idx, sorted_logit, topk, image_hw, min_size=0.0):
+    """head [B,HW,ld] fp32 -> (cand_boxes [B,topk,4], cand_scores [B,topk], cand_count [B])"""
+    b, hw, ld = head.shape
+    ncap = anchors.shape[0]
+    dev = head.device
+    cb = torch.empty((b, topk, 4), dtype=torch.float32, device=dev)
+    cs = torch.empty((b, topk), dtype=torch.float32, device=dev)
+    cc = torch.empty((b,), dtype=torch.int32, device=dev)
+    check(lib().unit_rpn_decode_select(_p(head), hw * ld, ld, a, delta_col0, _p(anchors), _p(sorted_idx), _p(sorted_logit), b, ncap,
+                                       topk, _p(image_hw), SCALE_CLAMP, float(min_size), _p(cb), _p(cs), _p(cc), _s()),
+          "rpn_decode_select")
+    return cb, cs, cc
+
+
+def nms(boxes_sorted, scores_sorted, count, thresh, max_keep):
+    """boxes [B,cap,4] in descending score order -> (keep_idx [B,max_keep], keep_count [B], out_boxes, out_scores)"""
+    b, cap = boxes_sorted.shape[0], boxes_sorted.shape[1]
+    dev = boxes_sorted.device
+    keep = torch.full((b, max_keep), -1, dtype=torch.int32, device=dev)
+    kc = torch.empty((b,), dtype=torch.int32, device=dev)
+    ob = torch.zeros((b, max_keep, 4), dtype=torch.float32, device=dev)
+    osc = torch.zeros((b, max_keep), dtype=torch.float32, device=dev)
+    nb = lib().unit_nms_workspace_bytes(b, cap)
+    ws = workspace(nb, dev)
+    check(lib().unit_nms(_p(boxes_sorted), _p(scores_sorted), _p(count), b, cap, float(thresh), max_keep, _p(keep), _p(kc), _p(ob),
+                         _p(osc), _p(ws), ws.numel(), _s()), "nms")
+    return keep, kc, ob, osc
+
+
+# ------------------------------------------------------------------------------------------------ a7 plumbing
+def append_gt(props, pcount, gt, gcount):
+    b, pcap = props.shape[0], props.shape[1]
+    mcap = gt.shape[1]
+    cat = torch.empty((b, pcap + mcap, 4), dtype=torch.float32, device=props.device)
+    cc = torch.empty((b,), dtype=torch.int32, device=props.device)
+    check(lib().unit_append_gt(_p(props), _p(pcount), pcap, _p(gt), _p(gcount), mcap, b, _p(cat), _p(cc), _s()), "append_gt")
+    return cat, cc
+
+
+def roi_classes(match_idx, match_label, count, gt_classes, gcount, k):
+    b, ncap = match_idx.shape
+    cls = torch.empty((b, ncap), dtype=torch.int64, device=match_idx.device)
+    check(lib().unit_roi_classes(_p(match_idx), _p(match_label), _p(count), _p(gt_classes), _p(gcount), gt_classes.shape[1], b, ncap,
+                                 k, _p(cls), _s()), "roi_classes")
+    return cls
+
+
+def gather_rois(cat, sampled_idx, cls, match_idx, gt, gcount):
+    b, ncap = cat.shape[0], cat.shape[1]
+    s = sampled_idx.shape[1]
+    dev = cat.device
+    rois = torch.empty((b * s, 5), dtype=torch.float32, device=dev)
+    rcls = torch.empty((b * s,), dtype=torch.int32, device=dev)
+    rgt = torch.empty((b * s, 4), dtype=torch.float32, device=dev)
+    check(lib().unit_gather_rois(_p(cat), ncap, _p(sampled_idx), s, _p(cls), _p(match_idx), _p(gt), _p(gcount), gt.shape[1], b,
+                                 _p(rois), _p(rcls), _p(rgt), _s()), "gather_rois")
+    return rois, rcls, rgt
+
+
+def first_k_rois(props, pcount, s, batch_index_offset=0):
+    b, pcap = props.shape[0], props.shape[1]
+    rois = torch.empty((b * s, 5), dtype=torch.float32, device=props.device)
+    valid = torch.empty((b * s,), dtype=torch.int32, device=props.device)
+    check(lib().unit_first_k_rois(_p(props), _p(pcount), pcap, s, b, batch_index_offset, _p(rois), _p(valid), _s()), "first_k_rois")
+    return rois, valid
+
+
+# ------------------------------------------------------------------------------------------------ a8
+def roi_align(feat, rois, pooled_size=14, out_size=None, bin_step=1, spatial_scale=1.0 / 16, sampling_ratio=0, aligned=True,
+              roi_count=None):
+    n, h, w, c = feat.shape
+    r = rois.shape[0]
+    out_size = out_size or pooled_size
+    out = torch.empty((r, out_size, out_size, c), dtype=feat.dtype, device=feat.device)
+    check(lib().unit_roi_align_fwd(_p(feat), dt(feat.dtype), n, h, w, c, _p(rois), _p(roi_count), r, pooled_size, out_size, bin_step,
+                                   float(spatial_scale), sampling_ratio, int(aligned), _p(out), _s()), "roi_align_fwd")
+    return out
+
+
+def roi_align_bwd(gout, feat_shape, rois, dfeat32=None, pooled_size=14, bin_step=1, spatial_scale=1.0 / 16, sampling_ratio=0,
+                  aligned=True, roi_count=None):
+    n, h, w, c = feat_shape
+    r, out_size = gout.shape[0], gout.shape[1]
+    if dfeat32 is None:
+        dfeat32 = torch.zeros((n, h, w, c), dtype=torch.float32, device=gout.device)
+    check(lib().unit_roi_align_bwd(_p(gout), dt(gout.dtype), n, h, w, c, _p(rois), _p(roi_count), r, pooled_size, out_size, bin_step,
+                                   float(spatial_scale), sampling_ratio, int(aligned), _p(dfeat32), _s()), "roi_align_bwd")
+    return dfeat32
+
+
+# ------------------------------------------------------------------------------------------------ losses
+def rpn_loss(head, a, dcol0, labels, match_idx, gt_boxes, anchors, normalizer, grad_dtype, gscale=1.0):
+    b, hw, ld = head.shape
+    ncap = anchors.shape[0]
+    loss2 = torch.empty(2, dtype=torch.float32, device=head.device)
+    dhead = torch.empty((b, hw, ld), dtype=grad_dtype, device=head.device)
+    check(lib().unit_rpn_loss(_p(head), ld, a, dcol0, _p(labels), _p(match_idx), _p(gt_boxes), gt_boxes.shape[1], _p(anchors), b, ncap,
+                              float(normalizer), float(gscale), _p(loss2), _p(dhead), dt(grad_dtype), _s()), "rpn_loss")
+    return loss2, dhead
+
+
+def sup_scores(delta, dcol0, weak, wcol0, n_oicr, ncls, novel_mask=None, extra=None, ecol0=0):
+    r = delta.shape[0]
+    out = torch.empty((r, ncls), dtype=torch.float32, device=delta.device)
+    check(lib().unit_sup_scores(_p(delta), delta.shape[1], dcol0, _p(weak), weak.shape[1] if weak is not None else 0, wcol0, n_oicr,
+                                ncls, _p(novel_mask), _p(extra), extra.shape[1] if extra is not None else 0, ecol0, _p(out), ncls, r,
+                                _s()), "sup_scores")
+    return out
+
+
+def softmax_ce(logits, col0, ncls, labels, weights=None, dy=None, dcol0=0, gscale=1.0, loss_out=None):
+    r, ld = logits.shape
+    loss = loss_out if loss_out is not None else torch.empty(1, dtype=torch.float32, device=logits.device)
+    check(lib().unit_softmax_ce(_p(logits), ld, col0, ncls, _p(labels), _p(weights), r, float(gscale), _p(loss), _p(dy),
+                                dt(dy.dtype) if dy is not None else 0, dy.shape[1] if dy is not None else 0, dcol0, _s()), "softmax_ce")
+    return loss
+
+
+def box_reg_loss(bbox, col0, k, labels, rois5, gt_boxes, weights, dy=None, dcol0=0, gscale=1.0, loss_out=None):
+    r, ld = bbox.shape
+    loss = loss_out if loss_out is not None else torch.empty(1, dtype=torch.float32, device=bbox.device)
+    w = (ctypes.c_float * 4)(*weights)
+    check(lib().unit_box_reg_loss(_p(bbox), ld, col0, k, _p(labels), _p(rois5), _p(gt_boxes), w, r, float(gscale), _p(loss), _p(dy),
+                                  dt(dy.dtype) if dy is not None else 0, dy.shape[1] if dy is not None else 0, dcol0, _s()), "box_reg_loss")
+    return loss
+
+
+def wsddn_mil(streams, ccol0, dcol0, k, valid, s, b, multihot, cls_temp, det_temp, mil_multiplier, dy=None, dyc0=0, dyd0=0,
+              gscale=1.0, loss_out=None):
+    rtot, ld = streams.shape
+    loss = loss_out if loss_out is not None else torch.empty(1, dtype=torch.float32, device=streams.device)
+    xr = torch.empty((rtot, k), dtype=torch.float32, device=streams.device)
+    check(lib().unit_wsddn_mil(_p(streams), ld, ccol0, dcol0, k, _p(valid), s, b, _p(multihot), float(cls_temp), float(det_temp),
+                               float(mil_multiplier), float(gscale), _p(loss), _p(xr), _p(dy), dt(dy.dtype) if dy is not None else 0,
+                               dy.shape[1] if dy is not None else 0, dyc0, dyd0, _s()), "wsddn_mil")
+    return loss, xr
+
+
+def oicr_targets(src, col0, mode, k, rois5, valid, s, b, multihot, fg_thresh=0.5, bg_thresh=0.1):
+    rtot = rois5.shape[0]
+    labels = torch.empty((rtot,), dtype=torch.int32, device=src.device)
+    weights = torch.empty((rtot,), dtype=torch.float32, device=src.device)
+    check(lib().unit_oicr_targets(_p(src), src.shape[1], col0, mode, k, _p(rois5), _p(valid), s, b, _p(multihot), float(fg_thresh),
+                                  float(bg_thresh), _p(labels), _p(weights), _s()), "oicr_targets")
+    return labels, weights
+
+
+def sum_losses(losses, out=None):
+    out = out if out is not None else torch.empty(1, dtype=torch.float32, device=losses.device)
+    check(lib().unit_sum_losses(_p(losses), losses.numel(), _p(out), _s()), "sum_losses")
+    return out
+
+
+def sgd_momentum(p, g, buf, lr, momentum, weight_decay, grad_scale=1.0, first_step=False):
+    check(lib().unit_sgd_momentum(_p(p), _p(g), _p(buf), p.numel(), float(lr), float(momentum), float(weight_decay), float(grad_scale),
+                                  int(first_step), _s()), "sgd_momentum")
