@@ -27,7 +27,7 @@ int unit_preprocess_image(const float* img_chw, int C, int H, int W, const float
 int unit_nchw_to_nhwc(const float* x, void* y, int dtype, int N, int C, int H, int W, int Cp, void* stream);
 int unit_nhwc_to_nchw(const void* x, int dtype, float* y, int N, int C, int H, int W, int Cp, void* stream);
 int unit_cast(const void* x, int in_dtype, void* y, int out_dtype, long n, void* stream);
-int unit_add_cast(const float* a32, const void* b, void* y, int dtype, long n, void* stream);
+int unit_add_cast(const float* a32, const void* b, const void* mask_ref, void* y, int dtype, long n, void* stream);
 
 /* ---- a2/a3/a9/a10 convolution as implicit GEMM on MFMA: backbone (configs/VOC/VOC-RCNN-101-C4-split1.yaml:6-10 ->
  * detectron2 build_resnet_backbone), RPN head (modeling/proposal_generator/rpn.py:24), Res5 heads
@@ -62,6 +62,9 @@ int unit_iou_match(const float* gt, const int* gt_count, int B, int Mcap, const 
                    int allow_low_quality, int64_t* match_idx, int8_t* match_label, float* match_val, void* workspace,
                    size_t workspace_bytes, void* stream);
 int unit_pairwise_iou(const float* b1, int M, const float* b2, int Nb, float* out, void* stream);
+/* Matcher.__call__(match_quality_matrix): modeling/matcher.py:54 on a precomputed M x N matrix; rowmax_ws: M floats */
+int unit_match_matrix(const float* q, int M, int N, const float* thresholds, const int* labels, int n_thresh, int allow_low_quality,
+                      int64_t* match_idx, int8_t* match_label, float* match_val, float* rowmax_ws, void* stream);
 
 /* ---- K8 subsample_labels with the explicit-permutation contract (detectron2.modeling.sampling via rpn.py:41,
  * roi_heads.py:563, roi_heads.py:415) ---- */

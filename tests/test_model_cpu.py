@@ -1,0 +1,88 @@
+"""CPU tests of the host-side model mirror: registry names, state-dict keys (the checkpoint contract),
+freeze lists, flat parameter store layout. No kernels are launched."""
+import torch
+
+from unit_amd import config
+from unit_amd.modeling import build_model
+from unit_amd.structures import (FAST_RCNN_REGISTRY, META_ARCH_REGISTRY, PROPOSAL_GENERATOR_REGISTRY, ROI_BOX_HEAD_REGISTRY,
+                                 ROI_HEADS_REGISTRY)
+
+
+def _cfg(depth=50, ft=False):
+    c = config.voc_rcnn_c4_split1_ft(depth) if ft else config.voc_rcnn_c4_split1(depth)
+    c.MODEL.DEVICE = "cpu"
+    return c
+
+
+def test_registry_names_match_reference_yaml():
+    for reg, names in [(META_ARCH_REGISTRY, ["WeaklySupervisedRCNNNoMeta"]), (PROPOSAL_GENERATOR_REGISTRY, ["WSRPN"]),
+                       (ROI_HEADS_REGISTRY, ["WSROIHeadNoMeta", "WSROIHeadFineTune"]),
+                       (ROI_BOX_HEAD_REGISTRY, ["Res5BoxHead", "Res5BoxHeadWithMask"]),
+                       (FAST_RCNN_REGISTRY, ["SupervisedDetectorOutputsBase", "SupervisedDetectorOutputsFineTune"])]:
+        for n in names:
+            assert n in reg, n
+
+
+def test_state_dict_keys_and_shapes():
+    m = build_model(_cfg(50))
+    sd = m.state_dict()
+    expect = {
+        "backbone.stem.conv1.weight": (64, 3, 7, 7), "backbone.stem.conv1.norm.running_var": (64,),
+        "backbone.res2.0.shortcut.weight": (256, 64, 1, 1), "backbone.res3.0.conv1.weight": (128, 256, 1, 1),
+        "backbone.res4.5.conv2.weight": (256, 256, 3, 3), "backbone.res4.0.shortcut.norm.bias": (1024,),
+        "proposal_generator.rpn_head.conv.weight": (1024, 1024, 3, 3), "proposal_generator.rpn_head.conv.bias": (1024,),
+        "proposal_generator.rpn_head.objectness_logits.weight": (15, 1024, 1, 1),
+        "proposal_generator.rpn_head.anchor_deltas.bias": (60,), "proposal_generator.anchor_generator.cell_anchors.0": (15, 4),
+        "roi_heads.box_head.res5.0.shortcut.weight": (2048, 1024, 1, 1), "roi_heads.weak_box_head.res5.2.conv3.weight": (2048, 512, 1, 1),
+        "roi_heads.box_predictor.cls_score_delta.weight": (21, 2048), "roi_heads.box_predictor.bbox_pred_delta.bias": (80,),
+        "roi_heads.box_predictor.weak_detector_head.classifier_stream.weight": (20, 2048),
+        "roi_heads.box_predictor.weak_detector_head.oicr_predictors.2.bias": (21,),
+        "roi_heads.box_predictor.embeddings.weight": (80, 300),
+    }
+    for k, shp in expect.items():
+        assert k in sd and tuple(sd[k].shape) == shp, k
+    assert not any(k.startswith("backbone.res5") for k in sd)
+    assert len([k for k in sd if k.startswith("backbone.res4.")]) == 6 * (3 * 5) + 5   # R50: 6 blocks, one shortcut
+
+
+def test_freeze_at_and_finetune_freeze_lists():
+    m = build_model(_cfg(50))
+    req = {n: p.requires_grad for n, p in m.named_parameters()}
+    assert not req["backbone.stem.conv1.weight"] and not req["backbone.res2.2.conv3.weight"]
+    assert req["backbone.res3.0.conv1.weight"] and req["roi_heads.weak_box_head.res5.0.conv1.weight"]
+    assert not req["roi_heads.box_predictor.embeddings.weight"]
+    ft = build_model(_cfg(50, ft=True))
+    trainable = sorted(n for n, p in ft.named_parameters() if p.requires_grad)
+    assert trainable == ["roi_heads.box_predictor.bbox_pred_ft.bias", "roi_heads.box_predictor.bbox_pred_ft.weight",
+                         "roi_heads.box_predictor.cls_score_ft.bias", "roi_heads.box_predictor.cls_score_ft.weight"]
+    assert sum(p.numel() for p in ft.parameters() if p.requires_grad) == 21 * 2048 + 21 + 80 * 2048 + 80   # 0.207 M
+
+
+def test_flat_store_layout_and_fused_heads():
+    m = build_model(_cfg(50))
+    before = {k: v.clone() for k, v in m.state_dict().items()}
+    st = m.flatten_parameters()
+    after = m.state_dict()
+    for k in before:
+        assert torch.equal(before[k], after[k]), k          # values preserved
+    n_train = sum(p.numel() for p in m.parameters() if p.requires_grad)
+    assert st.size >= n_train and st.size < n_train * 1.01
+    w = m.backbone.res4[0].conv2.weight
+    assert w.data.permute(0, 2, 3, 1).is_contiguous() and w.grad.permute(0, 2, 3, 1).is_contiguous()   # physical [K][R][S][C]
+    bp = m.roi_heads.box_predictor
+    for grp in (bp.group, bp.weak_detector_head.group, m.proposal_generator.rpn_head.pred):
+        wv, bv = grp._fused_views("data")
+        assert wv is not None and wv.shape == (grp.kp, grp.cin) and bv.shape == (grp.k,)
+        gv, gb = grp._fused_views("grad")
+        assert gv is not None
+        assert torch.count_nonzero(wv[grp.k:]) == 0          # pad rows
+    tags = [t for t, _, _ in st.tags]
+    assert tags.index("heads") < tags.index("box_head") < tags.index("rpn") < tags.index("res4") < tags.index("res3")
+    # R50 trainable parameter count (~48.1 M)
+    assert abs(n_train - 48.1e6) < 0.5e6, n_train
+
+
+def test_r101_parameter_count():
+    m = build_model(_cfg(101))
+    n_train = sum(p.numel() for p in m.parameters() if p.requires_grad)
+    assert abs(n_train - 67.05e6) < 0.5e6, n_train      # 67.0 M trainable

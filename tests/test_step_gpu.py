@@ -1,0 +1,139 @@
+"""End-to-end parity of one UniT training step (S1: TrainerNoMeta.run_step semantics) against the CPU oracle:
+same weights (state_dict), same images / GT / image-level labels, same sampling permutations.
+fp32 compute mode: losses within 1e-4 (north_star), parameter gradients within 1e-3 relative to their max."""
+import pytest
+import torch
+
+import unit_oracle as orc
+from unit_amd import config
+from unit_amd.modeling import build_model
+from unit_amd.modeling.rcnn import LOSS_NAMES
+from unit_amd.solver import FlatSGD
+from unit_amd.synthetic import init_synthetic_weights, synthetic_batch
+
+pytestmark = pytest.mark.gpu
+
+
+def small_cfg(depth=50, rois=32, pre=600, post=100):
+    c = config.voc_rcnn_c4_split1(depth)
+    c.MODEL.DEVICE = "cuda"
+    c.MODEL.ROI_HEADS.BATCH_SIZE_PER_IMAGE = rois
+    c.MODEL.RPN.PRE_NMS_TOPK_TRAIN = pre
+    c.MODEL.RPN.POST_NMS_TOPK_TRAIN = post
+    c.SEED = 3
+    return c
+
+
+def oracle_step(model, cfg, sup, weak, perms):
+    names_trainable = {n for n, p in model.named_parameters() if p.requires_grad}
+    p = {}
+    for k, v in model.state_dict().items():
+        t = v.detach().cpu().clone().contiguous()
+        if k in names_trainable:
+            t.requires_grad_(True)
+        p[k] = t
+    ocfg = dict(depth=cfg.MODEL.RESNETS.DEPTH, num_classes=cfg.MODEL.ROI_HEADS.NUM_CLASSES,
+                novel_classes=list(cfg.DATASETS.FEWSHOT.NOVEL_CLASSES_ID), pixel_mean=cfg.MODEL.PIXEL_MEAN, pixel_std=cfg.MODEL.PIXEL_STD,
+                rois_per_image=cfg.MODEL.ROI_HEADS.BATCH_SIZE_PER_IMAGE, pre_nms_topk=cfg.MODEL.RPN.PRE_NMS_TOPK_TRAIN,
+                post_nms_topk=cfg.MODEL.RPN.POST_NMS_TOPK_TRAIN, multi_box_head=cfg.MODEL.ROI_HEADS.MULTI_BOX_HEAD)
+    operms = dict(rpn=[x.long().cpu() for x in perms["rpn"]], roi=[x.long().cpu() for x in perms["roi"]])
+    losses, aux = orc.step_losses(p, [x["image"] for x in sup], [x["instances"].gt_boxes.tensor for x in sup],
+                                  [x["instances"].gt_classes for x in sup], [x["image"] for x in weak] if weak else None,
+                                  [x["instances"].gt_classes for x in weak] if weak else None, operms, ocfg)
+    sum(losses.values()).backward()
+    return losses, p, aux
+
+
+@pytest.mark.parametrize("pool_mode", ["strided", "full"])
+def test_s1_step_parity_fp32(dev, pool_mode):
+    cfg = small_cfg()
+    model = build_model(cfg)
+    init_synthetic_weights(model, seed=1)
+    model.train()
+    model.compute_dtype = torch.float32
+    model.roi_heads.pool_mode = pool_mode
+    sup, weak = synthetic_batch(2, 2, hw=(128, 192), seed=5, max_gt=4)
+    batch = model.pack_batch(sup, weak)
+    model._ensure_ready()
+    n_anchor = 8 * 12 * 15
+    perms = model.sampling_permutations(2, n_anchor, cfg.MODEL.RPN.POST_NMS_TOPK_TRAIN + batch.gt_boxes.shape[1])
+    step = model.forward_train(batch, perms)
+    model.backward_train(step)
+    got = dict(zip(LOSS_NAMES, step.losses.cpu().tolist()))
+    ref, p, aux = oracle_step(model, cfg, sup, weak, perms)
+    # index-exact intermediate decisions
+    assert torch.equal(step.anchor_labels.cpu(), torch.stack(aux["anchor_labels"]))
+    for i in range(2):
+        rb = aux["sampled"][i]["boxes"]
+        m = len(rb)
+        sl = slice(i * 32, i * 32 + m)
+        assert torch.allclose(step.rois[sl, 1:].cpu(), rb, rtol=1e-5, atol=1e-3)
+        assert torch.equal(step.roi_cls[sl].cpu().long(), aux["sampled"][i]["gt_classes"])
+    for k in LOSS_NAMES:
+        assert abs(got[k] - ref[k].item()) <= 1e-4 * max(1.0, abs(ref[k].item())), (k, got[k], ref[k].item())
+    checked = 0
+    for name, prm in model.named_parameters():
+        if not prm.requires_grad:
+            continue
+        g_ref = p[name].grad
+        assert g_ref is not None, name
+        g = prm.grad.detach().cpu()
+        scale = g_ref.abs().max().item() + 1e-12
+        err = (g - g_ref).abs().max().item()
+        assert err <= 2e-3 * scale + 1e-7, (name, err, scale)
+        checked += 1
+    assert checked > 100
+
+
+def test_s1_step_bf16_runs_and_tracks_fp32(dev):
+    """bf16 compute mode: stated looser tolerance (bf16 has 8 significant bits; 50+ layers deep)."""
+    cfg = small_cfg()
+    losses = {}
+    for dt in (torch.float32, torch.bfloat16):
+        model = build_model(cfg)
+        init_synthetic_weights(model, seed=1)
+        model.train()
+        model.compute_dtype = dt
+        sup, weak = synthetic_batch(2, 2, hw=(128, 192), seed=5, max_gt=4)
+        batch = model.pack_batch(sup, weak)
+        model._ensure_ready()
+        perms = model.sampling_permutations(2, 8 * 12 * 15, cfg.MODEL.RPN.POST_NMS_TOPK_TRAIN + batch.gt_boxes.shape[1])
+        step = model.forward_train(batch, perms)
+        model.backward_train(step)
+        losses[dt] = step.losses.cpu()
+        assert torch.isfinite(losses[dt]).all()
+    assert torch.allclose(losses[torch.bfloat16], losses[torch.float32], rtol=0.1, atol=0.05), losses
+
+
+def test_autograd_surface_and_sgd(dev):
+    """Drop-in surface: loss_dict = model(data, weak_batched_inputs=...); sum(...).backward(); optimizer.step()
+    (engine/defaults.py:279-284) == train_step(); a second step sees the updated (re-prepared) weights."""
+    cfg = small_cfg()
+    model = build_model(cfg)
+    init_synthetic_weights(model, seed=1)
+    model.train()
+    model.compute_dtype = torch.float32
+    opt = FlatSGD(model, cfg)
+    sup, weak = synthetic_batch(2, 2, hw=(128, 192), seed=5, max_gt=4)
+    model._ensure_ready()
+    batch = model.pack_batch(sup, weak)
+    perms = model.sampling_permutations(2, 8 * 12 * 15, cfg.MODEL.RPN.POST_NMS_TOPK_TRAIN + batch.gt_boxes.shape[1])
+    loss_dict = model(sup, weak_batched_inputs=weak, perms=perms)
+    assert set(loss_dict) == set(LOSS_NAMES)
+    total = sum(loss_dict.values())
+    for p in model.parameters():
+        p.grad = None                      # optimizer.zero_grad(set_to_none=True)
+    total.backward()
+    g1 = model.store.grads.clone()
+    assert torch.isfinite(g1).all() and g1.abs().sum() > 0
+    w_before = model.store.params.clone()
+    opt.step()
+    assert not torch.equal(w_before, model.store.params)
+    l0 = torch.stack([loss_dict[k] for k in LOSS_NAMES]).detach().cpu()
+    l1 = model.train_step(batch, None, perms).cpu()
+    assert not torch.allclose(l0, l1)      # weights changed -> losses changed (layers re-prepared their bf16/fp32 copies)
+    model.store.params.copy_(w_before)
+    model.version += 1
+    l2 = model.train_step(batch, None, perms).cpu()
+    assert torch.allclose(l0, l2, rtol=1e-6, atol=1e-7)
+    assert torch.allclose(model.store.grads, g1, rtol=1e-4, atol=1e-6)

@@ -353,3 +353,53 @@ extern "C" int unit_rpn_decode_select(const float* head, long head_batch_stride,
   UNIT_LAUNCH_CHECK();
   return UNIT_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------
+// Matcher on a precomputed M x N quality matrix -- the exact call shape of /root/reference/modeling/matcher.py:54
+// (`Matcher.__call__(match_quality_matrix)`), used by the plugin-surface `unit_amd.modeling.Matcher`.
+// ---------------------------------------------------------------------------------------------------
+__global__ void matrix_rowmax_kernel(const float* __restrict__ q, int M, int N, float* __restrict__ rowmax) {
+  __shared__ float lds[16];
+  int m = blockIdx.x;
+  float v = -INFINITY;
+  for (int n = threadIdx.x; n < N; n += blockDim.x) v = fmaxf(v, q[(size_t)m * N + n]);
+  v = wave_reduce_max(v);
+  if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) { float mm = -INFINITY; for (int w = 0; w < (int)(blockDim.x >> 6); ++w) mm = fmaxf(mm, lds[w]); rowmax[m] = mm; }
+}
+__global__ void matrix_match_kernel(const float* __restrict__ q, int M, int N, MatchCfg cfg, int allow_lq, const float* __restrict__ rowmax,
+                                    int64_t* __restrict__ midx, int8_t* __restrict__ mlab, float* __restrict__ mval) {
+  int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N) return;
+  if (M == 0) { midx[n] = 0; mlab[n] = (int8_t)cfg.lab[0]; mval[n] = 0.f; return; }
+  float best = q[n]; int bi = 0; bool hit = (best == rowmax[0]);
+  for (int m = 1; m < M; ++m) {
+    float v = q[(size_t)m * N + n];
+    if (v > best) { best = v; bi = m; }
+    hit |= (v == rowmax[m]);
+  }
+  int8_t lab = 1; float low = -INFINITY;
+  for (int l = 0; l <= cfg.nthr; ++l) {
+    float high = l < cfg.nthr ? cfg.thr[l] : INFINITY;
+    if (best >= low && best < high) lab = (int8_t)cfg.lab[l];
+    low = high;
+  }
+  if (allow_lq && hit) lab = 1;
+  midx[n] = bi; mlab[n] = lab; mval[n] = best;
+}
+extern "C" int unit_match_matrix(const float* q, int M, int N, const float* thresholds, const int* labels, int n_thresh,
+                                 int allow_low_quality, int64_t* match_idx, int8_t* match_label, float* match_val,
+                                 float* rowmax_ws, void* stream) {
+  UNIT_CHECK_ARG(n_thresh >= 1 && n_thresh <= 4, "match_matrix: 1..4 thresholds");
+  if (N == 0) return UNIT_OK;
+  hipStream_t st = (hipStream_t)stream;
+  MatchCfg cfg;
+  for (int i = 0; i < n_thresh; ++i) cfg.thr[i] = thresholds[i];
+  for (int i = 0; i <= n_thresh; ++i) cfg.lab[i] = labels[i];
+  cfg.nthr = n_thresh;
+  if (M > 0) { matrix_rowmax_kernel<<<M, 256, 0, st>>>(q, M, N, rowmax_ws); UNIT_LAUNCH_CHECK(); }
+  matrix_match_kernel<<<cdiv(N, 256), 256, 0, st>>>(q, M, N, cfg, allow_low_quality, rowmax_ws, match_idx, match_label, match_val);
+  UNIT_LAUNCH_CHECK();
+  return UNIT_OK;
+}

@@ -270,7 +270,7 @@ extern "C" int unit_sgd_momentum(float* p, const float* g, float* buf, long n, f
 // small helpers: y = cast(a32 [+ b]) ; used to merge the fp32 RoIAlign-backward accumulator with the RPN dgrad
 // ---------------------------------------------------------------------------------------------------
 template <typename T>
-__global__ void add_cast_kernel(const float* __restrict__ a32, const T* __restrict__ b, T* __restrict__ y, long n8) {
+__global__ void add_cast_kernel(const float* __restrict__ a32, const T* __restrict__ b, const T* __restrict__ mask, T* __restrict__ y, long n8) {
   long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n8) return;
   float a[8], bb[8];
@@ -280,14 +280,20 @@ __global__ void add_cast_kernel(const float* __restrict__ a32, const T* __restri
 #pragma unroll
     for (int j = 0; j < 8; ++j) a[j] += bb[j];
   }
+  if (mask) {
+    Vec8<T>::load(mask + i * 8, bb);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) a[j] = bb[j] > 0.f ? a[j] : 0.f;
+  }
   Vec8<T>::store(y + i * 8, a);
 }
-extern "C" int unit_add_cast(const float* a32, const void* b, void* y, int dtype, long n, void* stream) {
+// y = cast((a32 [+ b]) [* (mask_ref > 0)])
+extern "C" int unit_add_cast(const float* a32, const void* b, const void* mask_ref, void* y, int dtype, long n, void* stream) {
   UNIT_CHECK_ARG(n % 8 == 0, "add_cast: n % 8 != 0");
   if (n == 0) return UNIT_OK;
   hipStream_t st = (hipStream_t)stream;
-  if (dtype == UNIT_BF16) add_cast_kernel<bf16_t><<<cdiv(n / 8, 256), 256, 0, st>>>(a32, (const bf16_t*)b, (bf16_t*)y, n / 8);
-  else add_cast_kernel<float><<<cdiv(n / 8, 256), 256, 0, st>>>(a32, (const float*)b, (float*)y, n / 8);
+  if (dtype == UNIT_BF16) add_cast_kernel<bf16_t><<<cdiv(n / 8, 256), 256, 0, st>>>(a32, (const bf16_t*)b, (const bf16_t*)mask_ref, (bf16_t*)y, n / 8);
+  else add_cast_kernel<float><<<cdiv(n / 8, 256), 256, 0, st>>>(a32, (const float*)b, (const float*)mask_ref, (float*)y, n / 8);
   UNIT_LAUNCH_CHECK();
   return UNIT_OK;
 }

@@ -10,6 +10,7 @@
 // ---------------------------------------------------------------------------------------------------
 __device__ __forceinline__ unsigned desc_key(float f) {
   unsigned u = __float_as_uint(f);
+  if (u == 0x80000000u) u = 0u;   // -0.0 == +0.0 for the comparison sort the reference uses
   unsigned asc = (u & 0x80000000u) ? ~u : (u | 0x80000000u);  // ascending-order key
   return ~asc;                                                 // descending
 }
@@ -93,8 +94,10 @@ __global__ void __launch_bounds__(SORT_THREADS) radix_sort_kernel(const float* _
     int* ti = i0; i0 = i1; i1 = ti;
   }
   for (int i = tid; i < n; i += SORT_THREADS) {
-    out_keys[(size_t)b * n + i] = key_to_float(k0[i]);
-    out_idx[(size_t)b * n + i] = i0[i];
+    int id = i0[i];
+    int pix = id / A, a = id - pix * A;
+    out_keys[(size_t)b * n + i] = src[(size_t)b * bstride + (size_t)pix * ld + col0 + a];   // original bits (keeps -0.0)
+    out_idx[(size_t)b * n + i] = id;
   }
 }
 

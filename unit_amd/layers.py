@@ -1,0 +1,276 @@
+"""Execution layers with EXPLICIT forward / backward over the HIP kernels (no tracing, no autograd graph inside).
+
+Each layer is an nn.Module only so that its parameters / buffers carry the reference's state-dict keys
+(Detectron2 names: `conv1.weight`, `conv1.norm.running_var`, ...). The arithmetic is done by `fwd` / `bwd` methods
+that launch the C-ABI kernels on the current HIP stream and hand activations around as NHWC tensors.
+
+Conventions
+  * activations: NHWC, dtype = compute dtype (bf16 for speed, fp32 for the parity mode);
+  * `g` passed to a block's bwd is d(loss)/d(block output) ALREADY multiplied by the ReLU mask (out > 0);
+    a block's bwd returns d(loss)/d(block input) multiplied by (input > 0) when `mask_input` (the input is the
+    previous block's post-ReLU output), so masks are fused into the dgrad epilogues and never run as kernels.
+"""
+import torch
+from torch import nn
+
+from . import ops
+
+
+def _krsc_storage(w):
+    """fp32 tensor whose MEMORY is [K][R][S][C] for a logical [K,C,R,S] weight (zero-copy when channels_last view)."""
+    if w.dim() == 2:
+        return w if w.is_contiguous() else w.contiguous()
+    k, c, r, s = w.shape
+    p = w.permute(0, 2, 3, 1)
+    return p if p.is_contiguous() else p.contiguous()
+
+
+class FrozenBatchNorm2d(nn.Module):
+    """detectron2.layers.FrozenBatchNorm2d (eps 1e-5): buffers only; folded into the conv (scale -> weights, shift -> bias)."""
+
+    def __init__(self, num_features, eps=1e-5):
+        super().__init__()
+        self.num_features, self.eps = num_features, eps
+        self.register_buffer("weight", torch.ones(num_features))
+        self.register_buffer("bias", torch.zeros(num_features))
+        self.register_buffer("running_mean", torch.zeros(num_features))
+        self.register_buffer("running_var", torch.ones(num_features) - eps)
+
+
+class Conv2d(nn.Module):
+    """conv (+ FrozenBN | bias) (+ ReLU / residual) executed by unit_conv2d_fwd / _wgrad.  `cin_pad`: stem pads 3 -> 8."""
+
+    def __init__(self, cin, cout, k, stride=1, pad=0, norm=False, bias=False, cin_pad=None):
+        super().__init__()
+        self.cin, self.cout, self.k, self.stride, self.pad = cin, cout, k, stride, pad
+        self.cin_pad = cin_pad or cin
+        self.weight = nn.Parameter(torch.empty(cout, cin, k, k))
+        nn.init.kaiming_normal_(self.weight, mode="fan_out", nonlinearity="relu")   # fvcore c2_msra_fill
+        self.bias = nn.Parameter(torch.zeros(cout)) if bias else None
+        self.norm = FrozenBatchNorm2d(cout) if norm else None
+        self._prep_key = None
+        self.wf = self.wd = self.scale = self.shift = None
+
+    # -- weight preparation (FrozenBN fold + cast + dgrad re-layout); re-run when the master weights changed
+    def prepare(self, dtype, version, need_dgrad=True):
+        key = (dtype, version if self.weight.requires_grad else -1, self.weight.data_ptr(), need_dgrad)
+        if key == self._prep_key:
+            return
+        if self.norm is not None:
+            self.scale, self.shift = ops.frozen_bn_fold(self.norm.weight, self.norm.bias, self.norm.running_mean,
+                                                        self.norm.running_var, self.norm.eps)
+        else:
+            self.scale, self.shift = None, (self.bias.data if self.bias is not None else None)
+        src = _krsc_storage(self.weight.data)
+        self.wf, self.wd = ops.weight_prep(src, self.scale, self.cout, self.k, self.k, self.cin, self.cin_pad, dtype,
+                                           want_dgrad=need_dgrad, w_fwd=self.wf if self.wf is not None and self.wf.dtype == dtype else None,
+                                           w_dgrad=self.wd if self.wd is not None and self.wd.dtype == dtype else None)
+        self._prep_key = key
+
+    def fwd(self, x, relu=False, residual=None, out_dtype=None, stride=None):
+        st = self.stride if stride is None else stride
+        return ops.conv2d(x, self.wf, self.cout, self.k, self.k, st, self.pad, bias=self.shift, residual=residual, relu=relu,
+                          out_dtype=out_dtype)
+
+    def dgrad(self, dy, in_hw, mask_ref=None, residual=None, stride=None):
+        """d(loss)/d(input) [N,H,W,cin]; 1x1 stride-2: strided scatter into a zeroed full-resolution tensor."""
+        st = self.stride if stride is None else stride
+        if st == 1:
+            return ops.conv2d(dy, self.wd, self.cin, self.k, self.k, 1, self.k - 1 - self.pad, residual=residual, mask_ref=mask_ref)
+        assert self.k == 1, "strided dgrad is only needed for the 1x1 stride-2 convs of C4 ResNets"
+        return ops.conv2d(dy, self.wd, self.cin, 1, 1, 1, 0, residual=residual, mask_ref=mask_ref, scatter=(st, in_hw[0], in_hw[1]))
+
+    def wgrad(self, x, dy, stride=None):
+        if not self.weight.requires_grad:
+            return
+        st = self.stride if stride is None else stride
+        g = self.weight.grad
+        if g is None:
+            g = torch.zeros_like(self.weight.data, memory_format=torch.channels_last)
+            self.weight.grad = g
+        gk = g.permute(0, 2, 3, 1)
+        if not gk.is_contiguous():
+            raise RuntimeError("conv weight .grad must be a channels_last ([K][R][S][C]) tensor")
+        ops.conv2d_wgrad(x, dy, self.cout, self.k, self.k, st, self.pad, scale=self.scale, out=gk)
+        if self.bias is not None and self.bias.requires_grad:
+            if self.bias.grad is None:
+                self.bias.grad = torch.zeros_like(self.bias.data)
+            ops.bias_grad(dy.reshape(-1, dy.shape[-1]), self.cout, out=self.bias.grad)
+
+
+class BottleneckBlock(nn.Module):
+    """detectron2 BottleneckBlock, stride_in_1x1=True, FrozenBN; used by res2..res4 and the Res5 heads."""
+
+    def __init__(self, cin, cout, bottleneck, stride):
+        super().__init__()
+        self.stride = stride
+        self.shortcut = Conv2d(cin, cout, 1, stride, 0, norm=True) if cin != cout else None
+        self.conv1 = Conv2d(cin, bottleneck, 1, stride, 0, norm=True)
+        self.conv2 = Conv2d(bottleneck, bottleneck, 3, 1, 1, norm=True)
+        self.conv3 = Conv2d(bottleneck, cout, 1, 1, 0, norm=True)
+
+    def convs(self):
+        return [c for c in (self.conv1, self.conv2, self.conv3, self.shortcut) if c is not None]
+
+    def fwd(self, x, save=False, stride=None):
+        st = self.stride if stride is None else stride
+        y1 = self.conv1.fwd(x, relu=True, stride=st)
+        y2 = self.conv2.fwd(y1, relu=True)
+        sc = self.shortcut.fwd(x, stride=st) if self.shortcut is not None else x
+        out = self.conv3.fwd(y2, relu=True, residual=sc)
+        return out, ((x, y1, y2, st) if save else None)
+
+    def bwd(self, ctx, g, need_dx=True, mask_input=True):
+        x, y1, y2, st = ctx
+        self.conv3.wgrad(y2, g)
+        dy2 = self.conv3.dgrad(g, y2.shape[1:3], mask_ref=y2)
+        self.conv2.wgrad(y1, dy2)
+        dy1 = self.conv2.dgrad(dy2, y1.shape[1:3], mask_ref=y1)
+        self.conv1.wgrad(x, dy1, stride=st)
+        if self.shortcut is not None:
+            self.shortcut.wgrad(x, g, stride=st)
+        if not need_dx:
+            return None
+        hw = x.shape[1:3]
+        if self.shortcut is not None:
+            dsc = self.shortcut.dgrad(g, hw, stride=st)
+        else:
+            dsc = g
+        return self.conv1.dgrad(dy1, hw, mask_ref=x if mask_input else None, residual=dsc, stride=st)
+
+
+class ResStage(nn.Sequential):
+    def __init__(self, num_blocks, cin, cout, bottleneck, first_stride):
+        blocks = [BottleneckBlock(cin if i == 0 else cout, cout, bottleneck, first_stride if i == 0 else 1) for i in range(num_blocks)]
+        super().__init__(*blocks)
+
+    def fwd(self, x, save=False, first_stride=None):
+        ctxs = []
+        for i, b in enumerate(self):
+            x, c = b.fwd(x, save, stride=first_stride if i == 0 else None)
+            ctxs.append(c)
+        return x, ctxs
+
+    def bwd(self, ctxs, g, need_dx=True, mask_input=True):
+        n = len(self)
+        for i in range(n - 1, -1, -1):
+            first = i == 0
+            g = self[i].bwd(ctxs[i], g, need_dx=(need_dx or not first), mask_input=(mask_input or not first))
+        return g
+
+
+class BasicStem(nn.Module):
+    """detectron2 BasicStem: conv 7x7 s2 p3 + FrozenBN + ReLU + max_pool2d(3,2,1) (frozen: FREEZE_AT >= 1)."""
+
+    def __init__(self, cout=64):
+        super().__init__()
+        self.conv1 = Conv2d(3, cout, 7, 2, 3, norm=True, cin_pad=8)
+
+    def fwd(self, x):
+        return ops.maxpool3x3s2(self.conv1.fwd(x, relu=True))
+
+
+class Linear(nn.Module):
+    """nn.Linear-shaped parameters (weight [out,in], bias [out]); evaluated in fused groups by LinearGroup."""
+
+    def __init__(self, cin, cout):
+        super().__init__()
+        self.in_features, self.out_features = cin, cout
+        self.weight = nn.Parameter(torch.zeros(cout, cin))
+        self.bias = nn.Parameter(torch.zeros(cout))
+
+
+class LinearGroup:
+    """Several Linear layers on the same input evaluated as ONE GEMM with concatenated output columns
+    (padded to a multiple of 8). If the members' parameters are adjacent rows of a FlatStore the fused master weight /
+    grad are zero-copy views; otherwise they are gathered / scattered with small copies."""
+
+    def __init__(self, members):
+        self.members = members
+        for m in members:  # Linear, or a 1x1 Conv2d (weight [out,in,1,1]) such as the RPN predictors
+            if not hasattr(m, "out_features"):
+                m.out_features = m.weight.shape[0]
+        self.cin = members[0].weight.shape[1]
+        self.cols = []
+        c = 0
+        for m in members:
+            self.cols.append(c)
+            c += m.out_features
+        self.k = c
+        self.kp = (c + 7) // 8 * 8
+        self._prep_key = None
+        self.wf = self.wd = self.bias = None
+
+    def _fused_views(self, attr):
+        """(weight_view [kp,cin] or None, bias_view [k] or None) if the members are contiguous in memory."""
+        ts = [getattr(m.weight, attr) if attr == "grad" else m.weight.data for m in self.members]
+        bs = [getattr(m.bias, attr) if attr == "grad" else m.bias.data for m in self.members]
+        if any(t is None for t in ts + bs):
+            return None, None
+        p0 = ts[0].data_ptr()
+        ok = all(t.numel() == self.members[i].out_features * self.cin and t.data_ptr() == p0 + 4 * self.cols[i] * self.cin
+                 for i, t in enumerate(ts))
+        b0 = bs[0].data_ptr()
+        okb = all(b.data_ptr() == b0 + 4 * self.cols[i] for i, b in enumerate(bs))
+        if not (ok and okb):
+            return None, None
+        base = ts[0]
+        try:
+            w = torch.as_strided(base, (self.kp, self.cin), (self.cin, 1))
+            b = torch.as_strided(bs[0], (self.k,), (1,))
+        except RuntimeError:
+            return None, None
+        return w, b
+
+    def prepare(self, dtype, version):
+        trainable = any(m.weight.requires_grad for m in self.members)
+        key = (dtype, version if trainable else -1, self.members[0].weight.data_ptr())
+        if key == self._prep_key:
+            return
+        w, b = self._fused_views("data")
+        if w is None:
+            dev = self.members[0].weight.device
+            w = torch.zeros((self.kp, self.cin), dtype=torch.float32, device=dev)
+            b = torch.zeros((self.k,), dtype=torch.float32, device=dev)
+            for m, c in zip(self.members, self.cols):
+                w[c:c + m.out_features].copy_(m.weight.data.reshape(m.out_features, self.cin))
+                b[c:c + m.out_features].copy_(m.bias.data)
+        self.bias = b
+        self.wf, self.wd = ops.weight_prep(w, None, self.kp, 1, 1, self.cin, self.cin, dtype, w_fwd=self.wf if self.wf is not None and self.wf.dtype == dtype else None,
+                                           w_dgrad=self.wd if self.wd is not None and self.wd.dtype == dtype else None)
+        self._prep_key = key
+
+    def fwd(self, x2d):
+        """x [R,cin] -> fp32 [R,kp]"""
+        r = x2d.shape[0]
+        y = ops.conv2d(x2d.view(r, 1, 1, self.cin), self.wf, self.k, 1, 1, bias=self.bias, out_dtype=torch.float32, ldy=self.kp)
+        return y.view(r, self.kp)
+
+    def bwd(self, x2d, dy2d, need_dx=True, mask_ref=None):
+        """dy [R,kp] (compute dtype, pad columns zero). Writes member .grad; returns dx [R,cin] (* (mask_ref > 0))."""
+        r = x2d.shape[0]
+        gw, gb = self._fused_views("grad")
+        trainable = any(m.weight.requires_grad for m in self.members)
+        if trainable:
+            if gw is not None:
+                ops.conv2d_wgrad(x2d.view(r, 1, 1, self.cin), dy2d.view(r, 1, 1, self.kp), self.kp, 1, 1, out=gw.view(self.kp, 1, 1, self.cin))
+                ops.bias_grad(dy2d, self.k, out=gb)
+            else:
+                tmp = ops.conv2d_wgrad(x2d.view(r, 1, 1, self.cin), dy2d.view(r, 1, 1, self.kp), self.kp, 1, 1).view(self.kp, self.cin)
+                tb = ops.bias_grad(dy2d, self.k)
+                for m, c in zip(self.members, self.cols):
+                    if m.weight.requires_grad:
+                        gw_m = tmp[c:c + m.out_features].reshape(m.weight.shape)
+                        if m.weight.grad is None:
+                            m.weight.grad = gw_m.clone()
+                        else:
+                            m.weight.grad.copy_(gw_m)
+                        if m.bias.grad is None:
+                            m.bias.grad = tb[c:c + m.out_features].clone()
+                        else:
+                            m.bias.grad.copy_(tb[c:c + m.out_features])
+        if not need_dx:
+            return None
+        dx = ops.conv2d(dy2d.view(r, 1, 1, self.kp), self.wd, self.cin, 1, 1,
+                        mask_ref=mask_ref.view(r, 1, 1, self.cin) if mask_ref is not None else None)
+        return dx.view(r, self.cin)

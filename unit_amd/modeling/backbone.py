@@ -1,0 +1,93 @@
+"""ResNet-C4 backbone (stem, res2, res3, res4) -- the MI355X counterpart of detectron2's `build_resnet_backbone`, which the
+reference selects at configs/VOC/VOC-RCNN-101-C4-split1.yaml:6-10 and re-exports at modeling/backbone/backbone.py:10.
+State-dict keys equal Detectron2's (`stem.conv1.weight`, `res4.22.conv3.norm.running_var`, ...)."""
+import torch
+from torch import nn
+
+from .. import ops
+from ..layers import BasicStem, ResStage
+from ..structures import BACKBONE_REGISTRY, ShapeSpec
+
+BLOCKS = {50: [3, 4, 6, 3], 101: [3, 4, 23, 3], 152: [3, 8, 36, 3]}
+
+
+class ResNet(nn.Module):
+    def __init__(self, depth=101, freeze_at=2, res2_out=256, width=64):
+        super().__init__()
+        nb = BLOCKS[depth]
+        self.depth = depth
+        self.stem = BasicStem(64)
+        self.res2 = ResStage(nb[0], 64, res2_out, width, 1)
+        self.res3 = ResStage(nb[1], res2_out, res2_out * 2, width * 2, 2)
+        self.res4 = ResStage(nb[2], res2_out * 2, res2_out * 4, width * 4, 2)
+        self.out_channels = res2_out * 4
+        self.size_divisibility = 0
+        self.freeze_at = freeze_at
+        self.freeze(freeze_at)
+
+    def freeze(self, freeze_at):
+        """detectron2 ResNet.freeze: stem is stage 1, res2 stage 2, ..."""
+        stages = [self.stem, self.res2, self.res3, self.res4]
+        for i, s in enumerate(stages, start=1):
+            if freeze_at >= i:
+                for p in s.parameters():
+                    p.requires_grad = False
+        return self
+
+    def output_shape(self):
+        return {"res4": ShapeSpec(channels=self.out_channels, stride=16)}
+
+    def all_convs(self):
+        cs = [self.stem.conv1]
+        for st in (self.res2, self.res3, self.res4):
+            for b in st:
+                cs += b.convs()
+        return cs
+
+    def prepare(self, dtype, version):
+        for c in self.all_convs():
+            c.prepare(dtype, version, need_dgrad=c.weight.requires_grad)
+
+    def first_trainable_stage(self):
+        for i, st in enumerate((self.res2, self.res3, self.res4)):
+            if any(p.requires_grad for p in st.parameters()):
+                return i
+        return 3
+
+    # ---- explicit forward / backward on NHWC activations
+    def fwd(self, x, save=False):
+        x = self.stem.fwd(x)
+        ft = self.first_trainable_stage()
+        ctx = []
+        for i, st in enumerate((self.res2, self.res3, self.res4)):
+            x, c = st.fwd(x, save=save and i >= ft)
+            ctx.append(c)
+        return x, ctx
+
+    def bwd(self, ctx, g, on_stage_done=None):
+        """g: d(loss)/d(res4 output) already masked by (out > 0). Stops at the first frozen stage (FREEZE_AT)."""
+        ft = self.first_trainable_stage()
+        stages = (self.res2, self.res3, self.res4)
+        for i in (2, 1, 0):
+            if i < ft:
+                break
+            g = stages[i].bwd(ctx[i], g, need_dx=(i > ft), mask_input=True)
+            if on_stage_done is not None:
+                on_stage_done(("res2", "res3", "res4")[i])
+        return None
+
+    # ---- plugin surface: NCHW fp32 in, {"res4": NCHW fp32} out (inference / feature extraction only)
+    def forward(self, x):
+        dtype = getattr(self, "compute_dtype", torch.bfloat16)
+        self.prepare(dtype, 0)
+        xh = ops.nchw_to_nhwc(x, dtype=dtype, cpad=8)
+        y, _ = self.fwd(xh)
+        return {"res4": ops.nhwc_to_nchw(y)}
+
+
+@BACKBONE_REGISTRY.register()
+def build_resnet_backbone(cfg, input_shape=None):
+    r = cfg.MODEL.RESNETS
+    assert r.NORM == "FrozenBN" and r.STRIDE_IN_1X1 and r.NUM_GROUPS == 1, "C4 hot path: FrozenBN, stride_in_1x1, groups=1"
+    assert list(r.OUT_FEATURES) == ["res4"]
+    return ResNet(r.DEPTH, cfg.MODEL.BACKBONE.FREEZE_AT, r.RES2_OUT_CHANNELS, r.WIDTH_PER_GROUP)

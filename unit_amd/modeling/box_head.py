@@ -1,0 +1,66 @@
+"""Res5BoxHead / Res5BoxHeadWithMask -- /root/reference/modeling/roi_heads/box_head.py:47-89,138-141:
+ResNet.make_stage(BottleneckBlock, 3, stride_per_block=[2,1,1], 1024 -> 2048, bottleneck 512, stride_in_1x1) then
+x.mean(dim=[2,3]).  State-dict keys: `res5.{0,1,2}.{conv1,conv2,conv3,shortcut}.{weight,norm.*}`.
+
+`pool_mode="strided"`: the first block's 1x1 stride-2 convs (conv1 AND shortcut, stride_in_1x1) read only every other
+bin of the 14x14 RoIAlign output, so the pooler materialises just those 7x7 bins and the block runs at stride 1 --
+identical results, 4x less RoIAlign traffic. `pool_mode="full"` is the reference-shaped 14x14 path (parity tests)."""
+import torch
+from torch import nn
+
+from .. import ops
+from ..layers import ResStage
+from ..structures import ROI_BOX_HEAD_REGISTRY, ShapeSpec
+
+
+@ROI_BOX_HEAD_REGISTRY.register()
+class Res5BoxHead(nn.Module):
+    do_mean = True
+
+    def __init__(self, cfg=None, input_shape=None):
+        super().__init__()
+        r2 = cfg.MODEL.RESNETS.RES2_OUT_CHANNELS if cfg is not None else 256
+        width = (cfg.MODEL.RESNETS.NUM_GROUPS * cfg.MODEL.RESNETS.WIDTH_PER_GROUP) if cfg is not None else 64
+        self.out_channels = r2 * 8
+        self.res5 = ResStage(3, self.out_channels // 2, self.out_channels, width * 8, 2)
+        if cfg is not None:
+            for name, p in self.named_parameters():   # box_head.py: _freeze_layers by first name component
+                if any(layer == name.split(".")[0] for layer in cfg.MODEL.FREEZE_LAYERS.BOX_HEAD):
+                    p.requires_grad = False
+
+    @property
+    def output_shape(self):
+        return ShapeSpec(channels=self.out_channels, height=1 if self.do_mean else 7, width=1 if self.do_mean else 7)
+
+    def prepare(self, dtype, version):
+        for b in self.res5:
+            for c in b.convs():
+                c.prepare(dtype, version, need_dgrad=True)
+
+    def fwd(self, pooled, save=False):
+        """pooled [R,14,14,C] (full) or [R,7,7,C] (strided) -> ([R,2048] | [R,7,7,2048], ctx)"""
+        first_stride = 1 if pooled.shape[1] == 7 else 2
+        y, ctxs = self.res5.fwd(pooled, save=save, first_stride=first_stride)
+        out = ops.global_avgpool(y) if self.do_mean else y
+        return out, ((ctxs, y) if save else None)
+
+    def bwd(self, ctx, dfeat, row_slice=None):
+        """dfeat: d(loss)/d(features) [R,2048] (mean) -> d(loss)/d(pooled).  row_slice: backprop only these RoI rows."""
+        ctxs, y = ctx
+        if row_slice is not None:
+            y = y[row_slice]
+            ctxs = [tuple(t[row_slice] if torch.is_tensor(t) else t for t in c) for c in ctxs]
+        g = ops.global_avgpool_bwd_relu(dfeat, y) if self.do_mean else dfeat
+        return self.res5.bwd(ctxs, g, need_dx=True, mask_input=False)
+
+    def forward(self, x):
+        """plugin surface (NCHW fp32 [R,1024,14,14] -> [R,2048]); inference only."""
+        dtype = getattr(self, "compute_dtype", torch.bfloat16)
+        self.prepare(dtype, 0)
+        out, _ = self.fwd(ops.nchw_to_nhwc(x, dtype=dtype))
+        return ops.cast(out, torch.float32) if self.do_mean else ops.nhwc_to_nchw(out)
+
+
+@ROI_BOX_HEAD_REGISTRY.register()
+class Res5BoxHeadWithMask(Res5BoxHead):
+    do_mean = False

@@ -1,0 +1,378 @@
+"""WeaklySupervisedRCNNNoMeta -- the MI355X counterpart of /root/reference/modeling/meta_arch/rcnn.py:431-542
+(training `forward` :433-491, `preprocess_image` :257-266, `inference` :493-542, `_postprocess` :411-429).
+
+One training step = ONE explicit forward plan + ONE explicit backward plan over the HIP kernels (no autograd graph, no
+host sync): `forward_train` saves exactly the activations the backward needs, `backward_train` walks them in reverse and
+writes parameter gradients straight into the flat gradient buffer (unit_amd/flat.py). For drop-in use under a
+Detectron2-style trainer (`loss_dict = model(data, weak_batched_inputs=...); sum(loss_dict.values()).backward()`,
+engine/defaults.py:279-283) the plan is exposed to torch.autograd as a single Function node.
+
+Batching: the supervised and the weak images of a step go through the backbone and the RPN head as ONE batch
+(rcnn.py:439,452 run the backbone twice; same arithmetic per image), the supervised and weak RoIs go through RoIAlign
+and `weak_box_head` as ONE batch (roi_heads.py:499-513).
+"""
+import torch
+from torch import nn
+
+from .. import ops
+from ..flat import FlatStore
+from ..structures import (BACKBONE_REGISTRY, META_ARCH_REGISTRY, PROPOSAL_GENERATOR_REGISTRY, ROI_HEADS_REGISTRY, Boxes, ImageList,
+                          Instances)
+
+LOSS_NAMES = ["loss_cls", "loss_box_reg", "loss_im_cls", "loss_oicr_1", "loss_oicr_2", "loss_oicr_3", "loss_rpn_cls", "loss_rpn_loc"]
+
+
+class PackedBatch:
+    """Device-resident, padded form of `batched_inputs` (+ weak) so that the step itself never touches the host."""
+
+    def __init__(self, images, gt_boxes, gt_classes, gt_count, n_sup, multihot=None):
+        self.images = images            # list of CHW fp32 device tensors: supervised first, then weak
+        self.gt_boxes, self.gt_classes, self.gt_count = gt_boxes, gt_classes, gt_count
+        self.n_sup = n_sup
+        self.multihot = multihot        # [n_weak, K] uint8 or None
+
+    @property
+    def n_weak(self):
+        return len(self.images) - self.n_sup
+
+
+class _StepFn(torch.autograd.Function):
+    """Exposes the explicit plan to torch.autograd as one node: forward has already run, backward runs the backward plan."""
+
+    @staticmethod
+    def forward(ctx, anchor, model, step, loss_vec):
+        ctx.model, ctx.step = model, step
+        return loss_vec.view_as(loss_vec)
+
+    @staticmethod
+    def backward(ctx, grad_losses):
+        # every loss enters the total with weight 1 (engine/defaults.py:280 `sum(loss_dict.values())`)
+        ctx.model.backward_train(ctx.step)
+        return torch.zeros(1, device=grad_losses.device), None, None, None
+
+
+@META_ARCH_REGISTRY.register()
+class WeaklySupervisedRCNNNoMeta(nn.Module):
+    def __init__(self, cfg, thing_classes=None):
+        super().__init__()
+        self.cfg = cfg
+        self.backbone = BACKBONE_REGISTRY.get(cfg.MODEL.BACKBONE.NAME)(cfg)
+        shape = self.backbone.output_shape()
+        self.proposal_generator = PROPOSAL_GENERATOR_REGISTRY.get(cfg.MODEL.PROPOSAL_GENERATOR.NAME)(cfg, shape)
+        self.roi_heads = ROI_HEADS_REGISTRY.get(cfg.MODEL.ROI_HEADS.NAME)(cfg, shape, thing_classes)
+        self.register_buffer("pixel_mean", torch.tensor(cfg.MODEL.PIXEL_MEAN).view(-1, 1, 1), persistent=False)
+        self.register_buffer("pixel_std", torch.tensor(cfg.MODEL.PIXEL_STD).view(-1, 1, 1), persistent=False)
+        self._pixel_mean, self._pixel_std = list(cfg.MODEL.PIXEL_MEAN), list(cfg.MODEL.PIXEL_STD)
+        self.normalize_images = cfg.INPUT.NORMALIZE_IMAGES
+        self.num_classes = cfg.MODEL.ROI_HEADS.NUM_CLASSES
+        for name, p in self.named_parameters():   # rcnn.py:250-255
+            if any(layer == name.split(".")[0] for layer in cfg.MODEL.FREEZE_LAYERS.META_ARCH):
+                p.requires_grad = False
+        self.compute_dtype = torch.bfloat16
+        self.version = 0          # bumped by the optimizer: layers re-fold / re-cast their weights when it changes
+        self.store = None
+        self._anchor = None
+        self._gen = None
+        self.on_grad_ready = None  # data-parallel hook: called with a stage name as soon as its gradients are final
+
+    @property
+    def device(self):
+        return self.pixel_mean.device
+
+    # ------------------------------------------------------------------ parameters
+    def trainable_order(self):
+        """(name, param) in the order gradients become final during backward (bucket order for data parallelism)."""
+        rh, bp = self.roi_heads, self.roi_heads.box_predictor
+        groups = []   # list of (tag, [(name, param, pad_after)], reserve_numel)
+
+        def fused(tag, prefix, group):
+            ws = [(f"{prefix}.{n}.weight", m.weight) for n, m in group]
+            bs = [(f"{prefix}.{n}.bias", m.bias) for n, m in group]
+            if not all(p.requires_grad for _, p in ws + bs):
+                return
+            lg_k = sum(m.weight.shape[0] for _, m in group)
+            kp = (lg_k + 7) // 8 * 8
+            cin = group[0][1].weight.shape[1]
+            groups.append((tag, [(n, p, False) for n, p in ws], (kp - lg_k) * cin))
+            groups.append((tag, [(n, p, False) for n, p in bs], 0))
+
+        if getattr(bp, "finetune", False):
+            fused("heads", "roi_heads.box_predictor", [("cls_score_ft", bp.cls_score_ft), ("bbox_pred_ft", bp.bbox_pred_ft)])
+        fused("heads", "roi_heads.box_predictor", [("cls_score_delta", bp.cls_score_delta), ("bbox_pred_delta", bp.bbox_pred_delta)])
+        wh = bp.weak_detector_head
+        fused("heads", "roi_heads.box_predictor.weak_detector_head",
+              [("classifier_stream", wh.classifier_stream), ("detection_stream", wh.detection_stream)] +
+              [(f"oicr_predictors.{i}", m) for i, m in enumerate(wh.oicr_predictors)])
+
+        def stage(tag, prefix, st):
+            items = []
+            for i in range(len(st) - 1, -1, -1):
+                b = st[i]
+                for cn in ("conv3", "conv2", "conv1", "shortcut"):
+                    c = getattr(b, cn)
+                    if c is not None and c.weight.requires_grad:
+                        items.append((f"{prefix}.{i}.{cn}.weight", c.weight, True))
+            if items:
+                groups.append((tag, items, 0))
+
+        stage("box_head", "roi_heads.box_head.res5", rh.box_head.res5)
+        if rh.weak_box_head is not None:
+            stage("weak_box_head", "roi_heads.weak_box_head.res5", rh.weak_box_head.res5)
+        h = self.proposal_generator.rpn_head
+        fused("rpn", "proposal_generator.rpn_head", [("objectness_logits", h.objectness_logits), ("anchor_deltas", h.anchor_deltas)])
+        if h.conv.weight.requires_grad:
+            groups.append(("rpn", [("proposal_generator.rpn_head.conv.weight", h.conv.weight, True),
+                                   ("proposal_generator.rpn_head.conv.bias", h.conv.bias, True)], 0))
+        stage("res4", "backbone.res4", self.backbone.res4)
+        stage("res3", "backbone.res3", self.backbone.res3)
+        stage("res2", "backbone.res2", self.backbone.res2)
+        return groups
+
+    def flatten_parameters(self):
+        """Moves all trainable parameters into one flat fp32 buffer (+ flat grads); idempotent; call after .to(device)."""
+        dev = self.device
+        store = FlatStore(dev)
+        store.tags = []   # (tag, start, end) ranges for the data-parallel buckets
+        seen = set()
+        for tag, items, reserve in self.trainable_order():
+            start = store.size
+            for name, p, pad_after in items:
+                store.add(name, p, pad_after=pad_after)
+                seen.add(id(p))
+            if reserve:
+                store.reserve(reserve)
+            store.pad()
+            store.tags.append((tag, start, store.size))
+        missing = [n for n, p in self.named_parameters() if p.requires_grad and id(p) not in seen]
+        if missing:
+            raise RuntimeError(f"trainable parameters without a slot in the backward plan: {missing[:5]}")
+        store.materialize()
+        self.store = store
+        self.version += 1
+        return store
+
+    def _ensure_ready(self):
+        if self.training and (self.store is None or not self.store.is_current()):
+            self.flatten_parameters()
+        dt, v = self.compute_dtype, self.version
+        self.backbone.prepare(dt, v)
+        self.proposal_generator.rpn_head.prepare(dt, v)
+        self.roi_heads.prepare(dt, v)
+
+    # ------------------------------------------------------------------ inputs
+    def pack_batch(self, batched_inputs, weak_batched_inputs=None):
+        dev = self.device
+        sup = batched_inputs or []
+        weak = weak_batched_inputs or []
+        images = [x["image"].to(dev, non_blocking=True).float() for x in list(sup) + list(weak)]
+        n = len(sup)
+        gtb, gtc = [], []
+        for x in sup:
+            inst = x["instances"]
+            b = inst.gt_boxes.tensor if hasattr(inst.gt_boxes, "tensor") else inst.gt_boxes
+            gtb.append(b)
+            gtc.append(inst.gt_classes)
+        mcap = max([len(b) for b in gtb] + [1])
+        mcap = (mcap + 7) // 8 * 8
+        gt_boxes = torch.zeros((max(n, 1), mcap, 4), dtype=torch.float32)
+        gt_classes = torch.zeros((max(n, 1), mcap), dtype=torch.int64)
+        for i in range(n):
+            gt_boxes[i, : len(gtb[i])] = gtb[i].float().cpu() if gtb[i].is_cuda else gtb[i].float()
+            gt_classes[i, : len(gtc[i])] = gtc[i].cpu() if gtc[i].is_cuda else gtc[i]
+        gt_count = torch.tensor([len(b) for b in gtb] or [0], dtype=torch.int32)
+        multihot = None
+        if weak:
+            multihot = torch.zeros((len(weak), self.num_classes), dtype=torch.uint8)
+            for i, x in enumerate(weak):
+                c = x["instances"].gt_classes if "instances" in x else x["gt_classes"]
+                multihot[i, c.long().cpu()] = 1     # torch.unique(gt_classes) (weak_detector_fast_rcnn.py:203)
+            multihot = multihot.to(dev, non_blocking=True)
+        return PackedBatch(images, gt_boxes.to(dev, non_blocking=True), gt_classes.to(dev, non_blocking=True),
+                           gt_count.to(dev, non_blocking=True), n, multihot)
+
+    def preprocess_image(self, batched_inputs):
+        """rcnn.py:257-266 -> ImageList(NHWC tensor with channels padded to 8, image_sizes)."""
+        imgs = [x["image"].to(self.device).float() if isinstance(x, dict) else x for x in batched_inputs]
+        t, sizes = ops.preprocess_images(imgs, self._pixel_mean, self._pixel_std, self.compute_dtype, 8, self.normalize_images)
+        return ImageList(t, sizes)
+
+    def sampling_permutations(self, n_sup, n_anchor, n_roi_cap):
+        """RNG for subsample_labels: one permutation per image and per sampler (explicit-permutation contract)."""
+        if self._gen is None:
+            self._gen = torch.Generator(device=self.device)
+            seed = self.cfg.SEED if self.cfg.SEED >= 0 else 0
+            rank = torch.distributed.get_rank() if torch.distributed.is_available() and torch.distributed.is_initialized() else 0
+            self._gen.manual_seed(seed + rank)
+        rpn = torch.stack([torch.randperm(n_anchor, device=self.device, generator=self._gen) for _ in range(n_sup)]).int()
+        roi = torch.stack([torch.randperm(n_roi_cap, device=self.device, generator=self._gen) for _ in range(n_sup)]).int()
+        return {"rpn": rpn, "roi": roi}
+
+    # ------------------------------------------------------------------ the training step: forward plan
+    def forward_train(self, batch, perms=None):
+        """-> step context (holds `losses` fp32[8] on the device and everything backward_train needs)."""
+        self._ensure_ready()
+        rpn, rh, bp = self.proposal_generator, self.roi_heads, self.roi_heads.box_predictor
+        dt = self.compute_dtype
+        c = type("StepCtx", (), {})()
+        n_sup, n_weak = batch.n_sup, batch.n_weak
+        n_img = n_sup + n_weak
+        c.n_sup, c.n_weak = n_sup, n_weak
+        c.losses = torch.zeros(len(LOSS_NAMES), dtype=torch.float32, device=self.device)
+
+        # a1 preprocess + a2 backbone (supervised + weak images as one batch; both with grad: rcnn.py:439,452)
+        x, sizes = ops.preprocess_images(batch.images, self._pixel_mean, self._pixel_std, dt, 8, self.normalize_images)
+        c.image_sizes = sizes
+        feat, c.bb_ctx = self.backbone.fwd(x, save=True)
+        c.feat = feat
+        n, fh, fw, fc = feat.shape
+        anchors = rpn.anchor_generator.grid(fh, fw)
+
+        # a3 RPN head on all images; a4/a5 labels + loss on the supervised ones; a6 proposals for all (no grad)
+        head, c.rpn_ctx = rpn.rpn_head.fwd(feat, save=True)
+        if perms is None:
+            perms = self.sampling_permutations(n_sup, anchors.shape[0], rpn.post_nms_topk[True] + batch.gt_boxes.shape[1])
+        c.dhead = None
+        if n_sup > 0:
+            c.anchor_labels, c.anchor_match, _ = rpn.label_and_sample_anchors(anchors, batch.gt_boxes, batch.gt_count, perms["rpn"])
+            _, c.dhead = ops.rpn_loss(head[:n_sup], rpn.num_anchors, rpn.num_anchors, c.anchor_labels, c.anchor_match, batch.gt_boxes,
+                                      anchors, rpn.batch_size_per_image * n_sup, dt, loss_out=c.losses[6:8])
+        hw = torch.tensor(sizes, dtype=torch.float32).to(self.device, non_blocking=True)
+        props, pscores, pcount = rpn.predict_proposals(head, anchors, hw, True)
+        c.proposals = (props, pscores, pcount)
+
+        # a7 RoI sampling (supervised) + first-512 weak proposals ; a8 RoIAlign on all RoIs at once
+        s = rh.batch_size_per_image
+        rois, c.roi_cls, c.roi_gt = [], None, None
+        if n_sup > 0:
+            r5, c.roi_cls, c.roi_gt, c.roi_counts = rh.label_and_sample_proposals(props[:n_sup], pcount[:n_sup], batch.gt_boxes,
+                                                                                  batch.gt_classes, batch.gt_count, perms["roi"])
+            rois.append(r5)
+        if n_weak > 0:
+            rw5, c.weak_valid = rh.weak_rois(props[n_sup:], pcount[n_sup:], n_sup)
+            rois.append(rw5)
+        c.rois = torch.cat(rois, 0) if len(rois) > 1 else rois[0]
+        rs = n_sup * s
+        rw = c.rois.shape[0] - rs
+        c.rs, c.rw = rs, rw
+        pooled = rh.pool(feat, c.rois)
+
+        # a9 Res5 heads: box_head on the supervised RoIs (grad); weak_box_head on ALL RoIs in one pass -- its supervised
+        # half is the reference's no_grad evaluation (roi_heads.py:502-504), its weak half has grad (:512-513)
+        multi = rh.weak_box_head is not None
+        box_trainable = any(p.requires_grad for p in rh.box_head.parameters())
+        if multi:
+            c.box_feat, c.box_ctx = rh.box_head.fwd(pooled[:rs], save=box_trainable) if rs > 0 else (None, None)
+            wfeat_all, c.weak_ctx = rh.weak_box_head.fwd(pooled, save=(rw > 0))
+            sup_weak_feat, weak_feat = wfeat_all[:rs], wfeat_all[rs:]
+        else:
+            feat_all, c.box_ctx = rh.box_head.fwd(pooled, save=box_trainable)
+            c.box_feat, weak_feat = feat_all[:rs], feat_all[rs:]
+            sup_weak_feat, c.weak_ctx = c.box_feat, None
+            wfeat_all = feat_all
+        c.weak_feat = weak_feat
+
+        # a10-a12 predictors + losses (+ gradients w.r.t. the Linear outputs)
+        lin_weak_all = bp.weak_detector_head.group.fwd(wfeat_all)            # [rs+rw, 104] (oicr cols feed the sup scores)
+        c.dy_sup = c.dy_weak = None
+        if rs > 0:
+            lin_sup = bp.group.fwd(c.box_feat)
+            if getattr(bp, "finetune", False):
+                raise NotImplementedError("fine-tune predictor runs through forward_finetune")
+            c.dy_sup, c.scores = bp.sup_losses(lin_sup, lin_weak_all[:rs], c.roi_cls, c.rois[:rs], c.roi_gt, c.losses[0:2], dt)
+        if rw > 0:
+            c.dy_weak = bp.weak_detector_head.losses(lin_weak_all[rs:], c.rois[rs:], c.weak_valid, s // rh.weak_divisor, n_weak,
+                                                     batch.multihot, c.losses[2:6], dt)
+        return c
+
+    # ------------------------------------------------------------------ the training step: backward plan
+    def backward_train(self, c):
+        rpn, rh, bp = self.proposal_generator, self.roi_heads, self.roi_heads.box_predictor
+        dt = self.compute_dtype
+        self._reattach_grads()
+        rs, rw, n_sup = c.rs, c.rw, c.n_sup
+        multi = rh.weak_box_head is not None
+        done = self.on_grad_ready or (lambda tag: None)
+        feat = c.feat
+        dfeat32 = torch.zeros(feat.shape, dtype=torch.float32, device=feat.device)
+        bb_trainable = self.backbone.first_trainable_stage() < 3
+        box_trainable = c.box_ctx is not None
+
+        dbox = dweak = None
+        if c.dy_sup is not None:
+            dbox = bp.group.bwd(c.box_feat, c.dy_sup, need_dx=box_trainable or bb_trainable)
+        if c.dy_weak is not None:
+            dweak = bp.weak_detector_head.group.bwd(c.weak_feat, c.dy_weak, need_dx=True)
+        done("heads")
+        if multi:
+            if dbox is not None and box_trainable:
+                dpool = rh.box_head.bwd(c.box_ctx, dbox)
+                done("box_head")
+                if bb_trainable:
+                    rh.pool_bwd(dpool, feat.shape, c.rois[:rs], dfeat32)
+            if dweak is not None:
+                dpool_w = rh.weak_box_head.bwd(c.weak_ctx, dweak, row_slice=slice(rs, rs + rw))
+                done("weak_box_head")
+                if bb_trainable:
+                    rh.pool_bwd(dpool_w, feat.shape, c.rois[rs:], dfeat32)
+        else:
+            parts = [t for t in (dbox, dweak) if t is not None]
+            dall = torch.cat(parts, 0) if len(parts) > 1 else parts[0]
+            dpool = rh.box_head.bwd(c.box_ctx, dall)
+            done("box_head")
+            if bb_trainable:
+                rh.pool_bwd(dpool, feat.shape, c.rois, dfeat32)
+
+        drpn = None
+        if c.dhead is not None and any(p.requires_grad for p in rpn.rpn_head.parameters()):
+            drpn = rpn.rpn_head.bwd(c.rpn_ctx, c.dhead, n_sup)
+            done("rpn")
+        if bb_trainable:
+            g = torch.empty_like(feat)
+            if n_sup > 0:
+                ops.add_cast(dfeat32[:n_sup], drpn, dt, mask_ref=feat[:n_sup], out=g[:n_sup])
+            if feat.shape[0] > n_sup:
+                ops.add_cast(dfeat32[n_sup:], None, dt, mask_ref=feat[n_sup:], out=g[n_sup:])
+            self.backbone.bwd(c.bb_ctx, g, on_stage_done=done)
+
+    def _reattach_grads(self):
+        """optimizer.zero_grad(set_to_none=True) drops .grad: point them at the flat gradient buffer again."""
+        st = self.store
+        if st is None:
+            return
+        for e in st.entries:
+            p = e["param"]
+            if p.requires_grad and p.grad is None:
+                p.grad = st._view(st.grads, e["offset"], p)
+
+    # ------------------------------------------------------------------ plugin surface
+    def forward(self, batched_inputs, weak_batched_inputs=None, return_similarity=False, train_only_weak=False, perms=None):
+        if not self.training:
+            return self.inference(batched_inputs, return_similarity=return_similarity)
+        if train_only_weak:
+            raise NotImplementedError("train_only_weak is not used by TrainerNoMeta / TrainerFineTune (engine/defaults.py:279,454)")
+        batch = batched_inputs if isinstance(batched_inputs, PackedBatch) else self.pack_batch(batched_inputs, weak_batched_inputs)
+        step = self.forward_train(batch, perms)
+        if self._anchor is None or self._anchor.device != self.device:
+            self._anchor = torch.zeros(1, device=self.device, requires_grad=True)
+        lv = _StepFn.apply(self._anchor, self, step, step.losses)
+        names = LOSS_NAMES if batch.n_weak > 0 else [n for n in LOSS_NAMES if not (n.startswith("loss_oicr") or n == "loss_im_cls")]
+        return {n: lv[LOSS_NAMES.index(n)] for n in names}
+
+    def train_step(self, batch, optimizer=None, perms=None):
+        """forward + backward (+ optimizer) without going through torch.autograd; returns the device loss vector."""
+        step = self.forward_train(batch, perms)
+        self.backward_train(step)
+        if optimizer is not None:
+            optimizer.step()
+        return step.losses
+
+    def inference(self, batched_inputs, detected_instances=None, do_postprocess=True, return_similarity=False):
+        from .inference import inference as _inf
+        return _inf(self, batched_inputs, do_postprocess)
+
+
+def build_model(cfg, thing_classes=None):
+    """detectron2.modeling.build_model: META_ARCH_REGISTRY lookup + .to(cfg.MODEL.DEVICE)."""
+    model = META_ARCH_REGISTRY.get(cfg.MODEL.META_ARCHITECTURE)(cfg, thing_classes)
+    model.to(torch.device(cfg.MODEL.DEVICE))
+    return model

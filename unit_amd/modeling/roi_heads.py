@@ -1,0 +1,108 @@
+"""ROI heads -- MI355X counterparts of WSROIHeadNoMeta (/root/reference/modeling/roi_heads/roi_heads.py:489-591) and
+WSROIHeadFineTune (:594-644), plus the Detectron2 `label_and_sample_proposals` they inherit.
+
+Module / parameter names equal the reference's: `box_head`, `weak_box_head` (iff MULTI_BOX_HEAD), `box_predictor`.
+The whole RoI stage is sync-free: proposal / RoI counts stay in device int32 arrays, RoIs live in fixed 512-per-image
+slots (empty slots carry class -1 and contribute neither loss nor gradient)."""
+import numpy as np
+import torch
+from torch import nn
+
+from .. import ops
+from ..structures import FAST_RCNN_REGISTRY, ROI_BOX_HEAD_REGISTRY, ROI_HEADS_REGISTRY, ShapeSpec
+
+VOC_CLASSES = ["aeroplane", "bicycle", "bird", "boat", "bottle", "bus", "car", "cat", "chair", "cow", "diningtable", "dog",
+               "horse", "motorbike", "person", "pottedplant", "sheep", "sofa", "train", "tvmonitor"]
+_COCO = ['person', 'bicycle', 'car', 'motorcycle', 'airplane', 'bus', 'train', 'truck', 'boat', 'traffic light', 'fire hydrant',
+         'stop sign', 'parking meter', 'bench', 'bird', 'cat', 'dog', 'horse', 'sheep', 'cow', 'elephant', 'bear', 'zebra',
+         'giraffe', 'backpack', 'umbrella', 'handbag', 'tie', 'suitcase', 'frisbee', 'skis', 'snowboard', 'sports ball', 'kite',
+         'baseball bat', 'baseball glove', 'skateboard', 'surfboard', 'tennis racket', 'bottle', 'wine glass', 'cup', 'fork',
+         'knife', 'spoon', 'bowl', 'banana', 'apple', 'sandwich', 'orange', 'broccoli', 'carrot', 'hot dog', 'pizza', 'donut',
+         'cake', 'chair', 'couch', 'potted plant', 'bed', 'dining table', 'toilet', 'tv', 'laptop', 'mouse', 'remote', 'keyboard',
+         'cell phone', 'microwave', 'oven', 'toaster', 'sink', 'refrigerator', 'book', 'clock', 'vase', 'scissors', 'teddy bear',
+         'hair drier', 'toothbrush']
+_VOC2COCO = {'aeroplane': 'airplane', 'diningtable': 'dining table', 'motorbike': 'motorcycle', 'pottedplant': 'potted plant',
+             'sofa': 'couch', 'tvmonitor': 'tv'}
+
+
+def coco_indexer(thing_classes):
+    """WSROIHead._class_mappings roi_heads.py:190-216: index of each dataset class in the 80-row GloVe table."""
+    idx = {n: i for i, n in enumerate(_COCO)}
+    return [idx[_VOC2COCO.get(n, n)] for n in thing_classes]
+
+
+@ROI_HEADS_REGISTRY.register()
+class WSROIHeadNoMeta(nn.Module):
+    finetune = False
+
+    def __init__(self, cfg, input_shape=None, thing_classes=None):
+        super().__init__()
+        rh = cfg.MODEL.ROI_HEADS
+        self.num_classes = rh.NUM_CLASSES
+        self.batch_size_per_image, self.positive_fraction = rh.BATCH_SIZE_PER_IMAGE, rh.POSITIVE_FRACTION
+        self.iou_thresholds, self.iou_labels = list(rh.IOU_THRESHOLDS), list(rh.IOU_LABELS)
+        self.proposal_append_gt = rh.PROPOSAL_APPEND_GT
+        self.weak_divisor = rh.WEAK_CLASSIFIER_PROPOSAL_DIVISOR
+        self.pooler_resolution = cfg.MODEL.ROI_BOX_HEAD.POOLER_RESOLUTION
+        self.pooler_scale = 1.0 / 16
+        self.sampling_ratio = cfg.MODEL.ROI_BOX_HEAD.POOLER_SAMPLING_RATIO
+        assert cfg.MODEL.ROI_BOX_HEAD.POOLER_TYPE == "ROIAlignV2"
+        self.mask_on = cfg.MODEL.MASK_ON
+        self.pool_mode = "strided"   # "full": materialise all 14x14 bins like the reference (parity tests)
+        in_ch = input_shape["res4"].channels if input_shape else 1024
+        pooled = ShapeSpec(channels=in_ch, height=self.pooler_resolution, width=self.pooler_resolution)
+        self.box_head = ROI_BOX_HEAD_REGISTRY.get(cfg.MODEL.ROI_BOX_HEAD.NAME)(cfg, pooled)
+        self.weak_box_head = ROI_BOX_HEAD_REGISTRY.get(cfg.MODEL.ROI_BOX_HEAD.NAME)(cfg, pooled) if rh.MULTI_BOX_HEAD else None
+        self.box_predictor = FAST_RCNN_REGISTRY.get(rh.FAST_RCNN.NAME)(cfg, self.box_head.output_shape)
+        self._base_classes = list(cfg.DATASETS.FEWSHOT.BASE_CLASSES_ID)
+        self._novel_classes = list(cfg.DATASETS.FEWSHOT.NOVEL_CLASSES_ID)
+        self.terms = {"cls": list(rh.FINETUNE_TERMS.CLASSIFIER), "bbox": list(rh.FINETUNE_TERMS.BBOX)}
+        self.visual_threshold = rh.VISUAL_ATTENTION_HEAD.VISUAL_SIMILARITY_THRESHOLD
+        thing_classes = thing_classes or (VOC_CLASSES if self.num_classes == 20 else _COCO[: self.num_classes])
+        self._coco_indexer = coco_indexer(thing_classes)
+        for name, p in self.named_parameters():   # roi_heads.py:166-171
+            if any(layer == name.split(".")[0] for layer in cfg.MODEL.FREEZE_LAYERS.ROI_HEADS):
+                p.requires_grad = False
+
+    def prepare(self, dtype, version):
+        self.box_head.prepare(dtype, version)
+        if self.weak_box_head is not None:
+            self.weak_box_head.prepare(dtype, version)
+        self.box_predictor.prepare(dtype, version)
+
+    @property
+    def pool_out(self):
+        return (7, 2) if self.pool_mode == "strided" else (self.pooler_resolution, 1)
+
+    # ---- a7: ROIHeads.label_and_sample_proposals (roi_heads.py:563), device-resident counts
+    def label_and_sample_proposals(self, props, pcount, gt_boxes, gt_classes, gt_count, perm):
+        """props [B,P,4], pcount [B]; gt_* padded [B,Mcap,..]; perm [B, >= P+Mcap] int32.
+        -> rois5 [B*S,5], roi_cls int32 [B*S] (-1 = empty slot), roi_gt [B*S,4], counts [B,2]"""
+        if self.proposal_append_gt:
+            cat, cc = ops.append_gt(props, pcount, gt_boxes, gt_count)
+        else:
+            cat, cc = props, pcount
+        idx, lab, _ = ops.iou_match(gt_boxes, gt_count, cat, cc, self.iou_thresholds, self.iou_labels, False, want_vals=False)
+        cls = ops.roi_classes(idx, lab, cc, gt_classes, gt_count, self.num_classes)
+        _, sidx, counts = ops.subsample_labels(cls, cc, perm, self.batch_size_per_image, self.positive_fraction, self.num_classes,
+                                               want_labels=False)
+        rois5, roi_cls, roi_gt = ops.gather_rois(cat, sidx, cls, idx, gt_boxes, gt_count)
+        return rois5, roi_cls, roi_gt, counts
+
+    # ---- roi_heads.py:566-572: the first 512//divisor RPN outputs of every weak image, no GT, no sampling
+    def weak_rois(self, props, pcount, batch_index_offset):
+        return ops.first_k_rois(props, pcount, self.batch_size_per_image // self.weak_divisor, batch_index_offset)
+
+    def pool(self, feat, rois5):
+        out, step = self.pool_out
+        return ops.roi_align(feat, rois5, self.pooler_resolution, out, step, self.pooler_scale, self.sampling_ratio, True)
+
+    def pool_bwd(self, dpooled, feat_shape, rois5, dfeat32):
+        _, step = self.pool_out
+        return ops.roi_align_bwd(dpooled, feat_shape, rois5, dfeat32, self.pooler_resolution, step, self.pooler_scale,
+                                 self.sampling_ratio, True)
+
+
+@ROI_HEADS_REGISTRY.register()
+class WSROIHeadFineTune(WSROIHeadNoMeta):
+    finetune = True

@@ -89,9 +89,10 @@ def cast(x, dtype):
     return y
 
 
-def add_cast(a32, b, dtype):
-    y = torch.empty(a32.shape, dtype=dtype, device=a32.device)
-    check(lib().unit_add_cast(_p(a32), _p(b), _p(y), dt(dtype), a32.numel(), _s()), "add_cast")
+def add_cast(a32, b, dtype, mask_ref=None, out=None):
+    """y = cast((a32 [+ b]) [* (mask_ref > 0)])"""
+    y = out if out is not None else torch.empty(a32.shape, dtype=dtype, device=a32.device)
+    check(lib().unit_add_cast(_p(a32), _p(b), _p(mask_ref), _p(y), dt(dtype), a32.numel(), _s()), "add_cast")
     return y
 
 
@@ -234,6 +235,21 @@ def pairwise_iou(b1, b2):
     return out
 
 
+def match_matrix(q, thresholds, labels, allow_low_quality):
+    """Matcher.__call__ on an [M,N] quality matrix (modeling/matcher.py:54-98) -> (idx int64, label int8, val fp32)"""
+    m, n = q.shape
+    dev = q.device
+    idx = torch.empty((n,), dtype=torch.int64, device=dev)
+    lab = torch.empty((n,), dtype=torch.int8, device=dev)
+    val = torch.empty((n,), dtype=torch.float32, device=dev)
+    ws = torch.empty((max(m, 1),), dtype=torch.float32, device=dev)
+    th = (ctypes.c_float * len(thresholds))(*thresholds)
+    lb = (ctypes.c_int * len(labels))(*labels)
+    check(lib().unit_match_matrix(_p(q.contiguous()), m, n, th, lb, len(thresholds), int(allow_low_quality), _p(idx), _p(lab), _p(val),
+                                  _p(ws), _s()), "match_matrix")
+    return idx, lab, val
+
+
 def subsample_labels(labels, count, perm, num_samples, positive_fraction, bg_label, want_labels=True, want_idx=True):
     """labels [B,Ncap] int8|int64 ; perm [B,Pcap] int32 -> (out_labels int8 [B,Ncap], sampled_idx int32 [B,S], counts [B,2])"""
     b, ncap = labels.shape
@@ -369,10 +385,10 @@ def roi_align_bwd(gout, feat_shape, rois, dfeat32=None, pooled_size=14, bin_step
 
 
 # ------------------------------------------------------------------------------------------------ losses
-def rpn_loss(head, a, dcol0, labels, match_idx, gt_boxes, anchors, normalizer, grad_dtype, gscale=1.0):
+def rpn_loss(head, a, dcol0, labels, match_idx, gt_boxes, anchors, normalizer, grad_dtype, gscale=1.0, loss_out=None):
     b, hw, ld = head.shape
     ncap = anchors.shape[0]
-    loss2 = torch.empty(2, dtype=torch.float32, device=head.device)
+    loss2 = loss_out if loss_out is not None else torch.empty(2, dtype=torch.float32, device=head.device)
     dhead = torch.empty((b, hw, ld), dtype=grad_dtype, device=head.device)
     check(lib().unit_rpn_loss(_p(head), ld, a, dcol0, _p(labels), _p(match_idx), _p(gt_boxes), gt_boxes.shape[1], _p(anchors), b, ncap,
                               float(normalizer), float(gscale), _p(loss2), _p(dhead), dt(grad_dtype), _s()), "rpn_loss")

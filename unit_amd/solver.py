@@ -1,0 +1,80 @@
+"""Optimizer + LR schedule for the flat parameter store.
+
+FlatSGD reproduces the hyper-parameter rules of /root/reference/solver/build.py:61-114 (`build_optimizer_C4`:
+per-name LR factors REFINEMENT/MIL/DELTA, bias LR factor / weight decay) on top of torch.optim.SGD's update
+(momentum, no dampening, no nesterov), executed by the fused `unit_sgd_momentum` kernel: one launch per contiguous
+hyper-parameter segment of the flat buffer instead of one per tensor."""
+import bisect
+
+import torch
+
+from . import ops
+
+
+def hyper_for(cfg, name):
+    s = cfg.SOLVER
+    lr_mult, wd = 1.0, s.WEIGHT_DECAY
+    module_name = name.rsplit(".", 1)[0]
+    if name.endswith(".bias"):
+        lr_mult *= s.BIAS_LR_FACTOR
+        wd = s.WEIGHT_DECAY_BIAS
+    if "oicr_predictors" in module_name or "regression_branch" in module_name:
+        lr_mult *= s.REFINEMENT_LR_FACTOR
+    if "classifier_stream" in module_name or "detection_stream" in module_name:
+        lr_mult *= s.MIL_LR_FACTOR
+    if "cls_score_delta" in module_name or "bbox_pred_delta" in module_name:
+        lr_mult *= s.DELTA_LR_FACTOR
+    return (lr_mult, wd)
+
+
+class WarmupMultiStepLR:
+    """detectron2.solver.WarmupMultiStepLR (linear warm-up) as a pure function of the iteration."""
+
+    def __init__(self, cfg):
+        s = cfg.SOLVER
+        self.base_lr, self.steps, self.gamma = s.BASE_LR, sorted(s.STEPS), s.GAMMA
+        self.warmup_iters, self.warmup_factor = s.WARMUP_ITERS, s.WARMUP_FACTOR
+
+    def __call__(self, it):
+        f = 1.0
+        if it < self.warmup_iters:
+            alpha = it / self.warmup_iters
+            f = self.warmup_factor * (1 - alpha) + alpha
+        return self.base_lr * f * self.gamma ** bisect.bisect_right(self.steps, it)
+
+
+class FlatSGD:
+    def __init__(self, model, cfg, lr_schedule=None, grad_scale=1.0):
+        self.model, self.cfg = model, cfg
+        self.momentum = cfg.SOLVER.MOMENTUM
+        assert not cfg.SOLVER.NESTEROV
+        self.schedule = lr_schedule or WarmupMultiStepLR(cfg)
+        self.iter = 0
+        self.grad_scale = grad_scale
+        self._store = None
+        self._segments = None
+        self._buf = None
+
+    def _bind(self):
+        st = self.model.store
+        if st is None or not st.is_current():
+            st = self.model.flatten_parameters()
+        if st is not self._store:
+            self._store = st
+            self._segments = st.segments(lambda n, p: hyper_for(self.cfg, n))
+            self._buf = torch.zeros_like(st.params)
+            self._first = True
+        return st
+
+    def zero_grad(self, set_to_none=False):
+        pass   # wgrad kernels overwrite the flat gradient buffer every step
+
+    def step(self):
+        st = self._bind()
+        lr = self.schedule(self.iter)
+        for off, n, (lr_mult, wd) in self._segments:
+            ops.sgd_momentum(st.params[off:off + n], st.grads[off:off + n], self._buf[off:off + n], lr * lr_mult, self.momentum, wd,
+                             self.grad_scale, first_step=self._first)
+        self._first = False
+        self.iter += 1
+        self.model.version += 1

@@ -1,0 +1,128 @@
+"""Minimal stand-ins for detectron2.structures.{Boxes, Instances, ImageList} and detectron2.utils.registry.Registry
+with the attribute names the reference's plugin code uses (detectron2 is absent on the GPU box).
+They are plain containers -- no arithmetic lives here."""
+import torch
+
+
+class Registry:
+    def __init__(self, name):
+        self._name, self._map = name, {}
+
+    def register(self, obj=None):
+        def deco(o):
+            self._map[o.__name__] = o
+            return o
+        return deco(obj) if obj is not None else deco
+
+    def get(self, name):
+        if name not in self._map:
+            raise KeyError(f"No object named '{name}' found in '{self._name}' registry!")
+        return self._map[name]
+
+    def __contains__(self, name):
+        return name in self._map
+
+
+META_ARCH_REGISTRY = Registry("META_ARCH")
+BACKBONE_REGISTRY = Registry("BACKBONE")
+PROPOSAL_GENERATOR_REGISTRY = Registry("PROPOSAL_GENERATOR")
+ROI_HEADS_REGISTRY = Registry("ROI_HEADS")
+ROI_BOX_HEAD_REGISTRY = Registry("ROI_BOX_HEAD")
+ROI_MASK_HEAD_REGISTRY = Registry("ROI_MASK_HEAD")
+FAST_RCNN_REGISTRY = Registry("FAST_RCNN_REGISTRY")
+WEAK_DETECTOR_FAST_RCNN_REGISTRY = Registry("WEAK_DETECTOR_FAST_RCNN")
+
+
+class ShapeSpec:
+    def __init__(self, channels=None, height=None, width=None, stride=None):
+        self.channels, self.height, self.width, self.stride = channels, height, width, stride
+
+
+class Boxes:
+    def __init__(self, tensor):
+        if not isinstance(tensor, torch.Tensor):
+            tensor = torch.as_tensor(tensor, dtype=torch.float32)
+        if tensor.numel() == 0:
+            tensor = tensor.reshape((-1, 4)).to(dtype=torch.float32)
+        self.tensor = tensor
+
+    def __len__(self):
+        return self.tensor.shape[0]
+
+    def __getitem__(self, item):
+        if isinstance(item, int):
+            return Boxes(self.tensor[item].view(1, -1))
+        return Boxes(self.tensor[item])
+
+    def to(self, device):
+        return Boxes(self.tensor.to(device))
+
+    @property
+    def device(self):
+        return self.tensor.device
+
+    @staticmethod
+    def cat(boxes_list):
+        return Boxes(torch.cat([b.tensor for b in boxes_list], dim=0))
+
+
+class Instances:
+    def __init__(self, image_size, **kwargs):
+        self._image_size = image_size
+        self._fields = {}
+        for k, v in kwargs.items():
+            self.set(k, v)
+
+    @property
+    def image_size(self):
+        return self._image_size
+
+    def __setattr__(self, name, val):
+        if name.startswith("_"):
+            super().__setattr__(name, val)
+        else:
+            self.set(name, val)
+
+    def __getattr__(self, name):
+        if name == "_fields" or name not in self._fields:
+            raise AttributeError(f"Cannot find field '{name}' in the given Instances!")
+        return self._fields[name]
+
+    def set(self, name, value):
+        self._fields[name] = value
+
+    def has(self, name):
+        return name in self._fields
+
+    def get(self, name):
+        return self._fields[name]
+
+    def get_fields(self):
+        return self._fields
+
+    def to(self, device):
+        ret = Instances(self._image_size)
+        for k, v in self._fields.items():
+            ret.set(k, v.to(device) if hasattr(v, "to") else v)
+        return ret
+
+    def __getitem__(self, item):
+        ret = Instances(self._image_size)
+        for k, v in self._fields.items():
+            ret.set(k, v[item])
+        return ret
+
+    def __len__(self):
+        for v in self._fields.values():
+            return len(v)
+        return 0
+
+
+class ImageList:
+    """tensor is NHWC (channels padded) in this framework; image_sizes keeps the un-padded (h, w) like detectron2."""
+
+    def __init__(self, tensor, image_sizes):
+        self.tensor, self.image_sizes = tensor, image_sizes
+
+    def __len__(self):
+        return len(self.image_sizes)
