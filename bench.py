@@ -1,0 +1,183 @@
+#!/usr/bin/env python
+"""bench.py -- the headline benchmark of BASELINE.json on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+A "step" is one UniT base-training step exactly as TrainerNoMeta.run_step (engine/defaults.py:266-288): 2 supervised + 2
+weak 3x600x1000 images per GPU through ResNet-101-C4 + RPN + RoIAlign + the two Res5 heads + all eight losses, explicit
+backward, fused SGD step (variant "S1"). Synthetic VOC-shaped inputs already resident in HBM,
+random-init weights of the real architecture. `value` = supervised images / second over ALL ranks (weak scaling: 2
+supervised images per GPU). Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+# algorithmic FLOPs per step per GPU, SURVEY.md section 8d (1 MAC = 2 FLOP; fwd + bwd of trainable convs)
+STEP_TFLOP = {("s1", 101): 12.70, ("s1", 50): 11.61, ("s0", 101): 5.69}
+MFMA_PEAK_TFLOPS = 2500.0   # dense bf16, MI355X_MICROARCH.md (never the 2:1-sparse figure)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--depth", type=int, default=101)
+    ap.add_argument("--variant", default="s1", choices=["s1", "s0"])
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    return ap.parse_args()
+
+
+def cpu_baseline(depth, variant):
+    """The oracle (CPU restatement of the reference path, kind "port") timed on this box's host cores on a BOUNDED
+    sample: one S1 step (forward + backward) on ONE supervised + ONE weak 600x1000 image with 64 RoIs per image."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import unit_oracle as orc
+    from unit_amd import config
+    from unit_amd.modeling import build_model
+    from unit_amd.synthetic import init_synthetic_weights, synthetic_batch
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    cfg = config.voc_rcnn_c4_split1(depth)
+    cfg.MODEL.DEVICE = "cpu"
+    rois = 64
+    m = build_model(cfg)
+    init_synthetic_weights(m, seed=1)
+    trainable = {n for n, p in m.named_parameters() if p.requires_grad}
+    p = {}
+    for k, v in m.state_dict().items():
+        t = v.detach().clone().contiguous()
+        if k in trainable:
+            t.requires_grad_(True)
+        p[k] = t
+    sup, weak = synthetic_batch(1, 1 if variant == "s1" else 0, seed=0)
+    g = torch.Generator().manual_seed(2)
+    perms = dict(rpn=[torch.randperm(38 * 63 * 15, generator=g)], roi=[torch.randperm(2000 + 8, generator=g)])
+    ocfg = dict(depth=depth, num_classes=20, novel_classes=list(cfg.DATASETS.FEWSHOT.NOVEL_CLASSES_ID), pixel_mean=cfg.MODEL.PIXEL_MEAN,
+                pixel_std=cfg.MODEL.PIXEL_STD, rois_per_image=rois, pre_nms_topk=12000, post_nms_topk=2000, multi_box_head=True)
+    t0 = time.time()
+    losses, _ = orc.step_losses(p, [x["image"] for x in sup], [x["instances"].gt_boxes.tensor for x in sup],
+                                [x["instances"].gt_classes for x in sup], [x["image"] for x in weak] if weak else None,
+                                [x["instances"].gt_classes for x in weak] if weak else None, perms, ocfg)
+    sum(losses.values()).backward()
+    dt = time.time() - t0
+    return {"value": round(1.0 / dt, 4), "unit": "images/sec", "cores": cores, "kind": "port",
+            "sample": f"oracle (PyTorch-CPU fp32 + C) S1 fwd+bwd, R{depth}-C4, 1 supervised + 1 weak 3x600x1000 image, "
+                      f"{rois} RoIs/image (1/8 of 512), {dt:.1f} s"}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+
+    from unit_amd import config, ops
+    from unit_amd.modeling import build_model
+    from unit_amd.parallel import GradBuckets
+    from unit_amd.solver import FlatSGD
+    from unit_amd.synthetic import init_synthetic_weights, synthetic_batch
+
+    cfg = config.voc_rcnn_c4_split1(args.depth)
+    cfg.MODEL.DEVICE = f"cuda:{local_rank}"
+    cfg.SOLVER.IMS_PER_BATCH = 2 * world
+    cfg.SEED = 0
+    model = build_model(cfg)
+    init_synthetic_weights(model, seed=1)
+    model.train()
+    model.compute_dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    n_weak = 2 if args.variant == "s1" else 0
+    sup, weak = synthetic_batch(2, n_weak, seed=100 + rank)   # rank r's shard of the global batch
+    batch = model.pack_batch(sup, weak)                      # inputs resident in HBM before the timed region
+    buckets = GradBuckets(model)
+    buckets.broadcast_parameters()
+    opt = FlatSGD(model, cfg, grad_scale=buckets.grad_scale)
+
+    def one_step():
+        step = model.forward_train(batch)
+        model.backward_train(step)
+        buckets.finish()
+        opt.step()
+        return step.losses
+
+    for _ in range(args.warmup):
+        one_step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    prof = None if args.no_roofline else {}
+    ops.PROFILER = prof
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        losses = one_step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    ops.PROFILER = None
+    if world > 1:
+        t = torch.tensor([dt], device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    assert torch.isfinite(losses).all(), f"non-finite losses {losses}"
+
+    if rank == 0:
+        ms = dt / args.steps * 1e3
+        value = 2 * world * args.steps / dt
+        out = {
+            "metric": "images/sec (fwd+bwd+SGD) R101-C4 VOC 600x1000 bs=2/GPU" if args.depth == 101 else f"images/sec R{args.depth}-C4",
+            "value": round(value, 3), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": f"UniT base-training step {args.variant.upper()} (TrainerNoMeta.run_step): ResNet-{args.depth}-C4, "
+                                   f"VOC split1 K=20, 2 supervised + {n_weak} weak 3x600x1000 images per GPU, 512 RoIs/image, "
+                                   "two Res5 heads, RPN 12000->2000, all 8 losses, SGD momentum",
+                       "images_per_gpu": 2, "global_batch": 2 * world, "parallelism": f"dp{world}",
+                       "step_tflop_per_gpu": STEP_TFLOP.get((args.variant, args.depth)),
+                       "step_tflops_achieved_per_gpu": round(STEP_TFLOP.get((args.variant, args.depth), 0) / (ms / 1e3), 1)},
+        }
+        if prof is not None and prof.get("conv_igemm"):
+            ev = prof["conv_igemm"]
+            durs = [a.elapsed_time(b) for a, b, _ in ev]          # ms, HIP events on the launch stream
+            fl = sum(f for _, _, f in ev)
+            tot = sum(durs)
+            out["roofline"] = {"kernel": "conv_igemm_kernel (implicit-GEMM conv fwd/dgrad, bf16 MFMA 16x16x32)", "bound": "mfma",
+                               "achieved": round(fl / tot / 1e9, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                               "frac": round(fl / tot / 1e9 / MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                               "launches_per_step": len(ev) // args.steps, "avg_launch_us": round(tot / len(ev) * 1e3, 2),
+                               "algorithmic_gflop_per_launch": round(fl / len(ev) / 1e9, 2)}
+            if prof.get("conv_wgrad"):
+                ev2 = prof["conv_wgrad"]
+                tot2 = sum(a.elapsed_time(b) for a, b, _ in ev2)
+                out["roofline"]["wgrad_achieved_tflops"] = round(sum(f for _, _, f in ev2) / tot2 / 1e9, 1)
+                out["roofline"]["conv_time_share_of_step"] = round((tot + tot2) / (dt * 1e3), 3)
+        if not args.no_cpu_baseline and world == 1:
+            try:
+                out["cpu_baseline"] = cpu_baseline(args.depth, args.variant)
+            except Exception as e:  # noqa
+                out["cpu_baseline"] = {"error": repr(e)}
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -37,6 +37,9 @@ def _s():
 
 _WS = {}
 
+# bench.py sets this to a dict to time every conv_igemm launch with HIP events on the launch stream (roofline evidence)
+PROFILER = None
+
 
 def workspace(nbytes, device, slot=0):
     key = (device, slot)
@@ -118,9 +121,17 @@ def conv2d(x, w, k, r, s, stride=1, pad=0, bias=None, residual=None, mask_ref=No
             out = torch.zeros((n, ohf, owf, ldy), dtype=out_dtype, device=x.device)
         else:
             out = torch.empty((n, ohf, owf, ldy), dtype=out_dtype, device=x.device)
+    prof = PROFILER
+    if prof is not None:
+        e0 = torch.cuda.Event(enable_timing=True)
+        e0.record()
     check(lib().unit_conv2d_fwd(_p(x), _p(w), _p(out), _p(bias), _p(residual), _p(mask_ref), dt(x.dtype), dt(out_dtype),
                                 n, h, wd, c, k, r, s, stride, pad, oh, ow, ldy, oy_mul, ohf, owf, int(relu), tile_cfg, _s()),
           "unit_conv2d_fwd")
+    if prof is not None:
+        e1 = torch.cuda.Event(enable_timing=True)
+        e1.record()
+        prof.setdefault("conv_igemm", []).append((e0, e1, 2.0 * n * oh * ow * k * r * s * c))
     return out
 
 
@@ -133,8 +144,16 @@ def conv2d_wgrad(x, dy, k, r, s, stride=1, pad=0, scale=None, out=None, accumula
         out = torch.empty((k, r, s, c), dtype=torch.float32, device=x.device)
     nbytes = lib().unit_conv2d_wgrad_workspace_bytes(dt(x.dtype), n, oh, ow, k, r, s, c)
     ws = workspace(nbytes, x.device)
+    prof = PROFILER
+    if prof is not None:
+        e0 = torch.cuda.Event(enable_timing=True)
+        e0.record()
     check(lib().unit_conv2d_wgrad(_p(x), _p(dy), _p(out), _p(scale), dt(x.dtype), n, h, wd, c, k, r, s, stride, pad, oh, ow,
                                   ldy, int(accumulate), _p(ws), ws.numel(), _s()), "unit_conv2d_wgrad")
+    if prof is not None:
+        e1 = torch.cuda.Event(enable_timing=True)
+        e1.record()
+        prof.setdefault("conv_wgrad", []).append((e0, e1, 2.0 * n * oh * ow * k * r * s * c))
     return out
 
 

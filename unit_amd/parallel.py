@@ -1,0 +1,61 @@
+"""Data parallelism over the GPUs of one node: one process per GPU, RCCL (torch.distributed backend "nccl") over xGMI.
+
+The reference wraps the model in torch DistributedDataParallel inside Detectron2's DefaultTrainer (reached from
+/root/reference/engine/defaults.py:256; per-GPU batch = IMS_PER_BATCH // world, data/build.py:354-355) and barriers every
+step (engine/defaults.py:285). Here the gradients already live in ONE flat fp32 buffer laid out in the order they become
+final during the explicit backward (unit_amd/flat.py), so a bucket is a contiguous slice: no gradient copies, no
+autograd hooks. `ready(tag)` is called by the backward plan as soon as a stage's wgrad kernels are enqueued; the
+all-reduce of that slice is launched asynchronously (RCCL's stream, ordered after the compute stream by torch's
+ProcessGroup) and overlaps the remaining backward. xGMI is point-to-point (7 links/GPU): buckets are large (default
+64 MB) so each collective is bandwidth- not latency-bound; the 1/world scaling is folded into the SGD kernel.
+No per-step barrier, no per-step metric gather."""
+import torch
+import torch.distributed as dist
+
+
+class GradBuckets:
+    def __init__(self, model, group=None, bucket_bytes=64 << 20):
+        self.model, self.group = model, group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.bucket_elems = bucket_bytes // 4
+        self._works = []
+        self._plan = None
+        model.on_grad_ready = self.ready
+
+    def _build(self):
+        st = self.model.store
+        plan = {}
+        for tag, a, b in st.tags:
+            chunks = plan.setdefault(tag, [])
+            o = a
+            while o < b:
+                e = min(b, o + self.bucket_elems)
+                chunks.append((o, e))
+                o = e
+        self._plan, self._store = plan, st
+
+    def broadcast_parameters(self, src=0):
+        """initial parameter broadcast from rank 0 (DDP does this at construction)."""
+        if self.world > 1:
+            self.model._ensure_ready()
+            dist.broadcast(self.model.store.params, src, group=self.group)
+            self.model.version += 1
+
+    def ready(self, tag):
+        if self.world == 1:
+            return
+        if self._plan is None or self._store is not self.model.store:
+            self._build()
+        g = self.model.store.grads
+        for a, b in self._plan.get(tag, []):
+            self._works.append(dist.all_reduce(g[a:b], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+
+    def finish(self):
+        """make the compute stream wait for every outstanding bucket (no host sync)."""
+        for w in self._works:
+            w.wait()
+        self._works = []
+
+    @property
+    def grad_scale(self):
+        return 1.0 / self.world
