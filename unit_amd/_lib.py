@@ -4,6 +4,9 @@ import ctypes
 import os
 import re
 
+import torch  # noqa: F401  -- must be imported BEFORE libunit_hip.so is dlopen'ed: the library has to bind to the same
+#                               libamdhip64 runtime instance PyTorch uses (its device pointers / streams are passed in)
+
 HERE = os.path.dirname(os.path.abspath(__file__))
 HEADER = os.path.join(os.path.dirname(HERE), "include", "unit_hip.h")
 LIB_PATH = os.path.join(HERE, "_build", "libunit_hip.so")
