@@ -200,10 +200,21 @@ __global__ void __launch_bounds__(NMS_SCAN_THREADS) nms_scan_kernel(const float*
     nkept = s_nkept;
     if (nkept >= max_keep) break;
     if (tid < nw && tid > c) {
+      // OR in the mask rows of this chunk's kept boxes: 8 independent loads in flight per batch (latency-bound loop)
+      const unsigned long long* base = mk + (size_t)(c * 64) * nw + tid;
       while (kept) {
-        int j = __ffsll((long long)kept) - 1;
-        kept &= kept - 1;
-        removed |= mk[(size_t)(c * 64 + j) * nw + tid];
+        unsigned long long v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          v[u] = 0ull;
+          if (kept) {
+            int j = __ffsll((long long)kept) - 1;
+            kept &= kept - 1;
+            v[u] = base[(size_t)j * nw];
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) removed |= v[u];
       }
     }
   }

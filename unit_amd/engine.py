@@ -1,0 +1,56 @@
+"""Step semantics of the reference's trainers on top of the explicit forward/backward plan.
+
+  * TrainerNoMeta.run_step   /root/reference/engine/defaults.py:266-288 : one supervised + one weak batch per step
+    (`IMS_PER_BATCH // world` images each, data/build.py:354-355), loss_dict -> sum -> backward -> optimizer.step().
+  * TrainerFineTune.run_step /root/reference/engine/defaults.py:442-463 : supervised batch only.
+Differences by design: no per-step `comm.synchronize()` barrier (defaults.py:285), no per-step metric
+gather; losses stay on the device and are fetched only when the caller asks (`fetch_every`)."""
+import torch
+import torch.distributed as dist
+
+from .modeling.rcnn import LOSS_NAMES
+from .parallel import GradBuckets
+from .solver import FlatSGD
+
+
+def shard_batch(global_batch, rank, world):
+    """rank r takes images [r*k, (r+1)*k) with k = len // world (data/build.py:354-355 images_per_worker)."""
+    k = len(global_batch) // world
+    assert k * world == len(global_batch) and k > 0, "IMS_PER_BATCH must be a positive multiple of the world size"
+    return global_batch[rank * k:(rank + 1) * k]
+
+
+class TrainerNoMeta:
+    def __init__(self, cfg, model, data_iter=None, weak_data_iter=None, group=None):
+        self.cfg, self.model = cfg, model
+        self.data_iter, self.weak_data_iter = data_iter, weak_data_iter
+        self.buckets = GradBuckets(model, group)
+        self.buckets.broadcast_parameters()
+        self.optimizer = FlatSGD(model, cfg, grad_scale=self.buckets.grad_scale)
+        self.iter = 0
+        self.last_losses = None
+
+    def run_step(self, base_data=None, classifier_data=None):
+        assert self.model.training, "[TrainerNoMeta] model was changed to eval mode!"
+        if base_data is None:
+            base_data = next(self.data_iter)
+        if classifier_data is None and self.weak_data_iter is not None:
+            classifier_data = next(self.weak_data_iter)
+        batch = self.model.pack_batch(base_data, classifier_data)
+        step = self.model.forward_train(batch)
+        self.model.backward_train(step)          # buckets' all-reduces are launched from inside (on_grad_ready)
+        self.buckets.finish()
+        self.optimizer.step()
+        self.iter += 1
+        self.last_losses = step.losses
+        return step.losses
+
+    def loss_dict(self):
+        """host copy of the last step's losses (one sync; call sparingly)."""
+        vals = self.last_losses.cpu().tolist()
+        return dict(zip(LOSS_NAMES, vals))
+
+
+class TrainerFineTune(TrainerNoMeta):
+    def run_step(self, base_data=None, classifier_data=None):
+        return super().run_step(base_data, None)

@@ -16,6 +16,21 @@ from torch import nn
 from . import ops
 
 
+# Bumped whenever frozen tensors (FrozenBN statistics, frozen weights) may have changed in place (load_state_dict,
+# synthetic init): prepared (folded / cast) copies of frozen layers are keyed on it.
+_FROZEN_EPOCH = [0]
+
+
+def invalidate_prepared():
+    _FROZEN_EPOCH[0] += 1
+
+
+class _EpochOnLoad(nn.Module):
+    def _load_from_state_dict(self, *args, **kwargs):
+        invalidate_prepared()
+        return super()._load_from_state_dict(*args, **kwargs)
+
+
 def _krsc_storage(w):
     """fp32 tensor whose MEMORY is [K][R][S][C] for a logical [K,C,R,S] weight (zero-copy when channels_last view)."""
     if w.dim() == 2:
@@ -25,7 +40,7 @@ def _krsc_storage(w):
     return p if p.is_contiguous() else p.contiguous()
 
 
-class FrozenBatchNorm2d(nn.Module):
+class FrozenBatchNorm2d(_EpochOnLoad):
     """detectron2.layers.FrozenBatchNorm2d (eps 1e-5): buffers only; folded into the conv (scale -> weights, shift -> bias)."""
 
     def __init__(self, num_features, eps=1e-5):
@@ -37,7 +52,7 @@ class FrozenBatchNorm2d(nn.Module):
         self.register_buffer("running_var", torch.ones(num_features) - eps)
 
 
-class Conv2d(nn.Module):
+class Conv2d(_EpochOnLoad):
     """conv (+ FrozenBN | bias) (+ ReLU / residual) executed by unit_conv2d_fwd / _wgrad.  `cin_pad`: stem pads 3 -> 8."""
 
     def __init__(self, cin, cout, k, stride=1, pad=0, norm=False, bias=False, cin_pad=None):
@@ -53,12 +68,15 @@ class Conv2d(nn.Module):
 
     # -- weight preparation (FrozenBN fold + cast + dgrad re-layout); re-run when the master weights changed
     def prepare(self, dtype, version, need_dgrad=True):
-        key = (dtype, version if self.weight.requires_grad else -1, self.weight.data_ptr(), need_dgrad)
+        key = (dtype, version if self.weight.requires_grad else -1, _FROZEN_EPOCH[0], self.weight.data_ptr(), need_dgrad)
         if key == self._prep_key:
             return
         if self.norm is not None:
-            self.scale, self.shift = ops.frozen_bn_fold(self.norm.weight, self.norm.bias, self.norm.running_mean,
-                                                        self.norm.running_var, self.norm.eps)
+            fkey = (_FROZEN_EPOCH[0], self.norm.weight.data_ptr())
+            if fkey != getattr(self, "_fold_key", None):      # FrozenBN never changes during training: fold once
+                self.scale, self.shift = ops.frozen_bn_fold(self.norm.weight, self.norm.bias, self.norm.running_mean,
+                                                            self.norm.running_var, self.norm.eps)
+                self._fold_key = fkey
         else:
             self.scale, self.shift = None, (self.bias.data if self.bias is not None else None)
         src = _krsc_storage(self.weight.data)
@@ -170,7 +188,7 @@ class BasicStem(nn.Module):
         return ops.maxpool3x3s2(self.conv1.fwd(x, relu=True))
 
 
-class Linear(nn.Module):
+class Linear(_EpochOnLoad):
     """nn.Linear-shaped parameters (weight [out,in], bias [out]); evaluated in fused groups by LinearGroup."""
 
     def __init__(self, cin, cout):
@@ -224,7 +242,7 @@ class LinearGroup:
 
     def prepare(self, dtype, version):
         trainable = any(m.weight.requires_grad for m in self.members)
-        key = (dtype, version if trainable else -1, self.members[0].weight.data_ptr())
+        key = (dtype, version if trainable else -1, _FROZEN_EPOCH[0], self.members[0].weight.data_ptr())
         if key == self._prep_key:
             return
         w, b = self._fused_views("data")

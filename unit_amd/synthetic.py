@@ -42,6 +42,8 @@ def init_synthetic_weights(model, seed=1):
             elif cls == "Embedding":
                 if mod.weight.abs().sum() == 0:
                     mod.weight.copy_(torch.randn(mod.weight.shape, generator=g))
+    from .layers import invalidate_prepared
+    invalidate_prepared()
     return model
 
 
