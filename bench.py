@@ -47,7 +47,12 @@ def cpu_baseline(depth, variant):
     from unit_amd import config
     from unit_amd.modeling import build_model
     from unit_amd.synthetic import init_synthetic_weights, synthetic_batch
-    cores = os.cpu_count() or 1
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    cores = max(1, min(avail, 16))     # threads actually used (more threads than the container's CPU quota only thrash)
+    os.environ["OMP_NUM_THREADS"] = str(cores)
     torch.set_num_threads(cores)
     cfg = config.voc_rcnn_c4_split1(depth)
     cfg.MODEL.DEVICE = "cpu"
@@ -170,10 +175,17 @@ def main():
                 out["roofline"]["wgrad_achieved_tflops"] = round(sum(f for _, _, f in ev2) / tot2 / 1e9, 1)
                 out["roofline"]["conv_time_share_of_step"] = round((tot + tot2) / (dt * 1e3), 3)
         if not args.no_cpu_baseline and world == 1:
+            # bounded: the oracle runs in a child process with a wall-clock limit (never part of the timed region)
+            import subprocess
+            code = ("import sys, json; sys.argv=['bench.py']; sys.path.insert(0, %r); import bench; "
+                    "print('CPU_BASELINE ' + json.dumps(bench.cpu_baseline(%d, %r)))" % (ROOT, args.depth, args.variant))
             try:
-                out["cpu_baseline"] = cpu_baseline(args.depth, args.variant)
-            except Exception as e:  # noqa
-                out["cpu_baseline"] = {"error": repr(e)}
+                env = dict(os.environ, OMP_NUM_THREADS="16", CUDA_VISIBLE_DEVICES="", HIP_VISIBLE_DEVICES="")
+                r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=240, env=env)
+                line = [l for l in r.stdout.splitlines() if l.startswith("CPU_BASELINE ")]
+                out["cpu_baseline"] = json.loads(line[-1][len("CPU_BASELINE "):]) if line else {"error": r.stderr[-300:]}
+            except subprocess.TimeoutExpired:
+                out["cpu_baseline"] = {"error": "oracle sample exceeded the 240 s bound on this host"}
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

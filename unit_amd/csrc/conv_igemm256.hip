@@ -1,0 +1,226 @@
+// conv_igemm256.hip -- large-tile bf16 implicit-GEMM convolution (forward / dgrad) for the big-M layers of the hot path
+// (Res5 heads on 1024-2048 RoIs: M = 50 176 .. 100 352, RPN 3x3 conv) -- same math and epilogue as conv_igemm.hip.
+//
+// 256 (pixels) x 256 (channels) x 64 (k) tile, 512 threads = 8 waves (2 x 4), each wave 128 x 64 = 8 x 4 MFMA 16x16x32 tiles
+// (12 ds_read_b128 per 32 MFMAs).  Operand tiles go HBM/L2 -> LDS directly with LDS-DMA (`buffer_load_dwordx4 ... lds`):
+// no staging VGPRs, no ds_write; out-of-range voffsets (im2col zero padding, tile edges) deliver zeros. The LDS image is
+// lane-linear per wave instruction (8 rows x 128 B), so the bank-conflict XOR swizzle is applied to the per-lane SOURCE
+// chunk (chunk ^= (row>>1)&7) and undone in the fragment reads. Two 64 KB LDS buffers: the DMA of k-tile t+1 is in flight
+// while k-tile t is multiplied; one vmcnt(0)+barrier per k-tile.  Requires C % 64 == 0 (every layer except the stem).
+#include "common.h"
+
+struct Conv256Args {
+  const void* x; const void* w; void* y;
+  const float* bias; const void* residual; const void* mask_ref;
+  int N, H, W, C;
+  int K, R, S, stride, pad;
+  int OH, OW;
+  int ldy, oy_mul, OHf, OWf;
+  int relu;
+  int Kgemm, M;
+  int tiles_m, tiles_n;
+  unsigned x_bytes, w_bytes;
+};
+
+__device__ __forceinline__ int swz256(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
+
+template <typename TO> struct O4;
+template <> struct O4<float> {
+  static __device__ __forceinline__ void load(const float* p, float (&v)[4]) { f32x4 a = *reinterpret_cast<const f32x4*>(p); v[0] = a[0]; v[1] = a[1]; v[2] = a[2]; v[3] = a[3]; }
+  static __device__ __forceinline__ void store(float* p, const float (&v)[4]) { f32x4 a = {v[0], v[1], v[2], v[3]}; *reinterpret_cast<f32x4*>(p) = a; }
+};
+template <> struct O4<bf16_t> {
+  static __device__ __forceinline__ void load(const bf16_t* p, float (&v)[4]) {
+    bf16x4 a = *reinterpret_cast<const bf16x4*>(p);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = (float)a[i];
+  }
+  static __device__ __forceinline__ void store(bf16_t* p, const float (&v)[4]) {
+    bf16x4 a;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) a[i] = (bf16_t)v[i];
+    *reinterpret_cast<bf16x4*>(p) = a;
+  }
+};
+
+typedef __attribute__((address_space(3))) void lds_void;
+
+template <typename TO>
+__global__ void __launch_bounds__(512, 2) conv_igemm256_kernel(Conv256Args p) {
+  constexpr int BM = 256, BN = 256, BK = 64;
+  constexpr int BUF = (BM + BN) * 128;          // 64 KB per stage
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  int nwg = p.tiles_m * p.tiles_n;
+  int bid = blockIdx.x;
+  {
+    int q = nwg / 8, r = nwg % 8, xcd = bid % 8, loc = bid / 8;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+  }
+  int tile_n = bid % p.tiles_n, tile_m = bid / p.tiles_n;
+  int m0 = tile_m * BM, n0 = tile_n * BN;
+
+  const bf16_t* __restrict__ X = (const bf16_t*)p.x;
+  const bf16_t* __restrict__ Wt = (const bf16_t*)p.w;
+  __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(X), 0, (int)p.x_bytes, 0x00020000);
+  __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(Wt), 0, (int)p.w_bytes, 0x00020000);
+  constexpr unsigned OOB = 0xFFFFFFF0u;
+
+  int tid = threadIdx.x, lane = tid & 63;
+  int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int wm = wid >> 2, wn = wid & 3;
+  int lrow = lane >> 3, lc = lane & 7;
+
+  // staging pattern: wave `wid`, instruction i (0..3) covers tile rows R0 = (i*8 + wid)*8 .. +8 ; lane -> row R0 + lrow,
+  // LDS chunk lc (linear), source chunk lc ^ f(row)
+  int x_ih0[4], x_iw0[4]; unsigned x_base[4]; bool x_ok[4]; int x_q[4];
+  unsigned w_off[4]; bool w_ok[4]; int w_q[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    int row = (i * 8 + wid) * 8 + lrow;
+    int q = lc ^ ((row >> 1) & 7);
+    x_q[i] = q; w_q[i] = q;
+    int m = m0 + row;
+    x_ok[i] = m < p.M;
+    int mm = x_ok[i] ? m : 0;
+    int ow = mm % p.OW; int t = mm / p.OW; int oh = t % p.OH; int n = t / p.OH;
+    x_ih0[i] = oh * p.stride - p.pad; x_iw0[i] = ow * p.stride - p.pad;
+    x_base[i] = (unsigned)n * (unsigned)(p.H * p.W * p.C);
+    int nn = n0 + row;
+    w_ok[i] = nn < p.K;
+    w_off[i] = ((unsigned)(w_ok[i] ? nn : 0) * (unsigned)p.Kgemm + (unsigned)q * 8u) * 2u;
+  }
+
+  auto stage = [&](int kt, int buf) {
+    int k0 = kt * BK;                       // wave-uniform: C % 64 == 0 -> the whole k-tile sits inside one (r,s)
+    int rs = k0 / p.C; int ch0 = k0 - rs * p.C; int r = rs / p.S; int s = rs - r * p.S;
+    char* base = smem + buf * BUF;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      int R0 = (i * 8 + wid) * 8;
+      int ih = x_ih0[i] + r, iw = x_iw0[i] + s;
+      bool ok = x_ok[i] && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
+      unsigned off = (x_base[i] + (unsigned)((ih * p.W + iw) * p.C + ch0 + x_q[i] * 8)) * 2u;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, (lds_void*)(base + R0 * 128), 16, ok ? off : OOB, 0, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      int R0 = (i * 8 + wid) * 8;
+      unsigned off = w_off[i] + (unsigned)k0 * 2u;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (lds_void*)(base + BM * 128 + R0 * 128), 16, w_ok[i] ? off : OOB, 0, 0, 0);
+    }
+  };
+
+  f32x4 acc[4][8];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 8; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  int nk = p.Kgemm / BK;
+  int frow = lane & 15, fq = lane >> 4;
+  stage(0, 0);
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    int buf = kt & 1;
+    if (kt + 1 < nk) stage(kt + 1, buf ^ 1);
+    const char* bx = smem + buf * BUF;
+    const char* bw = bx + BM * 128;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      i32x4 fa[4], fb[8];
+#pragma unroll
+      for (int a = 0; a < 4; ++a) fa[a] = *reinterpret_cast<const i32x4*>(bw + swz256(wn * 64 + a * 16 + frow, ks * 4 + fq));
+#pragma unroll
+      for (int b = 0; b < 8; ++b) fb[b] = *reinterpret_cast<const i32x4*>(bx + swz256(wm * 128 + b * 16 + frow, ks * 4 + fq));
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 8; ++b)
+          acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fa[a]), __builtin_bit_cast(bf16x8, fb[b]), acc[a][b], 0, 0, 0);
+      __builtin_amdgcn_s_setprio(0);
+    }
+    __syncthreads();   // vmcnt(0): this wave's DMA of tile kt+1 landed ; barrier: everyone's did, and everyone finished reading `buf`
+  }
+
+  TO* __restrict__ Y = (TO*)p.y;
+  const TO* __restrict__ Rz = (const TO*)p.residual;
+  const TO* __restrict__ Mk = (const TO*)p.mask_ref;
+  bool plain = (p.oy_mul == 1 && p.OHf == p.OH && p.OWf == p.OW);
+#pragma unroll
+  for (int b = 0; b < 8; ++b) {
+    int m = m0 + wm * 128 + b * 16 + frow;
+    if (m >= p.M) continue;
+    long off;
+    if (plain) off = (long)m * p.ldy;
+    else {
+      int ow = m % p.OW; int t = m / p.OW; int oh = t % p.OH; int n = t / p.OH;
+      off = (((long)n * p.OHf + (long)oh * p.oy_mul) * p.OWf + (long)ow * p.oy_mul) * p.ldy;
+    }
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      int n = n0 + wn * 64 + a * 16 + fq * 4;
+      if (n >= p.ldy) continue;
+      float v[4] = {acc[a][b][0], acc[a][b][1], acc[a][b][2], acc[a][b][3]};
+      if (p.bias) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] += (n + j < p.K) ? p.bias[n + j] : 0.f;
+      }
+      if (Rz) {
+        float rr[4]; O4<TO>::load(Rz + off + n, rr);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] += rr[j];
+      }
+      if (p.relu) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
+      }
+      if (Mk) {
+        float mm[4]; O4<TO>::load(Mk + off + n, mm);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = mm[j] > 0.f ? v[j] : 0.f;
+      }
+      O4<TO>::store(Y + off + n, v);
+    }
+  }
+}
+
+template <typename TO>
+static int launch256(Conv256Args& a, hipStream_t st) {
+  a.tiles_m = cdiv(a.M, 256); a.tiles_n = cdiv(a.K, 256);
+  size_t lds = 2 * (256 + 256) * 128;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)conv_igemm256_kernel<TO>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  conv_igemm256_kernel<TO><<<a.tiles_m * a.tiles_n, 512, lds, st>>>(a);
+  UNIT_LAUNCH_CHECK();
+  return UNIT_OK;
+}
+
+// Same contract as unit_conv2d_fwd (include/unit_hip.h) restricted to bf16 inputs and C % 64 == 0.
+extern "C" int unit_conv2d_fwd_big(const void* x, const void* w, void* y, const float* bias, const void* residual,
+                                   const void* mask_ref, int out_dtype, int N, int H, int W, int C, int K, int R, int S, int stride,
+                                   int pad, int OH, int OW, int ldy, int oy_mul, int OHf, int OWf, int relu, void* stream) {
+  UNIT_CHECK_ARG(C % 64 == 0, "conv_big: C must be a multiple of 64");
+  UNIT_CHECK_ARG(ldy % 4 == 0 && ldy >= K, "conv_big: ldy must be a multiple of 4 and >= K");
+  UNIT_CHECK_ARG(OH == (H + 2 * pad - R) / stride + 1 && OW == (W + 2 * pad - S) / stride + 1, "conv_big: OH/OW mismatch");
+  UNIT_CHECK_ARG((OH - 1) * oy_mul < OHf && (OW - 1) * oy_mul < OWf, "conv_big: output scatter out of range");
+  UNIT_CHECK_ARG(((uintptr_t)x % 16 == 0) && ((uintptr_t)w % 16 == 0) && ((uintptr_t)y % 16 == 0), "conv_big: 16B alignment");
+  Conv256Args a;
+  a.x = x; a.w = w; a.y = y; a.bias = bias; a.residual = residual; a.mask_ref = mask_ref;
+  a.N = N; a.H = H; a.W = W; a.C = C; a.K = K; a.R = R; a.S = S; a.stride = stride; a.pad = pad;
+  a.OH = OH; a.OW = OW; a.ldy = ldy; a.oy_mul = oy_mul; a.OHf = OHf; a.OWf = OWf; a.relu = relu;
+  a.Kgemm = R * S * C; a.M = N * OH * OW;
+  size_t xb = (size_t)N * H * W * C * 2, wb = (size_t)K * R * S * C * 2;
+  UNIT_CHECK_ARG(xb < 0xFFFFFFF0ull && wb < 0xFFFFFFF0ull, "conv_big: operand larger than 4 GiB");
+  a.x_bytes = (unsigned)xb; a.w_bytes = (unsigned)wb;
+  if (a.M == 0 || K == 0) return UNIT_OK;
+  hipStream_t st = (hipStream_t)stream;
+  if (out_dtype == UNIT_BF16) return launch256<bf16_t>(a, st);
+  if (out_dtype == UNIT_F32) return launch256<float>(a, st);
+  unit_set_error("conv_big: unsupported out dtype");
+  return UNIT_ERR_UNSUPPORTED;
+}

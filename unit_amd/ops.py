@@ -37,6 +37,15 @@ def _s():
 
 _WS = {}
 
+
+
+def _big_tile_default(dtype, m, k, c):
+    """use the 256x256 LDS-DMA kernel when it fills the chip: bf16, C % 64 == 0, wide enough N, >= ~1.5 rounds of tiles"""
+    return False
+
+
+BIG_TILE_POLICY = _big_tile_default
+
 # bench.py sets this to a dict to time every conv_igemm launch with HIP events on the launch stream (roofline evidence)
 PROFILER = None
 
@@ -125,9 +134,15 @@ def conv2d(x, w, k, r, s, stride=1, pad=0, bias=None, residual=None, mask_ref=No
     if prof is not None:
         e0 = torch.cuda.Event(enable_timing=True)
         e0.record()
-    check(lib().unit_conv2d_fwd(_p(x), _p(w), _p(out), _p(bias), _p(residual), _p(mask_ref), dt(x.dtype), dt(out_dtype),
-                                n, h, wd, c, k, r, s, stride, pad, oh, ow, ldy, oy_mul, ohf, owf, int(relu), tile_cfg, _s()),
-          "unit_conv2d_fwd")
+    big = tile_cfg == 5 or (tile_cfg == 0 and BIG_TILE_POLICY(x.dtype, n * oh * ow, k, c))
+    if big:
+        check(lib().unit_conv2d_fwd_big(_p(x), _p(w), _p(out), _p(bias), _p(residual), _p(mask_ref), dt(out_dtype),
+                                        n, h, wd, c, k, r, s, stride, pad, oh, ow, ldy, oy_mul, ohf, owf, int(relu), _s()),
+              "unit_conv2d_fwd_big")
+    else:
+        check(lib().unit_conv2d_fwd(_p(x), _p(w), _p(out), _p(bias), _p(residual), _p(mask_ref), dt(x.dtype), dt(out_dtype),
+                                    n, h, wd, c, k, r, s, stride, pad, oh, ow, ldy, oy_mul, ohf, owf, int(relu), tile_cfg, _s()),
+              "unit_conv2d_fwd")
     if prof is not None:
         e1 = torch.cuda.Event(enable_timing=True)
         e1.record()
