@@ -111,6 +111,14 @@ int unit_roi_align_bwd(const void* gout, int dtype, int N, int H, int W, int C, 
                        int pooled_size, int out_size, int bin_step, float spatial_scale, int sampling_ratio, int aligned,
                        float* dfeat_f32, void* stream);
 
+/* deterministic gather-form backward (no atomics); optional fused "+ addend, * (mask_ref > 0), cast" consumer epilogue */
+size_t unit_roi_align_bwd_gather_workspace_bytes(int R);
+int unit_roi_align_bwd_gather(const void* gout, int dtype, int N, int H, int W, int C, const float* rois, const int* roi_count_dev,
+                              int R, int rois_per_image, int image_offset, int pooled_size, int out_size, int bin_step,
+                              float spatial_scale, int sampling_ratio, int aligned, const void* addend, int addend_images,
+                              const void* mask_ref, void* dfeat, int out_dtype, void* workspace, size_t workspace_bytes,
+                              void* stream);
+
 /* ---- a5/a10/a11/a12 fused loss forward+backward kernels ---- */
 int unit_rpn_loss(const float* head, int ld, int A, int dcol0, const int8_t* labels, const int64_t* match_idx, const float* gt_boxes,
                   int Mcap, const float* anchors, int B, int Ncap, float normalizer, float gscale, float* loss2, void* dhead,

@@ -403,6 +403,43 @@ def test_roi_align_fwd_bwd(dev, c):
     assert np.allclose(nchw(gots).numpy(), refs, rtol=1e-4, atol=1e-4)
 
 
+@pytest.mark.parametrize("mode", [(14, 1), (7, 2)])
+def test_roi_align_bwd_gather(dev, mode):
+    """deterministic gather-form backward == the fp64-accumulated oracle; fixed-slot hint, image offset, fused
+    '+ addend, * (mask > 0)' epilogue; two launches give bit-identical results."""
+    o = ops()
+    gen = g(31)
+    out_size, step = mode
+    n, h, w, c, s = 3, 20, 27, 64, 24
+    rois = torch.cat([make_rois(gen, s, 1, 16.0 * w, 16.0 * h) for _ in range(n)], 0)
+    rois[:, 0] = torch.arange(n).repeat_interleave(s).float()
+    gsmall = torch.randn(n * s, c, out_size, out_size, generator=gen)
+    gfull = torch.zeros(n * s, c, 14, 14)
+    gfull[:, :, ::step, ::step] = gsmall
+    ref = orc.roi_align_backward(gfull.numpy(), (n, c, h, w), rois.numpy())
+    gd = nhwc(gsmall).to(dev)
+    out = torch.empty(n, h, w, c, device=dev)
+    o.roi_align_bwd_gather(gd, n, h, w, rois.to(dev), out, 14, step, rois_per_image=s)
+    assert np.allclose(nchw(out.cpu()).numpy(), ref, rtol=1e-4, atol=1e-5)
+    out2 = torch.empty(n, h, w, c, device=dev)
+    o.roi_align_bwd_gather(gd, n, h, w, rois.to(dev), out2, 14, step)          # generic (no slot hint)
+    assert torch.equal(out, out2)
+    # images 1..2 only, with addend on the first of them and a ReLU mask
+    add = torch.randn(1, h, w, c, generator=gen)
+    msk = torch.randn(2, h, w, c, generator=gen)
+    out3 = torch.empty(2, h, w, c, device=dev)
+    o.roi_align_bwd_gather(gd[s:], 2, h, w, rois[s:].to(dev), out3, 14, step, rois_per_image=s, image_offset=1, addend=add.to(dev),
+                           addend_images=1, mask_ref=msk.to(dev))
+    exp = out[1:].cpu().clone()
+    exp[0] += add[0]
+    exp = exp * (msk > 0)
+    assert torch.allclose(out3.cpu(), exp, rtol=1e-5, atol=1e-6)
+    # bf16 in / bf16 out
+    outb = torch.empty(n, h, w, c, device=dev, dtype=torch.bfloat16)
+    o.roi_align_bwd_gather(gd.bfloat16(), n, h, w, rois.to(dev), outb, 14, step, rois_per_image=s)
+    assert torch.allclose(outb.float().cpu(), out.cpu(), rtol=3e-2, atol=3e-2)
+
+
 def test_roi_sampling_pipeline(dev):
     """a7: append GT -> IoU/match[0.5] -> classes -> subsample(512,25%) -> gather, vs oracle.label_and_sample_proposals."""
     o = ops()

@@ -18,6 +18,7 @@ struct WgradArgs {
   int Kgemm, M;
   int tiles_k, tiles_n, splits, m_per_split;
   unsigned x_bytes, dy_bytes;
+  unsigned magic_ohw, magic_ow; int OHW; int use_magic;
 };
 
 template <typename TI> struct WgCfg;
@@ -103,8 +104,18 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_kernel(WgradArgs p) {
       bool ok = mok && k_ok;
       if (pointwise) xoff = ((unsigned)m * (unsigned)p.C + (unsigned)ch) * (unsigned)sizeof(TI);
       else {
-        int ow = m % p.OW; int tt = m / p.OW; int oh = tt % p.OH; int n = tt / p.OH;
-        int ih = oh * p.stride - p.pad + kr, iw = ow * p.stride - p.pad + ksx;
+        // m -> (n, oh, ow) with multiply-high "magic" division (the rows change every step here, unlike the forward
+        // kernel): q = umulhi(m, ceil(2^32/d)) is exact while m*d < 2^32 (checked on the host), else one correction
+        unsigned um = (unsigned)m, n, oh, ow;
+        if (p.use_magic) {
+          n = __umulhi(um, p.magic_ohw); unsigned rem = um - n * (unsigned)p.OHW;
+          if (rem >= (unsigned)p.OHW) { rem -= p.OHW; ++n; }
+          oh = __umulhi(rem, p.magic_ow); ow = rem - oh * (unsigned)p.OW;
+          if (ow >= (unsigned)p.OW) { ow -= p.OW; ++oh; }
+        } else {
+          ow = um % (unsigned)p.OW; unsigned tt = um / (unsigned)p.OW; oh = tt % (unsigned)p.OH; n = tt / (unsigned)p.OH;
+        }
+        int ih = (int)oh * p.stride - p.pad + kr, iw = (int)ow * p.stride - p.pad + ksx;
         ok = ok && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
         xoff = ((unsigned)n * (unsigned)(p.H * p.W * p.C) + (unsigned)((ih * p.W + iw) * p.C + ch)) * (unsigned)sizeof(TI);
       }
@@ -222,6 +233,11 @@ extern "C" int unit_conv2d_wgrad(const void* x, const void* dy, float* dw, const
   size_t xb = (size_t)N * H * W * C * esz, db = (size_t)a.M * ldy * esz;
   UNIT_CHECK_ARG(xb < 0xFFFFFFF0ull && db < 0xFFFFFFF0ull, "wgrad: operand larger than 4 GiB");
   a.x_bytes = (unsigned)xb; a.dy_bytes = (unsigned)db;
+  a.OHW = OH * OW;
+  a.use_magic = ((unsigned long long)(a.M + 64) * (unsigned long long)a.OHW < 0xFFFFFFFFull) ? 1 : 0;
+  // ceil(2^32 / d); for d == 1 the quotient is m itself: magic 0xFFFFFFFF gives m-1 for m>0 and the correction fixes it
+  a.magic_ohw = a.OHW > 1 ? (unsigned)((0x100000000ull + a.OHW - 1) / (unsigned long long)a.OHW) : 0xFFFFFFFFu;
+  a.magic_ow = OW > 1 ? (unsigned)((0x100000000ull + OW - 1) / (unsigned long long)OW) : 0xFFFFFFFFu;
   a.tiles_k = cdiv(a.Kgemm, 128); a.tiles_n = cdiv(K, 128);
   int ms = in_dtype == UNIT_BF16 ? 64 : 32;
   a.splits = choose_splits(a.M, a.tiles_k * a.tiles_n, ms);

@@ -156,3 +156,145 @@ extern "C" int unit_roi_align_bwd(const void* gout, int dtype, int N, int H, int
   UNIT_LAUNCH_CHECK();
   return UNIT_OK;
 }
+
+// =====================================================================================================================
+// Deterministic RoIAlign backward in GATHER form (no atomics): one workgroup per feature-map pixel, lanes over channels.
+//   dfeat[n,y,x,c] = sum_r  (1/count_r) * sum_ph Wy_r[ph](y) * sum_pw Wx_r[pw](x) * g[r,ph,pw,c]
+// where Wy_r[ph](y) = sum_iy (1-D bilinear weight of sample (ph,iy) on row y) -- the 2-D bilinear weights of ROIAlignV2
+// factor into a row term and a column term, so the per-sample scatter of the reference's atomicAdd kernel becomes a
+// per-pixel sum over the (few) RoI bins that touch the pixel. Summation order is fixed -> bit-reproducible gradients.
+// Optionally fuses the consumer: out = cast((acc + addend) * (mask_ref > 0)) (the RPN-branch gradient and the ReLU mask
+// of the res4 output), which removes the fp32 accumulator round trip.
+// =====================================================================================================================
+struct RoiG { float sw, sh, bw, bh, inv_count; int gh, gw, b, y0, y1, x0, x1; };
+
+__global__ void roi_geom_kernel(const float* __restrict__ rois, const int* __restrict__ roi_count, int R, int H, int W, int pooled,
+                                int out_size, int bin_step, float scale, int sampling_ratio, int aligned, RoiG* __restrict__ tab) {
+  int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= R) return;
+  RoiG t;
+  if (roi_count && r >= *roi_count) { t.b = -1; t.y0 = 1; t.y1 = 0; t.x0 = 1; t.x1 = 0; t.gh = t.gw = 0; t.sw = t.sh = t.bw = t.bh = t.inv_count = 0.f; tab[r] = t; return; }
+  RoiGeom g = roi_geom(rois + 5 * (size_t)r, scale, pooled, sampling_ratio, aligned != 0);
+  t.sw = g.sw; t.sh = g.sh; t.bw = g.bw; t.bh = g.bh; t.inv_count = 1.0f / g.count; t.gh = g.gh; t.gw = g.gw; t.b = g.b;
+  int plast = (out_size - 1) * bin_step;
+  if (g.gh <= 0 || g.gw <= 0) { t.y0 = 1; t.y1 = 0; t.x0 = 1; t.x1 = 0; }
+  else {
+    float yf = g.sh + 0.5f * g.bh / (float)g.gh, yl = g.sh + (float)plast * g.bh + ((float)g.gh - 0.5f) * g.bh / (float)g.gh;
+    float xf = g.sw + 0.5f * g.bw / (float)g.gw, xl = g.sw + (float)plast * g.bw + ((float)g.gw - 0.5f) * g.bw / (float)g.gw;
+    t.y0 = max(0, (int)floorf(fminf(yf, yl)) - 1); t.y1 = min(H - 1, (int)floorf(fmaxf(yf, yl)) + 2);
+    t.x0 = max(0, (int)floorf(fminf(xf, xl)) - 1); t.x1 = min(W - 1, (int)floorf(fmaxf(xf, xl)) + 2);
+  }
+  tab[r] = t;
+}
+
+// 1-D weight of sample coordinate s on pixel index p (same clamping rules as bilinear_taps)
+__device__ __forceinline__ float tap1d(float s, int p, int L) {
+  if (s < -1.0f || s > (float)L) return 0.f;
+  if (s <= 0.f) s = 0.f;
+  int lo = (int)s, hi;
+  if (lo >= L - 1) { hi = lo = L - 1; s = (float)lo; } else hi = lo + 1;
+  float l = s - (float)lo, h = 1.0f - l;
+  return (lo == p ? h : 0.f) + (hi == p ? l : 0.f);
+}
+
+template <typename T, typename TOUT>
+__global__ void roi_align_bwd_gather_kernel(const T* __restrict__ gout, int H, int W, int C, const RoiG* __restrict__ tab, int R,
+                                            int rois_per_image, int image_offset, int out_size, int bin_step,
+                                            const T* __restrict__ addend, int addend_images, const T* __restrict__ mask_ref,
+                                            TOUT* __restrict__ dfeat) {
+  extern __shared__ float wlds[];   // per wave: 2 * 16 floats
+  int pix = blockIdx.x;
+  int n = pix / (H * W); int rem = pix - n * H * W; int py = rem / W, px = rem - py * W;
+  int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float* wy_s = wlds + wave * 32; float* wx_s = wy_s + 16;
+  int c0 = threadIdx.x * 8;
+  bool cvalid = c0 < C;
+  float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  int r_begin = 0, r_end = R;
+  if (rois_per_image > 0) { r_begin = n * rois_per_image; r_end = min(R, r_begin + rois_per_image); }
+  for (int r = r_begin; r < r_end; ++r) {
+    RoiG t = tab[r];                                   // wave-uniform
+    if (t.b != n + image_offset || py < t.y0 || py > t.y1 || px < t.x0 || px > t.x1) continue;
+    // lanes 0..out-1: row weights of bin (lane*step); lanes 32..32+out-1: column weights
+    float wv = 0.f;
+    int o = lane & 31;
+    if (o < out_size) {
+      bool isx = lane >= 32;
+      int p = o * bin_step;
+      float start = isx ? t.sw : t.sh, bsz = isx ? t.bw : t.bh;
+      int gn = isx ? t.gw : t.gh; int L = isx ? W : H; int pp = isx ? px : py;
+      for (int i = 0; i < gn; ++i) {
+        float s = start + (float)p * bsz + ((float)i + 0.5f) * bsz / (float)gn;
+        wv += tap1d(s, pp, L);
+      }
+    }
+    unsigned long long nz = __ballot(wv != 0.f);
+    unsigned ymask = (unsigned)(nz & 0xFFFFFFFFull), xmask = (unsigned)(nz >> 32);
+    if (ymask == 0u || xmask == 0u) continue;
+    if (o < out_size) { if (lane < 32) wy_s[o] = wv; else wx_s[o] = wv; }
+    __builtin_amdgcn_wave_barrier();
+    if (cvalid) {
+      const T* gr = gout + (size_t)r * out_size * out_size * C + c0;
+      for (unsigned ym = ymask; ym; ym &= ym - 1) {
+        int oy = __ffs(ym) - 1;
+        float wy = wy_s[oy] * t.inv_count;
+        for (unsigned xm = xmask; xm; xm &= xm - 1) {
+          int ox = __ffs(xm) - 1;
+          float w = wy * wx_s[ox];
+          float v[8];
+          Vec8<T>::load(gr + ((size_t)oy * out_size + ox) * C, v);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) acc[j] += w * v[j];
+        }
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+  if (!cvalid) return;
+  size_t o = (size_t)pix * C + c0;
+  if (addend && n < addend_images) {
+    float a[8]; Vec8<T>::load(addend + o, a);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] += a[j];
+  }
+  if (mask_ref) {
+    float m[8]; Vec8<T>::load(mask_ref + o, m);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = m[j] > 0.f ? acc[j] : 0.f;
+  }
+  Vec8<TOUT>::store(dfeat + o, acc);
+}
+
+extern "C" size_t unit_roi_align_bwd_gather_workspace_bytes(int R) { return sizeof(RoiG) * (size_t)(R > 0 ? R : 1); }
+
+// dfeat (out_dtype: 0 fp32 / 1 bf16) [N,H,W,C] is fully written (no pre-zeroing needed).
+// rois_per_image > 0 asserts that the RoIs of local image i occupy slots [i*S, (i+1)*S) (fixed-slot layout of the step).
+// image_offset: dfeat/addend/mask_ref point at image `image_offset` of the batch; RoI batch indices are global.
+extern "C" int unit_roi_align_bwd_gather(const void* gout, int dtype, int N, int H, int W, int C, const float* rois,
+                                         const int* roi_count_dev, int R, int rois_per_image, int image_offset, int pooled_size, int out_size,
+                                         int bin_step, float spatial_scale, int sampling_ratio, int aligned, const void* addend,
+                                         int addend_images, const void* mask_ref, void* dfeat, int out_dtype, void* workspace,
+                                         size_t workspace_bytes, void* stream) {
+  UNIT_CHECK_ARG(C % 8 == 0 && C / 8 <= 1024 && out_size <= 16, "roi_align_bwd_gather: C % 8, C <= 8192, out_size <= 16");
+  UNIT_CHECK_ARG(out_dtype == UNIT_F32 || out_dtype == dtype, "roi_align_bwd_gather: out dtype must be fp32 or the input dtype");
+  if (workspace_bytes < unit_roi_align_bwd_gather_workspace_bytes(R)) { unit_set_error("roi_align_bwd_gather: workspace too small"); return UNIT_ERR_WORKSPACE; }
+  hipStream_t st = (hipStream_t)stream;
+  RoiG* tab = (RoiG*)workspace;
+  if (R > 0) {
+    roi_geom_kernel<<<cdiv(R, 256), 256, 0, st>>>(rois, roi_count_dev, R, H, W, pooled_size, out_size, bin_step, spatial_scale,
+                                                sampling_ratio, aligned, tab);
+    UNIT_LAUNCH_CHECK();
+  }
+  int threads = ((C / 8 + 63) / 64) * 64;
+  size_t lds = (size_t)(threads / 64) * 32 * sizeof(float);
+  long blocks = (long)N * H * W;
+  if (blocks == 0) return UNIT_OK;
+#define LAUNCH_G(T, TOUT) roi_align_bwd_gather_kernel<T, TOUT><<<blocks, threads, lds, st>>>((const T*)gout, H, W, C, tab, R, rois_per_image, \
+    image_offset, out_size, bin_step, (const T*)addend, addend_images, (const T*)mask_ref, (TOUT*)dfeat)
+  if (dtype == UNIT_BF16 && out_dtype == UNIT_BF16) LAUNCH_G(bf16_t, bf16_t);
+  else if (dtype == UNIT_BF16) LAUNCH_G(bf16_t, float);
+  else LAUNCH_G(float, float);
+#undef LAUNCH_G
+  UNIT_LAUNCH_CHECK();
+  return UNIT_OK;
+}

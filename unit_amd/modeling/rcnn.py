@@ -293,7 +293,6 @@ class WeaklySupervisedRCNNNoMeta(nn.Module):
         multi = rh.weak_box_head is not None
         done = self.on_grad_ready or (lambda tag: None)
         feat = c.feat
-        dfeat32 = torch.zeros(feat.shape, dtype=torch.float32, device=feat.device)
         bb_trainable = self.backbone.first_trainable_stage() < 3
         box_trainable = c.box_ctx is not None
 
@@ -303,35 +302,39 @@ class WeaklySupervisedRCNNNoMeta(nn.Module):
         if c.dy_weak is not None:
             dweak = bp.weak_detector_head.group.bwd(c.weak_feat, c.dy_weak, need_dx=True)
         done("heads")
+        dpool_sup = dpool_weak = None      # d(loss)/d(pooled) of the supervised / weak RoIs
         if multi:
             if dbox is not None and box_trainable:
-                dpool = rh.box_head.bwd(c.box_ctx, dbox)
+                dpool_sup = rh.box_head.bwd(c.box_ctx, dbox)
                 done("box_head")
-                if bb_trainable:
-                    rh.pool_bwd(dpool, feat.shape, c.rois[:rs], dfeat32)
             if dweak is not None:
-                dpool_w = rh.weak_box_head.bwd(c.weak_ctx, dweak, row_slice=slice(rs, rs + rw))
+                dpool_weak = rh.weak_box_head.bwd(c.weak_ctx, dweak, row_slice=slice(rs, rs + rw))
                 done("weak_box_head")
-                if bb_trainable:
-                    rh.pool_bwd(dpool_w, feat.shape, c.rois[rs:], dfeat32)
         else:
             parts = [t for t in (dbox, dweak) if t is not None]
             dall = torch.cat(parts, 0) if len(parts) > 1 else parts[0]
             dpool = rh.box_head.bwd(c.box_ctx, dall)
             done("box_head")
-            if bb_trainable:
-                rh.pool_bwd(dpool, feat.shape, c.rois, dfeat32)
+            dpool_sup, dpool_weak = (dpool[:rs] if rs > 0 else None), (dpool[rs:] if rw > 0 else None)
 
         drpn = None
         if c.dhead is not None and any(p.requires_grad for p in rpn.rpn_head.parameters()):
             drpn = rpn.rpn_head.bwd(c.rpn_ctx, c.dhead, n_sup)
             done("rpn")
         if bb_trainable:
+            # d(loss)/d(res4 output) = RoIAlign backward (gather form, deterministic) + RPN branch, times the ReLU mask --
+            # one fused kernel per image group (supervised RoIs only touch supervised images, weak RoIs weak images)
             g = torch.empty_like(feat)
-            if n_sup > 0:
-                ops.add_cast(dfeat32[:n_sup], drpn, dt, mask_ref=feat[:n_sup], out=g[:n_sup])
-            if feat.shape[0] > n_sup:
-                ops.add_cast(dfeat32[n_sup:], None, dt, mask_ref=feat[n_sup:], out=g[n_sup:])
+            n_img, fh, fw, _ = feat.shape
+            for (dp, lo, hi, r_lo, r_hi, add) in ((dpool_sup, 0, n_sup, 0, rs, drpn), (dpool_weak, n_sup, n_img, rs, rs + rw, None)):
+                if hi <= lo:
+                    continue
+                if dp is not None:
+                    rh.pool_bwd_gather(dp, hi - lo, fh, fw, c.rois[r_lo:r_hi], g[lo:hi], image_offset=lo, addend=add,
+                                       mask_ref=feat[lo:hi])
+                else:
+                    z = torch.zeros(feat[lo:hi].shape, dtype=torch.float32, device=feat.device)
+                    ops.add_cast(z, add, dt, mask_ref=feat[lo:hi], out=g[lo:hi])
             self.backbone.bwd(c.bb_ctx, g, on_stage_done=done)
 
     def _reattach_grads(self):

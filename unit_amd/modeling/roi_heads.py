@@ -103,6 +103,16 @@ class WSROIHeadNoMeta(nn.Module):
                                  self.sampling_ratio, True)
 
 
+    def pool_bwd_gather(self, dpooled, n_images, h, w, rois5, out, image_offset=0, addend=None, mask_ref=None):
+        """deterministic gather-form RoIAlign backward fused with '+ RPN-branch gradient, * ReLU mask' (fixed RoI slots)."""
+        _, step = self.pool_out
+        s = rois5.shape[0] // n_images
+        return ops.roi_align_bwd_gather(dpooled, n_images, h, w, rois5, out, self.pooler_resolution, step, self.pooler_scale,
+                                        self.sampling_ratio, True, rois_per_image=s if s * n_images == rois5.shape[0] else 0,
+                                        image_offset=image_offset, addend=addend, addend_images=n_images if addend is not None else 0,
+                                        mask_ref=mask_ref)
+
+
 @ROI_HEADS_REGISTRY.register()
 class WSROIHeadFineTune(WSROIHeadNoMeta):
     finetune = True

@@ -39,9 +39,13 @@ _WS = {}
 
 
 
-def _big_tile_default(dtype, m, k, c):
-    """use the 256x256 LDS-DMA kernel when it fills the chip: bf16, C % 64 == 0, wide enough N, >= ~1.5 rounds of tiles"""
-    return False
+def _big_tile_default(dtype, m, k, c, kgemm):
+    """use the 256x256 LDS-DMA kernel when it pays (measured, tools/microbench.py): bf16, C % 64 == 0, at least half a
+    round of 256x256 tiles and a k-extent long enough to amortise the 128 KB-per-tile epilogue"""
+    if dtype != torch.bfloat16 or c % 64 != 0 or k < 256 or kgemm < 512:
+        return False
+    tiles = ((m + 255) // 256) * ((k + 255) // 256)
+    return tiles >= 128
 
 
 BIG_TILE_POLICY = _big_tile_default
@@ -134,7 +138,7 @@ def conv2d(x, w, k, r, s, stride=1, pad=0, bias=None, residual=None, mask_ref=No
     if prof is not None:
         e0 = torch.cuda.Event(enable_timing=True)
         e0.record()
-    big = tile_cfg == 5 or (tile_cfg == 0 and BIG_TILE_POLICY(x.dtype, n * oh * ow, k, c))
+    big = tile_cfg == 5 or (tile_cfg == 0 and BIG_TILE_POLICY(x.dtype, n * oh * ow, k, c, r * s * c))
     if big:
         check(lib().unit_conv2d_fwd_big(_p(x), _p(w), _p(out), _p(bias), _p(residual), _p(mask_ref), dt(out_dtype),
                                         n, h, wd, c, k, r, s, stride, pad, oh, ow, ldy, oy_mul, ohf, owf, int(relu), _s()),
@@ -416,6 +420,20 @@ def roi_align_bwd(gout, feat_shape, rois, dfeat32=None, pooled_size=14, bin_step
     check(lib().unit_roi_align_bwd(_p(gout), dt(gout.dtype), n, h, w, c, _p(rois), _p(roi_count), r, pooled_size, out_size, bin_step,
                                    float(spatial_scale), sampling_ratio, int(aligned), _p(dfeat32), _s()), "roi_align_bwd")
     return dfeat32
+
+
+def roi_align_bwd_gather(gout, n_images, h, w, rois, out, pooled_size=14, bin_step=1, spatial_scale=1.0 / 16, sampling_ratio=0,
+                         aligned=True, rois_per_image=0, image_offset=0, addend=None, addend_images=0, mask_ref=None, roi_count=None):
+    """deterministic gather-form RoIAlign backward; `out` [n_images,h,w,C] (fp32 or gout.dtype) is fully overwritten with
+    cast((sum_of_roi_contributions [+ addend]) [* (mask_ref > 0)])."""
+    r, out_size, c = gout.shape[0], gout.shape[1], gout.shape[3]
+    nb = lib().unit_roi_align_bwd_gather_workspace_bytes(r)
+    ws = workspace(nb, gout.device, slot=1)
+    check(lib().unit_roi_align_bwd_gather(_p(gout), dt(gout.dtype), n_images, h, w, c, _p(rois), _p(roi_count), r, rois_per_image,
+                                          image_offset, pooled_size, out_size, bin_step, float(spatial_scale), sampling_ratio,
+                                          int(aligned), _p(addend), addend_images, _p(mask_ref), _p(out), dt(out.dtype), _p(ws),
+                                          ws.numel(), _s()), "roi_align_bwd_gather")
+    return out
 
 
 # ------------------------------------------------------------------------------------------------ losses
