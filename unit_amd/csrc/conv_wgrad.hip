@@ -200,13 +200,21 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ partial, int split
 }
 
 static int choose_splits(int M, int tiles, int ms) {
-  int want = (512 + tiles - 1) / tiles;
+  // 2 workgroups of this kernel are co-resident per CU (72 KB LDS each): 512 slots per "round" on 256 CUs. Pick the
+  // split count whose grid fills whole rounds best (tile quantisation), preferring fewer splits (less slab traffic).
   int maxs = (M + 4 * ms - 1) / (4 * ms);   // at least 4 staged steps per split
   if (maxs < 1) maxs = 1;
-  int s = want < maxs ? want : maxs;
-  if (s < 1) s = 1;
-  if (s > 64) s = 64;
-  return s;
+  if (maxs > 64) maxs = 64;
+  int best = 1; double best_score = -1.0;
+  for (int s = 1; s <= maxs; ++s) {
+    long blocks = (long)tiles * s;
+    long rounds = (blocks + 511) / 512;
+    double fill = (double)blocks / (double)(rounds * 512);
+    double score = fill - 0.004 * s;         // mild preference for fewer splits
+    if (blocks < 256) score -= 1.0;          // do not leave most of the chip idle
+    if (score > best_score) { best_score = score; best = s; }
+  }
+  return best;
 }
 
 extern "C" size_t unit_conv2d_wgrad_workspace_bytes(int in_dtype, int N, int OH, int OW, int K, int R, int S, int C) {
