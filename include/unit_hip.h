@@ -138,6 +138,29 @@ int unit_oicr_targets(const float* src, int ld, int col0, int mode, int K, const
                       const unsigned char* multihot, float fg_thresh, float bg_thresh, int* labels, float* weights, void* stream);
 int unit_sum_losses(const float* losses, int n, float* out, void* stream);
 
+/* ---- a14 base->novel similarity transfer: modeling/roi_heads/roi_heads.py:245-336, fast_rcnn.py:376-382,401-423,504-533 ---- */
+int unit_embedding_similarity(const float* emb, int ld, int dim, const int* novel_rows, int n_novel, const int* base_rows, int n_base,
+                              float* out, void* stream);
+int unit_similarity(const float* lin_weak, int ld, int col0, int n_oicr, int ncls, const int* base_dev, int n_base, const float* lingual,
+                    int n_novel, float visual_threshold, int use_lingual, int use_visual, float* sim, int R, void* stream);
+int unit_transfer_predictions(const float* lin, int ld, int ccol0, int bcol0, int K, const float* weak, int ldw, int wcol0, int n_oicr,
+                              const float* ft, int ldf, int fccol0, int fbcol0, const float* sim_cls, const float* sim_bbox,
+                              const int* base_dev, int n_base, const int* novel_dev, int n_novel, const int8_t* role_dev,
+                              const int* slot_dev, float* scores, int lds, float* bbox, int ldb, int R, void* stream);
+/* ---- a15 detections: fast_rcnn.py:455-468 -> detectron2 fast_rcnn_inference; rcnn.py:411-429 detector_postprocess ---- */
+int unit_softmax_rows(const float* x, int ld, int ncls, float* y, int ldy, int R, void* stream);
+int unit_detection_candidates(const float* probs, int ldp, const float* deltas, int ldd, const float* props, const int* pcount, int B,
+                              int Rcap, int K, const float* weights4, float scale_clamp, const float* image_hw_dev, float score_thresh,
+                              int cap, float* cand_boxes, float* cand_scores, int* cand_class, int* cand_roi, int* cand_count,
+                              float* cand_max, void* stream);
+int unit_detection_offset_gather(const float* cand_boxes, const int* cand_class, const int* order, const int* cand_count,
+                                 const float* cand_max, int B, int cap, float* out, void* stream);
+int unit_detection_finalize(const float* cand_boxes, const float* cand_scores, const int* cand_class, const int* cand_roi, const int* order,
+                            const int* keep, const int* keep_count, int B, int cap, int topk, float* out_boxes, float* out_scores,
+                            int* out_class, int* out_roi, int* out_count, void* stream);
+int unit_detector_postprocess(float* boxes, const int* count, int B, int topk, const float* scale_xy_dev, const float* out_hw_dev,
+                              unsigned char* nonempty, void* stream);
+
 /* ---- K18 SGD momentum (solver/build.py:110-112) ---- */
 int unit_sgd_momentum(float* p, const float* g, float* buf, long n, float lr, float momentum, float wd, float grad_scale,
                       int first_step, void* stream);

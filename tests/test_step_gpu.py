@@ -138,3 +138,85 @@ def test_autograd_surface_and_sgd(dev):
     l2 = model.train_step(batch, None, perms).cpu()
     assert torch.allclose(l0, l2, rtol=1e-6, atol=1e-7)
     assert torch.allclose(model.store.grads, g1, rtol=1e-4, atol=1e-6)
+
+
+def _oracle_params(model):
+    trainable = {n for n, p in model.named_parameters() if p.requires_grad}
+    return {k: v.detach().cpu().clone().contiguous().requires_grad_(k in trainable) for k, v in model.state_dict().items()}
+
+
+def _ocfg(cfg, **kw):
+    d = dict(depth=cfg.MODEL.RESNETS.DEPTH, num_classes=cfg.MODEL.ROI_HEADS.NUM_CLASSES, novel_classes=list(cfg.DATASETS.FEWSHOT.NOVEL_CLASSES_ID),
+             base_classes=list(cfg.DATASETS.FEWSHOT.BASE_CLASSES_ID), coco_indexer=orc.VOC_COCO_INDEXER, pixel_mean=cfg.MODEL.PIXEL_MEAN,
+             pixel_std=cfg.MODEL.PIXEL_STD, rois_per_image=cfg.MODEL.ROI_HEADS.BATCH_SIZE_PER_IMAGE,
+             pre_nms_topk=cfg.MODEL.RPN.PRE_NMS_TOPK_TRAIN, post_nms_topk=cfg.MODEL.RPN.POST_NMS_TOPK_TRAIN, multi_box_head=True)
+    d.update(kw)
+    return d
+
+
+def test_s2_finetune_step_parity_fp32(dev):
+    """a14 / S2: TrainerFineTune.run_step -- frozen backbone/RPN/Res5/delta heads, similarity transfer in training,
+    only cls_score_ft / bbox_pred_ft receive gradients (configs/VOC/FT/1_shot/...-ft.yaml:6-9)."""
+    cfg = config.voc_rcnn_c4_split1_ft(50)
+    cfg.MODEL.DEVICE = "cuda"
+    cfg.MODEL.ROI_HEADS.BATCH_SIZE_PER_IMAGE = 32
+    cfg.MODEL.RPN.PRE_NMS_TOPK_TRAIN, cfg.MODEL.RPN.POST_NMS_TOPK_TRAIN = 600, 100
+    cfg.SEED = 3
+    model = build_model(cfg)
+    init_synthetic_weights(model, seed=2)
+    with torch.no_grad():   # non-zero ft heads so that their forward contribution is visible
+        g = torch.Generator().manual_seed(9)
+        model.roi_heads.box_predictor.cls_score_ft.weight.copy_(torch.randn(21, 2048, generator=g) * 0.01)
+        model.roi_heads.box_predictor.bbox_pred_ft.weight.copy_(torch.randn(80, 2048, generator=g) * 0.001)
+    model.train()
+    model.compute_dtype = torch.float32
+    sup, _ = synthetic_batch(2, 0, hw=(128, 192), seed=6, max_gt=4, base_ids=list(range(20)))
+    batch = model.pack_batch(sup, None)
+    model._ensure_ready()
+    assert model.store.size < 300_000                       # only the ft heads are in the flat trainable store
+    perms = model.sampling_permutations(2, 8 * 12 * 15, 100 + batch.gt_boxes.shape[1])
+    step = model.forward_train(batch, perms)
+    model.backward_train(step)
+    p = _oracle_params(model)
+    operms = dict(rpn=[x.long().cpu() for x in perms["rpn"]], roi=[x.long().cpu() for x in perms["roi"]])
+    ref, aux = orc.finetune_step_losses(p, [x["image"] for x in sup], [x["instances"].gt_boxes.tensor for x in sup],
+                                        [x["instances"].gt_classes for x in sup], operms, _ocfg(cfg))
+    sum(ref.values()).backward()
+    got = dict(zip(LOSS_NAMES, step.losses.cpu().tolist()))
+    for k in ("loss_cls", "loss_box_reg", "loss_rpn_cls", "loss_rpn_loc"):
+        assert abs(got[k] - ref[k].item()) <= 1e-4 * max(1.0, abs(ref[k].item())), (k, got[k], ref[k].item())
+    n = sum(len(s["boxes"]) for s in aux["sampled"])
+    assert torch.allclose(step.scores.cpu()[:32][: len(aux["sampled"][0]["boxes"])], aux["scores"].detach()[: len(aux["sampled"][0]["boxes"])],
+                          rtol=1e-4, atol=1e-4)
+    for name in ("cls_score_ft", "bbox_pred_ft"):
+        for part in ("weight", "bias"):
+            key = f"roi_heads.box_predictor.{name}.{part}"
+            gd = dict(model.named_parameters())[key].grad.cpu()
+            gr = p[key].grad
+            assert (gd - gr).abs().max() <= 2e-3 * gr.abs().max() + 1e-8, key
+    assert n > 0
+
+
+def test_inference_parity_fp32(dev):
+    """a15: eval path (6000 -> 1000 proposals, similarity transfer, softmax, score > 0.05, per-class NMS 0.5, top-100,
+    detector_postprocess) against the oracle on one image."""
+    cfg = small_cfg()
+    cfg.MODEL.RPN.PRE_NMS_TOPK_TEST, cfg.MODEL.RPN.POST_NMS_TOPK_TEST = 400, 80
+    model = build_model(cfg)
+    init_synthetic_weights(model, seed=4)
+    with torch.no_grad():   # make the class scores spread out so that several classes pass the 0.05 threshold
+        g = torch.Generator().manual_seed(11)
+        model.roi_heads.box_predictor.cls_score_delta.weight.copy_(torch.randn(21, 2048, generator=g) * 0.02)
+    model.eval()
+    model.compute_dtype = torch.float32
+    sup, _ = synthetic_batch(1, 0, hw=(128, 192), seed=8)
+    inp = [{"image": sup[0]["image"], "height": 256, "width": 384}]
+    out = model(inp)[0]["instances"]
+    p = {k: v.detach().cpu().clone().contiguous() for k, v in model.state_dict().items()}
+    b, s, c, r, aux = orc.inference(p, sup[0]["image"], _ocfg(cfg, pre_nms_topk_test=400, post_nms_topk_test=80), out_hw=(256, 384))
+    assert len(b) > 3
+    assert len(out) == len(b), (len(out), len(b))
+    assert torch.equal(out.pred_classes.cpu(), c)
+    assert torch.equal(out._roi_index.cpu().long(), r)
+    assert torch.allclose(out.scores.cpu(), s, rtol=1e-4, atol=1e-5)
+    assert torch.allclose(out.pred_boxes.tensor.cpu(), b, rtol=1e-4, atol=2e-2)

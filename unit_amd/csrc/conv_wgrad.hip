@@ -210,8 +210,7 @@ static int choose_splits(int M, int tiles, int ms) {
     long blocks = (long)tiles * s;
     long rounds = (blocks + 511) / 512;
     double fill = (double)blocks / (double)(rounds * 512);
-    double score = fill - 0.004 * s;         // mild preference for fewer splits
-    if (blocks < 256) score -= 1.0;          // do not leave most of the chip idle
+    double score = fill - 0.0005 * s;        // tie-break only: prefer fewer splits (less slab traffic)
     if (score > best_score) { best_score = score; best = s; }
   }
   return best;

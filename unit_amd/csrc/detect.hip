@@ -1,0 +1,332 @@
+// detect.hip -- base->novel similarity transfer (fine-tune / eval predictor) and the detection post-processing.
+//   a14  WSROIHead.get_similarity_matrices  modeling/roi_heads/roi_heads.py:245-336  ('lingual' + 'visual', "Sum")
+//        SupervisedDetectorOutputs*.forward transfer   modeling/roi_heads/fast_rcnn.py:401-423, 504-523
+//   a15  SupervisedDetectorOutputsBase.inference -> detectron2 fast_rcnn_inference (fast_rcnn.py:455-468)
+#include "common.h"
+
+#define DET_MAXC 96
+
+// out[i][j] = sum_k a[i][k] * b[j][k]   (tiny: label-embedding similarity 5x300 . 15x300^T, fast_rcnn.py:376-382)
+__global__ void small_matmul_nt_kernel(const float* __restrict__ a, const int* __restrict__ arow, int M, const float* __restrict__ b,
+                                       const int* __restrict__ brow, int N, int Kd, int lda, float* __restrict__ out) {
+  int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= M * N) return;
+  int i = idx / N, j = idx - i * N;
+  const float* pa = a + (size_t)(arow ? arow[i] : i) * lda;
+  const float* pb = b + (size_t)(brow ? brow[j] : j) * lda;
+  float s = 0.f;
+  for (int k = 0; k < Kd; ++k) s += pa[k] * pb[k];
+  out[idx] = s;
+}
+extern "C" int unit_embedding_similarity(const float* emb, int ld, int dim, const int* novel_rows, int n_novel, const int* base_rows,
+                                         int n_base, float* out, void* stream) {
+  if (n_novel * n_base == 0) return UNIT_OK;
+  small_matmul_nt_kernel<<<cdiv(n_novel * n_base, 128), 128, 0, (hipStream_t)stream>>>(emb, novel_rows, n_novel, emb, base_rows, n_base, dim, ld, out);
+  UNIT_LAUNCH_CHECK();
+  return UNIT_OK;
+}
+
+// sim[r][j][b] for j in novel, b in base (roi_heads.py:250-257, 269-272, 316-322):
+//   probs = mean_k oicr_k(x)           (K+1 logits)           vis = softmax(probs)[base] ; vis /= max(sum, 1e-9) ; vis[vis < thr] = 0
+//   s = 0.5 * softmax(lingual[j,:]) + 0.5 * vis              s /= max(sum_b s, 1e-9)
+__global__ void similarity_kernel(const float* __restrict__ lin, int ld, int col0, int n_oicr, int ncls, const int* __restrict__ base,
+                                  int n_base, const float* __restrict__ lingual, int n_novel, float thr, int use_lingual,
+                                  int use_visual, float* __restrict__ sim, int R) {
+  int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= R) return;
+  float vis[DET_MAXC];
+  if (use_visual) {
+    const float* x = lin + (size_t)r * ld + col0;
+    float mx = -INFINITY;
+    for (int c = 0; c < ncls; ++c) {
+      float s = 0.f;
+      for (int k = 0; k < n_oicr; ++k) s += x[k * ncls + c];
+      mx = fmaxf(mx, s / (float)n_oicr);
+    }
+    float se = 0.f;
+    for (int c = 0; c < ncls; ++c) {
+      float s = 0.f;
+      for (int k = 0; k < n_oicr; ++k) s += x[k * ncls + c];
+      se += expf(s / (float)n_oicr - mx);
+    }
+    float tot = 0.f;
+    for (int b = 0; b < n_base; ++b) {
+      int c = base[b];
+      float s = 0.f;
+      for (int k = 0; k < n_oicr; ++k) s += x[k * ncls + c];
+      vis[b] = expf(s / (float)n_oicr - mx) / se;
+      tot += vis[b];
+    }
+    tot = fmaxf(tot, 1e-9f);
+    for (int b = 0; b < n_base; ++b) { float v = vis[b] / tot; vis[b] = v < thr ? 0.f : v; }
+  }
+  float nterms = (float)(use_lingual + use_visual);
+  float wgt = nterms > 0.f ? 1.0f / nterms : 0.f;
+  for (int j = 0; j < n_novel; ++j) {
+    float lmx = -INFINITY, lse = 0.f;
+    if (use_lingual) {
+      for (int b = 0; b < n_base; ++b) lmx = fmaxf(lmx, lingual[j * n_base + b]);
+      for (int b = 0; b < n_base; ++b) lse += expf(lingual[j * n_base + b] - lmx);
+    }
+    float tot = 0.f;
+    float* o = sim + ((size_t)r * n_novel + j) * n_base;
+    for (int b = 0; b < n_base; ++b) {
+      float s = 0.f;
+      if (use_lingual) s = s + wgt * (expf(lingual[j * n_base + b] - lmx) / lse);
+      if (use_visual) s = s + wgt * vis[b];
+      o[b] = s; tot += s;
+    }
+    tot = fmaxf(tot, 1e-9f);
+    for (int b = 0; b < n_base; ++b) o[b] = nterms > 0.f ? o[b] / tot : 0.f;
+  }
+}
+extern "C" int unit_similarity(const float* lin_weak, int ld, int col0, int n_oicr, int ncls, const int* base_dev, int n_base,
+                               const float* lingual, int n_novel, float visual_threshold, int use_lingual, int use_visual,
+                               float* sim, int R, void* stream) {
+  UNIT_CHECK_ARG(n_base <= DET_MAXC, "similarity: more than 96 base classes");
+  if (R == 0) return UNIT_OK;
+  similarity_kernel<<<cdiv(R, 64), 64, 0, (hipStream_t)stream>>>(lin_weak, ld, col0, n_oicr, ncls, base_dev, n_base, lingual, n_novel,
+                                                                visual_threshold, use_lingual, use_visual, sim, R);
+  UNIT_LAUNCH_CHECK();
+  return UNIT_OK;
+}
+
+// fast_rcnn.py:401-423 / 504-523 + :425-426 (+ :525-528 fine-tune heads):
+//   scores[r,c] = delta[r,c] + [c novel] sum_b sim_cls[r,j,b] * delta[r,base_b]  + mean_k oicr_k  (+ ft)
+//   bbox[r,c,:] = (c base) delta ; (c novel) sum_b sim_bbox[r,j,b] * delta[r,base_b,:] ; (else) 0   (+ 0 weak) (+ ft)
+__global__ void transfer_kernel(const float* __restrict__ lin, int ld, int ccol0, int bcol0, int K, const float* __restrict__ weak, int ldw,
+                                int wcol0, int n_oicr, const float* __restrict__ ft, int ldf, int fccol0, int fbcol0,
+                                const float* __restrict__ sim_cls, const float* __restrict__ sim_bbox, const int* __restrict__ base, int n_base,
+                                const int* __restrict__ novel, int n_novel, const int8_t* __restrict__ role /* K: 0 none,1 base,2 novel */,
+                                const int* __restrict__ slot /* K: index into base/novel list */, float* __restrict__ scores, int lds_,
+                                float* __restrict__ bbox, int ldb, int R) {
+  int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  int ncls = K + 1;
+  if (idx >= R * ncls) return;
+  int r = idx / ncls, c = idx - r * ncls;
+  const float* x = lin + (size_t)r * ld;
+  float s = x[ccol0 + c];
+  if (c < K && sim_cls && role[c] == 2) {
+    const float* sm = sim_cls + ((size_t)r * n_novel + slot[c]) * n_base;
+    float t = 0.f;
+    for (int b = 0; b < n_base; ++b) t += sm[b] * x[ccol0 + base[b]];
+    s = s + t;
+  }
+  if (weak) {
+    float w = 0.f;
+    for (int k = 0; k < n_oicr; ++k) w += weak[(size_t)r * ldw + wcol0 + k * ncls + c];
+    s = s + w / (float)n_oicr;
+  }
+  if (ft) s = s + ft[(size_t)r * ldf + fccol0 + c];
+  scores[(size_t)r * lds_ + c] = s;
+  if (c >= K) return;
+  float o[4] = {0.f, 0.f, 0.f, 0.f};
+  if (!sim_bbox || role[c] == 1) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] = x[bcol0 + 4 * c + j];
+  } else if (role[c] == 2) {
+    const float* sm = sim_bbox + ((size_t)r * n_novel + slot[c]) * n_base;
+    for (int b = 0; b < n_base; ++b) {
+      float w = sm[b];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) o[j] += w * x[bcol0 + 4 * base[b] + j];
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) bbox[(size_t)r * ldb + 4 * c + j] = o[j] + (ft ? ft[(size_t)r * ldf + fbcol0 + 4 * c + j] : 0.f);
+}
+extern "C" int unit_transfer_predictions(const float* lin, int ld, int ccol0, int bcol0, int K, const float* weak, int ldw, int wcol0,
+                                         int n_oicr, const float* ft, int ldf, int fccol0, int fbcol0, const float* sim_cls,
+                                         const float* sim_bbox, const int* base_dev, int n_base, const int* novel_dev, int n_novel,
+                                         const int8_t* role_dev, const int* slot_dev, float* scores, int lds, float* bbox, int ldb,
+                                         int R, void* stream) {
+  if (R == 0) return UNIT_OK;
+  transfer_kernel<<<cdiv(R * (K + 1), 256), 256, 0, (hipStream_t)stream>>>(lin, ld, ccol0, bcol0, K, weak, ldw, wcol0, n_oicr, ft, ldf, fccol0,
+                                                                       fbcol0, sim_cls, sim_bbox, base_dev, n_base, novel_dev, n_novel,
+                                                                       role_dev, slot_dev, scores, lds, bbox, ldb, R);
+  UNIT_LAUNCH_CHECK();
+  return UNIT_OK;
+}
+
+// row softmax (predict_probs: F.softmax(scores, dim=-1))
+__global__ void softmax_rows_kernel(const float* __restrict__ x, int ld, int ncls, float* __restrict__ y, int ldy, int R) {
+  int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= R) return;
+  const float* p = x + (size_t)r * ld;
+  float mx = -INFINITY;
+  for (int c = 0; c < ncls; ++c) mx = fmaxf(mx, p[c]);
+  float se = 0.f;
+  for (int c = 0; c < ncls; ++c) se += expf(p[c] - mx);
+  for (int c = 0; c < ncls; ++c) y[(size_t)r * ldy + c] = expf(p[c] - mx) / se;
+}
+extern "C" int unit_softmax_rows(const float* x, int ld, int ncls, float* y, int ldy, int R, void* stream) {
+  if (R == 0) return UNIT_OK;
+  softmax_rows_kernel<<<cdiv(R, 128), 128, 0, (hipStream_t)stream>>>(x, ld, ncls, y, ldy, R);
+  UNIT_LAUNCH_CHECK();
+  return UNIT_OK;
+}
+
+// fast_rcnn_inference_single_image, first half: decode (weights w), clip, score > thresh -> candidates in (roi, class)
+// row-major order, compacted. One workgroup per image. Also returns max coordinate over the candidates (batched_nms offset).
+__device__ __forceinline__ int2 det_scan2(int2 v, int2* total, int2* lds) {
+  int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  int2 inc = v;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    int ax = __shfl_up(inc.x, o, 64), ay = __shfl_up(inc.y, o, 64);
+    if (lane >= o) { inc.x += ax; inc.y += ay; }
+  }
+  if (lane == 63) lds[wid] = inc;
+  __syncthreads();
+  if (threadIdx.x == 0) { int2 run = {0, 0}; for (int w = 0; w < nw; ++w) { int2 t = lds[w]; lds[w] = run; run.x += t.x; run.y += t.y; } lds[16] = run; }
+  __syncthreads();
+  int2 base = lds[wid];
+  *total = lds[16];
+  int2 ex = {base.x + inc.x - v.x, base.y + inc.y - v.y};
+  __syncthreads();
+  return ex;
+}
+
+__global__ void det_select_kernel(const float* __restrict__ probs, int ldp, const float* __restrict__ deltas, int ldd,
+                                  const float* __restrict__ props, const int* __restrict__ pcount, int Rcap, int K, f32x4 w,
+                                  float clampv, const float* __restrict__ image_hw, float thresh, int cap, float* __restrict__ cboxes,
+                                  float* __restrict__ cscores, int* __restrict__ cclass, int* __restrict__ croi, int* __restrict__ ccount,
+                                  float* __restrict__ cmax) {
+  __shared__ int2 lds[17];
+  __shared__ float smax[16];
+  int b = blockIdx.x;
+  int R = min(pcount ? pcount[b] : Rcap, Rcap);
+  float imh = image_hw[2 * b], imw = image_hw[2 * b + 1];
+  int total = R * K;
+  int chunk = (total + blockDim.x - 1) / blockDim.x;
+  int i0 = threadIdx.x * chunk, i1 = min(total, i0 + chunk);
+  int2 c = {0, 0};
+  float mx = -INFINITY;
+  for (int pass = 0; pass < 2; ++pass) {
+    int2 ex = {0, 0}, tot = {0, 0};
+    if (pass == 1) ex = det_scan2(c, &tot, lds);
+    for (int i = i0; i < i1; ++i) {
+      int r = i / K, k = i - r * K;
+      size_t row = (size_t)b * Rcap + r;
+      float sc = probs[row * ldp + k];
+      const float* dp = deltas + row * ldd + 4 * k;
+      const float* pb = props + row * 4;
+      f32x4 bx;
+      {
+        float bw = pb[2] - pb[0], bh = pb[3] - pb[1];
+        float cx = pb[0] + 0.5f * bw, cy = pb[1] + 0.5f * bh;
+        float dx = dp[0] / w[0], dy = dp[1] / w[1];
+        float dw = fminf(dp[2] / w[2], clampv), dh = fminf(dp[3] / w[3], clampv);
+        float pcx = dx * bw + cx, pcy = dy * bh + cy;
+        float pw = expf(dw) * bw, ph = expf(dh) * bh;
+        bx = f32x4{pcx - 0.5f * pw, pcy - 0.5f * ph, pcx + 0.5f * pw, pcy + 0.5f * ph};
+      }
+      bool fin = isfinite(bx[0]) && isfinite(bx[1]) && isfinite(bx[2]) && isfinite(bx[3]) && isfinite(sc);
+      bx[0] = fminf(fmaxf(bx[0], 0.f), imw); bx[1] = fminf(fmaxf(bx[1], 0.f), imh);
+      bx[2] = fminf(fmaxf(bx[2], 0.f), imw); bx[3] = fminf(fmaxf(bx[3], 0.f), imh);
+      bool keep = fin && sc > thresh;
+      if (pass == 0) { c.x += keep ? 1 : 0; }
+      else if (keep) {
+        if (ex.x < cap) {
+          size_t o = (size_t)b * cap + ex.x;
+          *reinterpret_cast<f32x4*>(cboxes + 4 * o) = bx;
+          cscores[o] = sc; cclass[o] = k; croi[o] = r;
+          mx = fmaxf(mx, fmaxf(fmaxf(bx[0], bx[1]), fmaxf(bx[2], bx[3])));
+        }
+        ex.x++;
+      }
+    }
+    if (pass == 1 && threadIdx.x == 0) ccount[b] = min(tot.x, cap);
+  }
+  mx = wave_reduce_max(mx);
+  if ((threadIdx.x & 63) == 0) smax[threadIdx.x >> 6] = mx;
+  __syncthreads();
+  if (threadIdx.x == 0) { float m = -INFINITY; for (int w2 = 0; w2 < (int)(blockDim.x >> 6); ++w2) m = fmaxf(m, smax[w2]); cmax[b] = m; }
+}
+extern "C" int unit_detection_candidates(const float* probs, int ldp, const float* deltas, int ldd, const float* props, const int* pcount,
+                                         int B, int Rcap, int K, const float* weights4, float scale_clamp, const float* image_hw_dev,
+                                         float score_thresh, int cap, float* cand_boxes, float* cand_scores, int* cand_class, int* cand_roi,
+                                         int* cand_count, float* cand_max, void* stream) {
+  if (B == 0) return UNIT_OK;
+  f32x4 w = {weights4[0], weights4[1], weights4[2], weights4[3]};
+  det_select_kernel<<<B, 1024, 0, (hipStream_t)stream>>>(probs, ldp, deltas, ldd, props, pcount, Rcap, K, w, scale_clamp, image_hw_dev,
+                                                        score_thresh, cap, cand_boxes, cand_scores, cand_class, cand_roi, cand_count, cand_max);
+  UNIT_LAUNCH_CHECK();
+  return UNIT_OK;
+}
+
+// batched_nms helper: gather candidates into score order and add class * (max_coordinate + 1) to all four coordinates
+__global__ void det_offset_gather_kernel(const float* __restrict__ cboxes, const int* __restrict__ cclass, const int* __restrict__ order,
+                                         const int* __restrict__ ccount, const float* __restrict__ cmax, int cap, float* __restrict__ out) {
+  int b = blockIdx.y;
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= cap) return;
+  f32x4 v = {0, 0, 0, 0};
+  if (i < ccount[b]) {
+    int src = order[(size_t)b * cap + i];
+    v = *reinterpret_cast<const f32x4*>(cboxes + ((size_t)b * cap + src) * 4);
+    float off = (float)cclass[(size_t)b * cap + src] * (cmax[b] + 1.0f);
+    v[0] += off; v[1] += off; v[2] += off; v[3] += off;
+  }
+  *reinterpret_cast<f32x4*>(out + ((size_t)b * cap + i) * 4) = v;
+}
+extern "C" int unit_detection_offset_gather(const float* cand_boxes, const int* cand_class, const int* order, const int* cand_count,
+                                            const float* cand_max, int B, int cap, float* out, void* stream) {
+  if (B == 0 || cap == 0) return UNIT_OK;
+  det_offset_gather_kernel<<<dim3(cdiv(cap, 256), B), 256, 0, (hipStream_t)stream>>>(cand_boxes, cand_class, order, cand_count, cand_max, cap, out);
+  UNIT_LAUNCH_CHECK();
+  return UNIT_OK;
+}
+
+// final gather: keep[j] indexes the score-sorted list; emit boxes (un-offset), scores, classes, roi indices
+__global__ void det_final_kernel(const float* __restrict__ cboxes, const float* __restrict__ cscores, const int* __restrict__ cclass,
+                                 const int* __restrict__ croi, const int* __restrict__ order, const int* __restrict__ keep,
+                                 const int* __restrict__ keep_count, int cap, int topk, float* __restrict__ oboxes, float* __restrict__ oscores,
+                                 int* __restrict__ oclass, int* __restrict__ oroi, int* __restrict__ ocount) {
+  int b = blockIdx.x;
+  int n = min(keep_count[b], topk);
+  for (int j = threadIdx.x; j < topk; j += blockDim.x) {
+    size_t o = (size_t)b * topk + j;
+    if (j < n) {
+      int src = order[(size_t)b * cap + keep[(size_t)b * topk + j]];
+      size_t s = (size_t)b * cap + src;
+      *reinterpret_cast<f32x4*>(oboxes + 4 * o) = *reinterpret_cast<const f32x4*>(cboxes + 4 * s);
+      oscores[o] = cscores[s]; oclass[o] = cclass[s]; oroi[o] = croi[s];
+    } else {
+      *reinterpret_cast<f32x4*>(oboxes + 4 * o) = f32x4{0, 0, 0, 0};
+      oscores[o] = 0.f; oclass[o] = -1; oroi[o] = -1;
+    }
+  }
+  if (threadIdx.x == 0) ocount[b] = n;
+}
+extern "C" int unit_detection_finalize(const float* cand_boxes, const float* cand_scores, const int* cand_class, const int* cand_roi,
+                                       const int* order, const int* keep, const int* keep_count, int B, int cap, int topk,
+                                       float* out_boxes, float* out_scores, int* out_class, int* out_roi, int* out_count, void* stream) {
+  if (B == 0) return UNIT_OK;
+  det_final_kernel<<<B, 128, 0, (hipStream_t)stream>>>(cand_boxes, cand_scores, cand_class, cand_roi, order, keep, keep_count, cap, topk,
+                                                      out_boxes, out_scores, out_class, out_roi, out_count);
+  UNIT_LAUNCH_CHECK();
+  return UNIT_OK;
+}
+
+// detector_postprocess (rcnn.py:411-429 -> detectron2): scale to the output resolution, clip, flag non-empty
+__global__ void postprocess_kernel(float* __restrict__ boxes, const int* __restrict__ count, int topk, const float* __restrict__ scale_xy,
+                                   const float* __restrict__ out_hw, unsigned char* __restrict__ nonempty) {
+  int b = blockIdx.x;
+  for (int j = threadIdx.x; j < topk; j += blockDim.x) {
+    size_t o = (size_t)b * topk + j;
+    f32x4 v = *reinterpret_cast<f32x4*>(boxes + 4 * o);
+    float sx = scale_xy[2 * b], sy = scale_xy[2 * b + 1], oh = out_hw[2 * b], ow = out_hw[2 * b + 1];
+    v[0] = fminf(fmaxf(v[0] * sx, 0.f), ow); v[2] = fminf(fmaxf(v[2] * sx, 0.f), ow);
+    v[1] = fminf(fmaxf(v[1] * sy, 0.f), oh); v[3] = fminf(fmaxf(v[3] * sy, 0.f), oh);
+    *reinterpret_cast<f32x4*>(boxes + 4 * o) = v;
+    nonempty[o] = (j < count[b] && (v[2] - v[0]) > 0.f && (v[3] - v[1]) > 0.f) ? 1 : 0;
+  }
+}
+extern "C" int unit_detector_postprocess(float* boxes, const int* count, int B, int topk, const float* scale_xy_dev, const float* out_hw_dev,
+                                         unsigned char* nonempty, void* stream) {
+  if (B == 0) return UNIT_OK;
+  postprocess_kernel<<<B, 128, 0, (hipStream_t)stream>>>(boxes, count, topk, scale_xy_dev, out_hw_dev, nonempty);
+  UNIT_LAUNCH_CHECK();
+  return UNIT_OK;
+}

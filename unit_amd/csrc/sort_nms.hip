@@ -105,7 +105,7 @@ extern "C" size_t unit_sort_workspace_bytes(int B, int n) { return (size_t)B * 2
 
 extern "C" int unit_sort_desc_stable(const float* src, long batch_stride, int ld, int A, int col0, int B, int n,
                                      float* out_keys, int* out_idx, void* workspace, size_t workspace_bytes, void* stream) {
-  UNIT_CHECK_ARG(n <= 64 * SORT_THREADS, "sort: n too large for the single-workgroup sorter (<= 65536)");
+  UNIT_CHECK_ARG(n <= 1024 * SORT_THREADS, "sort: n too large for the single-workgroup sorter (<= 1M keys)");
   if (workspace_bytes < unit_sort_workspace_bytes(B, n)) { unit_set_error("sort: workspace too small"); return UNIT_ERR_WORKSPACE; }
   if (B == 0 || n == 0) return UNIT_OK;
   unsigned* kbuf = (unsigned*)workspace;
@@ -156,7 +156,7 @@ __global__ void nms_mask_kernel(const float* __restrict__ boxes, const int* __re
   mask[((size_t)b * cap + i) * nw + cb] = bits;
 }
 
-#define NMS_SCAN_THREADS 256
+#define NMS_SCAN_THREADS 1024
 __global__ void __launch_bounds__(NMS_SCAN_THREADS) nms_scan_kernel(const float* __restrict__ boxes, const float* __restrict__ scores,
                                                             const int* __restrict__ count, int cap, int nw,
                                                             const unsigned long long* __restrict__ mask, int max_keep,
@@ -227,7 +227,8 @@ extern "C" int unit_nms(const float* boxes_sorted, const float* scores_sorted, c
                         float thresh, int max_keep, int* keep_idx, int* keep_count, float* out_boxes, float* out_scores,
                         void* workspace, size_t workspace_bytes, void* stream) {
   int nw = (cap + 63) / 64;
-  UNIT_CHECK_ARG(nw <= NMS_SCAN_THREADS, "nms: more than 16384 candidates per image");
+  UNIT_CHECK_ARG(nw <= NMS_SCAN_THREADS, "nms: more than 65536 candidates per image");
+  int scan_threads = nw <= 256 ? 256 : ((nw + 63) / 64) * 64;
   if (workspace_bytes < unit_nms_workspace_bytes(B, cap)) { unit_set_error("nms: workspace too small"); return UNIT_ERR_WORKSPACE; }
   if (B == 0) return UNIT_OK;
   hipStream_t st = (hipStream_t)stream;
@@ -235,7 +236,7 @@ extern "C" int unit_nms(const float* boxes_sorted, const float* scores_sorted, c
     nms_mask_kernel<<<dim3(nw, nw, B), 64, 0, st>>>(boxes_sorted, count, cap, nw, thresh, (unsigned long long*)workspace);
     UNIT_LAUNCH_CHECK();
   }
-  nms_scan_kernel<<<B, NMS_SCAN_THREADS, 0, st>>>(boxes_sorted, scores_sorted, count, cap, nw, (const unsigned long long*)workspace,
+  nms_scan_kernel<<<B, scan_threads, 0, st>>>(boxes_sorted, scores_sorted, count, cap, nw, (const unsigned long long*)workspace,
                                                   max_keep, keep_idx, keep_count, out_boxes, out_scores);
   UNIT_LAUNCH_CHECK();
   return UNIT_OK;

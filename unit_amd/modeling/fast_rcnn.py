@@ -134,3 +134,13 @@ class SupervisedDetectorOutputsBase(nn.Module):
 @FAST_RCNN_REGISTRY.register()
 class SupervisedDetectorOutputsFineTune(SupervisedDetectorOutputsBase):
     finetune = True
+
+    # ---- a14: SupervisedDetectorOutputsFineTune.forward fast_rcnn.py:484-533 (scores/bbox assembled by
+    # unit_transfer_predictions incl. the zero-initialised *_ft heads; no -inf fill) + FastRCNNOutputs.losses
+    def ft_losses(self, scores, bbox, roi_cls, rois5, roi_gt, loss_out, grad_dtype):
+        """d(loss)/d(scores|bbox) == d(loss)/d([cls_score_ft | bbox_pred_ft] outputs): the ft heads enter additively."""
+        k = self.num_classes
+        dy = torch.zeros((scores.shape[0], self.group_ft.kp), dtype=grad_dtype, device=scores.device)
+        ops.softmax_ce(scores, 0, k + 1, roi_cls, dy=dy, dcol0=self.col_cls, loss_out=loss_out[0:1])
+        ops.box_reg_loss(bbox, 0, k, roi_cls, rois5, roi_gt, self.bbox_reg_weights, dy=dy, dcol0=self.col_bbox, loss_out=loss_out[1:2])
+        return dy

@@ -277,8 +277,21 @@ class WeaklySupervisedRCNNNoMeta(nn.Module):
         if rs > 0:
             lin_sup = bp.group.fwd(c.box_feat)
             if getattr(bp, "finetune", False):
-                raise NotImplementedError("fine-tune predictor runs through forward_finetune")
-            c.dy_sup, c.scores = bp.sup_losses(lin_sup, lin_weak_all[:rs], c.roi_cls, c.rois[:rs], c.roi_gt, c.losses[0:2], dt)
+                # a14 (roi_heads.py:595-644 + fast_rcnn.py:484-533): similarity transfer is active in TRAINING too
+                from .inference import class_roles, similarity_matrices
+                frozen = not any(p.requires_grad for n, p in bp.named_parameters() if not n.split(".")[0].endswith("_ft"))
+                assert frozen and not box_trainable, "fine-tune step: everything but cls_score_ft / bbox_pred_ft must be frozen " \
+                                                     "(configs/VOC/FT/*/...-ft.yaml FREEZE_LAYERS)"
+                wh = bp.weak_detector_head
+                lin_ft = bp.group_ft.fwd(c.box_feat)
+                sim_cls, sim_bbox = similarity_matrices(self, wh.group.fwd(c.box_feat))
+                t = class_roles(self)
+                c.scores, bbox = ops.transfer_predictions(lin_sup, bp.col_cls, bp.col_bbox, rh.num_classes, lin_weak_all[:rs], wh.col_oicr[0],
+                                                          wh.oicr_iter, sim_cls, sim_bbox, t["base"], t["novel"], t["role"], t["slot"],
+                                                          ft=lin_ft, fccol0=bp.col_cls, fbcol0=bp.col_bbox)
+                c.dy_sup = bp.ft_losses(c.scores, bbox, c.roi_cls, c.rois[:rs], c.roi_gt, c.losses[0:2], dt)
+            else:
+                c.dy_sup, c.scores = bp.sup_losses(lin_sup, lin_weak_all[:rs], c.roi_cls, c.rois[:rs], c.roi_gt, c.losses[0:2], dt)
         if rw > 0:
             c.dy_weak = bp.weak_detector_head.losses(lin_weak_all[rs:], c.rois[rs:], c.weak_valid, s // rh.weak_divisor, n_weak,
                                                      batch.multihot, c.losses[2:6], dt)
@@ -297,7 +310,9 @@ class WeaklySupervisedRCNNNoMeta(nn.Module):
         box_trainable = c.box_ctx is not None
 
         dbox = dweak = None
-        if c.dy_sup is not None:
+        if c.dy_sup is not None and getattr(bp, "finetune", False):
+            bp.group_ft.bwd(c.box_feat, c.dy_sup, need_dx=False)      # the only trainable tensors of the fine-tune step
+        elif c.dy_sup is not None:
             dbox = bp.group.bwd(c.box_feat, c.dy_sup, need_dx=box_trainable or bb_trainable)
         if c.dy_weak is not None:
             dweak = bp.weak_detector_head.group.bwd(c.weak_feat, c.dy_weak, need_dx=True)
@@ -312,10 +327,11 @@ class WeaklySupervisedRCNNNoMeta(nn.Module):
                 done("weak_box_head")
         else:
             parts = [t for t in (dbox, dweak) if t is not None]
-            dall = torch.cat(parts, 0) if len(parts) > 1 else parts[0]
-            dpool = rh.box_head.bwd(c.box_ctx, dall)
-            done("box_head")
-            dpool_sup, dpool_weak = (dpool[:rs] if rs > 0 else None), (dpool[rs:] if rw > 0 else None)
+            if parts and box_trainable:
+                dall = torch.cat(parts, 0) if len(parts) > 1 else parts[0]
+                dpool = rh.box_head.bwd(c.box_ctx, dall)
+                done("box_head")
+                dpool_sup, dpool_weak = (dpool[:rs] if rs > 0 else None), (dpool[rs:] if rw > 0 else None)
 
         drpn = None
         if c.dhead is not None and any(p.requires_grad for p in rpn.rpn_head.parameters()):

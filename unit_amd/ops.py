@@ -493,6 +493,82 @@ def oicr_targets(src, col0, mode, k, rois5, valid, s, b, multihot, fg_thresh=0.5
     return labels, weights
 
 
+# ------------------------------------------------------------------------------------------------ a14 / a15
+def embedding_similarity(emb, novel_rows, base_rows):
+    """fast_rcnn.py:376-382: E[novel] @ E[base]^T (row index lists are device int32 tensors)"""
+    out = torch.empty((novel_rows.numel(), base_rows.numel()), dtype=torch.float32, device=emb.device)
+    check(lib().unit_embedding_similarity(_p(emb), emb.shape[1], emb.shape[1], _p(novel_rows), novel_rows.numel(), _p(base_rows),
+                                          base_rows.numel(), _p(out), _s()), "embedding_similarity")
+    return out
+
+
+def similarity(lin_weak, col0, n_oicr, ncls, base_dev, lingual, n_novel, visual_threshold, use_lingual=True, use_visual=True):
+    r = lin_weak.shape[0]
+    nb = base_dev.numel()
+    sim = torch.empty((r, n_novel, nb), dtype=torch.float32, device=lin_weak.device)
+    check(lib().unit_similarity(_p(lin_weak), lin_weak.shape[1], col0, n_oicr, ncls, _p(base_dev), nb, _p(lingual), n_novel,
+                                float(visual_threshold), int(use_lingual), int(use_visual), _p(sim), r, _s()), "similarity")
+    return sim
+
+
+def transfer_predictions(lin, ccol0, bcol0, k, weak, wcol0, n_oicr, sim_cls, sim_bbox, base_dev, novel_dev, role_dev, slot_dev,
+                         ft=None, fccol0=0, fbcol0=0):
+    """-> (scores [R,K+1], bbox [R,4K]) of SupervisedDetectorOutputs*.forward (eval / fine-tune branches)."""
+    r = lin.shape[0]
+    scores = torch.empty((r, k + 1), dtype=torch.float32, device=lin.device)
+    bbox = torch.empty((r, 4 * k), dtype=torch.float32, device=lin.device)
+    check(lib().unit_transfer_predictions(_p(lin), lin.shape[1], ccol0, bcol0, k, _p(weak), weak.shape[1] if weak is not None else 0, wcol0,
+                                          n_oicr, _p(ft), ft.shape[1] if ft is not None else 0, fccol0, fbcol0, _p(sim_cls), _p(sim_bbox),
+                                          _p(base_dev), base_dev.numel(), _p(novel_dev), novel_dev.numel(), _p(role_dev), _p(slot_dev),
+                                          _p(scores), k + 1, _p(bbox), 4 * k, r, _s()), "transfer_predictions")
+    return scores, bbox
+
+
+def softmax_rows(x, ncls):
+    y = torch.empty((x.shape[0], ncls), dtype=torch.float32, device=x.device)
+    check(lib().unit_softmax_rows(_p(x), x.shape[1], ncls, _p(y), ncls, x.shape[0], _s()), "softmax_rows")
+    return y
+
+
+def detections(probs, deltas, props, pcount, image_hw, weights, score_thresh, nms_thresh, topk, cand_cap=None):
+    """fast_rcnn_inference for B images: probs [B*Rcap, K+1], deltas [B*Rcap, 4K], props [B,Rcap,4], pcount [B] (device)
+    -> (boxes [B,topk,4], scores [B,topk], classes [B,topk], roi_idx [B,topk], count [B])"""
+    b, rcap = props.shape[0], props.shape[1]
+    k = deltas.shape[1] // 4
+    dev = probs.device
+    cap = cand_cap or min(rcap * k, 65536)
+    cb = torch.empty((b, cap, 4), dtype=torch.float32, device=dev)
+    cs = torch.zeros((b, cap), dtype=torch.float32, device=dev)
+    cc = torch.empty((b, cap), dtype=torch.int32, device=dev)
+    cr = torch.empty((b, cap), dtype=torch.int32, device=dev)
+    cnt = torch.empty((b,), dtype=torch.int32, device=dev)
+    cmax = torch.empty((b,), dtype=torch.float32, device=dev)
+    w = (ctypes.c_float * 4)(*weights)
+    check(lib().unit_detection_candidates(_p(probs), probs.shape[1], _p(deltas), deltas.shape[1], _p(props), _p(pcount), b, rcap, k, w,
+                                          SCALE_CLAMP, _p(image_hw), float(score_thresh), cap, _p(cb), _p(cs), _p(cc), _p(cr), _p(cnt),
+                                          _p(cmax), _s()), "detection_candidates")
+    # stable descending sort of the candidate scores (unused tail slots hold 0 <= thresh and sort behind every candidate)
+    _, order = sort_desc(cs, b, cap)
+    ob = torch.empty((b, cap, 4), dtype=torch.float32, device=dev)
+    check(lib().unit_detection_offset_gather(_p(cb), _p(cc), _p(order), _p(cnt), _p(cmax), b, cap, _p(ob), _s()), "detection_offset_gather")
+    keep, kc, _, _ = nms(ob, cs, cnt, nms_thresh, topk)
+    oboxes = torch.empty((b, topk, 4), dtype=torch.float32, device=dev)
+    oscores = torch.empty((b, topk), dtype=torch.float32, device=dev)
+    ocls = torch.empty((b, topk), dtype=torch.int32, device=dev)
+    oroi = torch.empty((b, topk), dtype=torch.int32, device=dev)
+    ocnt = torch.empty((b,), dtype=torch.int32, device=dev)
+    check(lib().unit_detection_finalize(_p(cb), _p(cs), _p(cc), _p(cr), _p(order), _p(keep), _p(kc), b, cap, topk, _p(oboxes), _p(oscores),
+                                        _p(ocls), _p(oroi), _p(ocnt), _s()), "detection_finalize")
+    return oboxes, oscores, ocls, oroi, ocnt
+
+
+def detector_postprocess(boxes, count, scale_xy, out_hw):
+    b, topk = boxes.shape[0], boxes.shape[1]
+    nonempty = torch.empty((b, topk), dtype=torch.uint8, device=boxes.device)
+    check(lib().unit_detector_postprocess(_p(boxes), _p(count), b, topk, _p(scale_xy), _p(out_hw), _p(nonempty), _s()), "detector_postprocess")
+    return nonempty
+
+
 def sum_losses(losses, out=None):
     out = out if out is not None else torch.empty(1, dtype=torch.float32, device=losses.device)
     check(lib().unit_sum_losses(_p(losses), losses.numel(), _p(out), _s()), "sum_losses")
