@@ -161,6 +161,18 @@ int unit_detection_finalize(const float* cand_boxes, const float* cand_scores, c
 int unit_detector_postprocess(float* boxes, const int* count, int B, int topk, const float* scale_xy_dev, const float* out_hw_dev,
                               unsigned char* nonempty, void* stream);
 
+/* ---- a16 mask head: modeling/roi_heads/mask_head.py:16-37, roi_heads.py:654-710 (+ detectron2 mask_rcnn_loss/inference,
+ * BitMasks.crop_and_resize). The 2x2/s2 ConvTranspose2d is one 1x1 GEMM with 4*Cout columns run by unit_conv2d_fwd. ---- */
+int unit_deconv2x2_weight_prep(const float* w, int Cin, int Cout, void* w_fwd, void* w_dgrad, int dtype, void* stream);
+int unit_deconv2x2_grad_unpack(const float* dw_gemm, const float* db_gemm, int Cin, int Cout, float* dw, float* db, void* stream);
+int unit_mask_targets(const unsigned char* gt_masks, int Mcap, int Hm, int Wm, const float* rois5, const int* gt_index, const int* cls,
+                      int K, int S, int M, unsigned char* out, void* stream);
+int unit_mask_bce_loss(const float* logits, int K, int ldk, const int* cls, const unsigned char* targets, int S, int M, float gscale,
+                       float* loss, void* dlogits, int d_dtype, void* stream);
+int unit_mask_probs(const float* logits, int K, int ldk, const int* cls, const float* sim, const int* base_dev, int n_base, int n_novel,
+                    const int8_t* role_dev, const int* slot_dev, int S, int M, float* out, void* stream);
+int unit_gather_match_index(const int* sampled_idx, int S, const int64_t* match_idx, int Ncap, int B, int* out, void* stream);
+
 /* ---- K18 SGD momentum (solver/build.py:110-112) ---- */
 int unit_sgd_momentum(float* p, const float* g, float* buf, long n, float lr, float momentum, float wd, float grad_scale,
                       int first_step, void* stream);

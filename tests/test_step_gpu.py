@@ -7,7 +7,9 @@ import torch
 import unit_oracle as orc
 from unit_amd import config
 from unit_amd.modeling import build_model
-from unit_amd.modeling.rcnn import LOSS_NAMES
+from unit_amd.modeling.rcnn import LOSS_NAMES as _ALL_LOSS_NAMES
+
+LOSS_NAMES = _ALL_LOSS_NAMES[:8]   # the VOC step has no mask head (loss_mask is the 9th slot of the loss vector)
 from unit_amd.solver import FlatSGD
 from unit_amd.synthetic import init_synthetic_weights, synthetic_batch
 
@@ -131,11 +133,11 @@ def test_autograd_surface_and_sgd(dev):
     opt.step()
     assert not torch.equal(w_before, model.store.params)
     l0 = torch.stack([loss_dict[k] for k in LOSS_NAMES]).detach().cpu()
-    l1 = model.train_step(batch, None, perms).cpu()
+    l1 = model.train_step(batch, None, perms).cpu()[:8]
     assert not torch.allclose(l0, l1)      # weights changed -> losses changed (layers re-prepared their bf16/fp32 copies)
     model.store.params.copy_(w_before)
     model.version += 1
-    l2 = model.train_step(batch, None, perms).cpu()
+    l2 = model.train_step(batch, None, perms).cpu()[:8]
     assert torch.allclose(l0, l2, rtol=1e-6, atol=1e-7)
     assert torch.allclose(model.store.grads, g1, rtol=1e-4, atol=1e-6)
 
@@ -220,3 +222,55 @@ def test_inference_parity_fp32(dev):
     assert torch.equal(out._roi_index.cpu().long(), r)
     assert torch.allclose(out.scores.cpu(), s, rtol=1e-4, atol=1e-5)
     assert torch.allclose(out.pred_boxes.tensor.cpu(), b, rtol=1e-4, atol=2e-2)
+
+
+def test_mask_step_parity_fp32(dev):
+    """a16: C4-segm configuration (configs/COCO/COCO-RCNN-50-C4-split1-segm.yaml shape: MASK_ON, WSROIHeadNoMetaWithMask,
+    Res5BoxHeadWithMask, single box head, mask head on the fg RoIs' res5 map) -- losses incl. loss_mask and the gradients of
+    the mask head, the shared Res5 head and the backbone against the oracle."""
+    cfg = small_cfg()
+    cfg.MODEL.MASK_ON = True
+    cfg.MODEL.ROI_HEADS.NAME = "WSROIHeadNoMetaWithMask"
+    cfg.MODEL.ROI_BOX_HEAD.NAME = "Res5BoxHeadWithMask"
+    cfg.MODEL.ROI_HEADS.MULTI_BOX_HEAD = False
+    model = build_model(cfg)
+    init_synthetic_weights(model, seed=5)
+    with torch.no_grad():
+        g = torch.Generator().manual_seed(3)
+        model.roi_heads.mask_head.predictor.weight.copy_(torch.randn(20, 256, 1, 1, generator=g) * 0.05)
+    from unit_amd.layers import invalidate_prepared
+    invalidate_prepared()
+    model.train()
+    model.compute_dtype = torch.float32
+    sup, weak = synthetic_batch(2, 2, hw=(128, 192), seed=9, max_gt=4)
+    masks = []
+    for x in sup:   # bitmask = ellipse inscribed in the GT box
+        b = x["instances"].gt_boxes.tensor
+        yy, xx = torch.meshgrid(torch.arange(128.0), torch.arange(192.0), indexing="ij")
+        m = torch.stack([(((xx - (bb[0] + bb[2]) / 2) / ((bb[2] - bb[0]) / 2)) ** 2 + ((yy - (bb[1] + bb[3]) / 2) / ((bb[3] - bb[1]) / 2)) ** 2) <= 1.0
+                         for bb in b])
+        x["instances"].gt_masks = m
+        masks.append(m)
+    batch = model.pack_batch(sup, weak)
+    assert batch.gt_masks is not None
+    model._ensure_ready()
+    perms = model.sampling_permutations(2, 8 * 12 * 15, cfg.MODEL.RPN.POST_NMS_TOPK_TRAIN + batch.gt_boxes.shape[1])
+    step = model.forward_train(batch, perms)
+    model.backward_train(step)
+    got = dict(zip(_ALL_LOSS_NAMES, step.losses.cpu().tolist()))
+    p = _oracle_params(model)
+    operms = dict(rpn=[x.long().cpu() for x in perms["rpn"]], roi=[x.long().cpu() for x in perms["roi"]])
+    ref, aux = orc.step_losses(p, [x["image"] for x in sup], [x["instances"].gt_boxes.tensor for x in sup],
+                               [x["instances"].gt_classes for x in sup], [x["image"] for x in weak], [x["instances"].gt_classes for x in weak],
+                               operms, _ocfg(cfg, multi_box_head=False, mask_on=True, gt_masks=masks))
+    sum(ref.values()).backward()
+    assert ref["loss_mask"].item() > 0.1
+    for k in _ALL_LOSS_NAMES:
+        assert abs(got[k] - ref[k].item()) <= 1e-4 * max(1.0, abs(ref[k].item())), (k, got[k], ref[k].item())
+    for name in ("roi_heads.mask_head.deconv.weight", "roi_heads.mask_head.deconv.bias", "roi_heads.mask_head.predictor.weight",
+                 "roi_heads.mask_head.predictor.bias", "roi_heads.box_head.res5.2.conv3.weight", "roi_heads.box_head.res5.0.conv1.weight",
+                 "backbone.res4.5.conv3.weight", "backbone.res3.0.conv1.weight"):
+        gd = dict(model.named_parameters())[name].grad.detach().cpu()
+        gr = p[name].grad
+        assert (gd - gr).abs().max() <= 2e-3 * gr.abs().max() + 1e-8, (name, (gd - gr).abs().max(), gr.abs().max())
+    assert "roi_heads.weak_box_head.res5.0.conv1.weight" not in p

@@ -1,0 +1,188 @@
+// mask.hip -- Mask-RCNN head pieces for the C4-segm configuration:
+//   MaskRCNNConvUpsampleHeadWithSimilarity.forward  /root/reference/modeling/roi_heads/mask_head.py:16-37
+//   (detectron2 MaskRCNNConvUpsampleHead: ConvTranspose2d(2048,256,k2,s2) -> ReLU -> Conv2d(256,K,1); mask_rcnn_loss /
+//    mask_rcnn_inference; BitMasks.crop_and_resize).
+// The 2x2 stride-2 transposed conv has no overlapping taps: it is ONE 1x1 GEMM with 4*Cout output columns
+// ([q = dy*2+dx][oc]) evaluated by the conv kernel; the output pixel (2y+dy, 2x+dx) lives at [roi, y, x, q, oc].  The 1x1
+// predictor and the loss work directly on that layout, so no pixel shuffle is ever materialised.
+#include "common.h"
+
+// ConvTranspose2d weight fp32 [Cin][Cout][2][2] -> forward GEMM weight [4*Cout][Cin] and dgrad weight [Cin][4*Cout]
+template <typename T>
+__global__ void deconv_prep_kernel(const float* __restrict__ w, int Cin, int Cout, T* __restrict__ wf, T* __restrict__ wd) {
+  long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  long total = (long)Cin * Cout * 4;
+  if (idx >= total) return;
+  int q = idx % 4; long t = idx / 4; int oc = t % Cout; int ic = t / Cout;
+  float v = w[idx];                                   // w[ic][oc][dy][dx], q = dy*2+dx
+  wf[((size_t)q * Cout + oc) * Cin + ic] = (T)v;
+  wd[(size_t)ic * (4 * Cout) + q * Cout + oc] = (T)v;
+}
+extern "C" int unit_deconv2x2_weight_prep(const float* w, int Cin, int Cout, void* w_fwd, void* w_dgrad, int dtype, void* stream) {
+  long total = (long)Cin * Cout * 4;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == UNIT_BF16) deconv_prep_kernel<bf16_t><<<cdiv(total, 256), 256, 0, st>>>(w, Cin, Cout, (bf16_t*)w_fwd, (bf16_t*)w_dgrad);
+  else deconv_prep_kernel<float><<<cdiv(total, 256), 256, 0, st>>>(w, Cin, Cout, (float*)w_fwd, (float*)w_dgrad);
+  UNIT_LAUNCH_CHECK();
+  return UNIT_OK;
+}
+// gradient of the GEMM weight [4*Cout][Cin] -> ConvTranspose2d layout [Cin][Cout][2][2]; bias grad: sum over the 4 taps
+__global__ void deconv_unpack_kernel(const float* __restrict__ dwp, const float* __restrict__ dbp, int Cin, int Cout, float* __restrict__ dw,
+                                     float* __restrict__ db) {
+  long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  long total = (long)Cin * Cout * 4;
+  if (idx < total) {
+    int q = idx % 4; long t = idx / 4; int oc = t % Cout; int ic = t / Cout;
+    dw[idx] = dwp[((size_t)q * Cout + oc) * Cin + ic];
+  }
+  if (db && idx < Cout) db[idx] = dbp[idx] + dbp[Cout + idx] + dbp[2 * Cout + idx] + dbp[3 * Cout + idx];
+}
+extern "C" int unit_deconv2x2_grad_unpack(const float* dw_gemm, const float* db_gemm, int Cin, int Cout, float* dw, float* db, void* stream) {
+  long total = (long)Cin * Cout * 4;
+  deconv_unpack_kernel<<<cdiv(total, 256), 256, 0, (hipStream_t)stream>>>(dw_gemm, db_gemm, Cin, Cout, dw, db);
+  UNIT_LAUNCH_CHECK();
+  return UNIT_OK;
+}
+
+// BitMasks.crop_and_resize: ROIAlign((M,M), 1.0, 0, aligned=True) on the float bitmask, then >= 0.5.
+// gt_masks u8 [B][Mcap][Hm][Wm]; slot s uses mask (image = rois5[s][0], instance = gt_index[s]); cls < 0 slots -> 0.
+__global__ void mask_targets_kernel(const unsigned char* __restrict__ masks, int Mcap, int Hm, int Wm, const float* __restrict__ rois5,
+                                    const int* __restrict__ gt_index, const int* __restrict__ cls, int K, int M, unsigned char* __restrict__ out) {
+  int s = blockIdx.x;
+  int c = cls[s];
+  for (int bin = threadIdx.x; bin < M * M; bin += blockDim.x) {
+    unsigned char v = 0;
+    if (c >= 0 && c < K) {
+      int ph = bin / M, pw = bin - ph * M;
+      const float* roi = rois5 + 5 * (size_t)s;
+      int b = (int)roi[0];
+      const unsigned char* mk = masks + ((size_t)b * Mcap + gt_index[s]) * Hm * Wm;
+      float sw = roi[1] - 0.5f, sh = roi[2] - 0.5f, ew = roi[3] - 0.5f, eh = roi[4] - 0.5f;
+      float rw = ew - sw, rh = eh - sh;
+      float bh = rh / (float)M, bw = rw / (float)M;
+      int gh = (int)ceilf(rh / (float)M), gw = (int)ceilf(rw / (float)M);
+      float count = (float)(gh * gw > 1 ? gh * gw : 1);
+      float acc = 0.f;
+      for (int iy = 0; iy < gh; ++iy) {
+        float y = sh + (float)ph * bh + ((float)iy + 0.5f) * bh / (float)gh;
+        for (int ix = 0; ix < gw; ++ix) {
+          float x = sw + (float)pw * bw + ((float)ix + 0.5f) * bw / (float)gw;
+          if (y < -1.0f || y > (float)Hm || x < -1.0f || x > (float)Wm) continue;
+          float yy = y <= 0.f ? 0.f : y, xx = x <= 0.f ? 0.f : x;
+          int yl = (int)yy, xl = (int)xx, yh, xh;
+          if (yl >= Hm - 1) { yh = yl = Hm - 1; yy = (float)yl; } else yh = yl + 1;
+          if (xl >= Wm - 1) { xh = xl = Wm - 1; xx = (float)xl; } else xh = xl + 1;
+          float ly = yy - (float)yl, lx = xx - (float)xl, hy = 1.f - ly, hx = 1.f - lx;
+          float val = hy * hx * (float)mk[yl * Wm + xl] + hy * lx * (float)mk[yl * Wm + xh] + ly * hx * (float)mk[yh * Wm + xl] +
+                      ly * lx * (float)mk[yh * Wm + xh];
+          acc += val;
+        }
+      }
+      v = (acc / count) >= 0.5f ? 1 : 0;
+    }
+    out[(size_t)s * M * M + bin] = v;
+  }
+}
+extern "C" int unit_mask_targets(const unsigned char* gt_masks, int Mcap, int Hm, int Wm, const float* rois5, const int* gt_index,
+                                 const int* cls, int K, int S, int M, unsigned char* out, void* stream) {
+  if (S == 0) return UNIT_OK;
+  mask_targets_kernel<<<S, 256, 0, (hipStream_t)stream>>>(gt_masks, Mcap, Hm, Wm, rois5, gt_index, cls, K, M, out);
+  UNIT_LAUNCH_CHECK();
+  return UNIT_OK;
+}
+
+// mask_rcnn_loss: mean over (#fg slots x M x M) of BCE-with-logits on the gt-class channel. logits [S][P][P][4][K] fp32
+// (P = M/2); pixel (Y,X) -> [Y/2][X/2][(Y&1)*2 + (X&1)]. Emits d(loss)/d(logits) in the same layout (dtype TD).
+template <typename TD>
+__global__ void mask_loss_kernel(const float* __restrict__ logits, int K, int ldk, const int* __restrict__ cls, const unsigned char* __restrict__ tgt,
+                                 int S, int M, float gscale, float* __restrict__ loss, TD* __restrict__ dlogits) {
+  __shared__ float lds[18];
+  int P = M / 2;
+  float cnt = 0.f;
+  for (int s = threadIdx.x; s < S; s += blockDim.x) cnt += (cls[s] >= 0 && cls[s] < K) ? 1.f : 0.f;
+  cnt = wave_reduce_sum(cnt);
+  if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = cnt;
+  __syncthreads();
+  if (threadIdx.x == 0) { float t = 0.f; for (int w = 0; w < (int)(blockDim.x >> 6); ++w) t += lds[w]; lds[16] = t; }
+  __syncthreads();
+  float nfg = lds[16];
+  float inv = nfg > 0.f ? 1.f / (nfg * (float)(M * M)) : 0.f;
+  float acc = 0.f;
+  long total = (long)S * M * M;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    int s = i / (M * M); int r = i - (long)s * M * M; int Y = r / M, X = r - Y * M;
+    int c = cls[s];
+    if (c < 0 || c >= K) continue;
+    size_t o = ((((size_t)s * P + (Y >> 1)) * P + (X >> 1)) * 4 + ((Y & 1) * 2 + (X & 1))) * ldk + c;
+    float x = logits[o], y = (float)tgt[i];
+    acc += fmaxf(x, 0.f) - x * y + log1pf(expf(-fabsf(x)));
+    if (dlogits) dlogits[o] = (TD)((1.f / (1.f + expf(-x)) - y) * inv * gscale);
+  }
+  acc = wave_reduce_sum(acc);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) { float t = 0.f; for (int w = 0; w < (int)(blockDim.x >> 6); ++w) t += lds[w]; atomicAdd(loss, t * inv); }
+}
+extern "C" int unit_mask_bce_loss(const float* logits, int K, int ldk, const int* cls, const unsigned char* targets, int S, int M,
+                                  float gscale, float* loss, void* dlogits, int d_dtype, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  (void)hipMemsetAsync(loss, 0, sizeof(float), st);
+  if (S == 0) return UNIT_OK;
+  size_t esz = d_dtype == UNIT_BF16 ? 2 : 4;
+  if (dlogits) (void)hipMemsetAsync(dlogits, 0, (size_t)S * M * M * ldk * esz, st);
+  int blocks = min(1024, cdiv((long)S * M * M, 256));
+  if (d_dtype == UNIT_BF16) mask_loss_kernel<bf16_t><<<blocks, 256, 0, st>>>(logits, K, ldk, cls, targets, S, M, gscale, loss, (bf16_t*)dlogits);
+  else mask_loss_kernel<float><<<blocks, 256, 0, st>>>(logits, K, ldk, cls, targets, S, M, gscale, loss, (float*)dlogits);
+  UNIT_LAUNCH_CHECK();
+  return UNIT_OK;
+}
+
+// mask_rcnn_inference (+ the base->novel mask transfer of mask_head.py:18-31 for the predicted class):
+// prob[s][Y][X] = sigmoid(logit of pred class)  where for a novel class j: logit = sum_b sim[s][j][b] * logit[base_b]
+__global__ void mask_probs_kernel(const float* __restrict__ logits, int K, int ldk, const int* __restrict__ cls, const float* __restrict__ sim,
+                                  const int* __restrict__ base, int n_base, int n_novel, const int8_t* __restrict__ role,
+                                  const int* __restrict__ slot, int S, int M, float* __restrict__ out) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  long total = (long)S * M * M;
+  if (i >= total) return;
+  int P = M / 2;
+  int s = i / (M * M); int r = i - (long)s * M * M; int Y = r / M, X = r - Y * M;
+  int c = cls[s];
+  float v = 0.f;
+  if (c >= 0 && c < K) {
+    const float* row = logits + ((((size_t)s * P + (Y >> 1)) * P + (X >> 1)) * 4 + ((Y & 1) * 2 + (X & 1))) * ldk;
+    float x;
+    if (sim && role[c] == 2) {
+      const float* sm = sim + ((size_t)s * n_novel + slot[c]) * n_base;
+      x = 0.f;
+      for (int b = 0; b < n_base; ++b) x += sm[b] * row[base[b]];
+    } else if (sim && role[c] == 0) x = 0.f;
+    else x = row[c];
+    v = 1.f / (1.f + expf(-x));
+  }
+  out[i] = v;
+}
+extern "C" int unit_mask_probs(const float* logits, int K, int ldk, const int* cls, const float* sim, const int* base_dev, int n_base,
+                               int n_novel, const int8_t* role_dev, const int* slot_dev, int S, int M, float* out, void* stream) {
+  if (S == 0) return UNIT_OK;
+  mask_probs_kernel<<<cdiv((long)S * M * M, 256), 256, 0, (hipStream_t)stream>>>(logits, K, ldk, cls, sim, base_dev, n_base, n_novel, role_dev,
+                                                                                slot_dev, S, M, out);
+  UNIT_LAUNCH_CHECK();
+  return UNIT_OK;
+}
+
+// index of the matched GT instance of every sampled RoI slot (gt_masks[matched_idx[sampled]] in label_and_sample_proposals)
+__global__ void gather_match_index_kernel(const int* __restrict__ sidx, int S, const int64_t* __restrict__ midx, int Ncap, int* __restrict__ out) {
+  int b = blockIdx.y;
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= S) return;
+  int id = sidx[(size_t)b * S + i];
+  out[(size_t)b * S + i] = id >= 0 ? (int)midx[(size_t)b * Ncap + id] : 0;
+}
+extern "C" int unit_gather_match_index(const int* sampled_idx, int S, const int64_t* match_idx, int Ncap, int B, int* out, void* stream) {
+  if (B == 0 || S == 0) return UNIT_OK;
+  gather_match_index_kernel<<<dim3(cdiv(S, 256), B), 256, 0, (hipStream_t)stream>>>(sampled_idx, S, match_idx, Ncap, out);
+  UNIT_LAUNCH_CHECK();
+  return UNIT_OK;
+}

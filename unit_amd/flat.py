@@ -48,7 +48,7 @@ class FlatStore:
     def _view(flat, off, p):
         n = p.numel()
         seg = flat[off:off + n]
-        if p.dim() == 4:
+        if p.dim() == 4 and not getattr(p, "_unit_plain_layout", False):
             k, c, r, s = p.shape
             return seg.view(k, r, s, c).permute(0, 3, 1, 2)   # logical [K,C,R,S], physical [K][R][S][C]
         return seg.view(p.shape)

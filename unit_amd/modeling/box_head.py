@@ -37,28 +37,33 @@ class Res5BoxHead(nn.Module):
             for c in b.convs():
                 c.prepare(dtype, version, need_dgrad=True)
 
-    def fwd(self, pooled, save=False):
-        """pooled [R,14,14,C] (full) or [R,7,7,C] (strided) -> ([R,2048] | [R,7,7,2048], ctx)"""
+    def fwd(self, pooled, save=False, keep_map=False):
+        """pooled [R,14,14,C] (full) or [R,7,7,C] (strided) -> (mean-pooled features [R,2048], ctx).
+        ctx = (block contexts, res5 output map [R,7,7,2048]); `keep_map` keeps the map even without `save` (mask head input:
+        Res5BoxHeadWithMask hands the un-pooled map to the mask head, roi_heads.py:691-710, and its mean to the predictor,
+        roi_heads.py:735-744)."""
         first_stride = 1 if pooled.shape[1] == 7 else 2
         y, ctxs = self.res5.fwd(pooled, save=save, first_stride=first_stride)
-        out = ops.global_avgpool(y) if self.do_mean else y
-        return out, ((ctxs, y) if save else None)
+        return ops.global_avgpool(y), ((ctxs, y) if (save or keep_map) else None)
 
-    def bwd(self, ctx, dfeat, row_slice=None):
-        """dfeat: d(loss)/d(features) [R,2048] (mean) -> d(loss)/d(pooled).  row_slice: backprop only these RoI rows."""
+    def bwd(self, ctx, dfeat, row_slice=None, map_grad_hook=None):
+        """dfeat: d(loss)/d(mean features) [R,2048] -> d(loss)/d(pooled). row_slice: backprop only these RoI rows.
+        map_grad_hook(g, y): adds further (ReLU-masked) gradient on the res5 output map in place (mask head)."""
         ctxs, y = ctx
         if row_slice is not None:
             y = y[row_slice]
             ctxs = [tuple(t[row_slice] if torch.is_tensor(t) else t for t in c) for c in ctxs]
-        g = ops.global_avgpool_bwd_relu(dfeat, y) if self.do_mean else dfeat
+        g = ops.global_avgpool_bwd_relu(dfeat, y)
+        if map_grad_hook is not None:
+            map_grad_hook(g, y)
         return self.res5.bwd(ctxs, g, need_dx=True, mask_input=False)
 
     def forward(self, x):
         """plugin surface (NCHW fp32 [R,1024,14,14] -> [R,2048]); inference only."""
         dtype = getattr(self, "compute_dtype", torch.bfloat16)
         self.prepare(dtype, 0)
-        out, _ = self.fwd(ops.nchw_to_nhwc(x, dtype=dtype))
-        return ops.cast(out, torch.float32) if self.do_mean else ops.nhwc_to_nchw(out)
+        out, ctx = self.fwd(ops.nchw_to_nhwc(x, dtype=dtype), keep_map=not self.do_mean)
+        return ops.cast(out, torch.float32) if self.do_mean else ops.nhwc_to_nchw(ctx[1])
 
 
 @ROI_BOX_HEAD_REGISTRY.register()

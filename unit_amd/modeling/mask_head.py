@@ -1,0 +1,137 @@
+"""MaskRCNNConvUpsampleHeadWithSimilarity -- /root/reference/modeling/roi_heads/mask_head.py:15-37 on top of Detectron2's
+MaskRCNNConvUpsampleHead with the C4 defaults NUM_CONV 0, CONV_DIM 256, NORM "" (SURVEY A.15):
+    deconv = ConvTranspose2d(2048, 256, 2, stride 2) -> ReLU -> predictor = Conv2d(256, K, 1)
+State-dict keys: `deconv.{weight,bias}`, `predictor.{weight,bias}`.
+Input = un-pooled Res5 features of the foreground RoIs [S,7,7,2048] (ROI_MASK_HEAD.POOLER_TYPE "None",
+roi_heads.py:691-710).  The transposed conv runs as one 1x1 GEMM with 4*256 columns (csrc/mask.hip)."""
+import ctypes
+
+import torch
+from torch import nn
+
+from .. import ops
+from .._lib import check, lib
+from ..layers import Conv2d, LinearGroup, _EpochOnLoad
+from ..structures import ROI_MASK_HEAD_REGISTRY
+
+
+class ConvTranspose2x2(_EpochOnLoad):
+    """nn.ConvTranspose2d(cin, cout, kernel_size=2, stride=2) parameters (weight [cin, cout, 2, 2], bias [cout])."""
+
+    def __init__(self, cin, cout):
+        super().__init__()
+        self.cin, self.cout = cin, cout
+        self.weight = nn.Parameter(torch.empty(cin, cout, 2, 2))
+        self.weight._unit_plain_layout = True           # flat store keeps [cin][cout][2][2] memory order
+        nn.init.kaiming_normal_(self.weight, mode="fan_out", nonlinearity="relu")
+        self.bias = nn.Parameter(torch.zeros(cout))
+        self.wf = self.wd = self.bias4 = None
+        self._key = None
+
+    def prepare(self, dtype, version):
+        key = (dtype, version if self.weight.requires_grad else -1, self.weight.data_ptr())
+        if key == self._key:
+            return
+        dev = self.weight.device
+        if self.wf is None or self.wf.dtype != dtype:
+            self.wf = torch.empty((4 * self.cout, 1, 1, self.cin), dtype=dtype, device=dev)
+            self.wd = torch.empty((self.cin, 1, 1, 4 * self.cout), dtype=dtype, device=dev)
+        w = self.weight.data if self.weight.data.is_contiguous() else self.weight.data.contiguous()
+        check(lib().unit_deconv2x2_weight_prep(ops._p(w), self.cin, self.cout, ops._p(self.wf), ops._p(self.wd), ops.dt(dtype), ops._s()),
+              "deconv2x2_weight_prep")
+        self.bias4 = self.bias.data.repeat(4)            # tiny (256 -> 1024) tiling of the bias over the four taps
+        self._key = key
+
+    def fwd(self, x):
+        """[S,P,P,cin] -> relu(deconv) as [S,P,P,4*cout] (tap-major columns)"""
+        return ops.conv2d(x, self.wf, 4 * self.cout, 1, 1, bias=self.bias4, relu=True)
+
+    def wgrad(self, x, dy):
+        gemm = ops.conv2d_wgrad(x, dy, 4 * self.cout, 1, 1)
+        db4 = ops.bias_grad(dy.reshape(-1, 4 * self.cout), 4 * self.cout)
+        if self.weight.grad is None:
+            self.weight.grad = torch.zeros_like(self.weight.data)
+        if self.bias.grad is None:
+            self.bias.grad = torch.zeros_like(self.bias.data)
+        if not self.weight.grad.is_contiguous():
+            raise RuntimeError("deconv weight .grad must be contiguous [cin][cout][2][2]")
+        check(lib().unit_deconv2x2_grad_unpack(ops._p(gemm), ops._p(db4), self.cin, self.cout, ops._p(self.weight.grad), ops._p(self.bias.grad),
+                                               ops._s()), "deconv2x2_grad_unpack")
+
+    def dgrad(self, dy, residual=None, mask_ref=None, out=None):
+        return ops.conv2d(dy, self.wd, self.cin, 1, 1, residual=residual, mask_ref=mask_ref, out=out)
+
+
+@ROI_MASK_HEAD_REGISTRY.register()
+class MaskRCNNConvUpsampleHeadWithSimilarity(nn.Module):
+    def __init__(self, cfg, input_shape):
+        super().__init__()
+        m = cfg.MODEL.ROI_MASK_HEAD
+        assert m.NUM_CONV == 0 and m.NORM == "" and not m.CLS_AGNOSTIC_MASK, "C4 mask head: NUM_CONV 0, no norm, per-class masks"
+        self.num_classes = cfg.MODEL.ROI_HEADS.NUM_CLASSES
+        self.deconv = ConvTranspose2x2(input_shape.channels, m.CONV_DIM)
+        self.predictor = Conv2d(m.CONV_DIM, self.num_classes, 1, bias=True)
+        nn.init.normal_(self.predictor.weight, std=0.001)
+        for name, p in self.named_parameters():
+            if any(layer == name.split(".")[0] for layer in cfg.MODEL.FREEZE_LAYERS.MASK_HEAD):
+                p.requires_grad = False
+        self.pred = LinearGroup([self.predictor])
+        self.mask_size = 14
+
+    def prepare(self, dtype, version):
+        self.deconv.prepare(dtype, version)
+        self.pred.prepare(dtype, version)
+
+    def logits(self, x):
+        """x [S,7,7,2048] -> (y1 [S,7,7,1024] post-ReLU, logits fp32 [S*196, kp] in [s][y][x][tap] row order)"""
+        y1 = self.deconv.fwd(x)
+        s = x.shape[0]
+        lg = self.pred.fwd(y1.view(s * 49 * 4, self.deconv.cout))
+        return y1, lg
+
+    # ---- training: mask_rcnn_loss (mean BCE on the gt-class channel over all fg RoIs) + gradient w.r.t. the logits
+    def fwd_train(self, x, cls, targets, loss_out, grad_dtype):
+        y1, lg = self.logits(x)
+        s = x.shape[0]
+        dlg = torch.empty((s * 196, self.pred.kp), dtype=grad_dtype, device=x.device)
+        check(lib().unit_mask_bce_loss(ops._p(lg), self.num_classes, self.pred.kp, ops._p(cls), ops._p(targets), s, self.mask_size, 1.0,
+                                       ops._p(loss_out), ops._p(dlg), ops.dt(grad_dtype), ops._s()), "mask_bce_loss")
+        return (x, y1, dlg)
+
+    def bwd(self, ctx, need_dx=True):
+        """-> dy1 [S,7,7,1024] (d loss / d deconv output, ReLU-masked); deconv dgrad is applied by the caller (it is fused
+        with the accumulation into the Res5 feature-map gradient)."""
+        x, y1, dlg = ctx
+        s = x.shape[0]
+        y1_2d = y1.view(s * 196, self.deconv.cout)
+        dy1 = self.pred.bwd(y1_2d, dlg, need_dx=True, mask_ref=y1_2d).view(s, 7, 7, 4 * self.deconv.cout)
+        self.deconv.wgrad(x, dy1)
+        return dy1
+
+    # ---- inference: mask_rcnn_inference (+ base->novel transfer of mask_head.py:18-31 for the predicted class)
+    def probs(self, x, pred_classes, sim=None, roles=None):
+        _, lg = self.logits(x)
+        s = x.shape[0]
+        out = torch.empty((s, self.mask_size, self.mask_size), dtype=torch.float32, device=x.device)
+        t = roles or {}
+        check(lib().unit_mask_probs(ops._p(lg), self.num_classes, self.pred.kp, ops._p(pred_classes), ops._p(sim), ops._p(t.get("base")),
+                                    t["base"].numel() if sim is not None else 0, t["novel"].numel() if sim is not None else 0,
+                                    ops._p(t.get("role")), ops._p(t.get("slot")), s, self.mask_size, ops._p(out), ops._s()), "mask_probs")
+        return out
+
+
+def mask_targets(gt_masks, rois5, gt_index, cls, num_classes, m=14):
+    """BitMasks.crop_and_resize for every slot: gt_masks u8 [B,Mcap,H,W] -> u8 [S,m,m]"""
+    s = rois5.shape[0]
+    out = torch.empty((s, m, m), dtype=torch.uint8, device=rois5.device)
+    check(lib().unit_mask_targets(ops._p(gt_masks), gt_masks.shape[1], gt_masks.shape[2], gt_masks.shape[3], ops._p(rois5), ops._p(gt_index),
+                                  ops._p(cls), num_classes, s, m, ops._p(out), ops._s()), "mask_targets")
+    return out
+
+
+def gather_match_index(sampled_idx, match_idx):
+    b, s = sampled_idx.shape
+    out = torch.empty((b * s,), dtype=torch.int32, device=sampled_idx.device)
+    check(lib().unit_gather_match_index(ops._p(sampled_idx), s, ops._p(match_idx), match_idx.shape[1], b, ops._p(out), ops._s()),
+          "gather_match_index")
+    return out

@@ -19,17 +19,19 @@ from ..flat import FlatStore
 from ..structures import (BACKBONE_REGISTRY, META_ARCH_REGISTRY, PROPOSAL_GENERATOR_REGISTRY, ROI_HEADS_REGISTRY, Boxes, ImageList,
                           Instances)
 
-LOSS_NAMES = ["loss_cls", "loss_box_reg", "loss_im_cls", "loss_oicr_1", "loss_oicr_2", "loss_oicr_3", "loss_rpn_cls", "loss_rpn_loc"]
+LOSS_NAMES = ["loss_cls", "loss_box_reg", "loss_im_cls", "loss_oicr_1", "loss_oicr_2", "loss_oicr_3", "loss_rpn_cls", "loss_rpn_loc",
+              "loss_mask"]
 
 
 class PackedBatch:
     """Device-resident, padded form of `batched_inputs` (+ weak) so that the step itself never touches the host."""
 
-    def __init__(self, images, gt_boxes, gt_classes, gt_count, n_sup, multihot=None):
+    def __init__(self, images, gt_boxes, gt_classes, gt_count, n_sup, multihot=None, gt_masks=None):
         self.images = images            # list of CHW fp32 device tensors: supervised first, then weak
         self.gt_boxes, self.gt_classes, self.gt_count = gt_boxes, gt_classes, gt_count
         self.n_sup = n_sup
         self.multihot = multihot        # [n_weak, K] uint8 or None
+        self.gt_masks = gt_masks        # [n_sup, Mcap, H, W] uint8 bitmasks or None (MASK_ON)
 
     @property
     def n_weak(self):
@@ -96,6 +98,12 @@ class WeaklySupervisedRCNNNoMeta(nn.Module):
             groups.append((tag, [(n, p, False) for n, p in ws], (kp - lg_k) * cin))
             groups.append((tag, [(n, p, False) for n, p in bs], 0))
 
+        mh = getattr(rh, "mask_head", None)
+        if mh is not None:
+            fused("mask_head", "roi_heads.mask_head", [("predictor", mh.predictor)])
+            if mh.deconv.weight.requires_grad:
+                groups.append(("mask_head", [("roi_heads.mask_head.deconv.weight", mh.deconv.weight, True),
+                                             ("roi_heads.mask_head.deconv.bias", mh.deconv.bias, True)], 0))
         if getattr(bp, "finetune", False):
             fused("heads", "roi_heads.box_predictor", [("cls_score_ft", bp.cls_score_ft), ("bbox_pred_ft", bp.bbox_pred_ft)])
         fused("heads", "roi_heads.box_predictor", [("cls_score_delta", bp.cls_score_delta), ("bbox_pred_delta", bp.bbox_pred_delta)])
@@ -187,8 +195,17 @@ class WeaklySupervisedRCNNNoMeta(nn.Module):
                 c = x["instances"].gt_classes if "instances" in x else x["gt_classes"]
                 multihot[i, c.long().cpu()] = 1     # torch.unique(gt_classes) (weak_detector_fast_rcnn.py:203)
             multihot = multihot.to(dev, non_blocking=True)
+        gt_masks = None
+        if n > 0 and all(x["instances"].has("gt_masks") for x in sup):
+            ms = [x["instances"].gt_masks for x in sup]
+            ms = [m.tensor if hasattr(m, "tensor") else m for m in ms]
+            hm, wm = max(m.shape[-2] for m in ms), max(m.shape[-1] for m in ms)
+            gt_masks = torch.zeros((n, mcap, hm, wm), dtype=torch.uint8)
+            for i, m in enumerate(ms):
+                gt_masks[i, : m.shape[0], : m.shape[-2], : m.shape[-1]] = m.to(torch.uint8).cpu() if m.is_cuda else m.to(torch.uint8)
+            gt_masks = gt_masks.to(dev, non_blocking=True)
         return PackedBatch(images, gt_boxes.to(dev, non_blocking=True), gt_classes.to(dev, non_blocking=True),
-                           gt_count.to(dev, non_blocking=True), n, multihot)
+                           gt_count.to(dev, non_blocking=True), n, multihot, gt_masks)
 
     def preprocess_image(self, batched_inputs):
         """rcnn.py:257-266 -> ImageList(NHWC tensor with channels padded to 8, image_sizes)."""
@@ -271,6 +288,23 @@ class WeaklySupervisedRCNNNoMeta(nn.Module):
             wfeat_all = feat_all
         c.weak_feat = weak_feat
 
+        # a16 mask head (roi_heads.py:691-710): un-pooled res5 map of the foreground RoIs -> deconv -> 1x1 -> mask BCE.
+        # The sampler emits [fg..., bg...] per image, so the fg RoIs of image i are the first n_fg_i <= 128 slots of its block.
+        c.mask_ctx = None
+        mh = getattr(rh, "mask_head", None)
+        if mh is not None and rs > 0 and batch.gt_masks is not None:
+            from .mask_head import gather_match_index, mask_targets
+            fgc = rh.max_fg_per_image
+            ymap = c.box_ctx[1]
+            sidx, midx = rh._last_sampling
+            gidx = gather_match_index(sidx, midx)
+            sel = [slice(i * s, i * s + fgc) for i in range(n_sup)]
+            x_fg = torch.cat([ymap[sl] for sl in sel], 0)
+            cls_fg = torch.cat([c.roi_cls[sl] for sl in sel], 0)
+            rois_fg = torch.cat([c.rois[sl] for sl in sel], 0)
+            tgt = mask_targets(batch.gt_masks, rois_fg, torch.cat([gidx[sl] for sl in sel], 0), cls_fg, rh.num_classes, mh.mask_size)
+            c.mask_ctx = (mh.fwd_train(x_fg, cls_fg, tgt, c.losses[8:9], dt), sel)
+
         # a10-a12 predictors + losses (+ gradients w.r.t. the Linear outputs)
         lin_weak_all = bp.weak_detector_head.group.fwd(wfeat_all)            # [rs+rw, 104] (oicr cols feed the sup scores)
         c.dy_sup = c.dy_weak = None
@@ -318,9 +352,22 @@ class WeaklySupervisedRCNNNoMeta(nn.Module):
             dweak = bp.weak_detector_head.group.bwd(c.weak_feat, c.dy_weak, need_dx=True)
         done("heads")
         dpool_sup = dpool_weak = None      # d(loss)/d(pooled) of the supervised / weak RoIs
+        mask_hook = None
+        if getattr(c, "mask_ctx", None) is not None:
+            mh = rh.mask_head
+
+            def mask_hook(g, y):
+                """adds the mask head's gradient to the res5 map gradient of the fg RoI slots (deconv dgrad with the
+                running gradient as residual and the ReLU mask of the map as epilogue, written in place)."""
+                ctx, sel = c.mask_ctx
+                dy1 = mh.bwd(ctx)
+                fgc = rh.max_fg_per_image
+                for i, sl in enumerate(sel):
+                    mh.deconv.dgrad(dy1[i * fgc:(i + 1) * fgc], residual=g[sl], mask_ref=y[sl], out=g[sl])
+                done("mask_head")
         if multi:
             if dbox is not None and box_trainable:
-                dpool_sup = rh.box_head.bwd(c.box_ctx, dbox)
+                dpool_sup = rh.box_head.bwd(c.box_ctx, dbox, map_grad_hook=mask_hook)
                 done("box_head")
             if dweak is not None:
                 dpool_weak = rh.weak_box_head.bwd(c.weak_ctx, dweak, row_slice=slice(rs, rs + rw))
@@ -329,7 +376,7 @@ class WeaklySupervisedRCNNNoMeta(nn.Module):
             parts = [t for t in (dbox, dweak) if t is not None]
             if parts and box_trainable:
                 dall = torch.cat(parts, 0) if len(parts) > 1 else parts[0]
-                dpool = rh.box_head.bwd(c.box_ctx, dall)
+                dpool = rh.box_head.bwd(c.box_ctx, dall, map_grad_hook=mask_hook)
                 done("box_head")
                 dpool_sup, dpool_weak = (dpool[:rs] if rs > 0 else None), (dpool[rs:] if rw > 0 else None)
 
@@ -375,6 +422,8 @@ class WeaklySupervisedRCNNNoMeta(nn.Module):
             self._anchor = torch.zeros(1, device=self.device, requires_grad=True)
         lv = _StepFn.apply(self._anchor, self, step, step.losses)
         names = LOSS_NAMES if batch.n_weak > 0 else [n for n in LOSS_NAMES if not (n.startswith("loss_oicr") or n == "loss_im_cls")]
+        if step.mask_ctx is None:
+            names = [n for n in names if n != "loss_mask"]
         return {n: lv[LOSS_NAMES.index(n)] for n in names}
 
     def train_step(self, batch, optimizer=None, perms=None):

@@ -87,6 +87,7 @@ class WSROIHeadNoMeta(nn.Module):
         _, sidx, counts = ops.subsample_labels(cls, cc, perm, self.batch_size_per_image, self.positive_fraction, self.num_classes,
                                                want_labels=False)
         rois5, roi_cls, roi_gt = ops.gather_rois(cat, sidx, cls, idx, gt_boxes, gt_count)
+        self._last_sampling = (sidx, idx)        # mask head: gt_masks[matched_idx[sampled]] (select + crop_and_resize)
         return rois5, roi_cls, roi_gt, counts
 
     # ---- roi_heads.py:566-572: the first 512//divisor RPN outputs of every weak image, no GT, no sampling
@@ -116,3 +117,30 @@ class WSROIHeadNoMeta(nn.Module):
 @ROI_HEADS_REGISTRY.register()
 class WSROIHeadFineTune(WSROIHeadNoMeta):
     finetune = True
+
+
+@ROI_HEADS_REGISTRY.register()
+class WSROIHeadNoMetaWithMask(WSROIHeadNoMeta):
+    """/root/reference/modeling/roi_heads/roi_heads.py:647-822: same box path with `Res5BoxHeadWithMask` (the predictor
+    sees the mean of the res5 map, :735-744) plus the mask head on the foreground RoIs' un-pooled res5 features
+    (`_init_mask_head` :654-689, `_forward_mask` :691-710; ROI_MASK_HEAD.POOLER_TYPE "None")."""
+
+    def __init__(self, cfg, input_shape=None, thing_classes=None):
+        super().__init__(cfg, input_shape, thing_classes)
+        self.mask_head = None
+        if cfg.MODEL.MASK_ON:
+            from ..structures import ROI_MASK_HEAD_REGISTRY
+            from . import mask_head as _mh  # noqa: F401  (registers the head)
+            assert cfg.MODEL.ROI_MASK_HEAD.POOLER_TYPE == "None", "C4-segm: the mask head reuses the box head's res5 features"
+            self.mask_head = ROI_MASK_HEAD_REGISTRY.get(cfg.MODEL.ROI_MASK_HEAD.NAME)(cfg, ShapeSpec(channels=self.box_head.out_channels,
+                                                                                                      height=7, width=7))
+        self.terms["seg"] = list(cfg.MODEL.ROI_HEADS.FINETUNE_TERMS.MASK)
+
+    def prepare(self, dtype, version):
+        super().prepare(dtype, version)
+        if self.mask_head is not None:
+            self.mask_head.prepare(dtype, version)
+
+    @property
+    def max_fg_per_image(self):
+        return int(self.batch_size_per_image * self.positive_fraction)
