@@ -30,7 +30,8 @@ class Res5BoxHead(nn.Module):
 
     @property
     def output_shape(self):
-        return ShapeSpec(channels=self.out_channels, height=1 if self.do_mean else 7, width=1 if self.do_mean else 7)
+        # box_head.py:82-89: Res5BoxHeadWithMask inherits this property unchanged (predictors are sized for the mean features)
+        return ShapeSpec(channels=self.out_channels, height=1, width=1)
 
     def prepare(self, dtype, version):
         for b in self.res5:
