@@ -79,6 +79,23 @@ def inference(model, batched_inputs, do_postprocess=True):
     probs = ops.softmax_rows(scores, rh.num_classes + 1)
     boxes, sc, cls, roi, cnt = ops.detections(probs, bbox, props, pcount, hw, bp.bbox_reg_weights, bp.test_score_thresh,
                                               bp.test_nms_thresh, bp.test_topk_per_image)
+    # a16 eval: forward_with_given_boxes (roi_heads.py:776-781) -> mask head on the detected boxes (before postprocess)
+    mask_probs = None
+    mh = getattr(rh, "mask_head", None)
+    if mh is not None:
+        topk = boxes.shape[1]
+        det_rois = torch.cat([torch.arange(n, device=dev, dtype=torch.float32).repeat_interleave(topk)[:, None], boxes.view(-1, 4)], 1)
+        _, dctx = rh.box_head.fwd(rh.pool(feat, det_rois), keep_map=True)
+        sim_seg = None
+        if "seg" in rh.terms:
+            key = ("lingual" in rh.terms["seg"], "visual" in rh.terms["seg"])
+            base_sim = sim_cls if key == ("lingual" in rh.terms["cls"], "visual" in rh.terms["cls"]) else \
+                ops.similarity(lin_w_box, wh.col_oicr[0], wh.oicr_iter, rh.num_classes + 1, t["base"],
+                               ops.embedding_similarity(bp.embeddings.weight, t["emb_novel"], t["emb_base"]), t["novel"].numel(),
+                               rh.visual_threshold, key[0], key[1])
+            flat_idx = (torch.arange(n, device=dev)[:, None] * rcap + roi.clamp(min=0).long()).view(-1)
+            sim_seg = base_sim[flat_idx].contiguous()          # similarity['seg'][filter_inds] (roi_heads.py:768-771)
+        mask_probs = mh.probs(dctx[1], cls.view(-1).contiguous(), sim_seg, t).view(n, topk, mh.mask_size, mh.mask_size)
     out_hw = [(x.get("height", s[0]), x.get("width", s[1])) for x, s in zip(batched_inputs, sizes)]
     if do_postprocess:
         scale = torch.tensor([[o[1] / s[1], o[0] / s[0]] for o, s in zip(out_hw, sizes)], dtype=torch.float32).to(dev)
@@ -91,5 +108,7 @@ def inference(model, batched_inputs, do_postprocess=True):
         keep = nonempty[i, :c].bool() if do_postprocess else slice(None)
         inst = Instances(size, pred_boxes=Boxes(boxes[i, :c][keep]), scores=sc[i, :c][keep], pred_classes=cls[i, :c][keep].long())
         inst._roi_index = roi[i, :c][keep]
+        if mask_probs is not None:
+            inst.pred_masks = mask_probs[i, :c][keep][:, None]      # (R,1,14,14) like mask_rcnn_inference; pasting is left to the caller
         results.append({"instances": inst} if do_postprocess else inst)
     return results
