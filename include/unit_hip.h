@@ -45,6 +45,13 @@ size_t unit_conv2d_wgrad_workspace_bytes(int in_dtype, int N, int OH, int OW, in
 int unit_conv2d_wgrad(const void* x, const void* dy, float* dw, const float* scale_k, int in_dtype, int N, int H, int W, int C,
                       int K, int R, int S, int stride, int pad, int OH, int OW, int ldy, int accumulate, void* workspace,
                       size_t workspace_bytes, void* stream);
+/* dw == NULL: unit_conv2d_wgrad leaves unit_conv2d_wgrad_splits() partial slabs in the workspace (no reduction); the
+ * multi-tensor kernels below reduce all layers of a gradient bucket / refresh all prepared weight copies in ONE launch.
+ * descs_dev: array of {const float* partial, *scale; void* wf, *wd; long offset; int splits,K,R,S,C,block0} (64 B each) */
+int unit_conv2d_wgrad_splits(int in_dtype, int N, int OH, int OW, int K, int R, int S, int C);
+size_t unit_tensor_desc_bytes(void);
+int unit_multi_wgrad_reduce(const void* descs_dev, int n, int total_blocks, float* grads_flat, void* stream);
+int unit_multi_weight_prep(const void* descs_dev, int n, int total_blocks, const float* params_flat, int dtype, void* stream);
 /* FrozenBatchNorm2d fold (detectron2 layers/batch_norm.py, eps 1e-5) and weight re-layout / cast */
 int unit_frozen_bn_fold(const float* w, const float* b, const float* rm, const float* rv, float eps, float* scale, float* shift,
                         int C, void* stream);

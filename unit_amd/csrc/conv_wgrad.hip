@@ -266,8 +266,16 @@ extern "C" int unit_conv2d_wgrad(const void* x, const void* dy, float* dw, const
     conv_wgrad_kernel<float><<<grid, 256, lds, st>>>(a);
   }
   UNIT_LAUNCH_CHECK();
+  if (dw == nullptr) return UNIT_OK;   // partial slabs only: the caller reduces later (unit_multi_wgrad_reduce)
   long KK = (long)K * a.Kgemm;
   wgrad_reduce_kernel<<<cdiv(KK / 4, 256), 256, 0, st>>>(a.partial, a.splits, KK, a.Kgemm, scale_k, dw, accumulate);
   UNIT_LAUNCH_CHECK();
   return UNIT_OK;
+}
+
+// number of split-M slabs unit_conv2d_wgrad writes for this shape (slab s at workspace + s*K*R*S*C floats)
+extern "C" int unit_conv2d_wgrad_splits(int in_dtype, int N, int OH, int OW, int K, int R, int S, int C) {
+  long M = (long)N * OH * OW;
+  int tiles = cdiv(R * S * C, 128) * cdiv(K, 128);
+  return choose_splits((int)M, tiles, in_dtype == UNIT_BF16 ? 64 : 32);
 }

@@ -102,6 +102,11 @@ class Conv2d(_EpochOnLoad):
         if not self.weight.requires_grad:
             return
         st = self.stride if stride is None else stride
+        if getattr(self, "_plan", None) is not None:
+            # multi-tensor plan (unit_amd/multi.py): leave the split-M slabs in this layer's resident buffer; one
+            # unit_multi_wgrad_reduce launch per bucket folds them into the flat gradient buffer later
+            self._slab, self._splits = ops.conv2d_wgrad_partial(x, dy, self.cout, self.k, self.k, st, self.pad, self._slab)
+            return
         g = self.weight.grad
         if g is None:
             g = torch.zeros_like(self.weight.data, memory_format=torch.channels_last)

@@ -76,6 +76,8 @@ class WeaklySupervisedRCNNNoMeta(nn.Module):
         self._anchor = None
         self._gen = None
         self.on_grad_ready = None  # data-parallel hook: called with a stage name as soon as its gradients are final
+        self.use_multi_tensor_plan = True
+        self.plan = None
 
     @property
     def device(self):
@@ -157,7 +159,16 @@ class WeaklySupervisedRCNNNoMeta(nn.Module):
         store.materialize()
         self.store = store
         self.version += 1
+        from ..multi import ConvPlan
+        self.plan = ConvPlan(self) if self.device.type == "cuda" and self.use_multi_tensor_plan else None
         return store
+
+    def after_optimizer_step(self):
+        """called by the optimizer once the flat parameters changed: bump the version and refresh every trainable conv's
+        prepared (FrozenBN-folded, cast, dgrad-transposed) copies in one multi-tensor launch."""
+        self.version += 1
+        if getattr(self, "plan", None) is not None:
+            self.plan.prep_all(self.compute_dtype, self.version)
 
     def _ensure_ready(self):
         if self.training and (self.store is None or not self.store.is_current()):
@@ -338,7 +349,14 @@ class WeaklySupervisedRCNNNoMeta(nn.Module):
         self._reattach_grads()
         rs, rw, n_sup = c.rs, c.rw, c.n_sup
         multi = rh.weak_box_head is not None
-        done = self.on_grad_ready or (lambda tag: None)
+        hook, plan = self.on_grad_ready, self.plan
+
+        def done(tag):
+            if plan is not None:
+                plan.reduce(tag)         # split-M slabs of this bucket -> flat gradient buffer (one launch)
+            if hook is not None:
+                hook(tag)                # data parallel: launch the bucket's all-reduce
+
         feat = c.feat
         bb_trainable = self.backbone.first_trainable_stage() < 3
         box_trainable = c.box_ctx is not None

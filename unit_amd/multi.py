@@ -1,0 +1,92 @@
+"""Multi-tensor end-of-step plan: per-layer split-M slabs stay resident (288 GB of HBM: ~2 GB of slabs is nothing), one
+`unit_multi_wgrad_reduce` launch per gradient bucket tag reduces them into the flat gradient buffer, and one
+`unit_multi_weight_prep` launch after the optimizer refreshes every trainable conv's bf16 forward / dgrad copies.
+Replaces ~220 launch-bound per-layer kernels per step (csrc/multi.hip)."""
+import ctypes
+
+import torch
+
+from . import ops
+from ._lib import check, lib
+from .layers import _FROZEN_EPOCH, Conv2d
+
+ELEMS_PER_BLOCK = 1024
+
+
+class TensorDesc(ctypes.Structure):
+    _fields_ = [("partial", ctypes.c_void_p), ("scale", ctypes.c_void_p), ("wf", ctypes.c_void_p), ("wd", ctypes.c_void_p),
+                ("offset", ctypes.c_long), ("splits", ctypes.c_int), ("K", ctypes.c_int), ("R", ctypes.c_int), ("S", ctypes.c_int),
+                ("C", ctypes.c_int), ("block0", ctypes.c_int)]
+
+
+class ConvPlan:
+    """Tracks the trainable Conv2d layers of a model whose weights live in the flat store."""
+
+    def __init__(self, model):
+        assert ctypes.sizeof(TensorDesc) == lib().unit_tensor_desc_bytes()
+        self.model = model
+        st = model.store
+        off = {id(e["param"]): e["offset"] for e in st.entries}
+        self.by_tag = {}
+        self.convs = []
+        tag_of = {}
+        for tag, a, b in st.tags:
+            for e in st.entries:
+                if a <= e["offset"] < b:
+                    tag_of[id(e["param"])] = tag
+        for name, m in model.named_modules():
+            if isinstance(m, Conv2d) and m.weight.requires_grad and id(m.weight) in off and m.cin_pad == m.cin and m.weight.dim() == 4 \
+                    and (m.cin * m.k * m.k) % 4 == 0 and m.norm is not None:
+                m._plan = self
+                m._flat_offset = off[id(m.weight)]
+                m._slab = None
+                m._splits = 0
+                self.convs.append(m)
+                self.by_tag.setdefault(tag_of[id(m.weight)], []).append(m)
+        self._tables = {}      # tag -> (device bytes tensor, n, total_blocks, signature)
+        self._prep_table = None
+
+    def _build(self, convs, with_partial):
+        descs = (TensorDesc * len(convs))()
+        b0 = 0
+        for i, m in enumerate(convs):
+            kk = m.cout * m.k * m.k * m.cin
+            d = descs[i]
+            d.partial = m._slab.data_ptr() if (with_partial and m._slab is not None) else None
+            d.scale = m.scale.data_ptr() if m.scale is not None else None
+            d.wf = m.wf.data_ptr() if m.wf is not None else None
+            d.wd = m.wd.data_ptr() if m.wd is not None else None
+            d.offset = m._flat_offset
+            d.splits, d.K, d.R, d.S, d.C, d.block0 = m._splits, m.cout, m.k, m.k, m.cin, b0
+            b0 += (kk + ELEMS_PER_BLOCK - 1) // ELEMS_PER_BLOCK
+        host = torch.frombuffer(bytearray(bytes(descs)), dtype=torch.uint8)
+        return host.to(self.model.device), len(convs), b0
+
+    def reduce(self, tag):
+        """grads[flat] = scale * sum(slabs) for every conv of this bucket tag (call before the bucket's all-reduce)."""
+        convs = [m for m in self.by_tag.get(tag, []) if m._slab is not None]
+        if not convs:
+            return
+        sig = tuple((m._slab.data_ptr(), m._splits) for m in convs)
+        tab = self._tables.get(tag)
+        if tab is None or tab[3] != sig:
+            dev, n, blocks = self._build(convs, True)
+            tab = (dev, n, blocks, sig)
+            self._tables[tag] = tab
+        check(lib().unit_multi_wgrad_reduce(ops._p(tab[0]), tab[1], tab[2], ops._p(self.model.store.grads), ops._s()), "multi_wgrad_reduce")
+
+    def prep_all(self, dtype, version):
+        """refresh wf / wd of every planned conv from the (just updated) flat parameters; marks them prepared."""
+        convs = [m for m in self.convs if m.wf is not None and m.wf.dtype == dtype and m.wd is not None]
+        if len(convs) != len(self.convs):
+            return False           # first step: the per-layer prepare() path allocates the copies
+        sig = tuple((m.wf.data_ptr(), m.wd.data_ptr()) for m in convs)
+        if self._prep_table is None or self._prep_table[3] != sig:
+            dev, n, blocks = self._build(convs, False)
+            self._prep_table = (dev, n, blocks, sig)
+        t = self._prep_table
+        check(lib().unit_multi_weight_prep(ops._p(t[0]), t[1], t[2], ops._p(self.model.store.params), ops.dt(dtype), ops._s()),
+              "multi_weight_prep")
+        for m in convs:
+            m._prep_key = (dtype, version, _FROZEN_EPOCH[0], m.weight.data_ptr(), True)
+        return True

@@ -176,6 +176,27 @@ def conv2d_wgrad(x, dy, k, r, s, stride=1, pad=0, scale=None, out=None, accumula
     return out
 
 
+def conv2d_wgrad_partial(x, dy, k, r, s, stride, pad, slab=None):
+    """split-M partial slabs only (no reduction): returns (slab uint8 tensor, n_splits); slab i = floats [i*k*r*s*C, ...)."""
+    n, h, wd, c = x.shape
+    oh, ow = conv_out_size(h, wd, r, s, stride, pad)
+    nbytes = lib().unit_conv2d_wgrad_workspace_bytes(dt(x.dtype), n, oh, ow, k, r, s, c)
+    if slab is None or slab.numel() < nbytes:
+        slab = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+    splits = lib().unit_conv2d_wgrad_splits(dt(x.dtype), n, oh, ow, k, r, s, c)
+    prof = PROFILER
+    if prof is not None:
+        e0 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+    check(lib().unit_conv2d_wgrad(_p(x), _p(dy), None, None, dt(x.dtype), n, h, wd, c, k, r, s, stride, pad, oh, ow, dy.shape[-1], 0,
+                                  _p(slab), slab.numel(), _s()), "unit_conv2d_wgrad(partial)")
+    if prof is not None:
+        e1 = torch.cuda.Event(enable_timing=True)
+        e1.record()
+        prof.setdefault("conv_wgrad", []).append((e0, e1, 2.0 * n * oh * ow * k * r * s * c))
+    return slab, splits
+
+
 def frozen_bn_fold(weight, bias, running_mean, running_var, eps=1e-5):
     c = weight.numel()
     scale = torch.empty(c, dtype=torch.float32, device=weight.device)

@@ -77,4 +77,4 @@ class FlatSGD:
                              self.grad_scale, first_step=self._first)
         self._first = False
         self.iter += 1
-        self.model.version += 1
+        self.model.after_optimizer_step()
