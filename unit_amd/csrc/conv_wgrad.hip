@@ -210,7 +210,7 @@ static int choose_splits(int M, int tiles, int ms) {
     long blocks = (long)tiles * s;
     long rounds = (blocks + 511) / 512;
     double fill = (double)blocks / (double)(rounds * 512);
-    double score = fill - 0.0005 * s;        // tie-break only: prefer fewer splits (less slab traffic)
+    double score = fill - 0.003 * s;         // every extra split costs one more fp32 slab write + read of the whole dW
     if (score > best_score) { best_score = score; best = s; }
   }
   return best;

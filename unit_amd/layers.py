@@ -105,7 +105,20 @@ class Conv2d(_EpochOnLoad):
         if getattr(self, "_plan", None) is not None:
             # multi-tensor plan (unit_amd/multi.py): leave the split-M slabs in this layer's resident buffer; one
             # unit_multi_wgrad_reduce launch per bucket folds them into the flat gradient buffer later
-            self._slab, self._splits = ops.conv2d_wgrad_partial(x, dy, self.cout, self.k, self.k, st, self.pad, self._slab)
+            side = ops.WGRAD_STREAM
+            if side is None:
+                self._slab, self._splits = ops.conv2d_wgrad_partial(x, dy, self.cout, self.k, self.k, st, self.pad, self._slab)
+                return
+            # weight gradients depend on nothing downstream: run them on a side HIP stream so that they fill the CUs the
+            # dgrad chain leaves idle (tile-quantisation tails, the small res3/res4 grids); joined before the bucket's reduce
+            main = torch.cuda.current_stream()
+            ev = torch.cuda.Event()
+            ev.record(main)
+            side.wait_event(ev)
+            x.record_stream(side)
+            dy.record_stream(side)
+            with torch.cuda.stream(side):
+                self._slab, self._splits = ops.conv2d_wgrad_partial(x, dy, self.cout, self.k, self.k, st, self.pad, self._slab)
             return
         g = self.weight.grad
         if g is None:

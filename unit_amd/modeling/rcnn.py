@@ -78,6 +78,7 @@ class WeaklySupervisedRCNNNoMeta(nn.Module):
         self.on_grad_ready = None  # data-parallel hook: called with a stage name as soon as its gradients are final
         self.use_multi_tensor_plan = True
         self.plan = None
+        self.overlap_streams = True
 
     @property
     def device(self):
@@ -288,9 +289,23 @@ class WeaklySupervisedRCNNNoMeta(nn.Module):
         # half is the reference's no_grad evaluation (roi_heads.py:502-504), its weak half has grad (:512-513)
         multi = rh.weak_box_head is not None
         box_trainable = any(p.requires_grad for p in rh.box_head.parameters())
+        c.head_overlap = False
         if multi:
-            c.box_feat, c.box_ctx = rh.box_head.fwd(pooled[:rs], save=box_trainable) if rs > 0 else (None, None)
-            wfeat_all, c.weak_ctx = rh.weak_box_head.fwd(pooled, save=(rw > 0))
+            if rs > 0 and self._streams_on() and getattr(rh, "mask_head", None) is None:
+                # the two Res5 heads are independent: run box_head on its own HIP stream so that its workgroups fill the
+                # tile-quantisation tails of weak_box_head's launches (and vice versa)
+                main, s1 = torch.cuda.current_stream(), self._head_stream
+                s1.wait_stream(main)
+                pooled.record_stream(s1)
+                with torch.cuda.stream(s1):
+                    c.box_feat, c.box_ctx = rh.box_head.fwd(pooled[:rs], save=box_trainable)
+                wfeat_all, c.weak_ctx = rh.weak_box_head.fwd(pooled, save=(rw > 0))
+                main.wait_stream(s1)
+                c.box_feat.record_stream(main)
+                c.head_overlap = True
+            else:
+                c.box_feat, c.box_ctx = rh.box_head.fwd(pooled[:rs], save=box_trainable) if rs > 0 else (None, None)
+                wfeat_all, c.weak_ctx = rh.weak_box_head.fwd(pooled, save=(rw > 0))
             sup_weak_feat, weak_feat = wfeat_all[:rs], wfeat_all[rs:]
         else:
             feat_all, c.box_ctx = rh.box_head.fwd(pooled, save=box_trainable)
@@ -351,7 +366,12 @@ class WeaklySupervisedRCNNNoMeta(nn.Module):
         multi = rh.weak_box_head is not None
         hook, plan = self.on_grad_ready, self.plan
 
+        side = self._wgrad_stream if self._streams_on() else None
+        ops.WGRAD_STREAM = side if plan is not None else None
+
         def done(tag):
+            if side is not None:
+                torch.cuda.current_stream().wait_stream(side)     # this bucket's wgrad kernels ran on the side stream
             if plan is not None:
                 plan.reduce(tag)         # split-M slabs of this bucket -> flat gradient buffer (one launch)
             if hook is not None:
@@ -384,12 +404,25 @@ class WeaklySupervisedRCNNNoMeta(nn.Module):
                     mh.deconv.dgrad(dy1[i * fgc:(i + 1) * fgc], residual=g[sl], mask_ref=y[sl], out=g[sl])
                 done("mask_head")
         if multi:
-            if dbox is not None and box_trainable:
-                dpool_sup = rh.box_head.bwd(c.box_ctx, dbox, map_grad_hook=mask_hook)
-                done("box_head")
-            if dweak is not None:
+            overlap = c.head_overlap and dbox is not None and box_trainable and dweak is not None
+            if overlap:
+                main, s1 = torch.cuda.current_stream(), self._head_stream
+                s1.wait_stream(main)
+                dbox.record_stream(s1)
+                with torch.cuda.stream(s1):
+                    dpool_sup = rh.box_head.bwd(c.box_ctx, dbox)
                 dpool_weak = rh.weak_box_head.bwd(c.weak_ctx, dweak, row_slice=slice(rs, rs + rw))
+                main.wait_stream(s1)
+                dpool_sup.record_stream(main)
+                done("box_head")
                 done("weak_box_head")
+            else:
+                if dbox is not None and box_trainable:
+                    dpool_sup = rh.box_head.bwd(c.box_ctx, dbox, map_grad_hook=mask_hook)
+                    done("box_head")
+                if dweak is not None:
+                    dpool_weak = rh.weak_box_head.bwd(c.weak_ctx, dweak, row_slice=slice(rs, rs + rw))
+                    done("weak_box_head")
         else:
             parts = [t for t in (dbox, dweak) if t is not None]
             if parts and box_trainable:
@@ -417,6 +450,18 @@ class WeaklySupervisedRCNNNoMeta(nn.Module):
                     z = torch.zeros(feat[lo:hi].shape, dtype=torch.float32, device=feat.device)
                     ops.add_cast(z, add, dt, mask_ref=feat[lo:hi], out=g[lo:hi])
             self.backbone.bwd(c.bb_ctx, g, on_stage_done=done)
+        if side is not None:
+            torch.cuda.current_stream().wait_stream(side)
+        ops.WGRAD_STREAM = None
+
+    def _streams_on(self):
+        """HIP-stream overlap (independent Res5 heads, weight-gradient kernels) -- on by default on the GPU."""
+        if not self.overlap_streams or self.device.type != "cuda" or self.plan is None:
+            return False   # (without the plan the wgrad kernels share one workspace and must stay on one stream)
+        if getattr(self, "_head_stream", None) is None:
+            self._head_stream = torch.cuda.Stream(self.device)
+            self._wgrad_stream = torch.cuda.Stream(self.device)
+        return True
 
     def _reattach_grads(self):
         """optimizer.zero_grad(set_to_none=True) drops .grad: point them at the flat gradient buffer again."""

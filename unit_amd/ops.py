@@ -50,6 +50,9 @@ def _big_tile_default(dtype, m, k, c, kgemm):
 
 BIG_TILE_POLICY = _big_tile_default
 
+# side HIP stream for the weight-gradient kernels (set by the model when stream overlap is enabled; None = inline)
+WGRAD_STREAM = None
+
 # bench.py sets this to a dict to time every conv_igemm launch with HIP events on the launch stream (roofline evidence)
 PROFILER = None
 
