@@ -117,7 +117,7 @@ def main():
     opt = FlatSGD(model, cfg, grad_scale=buckets.grad_scale)
 
     def one_step():
-        step = model.forward_train(batch)
+        step = model.forward_train(batch, early_backward=True)
         model.backward_train(step)
         buckets.finish()
         opt.step()

@@ -37,7 +37,7 @@ class TrainerNoMeta:
         if classifier_data is None and self.weak_data_iter is not None:
             classifier_data = next(self.weak_data_iter)
         batch = self.model.pack_batch(base_data, classifier_data)
-        step = self.model.forward_train(batch)
+        step = self.model.forward_train(batch, early_backward=True)
         self.model.backward_train(step)          # buckets' all-reduces are launched from inside (on_grad_ready)
         self.buckets.finish()
         self.optimizer.step()

@@ -237,9 +237,12 @@ class WeaklySupervisedRCNNNoMeta(nn.Module):
         return {"rpn": rpn, "roi": roi}
 
     # ------------------------------------------------------------------ the training step: forward plan
-    def forward_train(self, batch, perms=None):
-        """-> step context (holds `losses` fp32[8] on the device and everything backward_train needs)."""
+    def forward_train(self, batch, perms=None, early_backward=False):
+        """-> step context (holds `losses` fp32[9] on the device and everything backward_train needs).
+        early_backward: the caller WILL run backward_train right after (train_step / TrainerNoMeta.run_step); branches whose
+        backward does not depend on later forward work (the RPN head) may then start during the forward plan."""
         self._ensure_ready()
+        self._early_backward = early_backward
         rpn, rh, bp = self.proposal_generator, self.roi_heads, self.roi_heads.box_predictor
         dt = self.compute_dtype
         c = type("StepCtx", (), {})()
@@ -265,6 +268,19 @@ class WeaklySupervisedRCNNNoMeta(nn.Module):
             c.anchor_labels, c.anchor_match, _ = rpn.label_and_sample_anchors(anchors, batch.gt_boxes, batch.gt_count, perms["rpn"])
             _, c.dhead = ops.rpn_loss(head[:n_sup], rpn.num_anchors, rpn.num_anchors, c.anchor_labels, c.anchor_match, batch.gt_boxes,
                                       anchors, rpn.batch_size_per_image * n_sup, dt, loss_out=c.losses[6:8])
+        # The RPN branch's backward needs nothing but dhead: start it NOW on a side stream so that its dense conv work
+        # overlaps the latency-bound proposal pipeline (sort -> decode -> NMS -> sampling run on 1-4 workgroups).
+        c.drpn = None
+        c.rpn_bwd_early = False
+        if c.dhead is not None and early_backward and self._streams_on() and any(p.requires_grad for p in rpn.rpn_head.parameters()):
+            self._reattach_grads()
+            main, s2 = torch.cuda.current_stream(), self._rpn_stream
+            s2.wait_stream(main)
+            for t in (c.dhead, feat) + tuple(c.rpn_ctx):
+                t.record_stream(s2)
+            with torch.cuda.stream(s2):
+                c.drpn = rpn.rpn_head.bwd(c.rpn_ctx, c.dhead, n_sup)
+            c.rpn_bwd_early = True
         hw = torch.tensor(sizes, dtype=torch.float32).to(self.device, non_blocking=True)
         props, pscores, pcount = rpn.predict_proposals(head, anchors, hw, True)
         c.proposals = (props, pscores, pcount)
@@ -432,7 +448,12 @@ class WeaklySupervisedRCNNNoMeta(nn.Module):
                 dpool_sup, dpool_weak = (dpool[:rs] if rs > 0 else None), (dpool[rs:] if rw > 0 else None)
 
         drpn = None
-        if c.dhead is not None and any(p.requires_grad for p in rpn.rpn_head.parameters()):
+        if getattr(c, "rpn_bwd_early", False):
+            torch.cuda.current_stream().wait_stream(self._rpn_stream)      # launched during the forward plan
+            drpn = c.drpn
+            drpn.record_stream(torch.cuda.current_stream())
+            done("rpn")
+        elif c.dhead is not None and any(p.requires_grad for p in rpn.rpn_head.parameters()):
             drpn = rpn.rpn_head.bwd(c.rpn_ctx, c.dhead, n_sup)
             done("rpn")
         if bb_trainable:
@@ -461,6 +482,7 @@ class WeaklySupervisedRCNNNoMeta(nn.Module):
         if getattr(self, "_head_stream", None) is None:
             self._head_stream = torch.cuda.Stream(self.device)
             self._wgrad_stream = torch.cuda.Stream(self.device)
+            self._rpn_stream = torch.cuda.Stream(self.device)
         return True
 
     def _reattach_grads(self):
@@ -491,7 +513,7 @@ class WeaklySupervisedRCNNNoMeta(nn.Module):
 
     def train_step(self, batch, optimizer=None, perms=None):
         """forward + backward (+ optimizer) without going through torch.autograd; returns the device loss vector."""
-        step = self.forward_train(batch, perms)
+        step = self.forward_train(batch, perms, early_backward=True)
         self.backward_train(step)
         if optimizer is not None:
             optimizer.step()

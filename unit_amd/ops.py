@@ -165,7 +165,7 @@ def conv2d_wgrad(x, dy, k, r, s, stride=1, pad=0, scale=None, out=None, accumula
     if out is None:
         out = torch.empty((k, r, s, c), dtype=torch.float32, device=x.device)
     nbytes = lib().unit_conv2d_wgrad_workspace_bytes(dt(x.dtype), n, oh, ow, k, r, s, c)
-    ws = workspace(nbytes, x.device)
+    ws = workspace(nbytes, x.device, slot=2)   # own slot: these launches may run on a side stream next to sort/NMS (slot 0)
     prof = PROFILER
     if prof is not None:
         e0 = torch.cuda.Event(enable_timing=True)
