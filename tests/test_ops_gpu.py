@@ -136,10 +136,11 @@ def test_conv_dgrad_wgrad(dev, case, dtype):
     assert torch.allclose(dw2.cpu(), 2 * dw.cpu(), rtol=1e-5, atol=1e-6)
 
 
-@pytest.mark.parametrize("case", [(3, 30, 33, 256, 256, 3, 1, 1), (1, 38, 63, 128, 75, 1, 1, 0), (70, 7, 7, 64, 512, 3, 1, 1),
+@pytest.mark.parametrize("case", [(3, 30, 33, 256, 256, 3, 1, 1), (1, 38, 63, 128, 75, 1, 1, 0), (2, 9, 9, 64, 40, 1, 1, 0), (70, 7, 7, 64, 512, 3, 1, 1),
                                   (2, 19, 23, 64, 320, 1, 2, 0)])
-def test_conv_big_tile_kernel(dev, case):
-    """256x256x64 LDS-DMA kernel (tile_cfg=5) == F.conv2d incl. padding, partial tiles, K not a multiple of 256,
+@pytest.mark.parametrize("big", [5, 6])
+def test_conv_big_tile_kernel(dev, case, big):
+    """256x256x64 LDS-DMA kernel (tile_cfg=5; 6 = its ping-pong wave-group schedule) == F.conv2d incl. padding, partial tiles, K not a multiple of 256,
     residual + ReLU + mask epilogues and the strided-scatter dgrad form."""
     o = ops()
     n, h, w, c, k, r, stride, pad = case
@@ -149,18 +150,18 @@ def test_conv_big_tile_kernel(dev, case):
     bias = torch.randn(k, generator=gen)
     ref = F.conv2d(x, wt, bias, stride=stride, padding=pad)
     xd, wd = nhwc(x).to(dev).bfloat16(), krsc(wt).to(dev).bfloat16()
-    y = o.conv2d(xd, wd, k, r, r, stride, pad, bias=bias.to(dev), out_dtype=torch.float32, tile_cfg=5)
+    y = o.conv2d(xd, wd, k, r, r, stride, pad, bias=bias.to(dev), out_dtype=torch.float32, tile_cfg=big)
     got = nchw(y.cpu()[..., :k])
     assert torch.allclose(got, ref, rtol=2e-2, atol=8e-2), (got - ref).abs().max()
     ldy = (k + 3) // 4 * 4
     res = torch.randn(n, ref.shape[2], ref.shape[3], ldy, generator=gen).bfloat16()
     msk = torch.randn(n, ref.shape[2], ref.shape[3], ldy, generator=gen).bfloat16()
-    y2 = o.conv2d(xd, wd, k, r, r, stride, pad, bias=bias.to(dev), residual=res.to(dev), mask_ref=msk.to(dev), relu=True, tile_cfg=5)
+    y2 = o.conv2d(xd, wd, k, r, r, stride, pad, bias=bias.to(dev), residual=res.to(dev), mask_ref=msk.to(dev), relu=True, tile_cfg=big)
     y1 = o.conv2d(xd, wd, k, r, r, stride, pad, bias=bias.to(dev), residual=res.to(dev), mask_ref=msk.to(dev), relu=True, tile_cfg=1)
     assert torch.allclose(y2.float().cpu()[..., :k], y1.float().cpu()[..., :k], rtol=2e-2, atol=2e-2)
     if stride == 1 and r == 1:
         oh, ow = ref.shape[2], ref.shape[3]
-        s5 = o.conv2d(xd, wd, k, 1, 1, 1, 0, scatter=(2, 2 * oh, 2 * ow), tile_cfg=5)
+        s5 = o.conv2d(xd, wd, k, 1, 1, 1, 0, scatter=(2, 2 * oh, 2 * ow), tile_cfg=big)
         s1 = o.conv2d(xd, wd, k, 1, 1, 1, 0, scatter=(2, 2 * oh, 2 * ow), tile_cfg=1)
         assert torch.equal(s5.cpu()[:, 1::2], s1.cpu()[:, 1::2]) and torch.allclose(s5.float().cpu(), s1.float().cpu(), rtol=2e-2, atol=2e-2)
 

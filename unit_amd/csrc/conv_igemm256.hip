@@ -45,7 +45,7 @@ template <> struct O4<bf16_t> {
 
 typedef __attribute__((address_space(3))) void lds_void;
 
-template <typename TO>
+template <typename TO, bool PP>
 __global__ void __launch_bounds__(512, 2) conv_igemm256_kernel(Conv256Args p) {
   constexpr int BM = 256, BN = 256, BK = 64;
   constexpr int BUF = (BM + BN) * 128;          // 64 KB per stage
@@ -121,27 +121,73 @@ __global__ void __launch_bounds__(512, 2) conv_igemm256_kernel(Conv256Args p) {
   int frow = lane & 15, fq = lane >> 4;
   stage(0, 0);
   __syncthreads();
-  for (int kt = 0; kt < nk; ++kt) {
-    int buf = kt & 1;
-    if (kt + 1 < nk) stage(kt + 1, buf ^ 1);
-    const char* bx = smem + buf * BUF;
-    const char* bw = bx + BM * 128;
+  if constexpr (!PP) {
+    for (int kt = 0; kt < nk; ++kt) {
+      int buf = kt & 1;
+      if (kt + 1 < nk) stage(kt + 1, buf ^ 1);
+      const char* bx = smem + buf * BUF;
+      const char* bw = bx + BM * 128;
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      i32x4 fa[4], fb[8];
+      for (int ks = 0; ks < 2; ++ks) {
+        i32x4 fa[4], fb[8];
 #pragma unroll
-      for (int a = 0; a < 4; ++a) fa[a] = *reinterpret_cast<const i32x4*>(bw + swz256(wn * 64 + a * 16 + frow, ks * 4 + fq));
+        for (int a = 0; a < 4; ++a) fa[a] = *reinterpret_cast<const i32x4*>(bw + swz256(wn * 64 + a * 16 + frow, ks * 4 + fq));
 #pragma unroll
-      for (int b = 0; b < 8; ++b) fb[b] = *reinterpret_cast<const i32x4*>(bx + swz256(wm * 128 + b * 16 + frow, ks * 4 + fq));
-      __builtin_amdgcn_s_setprio(1);
+        for (int b = 0; b < 8; ++b) fb[b] = *reinterpret_cast<const i32x4*>(bx + swz256(wm * 128 + b * 16 + frow, ks * 4 + fq));
+        __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-      for (int a = 0; a < 4; ++a)
+        for (int a = 0; a < 4; ++a)
 #pragma unroll
-        for (int b = 0; b < 8; ++b)
-          acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fa[a]), __builtin_bit_cast(bf16x8, fb[b]), acc[a][b], 0, 0, 0);
-      __builtin_amdgcn_s_setprio(0);
+          for (int b = 0; b < 8; ++b)
+            acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fa[a]), __builtin_bit_cast(bf16x8, fb[b]), acc[a][b], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+      }
+      __syncthreads();   // vmcnt(0): this wave's DMA of tile kt+1 landed ; barrier: everyone's did, and everyone finished reading `buf`
     }
-    __syncthreads();   // vmcnt(0): this wave's DMA of tile kt+1 landed ; barrier: everyone's did, and everyone finished reading `buf`
+  } else {
+    // ---- ping-pong schedule: waves 0-3 (group 0) and waves 4-7 (group 1) share the four SIMDs pairwise (wave i and i+4).
+    // Every interval between two workgroup barriers one group runs a pure-MFMA section (32 MFMAs, 512 cycles) while the
+    // other runs its LOAD section (12 ds_read_b128 fragments + the LDS-DMA issue of the next k-tile): the matrix pipe of each
+    // SIMD always has exactly one wave feeding it, and no wave ever waits for LDS data inside its MFMA section.
+    // Group 1 runs one interval behind group 0 (one extra barrier up front, one fewer at the end).
+    // Hazards (2 LDS buffers, prefetch distance 1 k-tile):
+    //   WAR  DMA(t+1) -> buffer of tile t-1: issued by a group in its LOAD(t, ks=0) section; the other group's last reads of
+    //        tile t-1 were completed (lgkmcnt(0)) before the barrier that precedes this interval.
+    //   RAW  tile t+1 is first read one barrier after every wave waited vmcnt(0) for its own DMA (end of LOAD(t, ks=1)).
+    const int grp = wm;     // wm == wid >> 2
+    if (grp == 1) __builtin_amdgcn_s_barrier();
+    for (int kt = 0; kt < nk; ++kt) {
+      int buf = kt & 1;
+      const char* bx = smem + buf * BUF;
+      const char* bw = bx + BM * 128;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        // LOAD section
+        if (ks == 0 && kt + 1 < nk) stage(kt + 1, buf ^ 1);
+        i32x4 fa[4], fb[8];
+#pragma unroll
+        for (int a = 0; a < 4; ++a) fa[a] = *reinterpret_cast<const i32x4*>(bw + swz256(wn * 64 + a * 16 + frow, ks * 4 + fq));
+#pragma unroll
+        for (int b = 0; b < 8; ++b) fb[b] = *reinterpret_cast<const i32x4*>(bx + swz256(wm * 128 + b * 16 + frow, ks * 4 + fq));
+        if (ks == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        // MFMA section (registers only)
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+          for (int b = 0; b < 8; ++b)
+            acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fa[a]), __builtin_bit_cast(bf16x8, fb[b]), acc[a][b], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    if (grp == 0) __builtin_amdgcn_s_barrier();
   }
 
   TO* __restrict__ Y = (TO*)p.y;
@@ -186,16 +232,16 @@ __global__ void __launch_bounds__(512, 2) conv_igemm256_kernel(Conv256Args p) {
   }
 }
 
-template <typename TO>
+template <typename TO, bool PP>
 static int launch256(Conv256Args& a, hipStream_t st) {
   a.tiles_m = cdiv(a.M, 256); a.tiles_n = cdiv(a.K, 256);
   size_t lds = 2 * (256 + 256) * 128;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)conv_igemm256_kernel<TO>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)conv_igemm256_kernel<TO, PP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
-  conv_igemm256_kernel<TO><<<a.tiles_m * a.tiles_n, 512, lds, st>>>(a);
+  conv_igemm256_kernel<TO, PP><<<a.tiles_m * a.tiles_n, 512, lds, st>>>(a);
   UNIT_LAUNCH_CHECK();
   return UNIT_OK;
 }
@@ -203,7 +249,7 @@ static int launch256(Conv256Args& a, hipStream_t st) {
 // Same contract as unit_conv2d_fwd (include/unit_hip.h) restricted to bf16 inputs and C % 64 == 0.
 extern "C" int unit_conv2d_fwd_big(const void* x, const void* w, void* y, const float* bias, const void* residual,
                                    const void* mask_ref, int out_dtype, int N, int H, int W, int C, int K, int R, int S, int stride,
-                                   int pad, int OH, int OW, int ldy, int oy_mul, int OHf, int OWf, int relu, void* stream) {
+                                   int pad, int OH, int OW, int ldy, int oy_mul, int OHf, int OWf, int relu, int variant, void* stream) {
   UNIT_CHECK_ARG(C % 64 == 0, "conv_big: C must be a multiple of 64");
   UNIT_CHECK_ARG(ldy % 4 == 0 && ldy >= K, "conv_big: ldy must be a multiple of 4 and >= K");
   UNIT_CHECK_ARG(OH == (H + 2 * pad - R) / stride + 1 && OW == (W + 2 * pad - S) / stride + 1, "conv_big: OH/OW mismatch");
@@ -219,8 +265,9 @@ extern "C" int unit_conv2d_fwd_big(const void* x, const void* w, void* y, const 
   a.x_bytes = (unsigned)xb; a.w_bytes = (unsigned)wb;
   if (a.M == 0 || K == 0) return UNIT_OK;
   hipStream_t st = (hipStream_t)stream;
-  if (out_dtype == UNIT_BF16) return launch256<bf16_t>(a, st);
-  if (out_dtype == UNIT_F32) return launch256<float>(a, st);
+  // variant 0: one barrier per k-tile; variant 1: ping-pong wave groups (MFMA section || LOAD section)
+  if (out_dtype == UNIT_BF16) return variant ? launch256<bf16_t, true>(a, st) : launch256<bf16_t, false>(a, st);
+  if (out_dtype == UNIT_F32) return variant ? launch256<float, true>(a, st) : launch256<float, false>(a, st);
   unit_set_error("conv_big: unsupported out dtype");
   return UNIT_ERR_UNSUPPORTED;
 }

@@ -49,6 +49,7 @@ def _big_tile_default(dtype, m, k, c, kgemm):
 
 
 BIG_TILE_POLICY = _big_tile_default
+BIG_TILE_VARIANT = 0     # 0: one barrier per k-tile, 1: ping-pong wave groups (see csrc/conv_igemm256.hip)
 
 # side HIP stream for the weight-gradient kernels (set by the model when stream overlap is enabled; None = inline)
 WGRAD_STREAM = None
@@ -141,10 +142,11 @@ def conv2d(x, w, k, r, s, stride=1, pad=0, bias=None, residual=None, mask_ref=No
     if prof is not None:
         e0 = torch.cuda.Event(enable_timing=True)
         e0.record()
-    big = tile_cfg == 5 or (tile_cfg == 0 and BIG_TILE_POLICY(x.dtype, n * oh * ow, k, c, r * s * c))
+    big = tile_cfg in (5, 6) or (tile_cfg == 0 and BIG_TILE_POLICY(x.dtype, n * oh * ow, k, c, r * s * c))
     if big:
         check(lib().unit_conv2d_fwd_big(_p(x), _p(w), _p(out), _p(bias), _p(residual), _p(mask_ref), dt(out_dtype),
-                                        n, h, wd, c, k, r, s, stride, pad, oh, ow, ldy, oy_mul, ohf, owf, int(relu), _s()),
+                                        n, h, wd, c, k, r, s, stride, pad, oh, ow, ldy, oy_mul, ohf, owf, int(relu),
+                                        BIG_TILE_VARIANT if tile_cfg == 0 else (1 if tile_cfg == 6 else 0), _s()),
               "unit_conv2d_fwd_big")
     else:
         check(lib().unit_conv2d_fwd(_p(x), _p(w), _p(out), _p(bias), _p(residual), _p(mask_ref), dt(x.dtype), dt(out_dtype),
