@@ -319,6 +319,28 @@ def test_sort_desc_stable(dev):
     assert torch.equal(i2[0].cpu().long(), ri) and torch.equal(k2[0].cpu(), rk)
 
 
+@pytest.mark.parametrize("n,topk,a,ld", [(35910, 12000, 15, 80), (35910, 6000, 15, 75), (5000, 12000, 1, 1), (70, 64, 3, 8), (1, 1, 1, 1)])
+def test_sort_desc_topk(dev, n, topk, a, ld):
+    """chip-wide select + rank sort == the first topk entries of torch's stable descending sort (ties, -0.0, clustered keys)."""
+    o = ops()
+    gen = g(81)
+    hw = (n + a - 1) // a
+    n = hw * a
+    for mode in range(3):
+        head = torch.randn(3, hw, ld, generator=gen)
+        if mode == 1:
+            head = torch.round(head * 2) / 2          # massive ties (and +-0.0)
+            head[0, ::5] = -0.0
+        if mode == 2:
+            head = head * 1e-3 + 0.5                  # all keys inside one or two histogram bins
+        k, i = o.sort_desc(head.to(dev), 3, n, ld=ld, a=a, col0=0, topk=topk)
+        flat = head[:, :, :a].reshape(3, -1)
+        rk, ri = torch.sort(flat, dim=1, descending=True, stable=True)
+        t = min(topk, n)
+        assert torch.equal(i.cpu().long()[:, :t], ri[:, :t]), mode
+        assert torch.equal(k.cpu()[:, :t].view(torch.int32), rk[:, :t].view(torch.int32)), mode
+
+
 def test_nms_exact(dev):
     o = ops()
     gen = g(9)

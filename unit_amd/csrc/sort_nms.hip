@@ -213,6 +213,118 @@ extern "C" int unit_sort_desc_stable(const float* src, long batch_stride, int ld
 }
 
 // ---------------------------------------------------------------------------------------------------
+// K10b  top-k form of the same sort: find_top_rpn_proposals only consumes the first pre_nms_topk entries of the sorted
+// row (12 000 of 35 910 per image in training).  A single-workgroup radix sort leaves 252 of the 256 CUs idle for ~1 ms,
+// so the top-k path is chip-wide instead:
+//  (1) topk_select_kernel (one workgroup per image): 8192-bin histogram of the top 13 key bits -> the bin T holding the
+//      topk-th best key -> every key in a bin <= T becomes a candidate, packed as (key << 32 | index) in arbitrary order
+//      (wave-aggregated LDS counter). Nc >= min(topk, n) candidates; all non-candidates sort after every candidate.
+//  (2) rank_sort_kernel (64 candidates x 4 j-quarters per workgroup, ~800 workgroups): rank(i) = #{j : cand_j < cand_i}
+//      on the unique 64-bit composites (ties broken by ascending original index = the stable order), an O(Nc^2) count
+//      that is pure VALU + broadcast LDS reads; writes out[rank].  Entries beyond Nc are left untouched.
+// ---------------------------------------------------------------------------------------------------
+#define SEL_BINS 8192
+__global__ void __launch_bounds__(1024) topk_select_kernel(const float* __restrict__ src, long bstride, int ld, int A, int col0, int n,
+                                                           int topk, unsigned long long* __restrict__ cand, int* __restrict__ cand_count) {
+  __shared__ int hist[SEL_BINS];
+  __shared__ int wsum[16];
+  __shared__ int s_T, s_cnt;
+  int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const float* sb = src + (size_t)b * bstride + col0;
+  for (int i = tid; i < SEL_BINS; i += 1024) hist[i] = 0;
+  if (tid == 0) { s_T = SEL_BINS - 1; s_cnt = 0; }
+  __syncthreads();
+  for (int i = tid; i < n; i += 1024) {
+    int pix = i / A, a = i - pix * A;
+    atomicAdd(&hist[desc_key(sb[(size_t)pix * ld + a]) >> 19], 1);
+  }
+  __syncthreads();
+  int loc[8], sum = 0;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { loc[j] = sum; sum += hist[tid * 8 + j]; }
+  int inc = sum;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) { int t = __shfl_up(inc, o, 64); if (lane >= o) inc += t; }
+  if (lane == 63) wsum[wid] = inc;
+  __syncthreads();
+  int wbase = 0;
+  for (int w = 0; w < wid; ++w) wbase += wsum[w];
+  int excl = wbase + inc - sum;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    int lo = excl + loc[j], hi = lo + hist[tid * 8 + j];
+    if (lo < topk && hi >= topk) s_T = tid * 8 + j;      // exactly one bin satisfies this when n >= topk
+  }
+  __syncthreads();
+  unsigned T = (unsigned)s_T;
+  unsigned long long* cb = cand + (size_t)b * n;
+  for (int base = 0; base < n; base += 1024) {
+    int i = base + tid;
+    unsigned key = 0; bool c = false;
+    if (i < n) {
+      int pix = i / A, a = i - pix * A;
+      key = desc_key(sb[(size_t)pix * ld + a]);
+      c = (key >> 19) <= T;
+    }
+    unsigned long long bal = __ballot(c);
+    int wpos = 0;
+    if (lane == 0 && bal) wpos = atomicAdd(&s_cnt, __popcll(bal));
+    wpos = __shfl(wpos, 0, 64);
+    if (c) cb[wpos + __popcll(bal & ((1ull << lane) - 1ull))] = ((unsigned long long)key << 32) | (unsigned)i;
+  }
+  __syncthreads();
+  if (tid == 0) cand_count[b] = s_cnt;
+}
+
+__global__ void __launch_bounds__(256) rank_sort_kernel(const unsigned long long* __restrict__ cand, const int* __restrict__ cand_count,
+                                                        int n, const float* __restrict__ src, long bstride, int ld, int A, int col0,
+                                                        float* __restrict__ out_keys, int* __restrict__ out_idx) {
+  __shared__ unsigned long long tile[1024];
+  __shared__ int part[4][64];
+  int b = blockIdx.y;
+  int nc = cand_count[b];
+  int i0 = blockIdx.x * 64;
+  if (i0 >= nc) return;
+  int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const unsigned long long* c = cand + (size_t)b * n;
+  unsigned long long mine = (i0 + lane < nc) ? c[i0 + lane] : ~0ull;
+  int cnt = 0;
+  for (int j0 = 0; j0 < nc; j0 += 1024) {
+    __syncthreads();
+#pragma unroll
+    for (int t = tid; t < 1024; t += 256) tile[t] = (j0 + t < nc) ? c[j0 + t] : ~0ull;   // ~0 is never < anything
+    __syncthreads();
+    const unsigned long long* tq = tile + wid * 256;
+#pragma unroll 16
+    for (int j = 0; j < 256; ++j) cnt += (tq[j] < mine) ? 1 : 0;
+  }
+  part[wid][lane] = cnt;
+  __syncthreads();
+  if (wid == 0 && i0 + lane < nc) {
+    int r = part[0][lane] + part[1][lane] + part[2][lane] + part[3][lane];
+    int id = (int)(unsigned)(mine & 0xffffffffull);
+    int pix = id / A, a = id - pix * A;
+    out_keys[(size_t)b * n + r] = src[(size_t)b * bstride + (size_t)pix * ld + col0 + a];   // original bits (keeps -0.0)
+    out_idx[(size_t)b * n + r] = id;
+  }
+}
+
+extern "C" int unit_sort_desc_stable_topk(const float* src, long batch_stride, int ld, int A, int col0, int B, int n, int topk,
+                                          float* out_keys, int* out_idx, void* workspace, size_t workspace_bytes, void* stream) {
+  if (workspace_bytes < unit_sort_workspace_bytes(B, n)) { unit_set_error("sort: workspace too small"); return UNIT_ERR_WORKSPACE; }
+  UNIT_CHECK_ARG(topk > 0, "sort_topk: topk must be positive");
+  if (B == 0 || n == 0) return UNIT_OK;
+  unsigned long long* cand = (unsigned long long*)workspace;
+  int* cand_count = (int*)((char*)workspace + (size_t)B * n * 8);
+  hipStream_t st = (hipStream_t)stream;
+  topk_select_kernel<<<B, 1024, 0, st>>>(src, batch_stride, ld, A, col0, n, topk, cand, cand_count);
+  UNIT_LAUNCH_CHECK();
+  rank_sort_kernel<<<dim3((n + 63) / 64, B), 256, 0, st>>>(cand, cand_count, n, src, batch_stride, ld, A, col0, out_keys, out_idx);
+  UNIT_LAUNCH_CHECK();
+  return UNIT_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
 // K11  NMS (torchvision.ops.nms semantics): boxes sorted by descending score; box j is suppressed
 // iff an already-kept i<j has IoU(i,j) > thresh (strict); IoU = inter / (area_i + area_j - inter), no +1.
 //  (1) nms_mask_kernel: 64x64 tiles of the upper triangle -> bitmask[i][j/64]
@@ -269,12 +381,16 @@ __global__ void __launch_bounds__(NMS_SCAN_THREADS) nms_scan_kernel(const float*
   int nkept = 0;
   if (tid == 0) s_nkept = 0;
   int nchunks = (n + 63) / 64;
+  // wave 0 prefetches the next chunk's diagonal words while the row ORs of the current chunk are in flight
+  unsigned long long diag_next = (tid < 64 && tid < n) ? mk[(size_t)tid * nw] : 0ull;
   for (int c = 0; c < nchunks; ++c) {
     if (tid == c) s_cur = removed;
     __syncthreads();
     if (tid < 64) {
       int i = c * 64 + tid;
-      unsigned long long diag = (i < n) ? mk[(size_t)i * nw + c] : 0ull;
+      unsigned long long diag = diag_next;
+      int inext = i + 64;
+      diag_next = (inext < n) ? mk[(size_t)inext * nw + c + 1] : 0ull;
       unsigned long long cur = s_cur, kept = 0;
       int cnt = s_nkept;
       int lim = min(64, n - c * 64);
@@ -297,12 +413,12 @@ __global__ void __launch_bounds__(NMS_SCAN_THREADS) nms_scan_kernel(const float*
     nkept = s_nkept;
     if (nkept >= max_keep) break;
     if (tid < nw && tid > c) {
-      // OR in the mask rows of this chunk's kept boxes: 8 independent loads in flight per batch (latency-bound loop)
+      // OR in the mask rows of this chunk's kept boxes: 16 independent loads in flight per batch (latency-bound loop)
       const unsigned long long* base = mk + (size_t)(c * 64) * nw + tid;
       while (kept) {
-        unsigned long long v[8];
+        unsigned long long v[16];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
+        for (int u = 0; u < 16; ++u) {
           v[u] = 0ull;
           if (kept) {
             int j = __ffsll((long long)kept) - 1;
@@ -311,7 +427,7 @@ __global__ void __launch_bounds__(NMS_SCAN_THREADS) nms_scan_kernel(const float*
           }
         }
 #pragma unroll
-        for (int u = 0; u < 8; ++u) removed |= v[u];
+        for (int u = 0; u < 16; ++u) removed |= v[u];
       }
     }
   }

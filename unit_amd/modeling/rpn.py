@@ -119,7 +119,7 @@ class WSRPN(nn.Module):
         n, hw, ld = head.shape
         ntot = hw * a
         topk = min(self.pre_nms_topk[training], ntot)
-        skeys, sidx = ops.sort_desc(head, n, ntot, ld=ld, a=a, col0=0)
+        skeys, sidx = ops.sort_desc(head, n, ntot, ld=ld, a=a, col0=0, topk=topk)
         cb, cs, cc = ops.rpn_decode_select(head, a, a, anchors, sidx, skeys, topk, image_hw_dev, self.min_box_size)
         _, kc, boxes, scores = ops.nms(cb, cs, cc, self.nms_thresh, self.post_nms_topk[training])
         return boxes, scores, kc

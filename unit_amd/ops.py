@@ -344,8 +344,9 @@ def box_decode(deltas, boxes, weights, k=None, col0=0):
     return out
 
 
-def sort_desc(src, b, n, ld=1, a=1, col0=0, batch_stride=None):
-    """stable descending sort of n keys per batch row; keys read as src[b*bstride + (i//a)*ld + col0 + i%a]."""
+def sort_desc(src, b, n, ld=1, a=1, col0=0, batch_stride=None, topk=None):
+    """stable descending sort of n keys per batch row; keys read as src[b*bstride + (i//a)*ld + col0 + i%a].
+    topk: only the first min(topk, n) entries of each output row are needed (chip-wide select + rank sort)."""
     dev = src.device
     keys = torch.empty((b, n), dtype=torch.float32, device=dev)
     idx = torch.empty((b, n), dtype=torch.int32, device=dev)
@@ -353,6 +354,10 @@ def sort_desc(src, b, n, ld=1, a=1, col0=0, batch_stride=None):
         batch_stride = (n // a) * ld
     nb = lib().unit_sort_workspace_bytes(b, n)
     ws = workspace(nb, dev)
+    if topk is not None:
+        check(lib().unit_sort_desc_stable_topk(_p(src), batch_stride, ld, a, col0, b, n, int(topk), _p(keys), _p(idx), _p(ws),
+                                               ws.numel(), _s()), "sort_desc_stable_topk")
+        return keys, idx
     check(lib().unit_sort_desc_stable(_p(src), batch_stride, ld, a, col0, b, n, _p(keys), _p(idx), _p(ws), ws.numel(), _s()),
           "sort_desc_stable")
     return keys, idx
