@@ -196,6 +196,10 @@ def test_pools_bias_misc(dev):
     dy = torch.randn(1000, 80, generator=gen)
     db = o.bias_grad(dy.to(dev), 75).cpu()
     assert torch.allclose(db, dy[:, :75].sum(0), rtol=1e-4, atol=1e-4)
+    for m_, k_, ld_ in [(4788, 1024, 1024), (1000, 75, 80), (37, 104, 104), (300, 260, 264)]:   # bf16 vector path (ld % 8 == 0)
+        dyb = torch.randn(m_, ld_, generator=gen).bfloat16()
+        dbb = o.bias_grad(dyb.to(dev), k_).cpu()
+        assert torch.allclose(dbb, dyb.float()[:, :k_].sum(0), rtol=1e-4, atol=2e-3)
     bnw, bnb, rm, rv = [torch.rand(64, generator=gen) + 0.5 for _ in range(4)]
     sc, sh = o.frozen_bn_fold(bnw.to(dev), bnb.to(dev), rm.to(dev), rv.to(dev))
     sref = bnw * (rv + 1e-5).rsqrt()

@@ -341,12 +341,86 @@ __global__ void rpn_decode_select_kernel(const float* __restrict__ head, long he
   }
 }
 
+// Same result for topk <= 16 * 1024: thread t decodes entries t, t+1024, ... (all gathers of a thread independent and in
+// flight together, one decode per entry), keeps are counted per (row of 1024, wave) with ballots, one LDS scan gives every
+// (row, wave) its ordered output offset.
+#define DEC_ROWS 16
+__global__ void __launch_bounds__(1024) rpn_decode_select_rows_kernel(const float* __restrict__ head, long head_bstride, int ld, int A,
+                                                                      int delta_col0, const float* __restrict__ anchors,
+                                                                      const int* __restrict__ sorted_idx,
+                                                                      const float* __restrict__ sorted_logit, int Ncap, int topk,
+                                                                      const float* __restrict__ image_hw, float clampv, float min_size,
+                                                                      float* __restrict__ cand_boxes, float* __restrict__ cand_scores,
+                                                                      int* __restrict__ cand_count) {
+  __shared__ int cnt[DEC_ROWS * 16 + 1];
+  int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  float imh = image_hw[2 * b], imw = image_hw[2 * b + 1];
+  const f32x4 wt = {1.f, 1.f, 1.f, 1.f};
+  int aid[DEC_ROWS]; float sc[DEC_ROWS]; f32x4 bx[DEC_ROWS]; unsigned long long bal[DEC_ROWS];
+#pragma unroll
+  for (int k = 0; k < DEC_ROWS; ++k) {
+    int i = k * 1024 + tid;
+    aid[k] = i < topk ? sorted_idx[(size_t)b * Ncap + i] : -1;
+    sc[k] = i < topk ? sorted_logit[(size_t)b * Ncap + i] : 0.f;
+  }
+#pragma unroll
+  for (int k = 0; k < DEC_ROWS; ++k) {
+    bool keep = false;
+    if (aid[k] >= 0) {
+      int pix = aid[k] / A, a = aid[k] - pix * A;
+      const float* dp = head + (size_t)b * head_bstride + (size_t)pix * ld + delta_col0 + 4 * a;
+      f32x4 d = {dp[0], dp[1], dp[2], dp[3]};
+      f32x4 v = box_decode1(d, *reinterpret_cast<const f32x4*>(anchors + 4 * (size_t)aid[k]), wt, clampv);
+      bool fin = isfinite(v[0]) && isfinite(v[1]) && isfinite(v[2]) && isfinite(v[3]) && isfinite(sc[k]);
+      v[0] = fminf(fmaxf(v[0], 0.f), imw); v[1] = fminf(fmaxf(v[1], 0.f), imh);
+      v[2] = fminf(fmaxf(v[2], 0.f), imw); v[3] = fminf(fmaxf(v[3], 0.f), imh);
+      keep = fin && (v[2] - v[0] > min_size) && (v[3] - v[1] > min_size);
+      bx[k] = v;
+    }
+    bal[k] = __ballot(keep);
+    if (lane == 0) cnt[k * 16 + wid] = __popcll(bal[k]);
+  }
+  __syncthreads();
+  // exclusive scan of the DEC_ROWS*16 = 256 (row, wave) counts by waves 0-3
+  __shared__ int wtot[4];
+  int v = 0, inc = 0;
+  if (tid < DEC_ROWS * 16) {
+    v = cnt[tid]; inc = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { int t = __shfl_up(inc, o, 64); if (lane >= o) inc += t; }
+    if (lane == 63) wtot[wid] = inc;
+  }
+  __syncthreads();
+  if (tid < DEC_ROWS * 16) {
+    int base = 0;
+    for (int w = 0; w < wid; ++w) base += wtot[w];
+    cnt[tid] = base + inc - v;
+    if (tid == DEC_ROWS * 16 - 1) cand_count[b] = base + inc;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < DEC_ROWS; ++k) {
+    if ((bal[k] >> lane) & 1ull) {
+      size_t o = (size_t)b * topk + cnt[k * 16 + wid] + __popcll(bal[k] & ((1ull << lane) - 1ull));
+      *reinterpret_cast<f32x4*>(cand_boxes + 4 * o) = bx[k];
+      cand_scores[o] = sc[k];
+    }
+  }
+}
+
 extern "C" int unit_rpn_decode_select(const float* head, long head_batch_stride, int ld, int A, int delta_col0,
                                       const float* anchors, const int* sorted_idx, const float* sorted_logit, int B,
                                       int Ncap, int topk, const float* image_hw_dev, float scale_clamp, float min_size,
                                       float* cand_boxes, float* cand_scores, int* cand_count, void* stream) {
   UNIT_CHECK_ARG(topk <= Ncap, "rpn_decode_select: topk > Ncap");
   if (B == 0) return UNIT_OK;
+  if (topk <= DEC_ROWS * 1024) {
+    rpn_decode_select_rows_kernel<<<B, 1024, 0, (hipStream_t)stream>>>(head, head_batch_stride, ld, A, delta_col0, anchors, sorted_idx,
+                                                                    sorted_logit, Ncap, topk, image_hw_dev, scale_clamp, min_size,
+                                                                    cand_boxes, cand_scores, cand_count);
+    UNIT_LAUNCH_CHECK();
+    return UNIT_OK;
+  }
   rpn_decode_select_kernel<<<B, 1024, 0, (hipStream_t)stream>>>(head, head_batch_stride, ld, A, delta_col0, anchors, sorted_idx,
                                                              sorted_logit, Ncap, topk, image_hw_dev, scale_clamp, min_size,
                                                              cand_boxes, cand_scores, cand_count);

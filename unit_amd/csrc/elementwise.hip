@@ -219,10 +219,42 @@ __global__ void bias_grad_kernel(const T* __restrict__ dy, int M, int K, int ld,
   for (int m = m0; m < m1; ++m) acc += (float)dy[(size_t)m * ld + k];
   atomicAdd(db + k, acc);
 }
+// bf16, ld % 8 == 0: 16-byte loads (8 columns per thread), 8 row lanes per workgroup reduced through LDS
+__global__ void __launch_bounds__(256) bias_grad_vec_kernel(const bf16_t* __restrict__ dy, int M, int K, int ld, float* __restrict__ db,
+                                                            int rows_per_block) {
+  __shared__ float red[8][257];
+  int cg = threadIdx.x & 31, rl = threadIdx.x >> 5;
+  int c0 = (blockIdx.x * 32 + cg) * 8;
+  int m0 = blockIdx.y * rows_per_block, m1 = min(M, m0 + rows_per_block);
+  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (c0 < K) {
+    for (int m = m0 + rl; m < m1; m += 8) {
+      bf16x8 v = *reinterpret_cast<const bf16x8*>(dy + (size_t)m * ld + c0);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[j] += (float)v[j];
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) red[rl][cg * 8 + j] = acc[j];
+  __syncthreads();
+  int c = blockIdx.x * 256 + threadIdx.x;
+  if (c < K) {
+    float s = 0.f;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) s += red[r][threadIdx.x];
+    atomicAdd(db + c, s);
+  }
+}
 extern "C" int unit_bias_grad(const void* dy, int dtype, int M, int K, int ld, float* db, int accumulate, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   if (!accumulate) hipMemsetAsync(db, 0, sizeof(float) * K, st);
   if (M == 0) return UNIT_OK;
+  if (dtype == UNIT_BF16 && ld % 8 == 0 && ((uintptr_t)dy % 16 == 0)) {
+    int rows = 128;
+    bias_grad_vec_kernel<<<dim3(cdiv(K, 256), cdiv(M, rows)), 256, 0, st>>>((const bf16_t*)dy, M, K, ld, db, rows);
+    UNIT_LAUNCH_CHECK();
+    return UNIT_OK;
+  }
   int rpb = 256;
   dim3 grid(cdiv(K, 64), cdiv(M, rpb));
   if (dtype == UNIT_BF16) bias_grad_kernel<bf16_t><<<grid, 64, 0, st>>>((const bf16_t*)dy, M, K, ld, db, rpb);

@@ -335,10 +335,11 @@ __global__ void wsddn_mil_kernel(const float* __restrict__ streams, int ld, int 
   __shared__ float lds[17];
   int b = blockIdx.x;
   int tid = threadIdx.x;
-  // column max of det logits over valid rows
-  for (int c = tid; c < K; c += blockDim.x) { colmax[c] = -INFINITY; colsum[c] = 0.f; pcls[c] = 0.f; coldot[c] = 0.f; }
-  __syncthreads();
-  // each thread owns rows r = tid, tid+blockDim, ... of this image
+  // All K column reductions of a pass are batched: each wave reduces its rows for every column, lane 0 parks the K
+  // partials in LDS, ONE barrier, threads c < K combine the waves in wave order (3 barriers per pass instead of 3 per column).
+  __shared__ float part[16][MIL_MAXK];
+  const int lane = tid & 63, wid = tid >> 6, nwv = (blockDim.x + 63) >> 6;
+  // pass 1: column max of det logits over valid rows
   for (int c = 0; c < K; ++c) {
     float m = -INFINITY;
     for (int r = tid; r < S; r += blockDim.x) {
@@ -346,44 +347,51 @@ __global__ void wsddn_mil_kernel(const float* __restrict__ streams, int ld, int 
       if (valid[row] >= 0) m = fmaxf(m, streams[row * ld + dcol0 + c] / td);
     }
     m = wave_reduce_max(m);
-    __syncthreads();
-    if ((tid & 63) == 0) lds[tid >> 6] = m;
-    __syncthreads();
-    if (tid == 0) { float mm = -INFINITY; for (int w = 0; w < (int)(blockDim.x >> 6); ++w) mm = fmaxf(mm, lds[w]); colmax[c] = mm; }
-    __syncthreads();
-  }
-  for (int c = 0; c < K; ++c) {
-    float s = 0.f;
-    for (int r = tid; r < S; r += blockDim.x) {
-      size_t row = (size_t)b * S + r;
-      if (valid[row] >= 0) s += expf(streams[row * ld + dcol0 + c] / td - colmax[c]);
-    }
-    float t = block_sum(s, lds);
-    if (tid == 0) colsum[c] = t;
+    if (lane == 0) part[wid][c] = m;
   }
   __syncthreads();
-  // x_r and class vector
+  if (tid < K) { float mm = -INFINITY; for (int w = 0; w < nwv; ++w) mm = fmaxf(mm, part[w][tid]); colmax[tid] = mm; }
+  __syncthreads();
+  // pass 2: column sum of exp
   for (int c = 0; c < K; ++c) {
-    float s = 0.f;
+    float sacc = 0.f;
     for (int r = tid; r < S; r += blockDim.x) {
       size_t row = (size_t)b * S + r;
-      float x = 0.f;
-      if (valid[row] >= 0) {
-        const float* cs = streams + row * ld + ccol0;
-        float mx = -INFINITY;
-        for (int k = 0; k < K; ++k) mx = fmaxf(mx, cs[k] / tc);
-        float se = 0.f;
-        for (int k = 0; k < K; ++k) se += expf(cs[k] / tc - mx);
+      if (valid[row] >= 0) sacc += expf(streams[row * ld + dcol0 + c] / td - colmax[c]);
+    }
+    sacc = wave_reduce_sum(sacc);
+    if (lane == 0) part[wid][c] = sacc;
+  }
+  __syncthreads();
+  if (tid < K) { float t = 0.f; for (int w = 0; w < nwv; ++w) t += part[w][tid]; colsum[tid] = t; }
+  __syncthreads();
+  // pass 3: x_r (row softmax evaluated once per row) ...
+  for (int r = tid; r < S; r += blockDim.x) {
+    size_t row = (size_t)b * S + r;
+    if (valid[row] >= 0) {
+      const float* cs = streams + row * ld + ccol0;
+      float mx = -INFINITY;
+      for (int k = 0; k < K; ++k) mx = fmaxf(mx, cs[k] / tc);
+      float se = 0.f;
+      for (int k = 0; k < K; ++k) se += expf(cs[k] / tc - mx);
+      for (int c = 0; c < K; ++c) {
         float s1 = expf(cs[c] / tc - mx) / se;
         float s2 = expf(streams[row * ld + dcol0 + c] / td - colmax[c]) / colsum[c];
-        x = s1 * s2;
+        xr_out[row * K + c] = s1 * s2;
       }
-      if (xr_out) xr_out[row * K + c] = x;
-      s += x;
+    } else {
+      for (int c = 0; c < K; ++c) xr_out[row * K + c] = 0.f;
     }
-    float t = block_sum(s, lds);
-    if (tid == 0) pcls[c] = t;
   }
+  // ... and the class vector p_c = sum_r x_rc (every thread re-reads only the rows it wrote itself)
+  for (int c = 0; c < K; ++c) {
+    float sacc = 0.f;
+    for (int r = tid; r < S; r += blockDim.x) sacc += xr_out[((size_t)b * S + r) * K + c];
+    sacc = wave_reduce_sum(sacc);
+    if (lane == 0) part[wid][c] = sacc;
+  }
+  __syncthreads();
+  if (tid < K) { float t = 0.f; for (int w = 0; w < nwv; ++w) t += part[w][tid]; pcls[tid] = t; }
   __syncthreads();
   // BCE on clamped class vector ; d loss / d p
   float l = 0.f;
@@ -402,15 +410,7 @@ __global__ void wsddn_mil_kernel(const float* __restrict__ streams, int ld, int 
   if (!dy) return;
   __syncthreads();
   // backward: x = s1*s2 ; dcs = s1 * (dx*s2 - sum_c dx*s2*s1) / tc ; dds = s2 * (dx*s1 - coldot_c) / td , coldot_c = sum_r dx*s1*s2
-  for (int c = 0; c < K; ++c) {
-    float s = 0.f;
-    for (int r = tid; r < S; r += blockDim.x) {
-      size_t row = (size_t)b * S + r;
-      if (valid[row] >= 0 && xr_out) s += dp[c] * xr_out[row * K + c];
-    }
-    float t = block_sum(s, lds);
-    if (tid == 0) coldot[c] = t;
-  }
+  if (tid < K) coldot[tid] = dp[tid] * pcls[tid];      // sum_r dp_c * x_rc  (x_rc = 0 on invalid rows)
   __syncthreads();
   for (int r = tid; r < S; r += blockDim.x) {
     size_t row = (size_t)b * S + r;

@@ -36,24 +36,57 @@ __global__ void multi_reduce_kernel(const UnitTensorDesc* __restrict__ descs, in
   *reinterpret_cast<f32x4*>(grads + d.offset + i) = s;
 }
 
+__device__ __forceinline__ void store4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+__device__ __forceinline__ void store4(bf16_t* p, f32x4 v) {
+  bf16x4 o = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
+  *reinterpret_cast<bf16x4*>(p) = o;
+}
+
+// One workgroup = one 32 (k) x 32 (c) tile of one (r, s) tap: the forward copy keeps the [K][R][S][C] order (coalesced
+// along c); the dgrad copy is [C][R'][S'][K], i.e. a transpose of the tile, staged through LDS so that its stores are
+// coalesced along k as well (the direct form scattered 2-byte stores with a stride of K elements).
+// block count per tensor: cdiv(K,32) * cdiv(C,32) * R * S  (unit_amd/multi.py builds block0 with the same formula).
 template <typename T>
-__global__ void multi_prep_kernel(const UnitTensorDesc* __restrict__ descs, int n, const float* __restrict__ params) {
+__global__ void __launch_bounds__(256) multi_prep_kernel(const UnitTensorDesc* __restrict__ descs, int n, const float* __restrict__ params) {
+  __shared__ float tile[32][33];
   int t = find_tensor(descs, n, blockIdx.x);
   UnitTensorDesc d = descs[t];
-  int RSC = d.R * d.S * d.C;
-  long KK = (long)d.K * RSC;
-  long i0 = (long)(blockIdx.x - d.block0) * MT_ELEMS_PER_BLOCK + threadIdx.x * 4;
-  if (i0 >= KK) return;
-  f32x4 p = *reinterpret_cast<const f32x4*>(params + d.offset + i0);
-  int k = i0 / RSC; int rem = i0 - (long)k * RSC;          // the 4 elements share k, r, s (C % 4 == 0)
-  int c = rem % d.C; int rs = rem / d.C; int s = rs % d.S; int r = rs / d.S;
-  float sc = d.scale ? d.scale[k] : 1.0f;
+  int lb = blockIdx.x - d.block0;
+  int tiles_c = (d.C + 31) >> 5, tiles_k = (d.K + 31) >> 5;
+  int rs = lb / (tiles_k * tiles_c); int rem = lb - rs * (tiles_k * tiles_c);
+  int k0 = (rem / tiles_c) * 32, c0 = (rem % tiles_c) * 32;
+  int r = rs / d.S, sx = rs - r * d.S;
   T* wf = (T*)d.wf; T* wd = (T*)d.wd;
+  {
+    int ky = threadIdx.x >> 3, cx = (threadIdx.x & 7) * 4;
+    int k = k0 + ky, c = c0 + cx;
+    f32x4 p = {0.f, 0.f, 0.f, 0.f};
+    if (k < d.K && c < d.C) {                                  // C % 4 == 0: the 4 channels are in range together
+      size_t i = ((size_t)k * d.R * d.S + rs) * d.C + c;
+      p = *reinterpret_cast<const f32x4*>(params + d.offset + i);
+      float sc = d.scale ? d.scale[k] : 1.0f;
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    float v = p[j] * sc;
-    wf[i0 + j] = (T)v;
-    if (wd) wd[(((size_t)(c + j) * d.R + (d.R - 1 - r)) * d.S + (d.S - 1 - s)) * d.K + k] = (T)v;
+      for (int j = 0; j < 4; ++j) p[j] *= sc;
+      store4(wf + i, p);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) tile[cx + j][ky] = p[j];
+  }
+  if (!wd) return;
+  __syncthreads();
+  {
+    int cy = threadIdx.x >> 3, kx = (threadIdx.x & 7) * 4;
+    int c = c0 + cy;
+    if (c < d.C) {
+      size_t o = (((size_t)c * d.R + (d.R - 1 - r)) * d.S + (d.S - 1 - sx)) * d.K + k0 + kx;
+      if ((d.K & 3) == 0) {                                      // rows of the dgrad copy stay 4-element aligned
+        if (k0 + kx < d.K) store4(wd + o, f32x4{tile[cy][kx], tile[cy][kx + 1], tile[cy][kx + 2], tile[cy][kx + 3]});
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (k0 + kx + j < d.K) wd[o + j] = (T)tile[cy][kx + j];
+      }
+    }
   }
 }
 

@@ -212,9 +212,16 @@ __global__ void roi_align_bwd_gather_kernel(const T* __restrict__ gout, int H, i
   float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   int r_begin = 0, r_end = R;
   if (rois_per_image > 0) { r_begin = n * rois_per_image; r_end = min(R, r_begin + rois_per_image); }
-  for (int r = r_begin; r < r_end; ++r) {
+  // 64 RoIs are tested per iteration (one per lane, bounding box of their sample taps); only the hits are visited
+  for (int rb = r_begin; rb < r_end; rb += 64) {
+   bool hit = false;
+   if (rb + lane < r_end) {
+     const RoiG& q = tab[rb + lane];
+     hit = q.b == n + image_offset && py >= q.y0 && py <= q.y1 && px >= q.x0 && px <= q.x1;
+   }
+   for (unsigned long long hm = __ballot(hit); hm; hm &= hm - 1) {
+    int r = rb + __ffsll((long long)hm) - 1;
     RoiG t = tab[r];                                   // wave-uniform
-    if (t.b != n + image_offset || py < t.y0 || py > t.y1 || px < t.x0 || px > t.x1) continue;
     // lanes 0..out-1: row weights of bin (lane*step); lanes 32..32+out-1: column weights
     float wv = 0.f;
     int o = lane & 31;
@@ -249,6 +256,7 @@ __global__ void roi_align_bwd_gather_kernel(const T* __restrict__ gout, int H, i
       }
     }
     __builtin_amdgcn_wave_barrier();
+   }
   }
   if (!cvalid) return;
   size_t o = (size_t)pix * C + c0;

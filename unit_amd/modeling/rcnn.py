@@ -260,30 +260,53 @@ class WeaklySupervisedRCNNNoMeta(nn.Module):
         anchors = rpn.anchor_generator.grid(fh, fw)
 
         # a3 RPN head on all images; a4/a5 labels + loss on the supervised ones; a6 proposals for all (no grad)
-        head, c.rpn_ctx = rpn.rpn_head.fwd(feat, save=True)
+        n_roi_cap = rpn.post_nms_topk[True] + batch.gt_boxes.shape[1]
+        # The RPN branch (anchor labelling -> loss -> backward) needs nothing from the proposal pipeline and vice versa: with
+        # early_backward the whole branch runs on a side stream, so that its dense conv work fills the chip while the
+        # latency-bound proposal chain (select -> rank sort -> decode -> NMS -> sampling, a few workgroups each) is the
+        # only thing on the main stream's critical path.  The sampling permutations have no data dependence at all: they
+        # are drawn on the side stream while the backbone is still running.
+        side_rpn = (early_backward and n_sup > 0 and self._streams_on()
+                    and any(p.requires_grad for p in rpn.rpn_head.parameters()))
+        perm_ready = None
         if perms is None:
-            perms = self.sampling_permutations(n_sup, anchors.shape[0], rpn.post_nms_topk[True] + batch.gt_boxes.shape[1])
+            if side_rpn:
+                with torch.cuda.stream(self._rpn_stream):
+                    perms = self.sampling_permutations(n_sup, anchors.shape[0], n_roi_cap)
+                    perm_ready = torch.cuda.Event()
+                    perm_ready.record()
+                perms["roi"].record_stream(torch.cuda.current_stream())
+            else:
+                perms = self.sampling_permutations(n_sup, anchors.shape[0], n_roi_cap)
+        head, c.rpn_ctx = rpn.rpn_head.fwd(feat, save=True)
         c.dhead = None
-        if n_sup > 0:
-            c.anchor_labels, c.anchor_match, _ = rpn.label_and_sample_anchors(anchors, batch.gt_boxes, batch.gt_count, perms["rpn"])
-            _, c.dhead = ops.rpn_loss(head[:n_sup], rpn.num_anchors, rpn.num_anchors, c.anchor_labels, c.anchor_match, batch.gt_boxes,
-                                      anchors, rpn.batch_size_per_image * n_sup, dt, loss_out=c.losses[6:8])
-        # The RPN branch's backward needs nothing but dhead: start it NOW on a side stream so that its dense conv work
-        # overlaps the latency-bound proposal pipeline (sort -> decode -> NMS -> sampling run on 1-4 workgroups).
         c.drpn = None
         c.rpn_bwd_early = False
-        if c.dhead is not None and early_backward and self._streams_on() and any(p.requires_grad for p in rpn.rpn_head.parameters()):
+
+        def rpn_branch():
+            c.anchor_labels, c.anchor_match, _ = rpn.label_and_sample_anchors(anchors, batch.gt_boxes, batch.gt_count, perms["rpn"])
+            _, c.dhead = ops.rpn_loss(head[:n_sup], rpn.num_anchors, rpn.num_anchors, c.anchor_labels, c.anchor_match, batch.gt_boxes,
+                                      anchors, rpn.batch_size_per_image * n_sup, dt, loss_out=c.rpn_losses)
+
+        if side_rpn:
             self._reattach_grads()
             main, s2 = torch.cuda.current_stream(), self._rpn_stream
             s2.wait_stream(main)
-            for t in (c.dhead, feat) + tuple(c.rpn_ctx):
+            for t in (head, feat, anchors, perms["rpn"]) + tuple(c.rpn_ctx):
                 t.record_stream(s2)
             with torch.cuda.stream(s2):
+                c.rpn_losses = torch.zeros(2, dtype=torch.float32, device=self.device)   # folded into c.losses at the join
+                rpn_branch()
                 c.drpn = rpn.rpn_head.bwd(c.rpn_ctx, c.dhead, n_sup)
             c.rpn_bwd_early = True
+        elif n_sup > 0:
+            c.rpn_losses = c.losses[6:8]
+            rpn_branch()
         hw = torch.tensor(sizes, dtype=torch.float32).to(self.device, non_blocking=True)
         props, pscores, pcount = rpn.predict_proposals(head, anchors, hw, True)
         c.proposals = (props, pscores, pcount)
+        if perm_ready is not None:
+            torch.cuda.current_stream().wait_event(perm_ready)
 
         # a7 RoI sampling (supervised) + first-512 weak proposals ; a8 RoIAlign on all RoIs at once
         s = rh.batch_size_per_image
@@ -452,6 +475,8 @@ class WeaklySupervisedRCNNNoMeta(nn.Module):
             torch.cuda.current_stream().wait_stream(self._rpn_stream)      # launched during the forward plan
             drpn = c.drpn
             drpn.record_stream(torch.cuda.current_stream())
+            c.rpn_losses.record_stream(torch.cuda.current_stream())
+            c.losses[6:8] += c.rpn_losses                                  # the branch's loss_rpn_cls / loss_rpn_loc
             done("rpn")
         elif c.dhead is not None and any(p.requires_grad for p in rpn.rpn_head.parameters()):
             drpn = rpn.rpn_head.bwd(c.rpn_ctx, c.dhead, n_sup)

@@ -58,7 +58,10 @@ class ConvPlan:
             d.wd = m.wd.data_ptr() if m.wd is not None else None
             d.offset = m._flat_offset
             d.splits, d.K, d.R, d.S, d.C, d.block0 = m._splits, m.cout, m.k, m.k, m.cin, b0
-            b0 += (kk + ELEMS_PER_BLOCK - 1) // ELEMS_PER_BLOCK
+            if with_partial:
+                b0 += (kk + ELEMS_PER_BLOCK - 1) // ELEMS_PER_BLOCK
+            else:   # weight prep: one workgroup per 32 (k) x 32 (c) tile of each (r, s) tap (csrc/multi.hip)
+                b0 += ((m.cout + 31) // 32) * ((m.cin + 31) // 32) * m.k * m.k
         host = torch.frombuffer(bytearray(bytes(descs)), dtype=torch.uint8)
         return host.to(self.model.device), len(convs), b0
 
