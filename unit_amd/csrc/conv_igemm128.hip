@@ -1,0 +1,246 @@
+// conv_igemm128.hip -- mid-size LDS-DMA implicit-GEMM convolution (forward / dgrad) for the backbone layers
+// (res2-res4 on 2-4 images: M = 9 576 .. 150 000 output pixels, 64..1024 channels), where a 256x256 tile leaves most of
+// the 256 CUs without a workgroup and the register-staged conv_igemm.hip kernel is latency-bound at one wave per SIMD.
+//
+// Same math, operand layout, swizzle and epilogue as conv_igemm256.hip, scaled to 4 waves (2 x 2) per workgroup:
+//   BM x BN x 64 tile, BM, BN in {128, 64}; each wave (BM/2) x (BN/2); operands HBM/L2 -> LDS by LDS-DMA
+//   (`buffer_load_dwordx4 ... lds`, no staging VGPRs), two LDS stages of (BM+BN)*128 B: 64 KB at 128x128, so that two
+//   workgroups share a CU (2 waves per SIMD: one wave's fragment reads hide under the other's MFMAs).
+//   All 16 fragment reads of a k-tile are issued up front; the MFMAs start on counted lgkmcnt waits as they land.
+// Requires bf16 operands and C % 64 == 0.
+#include "common.h"
+
+struct ConvDmaArgs {
+  const void* x; const void* w; void* y;
+  const float* bias; const void* residual; const void* mask_ref;
+  int N, H, W, C;
+  int K, R, S, stride, pad;
+  int OH, OW;
+  int ldy, oy_mul, OHf, OWf;
+  int relu;
+  int Kgemm, M;
+  int tiles_m, tiles_n;
+  unsigned x_bytes, w_bytes;
+};
+
+__device__ __forceinline__ int swz128(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
+
+template <typename TO> struct Out4;
+template <> struct Out4<float> {
+  static __device__ __forceinline__ void load(const float* p, float (&v)[4]) { f32x4 a = *reinterpret_cast<const f32x4*>(p); v[0] = a[0]; v[1] = a[1]; v[2] = a[2]; v[3] = a[3]; }
+  static __device__ __forceinline__ void store(float* p, const float (&v)[4]) { f32x4 a = {v[0], v[1], v[2], v[3]}; *reinterpret_cast<f32x4*>(p) = a; }
+};
+template <> struct Out4<bf16_t> {
+  static __device__ __forceinline__ void load(const bf16_t* p, float (&v)[4]) {
+    bf16x4 a = *reinterpret_cast<const bf16x4*>(p);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = (float)a[i];
+  }
+  static __device__ __forceinline__ void store(bf16_t* p, const float (&v)[4]) {
+    bf16x4 a;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) a[i] = (bf16_t)v[i];
+    *reinterpret_cast<bf16x4*>(p) = a;
+  }
+};
+
+typedef __attribute__((address_space(3))) void lds_void_t;
+
+template <typename TO, int BM, int BN>
+__global__ void __launch_bounds__(256, 2) conv_igemm_dma_kernel(ConvDmaArgs p) {
+  constexpr int BK = 64;
+  constexpr int BUF = (BM + BN) * 128;           // bytes per stage
+  constexpr int WMT = BM / 2, WNT = BN / 2;      // wave tile: pixels x channels
+  constexpr int FB = WMT / 16, FA = WNT / 16;    // MFMA tiles per wave: pixels (B operand), channels (A operand)
+  constexpr int XI = BM / 32, WI = BN / 32;      // LDS-DMA instructions per wave and operand (8 rows each)
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  int nwg = p.tiles_m * p.tiles_n;
+  int bid = blockIdx.x;
+  {
+    int q = nwg / 8, r = nwg % 8, xcd = bid % 8, loc = bid / 8;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+  }
+  int tile_n = bid % p.tiles_n, tile_m = bid / p.tiles_n;
+  int m0 = tile_m * BM, n0 = tile_n * BN;
+
+  const bf16_t* __restrict__ X = (const bf16_t*)p.x;
+  const bf16_t* __restrict__ Wt = (const bf16_t*)p.w;
+  __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(X), 0, (int)p.x_bytes, 0x00020000);
+  __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(Wt), 0, (int)p.w_bytes, 0x00020000);
+  constexpr unsigned OOB = 0xFFFFFFF0u;
+
+  int tid = threadIdx.x, lane = tid & 63;
+  int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int wm = wid >> 1, wn = wid & 1;
+  int lrow = lane >> 3, lc = lane & 7;
+
+  // staging: wave `wid`, instruction i covers tile rows R0 = (i*4 + wid)*8 .. +8 ; lane -> row R0 + lrow, LDS chunk lc
+  // (lane-linear image), source chunk lc ^ f(row)
+  int x_ih0[XI], x_iw0[XI]; unsigned x_base[XI]; bool x_ok[XI]; int x_q[XI];
+  unsigned w_off[WI]; bool w_ok[WI];
+#pragma unroll
+  for (int i = 0; i < XI; ++i) {
+    int row = (i * 4 + wid) * 8 + lrow;
+    x_q[i] = lc ^ ((row >> 1) & 7);
+    int m = m0 + row;
+    x_ok[i] = m < p.M;
+    int mm = x_ok[i] ? m : 0;
+    int ow = mm % p.OW; int t = mm / p.OW; int oh = t % p.OH; int n = t / p.OH;
+    x_ih0[i] = oh * p.stride - p.pad; x_iw0[i] = ow * p.stride - p.pad;
+    x_base[i] = (unsigned)n * (unsigned)(p.H * p.W * p.C);
+  }
+#pragma unroll
+  for (int i = 0; i < WI; ++i) {
+    int row = (i * 4 + wid) * 8 + lrow;
+    int q = lc ^ ((row >> 1) & 7);
+    int nn = n0 + row;
+    w_ok[i] = nn < p.K;
+    w_off[i] = ((unsigned)(w_ok[i] ? nn : 0) * (unsigned)p.Kgemm + (unsigned)q * 8u) * 2u;
+  }
+
+  auto stage = [&](int kt, int buf) {
+    int k0 = kt * BK;                       // wave-uniform: C % 64 == 0 -> the whole k-tile sits inside one (r,s)
+    int rs = k0 / p.C; int ch0 = k0 - rs * p.C; int r = rs / p.S; int s = rs - r * p.S;
+    char* base = smem + buf * BUF;
+#pragma unroll
+    for (int i = 0; i < XI; ++i) {
+      int R0 = (i * 4 + wid) * 8;
+      int ih = x_ih0[i] + r, iw = x_iw0[i] + s;
+      bool ok = x_ok[i] && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
+      unsigned off = (x_base[i] + (unsigned)((ih * p.W + iw) * p.C + ch0 + x_q[i] * 8)) * 2u;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, (lds_void_t*)(base + R0 * 128), 16, ok ? off : OOB, 0, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < WI; ++i) {
+      int R0 = (i * 4 + wid) * 8;
+      unsigned off = w_off[i] + (unsigned)k0 * 2u;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (lds_void_t*)(base + BM * 128 + R0 * 128), 16, w_ok[i] ? off : OOB, 0, 0, 0);
+    }
+  };
+
+  f32x4 acc[FA][FB];
+#pragma unroll
+  for (int a = 0; a < FA; ++a)
+#pragma unroll
+    for (int b = 0; b < FB; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  int nk = p.Kgemm / BK;
+  int frow = lane & 15, fq = lane >> 4;
+  stage(0, 0);
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    int buf = kt & 1;
+    if (kt + 1 < nk) stage(kt + 1, buf ^ 1);
+    const char* bx = smem + buf * BUF;
+    const char* bw = bx + BM * 128;
+    i32x4 fa[2][FA], fb[2][FB];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+      for (int a = 0; a < FA; ++a) fa[ks][a] = *reinterpret_cast<const i32x4*>(bw + swz128(wn * WNT + a * 16 + frow, ks * 4 + fq));
+#pragma unroll
+      for (int b = 0; b < FB; ++b) fb[ks][b] = *reinterpret_cast<const i32x4*>(bx + swz128(wm * WMT + b * 16 + frow, ks * 4 + fq));
+    }
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int a = 0; a < FA; ++a)
+#pragma unroll
+        for (int b = 0; b < FB; ++b)
+          acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fa[ks][a]), __builtin_bit_cast(bf16x8, fb[ks][b]), acc[a][b], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+    __syncthreads();   // vmcnt(0): this wave's DMA of tile kt+1 landed ; barrier: everyone's did, and everyone finished reading `buf`
+  }
+
+  TO* __restrict__ Y = (TO*)p.y;
+  const TO* __restrict__ Rz = (const TO*)p.residual;
+  const TO* __restrict__ Mk = (const TO*)p.mask_ref;
+  bool plain = (p.oy_mul == 1 && p.OHf == p.OH && p.OWf == p.OW);
+#pragma unroll
+  for (int b = 0; b < FB; ++b) {
+    int m = m0 + wm * WMT + b * 16 + frow;
+    if (m >= p.M) continue;
+    long off;
+    if (plain) off = (long)m * p.ldy;
+    else {
+      int ow = m % p.OW; int t = m / p.OW; int oh = t % p.OH; int n = t / p.OH;
+      off = (((long)n * p.OHf + (long)oh * p.oy_mul) * p.OWf + (long)ow * p.oy_mul) * p.ldy;
+    }
+#pragma unroll
+    for (int a = 0; a < FA; ++a) {
+      int n = n0 + wn * WNT + a * 16 + fq * 4;
+      if (n >= p.ldy) continue;
+      float v[4] = {acc[a][b][0], acc[a][b][1], acc[a][b][2], acc[a][b][3]};
+      if (p.bias) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] += (n + j < p.K) ? p.bias[n + j] : 0.f;
+      }
+      if (Rz) {
+        float rr[4]; Out4<TO>::load(Rz + off + n, rr);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] += rr[j];
+      }
+      if (p.relu) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
+      }
+      if (Mk) {
+        float mm[4]; Out4<TO>::load(Mk + off + n, mm);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = mm[j] > 0.f ? v[j] : 0.f;
+      }
+      Out4<TO>::store(Y + off + n, v);
+    }
+  }
+}
+
+template <typename TO, int BM, int BN>
+static int launch_dma(ConvDmaArgs& a, hipStream_t st) {
+  a.tiles_m = cdiv(a.M, BM); a.tiles_n = cdiv(a.K, BN);
+  size_t lds = 2 * (BM + BN) * 128;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)conv_igemm_dma_kernel<TO, BM, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  conv_igemm_dma_kernel<TO, BM, BN><<<a.tiles_m * a.tiles_n, 256, lds, st>>>(a);
+  UNIT_LAUNCH_CHECK();
+  return UNIT_OK;
+}
+
+// Same contract as unit_conv2d_fwd (include/unit_hip.h) restricted to bf16 inputs and C % 64 == 0.
+// tile: 0 = 128x128, 1 = 64 (pixels) x 128 (channels), 2 = 128 x 64.
+extern "C" int unit_conv2d_fwd_mid(const void* x, const void* w, void* y, const float* bias, const void* residual,
+                                   const void* mask_ref, int out_dtype, int N, int H, int W, int C, int K, int R, int S, int stride,
+                                   int pad, int OH, int OW, int ldy, int oy_mul, int OHf, int OWf, int relu, int tile, void* stream) {
+  UNIT_CHECK_ARG(C % 64 == 0, "conv_mid: C must be a multiple of 64");
+  UNIT_CHECK_ARG(ldy % 4 == 0 && ldy >= K, "conv_mid: ldy must be a multiple of 4 and >= K");
+  UNIT_CHECK_ARG(OH == (H + 2 * pad - R) / stride + 1 && OW == (W + 2 * pad - S) / stride + 1, "conv_mid: OH/OW mismatch");
+  UNIT_CHECK_ARG((OH - 1) * oy_mul < OHf && (OW - 1) * oy_mul < OWf, "conv_mid: output scatter out of range");
+  UNIT_CHECK_ARG(((uintptr_t)x % 16 == 0) && ((uintptr_t)w % 16 == 0) && ((uintptr_t)y % 16 == 0), "conv_mid: 16B alignment");
+  UNIT_CHECK_ARG(tile >= 0 && tile <= 2, "conv_mid: tile must be 0..2");
+  ConvDmaArgs a;
+  a.x = x; a.w = w; a.y = y; a.bias = bias; a.residual = residual; a.mask_ref = mask_ref;
+  a.N = N; a.H = H; a.W = W; a.C = C; a.K = K; a.R = R; a.S = S; a.stride = stride; a.pad = pad;
+  a.OH = OH; a.OW = OW; a.ldy = ldy; a.oy_mul = oy_mul; a.OHf = OHf; a.OWf = OWf; a.relu = relu;
+  a.Kgemm = R * S * C; a.M = N * OH * OW;
+  size_t xb = (size_t)N * H * W * C * 2, wb = (size_t)K * R * S * C * 2;
+  UNIT_CHECK_ARG(xb < 0xFFFFFFF0ull && wb < 0xFFFFFFF0ull, "conv_mid: operand larger than 4 GiB");
+  a.x_bytes = (unsigned)xb; a.w_bytes = (unsigned)wb;
+  if (a.M == 0 || K == 0) return UNIT_OK;
+  hipStream_t st = (hipStream_t)stream;
+  if (out_dtype == UNIT_BF16) {
+    if (tile == 0) return launch_dma<bf16_t, 128, 128>(a, st);
+    if (tile == 1) return launch_dma<bf16_t, 64, 128>(a, st);
+    return launch_dma<bf16_t, 128, 64>(a, st);
+  }
+  if (out_dtype == UNIT_F32) {
+    if (tile == 0) return launch_dma<float, 128, 128>(a, st);
+    if (tile == 1) return launch_dma<float, 64, 128>(a, st);
+    return launch_dma<float, 128, 64>(a, st);
+  }
+  unit_set_error("conv_mid: unsupported out dtype");
+  return UNIT_ERR_UNSUPPORTED;
+}

@@ -48,6 +48,12 @@ def _big_tile_default(dtype, m, k, c, kgemm):
     return tiles >= 128
 
 
+def _mid_tile_default(dtype, m, k, c, kgemm):
+    """-1: use the register-staged conv_igemm.hip kernel; 0..2: LDS-DMA 4-wave kernel with that tile (csrc/conv_igemm128.hip)"""
+    return -1
+
+
+MID_TILE_POLICY = _mid_tile_default
 BIG_TILE_POLICY = _big_tile_default
 BIG_TILE_VARIANT = 0     # 0: one barrier per k-tile, 1: ping-pong wave groups (see csrc/conv_igemm256.hip)
 
@@ -143,7 +149,16 @@ def conv2d(x, w, k, r, s, stride=1, pad=0, bias=None, residual=None, mask_ref=No
         e0 = torch.cuda.Event(enable_timing=True)
         e0.record()
     big = tile_cfg in (5, 6) or (tile_cfg == 0 and BIG_TILE_POLICY(x.dtype, n * oh * ow, k, c, r * s * c))
-    if big:
+    mid = -1
+    if tile_cfg in (7, 8, 9):
+        mid = tile_cfg - 7
+    elif tile_cfg == 0 and not big:
+        mid = MID_TILE_POLICY(x.dtype, n * oh * ow, k, c, r * s * c)
+    if mid >= 0:
+        check(lib().unit_conv2d_fwd_mid(_p(x), _p(w), _p(out), _p(bias), _p(residual), _p(mask_ref), dt(out_dtype),
+                                        n, h, wd, c, k, r, s, stride, pad, oh, ow, ldy, oy_mul, ohf, owf, int(relu), mid, _s()),
+              "unit_conv2d_fwd_mid")
+    elif big:
         check(lib().unit_conv2d_fwd_big(_p(x), _p(w), _p(out), _p(bias), _p(residual), _p(mask_ref), dt(out_dtype),
                                         n, h, wd, c, k, r, s, stride, pad, oh, ow, ldy, oy_mul, ohf, owf, int(relu),
                                         BIG_TILE_VARIANT if tile_cfg == 0 else (1 if tile_cfg == 6 else 0), _s()),
@@ -155,7 +170,7 @@ def conv2d(x, w, k, r, s, stride=1, pad=0, bias=None, residual=None, mask_ref=No
     if prof is not None:
         e1 = torch.cuda.Event(enable_timing=True)
         e1.record()
-        prof.setdefault("conv_igemm", []).append((e0, e1, 2.0 * n * oh * ow * k * r * s * c))
+        prof.setdefault("conv_igemm256" if (big and mid < 0) else ("conv_igemm_dma" if mid >= 0 else "conv_igemm"), []).append((e0, e1, 2.0 * n * oh * ow * k * r * s * c))
     return out
 
 
