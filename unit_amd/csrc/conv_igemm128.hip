@@ -77,8 +77,10 @@ __global__ void __launch_bounds__(256, 2) conv_igemm_dma_kernel(ConvDmaArgs p) {
 
   // staging: wave `wid`, instruction i covers tile rows R0 = (i*4 + wid)*8 .. +8 ; lane -> row R0 + lrow, LDS chunk lc
   // (lane-linear image), source chunk lc ^ f(row)
-  int x_ih0[XI], x_iw0[XI]; unsigned x_base[XI]; bool x_ok[XI]; int x_q[XI];
-  unsigned w_off[WI]; bool w_ok[WI];
+  // (arrays sized 4 = max(XI, WI): hipcc's host pass silently drops the kernel instantiation when these are sized by XI / WI)
+  int x_ih0[4], x_iw0[4]; unsigned x_base[4]; bool x_ok[4]; int x_q[4];
+  unsigned w_off[4]; bool w_ok[4];
+  static_assert(XI <= 4 && WI <= 4, "staging tables hold 4 rows groups per wave");
 #pragma unroll
   for (int i = 0; i < XI; ++i) {
     int row = (i * 4 + wid) * 8 + lrow;
