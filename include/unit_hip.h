@@ -42,7 +42,7 @@ int unit_conv2d_fwd_big(const void* x, const void* w, void* y, const float* bias
                         int out_dtype, int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int OH, int OW, int ldy,
                         int oy_mul, int OHf, int OWf, int relu, int variant, void* stream);
 /* mid-size variant (4 waves, LDS-DMA, two workgroups per CU) for the backbone layers; bf16 inputs, C % 64 == 0;
- * tile: 0 = 128x128, 1 = 64 pixels x 128 channels, 2 = 128 x 64 */
+ * tile: 0 = 128x128, 1 = 64 pixels x 128 channels, 2 = 128 x 64, 3 = 128x128 with in-workgroup split-K (few-tile layers) */
 int unit_conv2d_fwd_mid(const void* x, const void* w, void* y, const float* bias, const void* residual, const void* mask_ref,
                         int out_dtype, int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int OH, int OW, int ldy,
                         int oy_mul, int OHf, int OWf, int relu, int tile, void* stream);

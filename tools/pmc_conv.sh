@@ -1,0 +1,24 @@
+#!/bin/bash
+# PMC passes for one conv config: tools/pmc_conv.sh <shape> <tile> <tag>
+cd /tmp && export TMPDIR=/tmp
+R=$GRAFT_REPO_ROOT; S=$1; T=$2; TAG=$3
+P1="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS"
+P2="SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_LDS_DATA_FIFO_FULL SQ_LDS_CMD_FIFO_FULL SQ_ACTIVE_INST_VMEM SQ_INST_CYCLES_VMEM_RD SQ_INSTS_VALU_MFMA_MOPS_BF16"
+P3="TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum"
+P4="GRBM_GUI_ACTIVE TCP_PENDING_STALL_CYCLES_sum TCP_TCR_TCP_STALL_CYCLES_sum TA_TA_BUSY_sum"
+i=0
+for P in "$P1" "$P2" "$P3" "$P4"; do
+  i=$((i+1))
+  rocprofv3 --pmc $P --kernel-trace -d $R/gpurun_out/pmc_${TAG}_p$i -o pmc --output-format csv -- python3 $R/tools/convprobe.py $S $T 6 > /dev/null 2>&1
+done
+python3 - <<PY
+import csv, glob, collections
+for i in range(1,5):
+    fs = glob.glob("$R/gpurun_out/pmc_${TAG}_p%d/*counter_collection.csv" % i)
+    if not fs: print("pass", i, "no output"); continue
+    acc = collections.defaultdict(list)
+    for r in csv.DictReader(open(fs[0])):
+        if "conv_igemm" in r["Kernel_Name"]:
+            acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
+    for k, v in acc.items(): print("%-34s n=%d avg=%.4g" % (k, len(v), sum(v[1:]) / max(1, len(v) - 1)))
+PY

@@ -150,7 +150,7 @@ def conv2d(x, w, k, r, s, stride=1, pad=0, bias=None, residual=None, mask_ref=No
         e0.record()
     big = tile_cfg in (5, 6) or (tile_cfg == 0 and BIG_TILE_POLICY(x.dtype, n * oh * ow, k, c, r * s * c))
     mid = -1
-    if tile_cfg in (7, 8, 9):
+    if tile_cfg in (7, 8, 9, 10):
         mid = tile_cfg - 7
     elif tile_cfg == 0 and not big:
         mid = MID_TILE_POLICY(x.dtype, n * oh * ow, k, c, r * s * c)
