@@ -410,11 +410,19 @@ class WeaklySupervisedRCNNNoMeta(nn.Module):
 
         def done(tag):
             if side is not None:
-                torch.cuda.current_stream().wait_stream(side)     # this bucket's wgrad kernels ran on the side stream
+                # the bucket's wgrad kernels ran on the side stream: reduce its slabs (and launch its all-reduce) THERE, so
+                # that the main stream's dgrad chain never waits for weight gradients; the streams join before the optimizer
+                if hook is not None:
+                    side.wait_stream(torch.cuda.current_stream())      # bias / Linear gradients of the bucket come from main
+                with torch.cuda.stream(side):
+                    plan.reduce(tag)     # split-M slabs of this bucket -> flat gradient buffer (one launch)
+                    if hook is not None:
+                        hook(tag)        # data parallel: launch the bucket's all-reduce
+                return
             if plan is not None:
-                plan.reduce(tag)         # split-M slabs of this bucket -> flat gradient buffer (one launch)
+                plan.reduce(tag)
             if hook is not None:
-                hook(tag)                # data parallel: launch the bucket's all-reduce
+                hook(tag)
 
         feat = c.feat
         bb_trainable = self.backbone.first_trainable_stage() < 3
@@ -473,6 +481,8 @@ class WeaklySupervisedRCNNNoMeta(nn.Module):
         drpn = None
         if getattr(c, "rpn_bwd_early", False):
             torch.cuda.current_stream().wait_stream(self._rpn_stream)      # launched during the forward plan
+            if side is not None:
+                side.wait_stream(self._rpn_stream)                         # its wgrad slabs are reduced on the side stream
             drpn = c.drpn
             drpn.record_stream(torch.cuda.current_stream())
             c.rpn_losses.record_stream(torch.cuda.current_stream())

@@ -49,8 +49,15 @@ def _big_tile_default(dtype, m, k, c, kgemm):
 
 
 def _mid_tile_default(dtype, m, k, c, kgemm):
-    """-1: use the register-staged conv_igemm.hip kernel; 0..2: LDS-DMA 4-wave kernel with that tile (csrc/conv_igemm128.hip)"""
-    return -1
+    """-1: use the register-staged conv_igemm.hip kernel; 0..3: LDS-DMA 4-wave kernel with that tile (csrc/conv_igemm128.hip).
+    Measured on the backbone shapes (tools/microbench.py): 128x64 for 64-channel outputs, 128x128 when that tiling still
+    gives every CU a workgroup or two, 64x128 below that."""
+    if dtype != torch.bfloat16 or c % 64 != 0 or k < 64:
+        return -1
+    if k <= 64:
+        return 2
+    tiles = ((m + 127) // 128) * ((k + 127) // 128)
+    return 0 if tiles >= 400 else 1
 
 
 MID_TILE_POLICY = _mid_tile_default
