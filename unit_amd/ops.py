@@ -48,11 +48,14 @@ def _big_tile_default(dtype, m, k, c, kgemm):
     return tiles >= 128
 
 
+_NO_MID = bool(int(__import__("os").environ.get("UNIT_NO_MID_TILE", "0")))   # A/B switch for tools/ and debugging
+
+
 def _mid_tile_default(dtype, m, k, c, kgemm):
     """-1: use the register-staged conv_igemm.hip kernel; 0..3: LDS-DMA 4-wave kernel with that tile (csrc/conv_igemm128.hip).
     Measured on the backbone shapes (tools/microbench.py): 128x64 for 64-channel outputs, 128x128 when that tiling still
     gives every CU a workgroup or two, 64x128 below that."""
-    if dtype != torch.bfloat16 or c % 64 != 0 or k < 64:
+    if dtype != torch.bfloat16 or c % 64 != 0 or k < 64 or _NO_MID:
         return -1
     if k <= 64:
         return 2
@@ -72,7 +75,10 @@ PROFILER = None
 
 
 def workspace(nbytes, device, slot=0):
-    key = (device, slot)
+    """scratch buffer for the kernels that need one; one buffer per (slot, HIP stream): the step runs the RPN-loss branch,
+    the proposal chain and the weight gradients on different streams at the same time, and scratch must never be shared
+    between kernels that are not ordered by a stream"""
+    key = (device, slot, torch.cuda.current_stream().cuda_stream if device.type == "cuda" else 0)
     w = _WS.get(key)
     if w is None or w.numel() < nbytes:
         w = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
