@@ -46,8 +46,10 @@ def oracle_step(model, cfg, sup, weak, perms):
     return losses, p, aux
 
 
-@pytest.mark.parametrize("pool_mode", ["strided", "full"])
-def test_s1_step_parity_fp32(dev, pool_mode):
+@pytest.mark.parametrize("pool_mode,early", [("strided", False), ("full", False), ("strided", True)])
+def test_s1_step_parity_fp32(dev, pool_mode, early):
+    """early=True is the bench / TrainerNoMeta.run_step schedule: RPN-loss branch and its backward on a side HIP stream
+    during the proposal chain, the two Res5 heads on two streams, weight gradients + slab reduction on a third."""
     cfg = small_cfg()
     model = build_model(cfg)
     init_synthetic_weights(model, seed=1)
@@ -59,7 +61,7 @@ def test_s1_step_parity_fp32(dev, pool_mode):
     model._ensure_ready()
     n_anchor = 8 * 12 * 15
     perms = model.sampling_permutations(2, n_anchor, cfg.MODEL.RPN.POST_NMS_TOPK_TRAIN + batch.gt_boxes.shape[1])
-    step = model.forward_train(batch, perms)
+    step = model.forward_train(batch, perms, early_backward=early)
     model.backward_train(step)
     got = dict(zip(LOSS_NAMES, step.losses.cpu().tolist()))
     ref, p, aux = oracle_step(model, cfg, sup, weak, perms)
