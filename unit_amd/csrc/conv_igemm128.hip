@@ -103,8 +103,10 @@ __global__ void __launch_bounds__(256, 2) conv_igemm_dma_kernel(ConvDmaArgs p) {
   }
 
   auto stage = [&](int kt, int buf) {
-    int k0 = kt * BK;                       // wave-uniform: C % 64 == 0 -> the whole k-tile sits inside one (r,s)
-    int rs = k0 / p.C; int ch0 = k0 - rs * p.C; int r = rs / p.S; int s = rs - r * p.S;
+    // k-tile order: channel block outermost, the R*S taps innermost (input rows stay L2/L1-resident across the taps)
+    int RS = p.R * p.S;
+    int cb = kt / RS; int rs = kt - cb * RS;  // wave-uniform: C % 64 == 0 -> the whole k-tile sits inside one (r,s)
+    int ch0 = cb * BK; int k0 = rs * p.C + ch0; int r = rs / p.S; int s = rs - r * p.S;
     char* base = smem + buf * BUF;
 #pragma unroll
     for (int i = 0; i < XI; ++i) {
@@ -274,8 +276,9 @@ __global__ void __launch_bounds__(512, 2) conv_igemm_dma_ksplit_kernel(ConvDmaAr
   }
 
   auto stage = [&](int kt, int buf) {
-    int k0 = kt * BK;
-    int rs = k0 / p.C; int ch0 = k0 - rs * p.C; int r = rs / p.S; int s = rs - r * p.S;
+    int RS = p.R * p.S;
+    int cb = kt / RS; int rs = kt - cb * RS;
+    int ch0 = cb * BK; int k0 = rs * p.C + ch0; int r = rs / p.S; int s = rs - r * p.S;
     char* base = gbase + buf * BUF;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {

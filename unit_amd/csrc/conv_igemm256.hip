@@ -92,8 +92,12 @@ __global__ void __launch_bounds__(512, 2) conv_igemm256_kernel(Conv256Args p) {
   }
 
   auto stage = [&](int kt, int buf) {
-    int k0 = kt * BK;                       // wave-uniform: C % 64 == 0 -> the whole k-tile sits inside one (r,s)
-    int rs = k0 / p.C; int ch0 = k0 - rs * p.C; int r = rs / p.S; int s = rs - r * p.S;
+    // k-tile order: channel block outermost, the R*S taps innermost. Consecutive k-tiles then read the SAME input rows
+    // shifted by one pixel / one row (L2- and mostly L1-resident), instead of coming back to them C/64 k-tiles later when
+    // the other workgroups of the XCD have pushed them out of the 4 MB L2 (3x3: the input was fetched ~9x past L2).
+    int RS = p.R * p.S;
+    int cb = kt / RS; int rs = kt - cb * RS;  // wave-uniform: C % 64 == 0 -> the whole k-tile sits inside one (r,s)
+    int ch0 = cb * BK; int k0 = rs * p.C + ch0; int r = rs / p.S; int s = rs - r * p.S;
     char* base = smem + buf * BUF;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
