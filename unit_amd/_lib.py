@@ -9,7 +9,7 @@ import torch  # noqa: F401  -- must be imported BEFORE libunit_hip.so is dlopen'
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 HEADER = os.path.join(os.path.dirname(HERE), "include", "unit_hip.h")
-LIB_PATH = os.path.join(HERE, "_build", "libunit_hip.so")
+LIB_PATH = os.environ.get("UNIT_HIP_LIB") or os.path.join(HERE, "_build", "libunit_hip.so")   # override: diagnostic builds
 
 _CT = {
     "int": ctypes.c_int, "long": ctypes.c_long, "float": ctypes.c_float, "size_t": ctypes.c_size_t,

@@ -9,6 +9,12 @@
 // while k-tile t is multiplied; one vmcnt(0)+barrier per k-tile.  Requires C % 64 == 0 (every layer except the stem).
 #include "common.h"
 
+// diagnostic builds only (tools/exp256.sh): 1 = no operand DMA after the first k-tile (MFMA + LDS-read bound of the loop),
+// 2 = MFMAs replaced by a few VALU adds on the fragments (DMA + LDS-read bound of the loop). Results are garbage in both.
+#ifndef UNIT_DBG256
+#define UNIT_DBG256 0
+#endif
+
 struct Conv256Args {
   const void* x; const void* w; void* y;
   const float* bias; const void* residual; const void* mask_ref;
@@ -128,7 +134,7 @@ __global__ void __launch_bounds__(512, 2) conv_igemm256_kernel(Conv256Args p) {
   if constexpr (!PP) {
     for (int kt = 0; kt < nk; ++kt) {
       int buf = kt & 1;
-      if (kt + 1 < nk) stage(kt + 1, buf ^ 1);
+      if (kt + 1 < nk && UNIT_DBG256 != 1) stage(kt + 1, buf ^ 1);
       const char* bx = smem + buf * BUF;
       const char* bw = bx + BM * 128;
 #pragma unroll
@@ -139,11 +145,18 @@ __global__ void __launch_bounds__(512, 2) conv_igemm256_kernel(Conv256Args p) {
 #pragma unroll
         for (int b = 0; b < 8; ++b) fb[b] = *reinterpret_cast<const i32x4*>(bx + swz256(wm * 128 + b * 16 + frow, ks * 4 + fq));
         __builtin_amdgcn_s_setprio(1);
+#if UNIT_DBG256 == 2
+#pragma unroll
+        for (int a = 0; a < 4; ++a) acc[a][0] += __builtin_bit_cast(f32x4, fa[a]);
+#pragma unroll
+        for (int b = 0; b < 8; ++b) acc[0][b] += __builtin_bit_cast(f32x4, fb[b]);
+#else
 #pragma unroll
         for (int a = 0; a < 4; ++a)
 #pragma unroll
           for (int b = 0; b < 8; ++b)
             acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fa[a]), __builtin_bit_cast(bf16x8, fb[b]), acc[a][b], 0, 0, 0);
+#endif
         __builtin_amdgcn_s_setprio(0);
       }
       __syncthreads();   // vmcnt(0): this wave's DMA of tile kt+1 landed ; barrier: everyone's did, and everyone finished reading `buf`
