@@ -36,12 +36,15 @@ def parse():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-overlap", action="store_true", help="single HIP stream for the whole run (profiling aid: every "
+                    "kernel's rocprof duration is then that kernel alone)")
     return ap.parse_args()
 
 
 def cpu_baseline(depth, variant):
     """The oracle (CPU restatement of the reference path, kind "port") timed on this box's host cores on a BOUNDED
-    sample: one S1 step (forward + backward) on ONE supervised + ONE weak 600x1000 image with 64 RoIs per image."""
+    sample: one S1 step (forward + backward) on 2 supervised + 2 weak 600x1000 images with 128 RoIs per image (the
+    bench workload with a quarter of the RoIs)."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import unit_oracle as orc
     from unit_amd import config
@@ -56,7 +59,7 @@ def cpu_baseline(depth, variant):
     torch.set_num_threads(cores)
     cfg = config.voc_rcnn_c4_split1(depth)
     cfg.MODEL.DEVICE = "cpu"
-    rois = 64
+    rois = 128
     m = build_model(cfg)
     init_synthetic_weights(m, seed=1)
     trainable = {n for n, p in m.named_parameters() if p.requires_grad}
@@ -66,9 +69,9 @@ def cpu_baseline(depth, variant):
         if k in trainable:
             t.requires_grad_(True)
         p[k] = t
-    sup, weak = synthetic_batch(1, 1 if variant == "s1" else 0, seed=0)
+    sup, weak = synthetic_batch(2, 2 if variant == "s1" else 0, seed=0)
     g = torch.Generator().manual_seed(2)
-    perms = dict(rpn=[torch.randperm(38 * 63 * 15, generator=g)], roi=[torch.randperm(2000 + 8, generator=g)])
+    perms = dict(rpn=[torch.randperm(38 * 63 * 15, generator=g) for _ in range(2)], roi=[torch.randperm(2000 + 8, generator=g) for _ in range(2)])
     ocfg = dict(depth=depth, num_classes=20, novel_classes=list(cfg.DATASETS.FEWSHOT.NOVEL_CLASSES_ID), pixel_mean=cfg.MODEL.PIXEL_MEAN,
                 pixel_std=cfg.MODEL.PIXEL_STD, rois_per_image=rois, pre_nms_topk=12000, post_nms_topk=2000, multi_box_head=True)
     t0 = time.time()
@@ -77,9 +80,9 @@ def cpu_baseline(depth, variant):
                                 [x["instances"].gt_classes for x in weak] if weak else None, perms, ocfg)
     sum(losses.values()).backward()
     dt = time.time() - t0
-    return {"value": round(1.0 / dt, 4), "unit": "images/sec", "cores": cores, "kind": "port",
-            "sample": f"oracle (PyTorch-CPU fp32 + C) S1 fwd+bwd, R{depth}-C4, 1 supervised + 1 weak 3x600x1000 image, "
-                      f"{rois} RoIs/image (1/8 of 512), {dt:.1f} s"}
+    return {"value": round(2.0 / dt, 4), "unit": "images/sec", "cores": cores, "kind": "port",
+            "sample": f"oracle (PyTorch-CPU fp32 + C) S1 fwd+bwd, R{depth}-C4, 2 supervised + 2 weak 3x600x1000 images, "
+                      f"{rois} RoIs/image (1/4 of 512), {dt:.1f} s"}
 
 
 def main():
@@ -109,6 +112,7 @@ def main():
     init_synthetic_weights(model, seed=1)
     model.train()
     model.compute_dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    model.overlap_streams = not args.no_overlap
     n_weak = 2 if args.variant == "s1" else 0
     sup, weak = synthetic_batch(2, n_weak, seed=100 + rank)   # rank r's shard of the global batch
     batch = model.pack_batch(sup, weak)                      # inputs resident in HBM before the timed region
@@ -135,11 +139,17 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    # roofline pass: the same K steps again with a HIP-event pair around every conv launch (on its launch stream). Kept out
-    # of the `value` timing above because ~650 extra event records per step perturb the step by a few per cent.
-    prof = None
+    # roofline passes (outside the `value` timing: ~650 extra HIP-event records per step perturb it by a few per cent):
+    # the same K steps again with a HIP-event pair around every conv launch, recorded on the launch stream --
+    #  (1) on ONE stream (overlap off): an event interval is then that kernel alone -> `achieved`
+    #  (2) with the production 3-stream schedule: the interval includes time shared with other streams -> `insitu`
+    prof = prof_insitu = None
     dt_events = None
-    if not args.no_roofline:          # every rank runs the pass (the steps contain collectives); rank 0 records events
+    if not args.no_roofline:          # every rank runs the passes (the steps contain collectives); rank 0 records events
+        was = model.overlap_streams
+        model.overlap_streams = False
+        one_step()
+        torch.cuda.synchronize()
         prof = {} if rank == 0 else None
         ops.PROFILER = prof
         t1 = time.perf_counter()
@@ -148,6 +158,16 @@ def main():
         torch.cuda.synchronize()
         dt_events = time.perf_counter() - t1
         ops.PROFILER = None
+        model.overlap_streams = was
+        if was:
+            one_step()
+            torch.cuda.synchronize()
+            prof_insitu = {} if rank == 0 else None
+            ops.PROFILER = prof_insitu
+            for _ in range(args.steps):
+                one_step()
+            torch.cuda.synchronize()
+            ops.PROFILER = None
     if world > 1:
         dist.barrier()
     if world > 1:
@@ -171,33 +191,40 @@ def main():
                        "step_tflop_per_gpu": STEP_TFLOP.get((args.variant, args.depth)),
                        "step_tflops_achieved_per_gpu": round(STEP_TFLOP.get((args.variant, args.depth), 0) / (ms / 1e3), 1)},
         }
-        if prof is not None and (prof.get("conv_igemm256") or prof.get("conv_igemm")):
-            # dominant kernel of the step: conv_igemm256_kernel (Res5 heads + RPN conv, fwd and dgrad; ~60 % of the step's
-            # FLOPs).  Durations are HIP-event pairs recorded on the launch stream around every launch of the timed region.
-            # NOTE the step overlaps up to three HIP streams (two Res5 heads, wgrad side stream), so a launch's event
-            # interval includes the time it shares the chip with the other streams' kernels: this is the in-situ rate; the
-            # isolated rate of the same kernel (tools/microbench.py, profiles/) is 1.5-2x higher.
-            key = "conv_igemm256" if prof.get("conv_igemm256") else "conv_igemm"
-            ev = prof[key]
-            durs = [a.elapsed_time(b) for a, b, _ in ev]          # ms
-            fl = sum(f for _, _, f in ev)
-            tot = sum(durs)
+        if prof is not None and (prof.get("conv_igemm256") or prof.get("conv_igemm_dma") or prof.get("conv_igemm")):
+            # dominant kernel of the step: conv_igemm256_kernel (Res5 heads + RPN conv, forward and dgrad: ~60 % of the
+            # step's FLOPs, ~45 % of its kernel time)
+            def rate(pr, key):
+                ev = pr.get(key) or []
+                if not ev:
+                    return None
+                tot = sum(a.elapsed_time(b) for a, b, _ in ev)      # ms
+                fl = sum(f for _, _, f in ev)
+                return {"tflops": round(fl / tot / 1e9, 1), "launches_per_step": len(ev) // args.steps,
+                        "avg_launch_us": round(tot / len(ev) * 1e3, 2), "gflop_per_launch": round(fl / len(ev) / 1e9, 2)}
+            key = next(k for k in ("conv_igemm256", "conv_igemm_dma", "conv_igemm") if prof.get(k))
+            r = rate(prof, key)
+            traffic = None
+            tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")     # written by tools/pmc_traffic.py from a
+            if os.path.exists(tpath):                                     # rocprofv3 --pmc run of this same command
+                try:
+                    traffic = json.load(open(tpath)).get(key + "_kernel", {}).get("hbm_bytes_per_launch")
+                except Exception:
+                    traffic = None
             out["roofline"] = {"kernel": key + "_kernel (implicit-GEMM conv fwd/dgrad, bf16 MFMA 16x16x32, 256x256x64 LDS-DMA tiles)",
-                               "bound": "mfma", "achieved": round(fl / tot / 1e9, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                               "frac": round(fl / tot / 1e9 / MFMA_PEAK_TFLOPS, 4), "traffic": None,
-                               "launches_per_step": len(ev) // args.steps, "avg_launch_us": round(tot / len(ev) * 1e3, 2),
-                               "algorithmic_gflop_per_launch": round(fl / len(ev) / 1e9, 2),
-                               "concurrent_streams": True,
-                               "measured_over": f"a second pass of the same {args.steps} steps with per-launch HIP events "
-                                                f"({dt_events / args.steps * 1e3:.2f} ms/step with events)"}
-            others = {}
-            for k2 in ("conv_igemm", "conv_wgrad"):
-                if k2 != key and prof.get(k2):
-                    ev2 = prof[k2]
-                    tot2 = sum(a.elapsed_time(b) for a, b, _ in ev2)
-                    others[k2 + "_tflops"] = round(sum(f for _, _, f in ev2) / tot2 / 1e9, 1)
-                    others[k2 + "_launches_per_step"] = len(ev2) // args.steps
-            out["roofline"]["other_conv_kernels"] = others
+                               "bound": "mfma", "achieved": r["tflops"], "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                               "frac": round(r["tflops"] / MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
+                               "launches_per_step": r["launches_per_step"], "avg_launch_us": r["avg_launch_us"],
+                               "algorithmic_gflop_per_launch": r["gflop_per_launch"],
+                               "measured_over": f"a second pass of the same {args.steps} steps on ONE HIP stream with a HIP-event pair "
+                                                f"around every launch ({dt_events / args.steps * 1e3:.2f} ms/step in that mode)",
+                               "other_conv_kernels": {k2: rate(prof, k2) for k2 in ("conv_igemm_dma", "conv_igemm", "conv_wgrad")
+                                                      if k2 != key and prof.get(k2)}}
+            if prof_insitu:
+                out["roofline"]["insitu"] = {k2: rate(prof_insitu, k2) for k2 in ("conv_igemm256", "conv_igemm_dma", "conv_igemm", "conv_wgrad")
+                                             if prof_insitu.get(k2)}
+                out["roofline"]["insitu"]["note"] = ("same events under the production schedule (Res5 heads on two streams, wgrad on a "
+                                                     "third): an interval includes the time the launch shares the chip")
         if not args.no_cpu_baseline and world == 1:
             # bounded: the oracle runs in a child process with a wall-clock limit (never part of the timed region)
             import subprocess

@@ -1,0 +1,30 @@
+"""HBM-side traffic per launch of the conv kernels from two rocprofv3 --pmc passes over bench.py (FETCH_SIZE, WRITE_SIZE
+in separate passes, MI355X_MICROARCH.md 'HBM'):  python3 tools/pmc_traffic.py <fetch_dir> <write_dir> <out.json>
+gfx950 corrections of that guide: FETCH_SIZE (KB) reports half of the bytes of wide (16 B/lane) streaming reads -> x2;
+WRITE_SIZE (KB) is exact for 16 B/lane streaming stores. Infinity-Cache hits are counted (traffic past the L2)."""
+import collections, csv, glob, json, sys
+
+def collect(d, counter):
+    fs = glob.glob(d + "/**/*counter_collection.csv", recursive=True)
+    acc = collections.defaultdict(list)
+    for f in fs:
+        for r in csv.DictReader(open(f)):
+            if r["Counter_Name"] == counter:
+                acc[r["Kernel_Name"].split("(")[0].split("<")[0].strip()].append(float(r["Counter_Value"]))
+    return acc
+
+fetch = collect(sys.argv[1], "FETCH_SIZE")
+write = collect(sys.argv[2], "WRITE_SIZE")
+out = {"_note": "bytes past the L2 (HBM + Infinity Cache) per launch, rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over "
+                "`bench.py --steps 2 --warmup 1 --no-overlap --no-roofline --no-cpu-baseline`; FETCH_SIZE doubled (gfx950 wide-read "
+                "correction, MI355X_MICROARCH.md); KB = 1024 B"}
+for k in sorted(set(fetch) | set(write)):
+    if not any(t in k for t in ("conv_igemm", "conv_wgrad", "multi_", "roi_align", "sgd")):
+        continue
+    name = "conv_igemm256_kernel" if "igemm256" in k else ("conv_igemm_dma_kernel" if "igemm_dma" in k and "ksplit" not in k else k.split("_Z")[-1])
+    f = fetch.get(k, []); w = write.get(k, [])
+    fb = 2.0 * 1024 * sum(f) / max(1, len(f)); wb = 1024.0 * sum(w) / max(1, len(w))
+    out[name] = {"launches": max(len(f), len(w)), "fetch_bytes_per_launch": round(fb), "write_bytes_per_launch": round(wb),
+                 "hbm_bytes_per_launch": round(fb + wb)}
+json.dump(out, open(sys.argv[3], "w"), indent=1)
+print(json.dumps({k: v for k, v in out.items() if "igemm256" in k or "wgrad" in k}, indent=1))
