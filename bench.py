@@ -198,10 +198,11 @@ def main():
                 ev = pr.get(key) or []
                 if not ev:
                     return None
-                tot = sum(a.elapsed_time(b) for a, b, _ in ev)      # ms
-                fl = sum(f for _, _, f in ev)
+                tot = sum(e[0].elapsed_time(e[1]) for e in ev)      # ms
+                fl = sum(e[2] for e in ev)
                 return {"tflops": round(fl / tot / 1e9, 1), "launches_per_step": len(ev) // args.steps,
-                        "avg_launch_us": round(tot / len(ev) * 1e3, 2), "gflop_per_launch": round(fl / len(ev) / 1e9, 2)}
+                        "avg_launch_us": round(tot / len(ev) * 1e3, 2), "gflop_per_launch": round(fl / len(ev) / 1e9, 2),
+                        "algorithmic_bytes_per_launch": round(sum(e[3] for e in ev) / len(ev))}
             key = next(k for k in ("conv_igemm256", "conv_igemm_dma", "conv_igemm") if prof.get(k))
             r = rate(prof, key)
             traffic = None
@@ -216,6 +217,7 @@ def main():
                                "frac": round(r["tflops"] / MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
                                "launches_per_step": r["launches_per_step"], "avg_launch_us": r["avg_launch_us"],
                                "algorithmic_gflop_per_launch": r["gflop_per_launch"],
+                               "algorithmic_bytes_per_launch": r["algorithmic_bytes_per_launch"],
                                "measured_over": f"a second pass of the same {args.steps} steps on ONE HIP stream with a HIP-event pair "
                                                 f"around every launch ({dt_events / args.steps * 1e3:.2f} ms/step in that mode)",
                                "other_conv_kernels": {k2: rate(prof, k2) for k2 in ("conv_igemm_dma", "conv_igemm", "conv_wgrad")

@@ -183,7 +183,10 @@ def conv2d(x, w, k, r, s, stride=1, pad=0, bias=None, residual=None, mask_ref=No
     if prof is not None:
         e1 = torch.cuda.Event(enable_timing=True)
         e1.record()
-        prof.setdefault("conv_igemm256" if (big and mid < 0) else ("conv_igemm_dma" if mid >= 0 else "conv_igemm"), []).append((e0, e1, 2.0 * n * oh * ow * k * r * s * c))
+        es = out.element_size()
+        nbytes = (x.numel() + w.numel()) * x.element_size() + n * oh * ow * ldy * es * (1 + (residual is not None) + (mask_ref is not None))
+        prof.setdefault("conv_igemm256" if (big and mid < 0) else ("conv_igemm_dma" if mid >= 0 else "conv_igemm"), []).append(
+            (e0, e1, 2.0 * n * oh * ow * k * r * s * c, nbytes))
     return out
 
 
@@ -205,7 +208,8 @@ def conv2d_wgrad(x, dy, k, r, s, stride=1, pad=0, scale=None, out=None, accumula
     if prof is not None:
         e1 = torch.cuda.Event(enable_timing=True)
         e1.record()
-        prof.setdefault("conv_wgrad", []).append((e0, e1, 2.0 * n * oh * ow * k * r * s * c))
+        prof.setdefault("conv_wgrad", []).append((e0, e1, 2.0 * n * oh * ow * k * r * s * c,
+                                                  (x.numel() + n * oh * ow * ldy) * x.element_size() + 4 * k * r * s * c))
     return out
 
 
@@ -217,6 +221,7 @@ def conv2d_wgrad_partial(x, dy, k, r, s, stride, pad, slab=None):
     if slab is None or slab.numel() < nbytes:
         slab = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
     splits = lib().unit_conv2d_wgrad_splits(dt(x.dtype), n, oh, ow, k, r, s, c)
+    ldy = dy.shape[-1]
     prof = PROFILER
     if prof is not None:
         e0 = torch.cuda.Event(enable_timing=True)
@@ -226,7 +231,8 @@ def conv2d_wgrad_partial(x, dy, k, r, s, stride, pad, slab=None):
     if prof is not None:
         e1 = torch.cuda.Event(enable_timing=True)
         e1.record()
-        prof.setdefault("conv_wgrad", []).append((e0, e1, 2.0 * n * oh * ow * k * r * s * c))
+        prof.setdefault("conv_wgrad", []).append((e0, e1, 2.0 * n * oh * ow * k * r * s * c,
+                                                  (x.numel() + n * oh * ow * ldy) * x.element_size() + 4 * k * r * s * c))
     return slab, splits
 
 
