@@ -11,6 +11,10 @@
 // Requires bf16 operands and C % 64 == 0.
 #include "common.h"
 
+#ifndef UNIT_DBGMID
+#define UNIT_DBGMID 0
+#endif
+
 struct ConvDmaArgs {
   const void* x; const void* w; void* y;
   const float* bias; const void* residual; const void* mask_ref;
@@ -164,6 +168,15 @@ __global__ void __launch_bounds__(256, 2) conv_igemm_dma_kernel(ConvDmaArgs p) {
       for (int b = 0; b < FB; ++b) fb[ks][b] = *reinterpret_cast<const i32x4*>(bx + swz128(wm * WMT + b * 16 + frow, ks * 4 + fq));
     }
     __builtin_amdgcn_s_setprio(1);
+#if UNIT_DBGMID == 2      // diagnostic build (tools/exp_feed.sh): no MFMA -> the loop runs at the operand feed rate
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+      for (int a = 0; a < FA; ++a) acc[a][0] += __builtin_bit_cast(f32x4, fa[ks][a]);
+#pragma unroll
+      for (int b = 0; b < FB; ++b) acc[0][b] += __builtin_bit_cast(f32x4, fb[ks][b]);
+    }
+#else
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
@@ -171,6 +184,7 @@ __global__ void __launch_bounds__(256, 2) conv_igemm_dma_kernel(ConvDmaArgs p) {
 #pragma unroll
         for (int b = 0; b < FB; ++b)
           acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fa[ks][a]), __builtin_bit_cast(bf16x8, fb[ks][b]), acc[a][b], 0, 0, 0);
+#endif
     __builtin_amdgcn_s_setprio(0);
     pbuf = buf;
     buf = (buf + 1 == NS) ? 0 : buf + 1;

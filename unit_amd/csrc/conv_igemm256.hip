@@ -249,6 +249,182 @@ __global__ void __launch_bounds__(512, 2) conv_igemm256_kernel(Conv256Args p) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// variant 2: the same 256x256 tile with FOUR 32 KB stages of 32 k each instead of two 64 KB stages of 64 k.
+// The two-stage loop drains the LDS-DMA queue at every barrier (all of a k-tile's 64 KB is issued in one burst, waited
+// for in full, and only then is the next burst issued): measured operand feed 14 TB/s chip-wide, co-limiting with the
+// MFMA pipe (tools/exp256.sh). With 32-k stages three stages (96 KB) stay in flight behind the one being multiplied and
+// every iteration waits only for the oldest group (counted vmcnt), which the 4-wave kernels show streams at 18-20 TB/s.
+// LDS image per stage: [256 pixel rows][64 B] + [256 channel rows][64 B]; one DMA piece = 16 rows x 64 B; a row's four
+// 16-B chunks are XOR-swizzled with g((row>>2)&3), g = {0,2,3,1}, which makes the 4x16-lane ds_read_b128 groups
+// conflict-free for this pitch.
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int swz_g(int row) { return (0x78 >> (((row >> 2) & 3) * 2)) & 3; }
+
+template <typename TO>
+__global__ void __launch_bounds__(512, 2) conv_igemm256_k32_kernel(Conv256Args p) {
+  constexpr int BM = 256, BN = 256, BK = 32, NS = 4;
+  constexpr int BUF = (BM + BN) * 64;           // 32 KB per stage
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  int nwg = p.tiles_m * p.tiles_n;
+  int bid = blockIdx.x;
+  {
+    int q = nwg / 8, r = nwg % 8, xcd = bid % 8, loc = bid / 8;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+  }
+  int tile_n = bid % p.tiles_n, tile_m = bid / p.tiles_n;
+  int m0 = tile_m * BM, n0 = tile_n * BN;
+
+  const bf16_t* __restrict__ X = (const bf16_t*)p.x;
+  const bf16_t* __restrict__ Wt = (const bf16_t*)p.w;
+  __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(X), 0, (int)p.x_bytes, 0x00020000);
+  __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(Wt), 0, (int)p.w_bytes, 0x00020000);
+  constexpr unsigned OOB = 0xFFFFFFF0u;
+
+  int tid = threadIdx.x, lane = tid & 63;
+  int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int wm = wid >> 2, wn = wid & 3;
+  int lrow = lane >> 2, lc = lane & 3;
+
+  // staging: wave `wid`, piece i (0..1) covers tile rows R0 = (i*8 + wid)*16 .. +16 ; lane -> row R0 + lrow, LDS chunk lc
+  int x_ih0[2], x_iw0[2]; unsigned x_base[2]; bool x_ok[2]; int x_q[2];
+  unsigned w_off[2]; bool w_ok[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    int row = (i * 8 + wid) * 16 + lrow;
+    int q = lc ^ swz_g(row);
+    x_q[i] = q;
+    int m = m0 + row;
+    x_ok[i] = m < p.M;
+    int mm = x_ok[i] ? m : 0;
+    int ow = mm % p.OW; int t = mm / p.OW; int oh = t % p.OH; int n = t / p.OH;
+    x_ih0[i] = oh * p.stride - p.pad; x_iw0[i] = ow * p.stride - p.pad;
+    x_base[i] = (unsigned)n * (unsigned)(p.H * p.W * p.C);
+    int nn = n0 + row;
+    w_ok[i] = nn < p.K;
+    w_off[i] = ((unsigned)(w_ok[i] ? nn : 0) * (unsigned)p.Kgemm + (unsigned)q * 8u) * 2u;
+  }
+
+  auto stage = [&](int kt, int buf) {
+    int RS = p.R * p.S;                       // k-tile order: channel block (32) outermost, taps innermost
+    int cb = kt / RS; int rs = kt - cb * RS;
+    int ch0 = cb * BK; int k0 = rs * p.C + ch0; int r = rs / p.S; int s = rs - r * p.S;
+    char* base = smem + buf * BUF;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      int R0 = (i * 8 + wid) * 16;
+      int ih = x_ih0[i] + r, iw = x_iw0[i] + s;
+      bool ok = x_ok[i] && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
+      unsigned off = (x_base[i] + (unsigned)((ih * p.W + iw) * p.C + ch0 + x_q[i] * 8)) * 2u;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, (lds_void*)(base + R0 * 64), 16, ok ? off : OOB, 0, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      int R0 = (i * 8 + wid) * 16;
+      unsigned off = w_off[i] + (unsigned)k0 * 2u;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (lds_void*)(base + BM * 64 + R0 * 64), 16, w_ok[i] ? off : OOB, 0, 0, 0);
+    }
+  };
+
+  f32x4 acc[4][8];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 8; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  int nk = p.Kgemm / BK;
+  int frow = lane & 15, fq = lane >> 4;
+  // per-lane fragment offsets inside a stage (row*64 + swizzled chunk): fixed for the whole loop
+  int offa[4], offb[8];
+#pragma unroll
+  for (int a = 0; a < 4; ++a) { int row = wn * 64 + a * 16 + frow; offa[a] = BM * 64 + row * 64 + ((fq ^ swz_g(row)) << 4); }
+#pragma unroll
+  for (int b = 0; b < 8; ++b) { int row = wm * 128 + b * 16 + frow; offb[b] = row * 64 + ((fq ^ swz_g(row)) << 4); }
+
+#pragma unroll
+  for (int s = 0; s < NS - 1; ++s)
+    if (s < nk) stage(s, s);
+  int buf = 0, pbuf = NS - 1;
+  for (int kt = 0; kt < nk; ++kt) {
+    if (kt + NS - 1 <= nk) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // 2 younger groups of 4 pieces stay in flight
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();      // everyone's DMA of stage kt landed, everyone finished reading buffer `pbuf` (stage kt-1)
+    __builtin_amdgcn_sched_barrier(0);
+    if (kt + NS - 1 < nk) stage(kt + NS - 1, pbuf);
+    const char* bs = smem + buf * BUF;
+    i32x4 fa[4], fb[8];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) fa[a] = *reinterpret_cast<const i32x4*>(bs + offa[a]);
+#pragma unroll
+    for (int b = 0; b < 8; ++b) fb[b] = *reinterpret_cast<const i32x4*>(bs + offb[b]);
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int b = 0; b < 8; ++b)
+        acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fa[a]), __builtin_bit_cast(bf16x8, fb[b]), acc[a][b], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+    pbuf = buf;
+    buf = (buf + 1) & (NS - 1);
+  }
+
+  TO* __restrict__ Y = (TO*)p.y;
+  const TO* __restrict__ Rz = (const TO*)p.residual;
+  const TO* __restrict__ Mk = (const TO*)p.mask_ref;
+  bool plain = (p.oy_mul == 1 && p.OHf == p.OH && p.OWf == p.OW);
+#pragma unroll
+  for (int b = 0; b < 8; ++b) {
+    int m = m0 + wm * 128 + b * 16 + frow;
+    if (m >= p.M) continue;
+    long off;
+    if (plain) off = (long)m * p.ldy;
+    else {
+      int ow = m % p.OW; int t = m / p.OW; int oh = t % p.OH; int n = t / p.OH;
+      off = (((long)n * p.OHf + (long)oh * p.oy_mul) * p.OWf + (long)ow * p.oy_mul) * p.ldy;
+    }
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      int n = n0 + wn * 64 + a * 16 + fq * 4;
+      if (n >= p.ldy) continue;
+      float v[4] = {acc[a][b][0], acc[a][b][1], acc[a][b][2], acc[a][b][3]};
+      if (p.bias) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] += (n + j < p.K) ? p.bias[n + j] : 0.f;
+      }
+      if (Rz) {
+        float rr[4]; O4<TO>::load(Rz + off + n, rr);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] += rr[j];
+      }
+      if (p.relu) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
+      }
+      if (Mk) {
+        float mm[4]; O4<TO>::load(Mk + off + n, mm);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = mm[j] > 0.f ? v[j] : 0.f;
+      }
+      O4<TO>::store(Y + off + n, v);
+    }
+  }
+}
+
+template <typename TO>
+static int launch256_k32(Conv256Args& a, hipStream_t st) {
+  a.tiles_m = cdiv(a.M, 256); a.tiles_n = cdiv(a.K, 256);
+  size_t lds = 4 * (256 + 256) * 64;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)conv_igemm256_k32_kernel<TO>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  conv_igemm256_k32_kernel<TO><<<a.tiles_m * a.tiles_n, 512, lds, st>>>(a);
+  UNIT_LAUNCH_CHECK();
+  return UNIT_OK;
+}
+
 template <typename TO, bool PP>
 static int launch256(Conv256Args& a, hipStream_t st) {
   a.tiles_m = cdiv(a.M, 256); a.tiles_n = cdiv(a.K, 256);
@@ -283,8 +459,9 @@ extern "C" int unit_conv2d_fwd_big(const void* x, const void* w, void* y, const 
   if (a.M == 0 || K == 0) return UNIT_OK;
   hipStream_t st = (hipStream_t)stream;
   // variant 0: one barrier per k-tile; variant 1: ping-pong wave groups (MFMA section || LOAD section)
-  if (out_dtype == UNIT_BF16) return variant ? launch256<bf16_t, true>(a, st) : launch256<bf16_t, false>(a, st);
-  if (out_dtype == UNIT_F32) return variant ? launch256<float, true>(a, st) : launch256<float, false>(a, st);
+  // variant 2: four 32-k stages, three in flight (counted vmcnt)
+  if (out_dtype == UNIT_BF16) return variant == 2 ? launch256_k32<bf16_t>(a, st) : variant ? launch256<bf16_t, true>(a, st) : launch256<bf16_t, false>(a, st);
+  if (out_dtype == UNIT_F32) return variant == 2 ? launch256_k32<float>(a, st) : variant ? launch256<float, true>(a, st) : launch256<float, false>(a, st);
   unit_set_error("conv_big: unsupported out dtype");
   return UNIT_ERR_UNSUPPORTED;
 }
