@@ -20,7 +20,7 @@ class GradBuckets:
         self.bucket_elems = bucket_bytes // 4
         self._works = []
         self._plan = None
-        model.on_grad_ready = self.ready
+        model.on_grad_ready = self.ready if self.world > 1 else None    # single process: nothing to launch per bucket
 
     def _build(self):
         st = self.model.store
