@@ -32,15 +32,15 @@ def _newer(target, deps):
 
 def build(force=False, verbose=False):
     os.makedirs(OUT_DIR, exist_ok=True)
-    hdr = os.path.join(CSRC, "common.h")
+    hdrs = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h"))
     srcs = [os.path.join(CSRC, s) for s in SOURCES]
-    if not force and _newer(LIB, srcs + [hdr]):
+    if not force and _newer(LIB, srcs + hdrs):
         return LIB
     hipcc = _hipcc()
 
     def compile_one(src):
         obj = os.path.join(OUT_DIR, os.path.basename(src).replace(".hip", ".o"))
-        if not force and _newer(obj, [src, hdr]):
+        if not force and _newer(obj, [src] + hdrs):
             return obj
         cmd = [hipcc] + FLAGS + ["-c", src, "-o", obj]
         if verbose:

@@ -10,6 +10,7 @@
 //   All 16 fragment reads of a k-tile are issued up front; the MFMAs start on counted lgkmcnt waits as they land.
 // Requires bf16 operands and C % 64 == 0.
 #include "common.h"
+#include "conv_epilogue.h"
 
 #ifndef UNIT_DBGMID
 #define UNIT_DBGMID 0
@@ -190,6 +191,13 @@ __global__ void __launch_bounds__(256, 2) conv_igemm_dma_kernel(ConvDmaArgs p) {
     buf = (buf + 1 == NS) ? 0 : buf + 1;
   }
 
+  if constexpr (sizeof(TO) == 2) {
+    if ((p.ldy & 7) == 0) {          // row-major epilogue through a wave-private LDS scratch (conv_epilogue.h)
+      __syncthreads();               // every wave is done with the operand stages
+      epilogue_rows_bf16<FA, FB>(acc, smem + wid * EpiCfg<FA>::BYTES, m0 + wm * WMT, n0 + wn * WNT, p, lane);
+      return;
+    }
+  }
   TO* __restrict__ Y = (TO*)p.y;
   const TO* __restrict__ Rz = (const TO*)p.residual;
   const TO* __restrict__ Mk = (const TO*)p.mask_ref;
@@ -382,6 +390,12 @@ __global__ void __launch_bounds__(512, 2) conv_igemm_dma_ksplit_kernel(ConvDmaAr
       acc[a][b] += o;
     }
 
+  if constexpr (sizeof(TO) == 2) {
+    if ((p.ldy & 7) == 0) {          // scratch = group 0's own operand stages (all waves passed the barrier above)
+      epilogue_rows_bf16<4, 4>(acc, smem + w4 * EpiCfg<4>::BYTES, m0 + wm * 64, n0 + wn * 64, p, lane);
+      return;
+    }
+  }
   TO* __restrict__ Y = (TO*)p.y;
   const TO* __restrict__ Rz = (const TO*)p.residual;
   const TO* __restrict__ Mk = (const TO*)p.mask_ref;

@@ -8,6 +8,7 @@
 // chunk (chunk ^= (row>>1)&7) and undone in the fragment reads. Two 64 KB LDS buffers: the DMA of k-tile t+1 is in flight
 // while k-tile t is multiplied; one vmcnt(0)+barrier per k-tile.  Requires C % 64 == 0 (every layer except the stem).
 #include "common.h"
+#include "conv_epilogue.h"
 
 // diagnostic builds only (tools/exp256.sh): 1 = no operand DMA after the first k-tile (MFMA + LDS-read bound of the loop),
 // 2 = MFMAs replaced by a few VALU adds on the fragments (DMA + LDS-read bound of the loop). Results are garbage in both.
@@ -207,6 +208,13 @@ __global__ void __launch_bounds__(512, 2) conv_igemm256_kernel(Conv256Args p) {
     if (grp == 0) __builtin_amdgcn_s_barrier();
   }
 
+  if constexpr (sizeof(TO) == 2) {
+    if ((p.ldy & 7) == 0) {          // row-major epilogue through a wave-private LDS scratch (conv_epilogue.h)
+      __syncthreads();               // every wave is done with the operand stages
+      epilogue_rows_bf16<4, 8>(acc, smem + wid * EpiCfg<4>::BYTES, m0 + wm * 128, n0 + wn * 64, p, lane);
+      return;
+    }
+  }
   TO* __restrict__ Y = (TO*)p.y;
   const TO* __restrict__ Rz = (const TO*)p.residual;
   const TO* __restrict__ Mk = (const TO*)p.mask_ref;
@@ -369,6 +377,13 @@ __global__ void __launch_bounds__(512, 2) conv_igemm256_k32_kernel(Conv256Args p
     buf = (buf + 1) & (NS - 1);
   }
 
+  if constexpr (sizeof(TO) == 2) {
+    if ((p.ldy & 7) == 0) {
+      __syncthreads();
+      epilogue_rows_bf16<4, 8>(acc, smem + wid * EpiCfg<4>::BYTES, m0 + wm * 128, n0 + wn * 64, p, lane);
+      return;
+    }
+  }
   TO* __restrict__ Y = (TO*)p.y;
   const TO* __restrict__ Rz = (const TO*)p.residual;
   const TO* __restrict__ Mk = (const TO*)p.mask_ref;
