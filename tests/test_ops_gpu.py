@@ -179,6 +179,29 @@ def test_wgrad_big_m(dev):
     assert torch.allclose(got, ref, rtol=2e-2, atol=2e-2 * ref.abs().max().item())
 
 
+@pytest.mark.parametrize("case", [(400, 7, 7, 256, 256, 3, 1, 1), (340, 7, 7, 512, 256, 1, 1, 0), (350, 14, 14, 256, 512, 1, 2, 0),
+                                  (2, 97, 101, 256, 256, 3, 1, 1)])
+def test_wgrad_big_tile_kernel(dev, case):
+    """256x256 LDS-DMA weight-gradient kernel (bf16, C % 256 == 0, K % 256 == 0, M >= 16384): 3x3 with padding, 1x1,
+    stride-2 1x1, ragged last m-step, FrozenBN scale fold; fp32 reference = autograd of F.conv2d on the bf16-rounded operands."""
+    o = ops()
+    n, h, w, c, k, r, stride, pad = case
+    gen = g(31)
+    x = torch.randn(n, c, h, w, generator=gen).bfloat16().float()
+    wt = torch.zeros(k, c, r, r, requires_grad=True)
+    y = F.conv2d(x, wt, None, stride=stride, padding=pad)
+    assert y.shape[0] * y.shape[2] * y.shape[3] >= 16384
+    dy = torch.randn(y.shape, generator=gen).bfloat16().float()
+    y.backward(dy)
+    scale = torch.rand(k, generator=gen) + 0.5
+    ref = wt.grad * scale.view(-1, 1, 1, 1)
+    dw = o.conv2d_wgrad(nhwc(x).to(dev).bfloat16(), nhwc(dy).to(dev).bfloat16(), k, r, r, stride, pad, scale=scale.to(dev))
+    got = dw.cpu().permute(0, 3, 1, 2)
+    assert torch.allclose(got, ref, rtol=2e-2, atol=2e-2 * ref.abs().max().item()), (got - ref).abs().max() / ref.abs().max()
+    # tight check against the 128x128 kernel's summation (same bf16 products, fp32 accumulation: only the order differs)
+    assert (got - ref).abs().max() <= 2e-3 * ref.abs().max()
+
+
 def test_pools_bias_misc(dev):
     o = ops()
     gen = g(4)

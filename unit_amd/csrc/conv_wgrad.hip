@@ -199,6 +199,12 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ partial, int split
   *reinterpret_cast<f32x4*>(dw + i) = s;
 }
 
+// conv_wgrad256.hip: 256x256 LDS-DMA kernel for the big-M bf16 layers (same slab layout)
+extern "C" int unit_wgrad_use_big(int in_dtype, long M, int K, int C);
+extern "C" int unit_wgrad_big_splits(long M, int tiles);
+extern "C" int unit_conv2d_wgrad_big_launch(const void* x, const void* dy, float* partial, int N, int H, int W, int C, int K, int R, int S,
+                                            int stride, int pad, int OH, int OW, int ldy, size_t workspace_bytes, void* stream);
+
 static int choose_splits(int M, int tiles, int ms) {
   // 2 workgroups of this kernel are co-resident per CU (72 KB LDS each): 512 slots per "round" on 256 CUs. Pick the
   // split count whose grid fills whole rounds best (tile quantisation), preferring fewer splits (less slab traffic).
@@ -219,6 +225,7 @@ static int choose_splits(int M, int tiles, int ms) {
 extern "C" size_t unit_conv2d_wgrad_workspace_bytes(int in_dtype, int N, int OH, int OW, int K, int R, int S, int C) {
   long M = (long)N * OH * OW;
   int Kgemm = R * S * C;
+  if (unit_wgrad_use_big(in_dtype, M, K, C)) return (size_t)unit_wgrad_big_splits(M, (Kgemm / 256) * (K / 256)) * K * Kgemm * sizeof(float);
   int tiles = cdiv(Kgemm, 128) * cdiv(K, 128);
   int splits = choose_splits((int)M, tiles, in_dtype == UNIT_BF16 ? 64 : 32);
   return (size_t)splits * K * Kgemm * sizeof(float);
@@ -245,6 +252,16 @@ extern "C" int unit_conv2d_wgrad(const void* x, const void* dy, float* dw, const
   // ceil(2^32 / d); for d == 1 the quotient is m itself: magic 0xFFFFFFFF gives m-1 for m>0 and the correction fixes it
   a.magic_ohw = a.OHW > 1 ? (unsigned)((0x100000000ull + a.OHW - 1) / (unsigned long long)a.OHW) : 0xFFFFFFFFu;
   a.magic_ow = OW > 1 ? (unsigned)((0x100000000ull + OW - 1) / (unsigned long long)OW) : 0xFFFFFFFFu;
+  hipStream_t st = (hipStream_t)stream;
+  if (unit_wgrad_use_big(in_dtype, a.M, K, C)) {
+    int sp = unit_conv2d_wgrad_big_launch(x, dy, (float*)workspace, N, H, W, C, K, R, S, stride, pad, OH, OW, ldy, workspace_bytes, stream);
+    if (sp < 0) return sp;
+    if (dw == nullptr) return UNIT_OK;
+    long KKb = (long)K * a.Kgemm;
+    wgrad_reduce_kernel<<<cdiv(KKb / 4, 256), 256, 0, st>>>((const float*)workspace, sp, KKb, a.Kgemm, scale_k, dw, accumulate);
+    UNIT_LAUNCH_CHECK();
+    return UNIT_OK;
+  }
   a.tiles_k = cdiv(a.Kgemm, 128); a.tiles_n = cdiv(K, 128);
   int ms = in_dtype == UNIT_BF16 ? 64 : 32;
   a.splits = choose_splits(a.M, a.tiles_k * a.tiles_n, ms);
@@ -252,7 +269,6 @@ extern "C" int unit_conv2d_wgrad(const void* x, const void* dy, float* dw, const
   a.m_per_split = cdiv(mps, ms) * ms;
   size_t need = (size_t)a.splits * K * a.Kgemm * sizeof(float);
   if (workspace_bytes < need) { unit_set_error("wgrad: workspace too small"); return UNIT_ERR_WORKSPACE; }
-  hipStream_t st = (hipStream_t)stream;
   int grid = a.tiles_k * a.tiles_n * a.splits;
   if (in_dtype == UNIT_BF16) {
     size_t lds = (size_t)2 * 2 * WgCfg<bf16_t>::MS * WgCfg<bf16_t>::ROWB;
@@ -276,6 +292,7 @@ extern "C" int unit_conv2d_wgrad(const void* x, const void* dy, float* dw, const
 // number of split-M slabs unit_conv2d_wgrad writes for this shape (slab s at workspace + s*K*R*S*C floats)
 extern "C" int unit_conv2d_wgrad_splits(int in_dtype, int N, int OH, int OW, int K, int R, int S, int C) {
   long M = (long)N * OH * OW;
+  if (unit_wgrad_use_big(in_dtype, M, K, C)) return unit_wgrad_big_splits(M, (R * S * C / 256) * (K / 256));
   int tiles = cdiv(R * S * C, 128) * cdiv(K, 128);
   return choose_splits((int)M, tiles, in_dtype == UNIT_BF16 ? 64 : 32);
 }

@@ -1,0 +1,203 @@
+// conv_wgrad256.hip -- large-tile bf16 weight gradient for the big-M layers (Res5 heads: M = 50 176 pixels per 1024 RoIs).
+//
+//   dW[n][k] = sum_m dy[m][n] * im2col(x)[m][k]        n = out channel, k = (r,s,c), m = output pixel
+// Same contract and slab layout as conv_wgrad.hip (split-M partial slabs [split][n][k], reduced later in a fixed order),
+// but a 256 (k) x 256 (n) tile per workgroup: the 128x128 kernel needs 64 B/clk/CU of operand feed at the MFMA rate and
+// gets ~27-37, this one needs half. 8 waves (2 along k x 4 along n), each 128 x 64 = 8 x 4 MFMA 16x16x32 tiles.
+// Operands go HBM/L2 -> LDS by LDS-DMA in their memory order ([m][c] and [m][n] rows of 512 B; one 1 KB DMA piece = two rows,
+// two 64 KB stages of 64 pixels each); the contraction index m is the ROW of both tiles, so the MFMA fragments (8
+// consecutive m per lane) come from the transposing LDS read ds_read_b64_tr_b16. Rows are 512 B apart (all on the same
+// banks), so 32-B column blocks are XOR-swizzled with (row & 7) on the DMA source side; a half-wave of the transposing
+// read then touches 8 rows x 32 B on 8 different bank groups.
+// Requires bf16, C % 256 == 0 (a k-tile stays inside one filter tap) and K % 256 == 0.
+#include "common.h"
+
+struct Wgrad256Args {
+  const void* x; const void* dy; float* partial;
+  int N, H, W, C;
+  int K, R, S, stride, pad;
+  int OH, OW;
+  int ldy;
+  int Kgemm, M;
+  int tiles_k, tiles_n, splits, m_per_split;
+  unsigned x_bytes, dy_bytes;
+  unsigned magic_ohw, magic_ow; int OHW; int use_magic;
+};
+
+typedef __attribute__((address_space(3))) void lds_void_w;
+typedef __attribute__((ext_vector_type(8))) short s16x8_w;
+
+__device__ __forceinline__ bf16x8 tr_frag(const char* tile, int sub, int col0, int lane) {
+  // lane l: g = l>>4, i = l&15 = 4q+p ; reads rows (32*sub + 16h + 4g + q), cols col0 + 4p..4p+3 ; element j=4h+q' of
+  // lane i <-> m-row 32*sub + 16h + 4g + q', column col0 + i   (same m permutation for both operands)
+  int g = lane >> 4, i = lane & 15, q = i >> 2, pq = i & 3;
+  int row = 32 * sub + 4 * g + q;
+  int sw = (((col0 >> 4) ^ (row & 7)) << 5) + 8 * pq;      // (row + 16) & 7 == row & 7
+  const char* a0 = tile + row * 512 + sw;
+  s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a0));
+  s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a0 + 16 * 512));
+  s16x8_w v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  return __builtin_bit_cast(bf16x8, v);
+}
+
+__global__ void __launch_bounds__(512, 2) conv_wgrad256_kernel(Wgrad256Args p) {
+  constexpr int MS = 64;
+  constexpr int TILE = MS * 512;               // 32 KB per operand per stage
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  int bid = blockIdx.x;
+  int tile_k = bid % p.tiles_k; int t = bid / p.tiles_k;
+  int tile_n = t % p.tiles_n; int split = t / p.tiles_n;
+  int k0 = tile_k * 256, n0 = tile_n * 256;
+  int m_begin = split * p.m_per_split, m_end = min(p.M, m_begin + p.m_per_split);
+  int rs = k0 / p.C, ch0 = k0 - rs * p.C, kr = rs / p.S, ksx = rs - kr * p.S;
+
+  const bf16_t* __restrict__ X = (const bf16_t*)p.x;
+  const bf16_t* __restrict__ DY = (const bf16_t*)p.dy;
+  __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(X), 0, (int)p.x_bytes, 0x00020000);
+  __amdgpu_buffer_rsrc_t rsD = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(DY), 0, (int)p.dy_bytes, 0x00020000);
+  constexpr unsigned OOB = 0xFFFFFFF0u;
+
+  int tid = threadIdx.x, lane = tid & 63;
+  int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int wk = wid >> 2, wn = wid & 3;
+  bool pointwise = (p.R == 1 && p.S == 1 && p.stride == 1 && p.pad == 0);
+
+  // staging: wave `wid`, piece i (0..3) covers tile rows R0 = (i*8 + wid)*2, R0+1 ; lane -> row R0 + (lane>>5),
+  // physical 16-B chunk lane&31 ; logical source chunk = 32-B block index XOR (row & 7), 16-B half kept
+  int s_row[4]; unsigned s_col[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    int row = (i * 8 + wid) * 2 + (lane >> 5);
+    int jp = lane & 31;
+    int j = ((((jp >> 1) ^ (row & 7)) << 1) | (jp & 1));
+    s_row[i] = row; s_col[i] = (unsigned)j * 8u;           // element offset inside the 256-wide row
+  }
+
+  auto stage = [&](int mstep, int buf) {
+    char* bx = smem + buf * 2 * TILE;
+    char* bd = bx + TILE;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      int R0 = (i * 8 + wid) * 2;
+      int m = mstep + s_row[i];
+      bool mok = m < m_end;
+      unsigned xoff;
+      bool ok = mok;
+      if (pointwise) xoff = ((unsigned)m * (unsigned)p.C + (unsigned)ch0 + s_col[i]) * 2u;
+      else {
+        unsigned um = (unsigned)m, n, oh, ow;
+        if (p.use_magic) {
+          n = __umulhi(um, p.magic_ohw); unsigned rem = um - n * (unsigned)p.OHW;
+          if (rem >= (unsigned)p.OHW) { rem -= p.OHW; ++n; }
+          oh = __umulhi(rem, p.magic_ow); ow = rem - oh * (unsigned)p.OW;
+          if (ow >= (unsigned)p.OW) { ow -= p.OW; ++oh; }
+        } else {
+          ow = um % (unsigned)p.OW; unsigned tt = um / (unsigned)p.OW; oh = tt % (unsigned)p.OH; n = tt / (unsigned)p.OH;
+        }
+        int ih = (int)oh * p.stride - p.pad + kr, iw = (int)ow * p.stride - p.pad + ksx;
+        ok = ok && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
+        xoff = ((unsigned)n * (unsigned)(p.H * p.W * p.C) + (unsigned)((ih * p.W + iw) * p.C + ch0) + s_col[i]) * 2u;
+      }
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, (lds_void_w*)(bx + R0 * 512), 16, ok ? xoff : OOB, 0, 0, 0);
+      unsigned doff = ((unsigned)m * (unsigned)p.ldy + (unsigned)n0 + s_col[i]) * 2u;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsD, (lds_void_w*)(bd + R0 * 512), 16, mok ? doff : OOB, 0, 0, 0);
+    }
+  };
+
+  f32x4 acc[8][4];
+#pragma unroll
+  for (int a = 0; a < 8; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  int nsteps = (m_end - m_begin + MS - 1) / MS;
+  if (nsteps > 0) stage(m_begin, 0);
+  __syncthreads();
+  for (int st = 0; st < nsteps; ++st) {
+    int buf = st & 1;
+    if (st + 1 < nsteps) stage(m_begin + (st + 1) * MS, buf ^ 1);
+    const char* bx = smem + buf * 2 * TILE;
+    const char* bd = bx + TILE;
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub) {
+      bf16x8 fa[8], fb[4];
+#pragma unroll
+      for (int a = 0; a < 8; ++a) fa[a] = tr_frag(bx, sub, wk * 128 + a * 16, lane);
+#pragma unroll
+      for (int b = 0; b < 4; ++b) fb[b] = tr_frag(bd, sub, wn * 64 + b * 16, lane);
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int a = 0; a < 8; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[a], fb[b], acc[a][b], 0, 0, 0);
+      __builtin_amdgcn_s_setprio(0);
+    }
+    __syncthreads();   // vmcnt(0): this wave's DMA of the next m-step landed ; barrier: everyone's did, everyone finished reading `buf`
+  }
+
+  // epilogue: D[row = k][col = n] -> partial[split][n][k..k+3]
+  float* out = p.partial + (size_t)split * p.K * p.Kgemm;
+  int fq = lane >> 4, fr = lane & 15;
+#pragma unroll
+  for (int b = 0; b < 4; ++b) {
+    int n = n0 + wn * 64 + b * 16 + fr;
+#pragma unroll
+    for (int a = 0; a < 8; ++a) {
+      int k = k0 + wk * 128 + a * 16 + fq * 4;
+      *reinterpret_cast<f32x4*>(out + (size_t)n * p.Kgemm + k) = acc[a][b];
+    }
+  }
+}
+
+// shared with conv_wgrad.hip: which kernel handles a shape, and with how many split-M slabs
+extern "C" int unit_wgrad_use_big(int in_dtype, long M, int K, int C) {
+  return in_dtype == UNIT_BF16 && (C % 256) == 0 && (K % 256) == 0 && M >= 16384;
+}
+
+extern "C" int unit_wgrad_big_splits(long M, int tiles) {
+  // one workgroup per CU (128 KB of LDS): 256 slots per round; >= 8 staged steps per split
+  int maxs = (int)((M + 8 * 64 - 1) / (8 * 64));
+  if (maxs < 1) maxs = 1;
+  if (maxs > 64) maxs = 64;
+  int best = 1; double best_score = -1.0;
+  for (int s = 1; s <= maxs; ++s) {
+    long blocks = (long)tiles * s;
+    long rounds = (blocks + 255) / 256;
+    double fill = (double)blocks / (double)(rounds * 256);
+    double score = fill - 0.004 * s;
+    if (score > best_score) { best_score = score; best = s; }
+  }
+  return best;
+}
+
+extern "C" int unit_conv2d_wgrad_big_launch(const void* x, const void* dy, float* partial, int N, int H, int W, int C, int K, int R, int S,
+                                            int stride, int pad, int OH, int OW, int ldy, size_t workspace_bytes, void* stream) {
+  Wgrad256Args a;
+  a.x = x; a.dy = dy; a.partial = partial;
+  a.N = N; a.H = H; a.W = W; a.C = C; a.K = K; a.R = R; a.S = S; a.stride = stride; a.pad = pad; a.OH = OH; a.OW = OW;
+  a.ldy = ldy; a.Kgemm = R * S * C; a.M = N * OH * OW;
+  UNIT_CHECK_ARG(ldy % 8 == 0, "wgrad_big: ldy must be a multiple of 8");
+  size_t xb = (size_t)N * H * W * C * 2, db = (size_t)a.M * ldy * 2;
+  UNIT_CHECK_ARG(xb < 0xFFFFFFF0ull && db < 0xFFFFFFF0ull, "wgrad_big: operand larger than 4 GiB");
+  a.x_bytes = (unsigned)xb; a.dy_bytes = (unsigned)db;
+  a.OHW = OH * OW;
+  a.use_magic = ((unsigned long long)(a.M + 64) * (unsigned long long)a.OHW < 0xFFFFFFFFull) ? 1 : 0;
+  a.magic_ohw = a.OHW > 1 ? (unsigned)((0x100000000ull + a.OHW - 1) / (unsigned long long)a.OHW) : 0xFFFFFFFFu;
+  a.magic_ow = OW > 1 ? (unsigned)((0x100000000ull + OW - 1) / (unsigned long long)OW) : 0xFFFFFFFFu;
+  a.tiles_k = a.Kgemm / 256; a.tiles_n = K / 256;
+  a.splits = unit_wgrad_big_splits(a.M, a.tiles_k * a.tiles_n);
+  int mps = cdiv(a.M, a.splits);
+  a.m_per_split = cdiv(mps, 64) * 64;
+  size_t need = (size_t)a.splits * K * a.Kgemm * sizeof(float);
+  if (workspace_bytes < need) { unit_set_error("wgrad_big: workspace too small"); return UNIT_ERR_WORKSPACE; }
+  size_t lds = 2 * 2 * 64 * 512;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)conv_wgrad256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  conv_wgrad256_kernel<<<a.tiles_k * a.tiles_n * a.splits, 512, lds, (hipStream_t)stream>>>(a);
+  UNIT_LAUNCH_CHECK();
+  return a.splits;
+}
