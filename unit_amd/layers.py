@@ -108,6 +108,7 @@ class Conv2d(_EpochOnLoad):
             side = ops.WGRAD_STREAM
             if side is None:
                 self._slab, self._splits = ops.conv2d_wgrad_partial(x, dy, self.cout, self.k, self.k, st, self.pad, self._slab)
+                self._plan.note_wgrad(self)
                 return
             # weight gradients depend on nothing downstream: run them on a side HIP stream so that they fill the CUs the
             # dgrad chain leaves idle (tile-quantisation tails, the small res3/res4 grids); joined before the bucket's reduce
@@ -119,6 +120,7 @@ class Conv2d(_EpochOnLoad):
             dy.record_stream(side)
             with torch.cuda.stream(side):
                 self._slab, self._splits = ops.conv2d_wgrad_partial(x, dy, self.cout, self.k, self.k, st, self.pad, self._slab)
+                self._plan.note_wgrad(self)
             return
         g = self.weight.grad
         if g is None:

@@ -43,8 +43,13 @@ class ConvPlan:
                 m._splits = 0
                 self.convs.append(m)
                 self.by_tag.setdefault(tag_of[id(m.weight)], []).append(m)
-        self._tables = {}      # tag -> (device bytes tensor, n, total_blocks, signature)
+        self._tables = {}      # signature -> (device bytes tensor, n, total_blocks)
         self._prep_table = None
+        # slabs written since the last reduction, per HIP stream (a reduction launched on a stream may only consume slabs
+        # whose wgrad kernels are ordered before it on that stream). Reducing every ~96 MB of slabs keeps them resident in
+        # the 256 MB Infinity Cache between the wgrad kernel that wrote them and the reduction that reads them back.
+        self._pending = {}
+        self.flush_bytes = 96 << 20
 
     def _build(self, convs, with_partial):
         descs = (TensorDesc * len(convs))()
@@ -65,18 +70,33 @@ class ConvPlan:
         host = torch.frombuffer(bytearray(bytes(descs)), dtype=torch.uint8)
         return host.to(self.model.device), len(convs), b0
 
-    def reduce(self, tag):
-        """grads[flat] = scale * sum(slabs) for every conv of this bucket tag (call before the bucket's all-reduce)."""
-        convs = [m for m in self.by_tag.get(tag, []) if m._slab is not None]
-        if not convs:
+    def note_wgrad(self, conv):
+        """called right after a conv's split-M slabs were enqueued on the current stream"""
+        key = torch.cuda.current_stream().cuda_stream if self.model.device.type == "cuda" else 0
+        lst = self._pending.setdefault(key, [0, []])
+        lst[1].append(conv)
+        lst[0] += conv._splits * conv.cout * conv.k * conv.k * conv.cin * 4
+        if lst[0] >= self.flush_bytes:
+            self._flush(key)
+
+    def _flush(self, key):
+        lst = self._pending.get(key)
+        if not lst or not lst[1]:
             return
-        sig = tuple((m._slab.data_ptr(), m._splits) for m in convs)
-        tab = self._tables.get(tag)
-        if tab is None or tab[3] != sig:
-            dev, n, blocks = self._build(convs, True)
-            tab = (dev, n, blocks, sig)
-            self._tables[tag] = tab
+        convs = lst[1]
+        self._pending[key] = [0, []]
+        sig = tuple((id(m), m._slab.data_ptr(), m._splits) for m in convs)
+        tab = self._tables.get(sig)
+        if tab is None:
+            tab = self._build(convs, True)
+            self._tables[sig] = tab
         check(lib().unit_multi_wgrad_reduce(ops._p(tab[0]), tab[1], tab[2], ops._p(self.model.store.grads), ops._s()), "multi_wgrad_reduce")
+
+    def reduce(self, tag=None):
+        """grads[flat] = scale * sum(slabs) for every conv whose slabs are still pending (call at a bucket boundary, on a
+        stream that is ordered after every stream that produced them, before the bucket's all-reduce)."""
+        for key in list(self._pending):
+            self._flush(key)
 
     def prep_all(self, dtype, version):
         """refresh wf / wd of every planned conv from the (just updated) flat parameters; marks them prepared."""
