@@ -128,12 +128,11 @@ def main():
     buckets.broadcast_parameters()
     opt = FlatSGD(model, cfg, grad_scale=buckets.grad_scale)
 
-    def one_step():                       # == engine.TrainerNoMeta.run_step on a pre-packed batch
-        with model.step_stream():         # high-priority HIP stream for the critical path (side streams: normal priority)
-            step = model.forward_train(batch, early_backward=True)
-            model.backward_train(step)
-            buckets.finish()
-            opt.step()
+    def one_step():
+        step = model.forward_train(batch, early_backward=True)
+        model.backward_train(step)
+        buckets.finish()
+        opt.step()
         return step.losses
 
     for _ in range(args.warmup):

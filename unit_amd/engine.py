@@ -37,13 +37,10 @@ class TrainerNoMeta:
         if classifier_data is None and self.weak_data_iter is not None:
             classifier_data = next(self.weak_data_iter)
         batch = self.model.pack_batch(base_data, classifier_data)
-        with self.model.step_stream():               # high-priority stream for the critical path (rcnn.py)
-            step = self.model.forward_train(batch, early_backward=True)
-            self.model.backward_train(step)          # buckets' all-reduces are launched from inside (on_grad_ready)
-            self.buckets.finish()
-            self.optimizer.step()
-        if step.losses.is_cuda:
-            step.losses.record_stream(torch.cuda.current_stream())
+        step = self.model.forward_train(batch, early_backward=True)
+        self.model.backward_train(step)          # buckets' all-reduces are launched from inside (on_grad_ready)
+        self.buckets.finish()
+        self.optimizer.step()
         self.iter += 1
         self.last_losses = step.losses
         return step.losses

@@ -520,29 +520,6 @@ class WeaklySupervisedRCNNNoMeta(nn.Module):
             self._rpn_stream = torch.cuda.Stream(self.device)
         return True
 
-    def step_stream(self):
-        """Context manager: run the training step on a HIGH-priority HIP stream. The step's own side streams (box_head,
-        RPN branch, weight gradients) are normal priority, so whenever a CU frees up the dispatcher hands it to the
-        critical-path (dgrad / forward) kernels first and the side-stream kernels only fill what is left -- without this a
-        256-workgroup weight-gradient launch (128 KB of LDS per workgroup) takes every CU for ~150 us at a time and the
-        main stream's kernels queue behind it. On entry the stream waits for the caller's stream, on exit the caller's
-        stream waits for it (two event waits per use; bench.py wraps its whole loop once)."""
-        import contextlib
-
-        @contextlib.contextmanager
-        def ctx():
-            if self.device.type != "cuda" or not self.overlap_streams:
-                yield None
-                return
-            if getattr(self, "_step_stream", None) is None:
-                self._step_stream = torch.cuda.Stream(self.device, priority=-1)
-            outer = torch.cuda.current_stream()
-            self._step_stream.wait_stream(outer)
-            with torch.cuda.stream(self._step_stream):
-                yield self._step_stream
-            outer.wait_stream(self._step_stream)
-        return ctx()
-
     def _reattach_grads(self):
         """optimizer.zero_grad(set_to_none=True) drops .grad: point them at the flat gradient buffer again."""
         st = self.store
