@@ -209,7 +209,7 @@ static int choose_splits(int M, int tiles, int ms) {
   // 2 workgroups of this kernel are co-resident per CU (72 KB LDS each): 512 slots per "round" on 256 CUs. Pick the
   // split count whose grid fills whole rounds best (tile quantisation), preferring fewer splits (less slab traffic).
   // Cost model (us), fitted to tools/microbench.py on the res3/res4/RPN shapes: a workgroup needs ~4 us of fixed time
-  // (launch ramp, first loads, slab store) plus ~0.6 us per staged 64-row step (operand-feed bound at this tile); the
+  // (launch ramp, first loads, slab store) plus ~1.0 us per staged 64-row step (operand-feed bound at this tile); the
   // grid runs in rounds of 512 workgroups; every split writes one fp32 slab of the whole dW (64 KB per tile) that the
   // reduction reads back: ~2 x 64 KB per tile and split at ~4 TB/s.
   int maxs = (M + 4 * ms - 1) / (4 * ms);   // at least 4 staged steps per split
@@ -220,7 +220,7 @@ static int choose_splits(int M, int tiles, int ms) {
   for (int s = 1; s <= maxs; ++s) {
     long blocks = (long)tiles * s;
     long rounds = (blocks + 511) / 512;
-    double per_block = 4.0 + 0.6 * (steps_total / s) * (ms / 64.0);
+    double per_block = 4.0 + 1.0 * (steps_total / s) * (ms / 64.0);
     double slab = (double)blocks * 2.0 * 65536.0 / 4.0e6;      // bytes / (4 TB/s) in us
     double cost = rounds * per_block + slab;
     if (cost < best_cost) { best_cost = cost; best = s; }
