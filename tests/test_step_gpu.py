@@ -306,3 +306,38 @@ def test_mask_step_parity_fp32(dev):
         # fp32 summation-order noise through ~40 layers and three gradient sources (box, weak, mask): 5e-3 of the tensor's max
         assert (gd - gr).abs().max() <= 5e-3 * gr.abs().max() + 1e-8, (name, (gd - gr).abs().max(), gr.abs().max())
     assert "roi_heads.weak_box_head.res5.0.conv1.weight" not in p
+
+
+def test_trainers_run_steps_bf16(dev):
+    """engine.TrainerNoMeta / TrainerFineTune run_step (the bench / drop-in path: multi-stream schedule, optimizer, weight
+    re-preparation) for a few iterations in bf16: finite losses, parameters move; the fine-tune trainer has NO trainable
+    conv (every conv of the plan is frozen) and only updates cls_score_ft / bbox_pred_ft."""
+    from unit_amd import engine
+    cfg = small_cfg()
+    model = build_model(cfg)
+    init_synthetic_weights(model, seed=1)
+    model.train()
+    sup, weak = synthetic_batch(2, 2, hw=(128, 192), seed=5, max_gt=4)
+    tr = engine.TrainerNoMeta(cfg, model)
+    w0 = None
+    for it in range(3):
+        losses = tr.run_step(sup, weak)
+        if w0 is None:
+            w0 = model.store.params.clone()
+    assert torch.isfinite(losses).all() and not torch.equal(w0, model.store.params)
+
+    cfg = config.voc_rcnn_c4_split1_ft(50)
+    cfg.MODEL.DEVICE = "cuda"
+    cfg.MODEL.ROI_HEADS.BATCH_SIZE_PER_IMAGE = 32
+    cfg.MODEL.RPN.PRE_NMS_TOPK_TRAIN, cfg.MODEL.RPN.POST_NMS_TOPK_TRAIN = 600, 100
+    model = build_model(cfg)
+    init_synthetic_weights(model, seed=2)
+    model.train()
+    sup, _ = synthetic_batch(2, 0, hw=(128, 192), seed=6, max_gt=4, base_ids=list(range(20)))
+    tr = engine.TrainerFineTune(cfg, model)
+    frozen = model.backbone.res4[0].conv1.weight.detach().clone()
+    for it in range(3):
+        losses = tr.run_step(sup)
+    assert torch.isfinite(losses[:8]).all()
+    assert torch.equal(frozen, model.backbone.res4[0].conv1.weight.detach())
+    assert model.roi_heads.box_predictor.cls_score_ft.weight.abs().sum() > 0      # zero-initialised, moved by SGD

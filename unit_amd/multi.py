@@ -100,6 +100,8 @@ class ConvPlan:
 
     def prep_all(self, dtype, version):
         """refresh wf / wd of every planned conv from the (just updated) flat parameters; marks them prepared."""
+        if not self.convs:
+            return True            # nothing trainable in the plan (fine-tune step: every conv is frozen)
         convs = [m for m in self.convs if m.wf is not None and m.wf.dtype == dtype and m.wd is not None]
         if len(convs) != len(self.convs):
             return False           # first step: the per-layer prepare() path allocates the copies
