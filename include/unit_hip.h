@@ -97,9 +97,11 @@ int unit_box_decode(const float* deltas, int ld, int col0, int K, const float* b
 size_t unit_sort_workspace_bytes(int B, int n);
 int unit_sort_desc_stable(const float* src, long batch_stride, int ld, int A, int col0, int B, int n, float* out_keys, int* out_idx,
                           void* workspace, size_t workspace_bytes, void* stream);
-/* top-k form (chip-wide select + rank sort): only the first min(topk, n) entries of each output row are defined */
-int unit_sort_desc_stable_topk(const float* src, long batch_stride, int ld, int A, int col0, int B, int n, int topk, float* out_keys,
-                               int* out_idx, void* workspace, size_t workspace_bytes, void* stream);
+/* top-k form (chip-wide select + rank sort): only the first min(topk, #keys > min_exclusive) entries of each output row are
+ * defined; pass -INFINITY to rank every key */
+int unit_sort_desc_stable_topk(const float* src, long batch_stride, int ld, int A, int col0, int B, int n, int topk,
+                               float min_exclusive, float* out_keys, int* out_idx, void* workspace, size_t workspace_bytes,
+                               void* stream);
 int unit_rpn_decode_select(const float* head, long head_batch_stride, int ld, int A, int delta_col0, const float* anchors,
                            const int* sorted_idx, const float* sorted_logit, int B, int Ncap, int topk, const float* image_hw_dev,
                            float scale_clamp, float min_size, float* cand_boxes, float* cand_scores, int* cand_count, void* stream);

@@ -368,6 +368,20 @@ def test_sort_desc_topk(dev, n, topk, a, ld):
         assert torch.equal(k.cpu()[:, :t].view(torch.int32), rk[:, :t].view(torch.int32)), mode
 
 
+def test_sort_desc_topk_min_exclusive(dev):
+    """detection candidates: scores > 0 ranked, the zero-filled tail never ranked (rows defined up to the valid count)."""
+    o = ops()
+    gen = g(82)
+    n = 20000
+    sc = torch.zeros(2, n)
+    valid = [3777, 0]
+    sc[0, :valid[0]] = torch.rand(valid[0], generator=gen) * 0.9 + 0.05
+    sc[0, 100:140] = 0.5                                         # ties
+    k, i = o.sort_desc(sc.to(dev), 2, n, topk=n, min_exclusive=0.0)
+    rk, ri = torch.sort(sc, dim=1, descending=True, stable=True)
+    assert torch.equal(i.cpu().long()[0, :valid[0]], ri[0, :valid[0]]) and torch.equal(k.cpu()[0, :valid[0]], rk[0, :valid[0]])
+
+
 def test_nms_exact(dev):
     o = ops()
     gen = g(9)

@@ -225,7 +225,8 @@ extern "C" int unit_sort_desc_stable(const float* src, long batch_stride, int ld
 // ---------------------------------------------------------------------------------------------------
 #define SEL_BINS 8192
 __global__ void __launch_bounds__(1024) topk_select_kernel(const float* __restrict__ src, long bstride, int ld, int A, int col0, int n,
-                                                           int topk, unsigned long long* __restrict__ cand, int* __restrict__ cand_count) {
+                                                           int topk, float min_excl, unsigned long long* __restrict__ cand,
+                                                           int* __restrict__ cand_count) {
   __shared__ int hist[SEL_BINS];
   __shared__ int wsum[16];
   __shared__ int s_T, s_cnt;
@@ -236,7 +237,8 @@ __global__ void __launch_bounds__(1024) topk_select_kernel(const float* __restri
   __syncthreads();
   for (int i = tid; i < n; i += 1024) {
     int pix = i / A, a = i - pix * A;
-    atomicAdd(&hist[desc_key(sb[(size_t)pix * ld + a]) >> 19], 1);
+    float v = sb[(size_t)pix * ld + a];
+    if (v > min_excl) atomicAdd(&hist[desc_key(v) >> 19], 1);       // keys <= min_excl never become candidates
   }
   __syncthreads();
   int loc[8], sum = 0;
@@ -263,8 +265,9 @@ __global__ void __launch_bounds__(1024) topk_select_kernel(const float* __restri
     unsigned key = 0; bool c = false;
     if (i < n) {
       int pix = i / A, a = i - pix * A;
-      key = desc_key(sb[(size_t)pix * ld + a]);
-      c = (key >> 19) <= T;
+      float v = sb[(size_t)pix * ld + a];
+      key = desc_key(v);
+      c = (key >> 19) <= T && v > min_excl;
     }
     unsigned long long bal = __ballot(c);
     int wpos = 0;
@@ -310,14 +313,15 @@ __global__ void __launch_bounds__(256) rank_sort_kernel(const unsigned long long
 }
 
 extern "C" int unit_sort_desc_stable_topk(const float* src, long batch_stride, int ld, int A, int col0, int B, int n, int topk,
-                                          float* out_keys, int* out_idx, void* workspace, size_t workspace_bytes, void* stream) {
+                                          float min_exclusive, float* out_keys, int* out_idx, void* workspace, size_t workspace_bytes,
+                                          void* stream) {
   if (workspace_bytes < unit_sort_workspace_bytes(B, n)) { unit_set_error("sort: workspace too small"); return UNIT_ERR_WORKSPACE; }
   UNIT_CHECK_ARG(topk > 0, "sort_topk: topk must be positive");
   if (B == 0 || n == 0) return UNIT_OK;
   unsigned long long* cand = (unsigned long long*)workspace;
   int* cand_count = (int*)((char*)workspace + (size_t)B * n * 8);
   hipStream_t st = (hipStream_t)stream;
-  topk_select_kernel<<<B, 1024, 0, st>>>(src, batch_stride, ld, A, col0, n, topk, cand, cand_count);
+  topk_select_kernel<<<B, 1024, 0, st>>>(src, batch_stride, ld, A, col0, n, topk, min_exclusive, cand, cand_count);
   UNIT_LAUNCH_CHECK();
   rank_sort_kernel<<<dim3((n + 63) / 64, B), 256, 0, st>>>(cand, cand_count, n, src, batch_stride, ld, A, col0, out_keys, out_idx);
   UNIT_LAUNCH_CHECK();

@@ -378,9 +378,10 @@ def box_decode(deltas, boxes, weights, k=None, col0=0):
     return out
 
 
-def sort_desc(src, b, n, ld=1, a=1, col0=0, batch_stride=None, topk=None):
+def sort_desc(src, b, n, ld=1, a=1, col0=0, batch_stride=None, topk=None, min_exclusive=None):
     """stable descending sort of n keys per batch row; keys read as src[b*bstride + (i//a)*ld + col0 + i%a].
-    topk: only the first min(topk, n) entries of each output row are needed (chip-wide select + rank sort)."""
+    topk: only the first min(topk, n) entries of each output row are needed (chip-wide select + rank sort);
+    min_exclusive (with topk): keys <= it are not ranked at all (rows are defined up to the number of larger keys)."""
     dev = src.device
     keys = torch.empty((b, n), dtype=torch.float32, device=dev)
     idx = torch.empty((b, n), dtype=torch.int32, device=dev)
@@ -389,8 +390,9 @@ def sort_desc(src, b, n, ld=1, a=1, col0=0, batch_stride=None, topk=None):
     nb = lib().unit_sort_workspace_bytes(b, n)
     ws = workspace(nb, dev)
     if topk is not None:
-        check(lib().unit_sort_desc_stable_topk(_p(src), batch_stride, ld, a, col0, b, n, int(topk), _p(keys), _p(idx), _p(ws),
-                                               ws.numel(), _s()), "sort_desc_stable_topk")
+        check(lib().unit_sort_desc_stable_topk(_p(src), batch_stride, ld, a, col0, b, n, int(topk),
+                                               float("-inf") if min_exclusive is None else float(min_exclusive), _p(keys), _p(idx),
+                                               _p(ws), ws.numel(), _s()), "sort_desc_stable_topk")
         return keys, idx
     check(lib().unit_sort_desc_stable(_p(src), batch_stride, ld, a, col0, b, n, _p(keys), _p(idx), _p(ws), ws.numel(), _s()),
           "sort_desc_stable")
@@ -613,7 +615,8 @@ def detections(probs, deltas, props, pcount, image_hw, weights, score_thresh, nm
                                           SCALE_CLAMP, _p(image_hw), float(score_thresh), cap, _p(cb), _p(cs), _p(cc), _p(cr), _p(cnt),
                                           _p(cmax), _s()), "detection_candidates")
     # stable descending sort of the candidate scores (unused tail slots hold 0 <= thresh and sort behind every candidate)
-    _, order = sort_desc(cs, b, cap)
+    # (chip-wide select + rank sort over the valid candidates only: every valid score is > score_thresh >= 0 = the fill value)
+    _, order = sort_desc(cs, b, cap, topk=cap, min_exclusive=0.0 if score_thresh >= 0 else None)
     ob = torch.empty((b, cap, 4), dtype=torch.float32, device=dev)
     check(lib().unit_detection_offset_gather(_p(cb), _p(cc), _p(order), _p(cnt), _p(cmax), b, cap, _p(ob), _s()), "detection_offset_gather")
     keep, kc, _, _ = nms(ob, cs, cnt, nms_thresh, topk)
