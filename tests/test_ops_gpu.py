@@ -138,7 +138,7 @@ def test_conv_dgrad_wgrad(dev, case, dtype):
 
 @pytest.mark.parametrize("case", [(3, 30, 33, 256, 256, 3, 1, 1), (1, 38, 63, 128, 75, 1, 1, 0), (2, 9, 9, 64, 40, 1, 1, 0), (70, 7, 7, 64, 512, 3, 1, 1),
                                   (2, 19, 23, 64, 320, 1, 2, 0)])
-@pytest.mark.parametrize("big", [5, 6, 7, 8, 9, 10, 11])
+@pytest.mark.parametrize("big", [5, 6, 7, 8, 9, 10, 11, 12, 13])
 def test_conv_big_tile_kernel(dev, case, big):
     """256x256x64 LDS-DMA kernel (tile_cfg=5; 6 = its ping-pong wave-group schedule; 7-9 = the 4-wave 128x128 / 64x128 / 128x64 LDS-DMA kernels) == F.conv2d incl. padding, partial tiles, K not a multiple of 256,
     residual + ReLU + mask epilogues and the strided-scatter dgrad form."""

@@ -50,7 +50,7 @@ def bench_conv(dtype=torch.bfloat16):
         oh, ow = o.conv_out_size(h, w, r, r, st, pad)
         flops = 2.0 * n * oh * ow * k * r * r * c
         best = None
-        for tile in ((1, 2, 3, 4, 5, 7, 8, 9, 10, 11) if c % 64 == 0 else (1, 2, 3, 4)):
+        for tile in ((1, 2, 3, 4, 7, 8, 12, 13, 5) if c % 64 == 0 else (1, 2, 3, 4)):
             try:
                 ms = timeit(lambda: o.conv2d(x, wt, k, r, r, st, pad, relu=True, tile_cfg=tile))
             except Exception as ex:  # noqa
@@ -59,8 +59,8 @@ def bench_conv(dtype=torch.bfloat16):
                 best = (tile, ms)
             if tile == 5:
                 name = f"{name} [big {flops / ms / 1e9:.0f}TF]"
-            if tile == 11:
-                name = f"{name} [k32 {flops / ms / 1e9:.0f}]"
+            if tile in (12, 13):
+                name = f"{name} [{'224' if tile == 12 else '256'}r {flops / ms / 1e9:.0f}]"
             if tile in (7, 8, 9, 10):
                 name = f"{name} [m{tile - 7} {flops / ms / 1e9:.0f}]"
         ms_auto = timeit(lambda: o.conv2d(x, wt, k, r, r, st, pad, relu=True, tile_cfg=0))

@@ -52,10 +52,13 @@ template <> struct O4<bf16_t> {
 
 typedef __attribute__((address_space(3))) void lds_void;
 
-template <typename TO, bool PP>
+// FB = 16-row MFMA blocks per wave along the pixel dimension: tile = (32*FB) pixels x 256 channels. FB = 7 (224 rows) divides
+// the Res5 problem sizes (50 176 = 224 * 224 pixels per 1024 RoIs) into whole rounds of 256 workgroups where 256-row tiles
+// leave the last round 1/2 - 3/4 empty; the LDS image keeps 256 rows per stage either way.
+template <typename TO, bool PP, int FB>
 __global__ void __launch_bounds__(512, 2) conv_igemm256_kernel(Conv256Args p) {
-  constexpr int BM = 256, BN = 256, BK = 64;
-  constexpr int BUF = (BM + BN) * 128;          // 64 KB per stage
+  constexpr int BM = 32 * FB, BMR = 256, BN = 256, BK = 64;
+  constexpr int BUF = (BMR + BN) * 128;         // 64 KB per stage
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   int nwg = p.tiles_m * p.tiles_n;
@@ -88,7 +91,7 @@ __global__ void __launch_bounds__(512, 2) conv_igemm256_kernel(Conv256Args p) {
     int q = lc ^ ((row >> 1) & 7);
     x_q[i] = q; w_q[i] = q;
     int m = m0 + row;
-    x_ok[i] = m < p.M;
+    x_ok[i] = m < p.M && row < BM;
     int mm = x_ok[i] ? m : 0;
     int ow = mm % p.OW; int t = mm / p.OW; int oh = t % p.OH; int n = t / p.OH;
     x_ih0[i] = oh * p.stride - p.pad; x_iw0[i] = ow * p.stride - p.pad;
@@ -109,6 +112,7 @@ __global__ void __launch_bounds__(512, 2) conv_igemm256_kernel(Conv256Args p) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       int R0 = (i * 8 + wid) * 8;
+      if (R0 >= BM) continue;                 // wave-uniform: pixel rows beyond a 224-row tile are never read
       int ih = x_ih0[i] + r, iw = x_iw0[i] + s;
       bool ok = x_ok[i] && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
       unsigned off = (x_base[i] + (unsigned)((ih * p.W + iw) * p.C + ch0 + x_q[i] * 8)) * 2u;
@@ -118,15 +122,15 @@ __global__ void __launch_bounds__(512, 2) conv_igemm256_kernel(Conv256Args p) {
     for (int i = 0; i < 4; ++i) {
       int R0 = (i * 8 + wid) * 8;
       unsigned off = w_off[i] + (unsigned)k0 * 2u;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (lds_void*)(base + BM * 128 + R0 * 128), 16, w_ok[i] ? off : OOB, 0, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (lds_void*)(base + BMR * 128 + R0 * 128), 16, w_ok[i] ? off : OOB, 0, 0, 0);
     }
   };
 
-  f32x4 acc[4][8];
+  f32x4 acc[4][FB];
 #pragma unroll
   for (int a = 0; a < 4; ++a)
 #pragma unroll
-    for (int b = 0; b < 8; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int b = 0; b < FB; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   int nk = p.Kgemm / BK;
   int frow = lane & 15, fq = lane >> 4;
@@ -137,25 +141,25 @@ __global__ void __launch_bounds__(512, 2) conv_igemm256_kernel(Conv256Args p) {
       int buf = kt & 1;
       if (kt + 1 < nk && UNIT_DBG256 != 1) stage(kt + 1, buf ^ 1);
       const char* bx = smem + buf * BUF;
-      const char* bw = bx + BM * 128;
+      const char* bw = bx + BMR * 128;
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
-        i32x4 fa[4], fb[8];
+        i32x4 fa[4], fb[FB];
 #pragma unroll
         for (int a = 0; a < 4; ++a) fa[a] = *reinterpret_cast<const i32x4*>(bw + swz256(wn * 64 + a * 16 + frow, ks * 4 + fq));
 #pragma unroll
-        for (int b = 0; b < 8; ++b) fb[b] = *reinterpret_cast<const i32x4*>(bx + swz256(wm * 128 + b * 16 + frow, ks * 4 + fq));
+        for (int b = 0; b < FB; ++b) fb[b] = *reinterpret_cast<const i32x4*>(bx + swz256(wm * (FB * 16) + b * 16 + frow, ks * 4 + fq));
         __builtin_amdgcn_s_setprio(1);
 #if UNIT_DBG256 == 2
 #pragma unroll
         for (int a = 0; a < 4; ++a) acc[a][0] += __builtin_bit_cast(f32x4, fa[a]);
 #pragma unroll
-        for (int b = 0; b < 8; ++b) acc[0][b] += __builtin_bit_cast(f32x4, fb[b]);
+        for (int b = 0; b < FB; ++b) acc[0][b] += __builtin_bit_cast(f32x4, fb[b]);
 #else
 #pragma unroll
         for (int a = 0; a < 4; ++a)
 #pragma unroll
-          for (int b = 0; b < 8; ++b)
+          for (int b = 0; b < FB; ++b)
             acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fa[a]), __builtin_bit_cast(bf16x8, fb[b]), acc[a][b], 0, 0, 0);
 #endif
         __builtin_amdgcn_s_setprio(0);
@@ -177,16 +181,16 @@ __global__ void __launch_bounds__(512, 2) conv_igemm256_kernel(Conv256Args p) {
     for (int kt = 0; kt < nk; ++kt) {
       int buf = kt & 1;
       const char* bx = smem + buf * BUF;
-      const char* bw = bx + BM * 128;
+      const char* bw = bx + BMR * 128;
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
         // LOAD section
         if (ks == 0 && kt + 1 < nk) stage(kt + 1, buf ^ 1);
-        i32x4 fa[4], fb[8];
+        i32x4 fa[4], fb[FB];
 #pragma unroll
         for (int a = 0; a < 4; ++a) fa[a] = *reinterpret_cast<const i32x4*>(bw + swz256(wn * 64 + a * 16 + frow, ks * 4 + fq));
 #pragma unroll
-        for (int b = 0; b < 8; ++b) fb[b] = *reinterpret_cast<const i32x4*>(bx + swz256(wm * 128 + b * 16 + frow, ks * 4 + fq));
+        for (int b = 0; b < FB; ++b) fb[b] = *reinterpret_cast<const i32x4*>(bx + swz256(wm * (FB * 16) + b * 16 + frow, ks * 4 + fq));
         if (ks == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
@@ -197,7 +201,7 @@ __global__ void __launch_bounds__(512, 2) conv_igemm256_kernel(Conv256Args p) {
 #pragma unroll
         for (int a = 0; a < 4; ++a)
 #pragma unroll
-          for (int b = 0; b < 8; ++b)
+          for (int b = 0; b < FB; ++b)
             acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fa[a]), __builtin_bit_cast(bf16x8, fb[b]), acc[a][b], 0, 0, 0);
         __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
@@ -211,7 +215,7 @@ __global__ void __launch_bounds__(512, 2) conv_igemm256_kernel(Conv256Args p) {
   if constexpr (sizeof(TO) == 2) {
     if ((p.ldy & 7) == 0) {          // row-major epilogue through a wave-private LDS scratch (conv_epilogue.h)
       __syncthreads();               // every wave is done with the operand stages
-      epilogue_rows_bf16<4, 8>(acc, smem + wid * EpiCfg<4>::BYTES, m0 + wm * 128, n0 + wn * 64, p, lane);
+      epilogue_rows_bf16<4, FB>(acc, smem + wid * EpiCfg<4>::BYTES, m0 + wm * (FB * 16), n0 + wn * 64, p, lane);
       return;
     }
   }
@@ -220,8 +224,8 @@ __global__ void __launch_bounds__(512, 2) conv_igemm256_kernel(Conv256Args p) {
   const TO* __restrict__ Mk = (const TO*)p.mask_ref;
   bool plain = (p.oy_mul == 1 && p.OHf == p.OH && p.OWf == p.OW);
 #pragma unroll
-  for (int b = 0; b < 8; ++b) {
-    int m = m0 + wm * 128 + b * 16 + frow;
+  for (int b = 0; b < FB; ++b) {
+    int m = m0 + wm * (FB * 16) + b * 16 + frow;
     if (m >= p.M) continue;
     long off;
     if (plain) off = (long)m * p.ldy;
@@ -440,16 +444,16 @@ static int launch256_k32(Conv256Args& a, hipStream_t st) {
   return UNIT_OK;
 }
 
-template <typename TO, bool PP>
+template <typename TO, bool PP, int FB>
 static int launch256(Conv256Args& a, hipStream_t st) {
-  a.tiles_m = cdiv(a.M, 256); a.tiles_n = cdiv(a.K, 256);
+  a.tiles_m = cdiv(a.M, 32 * FB); a.tiles_n = cdiv(a.K, 256);
   size_t lds = 2 * (256 + 256) * 128;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)conv_igemm256_kernel<TO, PP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)conv_igemm256_kernel<TO, PP, FB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
-  conv_igemm256_kernel<TO, PP><<<a.tiles_m * a.tiles_n, 512, lds, st>>>(a);
+  conv_igemm256_kernel<TO, PP, FB><<<a.tiles_m * a.tiles_n, 512, lds, st>>>(a);
   UNIT_LAUNCH_CHECK();
   return UNIT_OK;
 }
@@ -473,10 +477,24 @@ extern "C" int unit_conv2d_fwd_big(const void* x, const void* w, void* y, const 
   a.x_bytes = (unsigned)xb; a.w_bytes = (unsigned)wb;
   if (a.M == 0 || K == 0) return UNIT_OK;
   hipStream_t st = (hipStream_t)stream;
-  // variant 0: one barrier per k-tile; variant 1: ping-pong wave groups (MFMA section || LOAD section)
-  // variant 2: four 32-k stages, three in flight (counted vmcnt)
-  if (out_dtype == UNIT_BF16) return variant == 2 ? launch256_k32<bf16_t>(a, st) : variant ? launch256<bf16_t, true>(a, st) : launch256<bf16_t, false>(a, st);
-  if (out_dtype == UNIT_F32) return variant == 2 ? launch256_k32<float>(a, st) : variant ? launch256<float, true>(a, st) : launch256<float, false>(a, st);
+  // variant 0: one barrier per k-tile, pixel-tile height (256 or 224 rows) picked for the fewest rounds x rows;
+  // 1: ping-pong wave groups; 2: four 32-k stages; 3 / 4: variant 0 with 224 / 256 rows forced
+  bool rows224 = variant == 3;
+  if (variant == 0) {
+    long n_tiles = cdiv(K, 256);
+    long c256 = cdiv((long)cdiv(a.M, 256) * n_tiles, 256) * 256, c224 = cdiv((long)cdiv(a.M, 224) * n_tiles, 256) * 224;
+    rows224 = c224 < c256;
+  }
+  if (out_dtype == UNIT_BF16) {
+    if (variant == 2) return launch256_k32<bf16_t>(a, st);
+    if (variant == 1) return launch256<bf16_t, true, 8>(a, st);
+    return rows224 ? launch256<bf16_t, false, 7>(a, st) : launch256<bf16_t, false, 8>(a, st);
+  }
+  if (out_dtype == UNIT_F32) {
+    if (variant == 2) return launch256_k32<float>(a, st);
+    if (variant == 1) return launch256<float, true, 8>(a, st);
+    return rows224 ? launch256<float, false, 7>(a, st) : launch256<float, false, 8>(a, st);
+  }
   unit_set_error("conv_big: unsupported out dtype");
   return UNIT_ERR_UNSUPPORTED;
 }
