@@ -477,10 +477,12 @@ extern "C" int unit_conv2d_fwd_big(const void* x, const void* w, void* y, const 
   a.x_bytes = (unsigned)xb; a.w_bytes = (unsigned)wb;
   if (a.M == 0 || K == 0) return UNIT_OK;
   hipStream_t st = (hipStream_t)stream;
-  // variant 0: one barrier per k-tile, pixel-tile height (256 or 224 rows) picked for the fewest rounds x rows;
-  // 1: ping-pong wave groups; 2: four 32-k stages; 3 / 4: variant 0 with 224 / 256 rows forced
+  // variant 0 / 4: one barrier per k-tile, 256-row tiles; 3: 224-row tiles; 5: 224 or 256 rows, whichever needs fewer
+  // rounds x rows (isolated launches gain 6-7 % on the Res5 shapes: 50 176 = 224 * 224 pixels; inside the multi-stream step
+  // the other streams already fill the partial last round and the 7 % extra operand feed of the smaller tile costs 0.8 %);
+  // 1: ping-pong wave groups; 2: four 32-k stages
   bool rows224 = variant == 3;
-  if (variant == 0) {
+  if (variant == 5) {
     long n_tiles = cdiv(K, 256);
     long c256 = cdiv((long)cdiv(a.M, 256) * n_tiles, 256) * 256, c224 = cdiv((long)cdiv(a.M, 224) * n_tiles, 256) * 224;
     rows224 = c224 < c256;

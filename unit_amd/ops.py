@@ -65,7 +65,9 @@ def _mid_tile_default(dtype, m, k, c, kgemm):
 
 MID_TILE_POLICY = _mid_tile_default
 BIG_TILE_POLICY = _big_tile_default
-BIG_TILE_VARIANT = 0     # 0: one barrier per k-tile, 1: ping-pong wave groups (see csrc/conv_igemm256.hip)
+# 0: one barrier per k-tile, 256-row tiles; 1: ping-pong wave groups; 2: four 32-k stages; 3: 224-row tiles; 5: 224 or 256
+# rows per launch, whichever needs fewer rounds x rows (faster for isolated launches, see csrc/conv_igemm256.hip)
+BIG_TILE_VARIANT = int(__import__("os").environ.get("UNIT_BIG_VARIANT", "0"))
 
 # side HIP stream for the weight-gradient kernels (set by the model when stream overlap is enabled; None = inline)
 WGRAD_STREAM = None
