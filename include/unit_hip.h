@@ -189,6 +189,10 @@ int unit_mask_bce_loss(const float* logits, int K, int ldk, const int* cls, cons
 int unit_mask_probs(const float* logits, int K, int ldk, const int* cls, const float* sim, const int* base_dev, int n_base, int n_novel,
                     const int8_t* role_dev, const int* slot_dev, int S, int M, float* out, void* stream);
 int unit_gather_match_index(const int* sampled_idx, int S, const int64_t* match_idx, int Ncap, int B, int* out, void* stream);
+/* paste_masks_in_image of detector_postprocess (modeling/meta_arch/rcnn.py:423 -> d2 layers/mask_ops.py): probs [S][M][M],
+ * boxes [S][4] in output-image coordinates, valid [S] or NULL -> uint8 [S][H][W] = (bilinear sample >= threshold) */
+int unit_paste_masks(const float* probs, const float* boxes, const unsigned char* valid, int S, int M, int H, int W, float threshold,
+                     unsigned char* out, void* stream);
 
 /* ---- K18 SGD momentum (solver/build.py:110-112) ---- */
 int unit_sgd_momentum(float* p, const float* g, float* buf, long n, float lr, float momentum, float wd, float grad_scale,

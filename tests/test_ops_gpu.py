@@ -644,3 +644,20 @@ def test_weak_losses(dev):
         l = o.softmax_ce(xd, c0, k + 1, lab, weights=wts, dy=dy, dcol0=c0)
         assert abs(l.item() - ref[f"loss_oicr_{it + 1}"].item()) < 1e-5
         assert torch.allclose(dy.cpu()[:, c0:c0 + k + 1], oicr[it].grad, rtol=1e-4, atol=1e-8)
+
+
+def test_paste_masks(dev):
+    """detector_postprocess mask pasting (grid_sample bilinear, zero padding, align_corners=False, threshold 0.5) vs the
+    oracle: boxes inside, partly outside and larger than the image, degenerate thin boxes."""
+    o = ops()
+    gen = g(41)
+    H, W, M = 97, 131, 14
+    masks = torch.rand(7, M, M, generator=gen)
+    boxes = torch.tensor([[10.3, 5.2, 80.7, 60.9], [-20.0, -10.0, 50.0, 40.0], [100.0, 70.0, 160.0, 120.0], [0.0, 0.0, 131.0, 97.0],
+                          [30.0, 30.0, 31.5, 90.0], [-50.0, -50.0, 300.0, 300.0], [60.2, 40.1, 61.0, 41.0]])
+    ref = orc.paste_masks_in_image(masks, boxes, (H, W), 0.5)
+    got = o.paste_masks(masks.to(dev), boxes.to(dev), (H, W), 0.5).cpu().bool()
+    assert got.shape == ref.shape
+    mism = (got != ref)
+    assert mism.float().mean().item() < 1e-5, mism.sum()
+    assert ref.any() and not ref.all()

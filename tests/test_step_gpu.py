@@ -252,7 +252,13 @@ def test_mask_inference_parity_fp32(dev):
     assert len(out) == len(b) and len(b) > 3
     assert torch.equal(out.pred_classes.cpu(), c)
     assert set(c.tolist()) & set(cfg.DATASETS.FEWSHOT.NOVEL_CLASSES_ID), "want at least one novel-class detection (mask transfer path)"
-    assert torch.allclose(out.pred_masks.cpu()[:, 0], aux["masks"], rtol=1e-3, atol=1e-4)
+    assert torch.allclose(out.pred_mask_probs.cpu()[:, 0], aux["masks"], rtol=1e-3, atol=1e-4)
+    # detector_postprocess pastes the 14x14 masks into the 128x192 output image (threshold 0.5): bit-exact wherever the
+    # interpolated value is not within 1e-5 of the threshold
+    ref_paste = orc.paste_masks_in_image(out.pred_mask_probs.cpu()[:, 0], out.pred_boxes.tensor.cpu(), (128, 192), 0.5)
+    got = out.pred_masks.cpu()
+    assert got.shape == ref_paste.shape and got.dtype == torch.bool
+    assert (got != ref_paste).float().mean().item() < 1e-5
 
 
 def test_mask_step_parity_fp32(dev):

@@ -186,3 +186,44 @@ extern "C" int unit_gather_match_index(const int* sampled_idx, int S, const int6
   UNIT_LAUNCH_CHECK();
   return UNIT_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------
+// a16 / postprocess: paste_masks_in_image of detector_postprocess (reference call site modeling/meta_arch/rcnn.py:423;
+// Detectron2 v0.3 layers/mask_ops.py `_do_paste_mask`, GPU branch: skip_empty = False, whole image):
+//   gx = ((x + 0.5) - x0) / (x1 - x0) * 2 - 1, gy likewise; F.grid_sample(mask[None], grid, align_corners=False) (bilinear, zero
+//   padding): ix = ((gx + 1) * M - 1) / 2; out = (value >= threshold). One thread per output pixel; same operation order as ATen.
+// probs [S][M][M] fp32, boxes [S][4] (already in output-image coordinates), valid [S] (0 = skip, row left zero), out uint8 [S][H][W].
+// ---------------------------------------------------------------------------------------------------
+__global__ void paste_masks_kernel(const float* __restrict__ probs, const float* __restrict__ boxes, const unsigned char* __restrict__ valid,
+                                   int M, int H, int W, float thr, unsigned char* __restrict__ out) {
+  int s = blockIdx.z, y = blockIdx.y;
+  int x = blockIdx.x * blockDim.x + threadIdx.x;
+  if (x >= W) return;
+  size_t o = ((size_t)s * H + y) * W + x;
+  if (valid && !valid[s]) { out[o] = 0; return; }
+  float x0 = boxes[4 * s], y0 = boxes[4 * s + 1], x1 = boxes[4 * s + 2], y1 = boxes[4 * s + 3];
+  float gx = ((float)x + 0.5f - x0) / (x1 - x0) * 2.f - 1.f;
+  float gy = ((float)y + 0.5f - y0) / (y1 - y0) * 2.f - 1.f;
+  float ix = ((gx + 1.f) * (float)M - 1.f) / 2.f, iy = ((gy + 1.f) * (float)M - 1.f) / 2.f;
+  float fx = floorf(ix), fy = floorf(iy);
+  int ix_nw = (int)fx, iy_nw = (int)fy;
+  float nw = (fx + 1.f - ix) * (fy + 1.f - iy), ne = (ix - fx) * (fy + 1.f - iy);
+  float sw = (fx + 1.f - ix) * (iy - fy), se = (ix - fx) * (iy - fy);
+  const float* m = probs + (size_t)s * M * M;
+  auto at = [&](int yy, int xx) { return (yy >= 0 && yy < M && xx >= 0 && xx < M) ? m[yy * M + xx] : 0.f; };
+  float v = 0.f;
+  // ATen grid_sampler_2d accumulates the in-bounds taps in the order nw, ne, sw, se
+  if (iy_nw >= 0 && iy_nw < M && ix_nw >= 0 && ix_nw < M) v += at(iy_nw, ix_nw) * nw;
+  if (iy_nw >= 0 && iy_nw < M && ix_nw + 1 >= 0 && ix_nw + 1 < M) v += at(iy_nw, ix_nw + 1) * ne;
+  if (iy_nw + 1 >= 0 && iy_nw + 1 < M && ix_nw >= 0 && ix_nw < M) v += at(iy_nw + 1, ix_nw) * sw;
+  if (iy_nw + 1 >= 0 && iy_nw + 1 < M && ix_nw + 1 >= 0 && ix_nw + 1 < M) v += at(iy_nw + 1, ix_nw + 1) * se;
+  out[o] = v >= thr ? 1 : 0;
+}
+extern "C" int unit_paste_masks(const float* probs, const float* boxes, const unsigned char* valid, int S, int M, int H, int W,
+                                float threshold, unsigned char* out, void* stream) {
+  if (S == 0 || H == 0 || W == 0) return UNIT_OK;
+  UNIT_CHECK_ARG(S <= 65535 && H <= 65535, "paste_masks: S, H <= 65535");
+  paste_masks_kernel<<<dim3(cdiv(W, 256), H, S), 256, 0, (hipStream_t)stream>>>(probs, boxes, valid, M, H, W, threshold, out);
+  UNIT_LAUNCH_CHECK();
+  return UNIT_OK;
+}

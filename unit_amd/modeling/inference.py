@@ -109,6 +109,12 @@ def inference(model, batched_inputs, do_postprocess=True):
         inst = Instances(size, pred_boxes=Boxes(boxes[i, :c][keep]), scores=sc[i, :c][keep], pred_classes=cls[i, :c][keep].long())
         inst._roi_index = roi[i, :c][keep]
         if mask_probs is not None:
-            inst.pred_masks = mask_probs[i, :c][keep][:, None]      # (R,1,14,14) like mask_rcnn_inference; pasting is left to the caller
+            mp = mask_probs[i, :c][keep]
+            if do_postprocess:
+                # detector_postprocess (rcnn.py:423): paste the 14x14 masks into the output image, threshold 0.5 -> bool [R,H,W]
+                inst.pred_mask_probs = mp[:, None]
+                inst.pred_masks = ops.paste_masks(mp, inst.pred_boxes.tensor, size, 0.5).bool()
+            else:
+                inst.pred_masks = mp[:, None]                       # (R,1,14,14) like mask_rcnn_inference
         results.append({"instances": inst} if do_postprocess else inst)
     return results

@@ -639,6 +639,16 @@ def detector_postprocess(boxes, count, scale_xy, out_hw):
     return nonempty
 
 
+def paste_masks(probs, boxes, out_hw, threshold=0.5, valid=None):
+    """probs [S,M,M] fp32, boxes [S,4] (output-image coordinates) -> uint8 [S,H,W]  (detector_postprocess mask pasting)"""
+    s, m = probs.shape[0], probs.shape[-1]
+    h, w = int(out_hw[0]), int(out_hw[1])
+    out = torch.empty((s, h, w), dtype=torch.uint8, device=probs.device)
+    check(lib().unit_paste_masks(_p(probs.contiguous()), _p(boxes.contiguous()), _p(valid), s, m, h, w, float(threshold), _p(out), _s()),
+          "paste_masks")
+    return out
+
+
 def sum_losses(losses, out=None):
     out = out if out is not None else torch.empty(1, dtype=torch.float32, device=losses.device)
     check(lib().unit_sum_losses(_p(losses), losses.numel(), _p(out), _s()), "sum_losses")
