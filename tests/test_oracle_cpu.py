@@ -159,3 +159,23 @@ def test_library_exports_every_declared_symbol():
     for name in protos:
         assert hasattr(l, name), name
     assert _lib.lib().unit_version() >= 100
+
+
+def test_oracle_reproduces_step_golden():
+    """tests/golden/step_golden.npz (tiny end-to-end S1 step, made by tests/golden/gen_step_golden.py): the oracle still
+    produces the same losses, index decisions and gradients -- a regression pin of the checker itself."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("gen_step_golden", os.path.join(os.path.dirname(__file__), "golden", "gen_step_golden.py"))
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)
+    gold = np.load(os.path.join(os.path.dirname(__file__), "golden", "step_golden.npz"))
+    cfg = gen.tiny_cfg()
+    m, sup, weak, perms = gen.inputs(cfg)
+    assert np.array_equal(perms["rpn"][0].numpy(), gold["perm_rpn"]) and np.array_equal(perms["roi"][0].numpy(), gold["perm_roi"])
+    losses, aux, p = gen.oracle_step(m, cfg, sup, weak, perms)
+    for k, v in zip(gold["loss_names"], gold["losses"]):
+        assert abs(losses[str(k)].item() - v) <= 1e-6 * max(1.0, abs(v)), (k, losses[str(k)].item(), v)
+    assert np.array_equal(torch.stack(aux["anchor_labels"]).numpy(), gold["anchor_labels"])
+    assert np.array_equal(aux["sampled"][0]["gt_classes"].numpy(), gold["roi_classes"])
+    for k in gen.GRAD_KEYS:
+        assert abs(p[k].grad.double().norm().item() - gold["gradnorm/" + k]) <= 1e-5 * gold["gradnorm/" + k], k

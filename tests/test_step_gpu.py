@@ -347,3 +347,42 @@ def test_trainers_run_steps_bf16(dev):
     assert torch.isfinite(losses[:8]).all()
     assert torch.equal(frozen, model.backbone.res4[0].conv1.weight.detach())
     assert model.roi_heads.box_predictor.cls_score_ft.weight.abs().sum() > 0      # zero-initialised, moved by SGD
+
+
+def test_s1_step_vs_committed_golden(dev):
+    """HIP path (fp32 mode) against the committed end-to-end fixture tests/golden/step_golden.npz -- no oracle run here."""
+    import importlib.util
+    import os
+    import numpy as np
+    gdir = os.path.join(os.path.dirname(__file__), "golden")
+    spec = importlib.util.spec_from_file_location("gen_step_golden", os.path.join(gdir, "gen_step_golden.py"))
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)
+    gold = np.load(os.path.join(gdir, "step_golden.npz"))
+    cfg = gen.tiny_cfg()
+    cfg.MODEL.DEVICE = "cuda"
+    model = build_model(cfg)
+    init_synthetic_weights(model, seed=1)
+    model.train()
+    model.compute_dtype = torch.float32
+    sup, weak = synthetic_batch(1, 1, hw=(96, 128), seed=7, max_gt=3)
+    batch = model.pack_batch(sup, weak)
+    model._ensure_ready()
+    perms = {"rpn": torch.from_numpy(gold["perm_rpn"])[None].int().to(dev), "roi": torch.from_numpy(gold["perm_roi"])[None].int().to(dev)}
+    step = model.forward_train(batch, perms, early_backward=True)
+    model.backward_train(step)
+    got = dict(zip(LOSS_NAMES, step.losses.cpu().tolist()))
+    for k, v in zip(gold["loss_names"], gold["losses"]):
+        assert abs(got[str(k)] - v) <= 1e-4 * max(1.0, abs(v)), (k, got[str(k)], v)
+    assert np.array_equal(step.anchor_labels.cpu().numpy(), gold["anchor_labels"])
+    nr = len(gold["roi_classes"])
+    assert np.array_equal(step.roi_cls[:nr].cpu().numpy().astype(np.int64), gold["roi_classes"])
+    assert np.allclose(step.rois[:nr, 1:].cpu().numpy(), gold["roi_boxes"], rtol=1e-4, atol=1e-4 * 128)
+    params = dict(model.named_parameters())
+    for k in gen.GRAD_KEYS:
+        g = params[k].grad.detach().cpu()
+        assert abs(g.double().norm().item() - gold["gradnorm/" + k]) <= 2e-3 * gold["gradnorm/" + k], k
+        ref = torch.from_numpy(gold["gradhead/" + k])
+        if g.dim() == 4:      # conv weights live channels_last in memory: compare through the logical (K,C,R,S) order
+            g = g.contiguous()
+        assert (g.reshape(-1)[:64] - ref).abs().max() <= 2e-3 * float(gold["gradnorm/" + k]) + 1e-7, k
