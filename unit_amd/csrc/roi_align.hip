@@ -214,49 +214,49 @@ __global__ void roi_align_bwd_gather_kernel(const T* __restrict__ gout, int H, i
   if (rois_per_image > 0) { r_begin = n * rois_per_image; r_end = min(R, r_begin + rois_per_image); }
   // 64 RoIs are tested per iteration (one per lane, bounding box of their sample taps); only the hits are visited
   for (int rb = r_begin; rb < r_end; rb += 64) {
-   bool hit = false;
-   if (rb + lane < r_end) {
-     const RoiG& q = tab[rb + lane];
-     hit = q.b == n + image_offset && py >= q.y0 && py <= q.y1 && px >= q.x0 && px <= q.x1;
-   }
-   for (unsigned long long hm = __ballot(hit); hm; hm &= hm - 1) {
-    int r = rb + __ffsll((long long)hm) - 1;
-    RoiG t = tab[r];                                   // wave-uniform
-    // lanes 0..out-1: row weights of bin (lane*step); lanes 32..32+out-1: column weights
-    float wv = 0.f;
-    int o = lane & 31;
-    if (o < out_size) {
-      bool isx = lane >= 32;
-      int p = o * bin_step;
-      float start = isx ? t.sw : t.sh, bsz = isx ? t.bw : t.bh;
-      int gn = isx ? t.gw : t.gh; int L = isx ? W : H; int pp = isx ? px : py;
-      for (int i = 0; i < gn; ++i) {
-        float s = start + (float)p * bsz + ((float)i + 0.5f) * bsz / (float)gn;
-        wv += tap1d(s, pp, L);
-      }
+    bool hit = false;
+    if (rb + lane < r_end) {
+      const RoiG& q = tab[rb + lane];
+      hit = q.b == n + image_offset && py >= q.y0 && py <= q.y1 && px >= q.x0 && px <= q.x1;
     }
-    unsigned long long nz = __ballot(wv != 0.f);
-    unsigned ymask = (unsigned)(nz & 0xFFFFFFFFull), xmask = (unsigned)(nz >> 32);
-    if (ymask == 0u || xmask == 0u) continue;
-    if (o < out_size) { if (lane < 32) wy_s[o] = wv; else wx_s[o] = wv; }
-    __builtin_amdgcn_wave_barrier();
-    if (cvalid) {
-      const T* gr = gout + (size_t)r * out_size * out_size * C + c0;
-      for (unsigned ym = ymask; ym; ym &= ym - 1) {
-        int oy = __ffs(ym) - 1;
-        float wy = wy_s[oy] * t.inv_count;
-        for (unsigned xm = xmask; xm; xm &= xm - 1) {
-          int ox = __ffs(xm) - 1;
-          float w = wy * wx_s[ox];
-          float v[8];
-          Vec8<T>::load(gr + ((size_t)oy * out_size + ox) * C, v);
-#pragma unroll
-          for (int j = 0; j < 8; ++j) acc[j] += w * v[j];
+    for (unsigned long long hm = __ballot(hit); hm; hm &= hm - 1) {
+      int r = rb + __ffsll((long long)hm) - 1;
+      RoiG t = tab[r];                                   // wave-uniform
+      // lanes 0..out-1: row weights of bin (lane*step); lanes 32..32+out-1: column weights
+      float wv = 0.f;
+      int o = lane & 31;
+      if (o < out_size) {
+        bool isx = lane >= 32;
+        int p = o * bin_step;
+        float start = isx ? t.sw : t.sh, bsz = isx ? t.bw : t.bh;
+        int gn = isx ? t.gw : t.gh; int L = isx ? W : H; int pp = isx ? px : py;
+        for (int i = 0; i < gn; ++i) {
+          float s = start + (float)p * bsz + ((float)i + 0.5f) * bsz / (float)gn;
+          wv += tap1d(s, pp, L);
         }
       }
+      unsigned long long nz = __ballot(wv != 0.f);
+      unsigned ymask = (unsigned)(nz & 0xFFFFFFFFull), xmask = (unsigned)(nz >> 32);
+      if (ymask == 0u || xmask == 0u) continue;
+      if (o < out_size) { if (lane < 32) wy_s[o] = wv; else wx_s[o] = wv; }
+      __builtin_amdgcn_wave_barrier();
+      if (cvalid) {
+        const T* gr = gout + (size_t)r * out_size * out_size * C + c0;
+        for (unsigned ym = ymask; ym; ym &= ym - 1) {
+          int oy = __ffs(ym) - 1;
+          float wy = wy_s[oy] * t.inv_count;
+          for (unsigned xm = xmask; xm; xm &= xm - 1) {
+            int ox = __ffs(xm) - 1;
+            float w = wy * wx_s[ox];
+            float v[8];
+            Vec8<T>::load(gr + ((size_t)oy * out_size + ox) * C, v);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] += w * v[j];
+          }
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
     }
-    __builtin_amdgcn_wave_barrier();
-   }
   }
   if (!cvalid) return;
   size_t o = (size_t)pix * C + c0;
