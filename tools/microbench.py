@@ -1,7 +1,6 @@
 """Per-kernel microbenchmarks on the hot-path shapes. Run on the GPU box:
    python tools/microbench.py [conv|roi|all]"""
 import sys
-import time
 
 import torch
 

@@ -5,8 +5,6 @@
   * TrainerFineTune.run_step /root/reference/engine/defaults.py:442-463 : supervised batch only.
 Differences by design: no per-step `comm.synchronize()` barrier (defaults.py:285), no per-step metric
 gather; losses stay on the device and are fetched only when the caller asks (`fetch_every`)."""
-import torch
-import torch.distributed as dist
 
 from .modeling.rcnn import LOSS_NAMES
 from .parallel import GradBuckets

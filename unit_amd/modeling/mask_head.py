@@ -4,7 +4,6 @@ MaskRCNNConvUpsampleHead with the C4 defaults NUM_CONV 0, CONV_DIM 256, NORM "" 
 State-dict keys: `deconv.{weight,bias}`, `predictor.{weight,bias}`.
 Input = un-pooled Res5 features of the foreground RoIs [S,7,7,2048] (ROI_MASK_HEAD.POOLER_TYPE "None",
 roi_heads.py:691-710).  The transposed conv runs as one 1x1 GEMM with 4*256 columns (csrc/mask.hip)."""
-import ctypes
 
 import torch
 from torch import nn

@@ -2,7 +2,6 @@
 (thresholds, labels, allow_low_quality_matches), `__call__(match_quality_matrix) -> (matches int64, match_labels int8,
 matched_vals float32)`. Executed by the HIP kernel `unit_match_matrix`; the fused boxes->labels path the training step
 uses is `unit_iou_match` (same decisions, one pass)."""
-import torch
 
 from .. import ops
 

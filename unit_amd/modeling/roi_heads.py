@@ -4,8 +4,6 @@ WSROIHeadFineTune (:594-644), plus the Detectron2 `label_and_sample_proposals` t
 Module / parameter names equal the reference's: `box_head`, `weak_box_head` (iff MULTI_BOX_HEAD), `box_predictor`.
 The whole RoI stage is sync-free: proposal / RoI counts stay in device int32 arrays, RoIs live in fixed 512-per-image
 slots (empty slots carry class -1 and contribute neither loss nor gradient)."""
-import numpy as np
-import torch
 from torch import nn
 
 from .. import ops

@@ -9,7 +9,6 @@ all-reduce of that slice is launched asynchronously (RCCL's stream, ordered afte
 ProcessGroup) and overlaps the remaining backward. xGMI is point-to-point (7 links/GPU): buckets are large (default
 64 MB) so each collective is bandwidth- not latency-bound; the 1/world scaling is folded into the SGD kernel.
 No per-step barrier, no per-step metric gather."""
-import torch
 import torch.distributed as dist
 
 
