@@ -661,3 +661,27 @@ def test_paste_masks(dev):
     mism = (got != ref)
     assert mism.float().mean().item() < 1e-5, mism.sum()
     assert ref.any() and not ref.all()
+
+
+@pytest.mark.parametrize("case", [(70, 64, 512), (1, 128, 256), (37, 192, 300), (11, 512, 512)])
+def test_conv_halo7_kernel(dev, case):
+    """3x3 / s1 / p1 convolution on 7x7 maps with the input super-tile shared by the nine taps (tile_cfg 14 = variant 6 of the
+    256x256 kernel): map borders, RoI borders inside a tile, ragged last tile, several channel blocks, K tail; fused
+    bias + residual + ReLU + mask epilogue; against F.conv2d and the generic kernel."""
+    o = ops()
+    n, c, k = case
+    gen = g(51)
+    x = torch.randn(n, c, 7, 7, generator=gen).bfloat16().float()
+    wt = (torch.randn(k, c, 3, 3, generator=gen) / np.sqrt(c * 9)).bfloat16().float()
+    bias = torch.randn(k, generator=gen)
+    ref = F.conv2d(x, wt, bias, stride=1, padding=1)
+    xd, wd = nhwc(x).to(dev).bfloat16(), krsc(wt).to(dev).bfloat16()
+    ldy = (k + 7) // 8 * 8
+    y = o.conv2d(xd, wd, k, 3, 3, 1, 1, bias=bias.to(dev), ldy=ldy, tile_cfg=14)
+    got = nchw(y.float().cpu()[..., :k])
+    assert torch.allclose(got, ref, rtol=2e-2, atol=8e-2), (got - ref).abs().max()
+    res = torch.randn(n, 7, 7, ldy, generator=gen).bfloat16()
+    msk = torch.randn(n, 7, 7, ldy, generator=gen).bfloat16()
+    y2 = o.conv2d(xd, wd, k, 3, 3, 1, 1, bias=bias.to(dev), residual=res.to(dev), mask_ref=msk.to(dev), relu=True, ldy=ldy, tile_cfg=14)
+    y1 = o.conv2d(xd, wd, k, 3, 3, 1, 1, bias=bias.to(dev), residual=res.to(dev), mask_ref=msk.to(dev), relu=True, ldy=ldy, tile_cfg=13)
+    assert torch.allclose(y2.float().cpu()[..., :k], y1.float().cpu()[..., :k], rtol=2e-2, atol=2e-2)

@@ -262,6 +262,161 @@ __global__ void __launch_bounds__(512, 2) conv_igemm256_kernel(Conv256Args p) {
 }
 
 // ---------------------------------------------------------------------------------------------------
+// variant 6: 3x3 / stride 1 / pad 1 convolution on 7x7 maps (conv2 of the Res5 blocks and its dgrad: 47 % of the Res5 FLOPs)
+// with the INPUT tile shared by the nine taps. Output pixels of a tile are rows m0 .. m0+255 of the flattened [RoI][7][7]
+// pixel list; tap (r,s) of output row m reads input row m + (r-1)*7 + (s-1) when that neighbour is inside the 7x7 map and
+// zero otherwise. So one 272-row input "super-tile" (rows m0-8 .. m0+263, 34 KB) per 64-channel block serves all nine
+// k-tiles of that block: the per-k-tile operand feed drops from 64 KB (pixels + weights) to 32 KB of weights + 1/9 of
+// 34 KB, and the fragment reads of a tap address the super-tile through a per-lane row map (out-of-map neighbours point
+// at an all-zero LDS row). LDS: 2 x 273 x 128 B input (double-buffered across channel blocks) + 2 x 32 KB weight stages.
+// bf16 output, ldy % 8 == 0.
+// ---------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(512, 2) conv_igemm256_halo7_kernel(Conv256Args p) {
+  constexpr int BM = 256, BN = 256, BK = 64;
+  constexpr int XROWS = 272, XZERO = 272;         // super-tile rows; index of the all-zero row
+  constexpr int XBUF = (XROWS + 1) * 128;          // 34 944 B
+  constexpr int WBUF = BN * 128;                   // 32 KB
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* xs = smem;                                 // 2 x XBUF
+  char* ws = smem + 2 * XBUF;                      // 2 x WBUF
+
+  int nwg = p.tiles_m * p.tiles_n;
+  int bid = blockIdx.x;
+  {
+    int q = nwg / 8, r = nwg % 8, xcd = bid % 8, loc = bid / 8;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+  }
+  int tile_n = bid % p.tiles_n, tile_m = bid / p.tiles_n;
+  int m0 = tile_m * BM, n0 = tile_n * BN;
+
+  const bf16_t* __restrict__ X = (const bf16_t*)p.x;
+  const bf16_t* __restrict__ Wt = (const bf16_t*)p.w;
+  __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(X), 0, (int)p.x_bytes, 0x00020000);
+  __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(Wt), 0, (int)p.w_bytes, 0x00020000);
+  constexpr unsigned OOB = 0xFFFFFFF0u;
+
+  int tid = threadIdx.x, lane = tid & 63;
+  int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int wm = wid >> 2, wn = wid & 3;
+  int lrow = lane >> 3, lc = lane & 7;
+
+  // zero row of both input buffers (never written by the DMA)
+  if (tid < 16) {
+    *reinterpret_cast<i32x4*>(xs + XZERO * 128 + (tid & 7) * 16 + (tid >> 3) * XBUF) = i32x4{0, 0, 0, 0};
+  }
+
+  // weight staging (as in the generic kernel): wave `wid`, instruction i covers channel rows (i*8 + wid)*8 .. +8
+  unsigned w_off[4]; bool w_ok[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    int row = (i * 8 + wid) * 8 + lrow;
+    int q = lc ^ ((row >> 1) & 7);
+    int nn = n0 + row;
+    w_ok[i] = nn < p.K;
+    w_off[i] = ((unsigned)(w_ok[i] ? nn : 0) * (unsigned)p.Kgemm + (unsigned)q * 8u) * 2u;
+  }
+  // input super-tile staging: 34 pieces of 8 rows; wave `wid` takes pieces i*8 + wid (i = 0..4, piece < 34)
+  unsigned xs_off[5]; bool xs_ok[5];
+#pragma unroll
+  for (int i = 0; i < 5; ++i) {
+    int row = (i * 8 + wid) * 8 + lrow;            // super-tile row
+    long g = (long)m0 - 8 + row;                   // flattened input pixel
+    xs_ok[i] = row < XROWS && g >= 0 && g < (long)p.M;
+    int q = lc ^ ((row >> 1) & 7);
+    xs_off[i] = (unsigned)((xs_ok[i] ? g : 0) * p.C + q * 8) * 2u;
+  }
+  auto stage_x = [&](int cb, int buf) {
+    char* base = xs + buf * XBUF;
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+      int R0 = (i * 8 + wid) * 8;
+      if (R0 >= XROWS) continue;                   // wave-uniform
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, (lds_void*)(base + R0 * 128), 16, xs_ok[i] ? xs_off[i] + (unsigned)cb * 128u : OOB, 0, 0, 0);
+    }
+  };
+  auto stage_w = [&](int kt, int buf) {            // k-tile kt = (channel block cb, tap): weights k index = tap*C + cb*64
+    int cb = kt / 9, tap = kt - cb * 9;
+    int k0 = tap * p.C + cb * BK;
+    char* base = ws + buf * WBUF;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      int R0 = (i * 8 + wid) * 8;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (lds_void*)(base + R0 * 128), 16, w_ok[i] ? w_off[i] + (unsigned)k0 * 2u : OOB, 0, 0, 0);
+    }
+  };
+
+  // per-lane map of the 8 fragment rows of this wave: position inside the 7x7 map (packed oh*8 + ow)
+  int frow = lane & 15, fq = lane >> 4;
+  int pos[8];
+#pragma unroll
+  for (int b = 0; b < 8; ++b) {
+    int m = m0 + wm * 128 + b * 16 + frow;
+    int px = m % 49;
+    pos[b] = ((px / 7) << 3) | (px % 7);
+  }
+
+  f32x4 acc[4][8];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 8; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  int ncb = p.C / BK, nk = 9 * ncb;
+  stage_x(0, 0);
+  stage_w(0, 0);
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    int cb = kt / 9, tap = kt - cb * 9;
+    if (kt + 1 < nk) stage_w(kt + 1, (kt + 1) & 1);
+    if (tap == 0 && cb + 1 < ncb) stage_x(cb + 1, (cb + 1) & 1);
+    const char* bx = xs + (cb & 1) * XBUF;
+    const char* bw = ws + (kt & 1) * WBUF;
+    int dr = tap / 3 - 1, dc = tap - (tap / 3) * 3 - 1;
+    int delta = 8 + dr * 7 + dc;
+    // byte offset of this lane's 8 pixel rows inside the super-tile for this tap (swizzle term added per k-substep)
+    int rowoff[8], rowsw[8];
+#pragma unroll
+    for (int b = 0; b < 8; ++b) {
+      int oh = (pos[b] >> 3) + dr, ow = (pos[b] & 7) + dc;
+      bool ok = (unsigned)oh < 7u && (unsigned)ow < 7u;
+      int row = ok ? wm * 128 + b * 16 + frow + delta : XZERO;
+      rowoff[b] = row * 128; rowsw[b] = (row >> 1) & 7;
+    }
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      i32x4 fa[4], fb[8];
+#pragma unroll
+      for (int a = 0; a < 4; ++a) fa[a] = *reinterpret_cast<const i32x4*>(bw + swz256(wn * 64 + a * 16 + frow, ks * 4 + fq));
+#pragma unroll
+      for (int b = 0; b < 8; ++b) fb[b] = *reinterpret_cast<const i32x4*>(bx + rowoff[b] + (((ks * 4 + fq) ^ rowsw[b]) << 4));
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 8; ++b)
+          acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fa[a]), __builtin_bit_cast(bf16x8, fb[b]), acc[a][b], 0, 0, 0);
+      __builtin_amdgcn_s_setprio(0);
+    }
+    __syncthreads();   // vmcnt(0) + barrier: next weight stage (and, after tap 0, the next input super-tile) landed; reads of this stage done
+  }
+  __syncthreads();
+  epilogue_rows_bf16<4, 8>(acc, smem + wid * EpiCfg<4>::BYTES, m0 + wm * 128, n0 + wn * 64, p, lane);
+}
+
+static int launch256_halo7(Conv256Args& a, hipStream_t st) {
+  a.tiles_m = cdiv(a.M, 256); a.tiles_n = cdiv(a.K, 256);
+  size_t lds = 2 * (272 + 1) * 128 + 2 * 256 * 128;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)conv_igemm256_halo7_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  conv_igemm256_halo7_kernel<<<a.tiles_m * a.tiles_n, 512, lds, st>>>(a);
+  UNIT_LAUNCH_CHECK();
+  return UNIT_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
 // variant 2: the same 256x256 tile with FOUR 32 KB stages of 32 k each instead of two 64 KB stages of 64 k.
 // The two-stage loop drains the LDS-DMA queue at every barrier (all of a k-tile's 64 KB is issued in one burst, waited
 // for in full, and only then is the next burst issued): measured operand feed 14 TB/s chip-wide, co-limiting with the
@@ -481,6 +636,15 @@ extern "C" int unit_conv2d_fwd_big(const void* x, const void* w, void* y, const 
   // rounds x rows (isolated launches gain 6-7 % on the Res5 shapes: 50 176 = 224 * 224 pixels; inside the multi-stream step
   // the other streams already fill the partial last round and the 7 % extra operand feed of the smaller tile costs 0.8 %);
   // 1: ping-pong wave groups; 2: four 32-k stages
+  // 6 (and 0 when the shape allows it): 3x3 s1 p1 on 7x7 maps with the input super-tile shared by the nine taps
+  {
+    static int no_halo = -1;
+    if (no_halo < 0) { const char* e = getenv("UNIT_NO_HALO"); no_halo = e ? atoi(e) : 0; }
+    bool halo_ok = out_dtype == UNIT_BF16 && (ldy & 7) == 0 && R == 3 && S == 3 && stride == 1 && pad == 1 && H == 7 && W == 7 &&
+                   OH == 7 && OW == 7;
+    if (variant == 6 && !halo_ok) { unit_set_error("conv_big: variant 6 needs a bf16-out 3x3 s1 p1 conv on 7x7 maps"); return UNIT_ERR_UNSUPPORTED; }
+    if (halo_ok && (variant == 6 || (variant == 0 && !no_halo))) return launch256_halo7(a, st);
+  }
   bool rows224 = variant == 3;
   if (variant == 5) {
     long n_tiles = cdiv(K, 256);
