@@ -18,11 +18,22 @@ write = collect(sys.argv[2], "WRITE_SIZE")
 out = {"_note": "bytes past the L2 (HBM + Infinity Cache) per launch, rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over "
                 "`bench.py --steps 2 --warmup 1 --no-overlap --no-roofline --no-cpu-baseline`; FETCH_SIZE doubled (gfx950 wide-read "
                 "correction, MI355X_MICROARCH.md); KB = 1024 B"}
+groups = collections.defaultdict(lambda: [[], []])
 for k in sorted(set(fetch) | set(write)):
     if not any(t in k for t in ("conv_igemm", "conv_wgrad", "multi_", "roi_align", "sgd")):
         continue
-    name = "conv_igemm256_kernel" if "igemm256" in k else ("conv_igemm_dma_kernel" if "igemm_dma" in k and "ksplit" not in k else k.split("_Z")[-1])
-    f = fetch.get(k, []); w = write.get(k, [])
+    # all launch variants of one kernel family (template instances, the halo7 variant) are one roofline line
+    if "igemm256" in k:
+        name = "conv_igemm256_kernel"
+    elif "igemm_dma" in k and "ksplit" not in k:
+        name = "conv_igemm_dma_kernel"
+    elif "wgrad256" in k:
+        name = "conv_wgrad256_kernel"
+    else:
+        name = k.split("_Z")[-1]
+    groups[name][0] += fetch.get(k, [])
+    groups[name][1] += write.get(k, [])
+for name, (f, w) in groups.items():
     fb = 2.0 * 1024 * sum(f) / max(1, len(f)); wb = 1024.0 * sum(w) / max(1, len(w))
     out[name] = {"launches": max(len(f), len(w)), "fetch_bytes_per_launch": round(fb), "write_bytes_per_launch": round(wb),
                  "hbm_bytes_per_launch": round(fb + wb)}
