@@ -386,3 +386,34 @@ def test_s1_step_vs_committed_golden(dev):
         if g.dim() == 4:      # conv weights live channels_last in memory: compare through the logical (K,C,R,S) order
             g = g.contiguous()
         assert (g.reshape(-1)[:64] - ref).abs().max() <= 2e-3 * float(gold["gradnorm/" + k]) + 1e-7, k
+
+
+def test_s1_step_mixed_image_sizes_fp32(dev):
+    """Ragged batch: four images of four different sizes (zero-padded to the largest, ImageList.from_tensors semantics);
+    proposals are clipped to each image's own size, anchors live on the padded grid. Losses and index decisions vs oracle."""
+    cfg = small_cfg()
+    model = build_model(cfg)
+    init_synthetic_weights(model, seed=1)
+    model.train()
+    model.compute_dtype = torch.float32
+    sizes = [(128, 192), (112, 160), (96, 176), (128, 144)]
+    sup, weak = [], []
+    for i, hw in enumerate(sizes):
+        s, w = synthetic_batch(1, 1, hw=hw, seed=20 + i, max_gt=3)
+        (sup if i < 2 else weak).append(s[0] if i < 2 else w[0])
+    batch = model.pack_batch(sup, weak)
+    model._ensure_ready()
+    perms = model.sampling_permutations(2, 8 * 12 * 15, cfg.MODEL.RPN.POST_NMS_TOPK_TRAIN + batch.gt_boxes.shape[1])
+    step = model.forward_train(batch, perms, early_backward=True)
+    model.backward_train(step)
+    got = dict(zip(LOSS_NAMES, step.losses.cpu().tolist()))
+    ref, p, aux = oracle_step(model, cfg, sup, weak, perms)
+    assert torch.equal(step.anchor_labels.cpu(), torch.stack(aux["anchor_labels"]))
+    for i in range(2):
+        m = len(aux["sampled"][i]["boxes"])
+        assert torch.equal(step.roi_cls[i * 32:i * 32 + m].cpu().long(), aux["sampled"][i]["gt_classes"])
+    for k in LOSS_NAMES[:8]:
+        assert abs(got[k] - ref[k].item()) <= 1e-4 * max(1.0, abs(ref[k].item())), (k, got[k], ref[k].item())
+    name = "backbone.res4.0.conv1.weight"
+    g, gr = dict(model.named_parameters())[name].grad.cpu(), p[name].grad
+    assert (g - gr).abs().max() <= 2e-3 * gr.abs().max() + 1e-7
