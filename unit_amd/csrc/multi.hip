@@ -30,9 +30,11 @@ __global__ void multi_reduce_kernel(const UnitTensorDesc* __restrict__ descs, in
   long KK = (long)d.K * d.R * d.S * d.C;
   long i = (long)(blockIdx.x - d.block0) * MT_ELEMS_PER_BLOCK + threadIdx.x * 4;
   if (i >= KK || d.partial == nullptr) return;
+  int nsp = d.splits < 0 ? -d.splits : d.splits;      // splits < 0: second contribution to the same gradient -> accumulate
   f32x4 s = *reinterpret_cast<const f32x4*>(d.partial + i);
-  for (int sp = 1; sp < d.splits; ++sp) s += *reinterpret_cast<const f32x4*>(d.partial + (size_t)sp * KK + i);
+  for (int sp = 1; sp < nsp; ++sp) s += *reinterpret_cast<const f32x4*>(d.partial + (size_t)sp * KK + i);
   if (d.scale) s *= d.scale[i / ((long)d.R * d.S * d.C)];
+  if (d.splits < 0) s += *reinterpret_cast<const f32x4*>(grads + d.offset + i);
   *reinterpret_cast<f32x4*>(grads + d.offset + i) = s;
 }
 

@@ -102,13 +102,22 @@ class Conv2d(_EpochOnLoad):
         if not self.weight.requires_grad:
             return
         st = self.stride if stride is None else stride
+        acc = ops.WGRAD_ACCUMULATE      # second contribution to the same gradients (ragged batches: backbone backward runs twice)
         if getattr(self, "_plan", None) is not None:
             # multi-tensor plan (unit_amd/multi.py): leave the split-M slabs in this layer's resident buffer; one
             # unit_multi_wgrad_reduce launch per bucket folds them into the flat gradient buffer later
             side = ops.WGRAD_STREAM
+            which = "_slab2" if acc else "_slab"
+
+            def launch():
+                slab, splits = ops.conv2d_wgrad_partial(x, dy, self.cout, self.k, self.k, st, self.pad, getattr(self, which, None))
+                setattr(self, which, slab)
+                if not acc:
+                    self._splits = splits
+                self._plan.note_wgrad(self, slab, splits, accumulate=acc)
+
             if side is None:
-                self._slab, self._splits = ops.conv2d_wgrad_partial(x, dy, self.cout, self.k, self.k, st, self.pad, self._slab)
-                self._plan.note_wgrad(self)
+                launch()
                 return
             # weight gradients depend on nothing downstream: run them on a side HIP stream so that they fill the CUs the
             # dgrad chain leaves idle (tile-quantisation tails, the small res3/res4 grids); joined before the bucket's reduce
@@ -119,8 +128,7 @@ class Conv2d(_EpochOnLoad):
             x.record_stream(side)
             dy.record_stream(side)
             with torch.cuda.stream(side):
-                self._slab, self._splits = ops.conv2d_wgrad_partial(x, dy, self.cout, self.k, self.k, st, self.pad, self._slab)
-                self._plan.note_wgrad(self)
+                launch()
             return
         g = self.weight.grad
         if g is None:
@@ -129,11 +137,11 @@ class Conv2d(_EpochOnLoad):
         gk = g.permute(0, 2, 3, 1)
         if not gk.is_contiguous():
             raise RuntimeError("conv weight .grad must be a channels_last ([K][R][S][C]) tensor")
-        ops.conv2d_wgrad(x, dy, self.cout, self.k, self.k, st, self.pad, scale=self.scale, out=gk)
+        ops.conv2d_wgrad(x, dy, self.cout, self.k, self.k, st, self.pad, scale=self.scale, out=gk, accumulate=acc)
         if self.bias is not None and self.bias.requires_grad:
             if self.bias.grad is None:
                 self.bias.grad = torch.zeros_like(self.bias.data)
-            ops.bias_grad(dy.reshape(-1, dy.shape[-1]), self.cout, out=self.bias.grad)
+            ops.bias_grad(dy.reshape(-1, dy.shape[-1]), self.cout, out=self.bias.grad, accumulate=acc)
 
 
 class BottleneckBlock(nn.Module):

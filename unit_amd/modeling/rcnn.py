@@ -251,11 +251,28 @@ class WeaklySupervisedRCNNNoMeta(nn.Module):
         c.n_sup, c.n_weak = n_sup, n_weak
         c.losses = torch.zeros(len(LOSS_NAMES), dtype=torch.float32, device=self.device)
 
-        # a1 preprocess + a2 backbone (supervised + weak images as one batch; both with grad: rcnn.py:439,452)
-        x, sizes = ops.preprocess_images(batch.images, self._pixel_mean, self._pixel_std, dt, 8, self.normalize_images)
+        # a1 preprocess + a2 backbone. The reference runs the backbone once per batch (rcnn.py:439 supervised, :452 weak), each
+        # batch zero-padded to ITS OWN largest image (ImageList.from_tensors). When both batches pad to the same size (always
+        # the case for equally sized images, e.g. the benchmark) the two passes are arithmetically one batch of
+        # n_sup + n_weak images and run as such; otherwise (`split`) they stay two passes, because a feature near the border
+        # of the smaller padded tensor depends on where the zero padding of every conv layer starts.
+        raw = [(int(im.shape[-2]), int(im.shape[-1])) for im in batch.images]
+        pad_of = lambda ss: (max(s[0] for s in ss), max(s[1] for s in ss))
+        split = n_sup > 0 and n_weak > 0 and pad_of(raw[:n_sup]) != pad_of(raw[n_sup:])
+        c.split = split
+        feat_w = head_w = anchors_w = None
+        if not split:
+            x, sizes = ops.preprocess_images(batch.images, self._pixel_mean, self._pixel_std, dt, 8, self.normalize_images)
+            feat, c.bb_ctx = self.backbone.fwd(x, save=True)
+        else:
+            xa, sa = ops.preprocess_images(batch.images[:n_sup], self._pixel_mean, self._pixel_std, dt, 8, self.normalize_images)
+            xb, sb = ops.preprocess_images(batch.images[n_sup:], self._pixel_mean, self._pixel_std, dt, 8, self.normalize_images)
+            sizes = sa + sb
+            feat, c.bb_ctx = self.backbone.fwd(xa, save=True)          # `feat` = supervised images only
+            feat_w, c.bb_ctx_w = self.backbone.fwd(xb, save=True)
+            anchors_w = rpn.anchor_generator.grid(feat_w.shape[1], feat_w.shape[2])
         c.image_sizes = sizes
-        feat, c.bb_ctx = self.backbone.fwd(x, save=True)
-        c.feat = feat
+        c.feat, c.feat_w = feat, feat_w
         n, fh, fw, fc = feat.shape
         anchors = rpn.anchor_generator.grid(fh, fw)
 
@@ -279,6 +296,8 @@ class WeaklySupervisedRCNNNoMeta(nn.Module):
             else:
                 perms = self.sampling_permutations(n_sup, anchors.shape[0], n_roi_cap)
         head, c.rpn_ctx = rpn.rpn_head.fwd(feat, save=True)
+        if split:
+            head_w, _ = rpn.rpn_head.fwd(feat_w, save=False)          # weak images: proposals only (no RPN loss)
         c.dhead = None
         c.drpn = None
         c.rpn_bwd_early = False
@@ -303,7 +322,12 @@ class WeaklySupervisedRCNNNoMeta(nn.Module):
             c.rpn_losses = c.losses[6:8]
             rpn_branch()
         hw = torch.tensor(sizes, dtype=torch.float32).to(self.device, non_blocking=True)
-        props, pscores, pcount = rpn.predict_proposals(head, anchors, hw, True)
+        if not split:
+            props, pscores, pcount = rpn.predict_proposals(head, anchors, hw, True)
+        else:
+            pa = rpn.predict_proposals(head, anchors, hw[:n_sup].contiguous(), True)
+            pb = rpn.predict_proposals(head_w, anchors_w, hw[n_sup:].contiguous(), True)
+            props, pscores, pcount = (torch.cat([a, b], 0) for a, b in zip(pa, pb))
         c.proposals = (props, pscores, pcount)
         if perm_ready is not None:
             torch.cuda.current_stream().wait_event(perm_ready)
@@ -322,7 +346,15 @@ class WeaklySupervisedRCNNNoMeta(nn.Module):
         rs = n_sup * s
         rw = c.rois.shape[0] - rs
         c.rs, c.rw = rs, rw
-        pooled = rh.pool(feat, c.rois)
+        if not split:
+            pooled = rh.pool(feat, c.rois)
+        else:   # two feature tensors, one pooled buffer: supervised RoIs from `feat`, weak RoIs (batch index rebased) from `feat_w`
+            osz = rh.pool_out[0]
+            pooled = torch.empty((rs + rw, osz, osz, fc), dtype=feat.dtype, device=feat.device)
+            rh.pool(feat, c.rois[:rs], out=pooled[:rs])
+            rois_w = c.rois[rs:].clone()
+            rois_w[:, 0] -= n_sup
+            rh.pool(feat_w, rois_w, out=pooled[rs:])
 
         # a9 Res5 heads: box_head on the supervised RoIs (grad); weak_box_head on ALL RoIs in one pass -- its supervised
         # half is the reference's no_grad evaluation (roi_heads.py:502-504), its weak half has grad (:512-513)
@@ -494,18 +526,44 @@ class WeaklySupervisedRCNNNoMeta(nn.Module):
         if bb_trainable:
             # d(loss)/d(res4 output) = RoIAlign backward (gather form, deterministic) + RPN branch, times the ReLU mask --
             # one fused kernel per image group (supervised RoIs only touch supervised images, weak RoIs weak images)
-            g = torch.empty_like(feat)
-            n_img, fh, fw, _ = feat.shape
-            for (dp, lo, hi, r_lo, r_hi, add) in ((dpool_sup, 0, n_sup, 0, rs, drpn), (dpool_weak, n_sup, n_img, rs, rs + rw, None)):
-                if hi <= lo:
-                    continue
+            def grad_map(ft, dp, n_im, r_lo, r_hi, img0, add):
+                out = torch.empty_like(ft)
                 if dp is not None:
-                    rh.pool_bwd_gather(dp, hi - lo, fh, fw, c.rois[r_lo:r_hi], g[lo:hi], image_offset=lo, addend=add,
-                                       mask_ref=feat[lo:hi])
+                    rh.pool_bwd_gather(dp, n_im, ft.shape[1], ft.shape[2], c.rois[r_lo:r_hi], out, image_offset=img0, addend=add, mask_ref=ft)
                 else:
-                    z = torch.zeros(feat[lo:hi].shape, dtype=torch.float32, device=feat.device)
-                    ops.add_cast(z, add, dt, mask_ref=feat[lo:hi], out=g[lo:hi])
-            self.backbone.bwd(c.bb_ctx, g, on_stage_done=done)
+                    ops.add_cast(torch.zeros(ft.shape, dtype=torch.float32, device=ft.device), add, dt, mask_ref=ft, out=out)
+                return out
+
+            if not getattr(c, "split", False):
+                g = torch.empty_like(feat)
+                n_img, fh, fw, _ = feat.shape
+                for (dp, lo, hi, r_lo, r_hi, add) in ((dpool_sup, 0, n_sup, 0, rs, drpn), (dpool_weak, n_sup, n_img, rs, rs + rw, None)):
+                    if hi <= lo:
+                        continue
+                    if dp is not None:
+                        rh.pool_bwd_gather(dp, hi - lo, fh, fw, c.rois[r_lo:r_hi], g[lo:hi], image_offset=lo, addend=add,
+                                           mask_ref=feat[lo:hi])
+                    else:
+                        z = torch.zeros(feat[lo:hi].shape, dtype=torch.float32, device=feat.device)
+                        ops.add_cast(z, add, dt, mask_ref=feat[lo:hi], out=g[lo:hi])
+                self.backbone.bwd(c.bb_ctx, g, on_stage_done=done)
+            else:
+                # ragged batches (forward ran the backbone twice): two backward passes; the weight gradients of the second
+                # accumulate onto the first (whose slabs are reduced before the second pass may touch the same gradients)
+                g_sup = grad_map(feat, dpool_sup, n_sup, 0, rs, 0, drpn)
+                self.backbone.bwd(c.bb_ctx, g_sup, on_stage_done=None)
+                if plan is not None:
+                    if side is not None:
+                        with torch.cuda.stream(side):
+                            plan.reduce()
+                    else:
+                        plan.reduce()
+                g_weak = grad_map(c.feat_w, dpool_weak, c.n_weak, rs, rs + rw, n_sup, None)
+                ops.WGRAD_ACCUMULATE = True
+                try:
+                    self.backbone.bwd(c.bb_ctx_w, g_weak, on_stage_done=done)
+                finally:
+                    ops.WGRAD_ACCUMULATE = False
         if side is not None:
             torch.cuda.current_stream().wait_stream(side)
         ops.WGRAD_STREAM = None

@@ -92,9 +92,9 @@ class WSROIHeadNoMeta(nn.Module):
     def weak_rois(self, props, pcount, batch_index_offset):
         return ops.first_k_rois(props, pcount, self.batch_size_per_image // self.weak_divisor, batch_index_offset)
 
-    def pool(self, feat, rois5):
-        out, step = self.pool_out
-        return ops.roi_align(feat, rois5, self.pooler_resolution, out, step, self.pooler_scale, self.sampling_ratio, True)
+    def pool(self, feat, rois5, out=None):
+        osz, step = self.pool_out
+        return ops.roi_align(feat, rois5, self.pooler_resolution, osz, step, self.pooler_scale, self.sampling_ratio, True, out=out)
 
     def pool_bwd(self, dpooled, feat_shape, rois5, dfeat32):
         _, step = self.pool_out

@@ -51,18 +51,20 @@ class ConvPlan:
         self._pending = {}
         self.flush_bytes = 96 << 20
 
-    def _build(self, convs, with_partial):
+    def _build(self, convs, with_partial, entries=None):
+        """entries (reduce tables): [(conv, slab tensor, signed splits)]; splits < 0 = accumulate onto the gradient"""
         descs = (TensorDesc * len(convs))()
         b0 = 0
         for i, m in enumerate(convs):
             kk = m.cout * m.k * m.k * m.cin
             d = descs[i]
-            d.partial = m._slab.data_ptr() if (with_partial and m._slab is not None) else None
+            slab, splits = (entries[i][1], entries[i][2]) if entries is not None else (m._slab, m._splits)
+            d.partial = slab.data_ptr() if (with_partial and slab is not None) else None
             d.scale = m.scale.data_ptr() if m.scale is not None else None
             d.wf = m.wf.data_ptr() if m.wf is not None else None
             d.wd = m.wd.data_ptr() if m.wd is not None else None
             d.offset = m._flat_offset
-            d.splits, d.K, d.R, d.S, d.C, d.block0 = m._splits, m.cout, m.k, m.k, m.cin, b0
+            d.splits, d.K, d.R, d.S, d.C, d.block0 = splits, m.cout, m.k, m.k, m.cin, b0
             if with_partial:
                 b0 += (kk + ELEMS_PER_BLOCK - 1) // ELEMS_PER_BLOCK
             else:   # weight prep: one workgroup per 32 (k) x 32 (c) tile of each (r, s) tap (csrc/multi.hip)
@@ -70,12 +72,16 @@ class ConvPlan:
         host = torch.frombuffer(bytearray(bytes(descs)), dtype=torch.uint8)
         return host.to(self.model.device), len(convs), b0
 
-    def note_wgrad(self, conv):
-        """called right after a conv's split-M slabs were enqueued on the current stream"""
+    def note_wgrad(self, conv, slab=None, splits=None, accumulate=False):
+        """called right after a conv's split-M slabs were enqueued on the current stream. accumulate: the slabs hold a SECOND
+        contribution to the same gradient (ragged supervised / weak batches run the backbone twice, rcnn.py): the caller has
+        flushed the first one (`reduce()`), this one is added on top."""
         key = torch.cuda.current_stream().cuda_stream if self.model.device.type == "cuda" else 0
         lst = self._pending.setdefault(key, [0, []])
-        lst[1].append(conv)
-        lst[0] += conv._splits * conv.cout * conv.k * conv.k * conv.cin * 4
+        slab = conv._slab if slab is None else slab
+        splits = conv._splits if splits is None else splits
+        lst[1].append((conv, slab, -splits if accumulate else splits))
+        lst[0] += splits * conv.cout * conv.k * conv.k * conv.cin * 4
         if lst[0] >= self.flush_bytes:
             self._flush(key)
 
@@ -83,12 +89,12 @@ class ConvPlan:
         lst = self._pending.get(key)
         if not lst or not lst[1]:
             return
-        convs = lst[1]
+        entries = lst[1]
         self._pending[key] = [0, []]
-        sig = tuple((id(m), m._slab.data_ptr(), m._splits) for m in convs)
+        sig = tuple((id(m), slab.data_ptr(), sp) for m, slab, sp in entries)
         tab = self._tables.get(sig)
         if tab is None:
-            tab = self._build(convs, True)
+            tab = self._build([e[0] for e in entries], True, entries)
             self._tables[sig] = tab
         check(lib().unit_multi_wgrad_reduce(ops._p(tab[0]), tab[1], tab[2], ops._p(self.model.store.grads), ops._s()), "multi_wgrad_reduce")
 

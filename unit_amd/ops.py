@@ -71,6 +71,8 @@ BIG_TILE_VARIANT = int(__import__("os").environ.get("UNIT_BIG_VARIANT", "0"))
 
 # side HIP stream for the weight-gradient kernels (set by the model when stream overlap is enabled; None = inline)
 WGRAD_STREAM = None
+# True while a SECOND backbone backward of the same step runs (ragged supervised / weak batches): weight gradients accumulate
+WGRAD_ACCUMULATE = False
 
 # bench.py sets this to a dict to time every conv_igemm launch with HIP events on the launch stream (roofline evidence)
 PROFILER = None
@@ -470,11 +472,12 @@ def first_k_rois(props, pcount, s, batch_index_offset=0):
 
 # ------------------------------------------------------------------------------------------------ a8
 def roi_align(feat, rois, pooled_size=14, out_size=None, bin_step=1, spatial_scale=1.0 / 16, sampling_ratio=0, aligned=True,
-              roi_count=None):
+              roi_count=None, out=None):
     n, h, w, c = feat.shape
     r = rois.shape[0]
     out_size = out_size or pooled_size
-    out = torch.empty((r, out_size, out_size, c), dtype=feat.dtype, device=feat.device)
+    if out is None:
+        out = torch.empty((r, out_size, out_size, c), dtype=feat.dtype, device=feat.device)
     check(lib().unit_roi_align_fwd(_p(feat), dt(feat.dtype), n, h, w, c, _p(rois), _p(roi_count), r, pooled_size, out_size, bin_step,
                                    float(spatial_scale), sampling_ratio, int(aligned), _p(out), _s()), "roi_align_fwd")
     return out
