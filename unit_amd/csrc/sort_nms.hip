@@ -395,11 +395,17 @@ __global__ void __launch_bounds__(NMS_SCAN_THREADS) nms_scan_kernel(const float*
       unsigned long long diag = diag_next;
       int inext = i + 64;
       diag_next = (inext < n) ? mk[(size_t)inext * nw + c + 1] : 0ull;
-      unsigned long long cur = s_cur, kept = 0;
-      int cnt = s_nkept;
+      // the 64-step dependency chain runs on the SCALAR unit: every value is wave-uniform (v_readlane with a uniform lane
+      // index, s_or / s_bitcmp), instead of 64 dependent ds_bpermute round trips
+      unsigned dlo_v = (unsigned)diag, dhi_v = (unsigned)(diag >> 32);
+      unsigned long long cur0 = s_cur;
+      unsigned long long cur = ((unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)(cur0 >> 32)) << 32) |
+                               __builtin_amdgcn_readfirstlane((unsigned)cur0);
+      unsigned long long kept = 0;
+      int cnt = __builtin_amdgcn_readfirstlane(s_nkept);
       int lim = min(64, n - c * 64);
       for (int j = 0; j < lim; ++j) {
-        unsigned long long dj = __shfl(diag, j, 64);
+        unsigned long long dj = ((unsigned long long)__builtin_amdgcn_readlane(dhi_v, j) << 32) | __builtin_amdgcn_readlane(dlo_v, j);
         if (!((cur >> j) & 1ull) && cnt < max_keep) { kept |= 1ull << j; cur |= dj; cnt++; }
       }
       if (tid == 0) { s_kept = kept; s_nkept = cnt; }
