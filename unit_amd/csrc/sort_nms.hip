@@ -399,13 +399,15 @@ __global__ void __launch_bounds__(NMS_SCAN_THREADS) nms_scan_kernel(const float*
       // index, s_or / s_bitcmp), instead of 64 dependent ds_bpermute round trips
       unsigned dlo_v = (unsigned)diag, dhi_v = (unsigned)(diag >> 32);
       unsigned long long cur0 = s_cur;
-      unsigned long long cur = ((unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)(cur0 >> 32)) << 32) |
-                               __builtin_amdgcn_readfirstlane((unsigned)cur0);
+      // (the builtins return int: cast to unsigned before widening, or the low word sign-extends over the high one)
+      unsigned long long cur = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)(cur0 >> 32)) << 32) |
+                               (unsigned)__builtin_amdgcn_readfirstlane((unsigned)cur0);
       unsigned long long kept = 0;
       int cnt = __builtin_amdgcn_readfirstlane(s_nkept);
       int lim = min(64, n - c * 64);
       for (int j = 0; j < lim; ++j) {
-        unsigned long long dj = ((unsigned long long)__builtin_amdgcn_readlane(dhi_v, j) << 32) | __builtin_amdgcn_readlane(dlo_v, j);
+        unsigned long long dj = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane(dhi_v, j) << 32) |
+                                (unsigned)__builtin_amdgcn_readlane(dlo_v, j);
         if (!((cur >> j) & 1ull) && cnt < max_keep) { kept |= 1ull << j; cur |= dj; cnt++; }
       }
       if (tid == 0) { s_kept = kept; s_nkept = cnt; }
