@@ -1,0 +1,45 @@
+// conv_igemm256.h -- argument block and LDS layout helpers shared by the 256x256-tile implicit-GEMM conv kernels
+// (conv_igemm256.hip: 8-wave kernels; conv_igemm256p8.hip: phase-interleaved schedule with counted vmcnt).
+#pragma once
+#include "common.h"
+
+struct Conv256Args {
+  const void* x; const void* w; void* y;
+  const float* bias; const void* residual; const void* mask_ref;
+  int N, H, W, C;
+  int K, R, S, stride, pad;
+  int OH, OW;
+  int ldy, oy_mul, OHf, OWf;
+  int relu;
+  int Kgemm, M;
+  int tiles_m, tiles_n;
+  unsigned x_bytes, w_bytes;
+};
+
+// LDS image of an operand stage: [row][128 B = 64 k]; 16-B chunks XOR-swizzled with (row>>1)&7 (applied to the SOURCE
+// chunk of the lane-linear LDS-DMA, undone here by the fragment reads)
+__device__ __forceinline__ int swz256(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
+
+typedef __attribute__((address_space(3))) void lds_void;
+
+template <typename TO> struct O4;
+template <> struct O4<float> {
+  static __device__ __forceinline__ void load(const float* p, float (&v)[4]) { f32x4 a = *reinterpret_cast<const f32x4*>(p); v[0] = a[0]; v[1] = a[1]; v[2] = a[2]; v[3] = a[3]; }
+  static __device__ __forceinline__ void store(float* p, const float (&v)[4]) { f32x4 a = {v[0], v[1], v[2], v[3]}; *reinterpret_cast<f32x4*>(p) = a; }
+};
+template <> struct O4<bf16_t> {
+  static __device__ __forceinline__ void load(const bf16_t* p, float (&v)[4]) {
+    bf16x4 a = *reinterpret_cast<const bf16x4*>(p);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = (float)a[i];
+  }
+  static __device__ __forceinline__ void store(bf16_t* p, const float (&v)[4]) {
+    bf16x4 a;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) a[i] = (bf16_t)v[i];
+    *reinterpret_cast<bf16x4*>(p) = a;
+  }
+};
+
+// conv_igemm256p8.hip: the 8-phase (4 per k-tile) schedule of the same tile
+int unit_conv256_p8_launch(Conv256Args& a, int out_dtype, hipStream_t st);

@@ -7,7 +7,7 @@
 // lane-linear per wave instruction (8 rows x 128 B), so the bank-conflict XOR swizzle is applied to the per-lane SOURCE
 // chunk (chunk ^= (row>>1)&7) and undone in the fragment reads. Two 64 KB LDS buffers: the DMA of k-tile t+1 is in flight
 // while k-tile t is multiplied; one vmcnt(0)+barrier per k-tile.  Requires C % 64 == 0 (every layer except the stem).
-#include "common.h"
+#include "conv_igemm256.h"
 #include "conv_epilogue.h"
 
 // diagnostic builds only (tools/exp256.sh): 1 = no operand DMA after the first k-tile (MFMA + LDS-read bound of the loop),
@@ -15,42 +15,6 @@
 #ifndef UNIT_DBG256
 #define UNIT_DBG256 0
 #endif
-
-struct Conv256Args {
-  const void* x; const void* w; void* y;
-  const float* bias; const void* residual; const void* mask_ref;
-  int N, H, W, C;
-  int K, R, S, stride, pad;
-  int OH, OW;
-  int ldy, oy_mul, OHf, OWf;
-  int relu;
-  int Kgemm, M;
-  int tiles_m, tiles_n;
-  unsigned x_bytes, w_bytes;
-};
-
-__device__ __forceinline__ int swz256(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
-
-template <typename TO> struct O4;
-template <> struct O4<float> {
-  static __device__ __forceinline__ void load(const float* p, float (&v)[4]) { f32x4 a = *reinterpret_cast<const f32x4*>(p); v[0] = a[0]; v[1] = a[1]; v[2] = a[2]; v[3] = a[3]; }
-  static __device__ __forceinline__ void store(float* p, const float (&v)[4]) { f32x4 a = {v[0], v[1], v[2], v[3]}; *reinterpret_cast<f32x4*>(p) = a; }
-};
-template <> struct O4<bf16_t> {
-  static __device__ __forceinline__ void load(const bf16_t* p, float (&v)[4]) {
-    bf16x4 a = *reinterpret_cast<const bf16x4*>(p);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) v[i] = (float)a[i];
-  }
-  static __device__ __forceinline__ void store(bf16_t* p, const float (&v)[4]) {
-    bf16x4 a;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) a[i] = (bf16_t)v[i];
-    *reinterpret_cast<bf16x4*>(p) = a;
-  }
-};
-
-typedef __attribute__((address_space(3))) void lds_void;
 
 // FB = 16-row MFMA blocks per wave along the pixel dimension: tile = (32*FB) pixels x 256 channels. FB = 7 (224 rows) divides
 // the Res5 problem sizes (50 176 = 224 * 224 pixels per 1024 RoIs) into whole rounds of 256 workgroups where 256-row tiles
@@ -644,6 +608,12 @@ extern "C" int unit_conv2d_fwd_big(const void* x, const void* w, void* y, const 
                    OH == 7 && OW == 7;
     if (variant == 6 && !halo_ok) { unit_set_error("conv_big: variant 6 needs a bf16-out 3x3 s1 p1 conv on 7x7 maps"); return UNIT_ERR_UNSUPPORTED; }
     if (halo_ok && (variant == 6 || (variant == 0 && !no_halo))) return launch256_halo7(a, st);
+  }
+  // 7 (and 0 when UNIT_P8=1): four phases per k-tile, half-tile staging under a counted vmcnt (conv_igemm256p8.hip)
+  {
+    static int p8 = -1;
+    if (p8 < 0) { const char* e = getenv("UNIT_P8"); p8 = e ? atoi(e) : 0; }
+    if (variant == 7 || (variant == 0 && p8)) return unit_conv256_p8_launch(a, out_dtype, st);
   }
   bool rows224 = variant == 3;
   if (variant == 5) {

@@ -1,0 +1,272 @@
+// conv_igemm256p8.hip -- 256 (pixels) x 256 (channels) x 64 (k) implicit-GEMM conv tile, 8 waves (2 x 4, 128 x 64 each), with the
+// k-tile cut into FOUR phases and the operand stage cut into FOUR 16 KB half-tiles that are staged one per phase, six
+// phases ahead of their first read, under a COUNTED vmcnt (the LDS-DMA queue never drains inside the loop).
+//
+// Why (MI355X_MICROARCH.md cycle constants; tools/exp256.sh): one LDS-DMA piece costs the issuing wave 60-185 cycles and
+// the two-stage kernel of conv_igemm256.hip issues the 8 pieces of a k-tile in one burst, waits vmcnt(0) for all of them
+// at the next barrier and only then issues the next burst: operand feed 27 B/clk/CU, MFMA pipe idle ~55 % of the loop.
+// Here every phase = {LOAD section: <= 12 ds_read_b128 + 2 LDS-DMA pieces} barrier {16 MFMA} barrier, the two wave groups
+// (waves 0-3 / 4-7, one of each per SIMD) run half a phase apart so that a SIMD always has one wave in its MFMA section
+// while the other issues loads, and `s_waitcnt vmcnt(4)` once per k-tile leaves two half-tiles in flight across it.
+//
+// LDS (128 KB): buffer d = k-tile & 1, four half-tile slots [X0 | W0 | W1 | X1] of 128 rows x 128 B each.
+//   X half q holds tile pixels  wmr*128 + q*64 + i  at row wmr*64 + i   (wmr = 0,1 ; i < 64)
+//   W half q holds tile channels wnr*64 + q*32 + j  at row wnr*32 + j   (wnr = 0..3 ; j < 32)
+// so a wave (wm, wn) still owns the CONTIGUOUS 128 pixels x 64 channels block (wm*128.., wn*64..) -- the row permutation
+// lives only in the source addresses of the staging -- while each of its four quadrants (64 pixels x 32 channels x 64 k)
+// reads one X sub-tile (8 ds_read_b128) and one W sub-tile (4):
+//   phase 0: read X0,W0 sub-tiles ; quadrant (0,0)        phase 1: read W1 ; quadrant (0,1)
+//   phase 2: read X1 (over X0's registers) ; (1,0)        phase 3: no reads, the k-tile's vmcnt wait ; (1,1)
+// Staging order (one half-tile = 2 pieces per wave per phase): k-tile t phase 0 stages W1(t+1), phase 1 X1(t+1), phase 2
+// X0(t+2), phase 3 W0(t+2).
+//   WAR: a slot is restaged >= 2 phases after the phase that last read it (X0(t): read phase 0, restaged phase 2; the
+//        others 3) -- both groups' reads are retired (lgkmcnt(0) right after the barrier that ends their LOAD section) at
+//        least one whole barrier interval before either group issues the DMA.
+//   RAW: every wave waits vmcnt(4) [vmcnt(0) once nothing younger was issued] before the first barrier of phase 3: all of
+//        k-tile t+1 has landed for that wave; the later group does so one interval later, and the first read of k-tile
+//        t+1 by either group comes after the barrier that ends that interval.
+// Same swizzle / k order / accumulation order / epilogue as conv_igemm256.hip: results are bit-identical to it.
+#include "conv_igemm256.h"
+#include "conv_epilogue.h"
+
+#define MFMA_BF16(A, B, C) __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, A), __builtin_bit_cast(bf16x8, B), C, 0, 0, 0)
+
+template <typename TO>
+__global__ void __launch_bounds__(512, 2) conv_igemm256_p8_kernel(Conv256Args p) {
+  constexpr int BM = 256, BN = 256, BK = 64;
+  constexpr int HALF = 128 * 128;               // 16 KB half-tile
+  constexpr int SX0 = 0, SW0 = HALF, SW1 = 2 * HALF, SX1 = 3 * HALF, BUF = 4 * HALF;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  int nwg = p.tiles_m * p.tiles_n;
+  int bid = blockIdx.x;
+  {
+    int q = nwg / 8, r = nwg % 8, xcd = bid % 8, loc = bid / 8;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+  }
+  int tile_n = bid % p.tiles_n, tile_m = bid / p.tiles_n;
+  int m0 = tile_m * BM, n0 = tile_n * BN;
+
+  const bf16_t* __restrict__ X = (const bf16_t*)p.x;
+  const bf16_t* __restrict__ Wt = (const bf16_t*)p.w;
+  __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(X), 0, (int)p.x_bytes, 0x00020000);
+  __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(Wt), 0, (int)p.w_bytes, 0x00020000);
+  constexpr unsigned OOB = 0xFFFFFFF0u;
+
+  int tid = threadIdx.x, lane = tid & 63;
+  int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int wm = wid >> 2, wn = wid & 3;
+  const int grp = wm;                          // waves 4-7 run half a phase behind waves 0-3
+  int lrow = lane >> 3, lc = lane & 7;
+
+  // staging descriptors: half q (0,1), piece j (0,1) of this wave = half-tile rows R0 = (j*8 + wid)*8 .. +8 ; lane -> row
+  // R0 + lrow, LDS chunk lc (lane-linear), SOURCE chunk lc ^ ((row>>1)&7)
+  int x_ih0[4], x_iw0[4]; unsigned x_off0[4], w_off[4];
+#pragma unroll
+  for (int q = 0; q < 2; ++q)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      int R = (j * 8 + wid) * 8 + lrow;
+      int sw = lc ^ ((R >> 1) & 7);
+      int m = m0 + (R >> 6) * 128 + q * 64 + (R & 63);
+      bool ok = m < p.M;
+      int mm = ok ? m : 0;
+      int ow = mm % p.OW; int t = mm / p.OW; int oh = t % p.OH; int n = t / p.OH;
+      int ih0 = oh * p.stride - p.pad, iw0 = ow * p.stride - p.pad;
+      x_off0[q * 2 + j] = ((unsigned)n * (unsigned)(p.H * p.W * p.C) + (unsigned)((ih0 * p.W + iw0) * p.C + sw * 8)) * 2u;  // tap (0,0), wraps for negative ih0/iw0
+      x_ih0[q * 2 + j] = ok ? ih0 : -(1 << 20);                    // rows past M fail the bounds test of every tap
+      x_iw0[q * 2 + j] = iw0;
+      int nn = n0 + (R >> 5) * 64 + q * 32 + (R & 31);
+      w_off[q * 2 + j] = nn < p.K ? ((unsigned)nn * (unsigned)p.Kgemm + (unsigned)sw * 8u) * 2u : OOB;
+    }
+
+  // k-tile order: channel block outermost, the R*S taps innermost (conv_igemm256.hip). (cb, r, s) of the k-tile that the
+  // staging is currently working on, and the two byte offsets derived from them, live in scalar registers.
+  int st_cb = 0, st_r = 0, st_s = 0;
+  unsigned st_kx = 0, st_kw = 0;
+  auto st_advance = [&]() {
+    if (++st_s == p.S) { st_s = 0; if (++st_r == p.R) { st_r = 0; ++st_cb; } }
+    st_kx = (unsigned)((st_r * p.W + st_s) * p.C + st_cb * BK) * 2u;
+    st_kw = (unsigned)((st_r * p.S + st_s) * p.C + st_cb * BK) * 2u;
+  };
+  auto stage_x = [&](int q, int d) {
+    char* base = smem + d * BUF + (q ? SX1 : SX0);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      int ih = x_ih0[q * 2 + j] + st_r, iw = x_iw0[q * 2 + j] + st_s;
+      bool ok = (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, (lds_void*)(base + (j * 8 + wid) * 1024), 16, ok ? x_off0[q * 2 + j] + st_kx : OOB, 0, 0, 0);
+    }
+  };
+  auto stage_w = [&](int q, int d) {
+    char* base = smem + d * BUF + (q ? SW1 : SW0);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      unsigned o = w_off[q * 2 + j];
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (lds_void*)(base + (j * 8 + wid) * 1024), 16, o == OOB ? OOB : o + st_kw, 0, 0, 0);
+    }
+  };
+
+  f32x4 acc[4][8];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 8; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int nk = p.Kgemm / BK;
+  const int frow = lane & 15, fq = lane >> 4;
+  // per-lane fragment offsets inside a half-tile, k-substep 0 (substep 1 = ^ 64); tile rows b*16 / a*16 add b*2048 / a*2048
+  const int fsw = (fq ^ ((frow >> 1) & 7)) << 4;
+  const int offx = (wm * 64 + frow) * 128 + fsw;
+  const int offw = (wn * 32 + frow) * 128 + fsw;
+
+  i32x4 fx[4][2], fw0[2][2], fw1[2][2];
+  auto read_x = [&](const char* half) {
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      fx[b][0] = *reinterpret_cast<const i32x4*>(half + b * 2048 + offx);
+      fx[b][1] = *reinterpret_cast<const i32x4*>(half + b * 2048 + (offx ^ 64));
+    }
+  };
+  auto read_w = [&](const char* half, i32x4 (&fw)[2][2]) {
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+      fw[a][0] = *reinterpret_cast<const i32x4*>(half + a * 2048 + offw);
+      fw[a][1] = *reinterpret_cast<const i32x4*>(half + a * 2048 + (offw ^ 64));
+    }
+  };
+#define P8_BAR() do { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); } while (0)
+  // MFMA section of a phase: quadrant (qx, qw) = acc[qw*2 ..][qx*4 ..]
+#define P8_MFMA(QX, QW, FW)                                                            \
+  do {                                                                                 \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                 \
+    __builtin_amdgcn_sched_barrier(0);                                                 \
+    __builtin_amdgcn_s_setprio(1);                                                     \
+    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                   \
+      _Pragma("unroll") for (int a = 0; a < 2; ++a)                                    \
+        _Pragma("unroll") for (int b = 0; b < 4; ++b)                                  \
+          acc[(QW) * 2 + a][(QX) * 4 + b] = MFMA_BF16(FW[a][ks], fx[b][ks], acc[(QW) * 2 + a][(QX) * 4 + b]); \
+    __builtin_amdgcn_s_setprio(0);                                                     \
+  } while (0)
+
+  // ---- prologue: k-tile 0 (4 half-tiles) and X0, W0 of k-tile 1 in flight
+  stage_x(0, 0); stage_w(0, 0); stage_w(1, 0); stage_x(1, 0);
+  st_advance();
+  if (nk > 1) {
+    stage_x(0, 1); stage_w(0, 1);
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  } else {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  P8_BAR();
+  if (grp == 1) P8_BAR();
+
+  for (int t = 0; t < nk; ++t) {
+    const int d = t & 1;
+    const char* buf = smem + d * BUF;
+    const bool n1 = t + 1 < nk, n2 = t + 2 < nk;
+    // phase 0
+    read_w(buf + SW0, fw0);
+    __builtin_amdgcn_sched_barrier(0);
+    read_x(buf + SX0);
+    if (n1) stage_w(1, d ^ 1);
+    P8_BAR();
+    P8_MFMA(0, 0, fw0);
+    P8_BAR();
+    // phase 1
+    read_w(buf + SW1, fw1);
+    if (n1) stage_x(1, d ^ 1);
+    st_advance();
+    P8_BAR();
+    P8_MFMA(0, 1, fw1);
+    P8_BAR();
+    // phase 2
+    read_x(buf + SX1);
+    if (n2) stage_x(0, d);
+    P8_BAR();
+    P8_MFMA(1, 0, fw0);
+    P8_BAR();
+    // phase 3
+    if (n2) {
+      stage_w(0, d);
+      asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    P8_BAR();
+    P8_MFMA(1, 1, fw1);
+    P8_BAR();
+  }
+  if (grp == 0) P8_BAR();
+#undef P8_MFMA
+#undef P8_BAR
+
+  if constexpr (sizeof(TO) == 2) {
+    if ((p.ldy & 7) == 0) {          // row-major epilogue through a wave-private LDS scratch (conv_epilogue.h)
+      __syncthreads();               // every wave is done with the operand stages
+      epilogue_rows_bf16<4, 8>(acc, smem + wid * EpiCfg<4>::BYTES, m0 + wm * 128, n0 + wn * 64, p, lane);
+      return;
+    }
+  }
+  TO* __restrict__ Y = (TO*)p.y;
+  const TO* __restrict__ Rz = (const TO*)p.residual;
+  const TO* __restrict__ Mk = (const TO*)p.mask_ref;
+  bool plain = (p.oy_mul == 1 && p.OHf == p.OH && p.OWf == p.OW);
+#pragma unroll
+  for (int b = 0; b < 8; ++b) {
+    int m = m0 + wm * 128 + b * 16 + frow;
+    if (m >= p.M) continue;
+    long off;
+    if (plain) off = (long)m * p.ldy;
+    else {
+      int ow = m % p.OW; int t = m / p.OW; int oh = t % p.OH; int n = t / p.OH;
+      off = (((long)n * p.OHf + (long)oh * p.oy_mul) * p.OWf + (long)ow * p.oy_mul) * p.ldy;
+    }
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      int n = n0 + wn * 64 + a * 16 + fq * 4;
+      if (n >= p.ldy) continue;
+      float v[4] = {acc[a][b][0], acc[a][b][1], acc[a][b][2], acc[a][b][3]};
+      if (p.bias) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] += (n + j < p.K) ? p.bias[n + j] : 0.f;
+      }
+      if (Rz) {
+        float rr[4]; O4<TO>::load(Rz + off + n, rr);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] += rr[j];
+      }
+      if (p.relu) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
+      }
+      if (Mk) {
+        float mm[4]; O4<TO>::load(Mk + off + n, mm);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = mm[j] > 0.f ? v[j] : 0.f;
+      }
+      O4<TO>::store(Y + off + n, v);
+    }
+  }
+}
+
+template <typename TO>
+static int launch256_p8(Conv256Args& a, hipStream_t st) {
+  a.tiles_m = cdiv(a.M, 256); a.tiles_n = cdiv(a.K, 256);
+  size_t lds = 8 * 128 * 128;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)conv_igemm256_p8_kernel<TO>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  conv_igemm256_p8_kernel<TO><<<a.tiles_m * a.tiles_n, 512, lds, st>>>(a);
+  UNIT_LAUNCH_CHECK();
+  return UNIT_OK;
+}
+
+int unit_conv256_p8_launch(Conv256Args& a, int out_dtype, hipStream_t st) {
+  if (out_dtype == UNIT_BF16) return launch256_p8<bf16_t>(a, st);
+  if (out_dtype == UNIT_F32) return launch256_p8<float>(a, st);
+  unit_set_error("conv_big: unsupported out dtype");
+  return UNIT_ERR_UNSUPPORTED;
+}
