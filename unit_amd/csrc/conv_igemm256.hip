@@ -613,7 +613,7 @@ extern "C" int unit_conv2d_fwd_big(const void* x, const void* w, void* y, const 
   {
     static int p8 = -1;
     if (p8 < 0) { const char* e = getenv("UNIT_P8"); p8 = e ? atoi(e) : 0; }
-    if (variant == 7 || (variant == 0 && p8)) return unit_conv256_p8_launch(a, out_dtype, st);
+    if (variant == 7 || variant == 8 || (variant == 0 && p8)) return unit_conv256_p8_launch(a, out_dtype, variant == 8 || (variant == 0 && p8 == 2), st);
   }
   bool rows224 = variant == 3;
   if (variant == 5) {

@@ -29,9 +29,15 @@
 #include "conv_igemm256.h"
 #include "conv_epilogue.h"
 
+// diagnostic builds only (tools/exp_p8.sh): 1 = no LDS-DMA inside the loop, 2 = MFMAs replaced by one VALU add per fragment,
+// 3 = fragment reads only in the first k-tile, 4 = 1 + 2, 5 = 2 + 3. Results are garbage in all of them.
+#ifndef UNIT_DBGP8
+#define UNIT_DBGP8 0
+#endif
+
 #define MFMA_BF16(A, B, C) __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, A), __builtin_bit_cast(bf16x8, B), C, 0, 0, 0)
 
-template <typename TO>
+template <typename TO, bool RM>
 __global__ void __launch_bounds__(512, 2) conv_igemm256_p8_kernel(Conv256Args p) {
   constexpr int BM = 256, BN = 256, BK = 64;
   constexpr int HALF = 128 * 128;               // 16 KB half-tile
@@ -136,6 +142,11 @@ __global__ void __launch_bounds__(512, 2) conv_igemm256_p8_kernel(Conv256Args p)
     }
   };
 #define P8_BAR() do { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#if UNIT_DBGP8 == 2 || UNIT_DBGP8 == 4 || UNIT_DBGP8 == 5
+#define P8_FMA(ACC, A, B) do { if (b == 0) ACC += __builtin_bit_cast(f32x4, A); if (a == 0) ACC += __builtin_bit_cast(f32x4, B); } while (0)
+#else
+#define P8_FMA(ACC, A, B) ACC = MFMA_BF16(A, B, ACC)
+#endif
   // MFMA section of a phase: quadrant (qx, qw) = acc[qw*2 ..][qx*4 ..]
 #define P8_MFMA(QX, QW, FW)                                                            \
   do {                                                                                 \
@@ -145,10 +156,94 @@ __global__ void __launch_bounds__(512, 2) conv_igemm256_p8_kernel(Conv256Args p)
     _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                   \
       _Pragma("unroll") for (int a = 0; a < 2; ++a)                                    \
         _Pragma("unroll") for (int b = 0; b < 4; ++b)                                  \
-          acc[(QW) * 2 + a][(QX) * 4 + b] = MFMA_BF16(FW[a][ks], fx[b][ks], acc[(QW) * 2 + a][(QX) * 4 + b]); \
+          P8_FMA(acc[(QW) * 2 + a][(QX) * 4 + b], FW[a][ks], fx[b][ks]);               \
     __builtin_amdgcn_s_setprio(0);                                                     \
   } while (0)
 
+  if constexpr (RM) {
+    // ---- RM schedule: the fragment reads of phase p+1 are issued INSIDE the MFMA section of phase p (one per MFMA gap, a
+    // second X register set), so a LOAD section is only {2 LDS-DMA pieces, the k-tile's vmcnt wait}: tools/exp_p8.sh showed
+    // the plain schedule bound by its LOAD sections (reads + their latency + DMA issue ~ 440 clk against 256 clk of MFMA).
+    // Everything moves one phase earlier relative to the quadrants:
+    //   phase 0: stage X1(t+1) ; (0,0) || read W1(t)        phase 1: stage X0(t+2) ; (0,1) || read X1(t)
+    //   phase 2: stage W0(t+2), vmcnt wait ; (1,0)           phase 3: stage W1(t+2) ; (1,1) || read X0(t+1), W0(t+1)
+    // Reads are retired (lgkmcnt(0)) before the barrier that ends their MFMA section.
+    //   WAR: X0/W0(t) last read in M(t-1, 3), restaged in L(t, 1) / L(t, 2): >= 2 phases; X1(t-1): M(t-1, 1) -> L(t, 0): 3;
+    //        W1(t): M(t, 0) -> L(t, 3): 3.
+    //   RAW: vmcnt in L(t, 2) of both groups (two half-tiles younger than k-tile t+1 may stay in flight); first read of
+    //        k-tile t+1 in M(t, 3), which for either group starts after the barrier that ends the later group's L(t, 2).
+    i32x4 fxb[4][2];
+    auto read_xb = [&](const char* half) {
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        fxb[b][0] = *reinterpret_cast<const i32x4*>(half + b * 2048 + offx);
+        fxb[b][1] = *reinterpret_cast<const i32x4*>(half + b * 2048 + (offx ^ 64));
+      }
+    };
+#define P8_MM(QX, QW, FW, FX, NR, READS)                                                 \
+    do {                                                                                 \
+      __builtin_amdgcn_s_setprio(1);                                                     \
+      READS;                                                                             \
+      _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                   \
+        _Pragma("unroll") for (int a = 0; a < 2; ++a)                                    \
+          _Pragma("unroll") for (int b = 0; b < 4; ++b)                                  \
+            acc[(QW) * 2 + a][(QX) * 4 + b] = MFMA_BF16(FW[a][ks], FX[b][ks], acc[(QW) * 2 + a][(QX) * 4 + b]); \
+      _Pragma("unroll") for (int i = 0; i < (NR); ++i) {                                 \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                               \
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                               \
+      }                                                                                  \
+      __builtin_amdgcn_sched_group_barrier(0x008, 16 - (NR), 0);                         \
+      __builtin_amdgcn_s_setprio(0);                                                     \
+      if ((NR) > 0) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                   \
+    } while (0)
+    stage_x(0, 0); stage_w(0, 0); stage_w(1, 0); stage_x(1, 0);
+    st_advance();
+    if (nk > 1) {
+      stage_x(0, 1); stage_w(0, 1); stage_w(1, 1);
+      asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    P8_BAR();
+    read_w(smem + SW0, fw0);
+    read_x(smem + SX0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (grp == 1) P8_BAR();
+    for (int t = 0; t < nk; ++t) {
+      const int d = t & 1;
+      const char* buf = smem + d * BUF;
+      const char* bnx = smem + (d ^ 1) * BUF;
+      const bool n1 = t + 1 < nk, n2 = t + 2 < nk;
+      // phase 0
+      if (n1) stage_x(1, d ^ 1);
+      st_advance();
+      P8_BAR();
+      P8_MM(0, 0, fw0, fx, 4, read_w(buf + SW1, fw1));
+      P8_BAR();
+      // phase 1
+      if (n2) stage_x(0, d);
+      P8_BAR();
+      P8_MM(0, 1, fw1, fx, 8, read_xb(buf + SX1));
+      P8_BAR();
+      // phase 2
+      if (n2) {
+        stage_w(0, d);
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      P8_BAR();
+      P8_MM(1, 0, fw0, fxb, 0, (void)0);
+      P8_BAR();
+      // phase 3 (after the last k-tile the reads fetch stale, in-bounds LDS that nobody uses)
+      if (n2) stage_w(1, d);
+      P8_BAR();
+      P8_MM(1, 1, fw1, fxb, 12, read_w(bnx + SW0, fw0); read_x(bnx + SX0));
+      P8_BAR();
+    }
+    if (grp == 0) P8_BAR();
+#undef P8_MM
+  } else {
   // ---- prologue: k-tile 0 (4 half-tiles) and X0, W0 of k-tile 1 in flight
   stage_x(0, 0); stage_w(0, 0); stage_w(1, 0); stage_x(1, 0);
   st_advance();
@@ -164,24 +259,29 @@ __global__ void __launch_bounds__(512, 2) conv_igemm256_p8_kernel(Conv256Args p)
   for (int t = 0; t < nk; ++t) {
     const int d = t & 1;
     const char* buf = smem + d * BUF;
-    const bool n1 = t + 1 < nk, n2 = t + 2 < nk;
+    const bool n1 = t + 1 < nk && UNIT_DBGP8 != 1 && UNIT_DBGP8 != 4, n2 = t + 2 < nk && UNIT_DBGP8 != 1 && UNIT_DBGP8 != 4;
+#if UNIT_DBGP8 == 3 || UNIT_DBGP8 == 5
+#define P8_RD(stmt) do { if (t == 0) { stmt; } } while (0)
+#else
+#define P8_RD(stmt) do { stmt; } while (0)
+#endif
     // phase 0
-    read_w(buf + SW0, fw0);
+    P8_RD(read_w(buf + SW0, fw0));
     __builtin_amdgcn_sched_barrier(0);
-    read_x(buf + SX0);
+    P8_RD(read_x(buf + SX0));
     if (n1) stage_w(1, d ^ 1);
     P8_BAR();
     P8_MFMA(0, 0, fw0);
     P8_BAR();
     // phase 1
-    read_w(buf + SW1, fw1);
+    P8_RD(read_w(buf + SW1, fw1));
     if (n1) stage_x(1, d ^ 1);
     st_advance();
     P8_BAR();
     P8_MFMA(0, 1, fw1);
     P8_BAR();
     // phase 2
-    read_x(buf + SX1);
+    P8_RD(read_x(buf + SX1));
     if (n2) stage_x(0, d);
     P8_BAR();
     P8_MFMA(1, 0, fw0);
@@ -198,7 +298,10 @@ __global__ void __launch_bounds__(512, 2) conv_igemm256_p8_kernel(Conv256Args p)
     P8_BAR();
   }
   if (grp == 0) P8_BAR();
+  }
 #undef P8_MFMA
+#undef P8_FMA
+#undef P8_RD
 #undef P8_BAR
 
   if constexpr (sizeof(TO) == 2) {
@@ -250,23 +353,23 @@ __global__ void __launch_bounds__(512, 2) conv_igemm256_p8_kernel(Conv256Args p)
   }
 }
 
-template <typename TO>
+template <typename TO, bool RM>
 static int launch256_p8(Conv256Args& a, hipStream_t st) {
   a.tiles_m = cdiv(a.M, 256); a.tiles_n = cdiv(a.K, 256);
   size_t lds = 8 * 128 * 128;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)conv_igemm256_p8_kernel<TO>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)conv_igemm256_p8_kernel<TO, RM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
-  conv_igemm256_p8_kernel<TO><<<a.tiles_m * a.tiles_n, 512, lds, st>>>(a);
+  conv_igemm256_p8_kernel<TO, RM><<<a.tiles_m * a.tiles_n, 512, lds, st>>>(a);
   UNIT_LAUNCH_CHECK();
   return UNIT_OK;
 }
 
-int unit_conv256_p8_launch(Conv256Args& a, int out_dtype, hipStream_t st) {
-  if (out_dtype == UNIT_BF16) return launch256_p8<bf16_t>(a, st);
-  if (out_dtype == UNIT_F32) return launch256_p8<float>(a, st);
+int unit_conv256_p8_launch(Conv256Args& a, int out_dtype, bool reads_in_mfma, hipStream_t st) {
+  if (out_dtype == UNIT_BF16) return reads_in_mfma ? launch256_p8<bf16_t, true>(a, st) : launch256_p8<bf16_t, false>(a, st);
+  if (out_dtype == UNIT_F32) return reads_in_mfma ? launch256_p8<float, true>(a, st) : launch256_p8<float, false>(a, st);
   unit_set_error("conv_big: unsupported out dtype");
   return UNIT_ERR_UNSUPPORTED;
 }
