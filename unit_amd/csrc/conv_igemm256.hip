@@ -600,19 +600,20 @@ extern "C" int unit_conv2d_fwd_big(const void* x, const void* w, void* y, const 
   // rounds x rows (isolated launches gain 6-7 % on the Res5 shapes: 50 176 = 224 * 224 pixels; inside the multi-stream step
   // the other streams already fill the partial last round and the 7 % extra operand feed of the smaller tile costs 0.8 %);
   // 1: ping-pong wave groups; 2: four 32-k stages
-  // 6 (and 0 when the shape allows it): 3x3 s1 p1 on 7x7 maps with the input super-tile shared by the nine taps
+  // 6 (and 0 with UNIT_NO_HALO=0 when the shape allows it): 3x3 s1 p1 on 7x7 maps with the input super-tile shared by the nine taps
   {
     static int no_halo = -1;
-    if (no_halo < 0) { const char* e = getenv("UNIT_NO_HALO"); no_halo = e ? atoi(e) : 0; }
+    if (no_halo < 0) { const char* e = getenv("UNIT_NO_HALO"); no_halo = e ? atoi(e) : 1; }   // default: the p8 kernel below is faster
     bool halo_ok = out_dtype == UNIT_BF16 && (ldy & 7) == 0 && R == 3 && S == 3 && stride == 1 && pad == 1 && H == 7 && W == 7 &&
                    OH == 7 && OW == 7;
     if (variant == 6 && !halo_ok) { unit_set_error("conv_big: variant 6 needs a bf16-out 3x3 s1 p1 conv on 7x7 maps"); return UNIT_ERR_UNSUPPORTED; }
     if (halo_ok && (variant == 6 || (variant == 0 && !no_halo))) return launch256_halo7(a, st);
   }
-  // 7 (and 0 when UNIT_P8=1): four phases per k-tile, half-tile staging under a counted vmcnt (conv_igemm256p8.hip)
+  // 7 / 8 (8 = default for variant 0; UNIT_P8=0 falls back to the two-stage kernels below, =1 selects 7): four phases per k-tile,
+  // half-tile staging under a counted vmcnt; 8 also issues the fragment reads inside the MFMA sections (conv_igemm256p8.hip)
   {
     static int p8 = -1;
-    if (p8 < 0) { const char* e = getenv("UNIT_P8"); p8 = e ? atoi(e) : 0; }
+    if (p8 < 0) { const char* e = getenv("UNIT_P8"); p8 = e ? atoi(e) : 2; }
     if (variant == 7 || variant == 8 || (variant == 0 && p8)) return unit_conv256_p8_launch(a, out_dtype, variant == 8 || (variant == 0 && p8 == 2), st);
   }
   bool rows224 = variant == 3;
