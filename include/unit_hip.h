@@ -54,6 +54,9 @@ int unit_conv2d_wgrad(const void* x, const void* dy, float* dw, const float* sca
  * multi-tensor kernels below reduce all layers of a gradient bucket / refresh all prepared weight copies in ONE launch.
  * descs_dev: array of {const float* partial, *scale; void* wf, *wd; long offset; int splits,K,R,S,C,block0} (64 B each) */
 int unit_conv2d_wgrad_splits(int in_dtype, int N, int OH, int OW, int K, int R, int S, int C);
+/* big-M bf16 layers (C % 256 == 0, K % 256 == 0, M >= 16384) use a 256x256 tile: 1 (default) = two-stage loop
+ * (csrc/conv_wgrad256.hip), 0 = phase-interleaved schedule (csrc/conv_wgrad256p8.hip); same slabs bit for bit. Process-wide, not thread-safe. */
+int unit_wgrad_big_variant(int v);   /* returns the previous setting */
 size_t unit_tensor_desc_bytes(void);
 int unit_multi_wgrad_reduce(const void* descs_dev, int n, int total_blocks, float* grads_flat, void* stream);
 int unit_multi_weight_prep(const void* descs_dev, int n, int total_blocks, const float* params_flat, int dtype, void* stream);

@@ -10,22 +10,7 @@
 // banks), so 32-B column blocks are XOR-swizzled with (row & 7) on the DMA source side; a half-wave of the transposing
 // read then touches 8 rows x 32 B on 8 different bank groups.
 // Requires bf16, C % 256 == 0 (a k-tile stays inside one filter tap) and K % 256 == 0.
-#include "common.h"
-
-struct Wgrad256Args {
-  const void* x; const void* dy; float* partial;
-  int N, H, W, C;
-  int K, R, S, stride, pad;
-  int OH, OW;
-  int ldy;
-  int Kgemm, M;
-  int tiles_k, tiles_n, splits, m_per_split;
-  unsigned x_bytes, dy_bytes;
-  unsigned magic_ohw, magic_ow; int OHW; int use_magic;
-};
-
-typedef __attribute__((address_space(3))) void lds_void_w;
-typedef __attribute__((ext_vector_type(8))) short s16x8_w;
+#include "conv_wgrad256.h"
 
 __device__ __forceinline__ bf16x8 tr_frag(const char* tile, int sub, int col0, int lane) {
   // lane l: g = l>>4, i = l&15 = 4q+p ; reads rows (32*sub + 16h + 4g + q), cols col0 + 4p..4p+3 ; element j=4h+q' of
@@ -45,7 +30,14 @@ __global__ void __launch_bounds__(512, 2) conv_wgrad256_kernel(Wgrad256Args p) {
   constexpr int TILE = MS * 512;               // 32 KB per operand per stage
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
+  // XCD-aware remap (workgroup b runs on XCD b % 8): every XCD gets a contiguous chunk of (split, tile_n, tile_k) ids, i.e.
+  // the tiles of one or two split-M slabs. They walk the same pixel rows at the same pace, so an x / dy row block is
+  // fetched from HBM once per XCD and then served to the other tiles of the slab out of that XCD's 4 MB L2.
   int bid = blockIdx.x;
+  {
+    int nwg = gridDim.x, q = nwg / 8, r = nwg % 8, xcd = bid % 8, loc = bid / 8;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+  }
   int tile_k = bid % p.tiles_k; int t = bid / p.tiles_k;
   int tile_n = t % p.tiles_n; int split = t / p.tiles_n;
   int k0 = tile_k * 256, n0 = tile_n * 256;
@@ -150,6 +142,16 @@ __global__ void __launch_bounds__(512, 2) conv_wgrad256_kernel(Wgrad256Args p) {
   }
 }
 
+// 1 (default): the two-stage kernel above; 0: the phase-interleaved kernel of conv_wgrad256p8.hip. Measured (tools/wgrad_bench.py,
+// tools/exp_w8.sh): unlike the forward kernel, whose weight tile is L2-hot and whose pixel tile is shared by the channel
+// tiles, every workgroup here streams rows that are fetched from HBM / Infinity Cache exactly once per XCD (FETCH_SIZE =
+// the compulsory 245 MB on the 512->2048 layer), so the loop is bound by miss latency x the ~64-80 KB of LDS that can be in
+// flight per CU, not by LDS-DMA issue or fragment reads: the interleaved schedule is 5-20 % SLOWER (its staging is spread
+// thinner, and its L sections carry the im2col index arithmetic), 1.3 PF-equivalent with the DMA removed. Kept selectable
+// as the bit-exactness cross-check of the tests.
+static int g_wgrad_big_variant = 1;
+extern "C" int unit_wgrad_big_variant(int v) { int old = g_wgrad_big_variant; g_wgrad_big_variant = v; return old; }
+
 // shared with conv_wgrad.hip: which kernel handles a shape, and with how many split-M slabs
 extern "C" int unit_wgrad_use_big(int in_dtype, long M, int K, int C) {
   return in_dtype == UNIT_BF16 && (C % 256) == 0 && (K % 256) == 0 && M >= 16384;
@@ -191,6 +193,10 @@ extern "C" int unit_conv2d_wgrad_big_launch(const void* x, const void* dy, float
   a.m_per_split = cdiv(mps, 64) * 64;
   size_t need = (size_t)a.splits * K * a.Kgemm * sizeof(float);
   if (workspace_bytes < need) { unit_set_error("wgrad_big: workspace too small"); return UNIT_ERR_WORKSPACE; }
+  if (g_wgrad_big_variant == 0) {
+    int rc = unit_wgrad256_p8_launch(a, (hipStream_t)stream);
+    return rc == UNIT_OK ? a.splits : rc;
+  }
   size_t lds = 2 * 2 * 64 * 512;
   static bool attr_set = false;
   if (!attr_set) {

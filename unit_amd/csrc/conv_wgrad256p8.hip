@@ -1,0 +1,266 @@
+// conv_wgrad256p8.hip -- the 256 (k = (r,s,c)) x 256 (n = out channel) weight-gradient tile of conv_wgrad256.hip with the
+// schedule of conv_igemm256p8.hip: every 64-pixel step is cut into FOUR phases of 16 MFMAs (one 64 x 32 quadrant of the
+// wave's 128 x 64 tile, both 32-pixel sub-steps), the two operand tiles are cut into FOUR 16 KB half-tiles staged one per
+// phase under a counted vmcnt, the two wave groups (waves 0-3 / 4-7) run half a phase apart, and the transposing fragment
+// reads of phase p+1 are issued inside the MFMA section of phase p.
+//
+//   dW[n][k] = sum_m dy[m][n] * im2col(x)[m][k]     (contract, split-M slab layout and epilogue: conv_wgrad256.hip)
+//
+// LDS (128 KB): buffer d = step & 1, slots [X0 | D0 | D1 | X1], each 64 pixel rows x 256 B (128 columns):
+//   X half q holds columns  wkr*128 + q*64 + i  of the 256-column x tile at half-column wkr*64 + i   (wkr = 0,1 ; i < 64)
+//   D half q holds columns  wnr*64  + q*32 + j  of the 256-column dy tile at half-column wnr*32 + j  (wnr = 0..3 ; j < 32)
+// so wave (wk, wn) still owns the contiguous 128 (k) x 64 (n) block. One LDS-DMA piece = 4 rows x 256 B; the 32-B column
+// blocks of a row are XOR-swizzled with (row & 7) on the source side (8 blocks per row: a half-wave of ds_read_b64_tr_b16
+// touches 8 rows x 32 B on 8 different bank groups).
+// Schedule of step t (d = t & 1), fragments fx / fxb (x quadrant columns) and fd0 / fd1 (dy):
+//   phase 0: stage X1(t+1) ; quadrant (0,0) = fx  x fd0 || read D1(t) -> fd1
+//   phase 1: stage X0(t+2) ; quadrant (0,1) = fx  x fd1 || read X1(t) -> fxb
+//   phase 2: stage D0(t+2), vmcnt wait (step t+1 landed) ; quadrant (1,0) = fxb x fd0
+//   phase 3: stage D1(t+2) ; quadrant (1,1) = fxb x fd1 || read X0(t+1) -> fx, D0(t+1) -> fd0
+// WAR / RAW distances are those of conv_igemm256p8.hip (reads retired by lgkmcnt(0) before the barrier that ends their
+// MFMA section; a slot is restaged >= 2 phases after its last read; first read of step t+1 one phase after both groups'
+// vmcnt wait). Same m permutation inside a fragment and same accumulation order as conv_wgrad256.hip: bit-identical slabs.
+#include "conv_wgrad256.h"
+
+__global__ void __launch_bounds__(512, 2) conv_wgrad256_p8_kernel(Wgrad256Args p) {
+  constexpr int MS = 64;
+  constexpr int HALF = MS * 256;               // 16 KB
+  constexpr int SX0 = 0, SD0 = HALF, SD1 = 2 * HALF, SX1 = 3 * HALF, BUF = 4 * HALF;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  // XCD-aware remap (workgroup b runs on XCD b % 8): every XCD gets a contiguous chunk of (split, tile_n, tile_k) ids, i.e.
+  // the tiles of one or two split-M slabs. They walk the same pixel rows at the same pace, so an x / dy row block is
+  // fetched from HBM once per XCD and then served to the other tiles of the slab out of that XCD's 4 MB L2.
+  int bid = blockIdx.x;
+  {
+    int nwg = gridDim.x, q = nwg / 8, r = nwg % 8, xcd = bid % 8, loc = bid / 8;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+  }
+  int tile_k = bid % p.tiles_k; int tt = bid / p.tiles_k;
+  int tile_n = tt % p.tiles_n; int split = tt / p.tiles_n;
+  int k0 = tile_k * 256, n0 = tile_n * 256;
+  int m_begin = split * p.m_per_split, m_end = min(p.M, m_begin + p.m_per_split);
+  int rs = k0 / p.C, ch0 = k0 - rs * p.C, kr = rs / p.S, ksx = rs - kr * p.S;
+
+  const bf16_t* __restrict__ X = (const bf16_t*)p.x;
+  const bf16_t* __restrict__ DY = (const bf16_t*)p.dy;
+  __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(X), 0, (int)p.x_bytes, 0x00020000);
+  __amdgpu_buffer_rsrc_t rsD = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(DY), 0, (int)p.dy_bytes, 0x00020000);
+  constexpr unsigned OOB = 0xFFFFFFF0u;
+
+  int tid = threadIdx.x, lane = tid & 63;
+  int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int wk = wid >> 2, wn = wid & 3;
+  const int grp = wk;
+  const bool pointwise = (p.R == 1 && p.S == 1 && p.stride == 1 && p.pad == 0);
+
+  // staging: piece j (0,1) of this wave in every half-tile = rows (j*8 + wid)*4 .. +4 ; lane -> row + (lane>>4), physical
+  // 16-B chunk lane&15 ; logical chunk = (32-B block XOR (row & 7), 16-B half kept). (row & 7) does not depend on j.
+  int s_row[2]; unsigned xcol[2], dcol[2];
+  {
+    int r0 = wid * 4 + (lane >> 4);
+    s_row[0] = r0; s_row[1] = 32 + r0;
+    int jp = lane & 15;
+    int hcol = ((((jp >> 1) ^ (r0 & 7)) << 1) | (jp & 1)) * 8;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      xcol[q] = (unsigned)(ch0 + (hcol >> 6) * 128 + q * 64 + (hcol & 63));
+      dcol[q] = (unsigned)(n0 + (hcol >> 5) * 64 + q * 32 + (hcol & 31));
+    }
+  }
+  auto stage_x = [&](int q, int d, int mstep) {
+    char* base = smem + d * BUF + (q ? SX1 : SX0);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      int m = mstep + s_row[j];
+      bool ok = m < m_end;
+      unsigned xoff;
+      if (pointwise) xoff = ((unsigned)m * (unsigned)p.C + xcol[q]) * 2u;
+      else {
+        unsigned um = (unsigned)m, n, oh, ow;
+        if (p.use_magic) {
+          n = __umulhi(um, p.magic_ohw); unsigned rem = um - n * (unsigned)p.OHW;
+          if (rem >= (unsigned)p.OHW) { rem -= p.OHW; ++n; }
+          oh = __umulhi(rem, p.magic_ow); ow = rem - oh * (unsigned)p.OW;
+          if (ow >= (unsigned)p.OW) { ow -= p.OW; ++oh; }
+        } else {
+          ow = um % (unsigned)p.OW; unsigned t2 = um / (unsigned)p.OW; oh = t2 % (unsigned)p.OH; n = t2 / (unsigned)p.OH;
+        }
+        int ih = (int)oh * p.stride - p.pad + kr, iw = (int)ow * p.stride - p.pad + ksx;
+        ok = ok && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
+        xoff = ((unsigned)n * (unsigned)(p.H * p.W * p.C) + (unsigned)((ih * p.W + iw) * p.C) + xcol[q]) * 2u;
+      }
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, (lds_void_w*)(base + (j * 8 + wid) * 1024), 16, ok ? xoff : OOB, 0, 0, 0);
+    }
+  };
+  auto stage_d = [&](int q, int d, int mstep) {
+    char* base = smem + d * BUF + (q ? SD1 : SD0);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      int m = mstep + s_row[j];
+      unsigned doff = ((unsigned)m * (unsigned)p.ldy + dcol[q]) * 2u;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsD, (lds_void_w*)(base + (j * 8 + wid) * 1024), 16, m < m_end ? doff : OOB, 0, 0, 0);
+    }
+  };
+
+  f32x4 acc[8][4];
+#pragma unroll
+  for (int a = 0; a < 8; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // fragment addressing (tr_frag of conv_wgrad256.hip on 256-B rows): lane l: g = l>>4, i = l&15 = 4q+pq reads rows
+  // 32*sub + 16h + 4g + q, 8 B at column block (col>>4) ^ (row & 7); element j = 4h+q' of lane i <-> m-row 32*sub+16h+4g+q'
+  int offx[4], offd[2];
+  {
+    int g = lane >> 4, i = lane & 15, q4 = i >> 2, pq = i & 3;
+    int rowl = 4 * g + q4, r7 = rowl & 7;
+    int basel = rowl * 256 + 8 * pq;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) offx[a] = basel + (((wk * 4 + a) ^ r7) << 5);
+#pragma unroll
+    for (int b = 0; b < 2; ++b) offd[b] = basel + (((wn * 2 + b) ^ r7) << 5);
+  }
+  auto frag = [&](const char* half, int off, int sub) -> bf16x8 {
+    const char* a0 = half + off + sub * 8192;
+    s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a0));
+    s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a0 + 4096));
+    s16x8_w v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8, v);
+  };
+  bf16x8 fx[4][2], fxb[4][2], fd0[2][2], fd1[2][2];
+#define W8_READ_X(HALFP, FX)                                                          \
+  do {                                                                                \
+    _Pragma("unroll") for (int a = 0; a < 4; ++a)                                     \
+      _Pragma("unroll") for (int sub = 0; sub < 2; ++sub) FX[a][sub] = frag(HALFP, offx[a], sub); \
+  } while (0)
+#define W8_READ_D(HALFP, FD)                                                          \
+  do {                                                                                \
+    _Pragma("unroll") for (int b = 0; b < 2; ++b)                                     \
+      _Pragma("unroll") for (int sub = 0; sub < 2; ++sub) FD[b][sub] = frag(HALFP, offd[b], sub); \
+  } while (0)
+#define W8_BAR() do { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#if defined(UNIT_DBGW8) && UNIT_DBGW8 == 3
+#define W8_FMA(ACC, A, B) do { if (b == 0) ACC += __builtin_bit_cast(f32x4, A); if (a == 0) ACC += __builtin_bit_cast(f32x4, B); } while (0)
+#else
+#define W8_FMA(ACC, A, B) ACC = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A, B, ACC, 0, 0, 0)
+#endif
+#if defined(UNIT_DBGW8) && UNIT_DBGW8 == 4
+#define W8_RD(stmt) do { if (t == 0) { stmt; } } while (0)
+#else
+#define W8_RD(stmt) do { stmt; } while (0)
+#endif
+  // MFMA section: quadrant (QX, QN) = acc[QX*4 ..][QN*2 ..]; NR ds_read_b64_tr_b16 of READS spread PER per MFMA gap
+#define W8_MM(QX, QN, FX, FD, NR, PER, READS)                                          \
+  do {                                                                                 \
+    __builtin_amdgcn_s_setprio(1);                                                     \
+    READS;                                                                             \
+    _Pragma("unroll") for (int sub = 0; sub < 2; ++sub)                                \
+      _Pragma("unroll") for (int a = 0; a < 4; ++a)                                    \
+        _Pragma("unroll") for (int b = 0; b < 2; ++b)                                  \
+          W8_FMA(acc[(QX) * 4 + a][(QN) * 2 + b], FX[a][sub], FD[b][sub]);             \
+    _Pragma("unroll") for (int i = 0; i < (NR) / ((PER) > 0 ? (PER) : 1); ++i) {      \
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                               \
+      __builtin_amdgcn_sched_group_barrier(0x100, (PER), 0);                           \
+    }                                                                                  \
+    __builtin_amdgcn_sched_group_barrier(0x008, 16 - (NR) / ((PER) > 0 ? (PER) : 1), 0); \
+    __builtin_amdgcn_s_setprio(0);                                                     \
+    if ((NR) > 0) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                   \
+  } while (0)
+
+  const int nsteps = (m_end - m_begin + MS - 1) / MS;
+  if (nsteps > 0) {
+    int mst = m_begin;
+    stage_x(0, 0, mst); stage_d(0, 0, mst); stage_d(1, 0, mst); stage_x(1, 0, mst);
+    mst += MS;
+    if (nsteps > 1) {
+      stage_x(0, 1, mst); stage_d(0, 1, mst); stage_d(1, 1, mst);
+      asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    W8_BAR();
+    W8_READ_D(smem + SD0, fd0);
+    W8_READ_X(smem + SX0, fx);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (grp == 1) W8_BAR();
+    for (int t = 0; t < nsteps; ++t) {
+      const int d = t & 1;
+      const char* buf = smem + d * BUF;
+      const char* bnx = smem + (d ^ 1) * BUF;
+#if defined(UNIT_DBGW8) && UNIT_DBGW8 == 2
+      const bool n1 = false, n2 = false;
+#else
+      const bool n1 = t + 1 < nsteps, n2 = t + 2 < nsteps;
+#endif
+      // phase 0
+      if (n1) stage_x(1, d ^ 1, mst);
+      mst += MS;
+      W8_BAR();
+      W8_MM(0, 0, fx, fd0, 8, 1, W8_RD(W8_READ_D(buf + SD1, fd1)));
+      W8_BAR();
+      // phase 1
+      if (n2) stage_x(0, d, mst);
+      W8_BAR();
+      W8_MM(0, 1, fx, fd1, 16, 1, W8_RD(W8_READ_X(buf + SX1, fxb)));
+      W8_BAR();
+      // phase 2
+      if (n2) {
+        stage_d(0, d, mst);
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      W8_BAR();
+      W8_MM(1, 0, fxb, fd0, 0, 0, (void)0);
+      W8_BAR();
+      // phase 3 (after the last step the reads fetch stale, in-bounds LDS that nobody uses)
+      if (n2) stage_d(1, d, mst);
+      W8_BAR();
+      W8_MM(1, 1, fxb, fd1, 24, 2, W8_RD(W8_READ_D(bnx + SD0, fd0); W8_READ_X(bnx + SX0, fx)));
+      W8_BAR();
+    }
+    if (grp == 0) W8_BAR();
+  }
+#undef W8_MM
+#undef W8_FMA
+#undef W8_RD
+#undef W8_BAR
+#undef W8_READ_D
+#undef W8_READ_X
+
+  // epilogue: D[row = k][col = n] -> partial[split][n][k..k+3]
+  float* out = p.partial + (size_t)split * p.K * p.Kgemm;
+  int fq = lane >> 4, fr = lane & 15;
+#if defined(UNIT_DBGW8) && UNIT_DBGW8 == 1
+  // diagnostic build only (tools/exp_w8.sh): one store per lane instead of 32 -- what does the slab store cost?
+  f32x4 ssum = acc[0][0];
+#pragma unroll
+  for (int b = 0; b < 4; ++b)
+#pragma unroll
+    for (int a = 0; a < 8; ++a) if (a + b) ssum += acc[a][b];
+  *reinterpret_cast<f32x4*>(out + (size_t)(n0 + wn * 64 + fr) * p.Kgemm + k0 + wk * 128 + fq * 4) = ssum;
+#else
+#pragma unroll
+  for (int b = 0; b < 4; ++b) {
+    int n = n0 + wn * 64 + b * 16 + fr;
+#pragma unroll
+    for (int a = 0; a < 8; ++a) {
+      int k = k0 + wk * 128 + a * 16 + fq * 4;
+      *reinterpret_cast<f32x4*>(out + (size_t)n * p.Kgemm + k) = acc[a][b];
+    }
+  }
+#endif
+}
+
+int unit_wgrad256_p8_launch(const Wgrad256Args& a, hipStream_t st) {
+  size_t lds = 8 * 64 * 256;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)conv_wgrad256_p8_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  conv_wgrad256_p8_kernel<<<a.tiles_k * a.tiles_n * a.splits, 512, lds, st>>>(a);
+  UNIT_LAUNCH_CHECK();
+  return UNIT_OK;
+}

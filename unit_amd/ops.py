@@ -194,6 +194,11 @@ def conv2d(x, w, k, r, s, stride=1, pad=0, bias=None, residual=None, mask_ref=No
     return out
 
 
+def wgrad_big_variant(v):
+    """1 = two-stage 256x256 weight-gradient kernel (default), 0 = phase-interleaved schedule (slower here; bit-exactness cross-check)"""
+    lib().unit_wgrad_big_variant(int(v))
+
+
 def conv2d_wgrad(x, dy, k, r, s, stride=1, pad=0, scale=None, out=None, accumulate=False, ldy=None):
     """x [N,H,W,C], dy [N,OH,OW,ldy] -> dw fp32 [k,r,s,C] (scale[k] folded)."""
     n, h, wd, c = x.shape
