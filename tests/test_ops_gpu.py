@@ -168,7 +168,7 @@ def test_conv_big_tile_kernel(dev, case, big):
 
 @pytest.mark.parametrize("case", [(3, 30, 33, 256, 256, 3, 1, 1), (1, 38, 63, 128, 75, 1, 1, 0), (2, 9, 9, 64, 40, 1, 1, 0), (70, 7, 7, 64, 512, 3, 1, 1),
                                   (2, 19, 23, 64, 320, 1, 2, 0), (11, 7, 7, 192, 264, 3, 1, 1)])
-@pytest.mark.parametrize("cfg", [15, 16])
+@pytest.mark.parametrize("cfg", [15, 16, 17, 18])
 def test_conv_p8_kernel(dev, case, cfg):
     """256x256x64 kernel with the 4-phase-per-k-tile schedule, half-tile staging and counted vmcnt (tile_cfg=cfg)
     == F.conv2d incl. padding, partial tiles, one / two / many k-tiles, residual + ReLU + mask epilogue, strided-scatter form;
@@ -188,15 +188,15 @@ def test_conv_p8_kernel(dev, case, cfg):
     res = torch.randn(n, ref.shape[2], ref.shape[3], ldy, generator=gen).bfloat16()
     msk = torch.randn(n, ref.shape[2], ref.shape[3], ldy, generator=gen).bfloat16()
     y2 = o.conv2d(xd, wd, k, r, r, stride, pad, bias=bias.to(dev), residual=res.to(dev), mask_ref=msk.to(dev), relu=True, ldy=ldy, tile_cfg=cfg)
-    y1 = o.conv2d(xd, wd, k, r, r, stride, pad, bias=bias.to(dev), residual=res.to(dev), mask_ref=msk.to(dev), relu=True, ldy=ldy, tile_cfg=5)
+    y1 = o.conv2d(xd, wd, k, r, r, stride, pad, bias=bias.to(dev), residual=res.to(dev), mask_ref=msk.to(dev), relu=True, ldy=ldy, tile_cfg=13)
     assert torch.equal(y2.cpu()[..., :k], y1.cpu()[..., :k])
     if stride == 1 and r == 1:
         oh, ow = ref.shape[2], ref.shape[3]
         s5 = o.conv2d(xd, wd, k, 1, 1, 1, 0, scatter=(2, 2 * oh, 2 * ow), ldy=ldy, tile_cfg=cfg)
-        s1 = o.conv2d(xd, wd, k, 1, 1, 1, 0, scatter=(2, 2 * oh, 2 * ow), ldy=ldy, tile_cfg=5)
+        s1 = o.conv2d(xd, wd, k, 1, 1, 1, 0, scatter=(2, 2 * oh, 2 * ow), ldy=ldy, tile_cfg=13)
         assert torch.equal(s5.cpu(), s1.cpu())
     yf = o.conv2d(xd, wd, k, r, r, stride, pad, bias=bias.to(dev), out_dtype=torch.float32, tile_cfg=cfg)
-    y5 = o.conv2d(xd, wd, k, r, r, stride, pad, bias=bias.to(dev), out_dtype=torch.float32, tile_cfg=5)
+    y5 = o.conv2d(xd, wd, k, r, r, stride, pad, bias=bias.to(dev), out_dtype=torch.float32, tile_cfg=13)
     assert torch.equal(yf.cpu()[..., :k], y5.cpu()[..., :k])
 
 

@@ -1,4 +1,4 @@
-"""A/B of the 256x256 conv kernels on the big-M shapes: tile_cfg 5 (8 waves), 14 (8 waves, halo, 3x3 on 7x7 only), 15 (8-phase schedule), 16 (8-phase, reads inside the MFMA sections).
+"""A/B of the 256x256 conv kernels on the big-M shapes: tile_cfg 13 (two-stage 8-wave kernel), 14 (8 waves, halo, 3x3 on 7x7 only), 15 (8-phase schedule), 16 (8-phase, reads inside the MFMA sections).
    python tools/w4_bench.py"""
 import sys
 
@@ -21,7 +21,7 @@ for name, n, h, w, c, k, r, st, pad in SH:
     flops = 2.0 * n * oh * ow * k * r * r * c
     ref = None
     line = f"{name:32s}"
-    for tile in (5, 14, 15, 16):
+    for tile in (13, 15, 16, 17, 18):
         try:
             y = o.conv2d(x, wt, k, r, r, st, pad, relu=True, residual=res, tile_cfg=tile)
             ms = timeit(lambda: o.conv2d(x, wt, k, r, r, st, pad, relu=True, residual=res, tile_cfg=tile))

@@ -42,4 +42,4 @@ template <> struct O4<bf16_t> {
 };
 
 // conv_igemm256p8.hip: the 8-phase (4 per k-tile) schedule of the same tile
-int unit_conv256_p8_launch(Conv256Args& a, int out_dtype, bool reads_in_mfma, hipStream_t st);
+int unit_conv256_p8_launch(Conv256Args& a, int out_dtype, bool reads_in_mfma, bool rows224, hipStream_t st);

@@ -614,7 +614,19 @@ extern "C" int unit_conv2d_fwd_big(const void* x, const void* w, void* y, const 
   {
     static int p8 = -1;
     if (p8 < 0) { const char* e = getenv("UNIT_P8"); p8 = e ? atoi(e) : 2; }
-    if (variant == 7 || variant == 8 || (variant == 0 && p8)) return unit_conv256_p8_launch(a, out_dtype, variant == 8 || (variant == 0 && p8 == 2), st);
+    // 9: variant 8 on 224-row tiles; 10 (and 0 with UNIT_P8_ROWS=0): 224 or 256 rows, whichever needs fewer rounds x rows
+    // (+5 % per isolated launch on the Res5 shapes)
+    static int p8rows = -1;
+    if (p8rows < 0) { const char* e = getenv("UNIT_P8_ROWS"); p8rows = e ? atoi(e) : 256; }   // in the multi-stream step 256 rows win (19.4 vs 19.7 ms): the other streams fill the partial round
+    bool auto_rows = variant == 10 || (variant == 0 && p8 == 2 && p8rows == 0);
+    bool r224 = variant == 9 || (variant == 0 && p8 == 2 && p8rows == 224);
+    if (auto_rows) {
+      long n_tiles = cdiv(K, 256);
+      long c256 = (long)cdiv((long)cdiv(a.M, 256) * n_tiles, 256) * 256, c224 = (long)cdiv((long)cdiv(a.M, 224) * n_tiles, 256) * 224;
+      r224 = c224 < c256;
+    }
+    if (variant >= 7 && variant <= 10 || (variant == 0 && p8))
+      return unit_conv256_p8_launch(a, out_dtype, variant >= 8 || (variant == 0 && p8 == 2), r224, st);
   }
   bool rows224 = variant == 3;
   if (variant == 5) {

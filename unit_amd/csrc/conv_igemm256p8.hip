@@ -37,9 +37,15 @@
 
 #define MFMA_BF16(A, B, C) __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, A), __builtin_bit_cast(bf16x8, B), C, 0, 0, 0)
 
-template <typename TO, bool RM>
+// B1 = 16-row pixel blocks of the SECOND quadrant row of a wave (the first always has 4): 4 -> 256-row tiles, 3 -> 224-row
+// tiles (RM schedule only). 224 rows divide the Res5 problem sizes (50 176 = 224 * 224 pixels per 1024 RoIs) into whole
+// rounds of 256 workgroups where 256-row tiles leave the last round 1/2 - 3/4 empty. The LDS image keeps its 64-row groups
+// (the 16 unused rows of the X1 half are staged as zeros and never read).
+template <typename TO, bool RM, int B1>
 __global__ void __launch_bounds__(512, 2) conv_igemm256_p8_kernel(Conv256Args p) {
-  constexpr int BM = 256, BN = 256, BK = 64;
+  static_assert(RM || B1 == 4, "224-row tiles: RM schedule only");
+  constexpr int FBT = 4 + B1;
+  constexpr int BM = 32 * FBT, BN = 256, BK = 64;
   constexpr int HALF = 128 * 128;               // 16 KB half-tile
   constexpr int SX0 = 0, SW0 = HALF, SW1 = 2 * HALF, SX1 = 3 * HALF, BUF = 4 * HALF;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -74,8 +80,8 @@ __global__ void __launch_bounds__(512, 2) conv_igemm256_p8_kernel(Conv256Args p)
     for (int j = 0; j < 2; ++j) {
       int R = (j * 8 + wid) * 8 + lrow;
       int sw = lc ^ ((R >> 1) & 7);
-      int m = m0 + (R >> 6) * 128 + q * 64 + (R & 63);
-      bool ok = m < p.M;
+      int m = m0 + (R >> 6) * (FBT * 16) + q * 64 + (R & 63);
+      bool ok = m < p.M && (q == 0 || (R & 63) < B1 * 16);
       int mm = ok ? m : 0;
       int ow = mm % p.OW; int t = mm / p.OW; int oh = t % p.OH; int n = t / p.OH;
       int ih0 = oh * p.stride - p.pad, iw0 = ow * p.stride - p.pad;
@@ -113,11 +119,11 @@ __global__ void __launch_bounds__(512, 2) conv_igemm256_p8_kernel(Conv256Args p)
     }
   };
 
-  f32x4 acc[4][8];
+  f32x4 acc[4][FBT];
 #pragma unroll
   for (int a = 0; a < 4; ++a)
 #pragma unroll
-    for (int b = 0; b < 8; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int b = 0; b < FBT; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const int nk = p.Kgemm / BK;
   const int frow = lane & 15, fq = lane >> 4;
@@ -172,27 +178,27 @@ __global__ void __launch_bounds__(512, 2) conv_igemm256_p8_kernel(Conv256Args p)
     //        W1(t): M(t, 0) -> L(t, 3): 3.
     //   RAW: vmcnt in L(t, 2) of both groups (two half-tiles younger than k-tile t+1 may stay in flight); first read of
     //        k-tile t+1 in M(t, 3), which for either group starts after the barrier that ends the later group's L(t, 2).
-    i32x4 fxb[4][2];
+    i32x4 fxb[B1][2];
     auto read_xb = [&](const char* half) {
 #pragma unroll
-      for (int b = 0; b < 4; ++b) {
+      for (int b = 0; b < B1; ++b) {
         fxb[b][0] = *reinterpret_cast<const i32x4*>(half + b * 2048 + offx);
         fxb[b][1] = *reinterpret_cast<const i32x4*>(half + b * 2048 + (offx ^ 64));
       }
     };
-#define P8_MM(QX, QW, FW, FX, NR, READS)                                                 \
+#define P8_MM(QX, QW, FW, FX, NB, NR, READS)                                             \
     do {                                                                                 \
       __builtin_amdgcn_s_setprio(1);                                                     \
       READS;                                                                             \
       _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                   \
         _Pragma("unroll") for (int a = 0; a < 2; ++a)                                    \
-          _Pragma("unroll") for (int b = 0; b < 4; ++b)                                  \
+          _Pragma("unroll") for (int b = 0; b < (NB); ++b)                               \
             acc[(QW) * 2 + a][(QX) * 4 + b] = MFMA_BF16(FW[a][ks], FX[b][ks], acc[(QW) * 2 + a][(QX) * 4 + b]); \
       _Pragma("unroll") for (int i = 0; i < (NR); ++i) {                                 \
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                               \
         __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                               \
       }                                                                                  \
-      __builtin_amdgcn_sched_group_barrier(0x008, 16 - (NR), 0);                         \
+      if (4 * (NB) - (NR) > 0) __builtin_amdgcn_sched_group_barrier(0x008, 4 * (NB) - (NR) > 0 ? 4 * (NB) - (NR) : 1, 0); \
       __builtin_amdgcn_s_setprio(0);                                                     \
       if ((NR) > 0) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                   \
     } while (0)
@@ -218,12 +224,12 @@ __global__ void __launch_bounds__(512, 2) conv_igemm256_p8_kernel(Conv256Args p)
       if (n1) stage_x(1, d ^ 1);
       st_advance();
       P8_BAR();
-      P8_MM(0, 0, fw0, fx, 4, read_w(buf + SW1, fw1));
+      P8_MM(0, 0, fw0, fx, 4, 4, read_w(buf + SW1, fw1));
       P8_BAR();
       // phase 1
       if (n2) stage_x(0, d);
       P8_BAR();
-      P8_MM(0, 1, fw1, fx, 8, read_xb(buf + SX1));
+      P8_MM(0, 1, fw1, fx, 4, 2 * B1, read_xb(buf + SX1));
       P8_BAR();
       // phase 2
       if (n2) {
@@ -233,12 +239,12 @@ __global__ void __launch_bounds__(512, 2) conv_igemm256_p8_kernel(Conv256Args p)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       }
       P8_BAR();
-      P8_MM(1, 0, fw0, fxb, 0, (void)0);
+      P8_MM(1, 0, fw0, fxb, B1, 0, (void)0);
       P8_BAR();
       // phase 3 (after the last k-tile the reads fetch stale, in-bounds LDS that nobody uses)
       if (n2) stage_w(1, d);
       P8_BAR();
-      P8_MM(1, 1, fw1, fxb, 12, read_w(bnx + SW0, fw0); read_x(bnx + SX0));
+      P8_MM(1, 1, fw1, fxb, B1, 12, read_w(bnx + SW0, fw0); read_x(bnx + SX0));
       P8_BAR();
     }
     if (grp == 0) P8_BAR();
@@ -307,7 +313,7 @@ __global__ void __launch_bounds__(512, 2) conv_igemm256_p8_kernel(Conv256Args p)
   if constexpr (sizeof(TO) == 2) {
     if ((p.ldy & 7) == 0) {          // row-major epilogue through a wave-private LDS scratch (conv_epilogue.h)
       __syncthreads();               // every wave is done with the operand stages
-      epilogue_rows_bf16<4, 8>(acc, smem + wid * EpiCfg<4>::BYTES, m0 + wm * 128, n0 + wn * 64, p, lane);
+      epilogue_rows_bf16<4, FBT>(acc, smem + wid * EpiCfg<4>::BYTES, m0 + wm * (FBT * 16), n0 + wn * 64, p, lane);
       return;
     }
   }
@@ -316,8 +322,8 @@ __global__ void __launch_bounds__(512, 2) conv_igemm256_p8_kernel(Conv256Args p)
   const TO* __restrict__ Mk = (const TO*)p.mask_ref;
   bool plain = (p.oy_mul == 1 && p.OHf == p.OH && p.OWf == p.OW);
 #pragma unroll
-  for (int b = 0; b < 8; ++b) {
-    int m = m0 + wm * 128 + b * 16 + frow;
+  for (int b = 0; b < FBT; ++b) {
+    int m = m0 + wm * (FBT * 16) + b * 16 + frow;
     if (m >= p.M) continue;
     long off;
     if (plain) off = (long)m * p.ldy;
@@ -353,23 +359,24 @@ __global__ void __launch_bounds__(512, 2) conv_igemm256_p8_kernel(Conv256Args p)
   }
 }
 
-template <typename TO, bool RM>
+template <typename TO, bool RM, int B1>
 static int launch256_p8(Conv256Args& a, hipStream_t st) {
-  a.tiles_m = cdiv(a.M, 256); a.tiles_n = cdiv(a.K, 256);
+  a.tiles_m = cdiv(a.M, 32 * (4 + B1)); a.tiles_n = cdiv(a.K, 256);
   size_t lds = 8 * 128 * 128;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)conv_igemm256_p8_kernel<TO, RM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)conv_igemm256_p8_kernel<TO, RM, B1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
-  conv_igemm256_p8_kernel<TO, RM><<<a.tiles_m * a.tiles_n, 512, lds, st>>>(a);
+  conv_igemm256_p8_kernel<TO, RM, B1><<<a.tiles_m * a.tiles_n, 512, lds, st>>>(a);
   UNIT_LAUNCH_CHECK();
   return UNIT_OK;
 }
 
-int unit_conv256_p8_launch(Conv256Args& a, int out_dtype, bool reads_in_mfma, hipStream_t st) {
-  if (out_dtype == UNIT_BF16) return reads_in_mfma ? launch256_p8<bf16_t, true>(a, st) : launch256_p8<bf16_t, false>(a, st);
-  if (out_dtype == UNIT_F32) return reads_in_mfma ? launch256_p8<float, true>(a, st) : launch256_p8<float, false>(a, st);
+int unit_conv256_p8_launch(Conv256Args& a, int out_dtype, bool reads_in_mfma, bool rows224, hipStream_t st) {
+  if (rows224 && !reads_in_mfma) { unit_set_error("conv_big: 224-row tiles need the reads-in-MFMA schedule"); return UNIT_ERR_UNSUPPORTED; }
+  if (out_dtype == UNIT_BF16) return rows224 ? launch256_p8<bf16_t, true, 3>(a, st) : reads_in_mfma ? launch256_p8<bf16_t, true, 4>(a, st) : launch256_p8<bf16_t, false, 4>(a, st);
+  if (out_dtype == UNIT_F32) return rows224 ? launch256_p8<float, true, 3>(a, st) : reads_in_mfma ? launch256_p8<float, true, 4>(a, st) : launch256_p8<float, false, 4>(a, st);
   unit_set_error("conv_big: unsupported out dtype");
   return UNIT_ERR_UNSUPPORTED;
 }
