@@ -220,7 +220,8 @@ def main():
                     traffic = json.load(open(tpath)).get(key + "_kernel", {}).get("hbm_bytes_per_launch")
                 except Exception:
                     traffic = None
-            out["roofline"] = {"kernel": key + "_kernel (implicit-GEMM conv fwd/dgrad, bf16 MFMA 16x16x32, 256x256x64 LDS-DMA tiles)",
+            out["roofline"] = {"kernel": ("conv_igemm256_p8_kernel" if key == "conv_igemm256" else key + "_kernel") +
+                                         " (implicit-GEMM conv fwd/dgrad, bf16 MFMA 16x16x32, 256x256x64 LDS-DMA tiles)",
                                "bound": "mfma", "achieved": r["tflops"], "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                                "frac": round(r["tflops"] / MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
                                "launches_per_step": r["launches_per_step"], "avg_launch_us": r["avg_launch_us"],
