@@ -37,7 +37,11 @@ int unit_add_cast(const float* a32, const void* b, const void* mask_ref, void* y
 int unit_conv2d_fwd(const void* x, const void* w, void* y, const float* bias, const void* residual, const void* mask_ref,
                     int in_dtype, int out_dtype, int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int OH,
                     int OW, int ldy, int oy_mul, int OHf, int OWf, int relu, int tile_cfg, void* stream);
-/* large-tile variant (256x256x64, 8 waves, LDS-DMA operand staging) for the big-M layers; bf16 inputs, C % 64 == 0 */
+/* large-tile variant (256x256x64, 8 waves, LDS-DMA operand staging) for the big-M layers; bf16 inputs, C % 64 == 0.
+ * variant: 0 = default (= 8); 8 = four phases per k-tile, half-tile staging under a counted vmcnt, fragment reads inside the
+ * MFMA sections (csrc/conv_igemm256p8.hip); 7 = 8 without the reads-in-MFMA step; 9 = 8 on 224-row tiles; 10 = 224 or 256
+ * rows, whichever needs fewer rounds x rows; 4 = two-stage loop (csrc/conv_igemm256.hip), 1 / 2 / 3 / 5 / 6 = its ping-pong,
+ * 4 x 32-k, 224-row, auto-row and shared-input-super-tile (3x3 s1 p1 on 7x7 maps) forms. All variants: identical results. */
 int unit_conv2d_fwd_big(const void* x, const void* w, void* y, const float* bias, const void* residual, const void* mask_ref,
                         int out_dtype, int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int OH, int OW, int ldy,
                         int oy_mul, int OHf, int OWf, int relu, int variant, void* stream);
