@@ -51,19 +51,36 @@ class WeakDetectorOutputsBase(nn.Module):
         self.group.prepare(dtype, version)
 
     # ---- a12: WeakDetectorOutputsBase.losses weak_detector_fast_rcnn.py:189-255 (fused fwd + gradient into `dy`)
-    def losses(self, lin, rois5, valid, rois_per_image, n_images, multihot, loss_out, grad_dtype):
-        """lin fp32 [Rw, kp] = fused Linear outputs on the weak RoIs. Returns dy [Rw, kp] (grad_dtype)."""
+    def losses(self, lin, rois5, valid, rois_per_image, n_images, multihot, loss_out, grad_dtype, side_stream=None):
+        """lin fp32 [Rw, kp] = fused Linear outputs on the weak RoIs. Returns dy [Rw, kp] (grad_dtype).
+        Only OICR iteration 0 needs the MIL output x_r; iterations >= 1 take their pseudo-GT from softmax(oicr_{k-1} logits),
+        which are forward outputs: with `side_stream` they run beside the (single-workgroup-per-image, latency-bound) MIL
+        kernel instead of behind it. Every launch writes its own columns of dy / its own loss slot."""
         k = self.num_classes
         dy = torch.zeros((lin.shape[0], self.group.kp), dtype=grad_dtype, device=lin.device)
-        _, xr = ops.wsddn_mil(lin, self.col_cls, self.col_det, k, valid, rois_per_image, n_images, multihot, self.classifier_temp,
-                              self.detector_temp, self.mil_multiplier, dy=dy, dyc0=self.col_cls, dyd0=self.col_det, loss_out=loss_out[0:1])
-        for it in range(self.oicr_iter):
+
+        def oicr(it, xr):
             if it == 0:
                 lab, wts = ops.oicr_targets(xr, 0, 0, k, rois5, valid, rois_per_image, n_images, multihot, self.fg_threshold, self.bg_threshold)
             else:
                 lab, wts = ops.oicr_targets(lin, self.col_oicr[it - 1], 1, k, rois5, valid, rois_per_image, n_images, multihot,
                                             self.fg_threshold, self.bg_threshold)
             ops.softmax_ce(lin, self.col_oicr[it], k + 1, lab, weights=wts, dy=dy, dcol0=self.col_oicr[it], loss_out=loss_out[1 + it:2 + it])
+
+        if side_stream is not None and self.oicr_iter > 1:
+            main = torch.cuda.current_stream()
+            side_stream.wait_stream(main)                    # dy zeroed, lin complete
+            with torch.cuda.stream(side_stream):
+                for it in range(1, self.oicr_iter):
+                    oicr(it, None)
+        _, xr = ops.wsddn_mil(lin, self.col_cls, self.col_det, k, valid, rois_per_image, n_images, multihot, self.classifier_temp,
+                              self.detector_temp, self.mil_multiplier, dy=dy, dyc0=self.col_cls, dyd0=self.col_det, loss_out=loss_out[0:1])
+        oicr(0, xr)
+        if side_stream is not None and self.oicr_iter > 1:
+            torch.cuda.current_stream().wait_stream(side_stream)
+        else:
+            for it in range(1, self.oicr_iter):
+                oicr(it, None)
         return dy
 
 

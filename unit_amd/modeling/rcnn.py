@@ -11,6 +11,8 @@ Batching: the supervised and the weak images of a step go through the backbone a
 (rcnn.py:439,452 run the backbone twice; same arithmetic per image), the supervised and weak RoIs go through RoIAlign
 and `weak_box_head` as ONE batch (roi_heads.py:499-513).
 """
+import contextlib
+
 import torch
 from torch import nn
 
@@ -405,6 +407,7 @@ class WeaklySupervisedRCNNNoMeta(nn.Module):
         # a10-a12 predictors + losses (+ gradients w.r.t. the Linear outputs)
         lin_weak_all = bp.weak_detector_head.group.fwd(wfeat_all)            # [rs+rw, 104] (oicr cols feed the sup scores)
         c.dy_sup = c.dy_weak = None
+        sup_side = None
         if rs > 0:
             lin_sup = bp.group.fwd(c.box_feat)
             if getattr(bp, "finetune", False):
@@ -422,10 +425,18 @@ class WeaklySupervisedRCNNNoMeta(nn.Module):
                                                           ft=lin_ft, fccol0=bp.col_cls, fbcol0=bp.col_bbox)
                 c.dy_sup = bp.ft_losses(c.scores, bbox, c.roi_cls, c.rois[:rs], c.roi_gt, c.losses[0:2], dt)
             else:
-                c.dy_sup, c.scores = bp.sup_losses(lin_sup, lin_weak_all[:rs], c.roi_cls, c.rois[:rs], c.roi_gt, c.losses[0:2], dt)
+                # the supervised losses (5 small launches) do not depend on the weak chain: they run on the head stream beside it
+                sup_side = self._head_stream if (rw > 0 and self._streams_on()) else None
+                if sup_side is not None:
+                    sup_side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(sup_side) if sup_side is not None else contextlib.nullcontext():
+                    c.dy_sup, c.scores = bp.sup_losses(lin_sup, lin_weak_all[:rs], c.roi_cls, c.rois[:rs], c.roi_gt, c.losses[0:2], dt)
         if rw > 0:
             c.dy_weak = bp.weak_detector_head.losses(lin_weak_all[rs:], c.rois[rs:], c.weak_valid, s // rh.weak_divisor, n_weak,
-                                                     batch.multihot, c.losses[2:6], dt)
+                                                     batch.multihot, c.losses[2:6], dt,
+                                                     side_stream=self._rpn_stream if self._streams_on() else None)
+        if sup_side is not None:
+            torch.cuda.current_stream().wait_stream(sup_side)
         return c
 
     # ------------------------------------------------------------------ the training step: backward plan
