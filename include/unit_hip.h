@@ -23,6 +23,16 @@ const char* unit_last_error(void);
 /* ---- a1 preprocess_image: modeling/meta_arch/rcnn.py:257-266 (+ ImageList.from_tensors zero padding) ---- */
 int unit_preprocess_image(const float* img_chw, int C, int H, int W, const float* mean3, const float* std3, float prescale,
                           void* out_nhwc, int out_dtype, int Hmax, int Wmax, int Cpad, void* stream);
+/* ---- input pipeline on the device: data/dataset_mapper.py:13-31, data/build.py:476-497 -> Detectron2
+ * DatasetMapper = ResizeShortestEdge (Pillow BILINEAR on uint8 HWC) + RandomFlip, image.astype(float32) CHW.
+ * unit_resize_u8_pass: one pass of Pillow's 8-bit resampler (src/libImaging/Resample.c) along axis 1 (x) or 0 (y); bounds
+ * [out][2] = (first source index, taps), kk [out][ksize] 22-bit fixed-point taps, both device int32, computed by the caller
+ * exactly as Pillow does (unit_amd/data_pipeline.py). Horizontal pass first, then vertical, through a uint8 intermediate.
+ * unit_preprocess_u8: unit_preprocess_image for a uint8 HWC source with an optional horizontal flip. */
+int unit_resize_u8_pass(const unsigned char* src, int H, int W, int C, int axis, const int* bounds, const int* kk, int ksize,
+                        int out_size, unsigned char* dst, void* stream);
+int unit_preprocess_u8(const unsigned char* img_hwc, int C, int H, int W, int hflip, const float* mean3, const float* std3,
+                       float prescale, void* out_nhwc, int out_dtype, int Hmax, int Wmax, int Cpad, void* stream);
 /* NCHW fp32 <-> NHWC converters for the plugin boundary (reference tensors are NCHW fp32) */
 int unit_nchw_to_nhwc(const float* x, void* y, int dtype, int N, int C, int H, int W, int Cp, void* stream);
 int unit_nhwc_to_nchw(const void* x, int dtype, float* y, int N, int C, int H, int W, int Cp, void* stream);
