@@ -349,6 +349,29 @@ def test_trainers_run_steps_bf16(dev):
     assert model.roi_heads.box_predictor.cls_score_ft.weight.abs().sum() > 0      # zero-initialised, moved by SGD
 
 
+def test_early_bucket_update_is_bit_identical(dev):
+    """the per-bucket optimizer update launched from inside the backward plan (its own stream, as soon as a bucket's gradients
+    are final) leaves exactly the parameters and momentum buffers of the single update after the backward"""
+    from unit_amd import engine
+    outs = []
+    for early in (True, False):
+        cfg = small_cfg()
+        model = build_model(cfg)
+        init_synthetic_weights(model, seed=3)
+        model.train()
+        torch.manual_seed(0)
+        torch.cuda.manual_seed(0)
+        tr = engine.TrainerNoMeta(cfg, model, early_update=early)
+        assert (model.on_bucket_final is not None) == early
+        for it in range(3):
+            sup, weak = synthetic_batch(2, 2, hw=(128, 192), seed=7 + it, max_gt=4)
+            losses = tr.run_step(sup, weak)
+        torch.cuda.synchronize()
+        outs.append((model.store.params.clone(), tr.optimizer._buf.clone(), losses.clone()))
+        model.on_bucket_final = None
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1]) and torch.equal(outs[0][2], outs[1][2])
+
+
 def test_s1_step_vs_committed_golden(dev):
     """HIP path (fp32 mode) against the committed end-to-end fixture tests/golden/step_golden.npz -- no oracle run here."""
     import importlib.util

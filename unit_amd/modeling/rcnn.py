@@ -78,6 +78,7 @@ class WeaklySupervisedRCNNNoMeta(nn.Module):
         self._anchor = None
         self._gen = None
         self.on_grad_ready = None  # data-parallel hook: called with a stage name as soon as its gradients are final
+        self.on_bucket_final = None  # optimizer hook (tag, stream): the bucket's gradients are final once `stream` reaches this point
         self.use_multi_tensor_plan = True
         self.plan = None
         self.overlap_streams = True
@@ -451,16 +452,20 @@ class WeaklySupervisedRCNNNoMeta(nn.Module):
         side = self._wgrad_stream if self._streams_on() else None
         ops.WGRAD_STREAM = side if plan is not None else None
 
+        final = self.on_bucket_final
+
         def done(tag):
             if side is not None:
                 # the bucket's wgrad kernels ran on the side stream: reduce its slabs (and launch its all-reduce) THERE, so
                 # that the main stream's dgrad chain never waits for weight gradients; the streams join before the optimizer
-                if hook is not None:
+                if hook is not None or final is not None:
                     side.wait_stream(torch.cuda.current_stream())      # bias / Linear gradients of the bucket come from main
                 with torch.cuda.stream(side):
                     plan.reduce(tag)     # split-M slabs of this bucket -> flat gradient buffer (one launch)
                     if hook is not None:
                         hook(tag)        # data parallel: launch the bucket's all-reduce
+                if final is not None:
+                    final(tag, side)     # the bucket's gradients are final once `side` gets here: its optimizer update may start
                 return
             if plan is not None:
                 plan.reduce(tag)

@@ -18,6 +18,7 @@ class GradBuckets:
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.bucket_elems = bucket_bytes // 4
         self._works = []
+        self._tag_works = {}
         self._plan = None
         model.on_grad_ready = self.ready if self.world > 1 else None    # single process: nothing to launch per bucket
 
@@ -47,13 +48,21 @@ class GradBuckets:
             self._build()
         g = self.model.store.grads
         for a, b in self._plan.get(tag, []):
-            self._works.append(dist.all_reduce(g[a:b], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+            w = dist.all_reduce(g[a:b], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            self._works.append(w)
+            self._tag_works.setdefault(tag, []).append(w)
+
+    def wait_tag(self, tag):
+        """make the CURRENT stream wait for the all-reduces of one bucket (early per-bucket optimizer update)"""
+        for w in self._tag_works.pop(tag, []):
+            w.wait()
 
     def finish(self):
         """make the compute stream wait for every outstanding bucket (no host sync)."""
         for w in self._works:
             w.wait()
         self._works = []
+        self._tag_works = {}
 
     @property
     def grad_scale(self):

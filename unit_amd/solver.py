@@ -54,6 +54,7 @@ class FlatSGD:
         self._store = None
         self._segments = None
         self._buf = None
+        self._early = set()
 
     def _bind(self):
         st = self.model.store
@@ -69,12 +70,36 @@ class FlatSGD:
     def zero_grad(self, set_to_none=False):
         pass   # wgrad kernels overwrite the flat gradient buffer every step
 
-    def step(self):
-        st = self._bind()
+    def _apply(self, st, lo, hi):
+        """SGD-momentum on the flat range [lo, hi), cut at the hyper-parameter segment borders (solver/build.py:85-107 groups)"""
         lr = self.schedule(self.iter)
         for off, n, (lr_mult, wd) in self._segments:
-            ops.sgd_momentum(st.params[off:off + n], st.grads[off:off + n], self._buf[off:off + n], lr * lr_mult, self.momentum, wd,
-                             self.grad_scale, first_step=self._first)
+            a, b = max(off, lo), min(off + n, hi)
+            if a < b:
+                ops.sgd_momentum(st.params[a:b], st.grads[a:b], self._buf[a:b], lr * lr_mult, self.momentum, wd,
+                                 self.grad_scale, first_step=self._first)
+
+    def step_tag(self, tag):
+        """update the parameters of one gradient bucket as soon as its gradients are final (called from the backward plan on the
+        optimizer stream); `step()` then only covers what is left. Same kernel, same arithmetic, another launch partition."""
+        st = self._bind()
+        for t, a, b in st.tags:
+            if t == tag and (a, b) not in self._early:
+                self._apply(st, a, b)
+                self._early.add((a, b))
+
+    def step(self):
+        st = self._bind()
+        if self._early:
+            done = sorted(self._early)
+            lo = 0
+            for a, b in done + [(st.size, st.size)]:
+                if lo < a:
+                    self._apply(st, lo, a)
+                lo = max(lo, b)
+            self._early = set()
+        else:
+            self._apply(st, 0, st.size)
         self._first = False
         self.iter += 1
         self.model.after_optimizer_step()
