@@ -234,13 +234,16 @@ def test_wgrad_big_tile_kernel(dev, case):
     assert torch.allclose(got, ref, rtol=2e-2, atol=2e-2 * ref.abs().max().item()), (got - ref).abs().max() / ref.abs().max()
     # tight check against the 128x128 kernel's summation (same bf16 products, fp32 accumulation: only the order differs)
     assert (got - ref).abs().max() <= 2e-3 * ref.abs().max()
-    # the phase-interleaved 256x256 kernel accumulates in the same order: identical bits
-    o.wgrad_big_variant(0)
+    # the other schedules of the 256x256 tile (0 = phase-interleaved, 1 = two-stage, 2 = ring of four 32-pixel stages) accumulate
+    # in the same order: identical bits
+    prev = o.wgrad_big_variant(0)
     try:
-        dw1 = o.conv2d_wgrad(nhwc(x).to(dev).bfloat16(), nhwc(dy).to(dev).bfloat16(), k, r, r, stride, pad, scale=scale.to(dev))
+        for v in (0, 1, 2):
+            o.wgrad_big_variant(v)
+            dw1 = o.conv2d_wgrad(nhwc(x).to(dev).bfloat16(), nhwc(dy).to(dev).bfloat16(), k, r, r, stride, pad, scale=scale.to(dev))
+            assert torch.equal(dw.cpu(), dw1.cpu()), v
     finally:
-        o.wgrad_big_variant(1)
-    assert torch.equal(dw.cpu(), dw1.cpu())
+        o.wgrad_big_variant(prev)
 
 
 def test_pools_bias_misc(dev):

@@ -18,5 +18,29 @@ struct Wgrad256Args {
 typedef __attribute__((address_space(3))) void lds_void_w;
 typedef __attribute__((ext_vector_type(8))) short s16x8_w;
 
-// conv_wgrad256p8.hip
+// conv_wgrad256p8.hip / conv_wgrad256r.hip
 int unit_wgrad256_p8_launch(const Wgrad256Args& a, hipStream_t st);
+int unit_wgrad256_ring_launch(const Wgrad256Args& a, hipStream_t st);
+
+// ds_read_b64_tr_b16 through inline asm. Reason: hipcc (ROCm 7.2) puts `s_waitcnt vmcnt(0)` in front of the first
+// __builtin_amdgcn_ds_read_tr16_b64 of every step when LDS-DMA loads are in flight (the intrinsic carries no alias information,
+// so the waitcnt pass assumes it may read what the DMA is still writing) -- which silently removes the whole prefetch: every
+// step then waits for the stage it has just issued. The asm form is invisible to that pass; the price is that its result is
+// not tracked by lgkmcnt either: callers MUST pass the fragments through tr_wait() before the first use.
+__device__ __forceinline__ s16x4 ds_tr16(const char* p) {
+  s16x4 v;
+  unsigned a = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const char*)p;
+  asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(v) : "v"(a) : "memory");
+  return v;
+}
+// s_waitcnt lgkmcnt(0) that the consumers of the listed fragments depend on (so no MFMA can be scheduled above it)
+template <int N>
+__device__ __forceinline__ void tr_wait(bf16x8 (&f)[N]) {
+  static_assert(N == 4 || N == 8 || N == 2, "fragment array size");
+  if constexpr (N == 8)
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]), "+v"(f[4]), "+v"(f[5]), "+v"(f[6]), "+v"(f[7]) :: "memory");
+  else if constexpr (N == 4)
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]) :: "memory");
+  else
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f[0]), "+v"(f[1]) :: "memory");
+}

@@ -19,8 +19,8 @@ __device__ __forceinline__ bf16x8 tr_frag(const char* tile, int sub, int col0, i
   int row = 32 * sub + 4 * g + q;
   int sw = (((col0 >> 4) ^ (row & 7)) << 5) + 8 * pq;      // (row + 16) & 7 == row & 7
   const char* a0 = tile + row * 512 + sw;
-  s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a0));
-  s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a0 + 16 * 512));
+  s16x4 lo = ds_tr16(a0);
+  s16x4 hi = ds_tr16(a0 + 16 * 512);
   s16x8_w v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
   return __builtin_bit_cast(bf16x8, v);
 }
@@ -118,6 +118,7 @@ __global__ void __launch_bounds__(512, 2) conv_wgrad256_kernel(Wgrad256Args p) {
       for (int a = 0; a < 8; ++a) fa[a] = tr_frag(bx, sub, wk * 128 + a * 16, lane);
 #pragma unroll
       for (int b = 0; b < 4; ++b) fb[b] = tr_frag(bd, sub, wn * 64 + b * 16, lane);
+      tr_wait(fa); tr_wait(fb);
       __builtin_amdgcn_s_setprio(1);
 #pragma unroll
       for (int a = 0; a < 8; ++a)
@@ -142,14 +143,15 @@ __global__ void __launch_bounds__(512, 2) conv_wgrad256_kernel(Wgrad256Args p) {
   }
 }
 
-// 1 (default): the two-stage kernel above; 0: the phase-interleaved kernel of conv_wgrad256p8.hip. Measured (tools/wgrad_bench.py,
-// tools/exp_w8.sh): unlike the forward kernel, whose weight tile is L2-hot and whose pixel tile is shared by the channel
-// tiles, every workgroup here streams rows that are fetched from HBM / Infinity Cache exactly once per XCD (FETCH_SIZE =
-// the compulsory 245 MB on the 512->2048 layer), so the loop is bound by miss latency x the ~64-80 KB of LDS that can be in
-// flight per CU, not by LDS-DMA issue or fragment reads: the interleaved schedule is 5-20 % SLOWER (its staging is spread
-// thinner, and its L sections carry the im2col index arithmetic), 1.3 PF-equivalent with the DMA removed. Kept selectable
-// as the bit-exactness cross-check of the tests.
-static int g_wgrad_big_variant = 1;
+// Schedules of this tile (all bit-identical): 1 = the two-stage kernel above; 0 = phase-interleaved (conv_wgrad256p8.hip);
+// 2 = ring of four 32-pixel stages with a counted vmcnt (conv_wgrad256r.hip); 3 (default) = 0 for pointwise layers (1x1,
+// stride 1: no im2col index arithmetic in the staging), 2 otherwise.
+// History worth keeping: until the transposing reads went through inline asm (conv_wgrad256.h, ds_tr16) hipcc put
+// `s_waitcnt vmcnt(0)` in front of the first __builtin_amdgcn_ds_read_tr16_b64 of every step -- each step waited for the stage
+// it had just issued, so no schedule could prefetch, the loop looked "bound by miss latency" (147 us -> 81 us with the DMA
+// removed) and the interleaved schedules measured SLOWER than the two-stage loop. With the wait gone (tools/wgrad_bench.py):
+// 512->2048: two-stage 139 -> 121 us, ring 115, interleaved 113; 2048->512: 139 -> 126 / 112 / 103 us.
+static int g_wgrad_big_variant = 3;
 extern "C" int unit_wgrad_big_variant(int v) { int old = g_wgrad_big_variant; g_wgrad_big_variant = v; return old; }
 
 // shared with conv_wgrad.hip: which kernel handles a shape, and with how many split-M slabs
@@ -193,8 +195,14 @@ extern "C" int unit_conv2d_wgrad_big_launch(const void* x, const void* dy, float
   a.m_per_split = cdiv(mps, 64) * 64;
   size_t need = (size_t)a.splits * K * a.Kgemm * sizeof(float);
   if (workspace_bytes < need) { unit_set_error("wgrad_big: workspace too small"); return UNIT_ERR_WORKSPACE; }
-  if (g_wgrad_big_variant == 0) {
+  int variant = g_wgrad_big_variant;
+  if (variant == 3) variant = (R == 1 && S == 1 && stride == 1 && pad == 0) ? 0 : 2;
+  if (variant == 0) {
     int rc = unit_wgrad256_p8_launch(a, (hipStream_t)stream);
+    return rc == UNIT_OK ? a.splits : rc;
+  }
+  if (variant == 2) {
+    int rc = unit_wgrad256_ring_launch(a, (hipStream_t)stream);
     return rc == UNIT_OK ? a.splits : rc;
   }
   size_t lds = 2 * 2 * 64 * 512;

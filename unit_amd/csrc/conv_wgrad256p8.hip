@@ -123,8 +123,8 @@ __global__ void __launch_bounds__(512, 2) conv_wgrad256_p8_kernel(Wgrad256Args p
   }
   auto frag = [&](const char* half, int off, int sub) -> bf16x8 {
     const char* a0 = half + off + sub * 8192;
-    s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a0));
-    s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a0 + 4096));
+    s16x4 lo = ds_tr16(a0);
+    s16x4 hi = ds_tr16(a0 + 4096);
     s16x8_w v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
     return __builtin_bit_cast(bf16x8, v);
   };

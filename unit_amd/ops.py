@@ -195,8 +195,8 @@ def conv2d(x, w, k, r, s, stride=1, pad=0, bias=None, residual=None, mask_ref=No
 
 
 def wgrad_big_variant(v):
-    """1 = two-stage 256x256 weight-gradient kernel (default), 0 = phase-interleaved schedule (slower here; bit-exactness cross-check)"""
-    lib().unit_wgrad_big_variant(int(v))
+    """schedule of the 256x256 weight-gradient tile: 3 = auto (default), 0 = phase-interleaved, 1 = two-stage, 2 = ring; returns the previous one"""
+    return lib().unit_wgrad_big_variant(int(v))
 
 
 def conv2d_wgrad(x, dy, k, r, s, stride=1, pad=0, scale=None, out=None, accumulate=False, ldy=None):
