@@ -69,7 +69,7 @@ int unit_conv2d_wgrad(const void* x, const void* dy, float* dw, const float* sca
  * descs_dev: array of {const float* partial, *scale; void* wf, *wd; long offset; int splits,K,R,S,C,block0} (64 B each) */
 int unit_conv2d_wgrad_splits(int in_dtype, int N, int OH, int OW, int K, int R, int S, int C);
 /* big-M bf16 layers (C % 256 == 0, K % 256 == 0, M >= 16384) use a 256x256 tile: 3 (default) = phase-interleaved schedule
- * (csrc/conv_wgrad256p8.hip) for pointwise layers, ring of four 32-pixel stages (csrc/conv_wgrad256r.hip) otherwise; 0 / 2 force
+ * (csrc/conv_wgrad256p8.hip) for pointwise layers and maps of <= 1024 pixels, ring of four 32-pixel stages (csrc/conv_wgrad256r.hip) otherwise; 0 / 2 force
  * one of them, 1 = two-stage loop (csrc/conv_wgrad256.hip); same slabs bit for bit. Process-wide, not thread-safe. */
 int unit_wgrad_big_variant(int v);   /* returns the previous setting */
 size_t unit_tensor_desc_bytes(void);

@@ -144,8 +144,8 @@ __global__ void __launch_bounds__(512, 2) conv_wgrad256_kernel(Wgrad256Args p) {
 }
 
 // Schedules of this tile (all bit-identical): 1 = the two-stage kernel above; 0 = phase-interleaved (conv_wgrad256p8.hip);
-// 2 = ring of four 32-pixel stages with a counted vmcnt (conv_wgrad256r.hip); 3 (default) = 0 for pointwise layers (1x1,
-// stride 1: no im2col index arithmetic in the staging), 2 otherwise.
+// 2 = ring of four 32-pixel stages with a counted vmcnt (conv_wgrad256r.hip); 3 (default) = 0 whenever its staging needs no
+// per-step divisions (pointwise layers, or maps of <= 1024 pixels whose im2col offsets come from its LDS table), 2 otherwise.
 // History worth keeping: until the transposing reads went through inline asm (conv_wgrad256.h, ds_tr16) hipcc put
 // `s_waitcnt vmcnt(0)` in front of the first __builtin_amdgcn_ds_read_tr16_b64 of every step -- each step waited for the stage
 // it had just issued, so no schedule could prefetch, the loop looked "bound by miss latency" (147 us -> 81 us with the DMA
@@ -196,7 +196,7 @@ extern "C" int unit_conv2d_wgrad_big_launch(const void* x, const void* dy, float
   size_t need = (size_t)a.splits * K * a.Kgemm * sizeof(float);
   if (workspace_bytes < need) { unit_set_error("wgrad_big: workspace too small"); return UNIT_ERR_WORKSPACE; }
   int variant = g_wgrad_big_variant;
-  if (variant == 3) variant = (R == 1 && S == 1 && stride == 1 && pad == 0) ? 0 : 2;
+  if (variant == 3) variant = ((R == 1 && S == 1 && stride == 1 && pad == 0) || OH * OW <= 1024) ? 0 : 2;
   if (variant == 0) {
     int rc = unit_wgrad256_p8_launch(a, (hipStream_t)stream);
     return rc == UNIT_OK ? a.splits : rc;

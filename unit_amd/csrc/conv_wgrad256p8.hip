@@ -68,15 +68,56 @@ __global__ void __launch_bounds__(512, 2) conv_wgrad256_p8_kernel(Wgrad256Args p
       dcol[q] = (unsigned)(n0 + (hcol >> 5) * 64 + q * 32 + (hcol & 31));
     }
   }
+  // im2col rows without per-step divisions: the (n, pixel-in-image) pair of each of this lane's two piece rows is carried
+  // incrementally (+64 pixels per step) and a small LDS table maps the pixel to its input offset for THIS workgroup's filter
+  // tap ((ih*W + iw)*C, or -1 outside the map). Table after the operand stages (OHW <= 1024 entries; larger maps divide).
+  int* tab = reinterpret_cast<int*>(smem + 2 * BUF);
+  const bool use_tab = !pointwise && p.OHW <= 1024;
+  int xn[2] = {0, 0}, xp[2] = {0, 0};
+  const int adv_q = MS / p.OHW, adv_r = MS - adv_q * p.OHW;
+  if (use_tab) {
+    for (int px = tid; px < p.OHW; px += 512) {
+      int oh = px / p.OW, ow = px - oh * p.OW;
+      int ih = oh * p.stride - p.pad + kr, iw = ow * p.stride - p.pad + ksx;
+      tab[px] = ((unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W) ? (ih * p.W + iw) * p.C : -1;
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      unsigned um = (unsigned)(m_begin + s_row[j]);
+      unsigned n = um / (unsigned)p.OHW;
+      xn[j] = (int)n; xp[j] = (int)(um - n * (unsigned)p.OHW);
+    }
+    __syncthreads();
+  }
+  auto x_advance = [&]() {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      xn[j] += adv_q; xp[j] += adv_r;
+      if (xp[j] >= p.OHW) { xp[j] -= p.OHW; xn[j] += 1; }
+    }
+  };
   auto stage_x = [&](int q, int d, int mstep) {
     char* base = smem + d * BUF + (q ? SX1 : SX0);
+    int tv[2] = {0, 0};
+    if (use_tab) {
+      // (asm: a plain LDS load here would make hipcc drain vmcnt in front of it, conv_wgrad256.h)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        unsigned a = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const char*)(tab + xp[j]);
+        asm volatile("ds_read_b32 %0, %1" : "=v"(tv[j]) : "v"(a) : "memory");
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(tv[0]), "+v"(tv[1]) :: "memory");
+    }
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       int m = mstep + s_row[j];
       bool ok = m < m_end;
       unsigned xoff;
       if (pointwise) xoff = ((unsigned)m * (unsigned)p.C + xcol[q]) * 2u;
-      else {
+      else if (use_tab) {
+        ok = ok && tv[j] >= 0;
+        xoff = ((unsigned)xn[j] * (unsigned)(p.H * p.W * p.C) + (unsigned)tv[j] + xcol[q]) * 2u;
+      } else {
         unsigned um = (unsigned)m, n, oh, ow;
         if (p.use_magic) {
           n = __umulhi(um, p.magic_ohw); unsigned rem = um - n * (unsigned)p.OHW;
@@ -172,7 +213,7 @@ __global__ void __launch_bounds__(512, 2) conv_wgrad256_p8_kernel(Wgrad256Args p
   if (nsteps > 0) {
     int mst = m_begin;
     stage_x(0, 0, mst); stage_d(0, 0, mst); stage_d(1, 0, mst); stage_x(1, 0, mst);
-    mst += MS;
+    mst += MS; x_advance();
     if (nsteps > 1) {
       stage_x(0, 1, mst); stage_d(0, 1, mst); stage_d(1, 1, mst);
       asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
@@ -195,7 +236,7 @@ __global__ void __launch_bounds__(512, 2) conv_wgrad256_p8_kernel(Wgrad256Args p
 #endif
       // phase 0
       if (n1) stage_x(1, d ^ 1, mst);
-      mst += MS;
+      mst += MS; x_advance();
       W8_BAR();
       W8_MM(0, 0, fx, fd0, 8, 1, W8_RD(W8_READ_D(buf + SD1, fd1)));
       W8_BAR();
@@ -254,7 +295,7 @@ __global__ void __launch_bounds__(512, 2) conv_wgrad256_p8_kernel(Wgrad256Args p
 }
 
 int unit_wgrad256_p8_launch(const Wgrad256Args& a, hipStream_t st) {
-  size_t lds = 8 * 64 * 256;
+  size_t lds = 8 * 64 * 256 + 4096;      // operand stages + the pixel -> input offset table
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)conv_wgrad256_p8_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
