@@ -200,6 +200,34 @@ def test_conv_p8_kernel(dev, case, cfg):
     assert torch.equal(yf.cpu()[..., :k], y5.cpu()[..., :k])
 
 
+@pytest.mark.parametrize("case", [(4, 38, 63, 256, 256, 3, 1, 1), (4, 38, 63, 1024, 256, 1, 1, 0), (2, 75, 125, 128, 128, 3, 1, 1),
+                                  (3, 40, 50, 256, 512, 1, 2, 0), (5, 7, 9, 128, 256, 3, 1, 1), (1, 33, 40, 384, 128, 1, 1, 0)])
+def test_wgrad_ring128_kernel(dev, case):
+    """LDS-DMA ring form of the 128x128 weight-gradient tile (bf16, C % 128 == 0, K % 128 == 0: backbone / RPN shapes, incremental
+    and magic-division im2col, stride 2, narrow maps, ragged last stage) == autograd of F.conv2d, and bit-identical to the
+    register-staged kernel."""
+    o = ops()
+    n, h, w, c, k, r, stride, pad = case
+    gen = g(37)
+    x = torch.randn(n, c, h, w, generator=gen).bfloat16().float()
+    wt = torch.zeros(k, c, r, r, requires_grad=True)
+    y = F.conv2d(x, wt, None, stride=stride, padding=pad)
+    dy = torch.randn(y.shape, generator=gen).bfloat16().float()
+    y.backward(dy)
+    ref = wt.grad
+    xd, dyd = nhwc(x).to(dev).bfloat16(), nhwc(dy).to(dev).bfloat16()
+    prev = o.wgrad_mid_variant(0)
+    try:
+        dw0 = o.conv2d_wgrad(xd, dyd, k, r, r, stride, pad)
+        o.wgrad_mid_variant(1)
+        dw1 = o.conv2d_wgrad(xd, dyd, k, r, r, stride, pad)
+    finally:
+        o.wgrad_mid_variant(prev)
+    assert torch.equal(dw0.cpu(), dw1.cpu())
+    got = dw0.cpu().permute(0, 3, 1, 2)
+    assert (got - ref).abs().max() <= 2e-3 * ref.abs().max()
+
+
 def test_wgrad_big_m(dev):
     """M spans many split-M chunks and is not a multiple of the staging step."""
     o = ops()

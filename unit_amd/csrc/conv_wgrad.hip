@@ -8,6 +8,7 @@
 // The m-range is split across workgroups (split-M); partial fp32 slabs go to the workspace and unit_wgrad_reduce sums
 // them in a fixed order (bit-reproducible), applies the FrozenBN scale[n] fold and writes / accumulates dW [K][R][S][C].
 #include "common.h"
+#include "conv_wgrad256.h"
 
 struct WgradArgs {
   const void* x; const void* dy; float* partial;
@@ -205,6 +206,12 @@ extern "C" int unit_wgrad_big_splits(long M, int tiles);
 extern "C" int unit_conv2d_wgrad_big_launch(const void* x, const void* dy, float* partial, int N, int H, int W, int C, int K, int R, int S,
                                             int stride, int pad, int OH, int OW, int ldy, size_t workspace_bytes, void* stream);
 
+// 1 (default): the register-staged kernel below; 0: LDS-DMA ring kernel (conv_wgrad128r.hip) where it applies. Measured equal
+// on the backbone shapes (tools/wgrad128_bench.py: 18.2 vs 18.5 us, 31.9 vs 30.4 us; RPN 3x3 306 vs 284 us; step 18.4 vs 18.2 ms):
+// at M = 9 576 these launches are bound by their fp32 slab store and input streaming, not by the loop's load latency.
+static int g_wgrad_mid_variant = 1;
+extern "C" int unit_wgrad_mid_variant(int v) { int old = g_wgrad_mid_variant; g_wgrad_mid_variant = v; return old; }
+
 static int choose_splits(int M, int tiles, int ms) {
   // 2 workgroups of this kernel are co-resident per CU (72 KB LDS each): 512 slots per "round" on 256 CUs. Pick the
   // split count whose grid fills whole rounds best (tile quantisation), preferring fewer splits (less slab traffic).
@@ -276,7 +283,16 @@ extern "C" int unit_conv2d_wgrad(const void* x, const void* dy, float* dw, const
   size_t need = (size_t)a.splits * K * a.Kgemm * sizeof(float);
   if (workspace_bytes < need) { unit_set_error("wgrad: workspace too small"); return UNIT_ERR_WORKSPACE; }
   int grid = a.tiles_k * a.tiles_n * a.splits;
-  if (in_dtype == UNIT_BF16) {
+  // bf16 layers whose tiles are full (every trainable backbone / RPN conv): LDS-DMA ring kernel (conv_wgrad128r.hip), same slabs
+  if (in_dtype == UNIT_BF16 && C % 128 == 0 && K % 128 == 0 && g_wgrad_mid_variant == 0) {
+    Wgrad256Args b;
+    b.x = a.x; b.dy = a.dy; b.partial = a.partial; b.N = a.N; b.H = a.H; b.W = a.W; b.C = a.C; b.K = a.K; b.R = a.R; b.S = a.S;
+    b.stride = a.stride; b.pad = a.pad; b.OH = a.OH; b.OW = a.OW; b.ldy = a.ldy; b.Kgemm = a.Kgemm; b.M = a.M;
+    b.tiles_k = a.tiles_k; b.tiles_n = a.tiles_n; b.splits = a.splits; b.m_per_split = a.m_per_split;
+    b.x_bytes = a.x_bytes; b.dy_bytes = a.dy_bytes; b.magic_ohw = a.magic_ohw; b.magic_ow = a.magic_ow; b.OHW = a.OHW; b.use_magic = a.use_magic;
+    int rc = unit_wgrad128_ring_launch(b, st);
+    if (rc != UNIT_OK) return rc;
+  } else if (in_dtype == UNIT_BF16) {
     size_t lds = (size_t)2 * 2 * WgCfg<bf16_t>::MS * WgCfg<bf16_t>::ROWB;
     static bool set1 = false;
     if (!set1) { (void)hipFuncSetAttribute((const void*)conv_wgrad_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); set1 = true; }

@@ -21,6 +21,8 @@ typedef __attribute__((ext_vector_type(8))) short s16x8_w;
 // conv_wgrad256p8.hip / conv_wgrad256r.hip
 int unit_wgrad256_p8_launch(const Wgrad256Args& a, hipStream_t st);
 int unit_wgrad256_ring_launch(const Wgrad256Args& a, hipStream_t st);
+// conv_wgrad128r.hip: 128x128 tile, LDS-DMA ring (bf16, C % 128 == 0, K % 128 == 0)
+int unit_wgrad128_ring_launch(const Wgrad256Args& a, hipStream_t st);
 
 // ds_read_b64_tr_b16 through inline asm. Reason: hipcc (ROCm 7.2) puts `s_waitcnt vmcnt(0)` in front of the first
 // __builtin_amdgcn_ds_read_tr16_b64 of every step when LDS-DMA loads are in flight (the intrinsic carries no alias information,

@@ -199,6 +199,11 @@ def wgrad_big_variant(v):
     return lib().unit_wgrad_big_variant(int(v))
 
 
+def wgrad_mid_variant(v):
+    """128x128 weight-gradient tile: 1 = register-staged kernel (default), 0 = LDS-DMA ring kernel where it applies; returns the previous one"""
+    return lib().unit_wgrad_mid_variant(int(v))
+
+
 def conv2d_wgrad(x, dy, k, r, s, stride=1, pad=0, scale=None, out=None, accumulate=False, ldy=None):
     """x [N,H,W,C], dy [N,OH,OW,ldy] -> dw fp32 [k,r,s,C] (scale[k] folded)."""
     n, h, wd, c = x.shape
