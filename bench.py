@@ -38,6 +38,8 @@ def parse():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-overlap", action="store_true", help="single HIP stream for the whole run (profiling aid: every "
                     "kernel's rocprof duration is then that kernel alone)")
+    ap.add_argument("--early-update", action="store_true", help="per-bucket optimizer updates beside the backward instead of one "
+                    "update after it (engine.EarlyUpdate; measured 18.56 vs 18.43 ms per step: off by default)")
     return ap.parse_args()
 
 
@@ -127,11 +129,15 @@ def main():
     buckets = GradBuckets(model)
     buckets.broadcast_parameters()
     opt = FlatSGD(model, cfg, grad_scale=buckets.grad_scale)
+    from unit_amd.engine import EarlyUpdate
+    early = EarlyUpdate(model, buckets, opt) if args.early_update else None
 
     def one_step():
         step = model.forward_train(batch, early_backward=True)
         model.backward_train(step)
         buckets.finish()
+        if early is not None:
+            early.join()
         opt.step()
         return step.losses
 

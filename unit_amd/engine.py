@@ -18,8 +18,36 @@ def shard_batch(global_batch, rank, world):
     return global_batch[rank * k:(rank + 1) * k]
 
 
+class EarlyUpdate:
+    """Early per-bucket optimizer update: the SGD launches of a gradient bucket run on their own stream as soon as the bucket's
+    gradients are final (and, data parallel, all-reduced), beside the rest of the backward, instead of in a tail after it.
+    Bit-identical to the single update (tests/test_step_gpu.py). Call `join()` before `optimizer.step()`.
+    Off by default: on one GPU the memory-bound SGD launches take as much from the concurrent backward kernels as the shorter
+    tail gives back (18.56 vs 18.43 ms per step, bench.py --early-update)."""
+
+    def __init__(self, model, buckets, optimizer):
+        import torch
+        self.buckets, self.optimizer = buckets, optimizer
+        self.stream = None
+        if model.device.type == "cuda":
+            self.stream = torch.cuda.Stream(model.device)
+            model.on_bucket_final = self._bucket_final
+
+    def _bucket_final(self, tag, producer):
+        import torch
+        self.stream.wait_stream(producer)
+        with torch.cuda.stream(self.stream):
+            self.buckets.wait_tag(tag)
+            self.optimizer.step_tag(tag)
+
+    def join(self):
+        if self.stream is not None:
+            import torch
+            torch.cuda.current_stream().wait_stream(self.stream)
+
+
 class TrainerNoMeta:
-    def __init__(self, cfg, model, data_iter=None, weak_data_iter=None, group=None, early_update=True):
+    def __init__(self, cfg, model, data_iter=None, weak_data_iter=None, group=None, early_update=False):
         self.cfg, self.model = cfg, model
         self.data_iter, self.weak_data_iter = data_iter, weak_data_iter
         self.buckets = GradBuckets(model, group)
@@ -27,21 +55,7 @@ class TrainerNoMeta:
         self.optimizer = FlatSGD(model, cfg, grad_scale=self.buckets.grad_scale)
         self.iter = 0
         self.last_losses = None
-        # early per-bucket optimizer update: the SGD launches of a bucket run on their own stream as soon as the bucket's
-        # gradients are final (and all-reduced), beside the rest of the backward, instead of in a 0.2 ms tail after it
-        self._opt_stream = None
-        if early_update and model.device.type == "cuda":
-            import torch
-            self._opt_stream = torch.cuda.Stream(model.device)
-            model.on_bucket_final = self._bucket_final
-
-    def _bucket_final(self, tag, producer):
-        import torch
-        opt = self._opt_stream
-        opt.wait_stream(producer)
-        with torch.cuda.stream(opt):
-            self.buckets.wait_tag(tag)
-            self.optimizer.step_tag(tag)
+        self.early = EarlyUpdate(model, self.buckets, self.optimizer) if early_update else None
 
     def run_step(self, base_data=None, classifier_data=None):
         assert self.model.training, "[TrainerNoMeta] model was changed to eval mode!"
@@ -53,9 +67,8 @@ class TrainerNoMeta:
         step = self.model.forward_train(batch, early_backward=True)
         self.model.backward_train(step)          # buckets' all-reduces are launched from inside (on_grad_ready)
         self.buckets.finish()
-        if self._opt_stream is not None:
-            import torch
-            torch.cuda.current_stream().wait_stream(self._opt_stream)
+        if self.early is not None:
+            self.early.join()
         self.optimizer.step()
         self.iter += 1
         self.last_losses = step.losses
