@@ -201,7 +201,7 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ partial, int split
 }
 
 // conv_wgrad256.hip: 256x256 LDS-DMA kernel for the big-M bf16 layers (same slab layout)
-extern "C" int unit_wgrad_use_big(int in_dtype, long M, int K, int C);
+extern "C" int unit_wgrad_use_big(int in_dtype, long M, int K, int C, int RS);
 extern "C" int unit_wgrad_big_splits(long M, int tiles);
 extern "C" int unit_conv2d_wgrad_big_launch(const void* x, const void* dy, float* partial, int N, int H, int W, int C, int K, int R, int S,
                                             int stride, int pad, int OH, int OW, int ldy, size_t workspace_bytes, void* stream);
@@ -238,7 +238,7 @@ static int choose_splits(int M, int tiles, int ms) {
 extern "C" size_t unit_conv2d_wgrad_workspace_bytes(int in_dtype, int N, int OH, int OW, int K, int R, int S, int C) {
   long M = (long)N * OH * OW;
   int Kgemm = R * S * C;
-  if (unit_wgrad_use_big(in_dtype, M, K, C)) return (size_t)unit_wgrad_big_splits(M, (Kgemm / 256) * (K / 256)) * K * Kgemm * sizeof(float);
+  if (unit_wgrad_use_big(in_dtype, M, K, C, R * S)) return (size_t)unit_wgrad_big_splits(M, (Kgemm / 256) * (K / 256)) * K * Kgemm * sizeof(float);
   int tiles = cdiv(Kgemm, 128) * cdiv(K, 128);
   int splits = choose_splits((int)M, tiles, in_dtype == UNIT_BF16 ? 64 : 32);
   return (size_t)splits * K * Kgemm * sizeof(float);
@@ -266,7 +266,7 @@ extern "C" int unit_conv2d_wgrad(const void* x, const void* dy, float* dw, const
   a.magic_ohw = a.OHW > 1 ? (unsigned)((0x100000000ull + a.OHW - 1) / (unsigned long long)a.OHW) : 0xFFFFFFFFu;
   a.magic_ow = OW > 1 ? (unsigned)((0x100000000ull + OW - 1) / (unsigned long long)OW) : 0xFFFFFFFFu;
   hipStream_t st = (hipStream_t)stream;
-  if (unit_wgrad_use_big(in_dtype, a.M, K, C)) {
+  if (unit_wgrad_use_big(in_dtype, a.M, K, C, R * S)) {
     int sp = unit_conv2d_wgrad_big_launch(x, dy, (float*)workspace, N, H, W, C, K, R, S, stride, pad, OH, OW, ldy, workspace_bytes, stream);
     if (sp < 0) return sp;
     if (dw == nullptr) return UNIT_OK;
@@ -314,7 +314,7 @@ extern "C" int unit_conv2d_wgrad(const void* x, const void* dy, float* dw, const
 // number of split-M slabs unit_conv2d_wgrad writes for this shape (slab s at workspace + s*K*R*S*C floats)
 extern "C" int unit_conv2d_wgrad_splits(int in_dtype, int N, int OH, int OW, int K, int R, int S, int C) {
   long M = (long)N * OH * OW;
-  if (unit_wgrad_use_big(in_dtype, M, K, C)) return unit_wgrad_big_splits(M, (R * S * C / 256) * (K / 256));
+  if (unit_wgrad_use_big(in_dtype, M, K, C, R * S)) return unit_wgrad_big_splits(M, (R * S * C / 256) * (K / 256));
   int tiles = cdiv(R * S * C, 128) * cdiv(K, 128);
   return choose_splits((int)M, tiles, in_dtype == UNIT_BF16 ? 64 : 32);
 }

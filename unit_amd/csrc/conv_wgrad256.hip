@@ -155,22 +155,28 @@ static int g_wgrad_big_variant = 3;
 extern "C" int unit_wgrad_big_variant(int v) { int old = g_wgrad_big_variant; g_wgrad_big_variant = v; return old; }
 
 // shared with conv_wgrad.hip: which kernel handles a shape, and with how many split-M slabs
-extern "C" int unit_wgrad_use_big(int in_dtype, long M, int K, int C) {
-  return in_dtype == UNIT_BF16 && (C % 256) == 0 && (K % 256) == 0 && M >= 16384;
+extern "C" int unit_wgrad_use_big(int in_dtype, long M, int K, int C, int RS) {
+  if (in_dtype != UNIT_BF16 || (C % 256) != 0 || (K % 256) != 0) return 0;
+  // few pixels need many tiles: with >= 96 tiles (RPN 3x3 1024->1024 on 4 images: 144) two or three split-M slabs fill the chip
+  // and each workgroup still runs >= 50 steps; the backbone layers (4-16 tiles) would need ~64 slabs of 2-3 steps each
+  long tiles = (long)(RS * C / 256) * (K / 256);
+  return M >= 16384 || (M >= 8192 && tiles >= 96);
 }
 
 extern "C" int unit_wgrad_big_splits(long M, int tiles) {
-  // one workgroup per CU (128 KB of LDS): 256 slots per round; >= 8 staged steps per split
+  // one workgroup per CU (128 KB of LDS): 256 slots per round; >= 8 staged steps per split. Cost model (us): a workgroup
+  // needs ~6 us of fixed time plus ~1.3 us per 64-pixel step; the grid runs in rounds of 256 workgroups; every workgroup
+  // writes a 256 KB fp32 slab that the reduction reads back (~2 x 256 KB at ~4 TB/s).
   int maxs = (int)((M + 8 * 64 - 1) / (8 * 64));
   if (maxs < 1) maxs = 1;
   if (maxs > 64) maxs = 64;
-  int best = 1; double best_score = -1.0;
+  int best = 1; double best_cost = 1e30;
+  double steps_total = (double)((M + 63) / 64);
   for (int s = 1; s <= maxs; ++s) {
     long blocks = (long)tiles * s;
     long rounds = (blocks + 255) / 256;
-    double fill = (double)blocks / (double)(rounds * 256);
-    double score = fill - 0.004 * s;
-    if (score > best_score) { best_score = score; best = s; }
+    double cost = rounds * (6.0 + 1.3 * steps_total / s) + (double)blocks * 2.0 * 262144.0 / 4.0e6;
+    if (cost < best_cost) { best_cost = cost; best = s; }
   }
   return best;
 }
