@@ -242,7 +242,7 @@ def test_wgrad_big_m(dev):
 
 
 @pytest.mark.parametrize("case", [(400, 7, 7, 256, 256, 3, 1, 1), (340, 7, 7, 512, 256, 1, 1, 0), (350, 14, 14, 256, 512, 1, 2, 0),
-                                  (2, 97, 101, 256, 256, 3, 1, 1)])
+                                  (2, 97, 101, 256, 256, 3, 1, 1), (4, 120, 150, 256, 256, 1, 2, 0)])
 def test_wgrad_big_tile_kernel(dev, case):
     """256x256 LDS-DMA weight-gradient kernel (bf16, C % 256 == 0, K % 256 == 0, M >= 16384): 3x3 with padding, 1x1,
     stride-2 1x1, ragged last m-step, FrozenBN scale fold; fp32 reference = autograd of F.conv2d on the bf16-rounded operands."""

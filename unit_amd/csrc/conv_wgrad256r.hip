@@ -65,6 +65,18 @@ __global__ void __launch_bounds__(512, 2) conv_wgrad256_ring_kernel(Wgrad256Args
     s_row[i] = row; s_col[i] = (unsigned)j * 8u;
   }
 
+  // maps at least 32 pixels wide (the RPN conv: 63): the (image, oh, ow) triple of the two staged rows is carried incrementally
+  // (+32 pixels per stage, stages are issued in order) instead of being divided out of m for every piece
+  const bool incremental = !pointwise && p.OW >= MS;
+  int in_[2] = {0, 0}, ioh[2] = {0, 0}, iow[2] = {0, 0};
+  if (incremental) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      unsigned um = (unsigned)(m_begin + s_row[i]);
+      unsigned ow = um % (unsigned)p.OW, tt = um / (unsigned)p.OW;
+      iow[i] = (int)ow; ioh[i] = (int)(tt % (unsigned)p.OH); in_[i] = (int)(tt / (unsigned)p.OH);
+    }
+  }
   auto stage = [&](int mstep, int buf) {      // 4 LDS-DMA pieces per wave
     char* bx = smem + buf * 2 * TILE;
     char* bd = bx + TILE;
@@ -76,7 +88,13 @@ __global__ void __launch_bounds__(512, 2) conv_wgrad256_ring_kernel(Wgrad256Args
       unsigned xoff;
       bool ok = mok;
       if (pointwise) xoff = ((unsigned)m * (unsigned)p.C + (unsigned)ch0 + s_col[i]) * 2u;
-      else {
+      else if (incremental) {
+        int ih = ioh[i] * p.stride - p.pad + kr, iw = iow[i] * p.stride - p.pad + ksx;
+        ok = ok && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
+        xoff = ((unsigned)in_[i] * (unsigned)(p.H * p.W * p.C) + (unsigned)((ih * p.W + iw) * p.C + ch0) + s_col[i]) * 2u;
+        iow[i] += MS;
+        if (iow[i] >= p.OW) { iow[i] -= p.OW; ioh[i] += 1; if (ioh[i] >= p.OH) { ioh[i] = 0; in_[i] += 1; } }
+      } else {
         unsigned um = (unsigned)m, n, oh, ow;
         if (p.use_magic) {
           n = __umulhi(um, p.magic_ohw); unsigned rem = um - n * (unsigned)p.OHW;
