@@ -86,3 +86,23 @@ def test_r101_parameter_count():
     m = build_model(_cfg(101))
     n_train = sum(p.numel() for p in m.parameters() if p.requires_grad)
     assert abs(n_train - 67.05e6) < 0.5e6, n_train      # 67.0 M trainable
+
+
+def test_gradient_bucket_tags_follow_backward_order():
+    """flat store tags = data-parallel buckets in the order the backward completes them; the long res4 stage of R101 is four
+    buckets of six blocks (blocks 22..17 first), R50's six blocks are one"""
+    m = build_model(_cfg(101))
+    st = m.flatten_parameters()
+    tags = [t for t, a, b in st.tags]
+    assert tags[-6:] == ["res4", "res4.1", "res4.2", "res4.3", "res3"][-6:] or tags[-5:] == ["res4", "res4.1", "res4.2", "res4.3", "res3"]
+    assert all(b0 == a1 for (_, _, b0), (_, a1, _) in zip(st.tags, st.tags[1:])) and st.tags[0][1] == 0 and st.tags[-1][2] == st.size
+    off = {e["name"]: e["offset"] for e in st.entries}
+    rng = {t: (a, b) for t, a, b in st.tags if t.startswith("res4")}
+    assert rng["res4"][0] <= off["backbone.res4.22.conv3.weight"] < rng["res4"][1]
+    assert rng["res4"][0] <= off["backbone.res4.17.conv1.weight"] < rng["res4"][1]
+    assert rng["res4.1"][0] <= off["backbone.res4.16.conv3.weight"] < rng["res4.1"][1]
+    assert rng["res4.3"][0] <= off["backbone.res4.0.shortcut.weight"] < rng["res4.3"][1]
+    r4 = m.backbone.res4
+    assert [r4.last_block_of_bucket(k) for k in range(4)] == [17, 11, 5, 0] and r4.bucket_of_block(5) == 2 and r4.bucket_of_block(4) == 3
+    m50 = build_model(_cfg(50))
+    assert [t for t, a, b in m50.flatten_parameters().tags if t.startswith("res4")] == ["res4"]

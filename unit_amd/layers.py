@@ -197,12 +197,31 @@ class ResStage(nn.Sequential):
             ctxs.append(c)
         return x, ctxs
 
-    def bwd(self, ctxs, g, need_dx=True, mask_input=True):
+    def bwd(self, ctxs, g, need_dx=True, mask_input=True, on_block_done=None):
         n = len(self)
         for i in range(n - 1, -1, -1):
             first = i == 0
             g = self[i].bwd(ctxs[i], g, need_dx=(need_dx or not first), mask_input=(mask_input or not first))
+            if on_block_done is not None:
+                on_block_done(i)
         return g
+
+    # gradient buckets of a long stage (data-parallel all-reduce granularity): blocks [n-1 .. 0] in groups of BUCKET_BLOCKS, in the
+    # order their gradients become final; a stage of <= BUCKET_BLOCKS + 2 blocks is one bucket
+    BUCKET_BLOCKS = 6
+
+    def bucket_of_block(self, i):
+        n = len(self)
+        if n <= self.BUCKET_BLOCKS + 2:
+            return 0
+        return (n - 1 - i) // self.BUCKET_BLOCKS
+
+    def last_block_of_bucket(self, k):
+        """index of the block whose backward completes bucket k"""
+        n = len(self)
+        if n <= self.BUCKET_BLOCKS + 2:
+            return 0
+        return max(0, n - (k + 1) * self.BUCKET_BLOCKS)
 
 
 class BasicStem(nn.Module):

@@ -71,9 +71,16 @@ class ResNet(nn.Module):
         for i in (2, 1, 0):
             if i < ft:
                 break
-            g = stages[i].bwd(ctx[i], g, need_dx=(i > ft), mask_input=True)
+            name, st = ("res2", "res3", "res4")[i], stages[i]
+            cb = None
             if on_stage_done is not None:
-                on_stage_done(("res2", "res3", "res4")[i])
+                # long stages are several gradient buckets ("res4", "res4.1", ...: modeling/rcnn.py trainable_order): a bucket is
+                # signalled as soon as its last block is through, so its all-reduce overlaps the rest of the stage
+                def cb(j, name=name, st=st):
+                    k = st.bucket_of_block(j)
+                    if j == st.last_block_of_bucket(k):
+                        on_stage_done(name if k == 0 else f"{name}.{k}")
+            g = st.bwd(ctx[i], g, need_dx=(i > ft), mask_input=True, on_block_done=cb)
         return None
 
     # ---- plugin surface: NCHW fp32 in, {"res4": NCHW fp32} out (inference / feature extraction only)

@@ -119,15 +119,16 @@ class WeaklySupervisedRCNNNoMeta(nn.Module):
               [(f"oicr_predictors.{i}", m) for i, m in enumerate(wh.oicr_predictors)])
 
         def stage(tag, prefix, st):
-            items = []
+            buckets = {}
             for i in range(len(st) - 1, -1, -1):
                 b = st[i]
+                k = st.bucket_of_block(i) if hasattr(st, "bucket_of_block") else 0
                 for cn in ("conv3", "conv2", "conv1", "shortcut"):
                     c = getattr(b, cn)
                     if c is not None and c.weight.requires_grad:
-                        items.append((f"{prefix}.{i}.{cn}.weight", c.weight, True))
-            if items:
-                groups.append((tag, items, 0))
+                        buckets.setdefault(k, []).append((f"{prefix}.{i}.{cn}.weight", c.weight, True))
+            for k in sorted(buckets):        # "res4", "res4.1", ...: in the order the backward completes them (layers.ResStage)
+                groups.append((tag if k == 0 else f"{tag}.{k}", buckets[k], 0))
 
         stage("box_head", "roi_heads.box_head.res5", rh.box_head.res5)
         if rh.weak_box_head is not None:
