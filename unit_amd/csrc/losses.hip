@@ -246,6 +246,31 @@ __global__ void softmax_ce_kernel(const float* __restrict__ logits, int ld, int 
       if (dy) for (int c = 0; c < ncls; ++c) st(dy + (size_t)r * ldd + dcol0 + c, 0.f);
       continue;
     }
+    if (ncls <= 32) {
+      // the row in registers: one read of the logits instead of four dependent passes over L2 (same arithmetic, same order)
+      float xv[32];
+#pragma unroll
+      for (int c = 0; c < 32; ++c) xv[c] = c < ncls ? x[c] : -INFINITY;
+      float mx = -INFINITY;
+#pragma unroll
+      for (int c = 0; c < 32; ++c) if (c < ncls) mx = fmaxf(mx, xv[c]);
+      float se = 0.f;
+#pragma unroll
+      for (int c = 0; c < 32; ++c) if (c < ncls) se += expf(xv[c] - mx);
+      float lse = logf(se) + mx;
+      float w = weights ? weights[r] : 1.f;
+      float xl = 0.f;
+#pragma unroll
+      for (int c = 0; c < 32; ++c) if (c == lab) xl = xv[c];
+      acc += (lse - xl) * w;
+      if (dy) {
+        float g = w * inv * gscale;
+#pragma unroll
+        for (int c = 0; c < 32; ++c)
+          if (c < ncls) st(dy + (size_t)r * ldd + dcol0 + c, (expf(xv[c] - lse) - (c == lab ? 1.f : 0.f)) * g);
+      }
+      continue;
+    }
     float mx = -INFINITY;
     for (int c = 0; c < ncls; ++c) mx = fmaxf(mx, x[c]);
     float se = 0.f;
