@@ -250,7 +250,9 @@ extern "C" int unit_bias_grad(const void* dy, int dtype, int M, int K, int ld, f
   if (!accumulate) hipMemsetAsync(db, 0, sizeof(float) * K, st);
   if (M == 0) return UNIT_OK;
   if (dtype == UNIT_BF16 && ld % 8 == 0 && ((uintptr_t)dy % 16 == 0)) {
-    int rows = 128;
+    // up to 16 384 rows (every bias on the hot path: RPN head 9 576, predictors <= 2 048): one workgroup per 256 columns walks all
+    // rows, so each db[c] has a single adder and the sum is bit-reproducible; beyond that the row blocks add atomically
+    int rows = M <= 16384 ? M : 128;
     bias_grad_vec_kernel<<<dim3(cdiv(K, 256), cdiv(M, rows)), 256, 0, st>>>((const bf16_t*)dy, M, K, ld, db, rows);
     UNIT_LAUNCH_CHECK();
     return UNIT_OK;
