@@ -72,9 +72,9 @@ int unit_conv2d_wgrad_splits(int in_dtype, int N, int OH, int OW, int K, int R, 
  * (csrc/conv_wgrad256p8.hip) for pointwise layers and maps of <= 1024 pixels, ring of four 32-pixel stages (csrc/conv_wgrad256r.hip) otherwise; 0 / 2 force
  * one of them, 1 = two-stage loop (csrc/conv_wgrad256.hip); same slabs bit for bit. Process-wide, not thread-safe. */
 int unit_wgrad_big_variant(int v);
-/* 128x128 tile (all other layers): 1 (default) = register-staged kernel (csrc/conv_wgrad.hip), 0 = LDS-DMA ring kernel for
- * bf16 layers with C % 128 == 0 and K % 128 == 0 (csrc/conv_wgrad128r.hip; measured equal); same slabs bit for bit. Returns
- * the previous setting. */
+/* 128x128 tile (all other layers): 0 (default) = LDS-DMA ring kernel for bf16 layers with C % 128 == 0 and K % 128 == 0
+ * (csrc/conv_wgrad128r.hip), 1 = register-staged kernel everywhere (csrc/conv_wgrad.hip); same slabs bit for bit. Returns the
+ * previous setting. */
 int unit_wgrad_mid_variant(int v);   /* returns the previous setting */
 size_t unit_tensor_desc_bytes(void);
 int unit_multi_wgrad_reduce(const void* descs_dev, int n, int total_blocks, float* grads_flat, void* stream);

@@ -25,5 +25,5 @@ for name, n, h, w, c, k, r, st, pad in SH:
         if ref is None:
             ref = slab.clone()
         line += f" | v{v}: {ms * 1e3:7.1f} us {flops / ms / 1e9:6.0f} TF splits {sp} equal {torch.equal(ref, slab)}"
-    o.wgrad_mid_variant(1)
+    o.wgrad_mid_variant(0)
     print(line)

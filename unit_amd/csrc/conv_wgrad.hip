@@ -206,10 +206,12 @@ extern "C" int unit_wgrad_big_splits(long M, int tiles);
 extern "C" int unit_conv2d_wgrad_big_launch(const void* x, const void* dy, float* partial, int N, int H, int W, int C, int K, int R, int S,
                                             int stride, int pad, int OH, int OW, int ldy, size_t workspace_bytes, void* stream);
 
-// 1 (default): the register-staged kernel below; 0: LDS-DMA ring kernel (conv_wgrad128r.hip) where it applies. Measured equal
-// on the backbone shapes (tools/wgrad128_bench.py: 18.2 vs 18.5 us, 31.9 vs 30.4 us; RPN 3x3 306 vs 284 us; step 18.4 vs 18.2 ms):
-// at M = 9 576 these launches are bound by their fp32 slab store and input streaming, not by the loop's load latency.
-static int g_wgrad_mid_variant = 1;
+// 0 (default): LDS-DMA ring kernel (conv_wgrad128r.hip) where it applies (bf16, C % 128 == 0, K % 128 == 0); 1: the register-staged
+// kernel below everywhere. Isolated the two are equal on the backbone shapes (tools/wgrad128_bench.py: 18.2 vs 18.5 us, 31.9 vs
+// 30.4 us; RPN 3x3 306 vs 284 us -- at M = 9 576 these launches are bound by their fp32 slab store and input streaming, not by the
+// loop's load latency); inside the step the ring form is 0.05-0.1 ms ahead on the same box (18.36 vs 18.44-18.48 ms).
+// UNIT_WGRAD_MID_VARIANT overrides the default.
+static int g_wgrad_mid_variant = []{ const char* e = getenv("UNIT_WGRAD_MID_VARIANT"); return e ? atoi(e) : 0; }();
 extern "C" int unit_wgrad_mid_variant(int v) { int old = g_wgrad_mid_variant; g_wgrad_mid_variant = v; return old; }
 
 static int choose_splits(int M, int tiles, int ms) {

@@ -25,8 +25,9 @@ __device__ __forceinline__ bf16x8 tr_frag128(const char* tile, int col0, int lan
   return __builtin_bit_cast(bf16x8, v);
 }
 
+template <int NS>
 __global__ void __launch_bounds__(256, 2) conv_wgrad128_ring_kernel(Wgrad256Args p) {
-  constexpr int MS = 32, NS = 4;
+  constexpr int MS = 32;
   constexpr int TILE = MS * 256;               // 8 KB per operand per stage
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -130,8 +131,8 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad128_ring_kernel(Wgrad256Args
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
-    if (st + NS - 1 < nst) stage((st + NS - 1) & (NS - 1));
-    const char* bx = smem + (st & (NS - 1)) * 2 * TILE;
+    if (st + NS - 1 < nst) stage((st + NS - 1) % NS);
+    const char* bx = smem + (st % NS) * 2 * TILE;
     const char* bd = bx + TILE;
     bf16x8 fa[4], fb[4];
 #pragma unroll
@@ -160,13 +161,17 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad128_ring_kernel(Wgrad256Args
 }
 
 int unit_wgrad128_ring_launch(const Wgrad256Args& a, hipStream_t st) {
-  size_t lds = 4 * 2 * 32 * 256;
+  // UNIT_WG128_NS=3: three stages (48 KB of LDS, three workgroups per CU) instead of four (64 KB, two per CU)
+  static int ns = -1;
+  if (ns < 0) { const char* e = getenv("UNIT_WG128_NS"); ns = e ? atoi(e) : 4; }
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)conv_wgrad128_ring_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)conv_wgrad128_ring_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 2 * 32 * 256);
+    (void)hipFuncSetAttribute((const void*)conv_wgrad128_ring_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 2 * 32 * 256);
     attr_set = true;
   }
-  conv_wgrad128_ring_kernel<<<a.tiles_k * a.tiles_n * a.splits, 256, lds, st>>>(a);
+  if (ns == 3) conv_wgrad128_ring_kernel<3><<<a.tiles_k * a.tiles_n * a.splits, 256, 3 * 2 * 32 * 256, st>>>(a);
+  else conv_wgrad128_ring_kernel<4><<<a.tiles_k * a.tiles_n * a.splits, 256, 4 * 2 * 32 * 256, st>>>(a);
   UNIT_LAUNCH_CHECK();
   return UNIT_OK;
 }

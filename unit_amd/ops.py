@@ -200,7 +200,7 @@ def wgrad_big_variant(v):
 
 
 def wgrad_mid_variant(v):
-    """128x128 weight-gradient tile: 1 = register-staged kernel (default), 0 = LDS-DMA ring kernel where it applies; returns the previous one"""
+    """128x128 weight-gradient tile: 0 = LDS-DMA ring kernel where it applies (default), 1 = register-staged kernel; returns the previous one"""
     return lib().unit_wgrad_mid_variant(int(v))
 
 
