@@ -159,9 +159,12 @@ int unit_roi_align_bwd_gather(const void* gout, int dtype, int N, int H, int W, 
                               void* stream);
 
 /* ---- a5/a10/a11/a12 fused loss forward+backward kernels ---- */
+/* scratch (unit_rpn_loss_scratch_bytes, contents irrelevant): per-workgroup partial sums, added by the last workgroup in a fixed
+ * order -- the two loss scalars are bit-reproducible */
+size_t unit_rpn_loss_scratch_bytes(int B, int Ncap);
 int unit_rpn_loss(const float* head, int ld, int A, int dcol0, const int8_t* labels, const int64_t* match_idx, const float* gt_boxes,
                   int Mcap, const float* anchors, int B, int Ncap, float normalizer, float gscale, float* loss2, void* dhead,
-                  int dhead_dtype, void* stream);
+                  int dhead_dtype, float* scratch, size_t scratch_bytes, void* stream);
 int unit_sup_scores(const float* delta, int ldd, int dcol0, const float* weak, int ldw, int wcol0, int n_oicr, int ncls,
                     const unsigned char* novel_mask_dev, const float* extra, int lde, int ecol0, float* out, int ldo, int R,
                     void* stream);

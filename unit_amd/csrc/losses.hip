@@ -34,8 +34,9 @@ template <typename TD>
 __global__ void rpn_loss_kernel(const float* __restrict__ head, int ld, int A, int dcol0, const int8_t* __restrict__ labels,
                                 const int64_t* __restrict__ midx, const float* __restrict__ gt, int Mcap,
                                 const float* __restrict__ anchors, int Ncap, float inv_norm, float gscale,
-                                float* __restrict__ loss2, TD* __restrict__ dhead) {
+                                float* __restrict__ loss2, TD* __restrict__ dhead, float* __restrict__ scratch) {
   __shared__ float lds[17];
+  __shared__ int s_last;
   int b = blockIdx.y;
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   float lc = 0.f, ll = 0.f;
@@ -69,24 +70,51 @@ __global__ void rpn_loss_kernel(const float* __restrict__ head, int ld, int A, i
   }
   float sc = block_sum(lc, lds);
   float sl = block_sum(ll, lds);
-  if (threadIdx.x == 0) { atomicAdd(loss2, sc * inv_norm); atomicAdd(loss2 + 1, sl * inv_norm); }
+  // Bit-reproducible sums: every workgroup parks its two partials in its own scratch slot, the last one to arrive adds all slots in
+  // a fixed order. Hand-off through device-scope atomics only (a slot is zero and gets exactly one atomicAdd, the reader fetches it
+  // with atomicAdd(.., 0)): they execute at the memory side, so no assumption about the per-XCD L2s is needed.
+  const int nblk = gridDim.x * gridDim.y, blk = blockIdx.y * gridDim.x + blockIdx.x;
+  unsigned* ticket = reinterpret_cast<unsigned*>(scratch + 2 * nblk);
+  if (threadIdx.x == 0) {
+    atomicAdd(scratch + 2 * blk, sc);
+    atomicAdd(scratch + 2 * blk + 1, sl);
+    __threadfence();
+    s_last = (atomicAdd(ticket, 1u) == (unsigned)(nblk - 1)) ? 1 : 0;
+  }
+  __syncthreads();
+  if (!s_last) return;
+  float tc = 0.f, tl = 0.f;
+  for (int j = threadIdx.x; j < nblk; j += blockDim.x) {        // fixed assignment of slots to threads, fixed order per thread
+    tc += atomicAdd(scratch + 2 * j, 0.f);
+    tl += atomicAdd(scratch + 2 * j + 1, 0.f);
+  }
+  tc = block_sum(tc, lds);
+  tl = block_sum(tl, lds);
+  if (threadIdx.x == 0) { loss2[0] = tc * inv_norm; loss2[1] = tl * inv_norm; }
 }
+
+// two partial sums per workgroup + the arrival counter
+extern "C" size_t unit_rpn_loss_scratch_bytes(int B, int Ncap) { return ((size_t)2 * cdiv(Ncap, 256) * (B > 0 ? B : 1) + 1) * sizeof(float); }
 
 extern "C" int unit_rpn_loss(const float* head, int ld, int A, int dcol0, const int8_t* labels, const int64_t* match_idx,
                              const float* gt_boxes, int Mcap, const float* anchors, int B, int Ncap, float normalizer,
-                             float gscale, float* loss2, void* dhead, int dhead_dtype, void* stream) {
+                             float gscale, float* loss2, void* dhead, int dhead_dtype, float* scratch, size_t scratch_bytes,
+                             void* stream) {
   UNIT_CHECK_ARG(Ncap % A == 0, "rpn_loss: Ncap % A != 0");
   hipStream_t s = (hipStream_t)stream;
+  size_t need = unit_rpn_loss_scratch_bytes(B, Ncap);
+  if (scratch == nullptr || scratch_bytes < need) { unit_set_error("rpn_loss: scratch too small"); return UNIT_ERR_WORKSPACE; }
   (void)hipMemsetAsync(loss2, 0, 2 * sizeof(float), s);
+  (void)hipMemsetAsync(scratch, 0, need, s);
   size_t esz = dhead_dtype == UNIT_BF16 ? 2 : 4;
   (void)hipMemsetAsync(dhead, 0, (size_t)B * (Ncap / A) * ld * esz, s);   // pad columns stay zero
   if (B == 0 || Ncap == 0) return UNIT_OK;
   dim3 grid(cdiv(Ncap, 256), B);
   float inv = 1.0f / normalizer;
   if (dhead_dtype == UNIT_BF16)
-    rpn_loss_kernel<bf16_t><<<grid, 256, 0, s>>>(head, ld, A, dcol0, labels, match_idx, gt_boxes, Mcap, anchors, Ncap, inv, gscale, loss2, (bf16_t*)dhead);
+    rpn_loss_kernel<bf16_t><<<grid, 256, 0, s>>>(head, ld, A, dcol0, labels, match_idx, gt_boxes, Mcap, anchors, Ncap, inv, gscale, loss2, (bf16_t*)dhead, scratch);
   else
-    rpn_loss_kernel<float><<<grid, 256, 0, s>>>(head, ld, A, dcol0, labels, match_idx, gt_boxes, Mcap, anchors, Ncap, inv, gscale, loss2, (float*)dhead);
+    rpn_loss_kernel<float><<<grid, 256, 0, s>>>(head, ld, A, dcol0, labels, match_idx, gt_boxes, Mcap, anchors, Ncap, inv, gscale, loss2, (float*)dhead, scratch);
   UNIT_LAUNCH_CHECK();
   return UNIT_OK;
 }

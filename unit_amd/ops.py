@@ -524,8 +524,10 @@ def rpn_loss(head, a, dcol0, labels, match_idx, gt_boxes, anchors, normalizer, g
     ncap = anchors.shape[0]
     loss2 = loss_out if loss_out is not None else torch.empty(2, dtype=torch.float32, device=head.device)
     dhead = torch.empty((b, hw, ld), dtype=grad_dtype, device=head.device)
+    nbytes = lib().unit_rpn_loss_scratch_bytes(b, ncap)
+    scratch = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=head.device)
     check(lib().unit_rpn_loss(_p(head), ld, a, dcol0, _p(labels), _p(match_idx), _p(gt_boxes), gt_boxes.shape[1], _p(anchors), b, ncap,
-                              float(normalizer), float(gscale), _p(loss2), _p(dhead), dt(grad_dtype), _s()), "rpn_loss")
+                              float(normalizer), float(gscale), _p(loss2), _p(dhead), dt(grad_dtype), _p(scratch), nbytes, _s()), "rpn_loss")
     return loss2, dhead
 
 
