@@ -45,3 +45,16 @@ def test_shortest_edge_sizes_and_boxes():
         ref = io.transform_boxes(b, 375, 500, 600, 800, flip)
         assert np.allclose(got, ref, rtol=0, atol=1e-4)
         assert np.all(got[:, 2] >= got[:, 0]) and got[:, [0, 2]].max() <= 800 and got[:, [1, 3]].max() <= 600
+
+
+def test_aspect_ratio_grouping():
+    """d2 AspectRatioGroupedDataset: batches never mix landscape and portrait images, order inside a bin is arrival order"""
+    rng = np.random.RandomState(3)
+    items = [{"id": i, "width": int(w), "height": int(h)} for i, (w, h) in enumerate(rng.randint(300, 800, (41, 2)))]
+    batches = list(dp.AspectRatioGrouper(items, 4))
+    assert batches and all(len(b) == 4 for b in batches)
+    for b in batches:
+        assert len({d["width"] > d["height"] for d in b}) == 1
+        assert [d["id"] for d in b] == sorted(d["id"] for d in b)
+    land = [d["id"] for d in items if d["width"] > d["height"]]
+    assert [d["id"] for b in batches if b[0]["width"] > b[0]["height"] for d in b] == land[: len(land) // 4 * 4]

@@ -142,3 +142,22 @@ class DeviceInputPipeline:
             tb = [transform_boxes(b, int(img.shape[0]), int(img.shape[1]), hw[i][0], hw[i][1], flips[i])
                   for i, (b, img) in enumerate(zip(boxes, images))]
         return out, hw, tb
+
+
+class AspectRatioGrouper:
+    """d2 `AspectRatioGroupedDataset` (the train loader of `data/build.py:476-497` is built with `aspect_ratio_grouping=True`):
+    images are binned into landscape (w > h) and portrait, a batch is emitted as soon as one bin holds `batch_size` items -- so a
+    batch never mixes orientations and zero padding stays small. `items` yields dicts with "width" / "height" (anything else is
+    passed through); incomplete bins are dropped at the end of the stream, as in Detectron2."""
+
+    def __init__(self, items, batch_size):
+        self.items, self.batch_size = items, int(batch_size)
+
+    def __iter__(self):
+        buckets = [[], []]
+        for d in self.items:
+            b = buckets[0 if d["width"] > d["height"] else 1]
+            b.append(d)
+            if len(b) == self.batch_size:
+                yield b[:]
+                del b[:]
