@@ -473,6 +473,31 @@ def test_nms_exact(dev):
         assert torch.equal(ob[0, : len(ref)].cpu(), b[torch.from_numpy(ref)])
 
 
+def test_nms_ragged_and_degenerate_batches(dev):
+    """Edge cases in one batched launch: an image with no candidates, one with a single box, identical boxes (only the first
+    survives), pairwise disjoint boxes (all kept up to max_keep), and counts on the 64-box word boundaries."""
+    o = ops()
+    gen = g(19)
+    cap, mk = 320, 100
+    grid = torch.stack([torch.tensor([20.0 * (i % 16), 20.0 * (i // 16), 20.0 * (i % 16) + 10, 20.0 * (i // 16) + 10]) for i in range(cap)])
+    cases = [torch.zeros(0, 4), rand_boxes(gen, 1, lo=8, hi=200), rand_boxes(gen, 1, lo=8, hi=200).repeat(200, 1), grid,
+             rand_boxes(gen, 64, lo=8, hi=120), rand_boxes(gen, 65, lo=8, hi=120), rand_boxes(gen, 128, lo=8, hi=120)]
+    bb = torch.zeros(len(cases), cap, 4)
+    ss = torch.zeros(len(cases), cap)
+    for i, b in enumerate(cases):
+        bb[i, : len(b)] = b
+        ss[i, : len(b)] = torch.sort(torch.randn(len(b), generator=gen), descending=True)[0]
+    cnt = torch.tensor([len(b) for b in cases], dtype=torch.int32)
+    keep, kc, ob, osc = o.nms(bb.to(dev), ss.to(dev), cnt.to(dev), 0.7, mk)
+    for i, b in enumerate(cases):
+        ref = orc.nms_sorted(b.numpy(), 0.7)[:mk] if len(b) else np.zeros(0, np.int64)
+        assert int(kc[i]) == len(ref), (i, int(kc[i]), len(ref))
+        assert np.array_equal(keep[i, : len(ref)].cpu().numpy(), ref)
+        assert bool((keep[i, len(ref):] == -1).all())
+        assert torch.equal(ob[i, : len(ref)].cpu(), b[torch.from_numpy(ref)] if len(ref) else torch.zeros(0, 4))
+    assert int(kc[0]) == 0 and int(kc[2]) == 1 and int(kc[3]) == mk
+
+
 def test_rpn_proposals(dev):
     o = ops()
     gen = g(10)

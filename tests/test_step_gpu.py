@@ -1,6 +1,8 @@
 """End-to-end parity of one UniT training step (S1: TrainerNoMeta.run_step semantics) against the CPU oracle:
 same weights (state_dict), same images / GT / image-level labels, same sampling permutations.
 fp32 compute mode: losses within 1e-4 (north_star), parameter gradients within 1e-3 relative to their max."""
+import math
+
 import pytest
 import torch
 
@@ -438,6 +440,40 @@ def test_s1_step_mixed_image_sizes_fp32(dev):
         m = len(aux["sampled"][i]["boxes"])
         assert torch.equal(step.roi_cls[i * 32:i * 32 + m].cpu().long(), aux["sampled"][i]["gt_classes"])
     for k in LOSS_NAMES[:8]:
+        assert abs(got[k] - ref[k].item()) <= 1e-4 * max(1.0, abs(ref[k].item())), (k, got[k], ref[k].item())
+    name = "backbone.res4.0.conv1.weight"
+    g, gr = dict(model.named_parameters())[name].grad.cpu(), p[name].grad
+    assert (g - gr).abs().max() <= 2e-3 * gr.abs().max() + 1e-7
+
+
+def test_s1_step_with_an_image_without_gt_fp32(dev):
+    """Empty-GT edge case (d2 Matcher's empty branch, matcher.py:68-82 / roi_heads.py label_and_sample_proposals): the second
+    supervised image has no boxes -- all its anchors are negatives, all its sampled RoIs background with no box-regression
+    target; the first keeps its boxes. Losses and index decisions vs oracle."""
+    from unit_amd.structures import Boxes, Instances
+    cfg = small_cfg()
+    model = build_model(cfg)
+    init_synthetic_weights(model, seed=1)
+    model.train()
+    model.compute_dtype = torch.float32
+    sup, weak = synthetic_batch(2, 2, hw=(128, 192), seed=31, max_gt=4)
+    h, w = 128, 192
+    sup[1]["instances"] = Instances((h, w), gt_boxes=Boxes(torch.zeros(0, 4)), gt_classes=torch.zeros(0, dtype=torch.int64))
+    batch = model.pack_batch(sup, weak)
+    model._ensure_ready()
+    perms = model.sampling_permutations(2, 8 * 12 * 15, cfg.MODEL.RPN.POST_NMS_TOPK_TRAIN + batch.gt_boxes.shape[1])
+    step = model.forward_train(batch, perms, early_backward=True)
+    model.backward_train(step)
+    got = dict(zip(LOSS_NAMES, step.losses.cpu().tolist()))
+    ref, p, aux = oracle_step(model, cfg, sup, weak, perms)
+    assert torch.equal(step.anchor_labels.cpu(), torch.stack(aux["anchor_labels"]))
+    assert int((step.anchor_labels[1] == 1).sum()) == 0
+    for i in range(2):
+        m = len(aux["sampled"][i]["boxes"])
+        assert torch.equal(step.roi_cls[i * 32:i * 32 + m].cpu().long(), aux["sampled"][i]["gt_classes"])
+    assert bool((aux["sampled"][1]["gt_classes"] == cfg.MODEL.ROI_HEADS.NUM_CLASSES).all())
+    for k in LOSS_NAMES[:8]:
+        assert math.isfinite(got[k])
         assert abs(got[k] - ref[k].item()) <= 1e-4 * max(1.0, abs(ref[k].item())), (k, got[k], ref[k].item())
     name = "backbone.res4.0.conv1.weight"
     g, gr = dict(model.named_parameters())[name].grad.cpu(), p[name].grad
