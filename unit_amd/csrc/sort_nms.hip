@@ -336,37 +336,65 @@ extern "C" int unit_sort_desc_stable_topk(const float* src, long batch_stride, i
 //      wave 0 resolves each 64-box chunk serially from the diagonal words, all threads then OR in the rows of the
 //      boxes kept in that chunk.  Stops after max_keep boxes.  Emits kept boxes/scores (gathered) + indices.
 // ---------------------------------------------------------------------------------------------------
-__device__ __forceinline__ bool nms_suppress(const f32x4 a, const f32x4 b, float thresh) {
-  float xx1 = fmaxf(a[0], b[0]), yy1 = fmaxf(a[1], b[1]);
-  float xx2 = fminf(a[2], b[2]), yy2 = fminf(a[3], b[3]);
-  float w = fmaxf(0.0f, xx2 - xx1), h = fmaxf(0.0f, yy2 - yy1);
+// IoU > thresh without the IEEE division for all but the borderline pairs: with u = area_a + area_b - inter > 0 and
+// p = RN(thresh * u), inter > p (1 + 2^-20) implies inter / u > thresh (1 + 2^-21) >= the float after thresh, so the rounded
+// quotient exceeds thresh; inter < p (1 - 2^-20) implies the true (hence the rounded) quotient is <= thresh. Only pairs inside
+// that 2^-19-wide band (and degenerate unions) take the division -- the result is the reference's bit for every pair.
+__device__ __forceinline__ float vmax(float x, float y) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y)); return r; }
+__device__ __forceinline__ float vmin(float x, float y) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y)); return r; }
+__device__ __forceinline__ bool nms_suppress_fast(const f32x4 a, float areaa, const f32x4 b, float areab, float thresh, float t_hi,
+                                                  float t_lo) {
+  // t_hi = RN(thresh (1 + 2^-20)), t_lo = RN(thresh (1 - 2^-20)): one rounding more than in the bound above, still inside it
+  // (v_max / v_min through asm: fmaxf / fminf on values loaded from memory cost a canonicalising v_max x, x each in IEEE mode)
+  float xx1 = vmax(a[0], b[0]), yy1 = vmax(a[1], b[1]);
+  float xx2 = vmin(a[2], b[2]), yy2 = vmin(a[3], b[3]);
+  float w = vmax(0.0f, xx2 - xx1), h = vmax(0.0f, yy2 - yy1);
   float inter = w * h;
-  float areaa = (a[2] - a[0]) * (a[3] - a[1]);
-  float areab = (b[2] - b[0]) * (b[3] - b[1]);
-  return inter / (areaa + areab - inter) > thresh;
+  float u = areaa + areab - inter;
+  bool sure_yes = inter > t_hi * u;
+  bool sure_no = inter < t_lo * u;
+  if (__builtin_expect(u > 1e-30f && (sure_yes || sure_no), 1)) return sure_yes;
+  return inter / u > thresh;
 }
 
-__global__ void nms_mask_kernel(const float* __restrict__ boxes, const int* __restrict__ count, int cap, int nw,
-                                float thresh, unsigned long long* __restrict__ mask) {
+// 256 threads = four waves, wave w owns column block 4 * blockIdx.x + w of row block blockIdx.y
+__global__ void __launch_bounds__(256) nms_mask_kernel(const float* __restrict__ boxes, const int* __restrict__ count, int cap, int nw,
+                                                       float thresh, unsigned long long* __restrict__ mask) {
   int b = blockIdx.z;
   int n = count ? min(count[b], cap) : cap;
-  int rb = blockIdx.y, cb = blockIdx.x;
-  if (cb < rb) return;
-  if (rb * 64 >= n || cb * 64 >= n) return;
-  __shared__ f32x4 cbox[64];
+  int rb = blockIdx.y, cb0 = blockIdx.x * 4;
+  if (cb0 + 3 < rb) return;
+  if (rb * 64 >= n || cb0 * 64 >= n) return;
+  __shared__ f32x4 cbox[256];
+  __shared__ float carea[256];
   const float* bx = boxes + (size_t)b * cap * 4;
-  int cj = cb * 64 + threadIdx.x;
-  if (cj < n) cbox[threadIdx.x] = *reinterpret_cast<const f32x4*>(bx + 4 * (size_t)cj);
+  int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  int cj = cb0 * 64 + tid;
+  f32x4 cbx = cj < n ? *reinterpret_cast<const f32x4*>(bx + 4 * (size_t)cj) : f32x4{0.f, 0.f, 0.f, 0.f};
+  cbox[tid] = cbx;
+  carea[tid] = (cbx[2] - cbx[0]) * (cbx[3] - cbx[1]);
   __syncthreads();
-  int i = rb * 64 + threadIdx.x;
-  if (i >= n) return;
+  int cb = cb0 + wv;
+  int i = rb * 64 + lane;
+  if (cb < rb || cb >= nw || cb * 64 >= n || i >= n) return;
   f32x4 me = *reinterpret_cast<const f32x4*>(bx + 4 * (size_t)i);
-  unsigned long long bits = 0;
-  int jn = min(64, n - cb * 64);
-  int j0 = (rb == cb) ? threadIdx.x + 1 : 0;
-  for (int j = j0; j < jn; ++j)
-    if (nms_suppress(me, cbox[j], thresh)) bits |= 1ull << j;
-  mask[((size_t)b * cap + i) * nw + cb] = bits;
+  float areame = (me[2] - me[0]) * (me[3] - me[1]);
+  // all 64 columns unconditionally (columns >= n are zero boxes: never suppressed), the diagonal block keeps j > lane only
+  const float t_hi = thresh * 1.00000095367431640625f, t_lo = thresh * 0.99999904632568359375f;
+  unsigned lo = 0, hi = 0;
+  const f32x4* cbw = cbox + wv * 64;
+  const float* caw = carea + wv * 64;
+#pragma unroll 8
+  for (int j = 0; j < 32; ++j)
+    if (nms_suppress_fast(me, areame, cbw[j], caw[j], thresh, t_hi, t_lo)) lo |= 1u << j;
+#pragma unroll 8
+  for (int j = 32; j < 64; ++j)
+    if (nms_suppress_fast(me, areame, cbw[j], caw[j], thresh, t_hi, t_lo)) hi |= 1u << (j - 32);
+  if (rb == cb) {
+    unsigned long long keepm = lane >= 63 ? 0ull : (~0ull << (lane + 1));
+    lo &= (unsigned)keepm; hi &= (unsigned)(keepm >> 32);
+  }
+  mask[((size_t)b * cap + i) * nw + cb] = ((unsigned long long)hi << 32) | lo;
 }
 
 #define NMS_SCAN_THREADS 1024
@@ -609,7 +637,7 @@ extern "C" int unit_nms(const float* boxes_sorted, const float* scores_sorted, c
   if (B == 0) return UNIT_OK;
   hipStream_t st = (hipStream_t)stream;
   if (cap > 0) {
-    nms_mask_kernel<<<dim3(nw, nw, B), 64, 0, st>>>(boxes_sorted, count, cap, nw, thresh, (unsigned long long*)workspace);
+    nms_mask_kernel<<<dim3((nw + 3) / 4, nw, B), 256, 0, st>>>(boxes_sorted, count, cap, nw, thresh, (unsigned long long*)workspace);
     UNIT_LAUNCH_CHECK();
   }
   static int no_pf = -1;
