@@ -1,5 +1,6 @@
 // sort_nms.hip -- stable descending sort of RPN objectness (K10) and NMS (K11), latency-bound integer work.
 #include "common.h"
+#include <type_traits>
 
 // ---------------------------------------------------------------------------------------------------
 // K10  logits.sort(descending=True) (find_top_rpn_proposals via rpn.py:48).
@@ -379,7 +380,7 @@ __global__ void __launch_bounds__(256) nms_mask_kernel(const float* __restrict__
   if (cb < rb || cb >= nw || cb * 64 >= n || i >= n) return;
   f32x4 me = *reinterpret_cast<const f32x4*>(bx + 4 * (size_t)i);
   float areame = (me[2] - me[0]) * (me[3] - me[1]);
-  // all 64 columns unconditionally (columns >= n are zero boxes: never suppressed), the diagonal block keeps j > lane only
+  // all 64 columns unconditionally (columns >= n are zero boxes: never suppressed)
   const float t_hi = thresh * 1.00000095367431640625f, t_lo = thresh * 0.99999904632568359375f;
   unsigned lo = 0, hi = 0;
   const f32x4* cbw = cbox + wv * 64;
@@ -390,8 +391,8 @@ __global__ void __launch_bounds__(256) nms_mask_kernel(const float* __restrict__
 #pragma unroll 8
   for (int j = 32; j < 64; ++j)
     if (nms_suppress_fast(me, areame, cbw[j], caw[j], thresh, t_hi, t_lo)) hi |= 1u << (j - 32);
-  if (rb == cb) {
-    unsigned long long keepm = lane >= 63 ? 0ull : (~0ull << (lane + 1));
+  if (rb == cb) {       // the diagonal block is stored SYMMETRIC (IoU is, bit for bit): bit j of row i for every j != i, so that
+    unsigned long long keepm = ~(1ull << lane);    // lane i of the scan has its predecessors (bits j < i) without a transpose
     lo &= (unsigned)keepm; hi &= (unsigned)(keepm >> 32);
   }
   mask[((size_t)b * cap + i) * nw + cb] = ((unsigned long long)hi << 32) | lo;
@@ -588,19 +589,20 @@ __global__ void __launch_bounds__(256) nms_scan_pf_kernel(const float* __restric
       }
       // kept boxes that were not among the prefetched candidates
       const unsigned long long* base = mk + (size_t)(c * 64) * nw + tid;
+      // (one batch = one memory round trip on the chunk's critical path: 32 rows cover 64 kept boxes with the prefetched ones)
       while (kept) {
-        unsigned long long v[8];
+        unsigned long long v[NMS_PF];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
+        for (int u = 0; u < NMS_PF; ++u) {
           v[u] = 0ull;
-          if (kept) {
+          if (kept) {                                      // wave-uniform
             int j = __ffsll((long long)kept) - 1;
             kept &= kept - 1;
             v[u] = base[(size_t)j * nw];
           }
         }
 #pragma unroll
-        for (int u = 0; u < 8; ++u) removed |= v[u];
+        for (int u = 0; u < NMS_PF; ++u) removed |= v[u];
       }
     }
     return false;
@@ -625,6 +627,199 @@ __global__ void __launch_bounds__(256) nms_scan_pf_kernel(const float* __restric
 #undef NMS_LDS_BARRIER
 }
 
+// ---------------------------------------------------------------------------------------------------
+// nms_scan_dq_kernel: the scan with the serial chain DECOUPLED from the bulk of the row ORs (nw <= 256, max_keep <= 4096).
+// Measured on nms_scan_pf_kernel (clock64 per section, 4 x 12 000 candidates): a 64-box chunk cost 5.7 us = 1 us issuing the
+// candidate prefetch + 2.5 us for the scalar resolve chain (one step per kept box) + 2.2 us for a memory round trip after it
+// (rows of kept boxes that were not prefetched), with every wave of the workgroup in lock-step. Here:
+//   wave 0 (resolver) owns the chain and nothing else. Lane i of chunk c has the diagonal word of row 64 c + i (symmetric, from
+//     nms_mask_kernel): the greedy choice inside the chunk is the fixed point of "kept if no kept predecessor overlaps, removed
+//     if one does", found by iterating over the undecided set with two ballots per round (rounds = overlap chain depth, a
+//     handful) instead of one scalar step per kept box. It also ORs the rows of the boxes it keeps into the next D = 8 words of
+//     the removed bitmap itself: lane (k, g) holds word c+1+k of rows 8g .. 8g+7 (one 64-B line per row) -> select by the kept
+//     bits, three xor-shuffles, s_urg[c+1+k]. It issues no global load: a FEEDER wave (the last one) runs ahead of it, fetches
+//     the diagonal + lookahead words of F = 4 chunks per memory round trip and hands them over through an LDS ring of 8 chunks.
+//   waves 1 .. NB (bulk, lane = word t of the bitmap) follow the published kept list at their own pace: up to 64 row loads in
+//     flight per lane, rows of chunk r applied to words t >= r + D + 1 only (the resolver covers r+1 .. r+D), result and
+//     progress published in LDS. The resolver needs word c complete through chunk c-D-1 -- D chunks of slack -- and spins
+//     on the owner's progress counter if it is not (no barrier inside the scan; LDS ops of a wave execute in order, so a
+//     reader that sees a counter sees the data written before it).
+// Same keep set, order and max_keep cut as the serial scan (the fixed point is unique).
+// ---------------------------------------------------------------------------------------------------
+// LDS mailbox accesses of nms_scan_dq_kernel through asm: a `volatile` access makes hipcc drain vmcnt as well (the row loads
+// in flight), and ordering is all that is needed -- LDS ops of a wave execute in issue order
+__device__ __forceinline__ unsigned lds_addr(const void* p) { return (unsigned)(uintptr_t)(__attribute__((address_space(3))) const char*)p; }
+__device__ __forceinline__ int lds_ld32(const void* p) {
+  int r; asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(r) : "v"(lds_addr(p)) : "memory"); return r;
+}
+__device__ __forceinline__ unsigned long long lds_ld64(const void* p) {
+  unsigned long long r; asm volatile("ds_read_b64 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(r) : "v"(lds_addr(p)) : "memory"); return r;
+}
+__device__ __forceinline__ i32x4 lds_ld128(const void* p) {
+  i32x4 r; asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(r) : "v"(lds_addr(p)) : "memory"); return r;
+}
+__device__ __forceinline__ void lds_st32(void* p, int v) { asm volatile("ds_write_b32 %0, %1" :: "v"(lds_addr(p)), "v"(v) : "memory"); }
+__device__ __forceinline__ void lds_st64(void* p, unsigned long long v) { asm volatile("ds_write_b64 %0, %1" :: "v"(lds_addr(p)), "v"(v) : "memory"); }
+
+#define NMS_DQ_D 8
+#define NMS_DQ_RING 8
+#define NMS_DQ_F 4
+#define NMS_DQ_BATCH 64
+__global__ void __launch_bounds__(384) nms_scan_dq_kernel(const float* __restrict__ boxes, const float* __restrict__ scores,
+                                                          const int* __restrict__ count, int cap, int nw,
+                                                          const unsigned long long* __restrict__ mask, int max_keep,
+                                                          int* __restrict__ keep_idx, int* __restrict__ keep_count,
+                                                          float* __restrict__ out_boxes, float* __restrict__ out_scores) {
+  __shared__ int s_keep[NMS_PF_MAXKEEP];
+  __shared__ int s_cend[260];                               // s_cend[c + 1] = boxes kept through chunk c
+  __shared__ unsigned long long s_bulk[256];                // word t: rows applied by the bulk lane that owns it
+  __shared__ unsigned long long s_urg[256 + NMS_DQ_D + 8];  // word t: rows applied by the resolver (chunks t-D .. t-1)
+  __shared__ unsigned long long s_ring[NMS_DQ_RING][9][64]; // per chunk: [0][i] diagonal word of row i; [1+j][lane (k, g)] word
+                                                            // c+1+k of row 8g+j
+  __shared__ int s_done[4];                                 // kept-list entries applied by bulk wave k
+  __shared__ __attribute__((aligned(16))) int s_pub[4];     // [0] kept-list length, [1] chunks resolved, [2] stop, [3] chunks fed
+#define NMS_CBAR() asm volatile("" ::: "memory")
+  const int b = blockIdx.x;
+  const int n = count ? min(count[b], cap) : cap;
+  const unsigned long long* mk = mask + (size_t)b * cap * nw;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nbulk = (nw + 63) / 64;
+  const int nchunks = (n + 63) / 64;
+  for (int i = tid; i < 256; i += blockDim.x) s_bulk[i] = 0ull;
+  for (int i = tid; i < 256 + NMS_DQ_D + 8; i += blockDim.x) s_urg[i] = 0ull;
+  if (tid < 4) { s_done[tid] = 0; s_pub[tid] = 0; }
+  if (tid == 0) s_cend[0] = 0;
+  __syncthreads();
+
+  if (wid == 0) {
+    // ------------------------------------------------------------------ resolver
+    const int l = lane, g = l >> 3;
+    const unsigned long long lowmask = (1ull << l) - 1ull;
+    int nkept = 0;
+    for (int c = 0; c < nchunks; ++c) {
+      const int need = c > NMS_DQ_D ? s_cend[c - NMS_DQ_D] : 0;        // kept through chunk c - D - 1
+      while (__builtin_amdgcn_readfirstlane(lds_ld32(&s_pub[3])) <= c) __builtin_amdgcn_s_sleep(1);
+      while (__builtin_amdgcn_readfirstlane(lds_ld32(&s_done[c >> 6])) < need) __builtin_amdgcn_s_sleep(1);
+      const unsigned long long cur = nms_uniform64(lds_ld64(&s_bulk[c]) | s_urg[c]);
+      const unsigned long long(*rg)[64] = s_ring[c & (NMS_DQ_RING - 1)];
+      const int lim = n - c * 64;
+      unsigned long long U = ~cur & (lim >= 64 ? ~0ull : ((1ull << lim) - 1ull));
+      const unsigned long long pred = rg[0][l] & lowmask;
+      unsigned long long uw[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) uw[i] = rg[1 + i][l];
+      unsigned long long K = 0ull;
+      while (U != 0ull) {
+        const bool in_u = (U >> l) & 1ull;
+        const bool rem = in_u && (pred & K) != 0ull;
+        const bool kp = in_u && !rem && (pred & U) == 0ull;
+        const unsigned long long kb = __ballot(kp), rb = __ballot(rem);
+        K |= kb;
+        U &= ~(kb | rb);
+      }
+      {   // max_keep cut: the first `room` kept boxes of the chunk
+        const int room = max_keep - nkept;
+        const int rank = __popcll(K & lowmask);
+        K = __ballot(((K >> l) & 1ull) && rank < room);
+        if ((K >> l) & 1ull) s_keep[nkept + rank] = c * 64 + l;
+      }
+      nkept += __popcll(K);
+      if (l == 0) s_cend[c + 1] = nkept;
+      {   // rows of the kept boxes -> words c+1 .. c+D
+        unsigned long long acc = 0ull;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc |= ((K >> (g * 8 + i)) & 1ull) ? uw[i] : 0ull;
+        acc |= __shfl_xor(acc, 8); acc |= __shfl_xor(acc, 16); acc |= __shfl_xor(acc, 32);
+        if (l < 8) s_urg[c + 1 + l] |= acc;
+      }
+      NMS_CBAR();
+      if (l == 0) { lds_st32(&s_pub[0], nkept); lds_st32(&s_pub[1], c + 1); }
+      if (nkept >= max_keep) break;
+    }
+    NMS_CBAR();
+    if (l == 0) lds_st32(&s_pub[2], 1);
+  } else if (wid == 1 + nbulk) {
+    // ------------------------------------------------------------------ feeder: diagonal + lookahead words, F chunks per round trip
+    const int l = lane, k = l & 7, g = l >> 3;
+    for (int c0 = 0; c0 < nchunks; c0 += NMS_DQ_F) {
+      bool stop = false;
+      while (true) {
+        const i32x4 pub = lds_ld128(s_pub);
+        stop = __builtin_amdgcn_readfirstlane(pub[2]) != 0;
+        if (stop || c0 + NMS_DQ_F <= __builtin_amdgcn_readfirstlane(pub[1]) + NMS_DQ_RING) break;
+        __builtin_amdgcn_s_sleep(1);
+      }
+      if (stop) break;
+      unsigned long long d[NMS_DQ_F], u[NMS_DQ_F][8];
+#pragma unroll
+      for (int f = 0; f < NMS_DQ_F; ++f) {
+        const int cc = c0 + f;
+        d[f] = mk[(size_t)min(cc * 64 + l, cap - 1) * nw + min(cc, nw - 1)];
+        const int wq = min(cc + 1 + k, nw - 1);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) u[f][i] = mk[(size_t)min(cc * 64 + g * 8 + i, cap - 1) * nw + wq];
+      }
+#pragma unroll
+      for (int f = 0; f < NMS_DQ_F; ++f) {
+        unsigned long long(*rg)[64] = s_ring[(c0 + f) & (NMS_DQ_RING - 1)];
+        rg[0][l] = d[f];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) rg[1 + i][l] = u[f][i];
+      }
+      NMS_CBAR();
+      if (l == 0) lds_st32(&s_pub[3], c0 + NMS_DQ_F);
+    }
+  } else {
+    // ------------------------------------------------------------------ bulk: lane = word t of the removed bitmap
+    const int kb = wid - 1, t = kb * 64 + lane, tcl = min(t, nw - 1);
+    const int mylim = t < nw ? t - NMS_DQ_D - 1 : -1;            // rows of chunks <= mylim are this lane's
+    const int last_word = kb * 64 + 63;
+    unsigned long long removed = 0ull;
+    int pos = 0;
+    while (true) {
+      const i32x4 pub = lds_ld128(s_pub);
+      const int stop = __builtin_amdgcn_readfirstlane(pub[2]);
+      const int prog = __builtin_amdgcn_readfirstlane(pub[1]);
+      const int avail = __builtin_amdgcn_readfirstlane(pub[0]);
+      if (stop || prog > last_word) break;                       // nobody will read this wave's words any more
+      if (avail == pos) { __builtin_amdgcn_s_sleep(2); continue; }
+      // all row loads of a batch are issued before the first use (unconditional, clamped to the batch: a select next to its
+      // load makes hipcc wait for every load in turn); a short batch when the resolver is only a few boxes ahead
+      auto batch = [&](auto BT) {
+        constexpr int B = decltype(BT)::value;
+        const int cnt = min(avail - pos, B);
+        unsigned long long v[B];
+        int ch[B];
+#pragma unroll
+        for (int u = 0; u < B; ++u) {
+          const int idx = __builtin_amdgcn_readfirstlane(s_keep[pos + min(u, cnt - 1)]);
+          ch[u] = u < cnt ? (idx >> 6) : 0x7fffffff;
+          v[u] = mk[(size_t)idx * nw + tcl];
+        }
+#pragma unroll
+        for (int u = 0; u < B; ++u) removed |= ch[u] <= mylim ? v[u] : 0ull;
+        pos += cnt;
+      };
+      if (avail - pos > 16) batch(std::integral_constant<int, NMS_DQ_BATCH>{});
+      else batch(std::integral_constant<int, 16>{});
+      lds_st64(&s_bulk[t], removed);
+      if (lane == 0) lds_st32(&s_done[kb], pos);
+    }
+  }
+  __syncthreads();
+  const int nkept = s_pub[0];
+  if (tid == 0) keep_count[b] = nkept;
+  for (int r = tid; r < nkept; r += blockDim.x) {
+    int i = s_keep[r];
+    size_t o = (size_t)b * max_keep + r;
+    keep_idx[o] = i;
+    if (out_boxes) *reinterpret_cast<f32x4*>(out_boxes + 4 * o) = *reinterpret_cast<const f32x4*>(boxes + ((size_t)b * cap + i) * 4);
+    if (out_scores) out_scores[o] = scores[(size_t)b * cap + i];
+  }
+#undef NMS_CBAR
+}
+
 extern "C" size_t unit_nms_workspace_bytes(int B, int cap) { return (size_t)B * cap * ((cap + 63) / 64) * 8; }
 
 extern "C" int unit_nms(const float* boxes_sorted, const float* scores_sorted, const int* count, int B, int cap,
@@ -640,9 +835,13 @@ extern "C" int unit_nms(const float* boxes_sorted, const float* scores_sorted, c
     nms_mask_kernel<<<dim3((nw + 3) / 4, nw, B), 256, 0, st>>>(boxes_sorted, count, cap, nw, thresh, (unsigned long long*)workspace);
     UNIT_LAUNCH_CHECK();
   }
-  static int no_pf = -1;
-  if (no_pf < 0) { const char* e = getenv("UNIT_NMS_NO_PREFETCH"); no_pf = e ? atoi(e) : 0; }
-  if (nw <= 256 && cap > 0 && max_keep <= NMS_PF_MAXKEEP && !no_pf)
+  // UNIT_NMS_SCAN: 2 (default) decoupled resolver / bulk waves, 1 lock-step scan with prefetch, 0 plain scan
+  static int mode = -1;
+  if (mode < 0) { const char* e = getenv("UNIT_NMS_SCAN"); mode = e ? atoi(e) : 2; }
+  if (nw <= 256 && cap > 0 && max_keep <= NMS_PF_MAXKEEP && mode == 2)
+    nms_scan_dq_kernel<<<B, 64 * (2 + (nw + 63) / 64), 0, st>>>(boxes_sorted, scores_sorted, count, cap, nw, (const unsigned long long*)workspace,
+                                                                max_keep, keep_idx, keep_count, out_boxes, out_scores);
+  else if (nw <= 256 && cap > 0 && max_keep <= NMS_PF_MAXKEEP && mode == 1)
     nms_scan_pf_kernel<<<B, 256, 0, st>>>(boxes_sorted, scores_sorted, count, cap, nw, (const unsigned long long*)workspace,
                                           max_keep, keep_idx, keep_count, out_boxes, out_scores);
   else
