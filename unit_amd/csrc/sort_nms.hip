@@ -637,7 +637,7 @@ __global__ void __launch_bounds__(256) nms_scan_pf_kernel(const float* __restric
 //     if one does", found by iterating over the undecided set with two ballots per round (rounds = overlap chain depth, a
 //     handful) instead of one scalar step per kept box. It also ORs the rows of the boxes it keeps into the next D = 8 words of
 //     the removed bitmap itself: lane (k, g) holds word c+1+k of rows 8g .. 8g+7 (one 64-B line per row) -> select by the kept
-//     bits, three xor-shuffles, s_urg[c+1+k]. It issues no global load: a FEEDER wave (the last one) runs ahead of it, fetches
+//     bits, LDS atomic OR into s_urg[c+1+k]. It issues no global load: a FEEDER wave (the last one) runs ahead of it, fetches
 //     the diagonal + lookahead words of F = 4 chunks per memory round trip and hands them over through an LDS ring of 8 chunks.
 //   waves 1 .. NB (bulk, lane = word t of the bitmap) follow the published kept list at their own pace: up to 64 row loads in
 //     flight per lane, rows of chunk r applied to words t >= r + D + 1 only (the resolver covers r+1 .. r+D), result and
@@ -662,9 +662,15 @@ __device__ __forceinline__ void lds_st32(void* p, int v) { asm volatile("ds_writ
 __device__ __forceinline__ void lds_st64(void* p, unsigned long long v) { asm volatile("ds_write_b64 %0, %1" :: "v"(lds_addr(p)), "v"(v) : "memory"); }
 
 #define NMS_DQ_D 8
-#define NMS_DQ_RING 8
-#define NMS_DQ_F 4
+#ifndef NMS_DQ_RING
+#define NMS_DQ_RING 12
+#endif
+#ifndef NMS_DQ_F
+#define NMS_DQ_F 6
+#endif
+#ifndef NMS_DQ_BATCH
 #define NMS_DQ_BATCH 64
+#endif
 __global__ void __launch_bounds__(384) nms_scan_dq_kernel(const float* __restrict__ boxes, const float* __restrict__ scores,
                                                           const int* __restrict__ count, int cap, int nw,
                                                           const unsigned long long* __restrict__ mask, int max_keep,
@@ -674,7 +680,8 @@ __global__ void __launch_bounds__(384) nms_scan_dq_kernel(const float* __restric
   __shared__ int s_cend[260];                               // s_cend[c + 1] = boxes kept through chunk c
   __shared__ unsigned long long s_bulk[256];                // word t: rows applied by the bulk lane that owns it
   __shared__ unsigned long long s_urg[256 + NMS_DQ_D + 8];  // word t: rows applied by the resolver (chunks t-D .. t-1)
-  __shared__ unsigned long long s_ring[NMS_DQ_RING][9][64]; // per chunk: [0][i] diagonal word of row i; [1+j][lane (k, g)] word
+  extern __shared__ __attribute__((aligned(16))) unsigned long long s_ring_raw[];
+  unsigned long long(*s_ring)[9][64] = reinterpret_cast<unsigned long long(*)[9][64]>(s_ring_raw);   // [RING] per chunk: [0][i] diagonal word of row i; [1+j][lane (k, g)] word
                                                             // c+1+k of row 8g+j
   __shared__ int s_done[4];                                 // kept-list entries applied by bulk wave k
   __shared__ __attribute__((aligned(16))) int s_pub[4];     // [0] kept-list length, [1] chunks resolved, [2] stop, [3] chunks fed
@@ -696,13 +703,16 @@ __global__ void __launch_bounds__(384) nms_scan_dq_kernel(const float* __restric
     // ------------------------------------------------------------------ resolver
     const int l = lane, g = l >> 3;
     const unsigned long long lowmask = (1ull << l) - 1ull;
-    int nkept = 0;
+    int nkept = 0, fed = 0, done = 0;
     for (int c = 0; c < nchunks; ++c) {
       const int need = c > NMS_DQ_D ? s_cend[c - NMS_DQ_D] : 0;        // kept through chunk c - D - 1
-      while (__builtin_amdgcn_readfirstlane(lds_ld32(&s_pub[3])) <= c) __builtin_amdgcn_s_sleep(1);
-      while (__builtin_amdgcn_readfirstlane(lds_ld32(&s_done[c >> 6])) < need) __builtin_amdgcn_s_sleep(1);
-      const unsigned long long cur = nms_uniform64(lds_ld64(&s_bulk[c]) | s_urg[c]);
-      const unsigned long long(*rg)[64] = s_ring[c & (NMS_DQ_RING - 1)];
+      // (the counters only grow: poll again only when the cached value does not already satisfy the chunk)
+      while (fed <= c) { fed = __builtin_amdgcn_readfirstlane(lds_ld32(&s_pub[3])); if (fed <= c) __builtin_amdgcn_s_sleep(1); }
+      if ((c & 63) == 0) done = 0;                                     // next bulk wave's counter
+      while (done < need) { done = __builtin_amdgcn_readfirstlane(lds_ld32(&s_done[c >> 6])); if (done < need) __builtin_amdgcn_s_sleep(1); }
+      NMS_CBAR();
+      const unsigned long long cur = nms_uniform64(s_bulk[c] | s_urg[c]);
+      const unsigned long long(*rg)[64] = s_ring[c % NMS_DQ_RING];
       const int lim = n - c * 64;
       unsigned long long U = ~cur & (lim >= 64 ? ~0ull : ((1ull << lim) - 1ull));
       const unsigned long long pred = rg[0][l] & lowmask;
@@ -730,8 +740,10 @@ __global__ void __launch_bounds__(384) nms_scan_dq_kernel(const float* __restric
         unsigned long long acc = 0ull;
 #pragma unroll
         for (int i = 0; i < 8; ++i) acc |= ((K >> (g * 8 + i)) & 1ull) ? uw[i] : 0ull;
-        acc |= __shfl_xor(acc, 8); acc |= __shfl_xor(acc, 16); acc |= __shfl_xor(acc, 32);
-        if (l < 8) s_urg[c + 1 + l] |= acc;
+        if (acc != 0ull) {          // eight lanes per word: LDS atomic OR (no return) instead of three 64-bit xor-shuffles
+          unsigned a = lds_addr(&s_urg[c + 1 + (l & 7)]);
+          asm volatile("ds_or_b64 %0, %1" :: "v"(a), "v"(acc) : "memory");
+        }
       }
       NMS_CBAR();
       if (l == 0) { lds_st32(&s_pub[0], nkept); lds_st32(&s_pub[1], c + 1); }
@@ -762,7 +774,7 @@ __global__ void __launch_bounds__(384) nms_scan_dq_kernel(const float* __restric
       }
 #pragma unroll
       for (int f = 0; f < NMS_DQ_F; ++f) {
-        unsigned long long(*rg)[64] = s_ring[(c0 + f) & (NMS_DQ_RING - 1)];
+        unsigned long long(*rg)[64] = s_ring[(c0 + f) % NMS_DQ_RING];
         rg[0][l] = d[f];
 #pragma unroll
         for (int i = 0; i < 8; ++i) rg[1 + i][l] = u[f][i];
@@ -838,10 +850,13 @@ extern "C" int unit_nms(const float* boxes_sorted, const float* scores_sorted, c
   // UNIT_NMS_SCAN: 2 (default) decoupled resolver / bulk waves, 1 lock-step scan with prefetch, 0 plain scan
   static int mode = -1;
   if (mode < 0) { const char* e = getenv("UNIT_NMS_SCAN"); mode = e ? atoi(e) : 2; }
-  if (nw <= 256 && cap > 0 && max_keep <= NMS_PF_MAXKEEP && mode == 2)
-    nms_scan_dq_kernel<<<B, 64 * (2 + (nw + 63) / 64), 0, st>>>(boxes_sorted, scores_sorted, count, cap, nw, (const unsigned long long*)workspace,
-                                                                max_keep, keep_idx, keep_count, out_boxes, out_scores);
-  else if (nw <= 256 && cap > 0 && max_keep <= NMS_PF_MAXKEEP && mode == 1)
+  if (nw <= 256 && cap > 0 && max_keep <= NMS_PF_MAXKEEP && mode == 2) {
+    constexpr int ring_bytes = NMS_DQ_RING * 9 * 64 * 8;
+    static bool attr_set = false;
+    if (!attr_set) { (void)hipFuncSetAttribute((const void*)nms_scan_dq_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, ring_bytes); attr_set = true; }
+    nms_scan_dq_kernel<<<B, 64 * (2 + (nw + 63) / 64), ring_bytes, st>>>(boxes_sorted, scores_sorted, count, cap, nw, (const unsigned long long*)workspace,
+                                                                          max_keep, keep_idx, keep_count, out_boxes, out_scores);
+  } else if (nw <= 256 && cap > 0 && max_keep <= NMS_PF_MAXKEEP && mode == 1)
     nms_scan_pf_kernel<<<B, 256, 0, st>>>(boxes_sorted, scores_sorted, count, cap, nw, (const unsigned long long*)workspace,
                                           max_keep, keep_idx, keep_count, out_boxes, out_scores);
   else
