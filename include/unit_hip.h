@@ -127,6 +127,7 @@ int unit_sort_desc_stable_topk(const float* src, long batch_stride, int ld, int 
 int unit_rpn_decode_select(const float* head, long head_batch_stride, int ld, int A, int delta_col0, const float* anchors,
                            const int* sorted_idx, const float* sorted_logit, int B, int Ncap, int topk, const float* image_hw_dev,
                            float scale_clamp, float min_size, float* cand_boxes, float* cand_scores, int* cand_count, void* stream);
+/* entries behind keep_count[b] are written too: keep_idx = -1, out_boxes / out_scores = 0 */
 size_t unit_nms_workspace_bytes(int B, int cap);
 int unit_nms(const float* boxes_sorted, const float* scores_sorted, const int* count, int B, int cap, float thresh, int max_keep,
              int* keep_idx, int* keep_count, float* out_boxes, float* out_scores, void* workspace, size_t workspace_bytes,

@@ -829,6 +829,12 @@ __global__ void __launch_bounds__(384) nms_scan_dq_kernel(const float* __restric
     if (out_boxes) *reinterpret_cast<f32x4*>(out_boxes + 4 * o) = *reinterpret_cast<const f32x4*>(boxes + ((size_t)b * cap + i) * 4);
     if (out_scores) out_scores[o] = scores[(size_t)b * cap + i];
   }
+  for (int r = nkept + tid; r < max_keep; r += blockDim.x) {        // tail: index -1, zero box / score (no host-side fills)
+    size_t o = (size_t)b * max_keep + r;
+    keep_idx[o] = -1;
+    if (out_boxes) *reinterpret_cast<f32x4*>(out_boxes + 4 * o) = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (out_scores) out_scores[o] = 0.f;
+  }
 #undef NMS_CBAR
 }
 
@@ -856,7 +862,14 @@ extern "C" int unit_nms(const float* boxes_sorted, const float* scores_sorted, c
     if (!attr_set) { (void)hipFuncSetAttribute((const void*)nms_scan_dq_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, ring_bytes); attr_set = true; }
     nms_scan_dq_kernel<<<B, 64 * (2 + (nw + 63) / 64), ring_bytes, st>>>(boxes_sorted, scores_sorted, count, cap, nw, (const unsigned long long*)workspace,
                                                                           max_keep, keep_idx, keep_count, out_boxes, out_scores);
-  } else if (nw <= 256 && cap > 0 && max_keep <= NMS_PF_MAXKEEP && mode == 1)
+    UNIT_LAUNCH_CHECK();
+    return UNIT_OK;
+  }
+  // the other scans write the kept prefix only: index -1, zero box / score behind it
+  (void)hipMemsetAsync(keep_idx, 0xFF, (size_t)B * max_keep * sizeof(int), st);
+  if (out_boxes) (void)hipMemsetAsync(out_boxes, 0, (size_t)B * max_keep * 4 * sizeof(float), st);
+  if (out_scores) (void)hipMemsetAsync(out_scores, 0, (size_t)B * max_keep * sizeof(float), st);
+  if (nw <= 256 && cap > 0 && max_keep <= NMS_PF_MAXKEEP && mode == 1)
     nms_scan_pf_kernel<<<B, 256, 0, st>>>(boxes_sorted, scores_sorted, count, cap, nw, (const unsigned long long*)workspace,
                                           max_keep, keep_idx, keep_count, out_boxes, out_scores);
   else

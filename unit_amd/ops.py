@@ -431,10 +431,10 @@ def nms(boxes_sorted, scores_sorted, count, thresh, max_keep):
     """boxes [B,cap,4] in descending score order -> (keep_idx [B,max_keep], keep_count [B], out_boxes, out_scores)"""
     b, cap = boxes_sorted.shape[0], boxes_sorted.shape[1]
     dev = boxes_sorted.device
-    keep = torch.full((b, max_keep), -1, dtype=torch.int32, device=dev)
+    keep = torch.empty((b, max_keep), dtype=torch.int32, device=dev)      # unit_nms writes the tails (-1 / 0) itself
     kc = torch.empty((b,), dtype=torch.int32, device=dev)
-    ob = torch.zeros((b, max_keep, 4), dtype=torch.float32, device=dev)
-    osc = torch.zeros((b, max_keep), dtype=torch.float32, device=dev)
+    ob = torch.empty((b, max_keep, 4), dtype=torch.float32, device=dev)
+    osc = torch.empty((b, max_keep), dtype=torch.float32, device=dev)
     nb = lib().unit_nms_workspace_bytes(b, cap)
     ws = workspace(nb, dev)
     check(lib().unit_nms(_p(boxes_sorted), _p(scores_sorted), _p(count), b, cap, float(thresh), max_keep, _p(keep), _p(kc), _p(ob),
