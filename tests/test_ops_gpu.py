@@ -457,7 +457,9 @@ def test_sort_desc_topk_min_exclusive(dev):
 def test_nms_exact(dev):
     o = ops()
     gen = g(9)
-    for n, thr, mk in [(1, 0.7, 10), (63, 0.5, 100), (1500, 0.7, 2000), (6000, 0.7, 1000), (12000, 0.7, 2000)]:
+    # 16 384 = the largest candidate count of the decoupled scan (256 bitmap words, four bulk waves); 16 500 takes the plain scan
+    for n, thr, mk in [(1, 0.7, 10), (63, 0.5, 100), (1500, 0.7, 2000), (6000, 0.7, 1000), (12000, 0.7, 2000), (16384, 0.6, 4096),
+                       (16500, 0.5, 500)]:
         b = rand_boxes(gen, n, lo=8, hi=200)
         b[n // 2:] = b[: n - n // 2] + torch.rand(n - n // 2, 4, generator=gen) * 6  # heavy overlaps
         s = torch.sort(torch.randn(n, generator=gen), descending=True)[0]
