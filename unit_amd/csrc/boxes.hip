@@ -352,6 +352,7 @@ __global__ void __launch_bounds__(1024) rpn_decode_select_rows_kernel(const floa
                                                                       const float* __restrict__ image_hw, float clampv, float min_size,
                                                                       float* __restrict__ cand_boxes, float* __restrict__ cand_scores,
                                                                       int* __restrict__ cand_count) {
+  __builtin_amdgcn_s_setprio(2);   // proposal chain = critical path of the step
   __shared__ int cnt[DEC_ROWS * 16 + 1];
   int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   float imh = image_hw[2 * b], imw = image_hw[2 * b + 1];

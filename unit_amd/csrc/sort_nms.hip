@@ -228,6 +228,7 @@ extern "C" int unit_sort_desc_stable(const float* src, long batch_stride, int ld
 __global__ void __launch_bounds__(1024) topk_select_kernel(const float* __restrict__ src, long bstride, int ld, int A, int col0, int n,
                                                            int topk, float min_excl, unsigned long long* __restrict__ cand,
                                                            int* __restrict__ cand_count) {
+  __builtin_amdgcn_s_setprio(2);   // proposal chain = critical path of the step; the other streams' kernels are throughput work
   __shared__ int hist[SEL_BINS];
   __shared__ int wsum[16];
   __shared__ int s_T, s_cnt;
@@ -283,6 +284,7 @@ __global__ void __launch_bounds__(1024) topk_select_kernel(const float* __restri
 __global__ void __launch_bounds__(256) rank_sort_kernel(const unsigned long long* __restrict__ cand, const int* __restrict__ cand_count,
                                                         int n, const float* __restrict__ src, long bstride, int ld, int A, int col0,
                                                         float* __restrict__ out_keys, int* __restrict__ out_idx) {
+  __builtin_amdgcn_s_setprio(2);   // proposal chain = critical path of the step; the other streams' kernels are throughput work
   __shared__ unsigned long long tile[1024];
   __shared__ int part[4][64];
   int b = blockIdx.y;
@@ -361,6 +363,7 @@ __device__ __forceinline__ bool nms_suppress_fast(const f32x4 a, float areaa, co
 // 256 threads = four waves, wave w owns column block 4 * blockIdx.x + w of row block blockIdx.y
 __global__ void __launch_bounds__(256) nms_mask_kernel(const float* __restrict__ boxes, const int* __restrict__ count, int cap, int nw,
                                                        float thresh, unsigned long long* __restrict__ mask) {
+  __builtin_amdgcn_s_setprio(2);   // proposal chain = critical path of the step; the other streams' kernels are throughput work
   int b = blockIdx.z;
   int n = count ? min(count[b], cap) : cap;
   int rb = blockIdx.y, cb0 = blockIdx.x * 4;
@@ -698,6 +701,9 @@ __global__ void __launch_bounds__(384) nms_scan_dq_kernel(const float* __restric
   if (tid < 4) { s_done[tid] = 0; s_pub[tid] = 0; }
   if (tid == 0) s_cend[0] = 0;
   __syncthreads();
+  // the scan is a latency chain on the step's critical path, co-resident with throughput kernels of the other streams: its waves
+  // issue first on their SIMDs
+  __builtin_amdgcn_s_setprio(3);
 
   if (wid == 0) {
     // ------------------------------------------------------------------ resolver
