@@ -642,8 +642,8 @@ __global__ void __launch_bounds__(256) nms_scan_pf_kernel(const float* __restric
 //     the removed bitmap itself: lane (k, g) holds word c+1+k of rows 8g .. 8g+7 (one 64-B line per row) -> select by the kept
 //     bits, LDS atomic OR into s_urg[c+1+k]. It issues no global load: a FEEDER wave (the last one) runs ahead of it, fetches
 //     the diagonal + lookahead words of F = 4 chunks per memory round trip and hands them over through an LDS ring of 8 chunks.
-//   waves 1 .. NB (bulk, lane = word t of the bitmap) follow the published kept list at their own pace: up to 64 row loads in
-//     flight per lane, rows of chunk r applied to words t >= r + D + 1 only (the resolver covers r+1 .. r+D), result and
+//   waves 1 .. 2 NB (bulk, lane = word t of the bitmap, two waves per 64 words taking alternate 64-entry blocks of the list)
+//     follow the published kept list at their own pace: up to 64 row loads in flight per lane, rows of chunk r applied to words t >= r + D + 1 only (the resolver covers r+1 .. r+D), result and
 //     progress published in LDS. The resolver needs word c complete through chunk c-D-1 -- D chunks of slack -- and spins
 //     on the owner's progress counter if it is not (no barrier inside the scan; LDS ops of a wave execute in order, so a
 //     reader that sees a counter sees the data written before it).
@@ -674,19 +674,19 @@ __device__ __forceinline__ void lds_st64(void* p, unsigned long long v) { asm vo
 #ifndef NMS_DQ_BATCH
 #define NMS_DQ_BATCH 64
 #endif
-__global__ void __launch_bounds__(384) nms_scan_dq_kernel(const float* __restrict__ boxes, const float* __restrict__ scores,
+__global__ void __launch_bounds__(640) nms_scan_dq_kernel(const float* __restrict__ boxes, const float* __restrict__ scores,
                                                           const int* __restrict__ count, int cap, int nw,
                                                           const unsigned long long* __restrict__ mask, int max_keep,
                                                           int* __restrict__ keep_idx, int* __restrict__ keep_count,
                                                           float* __restrict__ out_boxes, float* __restrict__ out_scores) {
   __shared__ int s_keep[NMS_PF_MAXKEEP];
   __shared__ int s_cend[260];                               // s_cend[c + 1] = boxes kept through chunk c
-  __shared__ unsigned long long s_bulk[256];                // word t: rows applied by the bulk lane that owns it
+  __shared__ unsigned long long s_bulk[2][256];             // word t: rows applied by the two bulk lanes that own it
   __shared__ unsigned long long s_urg[256 + NMS_DQ_D + 8];  // word t: rows applied by the resolver (chunks t-D .. t-1)
   extern __shared__ __attribute__((aligned(16))) unsigned long long s_ring_raw[];
   unsigned long long(*s_ring)[9][64] = reinterpret_cast<unsigned long long(*)[9][64]>(s_ring_raw);   // [RING] per chunk: [0][i] diagonal word of row i; [1+j][lane (k, g)] word
                                                             // c+1+k of row 8g+j
-  __shared__ int s_done[4];                                 // kept-list entries applied by bulk wave k
+  __shared__ __attribute__((aligned(8))) int s_done[4][2];  // bulk wave (k, sub): every kept-list entry of ITS blocks below this index is applied
   __shared__ __attribute__((aligned(16))) int s_pub[4];     // [0] kept-list length, [1] chunks resolved, [2] stop, [3] chunks fed
 #define NMS_CBAR() asm volatile("" ::: "memory")
   const int b = blockIdx.x;
@@ -696,9 +696,9 @@ __global__ void __launch_bounds__(384) nms_scan_dq_kernel(const float* __restric
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int nbulk = (nw + 63) / 64;
   const int nchunks = (n + 63) / 64;
-  for (int i = tid; i < 256; i += blockDim.x) s_bulk[i] = 0ull;
+  for (int i = tid; i < 512; i += blockDim.x) (&s_bulk[0][0])[i] = 0ull;
   for (int i = tid; i < 256 + NMS_DQ_D + 8; i += blockDim.x) s_urg[i] = 0ull;
-  if (tid < 4) { s_done[tid] = 0; s_pub[tid] = 0; }
+  if (tid < 4) { s_done[tid][0] = 0; s_done[tid][1] = 64; s_pub[tid] = 0; }     // sub 1 owns nothing below entry 64
   if (tid == 0) s_cend[0] = 0;
   __syncthreads();
   // the scan is a latency chain on the step's critical path, co-resident with throughput kernels of the other streams: its waves
@@ -715,9 +715,13 @@ __global__ void __launch_bounds__(384) nms_scan_dq_kernel(const float* __restric
       // (the counters only grow: poll again only when the cached value does not already satisfy the chunk)
       while (fed <= c) { fed = __builtin_amdgcn_readfirstlane(lds_ld32(&s_pub[3])); if (fed <= c) __builtin_amdgcn_s_sleep(1); }
       if ((c & 63) == 0) done = 0;                                     // next bulk wave's counter
-      while (done < need) { done = __builtin_amdgcn_readfirstlane(lds_ld32(&s_done[c >> 6])); if (done < need) __builtin_amdgcn_s_sleep(1); }
+      while (done < need) {
+        const unsigned long long dd = lds_ld64(&s_done[c >> 6][0]);
+        done = __builtin_amdgcn_readfirstlane(min((int)(unsigned)dd, (int)(unsigned)(dd >> 32)));
+        if (done < need) __builtin_amdgcn_s_sleep(1);
+      }
       NMS_CBAR();
-      const unsigned long long cur = nms_uniform64(s_bulk[c] | s_urg[c]);
+      const unsigned long long cur = nms_uniform64(s_bulk[0][c] | s_bulk[1][c] | s_urg[c]);
       const unsigned long long(*rg)[64] = s_ring[c % NMS_DQ_RING];
       const int lim = n - c * 64;
       unsigned long long U = ~cur & (lim >= 64 ? ~0ull : ((1ull << lim) - 1ull));
@@ -757,7 +761,7 @@ __global__ void __launch_bounds__(384) nms_scan_dq_kernel(const float* __restric
     }
     NMS_CBAR();
     if (l == 0) lds_st32(&s_pub[2], 1);
-  } else if (wid == 1 + nbulk) {
+  } else if (wid == 1 + 2 * nbulk) {
     // ------------------------------------------------------------------ feeder: diagonal + lookahead words, F chunks per round trip
     const int l = lane, k = l & 7, g = l >> 3;
     for (int c0 = 0; c0 < nchunks; c0 += NMS_DQ_F) {
@@ -790,23 +794,27 @@ __global__ void __launch_bounds__(384) nms_scan_dq_kernel(const float* __restric
     }
   } else {
     // ------------------------------------------------------------------ bulk: lane = word t of the removed bitmap
-    const int kb = wid - 1, t = kb * 64 + lane, tcl = min(t, nw - 1);
+    // two waves per 64 words: wave (kb, sub) applies the kept-list blocks j = sub, sub + 2, ... (64 entries each) -- 2 x 64 row
+    // loads in flight per word when the resolver runs ahead (the scan is then bound by exactly that: latency x loads in flight)
+    const int kb = (wid - 1) >> 1, sub = (wid - 1) & 1, t = kb * 64 + lane, tcl = min(t, nw - 1);
     const int mylim = t < nw ? t - NMS_DQ_D - 1 : -1;            // rows of chunks <= mylim are this lane's
     const int last_word = kb * 64 + 63;
     unsigned long long removed = 0ull;
-    int pos = 0;
+    int base = sub * 64, off = 0;                                // current block of this wave, entries of it already applied
     while (true) {
       const i32x4 pub = lds_ld128(s_pub);
       const int stop = __builtin_amdgcn_readfirstlane(pub[2]);
       const int prog = __builtin_amdgcn_readfirstlane(pub[1]);
       const int avail = __builtin_amdgcn_readfirstlane(pub[0]);
       if (stop || prog > last_word) break;                       // nobody will read this wave's words any more
-      if (avail == pos) { __builtin_amdgcn_s_sleep(2); continue; }
+      const int pos = base + off;
+      const int end = min(avail, base + 64);
+      if (end <= pos) { __builtin_amdgcn_s_sleep(2); continue; }
       // all row loads of a batch are issued before the first use (unconditional, clamped to the batch: a select next to its
       // load makes hipcc wait for every load in turn); a short batch when the resolver is only a few boxes ahead
       auto batch = [&](auto BT) {
         constexpr int B = decltype(BT)::value;
-        const int cnt = min(avail - pos, B);
+        const int cnt = min(end - pos, B);
         unsigned long long v[B];
         int ch[B];
 #pragma unroll
@@ -817,12 +825,13 @@ __global__ void __launch_bounds__(384) nms_scan_dq_kernel(const float* __restric
         }
 #pragma unroll
         for (int u = 0; u < B; ++u) removed |= ch[u] <= mylim ? v[u] : 0ull;
-        pos += cnt;
+        off += cnt;
       };
-      if (avail - pos > 16) batch(std::integral_constant<int, NMS_DQ_BATCH>{});
+      if (end - pos > 16) batch(std::integral_constant<int, NMS_DQ_BATCH>{});
       else batch(std::integral_constant<int, 16>{});
-      lds_st64(&s_bulk[t], removed);
-      if (lane == 0) lds_st32(&s_done[kb], pos);
+      if (off == 64) { base += 128; off = 0; }                   // the block in between is the other wave's
+      lds_st64(&s_bulk[sub][t], removed);
+      if (lane == 0) lds_st32(&s_done[kb][sub], base + off);
     }
   }
   __syncthreads();
@@ -866,7 +875,7 @@ extern "C" int unit_nms(const float* boxes_sorted, const float* scores_sorted, c
     constexpr int ring_bytes = NMS_DQ_RING * 9 * 64 * 8;
     static bool attr_set = false;
     if (!attr_set) { (void)hipFuncSetAttribute((const void*)nms_scan_dq_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, ring_bytes); attr_set = true; }
-    nms_scan_dq_kernel<<<B, 64 * (2 + (nw + 63) / 64), ring_bytes, st>>>(boxes_sorted, scores_sorted, count, cap, nw, (const unsigned long long*)workspace,
+    nms_scan_dq_kernel<<<B, 64 * (2 + 2 * ((nw + 63) / 64)), ring_bytes, st>>>(boxes_sorted, scores_sorted, count, cap, nw, (const unsigned long long*)workspace,
                                                                           max_keep, keep_idx, keep_count, out_boxes, out_scores);
     UNIT_LAUNCH_CHECK();
     return UNIT_OK;
