@@ -194,7 +194,8 @@ __global__ void __launch_bounds__(SORT_THREADS) radix_sort_reg_kernel(const floa
   }
 }
 
-extern "C" size_t unit_sort_workspace_bytes(int B, int n) { return (size_t)B * 2 * n * 8; }
+// [B][n] candidates / sort ping-pong buffers, candidate counts, and the [B][8192] (start, end) group table of the top-k path
+extern "C" size_t unit_sort_workspace_bytes(int B, int n) { return (size_t)B * 2 * n * 8 + (size_t)B * 8192 * 8 + 256; }
 
 extern "C" int unit_sort_desc_stable(const float* src, long batch_stride, int ld, int A, int col0, int B, int n,
                                      float* out_keys, int* out_idx, void* workspace, size_t workspace_bytes, void* stream) {
@@ -218,16 +219,18 @@ extern "C" int unit_sort_desc_stable(const float* src, long batch_stride, int ld
 // row (12 000 of 35 910 per image in training).  A single-workgroup radix sort leaves 252 of the 256 CUs idle for ~1 ms,
 // so the top-k path is chip-wide instead:
 //  (1) topk_select_kernel (one workgroup per image): 8192-bin histogram of the top 13 key bits -> the bin T holding the
-//      topk-th best key -> every key in a bin <= T becomes a candidate, packed as (key << 32 | index) in arbitrary order
-//      (wave-aggregated LDS counter). Nc >= min(topk, n) candidates; all non-candidates sort after every candidate.
-//  (2) rank_sort_kernel (64 candidates x 4 j-quarters per workgroup, ~800 workgroups): rank(i) = #{j : cand_j < cand_i}
-//      on the unique 64-bit composites (ties broken by ascending original index = the stable order), an O(Nc^2) count
-//      that is pure VALU + broadcast LDS reads; writes out[rank].  Entries beyond Nc are left untouched.
+//      topk-th best key -> every key in a bin <= T becomes a candidate, packed as (key << 32 | index) and written GROUPED BY
+//      BIN (a counting sort on the 13 bits: position = prefix of the bin + an LDS cursor; order inside a group arbitrary);
+//      the (start, end) of every group goes to a table. Nc >= min(topk, n) candidates; non-candidates sort after them.
+//  (2) group_rank_kernel (64 candidates per workgroup): rank(i) = start of its group + #{j in the group : cand_j < cand_i} on the
+//      unique 64-bit composites (ties broken by ascending original index = the stable order); writes out[rank]. The groups
+//      hold a few hundred candidates (16 bins per octave of score), so this is ~1/50 of the all-pairs count it replaces
+//      (rank_sort_kernel, kept for reference: 85 us for 4 x 12 000). Entries beyond Nc are left untouched.
 // ---------------------------------------------------------------------------------------------------
 #define SEL_BINS 8192
 __global__ void __launch_bounds__(1024) topk_select_kernel(const float* __restrict__ src, long bstride, int ld, int A, int col0, int n,
                                                            int topk, float min_excl, unsigned long long* __restrict__ cand,
-                                                           int* __restrict__ cand_count) {
+                                                           int* __restrict__ cand_count, int2* __restrict__ groups) {
   __builtin_amdgcn_s_setprio(2);   // proposal chain = critical path of the step; the other streams' kernels are throughput work
   __shared__ int hist[SEL_BINS];
   __shared__ int wsum[16];
@@ -261,24 +264,67 @@ __global__ void __launch_bounds__(1024) topk_select_kernel(const float* __restri
   }
   __syncthreads();
   unsigned T = (unsigned)s_T;
-  unsigned long long* cb = cand + (size_t)b * n;
-  for (int base = 0; base < n; base += 1024) {
-    int i = base + tid;
-    unsigned key = 0; bool c = false;
-    if (i < n) {
-      int pix = i / A, a = i - pix * A;
-      float v = sb[(size_t)pix * ld + a];
-      key = desc_key(v);
-      c = (key >> 19) <= T && v > min_excl;
-    }
-    unsigned long long bal = __ballot(c);
-    int wpos = 0;
-    if (lane == 0 && bal) wpos = atomicAdd(&s_cnt, __popcll(bal));
-    wpos = __shfl(wpos, 0, 64);
-    if (c) cb[wpos + __popcll(bal & ((1ull << lane) - 1ull))] = ((unsigned long long)key << 32) | (unsigned)i;
+  // group table + cursors: hist[bin] becomes the write cursor of the bin (its exclusive prefix)
+  int2* gb = groups + (size_t)b * SEL_BINS;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    int bin = tid * 8 + j;
+    int lo = excl + loc[j], hi = lo + hist[bin];
+    gb[bin] = make_int2(lo, hi);
+    if ((unsigned)bin == T) s_cnt = hi;                   // candidates = every key of the bins <= T
   }
   __syncthreads();
+#pragma unroll
+  for (int j = 0; j < 8; ++j) hist[tid * 8 + j] = excl + loc[j];
+  __syncthreads();
+  unsigned long long* cb = cand + (size_t)b * n;
+  for (int i = tid; i < n; i += 1024) {
+    int pix = i / A, a = i - pix * A;
+    float v = sb[(size_t)pix * ld + a];
+    unsigned key = desc_key(v);
+    if ((key >> 19) <= T && v > min_excl) cb[atomicAdd(&hist[key >> 19], 1)] = ((unsigned long long)key << 32) | (unsigned)i;
+  }
   if (tid == 0) cand_count[b] = s_cnt;
+}
+
+__global__ void __launch_bounds__(256) group_rank_kernel(const unsigned long long* __restrict__ cand, const int* __restrict__ cand_count,
+                                                         const int2* __restrict__ groups, int n, const float* __restrict__ src, long bstride,
+                                                         int ld, int A, int col0, float* __restrict__ out_keys, int* __restrict__ out_idx) {
+  // 64 consecutive (bin-grouped) candidates per workgroup; they are compared with the candidates of THEIR groups only: everything
+  // before the first group is smaller, everything behind the last one larger. Tiles of 1024 composites through LDS, the four
+  // waves take a quarter of each tile (rank_sort_kernel's loop over a sub-range).
+  __builtin_amdgcn_s_setprio(2);   // proposal chain = critical path of the step
+  __shared__ unsigned long long tile[1024];
+  __shared__ int part[4][64];
+  int b = blockIdx.y;
+  int nc = cand_count[b];
+  int i0 = blockIdx.x * 64;
+  if (i0 >= nc) return;
+  int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const unsigned long long* c = cand + (size_t)b * n;
+  const int2* gb = groups + (size_t)b * SEL_BINS;
+  unsigned long long mine = (i0 + lane < nc) ? c[i0 + lane] : ~0ull;
+  int rs = gb[(unsigned)(c[i0] >> 51)].x;                                  // bin = key >> 19 = composite >> 51
+  int re = gb[(unsigned)(c[min(i0 + 63, nc - 1)] >> 51)].y;
+  int cnt = 0;
+  for (int j0 = rs; j0 < re; j0 += 1024) {
+    __syncthreads();
+#pragma unroll
+    for (int t = tid; t < 1024; t += 256) tile[t] = (j0 + t < re) ? c[j0 + t] : ~0ull;   // ~0 is never < anything
+    __syncthreads();
+    const unsigned long long* tq = tile + wid * 256;
+#pragma unroll 16
+    for (int j = 0; j < 256; ++j) cnt += (tq[j] < mine) ? 1 : 0;
+  }
+  part[wid][lane] = cnt;
+  __syncthreads();
+  if (wid == 0 && i0 + lane < nc) {
+    int r = rs + part[0][lane] + part[1][lane] + part[2][lane] + part[3][lane];
+    int id = (int)(unsigned)(mine & 0xffffffffull);
+    int pix = id / A, a = id - pix * A;
+    out_keys[(size_t)b * n + r] = src[(size_t)b * bstride + (size_t)pix * ld + col0 + a];   // original bits (keeps -0.0)
+    out_idx[(size_t)b * n + r] = id;
+  }
 }
 
 __global__ void __launch_bounds__(256) rank_sort_kernel(const unsigned long long* __restrict__ cand, const int* __restrict__ cand_count,
@@ -323,10 +369,15 @@ extern "C" int unit_sort_desc_stable_topk(const float* src, long batch_stride, i
   if (B == 0 || n == 0) return UNIT_OK;
   unsigned long long* cand = (unsigned long long*)workspace;
   int* cand_count = (int*)((char*)workspace + (size_t)B * n * 8);
+  int2* groups = (int2*)((char*)workspace + (((size_t)B * 2 * n * 8 + 255) & ~(size_t)255));
   hipStream_t st = (hipStream_t)stream;
-  topk_select_kernel<<<B, 1024, 0, st>>>(src, batch_stride, ld, A, col0, n, topk, min_exclusive, cand, cand_count);
+  topk_select_kernel<<<B, 1024, 0, st>>>(src, batch_stride, ld, A, col0, n, topk, min_exclusive, cand, cand_count, groups);
   UNIT_LAUNCH_CHECK();
-  rank_sort_kernel<<<dim3((n + 63) / 64, B), 256, 0, st>>>(cand, cand_count, n, src, batch_stride, ld, A, col0, out_keys, out_idx);
+  // UNIT_RANK_ALLPAIRS=1: the all-pairs rank count this replaced (A/B, tools/nms_bench.py)
+  static int allpairs = -1;
+  if (allpairs < 0) { const char* e = getenv("UNIT_RANK_ALLPAIRS"); allpairs = e ? atoi(e) : 0; }
+  if (allpairs) rank_sort_kernel<<<dim3((n + 63) / 64, B), 256, 0, st>>>(cand, cand_count, n, src, batch_stride, ld, A, col0, out_keys, out_idx);
+  else group_rank_kernel<<<dim3((n + 63) / 64, B), 256, 0, st>>>(cand, cand_count, groups, n, src, batch_stride, ld, A, col0, out_keys, out_idx);
   UNIT_LAUNCH_CHECK();
   return UNIT_OK;
 }
