@@ -175,17 +175,7 @@ class WeaklySupervisedRCNNNoMeta(nn.Module):
         if getattr(self, "plan", None) is not None:
             self.plan.prep_all(self.compute_dtype, self.version)
 
-    def _join_prep(self):
-        """the RoI heads' prepared weights of the last optimizer step are refreshed on a side stream (multi.ConvPlan.prep_all):
-        make the current stream wait for them."""
-        ev = getattr(self, "_prep_event", None)
-        if ev is not None:
-            torch.cuda.current_stream().wait_event(ev)
-            self._prep_event = None
-
-    def _ensure_ready(self, join_prep=True):
-        if join_prep:
-            self._join_prep()
+    def _ensure_ready(self):
         if self.training and (self.store is None or not self.store.is_current()):
             self.flatten_parameters()
         dt, v = self.compute_dtype, self.version
@@ -255,7 +245,7 @@ class WeaklySupervisedRCNNNoMeta(nn.Module):
         """-> step context (holds `losses` fp32[9] on the device and everything backward_train needs).
         early_backward: the caller WILL run backward_train right after (train_step / TrainerNoMeta.run_step); branches whose
         backward does not depend on later forward work (the RPN head) may then start during the forward plan."""
-        self._ensure_ready(join_prep=False)     # the heads' weight copies may still be refreshing: joined before the first head conv
+        self._ensure_ready()
         self._early_backward = early_backward
         rpn, rh, bp = self.proposal_generator, self.roi_heads, self.roi_heads.box_predictor
         dt = self.compute_dtype
@@ -372,7 +362,6 @@ class WeaklySupervisedRCNNNoMeta(nn.Module):
 
         # a9 Res5 heads: box_head on the supervised RoIs (grad); weak_box_head on ALL RoIs in one pass -- its supervised
         # half is the reference's no_grad evaluation (roi_heads.py:502-504), its weak half has grad (:512-513)
-        self._join_prep()
         multi = rh.weak_box_head is not None
         box_trainable = any(p.requires_grad for p in rh.box_head.parameters())
         c.head_overlap = False
@@ -604,7 +593,6 @@ class WeaklySupervisedRCNNNoMeta(nn.Module):
             self._head_stream = torch.cuda.Stream(self.device)
             self._wgrad_stream = torch.cuda.Stream(self.device)
             self._rpn_stream = torch.cuda.Stream(self.device)
-            self._prep_stream = torch.cuda.Stream(self.device)
         return True
 
     def _reattach_grads(self):

@@ -111,30 +111,13 @@ class ConvPlan:
         convs = [m for m in self.convs if m.wf is not None and m.wf.dtype == dtype and m.wd is not None]
         if len(convs) != len(self.convs):
             return False           # first step: the per-layer prepare() path allocates the copies
-        # two launches: backbone / RPN copies on the current stream (the next step needs them at once); the RoI heads' copies
-        # (two Res5 stacks: most of the bytes) on a side stream beside the next step's backbone forward -- the step waits for
-        # `model._prep_event` before its first head kernel (rcnn.forward_train), every other entry point in _ensure_ready
-        late_ids = {id(x) for x in self.model.roi_heads.modules()}
-        split = self.model._streams_on() if hasattr(self.model, "_streams_on") else False
-        early = [m for m in convs if id(m) not in late_ids] if split else convs
-        late = [m for m in convs if id(m) in late_ids] if split else []
-        sig = tuple((m.wf.data_ptr(), m.wd.data_ptr()) for m in early) + (None,) + tuple((m.wf.data_ptr(), m.wd.data_ptr()) for m in late)
-        if self._prep_table is None or self._prep_table[2] != sig:
-            self._prep_table = (self._build(early, False) if early else None, self._build(late, False) if late else None, sig)
-        te, tl, _ = self._prep_table
-        if te is not None:
-            check(lib().unit_multi_weight_prep(ops._p(te[0]), te[1], te[2], ops._p(self.model.store.params), ops.dt(dtype), ops._s()),
-                  "multi_weight_prep")
-        if tl is not None:
-            main = torch.cuda.current_stream()
-            side = self.model._prep_stream
-            side.wait_stream(main)
-            with torch.cuda.stream(side):
-                check(lib().unit_multi_weight_prep(ops._p(tl[0]), tl[1], tl[2], ops._p(self.model.store.params), ops.dt(dtype), ops._s()),
-                      "multi_weight_prep")
-                ev = torch.cuda.Event()
-                ev.record(side)
-            self.model._prep_event = ev
+        sig = tuple((m.wf.data_ptr(), m.wd.data_ptr()) for m in convs)
+        if self._prep_table is None or self._prep_table[3] != sig:
+            dev, n, blocks = self._build(convs, False)
+            self._prep_table = (dev, n, blocks, sig)
+        t = self._prep_table
+        check(lib().unit_multi_weight_prep(ops._p(t[0]), t[1], t[2], ops._p(self.model.store.params), ops.dt(dtype), ops._s()),
+              "multi_weight_prep")
         for m in convs:
             m._prep_key = (dtype, version, _FROZEN_EPOCH[0], m.weight.data_ptr(), True)
         return True
