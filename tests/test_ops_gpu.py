@@ -500,6 +500,37 @@ def test_nms_ragged_and_degenerate_batches(dev):
     assert int(kc[0]) == 0 and int(kc[2]) == 1 and int(kc[3]) == mk
 
 
+def test_nms_randomised_against_oracle(dev):
+    """30 random problems (batch, candidate count per image incl. empty, keep limit, threshold, cluster structure from a handful of
+    heavily overlapping objects to hundreds): keep lists, counts and the -1 tails vs the oracle (tools/nms_stress.py is the long form)."""
+    o = ops()
+    gen = g(77)
+    for it in range(30):
+        b = int(torch.randint(1, 5, (1,), generator=gen))
+        cap = int(torch.randint(1, 5000, (1,), generator=gen)) if it % 6 else int(torch.randint(12000, 16384, (1,), generator=gen))
+        mk = int(torch.randint(1, 2500, (1,), generator=gen))
+        thr = float(torch.rand(1, generator=gen) * 0.8 + 0.1)
+        nobj = int(torch.randint(1, 300, (1,), generator=gen))
+        jitter = float(torch.rand(1, generator=gen) * 30)
+        cnt = torch.randint(0, cap + 1, (b,), generator=gen).int()
+        cnt[0] = cap
+        ctr = torch.rand(b, nobj, 2, generator=gen) * torch.tensor([1000., 600.])
+        szo = 20 + torch.rand(b, nobj, generator=gen) * 300
+        pick = torch.randint(0, nobj, (b, cap), generator=gen)
+        c = torch.gather(ctr, 1, pick[..., None].expand(-1, -1, 2)) + torch.randn(b, cap, 2, generator=gen) * jitter
+        sz = torch.gather(szo, 1, pick) * (1 + 0.1 * torch.randn(b, cap, generator=gen)).abs()
+        boxes = torch.cat([c - sz[..., None] / 2, c + sz[..., None] / 2], -1).clamp(min=0)
+        scores = torch.sort(torch.randn(b, cap, generator=gen), dim=1, descending=True)[0]
+        keep, kc, ob, osc = o.nms(boxes.to(dev), scores.to(dev), cnt.to(dev), thr, mk)
+        keep, kc = keep.cpu().numpy(), kc.cpu().numpy()
+        for i in range(b):
+            n = int(cnt[i])
+            ref = orc.nms_sorted(boxes[i, :n].numpy(), thr)[:mk] if n else np.zeros(0, np.int64)
+            assert kc[i] == len(ref), (it, i, cap, n, mk, thr, kc[i], len(ref))
+            assert np.array_equal(keep[i, :len(ref)], ref) and (keep[i, len(ref):] == -1).all(), (it, i)
+            assert torch.equal(ob[i, :len(ref)].cpu(), boxes[i][torch.from_numpy(ref)]) if len(ref) else True
+
+
 def test_rpn_proposals(dev):
     o = ops()
     gen = g(10)
