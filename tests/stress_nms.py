@@ -1,4 +1,4 @@
-"""Randomised NMS stress against the oracle (sizes, thresholds, keep limits, batch, overlap structure): python tools/nms_stress.py [iters]
+"""Randomised NMS stress against the oracle (sizes, thresholds, keep limits, batch, overlap structure): python tests/stress_nms.py [iters]
 (run under `timeout`: the decoupled scan synchronises its waves through LDS mailboxes)"""
 import sys
 

@@ -502,7 +502,7 @@ def test_nms_ragged_and_degenerate_batches(dev):
 
 def test_nms_randomised_against_oracle(dev):
     """30 random problems (batch, candidate count per image incl. empty, keep limit, threshold, cluster structure from a handful of
-    heavily overlapping objects to hundreds): keep lists, counts and the -1 tails vs the oracle (tools/nms_stress.py is the long form)."""
+    heavily overlapping objects to hundreds): keep lists, counts and the -1 tails vs the oracle (tests/stress_nms.py is the long form)."""
     o = ops()
     gen = g(77)
     for it in range(30):
