@@ -212,8 +212,10 @@ int unit_mask_targets(const unsigned char* gt_masks, int Mcap, int Hm, int Wm, c
                       int K, int S, int M, unsigned char* out, void* stream);
 int unit_mask_bce_loss(const float* logits, int K, int ldk, const int* cls, const unsigned char* targets, int S, int M, float gscale,
                        float* loss, void* dlogits, int d_dtype, void* stream);
-int unit_mask_probs(const float* logits, int K, int ldk, const int* cls, const float* sim, const int* base_dev, int n_base, int n_novel,
-                    const int8_t* role_dev, const int* slot_dev, int S, int M, float* out, void* stream);
+/* delta_col0 >= 0: the logits carry K more columns from there (`predictor_delta` of MaskRCNNConvUpsampleHeadWithFineTune,
+ * mask_head.py:39-94), added AFTER the base->novel transfer (:91); -1: none */
+int unit_mask_probs(const float* logits, int K, int ldk, int delta_col0, const int* cls, const float* sim, const int* base_dev, int n_base,
+                    int n_novel, const int8_t* role_dev, const int* slot_dev, int S, int M, float* out, void* stream);
 int unit_gather_match_index(const int* sampled_idx, int S, const int64_t* match_idx, int Ncap, int B, int* out, void* stream);
 /* paste_masks_in_image of detector_postprocess (modeling/meta_arch/rcnn.py:423 -> d2 layers/mask_ops.py): probs [S][M][M],
  * boxes [S][4] in output-image coordinates, valid [S] or NULL -> uint8 [S][H][W] = (bilinear sample >= threshold) */

@@ -1,0 +1,171 @@
+"""Step-level half of gen_unit_golden.py: runs the reference's WeaklySupervisedRCNNNoMeta.forward (training and inference) on
+tiny synthetic inputs and writes tests/golden/ref_step_golden.npz.  See gen_unit_golden.py for what is reference code and
+what is supplied by the oracle (d2-ext).  The inputs are NOT stored: they are regenerated from seeds by `step_inputs(name)`
+below (weights: unit_amd.synthetic.init_synthetic_weights on the state-dict of unit_amd.modeling.build_model(cfg); images / GT:
+unit_amd.synthetic.synthetic_batch; permutations: seeded torch.randperm) -- the tests call the same function.
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+for p_ in (HERE, ROOT, os.path.join(ROOT, "oracle")):
+    if p_ not in sys.path:
+        sys.path.insert(0, p_)
+
+HW = (96, 128)
+COCO_NOVEL = [0, 1, 2, 3, 4, 5, 6, 8, 14, 15, 16, 17, 18, 19, 39, 56, 57, 58, 60, 62]
+COCO_BASE = [i for i in range(80) if i not in COCO_NOVEL]
+CASES = ("s1", "s1_single", "s2", "mask", "mask_ft", "coco_mask", "eval", "eval_ft", "eval_mask", "eval_mask_ft")
+
+
+def ellipse_masks(sup, hw):
+    masks = []
+    for x in sup:
+        b = x["instances"].gt_boxes.tensor
+        yy, xx = torch.meshgrid(torch.arange(float(hw[0])), torch.arange(float(hw[1])), indexing="ij")
+        m = [(((xx - (bb[0] + bb[2]) / 2) / ((bb[2] - bb[0]) / 2)) ** 2 + ((yy - (bb[1] + bb[3]) / 2) / ((bb[3] - bb[1]) / 2)) ** 2) <= 1.0
+             for bb in b]
+        m = torch.stack(m) if len(m) else torch.zeros((0,) + tuple(hw), dtype=torch.bool)
+        x["instances"].gt_masks = m
+        masks.append(m)
+    return masks
+
+
+def case_cfg(name, device="cpu"):
+    """unit_amd config of one fixture case (the tiny shapes; class names from the reference yaml of that configuration)"""
+    from unit_amd import config
+    ft = name in ("s2", "mask_ft", "eval_ft", "eval_mask_ft")
+    mask = "mask" in name
+    coco = name.startswith("coco")
+    c = config.voc_rcnn_c4_split1_ft(50) if ft else config.voc_rcnn_c4_split1(50)
+    c.MODEL.DEVICE = device
+    c.MODEL.ROI_HEADS.BATCH_SIZE_PER_IMAGE = 16
+    c.MODEL.RPN.PRE_NMS_TOPK_TRAIN, c.MODEL.RPN.POST_NMS_TOPK_TRAIN = 300, 50
+    c.MODEL.RPN.PRE_NMS_TOPK_TEST, c.MODEL.RPN.POST_NMS_TOPK_TEST = 300, 60
+    if name == "s1_single":
+        c.MODEL.ROI_HEADS.MULTI_BOX_HEAD = False
+    if mask:
+        c.MODEL.MASK_ON = True
+        c.MODEL.ROI_BOX_HEAD.NAME = "Res5BoxHeadWithMask"
+        if ft:       # configs/COCO/COCO-RCNN-50-C4-split1-segm-ft.yaml: two Res5 heads, fine-tune mask head
+            c.MODEL.ROI_HEADS.NAME = "WSROIHeadWithMaskFineTune"
+            c.MODEL.ROI_MASK_HEAD.NAME = "MaskRCNNConvUpsampleHeadWithFineTune"
+            c.MODEL.FREEZE_LAYERS.META_ARCH = ["backbone"]
+            c.MODEL.FREEZE_LAYERS.ROI_HEADS = ["box_pooler", "weak_box_head"]
+            c.MODEL.FREEZE_LAYERS.MASK_HEAD = ["deconv", "deconv_relu", "predictor"]
+        else:        # configs/COCO/COCO-RCNN-50-C4-split1-segm.yaml: one Res5 head
+            c.MODEL.ROI_HEADS.NAME = "WSROIHeadNoMetaWithMask"
+            c.MODEL.ROI_HEADS.MULTI_BOX_HEAD = False
+    if coco:
+        c.MODEL.ROI_HEADS.NUM_CLASSES = 80
+        c.DATASETS.FEWSHOT.BASE_CLASSES_ID, c.DATASETS.FEWSHOT.NOVEL_CLASSES_ID = list(COCO_BASE), list(COCO_NOVEL)
+        c.DATASETS.TRAIN = ("coco_base_training_query_train",)
+    return c
+
+
+def step_inputs(name, device="cpu"):
+    """-> (cfg, model, sup, weak, perms, masks). Deterministic; shared by the generator and the tests."""
+    from unit_amd.modeling import build_model
+    from unit_amd.synthetic import init_synthetic_weights, synthetic_batch
+    cfg = case_cfg(name, device)
+    K = cfg.MODEL.ROI_HEADS.NUM_CLASSES
+    model = build_model(cfg)
+    init_synthetic_weights(model, seed=1 + CASES.index(name))
+    g = torch.Generator().manual_seed(40 + CASES.index(name))
+    with torch.no_grad():
+        bp = model.roi_heads.box_predictor
+        bp.cls_score_delta.weight.copy_(torch.randn(bp.cls_score_delta.weight.shape, generator=g) * 0.02)
+        if hasattr(bp, "cls_score_ft"):
+            bp.cls_score_ft.weight.copy_(torch.randn(bp.cls_score_ft.weight.shape, generator=g) * 0.01)
+            bp.bbox_pred_ft.weight.copy_(torch.randn(bp.bbox_pred_ft.weight.shape, generator=g) * 0.001)
+        if cfg.MODEL.MASK_ON:
+            mh = model.roi_heads.mask_head
+            mh.deconv.weight.copy_(torch.randn(mh.deconv.weight.shape, generator=g) * (2.0 / (4 * mh.deconv.cout)) ** 0.5)
+            mh.predictor.weight.copy_(torch.randn(mh.predictor.weight.shape, generator=g) * 0.05)
+            if hasattr(mh, "predictor_delta"):
+                mh.predictor_delta.weight.copy_(torch.randn(mh.predictor_delta.weight.shape, generator=g) * 0.02)
+    from unit_amd.layers import invalidate_prepared
+    invalidate_prepared()
+    evalm = name.startswith("eval")
+    base_ids = list(range(K)) if (name in ("s2", "mask_ft")) else list(cfg.DATASETS.FEWSHOT.BASE_CLASSES_ID)
+    n_weak = 0 if (evalm or name in ("s2", "mask_ft")) else 2
+    sup, weak = synthetic_batch(1 if evalm else 2, n_weak, hw=HW, num_classes=K, base_ids=base_ids, seed=70 + CASES.index(name), max_gt=3)
+    masks = ellipse_masks(sup, HW) if cfg.MODEL.MASK_ON and not evalm else None
+    n_anchor = (HW[0] // 16) * (HW[1] // 16) * 15
+    perms = dict(rpn=[torch.randperm(n_anchor, generator=g) for _ in sup], roi=[torch.randperm(50 + 3, generator=g) for _ in sup])
+    return cfg, model, sup, weak, perms, masks
+
+
+def oracle_cfg(cfg, **kw):
+    import unit_oracle as orc
+    K = cfg.MODEL.ROI_HEADS.NUM_CLASSES
+    d = dict(depth=cfg.MODEL.RESNETS.DEPTH, num_classes=K, novel_classes=list(cfg.DATASETS.FEWSHOT.NOVEL_CLASSES_ID),
+             base_classes=list(cfg.DATASETS.FEWSHOT.BASE_CLASSES_ID), coco_indexer=orc.VOC_COCO_INDEXER if K == 20 else list(range(80)),
+             pixel_mean=cfg.MODEL.PIXEL_MEAN, pixel_std=cfg.MODEL.PIXEL_STD, rois_per_image=cfg.MODEL.ROI_HEADS.BATCH_SIZE_PER_IMAGE,
+             pre_nms_topk=cfg.MODEL.RPN.PRE_NMS_TOPK_TRAIN, post_nms_topk=cfg.MODEL.RPN.POST_NMS_TOPK_TRAIN,
+             pre_nms_topk_test=cfg.MODEL.RPN.PRE_NMS_TOPK_TEST, post_nms_topk_test=cfg.MODEL.RPN.POST_NMS_TOPK_TEST,
+             multi_box_head=cfg.MODEL.ROI_HEADS.MULTI_BOX_HEAD, mask_on=cfg.MODEL.MASK_ON,
+             finetune=cfg.MODEL.ROI_HEADS.FAST_RCNN.NAME.endswith("FineTune"),
+             mask_finetune=cfg.MODEL.ROI_MASK_HEAD.NAME.endswith("FineTune") and cfg.MODEL.MASK_ON,
+             visual_threshold=cfg.MODEL.ROI_HEADS.VISUAL_ATTENTION_HEAD.VISUAL_SIMILARITY_THRESHOLD)
+    d.update(kw)
+    return d
+
+
+def oracle_params(model):
+    trainable = {n for n, q in model.named_parameters() if q.requires_grad}
+    return {k: v.detach().cpu().clone().contiguous().requires_grad_(k in trainable) for k, v in model.state_dict().items()}
+
+
+def main(G):
+    """G = the gen_unit_golden module (stubs installed, reference modules loaded)."""
+    d2 = G.d2
+    out = {}
+    for name in CASES:
+        cfg, model, sup, weak, perms, masks = step_inputs(name)
+        p = oracle_params(model)
+        ocfg = oracle_cfg(cfg)
+        if ocfg["num_classes"] == 80:
+            d2._MetadataCatalog.table["coco_base_training_query_train"] = d2._Metadata(COCO_THING_CLASSES)
+        roi_cls, pred_cls = cfg.MODEL.ROI_HEADS.NAME, cfg.MODEL.ROI_HEADS.FAST_RCNN.NAME
+        mask_cls = cfg.MODEL.ROI_MASK_HEAD.NAME if cfg.MODEL.MASK_ON else None
+        ref, trace = G.build_reference_model(p, ocfg, perms, roi_cls=roi_cls, pred_cls=pred_cls, mask_cls=mask_cls)
+        if ocfg["num_classes"] == 80:
+            ref.roi_heads.train_dataset_name = "coco_base_training_query_train"
+            ref.roi_heads._class_mappings()
+        ref.roi_heads.visual_threshold = ocfg["visual_threshold"]
+        # the freeze lists of the yaml, applied by the reference's own _freeze_layers on its own modules
+        ref.roi_heads.box_predictor._freeze_layers(list(cfg.MODEL.FREEZE_LAYERS.FAST_RCNN))
+        if mask_cls and mask_cls.endswith("FineTune"):
+            ref.roi_heads.mask_head._freeze_layers(list(cfg.MODEL.FREEZE_LAYERS.MASK_HEAD))
+        if not name.startswith("eval"):
+            ref.train()
+            losses = ref(G.to_d2_inputs(sup, masks), G.to_d2_inputs(weak) if weak else None)
+            sum(losses.values()).backward()
+            G.collect_step(out, name, ref, losses, trace, p)
+            print(name, {k: round(v.item(), 6) for k, v in sorted(losses.items())})
+        else:
+            ref.eval()
+            with torch.no_grad():
+                res = ref([{"image": sup[0]["image"], "height": 2 * HW[0], "width": 2 * HW[1]}])[0]["instances"]
+            out[f"{name}/boxes"], out[f"{name}/scores"] = G.npy(res.pred_boxes.tensor), G.npy(res.scores)
+            out[f"{name}/classes"] = G.npy(res.pred_classes)
+            if res.has("pred_masks"):
+                out[f"{name}/masks"] = np.packbits(G.npy(res.pred_masks), axis=-1)
+            print(name, len(res), "detections; classes", sorted(set(res.pred_classes.tolist())))
+            assert len(res) > 3
+    np.savez_compressed(G.OUT_STEP, **out)
+    print("wrote", G.OUT_STEP, len(out), "arrays", os.path.getsize(G.OUT_STEP), "bytes")
+
+
+COCO_THING_CLASSES = ['person', 'bicycle', 'car', 'motorcycle', 'airplane', 'bus', 'train', 'truck', 'boat', 'traffic light', 'fire hydrant',
+                      'stop sign', 'parking meter', 'bench', 'bird', 'cat', 'dog', 'horse', 'sheep', 'cow', 'elephant', 'bear', 'zebra', 'giraffe',
+                      'backpack', 'umbrella', 'handbag', 'tie', 'suitcase', 'frisbee', 'skis', 'snowboard', 'sports ball', 'kite', 'baseball bat',
+                      'baseball glove', 'skateboard', 'surfboard', 'tennis racket', 'bottle', 'wine glass', 'cup', 'fork', 'knife', 'spoon', 'bowl',
+                      'banana', 'apple', 'sandwich', 'orange', 'broccoli', 'carrot', 'hot dog', 'pizza', 'donut', 'cake', 'chair', 'couch',
+                      'potted plant', 'bed', 'dining table', 'toilet', 'tv', 'laptop', 'mouse', 'remote', 'keyboard', 'cell phone', 'microwave',
+                      'oven', 'toaster', 'sink', 'refrigerator', 'book', 'clock', 'vase', 'scissors', 'teddy bear', 'hair drier', 'toothbrush']

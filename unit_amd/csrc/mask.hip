@@ -139,10 +139,11 @@ extern "C" int unit_mask_bce_loss(const float* logits, int K, int ldk, const int
 }
 
 // mask_rcnn_inference (+ the base->novel mask transfer of mask_head.py:18-31 for the predicted class):
-// prob[s][Y][X] = sigmoid(logit of pred class)  where for a novel class j: logit = sum_b sim[s][j][b] * logit[base_b]
-__global__ void mask_probs_kernel(const float* __restrict__ logits, int K, int ldk, const int* __restrict__ cls, const float* __restrict__ sim,
-                                  const int* __restrict__ base, int n_base, int n_novel, const int8_t* __restrict__ role,
-                                  const int* __restrict__ slot, int S, int M, float* __restrict__ out) {
+// prob[s][Y][X] = sigmoid(logit of pred class)  where for a novel class j: logit = sum_b sim[s][j][b] * logit[base_b];
+// delta_col0 >= 0: + logits[delta_col0 + c], the `predictor_delta` columns of MaskRCNNConvUpsampleHeadWithFineTune (mask_head.py:91)
+__global__ void mask_probs_kernel(const float* __restrict__ logits, int K, int ldk, int delta_col0, const int* __restrict__ cls,
+                                  const float* __restrict__ sim, const int* __restrict__ base, int n_base, int n_novel,
+                                  const int8_t* __restrict__ role, const int* __restrict__ slot, int S, int M, float* __restrict__ out) {
   long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   long total = (long)S * M * M;
   if (i >= total) return;
@@ -159,15 +160,16 @@ __global__ void mask_probs_kernel(const float* __restrict__ logits, int K, int l
       for (int b = 0; b < n_base; ++b) x += sm[b] * row[base[b]];
     } else if (sim && role[c] == 0) x = 0.f;
     else x = row[c];
+    if (delta_col0 >= 0) x = x + row[delta_col0 + c];
     v = 1.f / (1.f + expf(-x));
   }
   out[i] = v;
 }
-extern "C" int unit_mask_probs(const float* logits, int K, int ldk, const int* cls, const float* sim, const int* base_dev, int n_base,
-                               int n_novel, const int8_t* role_dev, const int* slot_dev, int S, int M, float* out, void* stream) {
+extern "C" int unit_mask_probs(const float* logits, int K, int ldk, int delta_col0, const int* cls, const float* sim, const int* base_dev,
+                               int n_base, int n_novel, const int8_t* role_dev, const int* slot_dev, int S, int M, float* out, void* stream) {
   if (S == 0) return UNIT_OK;
-  mask_probs_kernel<<<cdiv((long)S * M * M, 256), 256, 0, (hipStream_t)stream>>>(logits, K, ldk, cls, sim, base_dev, n_base, n_novel, role_dev,
-                                                                                slot_dev, S, M, out);
+  mask_probs_kernel<<<cdiv((long)S * M * M, 256), 256, 0, (hipStream_t)stream>>>(logits, K, ldk, delta_col0, cls, sim, base_dev, n_base, n_novel,
+                                                                                role_dev, slot_dev, S, M, out);
   UNIT_LAUNCH_CHECK();
   return UNIT_OK;
 }

@@ -63,6 +63,9 @@ class ConvTranspose2x2(_EpochOnLoad):
 
 @ROI_MASK_HEAD_REGISTRY.register()
 class MaskRCNNConvUpsampleHeadWithSimilarity(nn.Module):
+    finetune = False
+    delta_col0 = -1
+
     def __init__(self, cfg, input_shape):
         super().__init__()
         m = cfg.MODEL.ROI_MASK_HEAD
@@ -71,10 +74,17 @@ class MaskRCNNConvUpsampleHeadWithSimilarity(nn.Module):
         self.deconv = ConvTranspose2x2(input_shape.channels, m.CONV_DIM)
         self.predictor = Conv2d(m.CONV_DIM, self.num_classes, 1, bias=True)
         nn.init.normal_(self.predictor.weight, std=0.001)
+        members = [self.predictor]
+        if self.finetune:      # mask_head.py:45-49: zero-initialised 1x1 conv beside `predictor`, same input
+            self.predictor_delta = Conv2d(m.CONV_DIM, self.num_classes, 1, bias=True)
+            nn.init.constant_(self.predictor_delta.weight, 0.)
+            members.append(self.predictor_delta)
         for name, p in self.named_parameters():
             if any(layer == name.split(".")[0] for layer in cfg.MODEL.FREEZE_LAYERS.MASK_HEAD):
                 p.requires_grad = False
-        self.pred = LinearGroup([self.predictor])
+        self.pred = LinearGroup(members)          # ONE GEMM: [predictor | predictor_delta] columns
+        if self.finetune:
+            self.delta_col0 = self.pred.cols[1]
         self.mask_size = 14
 
     def prepare(self, dtype, version):
@@ -113,7 +123,7 @@ class MaskRCNNConvUpsampleHeadWithSimilarity(nn.Module):
         s = x.shape[0]
         out = torch.empty((s, self.mask_size, self.mask_size), dtype=torch.float32, device=x.device)
         t = roles or {}
-        check(lib().unit_mask_probs(ops._p(lg), self.num_classes, self.pred.kp, ops._p(pred_classes), ops._p(sim), ops._p(t.get("base")),
+        check(lib().unit_mask_probs(ops._p(lg), self.num_classes, self.pred.kp, self.delta_col0, ops._p(pred_classes), ops._p(sim), ops._p(t.get("base")),
                                     t["base"].numel() if sim is not None else 0, t["novel"].numel() if sim is not None else 0,
                                     ops._p(t.get("role")), ops._p(t.get("slot")), s, self.mask_size, ops._p(out), ops._s()), "mask_probs")
         return out
@@ -134,3 +144,11 @@ def gather_match_index(sampled_idx, match_idx):
     check(lib().unit_gather_match_index(ops._p(sampled_idx), s, ops._p(match_idx), match_idx.shape[1], b, ops._p(out), ops._s()),
           "gather_match_index")
     return out
+
+
+@ROI_MASK_HEAD_REGISTRY.register()
+class MaskRCNNConvUpsampleHeadWithFineTune(MaskRCNNConvUpsampleHeadWithSimilarity):
+    """/root/reference/modeling/roi_heads/mask_head.py:39-94: `layers` returns (predictor(x), predictor_delta(x)) (:67-72); the
+    base->novel transfer acts on the fixed branch only and the delta is added afterwards (:74-91). State-dict keys:
+    `deconv.*`, `predictor.*`, `predictor_delta.*`; FREEZE_LAYERS.MASK_HEAD freezes by first name component (:57-62)."""
+    finetune = True

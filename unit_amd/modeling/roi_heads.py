@@ -142,3 +142,12 @@ class WSROIHeadNoMetaWithMask(WSROIHeadNoMeta):
     @property
     def max_fg_per_image(self):
         return int(self.batch_size_per_image * self.positive_fraction)
+
+
+@ROI_HEADS_REGISTRY.register()
+class WSROIHeadWithMaskFineTune(WSROIHeadNoMetaWithMask):
+    """/root/reference/modeling/roi_heads/roi_heads.py:824-952 (configs/COCO/COCO-RCNN-50-C4-split1-segm-ft.yaml): the mask
+    variant whose `_forward_box` computes the similarity matrices in training too (:852) and hands them to the box predictor
+    (`SupervisedDetectorOutputsFineTune`) and, restricted to the foreground RoIs (:893-897), to the mask head
+    (`MaskRCNNConvUpsampleHeadWithFineTune`)."""
+    finetune = True
