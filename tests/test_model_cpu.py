@@ -106,3 +106,54 @@ def test_gradient_bucket_tags_follow_backward_order():
     assert [r4.last_block_of_bucket(k) for k in range(4)] == [17, 11, 5, 0] and r4.bucket_of_block(5) == 2 and r4.bucket_of_block(4) == 3
     m50 = build_model(_cfg(50))
     assert [t for t, a, b in m50.flatten_parameters().tags if t.startswith("res4")] == ["res4"]
+
+
+def test_config_merges_reference_style_yaml(tmp_path):
+    """yacs semantics of CfgNode.merge_from_file: string leaves that are python literals are evaluated (the reference's yaml files
+    write tuples as strings: `STEPS: (12000, 24000)`), `_BASE_` chains, type coercion list <-> tuple; the LR schedule then works."""
+    from unit_amd import config, solver
+    base = tmp_path / "Base.yaml"
+    base.write_text("MODEL:\n  RPN:\n    PRE_NMS_TOPK_TEST: 6000\n    POST_NMS_TOPK_TEST: 1000\nSOLVER:\n  IMS_PER_BATCH: 16\n")
+    y = tmp_path / "child.yaml"
+    y.write_text('_BASE_: "Base.yaml"\nMODEL:\n  RESNETS:\n    DEPTH: 101\n  ROI_HEADS:\n    NAME: "WSROIHeadNoMeta"\n    MULTI_BOX_HEAD: True\n'
+                 '  ROI_MASK_HEAD:\n    POOLER_TYPE: "None"\nINPUT:\n  MIN_SIZE_TRAIN: (480, 512, 800)\nSOLVER:\n  STEPS: (12000, 24000)\n'
+                 '  BASE_LR: 0.02\n  WARMUP_ITERS: 100\nDATASETS:\n  FEWSHOT:\n    NOVEL_CLASSES_ID: [2, 5, 9, 13, 17]\n')
+    c = config.get_cfg()
+    c.merge_from_file(str(y))
+    assert c.SOLVER.STEPS == (12000, 24000) and isinstance(c.SOLVER.STEPS, tuple)
+    assert c.INPUT.MIN_SIZE_TRAIN == (480, 512, 800) and c.SOLVER.IMS_PER_BATCH == 16 and c.MODEL.RESNETS.DEPTH == 101
+    assert c.MODEL.ROI_HEADS.NAME == "WSROIHeadNoMeta" and c.MODEL.ROI_MASK_HEAD.POOLER_TYPE in ("None", None)
+    sched = solver.WarmupMultiStepLR(c)
+    assert abs(sched(200) - 0.02) < 1e-12 and abs(sched(12000) - 0.002) < 1e-12 and abs(sched(24000) - 0.0002) < 1e-12
+    c.merge_from_list(["SOLVER.STEPS", "(50,)", "MODEL.ROI_HEADS.NAME", "WSROIHeadFineTune", "SOLVER.BASE_LR", "0.001"])
+    assert c.SOLVER.STEPS == (50,) and c.MODEL.ROI_HEADS.NAME == "WSROIHeadFineTune" and c.SOLVER.BASE_LR == 0.001
+
+
+def test_presets_equal_the_reference_yaml_files_when_present():
+    """the presets of unit_amd.config against the reference's own yaml files (authoring container only)."""
+    import os
+    import pytest
+    from unit_amd import config
+    root = "/root/reference/configs"
+    if not os.path.isdir(root):
+        pytest.skip("reference not present")
+    skip = ("DATASETS.TRAIN", "DATASETS.TEST", "MODEL.WEIGHTS", "MODEL.ROI_HEADS.EMBEDDING_PATH", "INPUT.MIN_SIZE_TRAIN", "TEST.EVAL_PERIOD",
+            "SOLVER.CHECKPOINT_PERIOD")
+
+    def diff(a, b, pre=""):
+        out = []
+        for k in sorted(set(a) & set(b)):
+            if isinstance(a[k], dict):
+                out += diff(a[k], b[k], pre + k + ".")
+            elif (pre + k) not in skip and a[k] != b[k] and not (isinstance(a[k], (list, tuple)) and list(a[k]) == list(b[k])) \
+                    and not (a[k] in ("None", None) and b[k] in ("None", None)):
+                out.append((pre + k, a[k], b[k]))
+        return out
+    for y, preset in (("VOC/VOC-RCNN-101-C4-split1.yaml", config.voc_rcnn_c4_split1(101)),
+                      ("VOC/FT/1_shot/VOC-RCNN-101-C4-split1-ft.yaml", config.voc_rcnn_c4_split1_ft(101)),
+                      ("COCO/COCO-RCNN-50-C4-split1.yaml", config.coco_rcnn_c4_split1(50)),
+                      ("COCO/COCO-RCNN-50-C4-split1-segm.yaml", config.coco_rcnn_c4_split1_segm(50)),
+                      ("COCO/COCO-RCNN-50-C4-split1-segm-ft.yaml", config.coco_rcnn_c4_split1_segm_ft(50))):
+        c = config.get_cfg()
+        c.merge_from_file(os.path.join(root, y))
+        assert diff(c, preset) == [], (y, diff(c, preset))

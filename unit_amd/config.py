@@ -26,7 +26,7 @@ class CfgNode(dict):
             if isinstance(v, dict) and isinstance(self.get(k), CfgNode):
                 self[k].merge_from_dict(v)
             else:
-                self[k] = _to_cfg(v)
+                self[k] = _coerce(_to_cfg(_literal(v)), self.get(k))
         return self
 
     def merge_from_file(self, path):
@@ -45,15 +45,36 @@ class CfgNode(dict):
             parts = k.split(".")
             for p in parts[:-1]:
                 node = node[p]
-            old = node.get(parts[-1])
-            if isinstance(v, str) and old is not None and not isinstance(old, str):
-                import ast
-                v = ast.literal_eval(v)
-            node[parts[-1]] = v
+            node[parts[-1]] = _coerce(_literal(v), node.get(parts[-1]))
         return self
 
 
 CN = CfgNode
+
+
+def _literal(v):
+    """yacs semantics: a string leaf is a python literal when it parses as one ("(12000, 24000)" -> tuple, "0.02" -> float);
+    anything else stays the raw string ("WSRPN", a path)."""
+    if isinstance(v, str):
+        import ast
+        try:
+            return ast.literal_eval(v)
+        except (ValueError, SyntaxError):
+            return v
+    return v
+
+
+def _coerce(v, old):
+    """yacs `_check_and_coerce_cfg_value_type`: tuple <-> list and int -> float follow the type of the value being replaced."""
+    if old is None or isinstance(old, CfgNode) or type(v) is type(old):
+        return v
+    if isinstance(old, tuple) and isinstance(v, list):
+        return tuple(v)
+    if isinstance(old, list) and isinstance(v, tuple):
+        return list(v)
+    if isinstance(old, float) and isinstance(v, int) and not isinstance(v, bool):
+        return float(v)
+    return v
 
 
 def _to_cfg(v):
@@ -149,4 +170,55 @@ def voc_rcnn_c4_split1_ft(depth=101):
     c.MODEL.FREEZE_LAYERS.META_ARCH = ["backbone", "proposal_generator"]
     c.MODEL.FREEZE_LAYERS.ROI_HEADS = ["box_pooler", "box_head", "weak_box_head"]
     c.MODEL.FREEZE_LAYERS.FAST_RCNN = ["weak_detector_head", "cls_score_delta", "bbox_pred_delta", "embeddings"]
+    c.SOLVER.BASE_LR, c.SOLVER.STEPS, c.SOLVER.MAX_ITER, c.SOLVER.WARMUP_ITERS, c.SOLVER.CHECKPOINT_PERIOD = 0.001, (50,), 50, 0, 50
+    return c
+
+
+COCO_SPLIT1_NOVEL = [0, 1, 2, 3, 4, 5, 6, 8, 14, 15, 16, 17, 18, 19, 39, 56, 57, 58, 60, 62]       # the 20 VOC classes inside COCO
+COCO_SPLIT1_BASE = [i for i in range(80) if i not in COCO_SPLIT1_NOVEL]
+
+
+def coco_rcnn_c4_split1(depth=50):
+    """configs/COCO/COCO-RCNN-50-C4-split1.yaml restated: K = 80, ONE Res5 head (MULTI_BOX_HEAD False), 60 base / 20 novel classes
+    (:13-14,38-39)."""
+    c = get_cfg()
+    c.MODEL.RESNETS.DEPTH = depth
+    c.MODEL.ROI_HEADS.NUM_CLASSES = 80
+    c.MODEL.ROI_HEADS.MULTI_BOX_HEAD = False
+    c.MODEL.ROI_HEADS.FAST_RCNN.WEAK_DETECTOR.DETECTOR_TEMP = 2.0
+    c.DATASETS.TRAIN = ("coco_base_training_query_train",)
+    c.DATASETS.TEST = ("coco_base_training_query_val",)
+    c.DATASETS.FEWSHOT.BASE_CLASSES_ID = list(COCO_SPLIT1_BASE)
+    c.DATASETS.FEWSHOT.NOVEL_CLASSES_ID = list(COCO_SPLIT1_NOVEL)
+    c.SOLVER.STEPS, c.SOLVER.MAX_ITER = (210000, 250000), 270000
+    return c
+
+
+def coco_rcnn_c4_split1_segm(depth=50):
+    """configs/COCO/COCO-RCNN-50-C4-split1-segm.yaml restated (BASELINE config 5): the above + MASK_ON, WSROIHeadNoMetaWithMask,
+    Res5BoxHeadWithMask, MaskRCNNConvUpsampleHeadWithSimilarity on the un-pooled res5 map (ROI_MASK_HEAD.POOLER_TYPE "None")."""
+    c = coco_rcnn_c4_split1(depth)
+    c.MODEL.MASK_ON = True
+    c.MODEL.ROI_HEADS.NAME = "WSROIHeadNoMetaWithMask"
+    c.MODEL.ROI_BOX_HEAD.NAME = "Res5BoxHeadWithMask"
+    c.MODEL.ROI_MASK_HEAD.NAME = "MaskRCNNConvUpsampleHeadWithSimilarity"
+    c.MODEL.ROI_MASK_HEAD.POOLER_TYPE = "None"
+    return c
+
+
+def coco_rcnn_c4_split1_segm_ft(depth=50):
+    """configs/COCO/COCO-RCNN-50-C4-split1-segm-ft.yaml restated: fine-tune ROI heads / predictor / mask head, two Res5 heads,
+    freeze lists :10-14, visual similarity threshold 0.04 (:31)."""
+    c = coco_rcnn_c4_split1_segm(depth)
+    c.MODEL.ROI_HEADS.NAME = "WSROIHeadWithMaskFineTune"
+    c.MODEL.ROI_HEADS.MULTI_BOX_HEAD = True
+    c.MODEL.ROI_HEADS.FAST_RCNN.NAME = "SupervisedDetectorOutputsFineTune"
+    c.MODEL.ROI_MASK_HEAD.NAME = "MaskRCNNConvUpsampleHeadWithFineTune"
+    c.MODEL.ROI_HEADS.VISUAL_ATTENTION_HEAD.VISUAL_SIMILARITY_THRESHOLD = 0.04
+    c.MODEL.FREEZE_LAYERS.META_ARCH = ["backbone"]
+    c.MODEL.FREEZE_LAYERS.ROI_HEADS = ["box_pooler", "weak_box_head"]
+    c.MODEL.FREEZE_LAYERS.FAST_RCNN = ["weak_detector_head", "cls_score_delta", "bbox_pred_delta", "embeddings"]
+    c.MODEL.FREEZE_LAYERS.MASK_HEAD = ["deconv", "deconv_relu", "predictor"]
+    c.DATASETS.TRAIN = ("coco_fine_tuning_query_train",)
+    c.SOLVER.BASE_LR, c.SOLVER.STEPS, c.SOLVER.MAX_ITER, c.SOLVER.WARMUP_ITERS = 0.001, (800,), 1000, 0
     return c

@@ -241,10 +241,12 @@ class WeaklySupervisedRCNNNoMeta(nn.Module):
         return {"rpn": rpn, "roi": roi}
 
     # ------------------------------------------------------------------ the training step: forward plan
-    def forward_train(self, batch, perms=None, early_backward=False):
+    def forward_train(self, batch, perms=None, early_backward=False, proposals=None):
         """-> step context (holds `losses` fp32[9] on the device and everything backward_train needs).
         early_backward: the caller WILL run backward_train right after (train_step / TrainerNoMeta.run_step); branches whose
-        backward does not depend on later forward work (the RPN head) may then start during the forward plan."""
+        backward does not depend on later forward work (the RPN head) may then start during the forward plan.
+        proposals: precomputed (boxes [B,P,4], objectness [B,P], count int32 [B]) for all images, supervised first -- the
+        reference's `"proposals" in batched_inputs[0]` branch (rcnn.py:474-481); the RPN still trains on its own outputs."""
         self._ensure_ready()
         self._early_backward = early_backward
         rpn, rh, bp = self.proposal_generator, self.roi_heads, self.roi_heads.box_predictor
@@ -326,7 +328,9 @@ class WeaklySupervisedRCNNNoMeta(nn.Module):
             c.rpn_losses = c.losses[6:8]
             rpn_branch()
         hw = torch.tensor(sizes, dtype=torch.float32).to(self.device, non_blocking=True)
-        if not split:
+        if proposals is not None:
+            props, pscores, pcount = proposals
+        elif not split:
             props, pscores, pcount = rpn.predict_proposals(head, anchors, hw, True)
         else:
             pa = rpn.predict_proposals(head, anchors, hw[:n_sup].contiguous(), True)

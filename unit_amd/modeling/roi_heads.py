@@ -129,7 +129,7 @@ class WSROIHeadNoMetaWithMask(WSROIHeadNoMeta):
         if cfg.MODEL.MASK_ON:
             from ..structures import ROI_MASK_HEAD_REGISTRY
             from . import mask_head as _mh  # noqa: F401  (registers the head)
-            assert cfg.MODEL.ROI_MASK_HEAD.POOLER_TYPE == "None", "C4-segm: the mask head reuses the box head's res5 features"
+            assert cfg.MODEL.ROI_MASK_HEAD.POOLER_TYPE in ("None", None), "C4-segm: the mask head reuses the box head's res5 features"
             self.mask_head = ROI_MASK_HEAD_REGISTRY.get(cfg.MODEL.ROI_MASK_HEAD.NAME)(cfg, ShapeSpec(channels=self.box_head.out_channels,
                                                                                                       height=7, width=7))
         self.terms["seg"] = list(cfg.MODEL.ROI_HEADS.FINETUNE_TERMS.MASK)
