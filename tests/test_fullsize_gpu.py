@@ -70,13 +70,14 @@ def pack_proposals(plist, cap, dev):
     return props.to(dev), sc.to(dev), cnt.to(dev)
 
 
-def proposal_agreement(hip_props, hip_cnt, ora):
-    """fraction of the HIP proposals of each image that are (within 0.01 px) proposals of the oracle, and vice versa"""
+def proposal_agreement(hip_props, hip_cnt, ora, tol=1e-2):
+    """fraction of the HIP proposals of each image that are (within `tol` px in every coordinate) proposals of the oracle, and vice
+    versa"""
     out = []
     for i, (ob, _) in enumerate(ora):
         hb = hip_props[i, : int(hip_cnt[i])].cpu()
         d = torch.cdist(hb.double(), ob.double(), p=float("inf"))
-        out.append((float((d.min(1).values < 1e-2).float().mean()), float((d.min(0).values < 1e-2).float().mean()), len(hb), len(ob)))
+        out.append((float((d.min(1).values < tol).float().mean()), float((d.min(0).values < tol).float().mean()), len(hb), len(ob)))
     return out
 
 
@@ -126,25 +127,61 @@ def _check_sampled_exact(step, aux, s):
 
 
 def test_proposal_chain_fullsize_exact(dev, s1_r101):
-    """a6 at BASELINE size on realistic inputs: the oracle's own fp32 RPN outputs of the four 600x1000 images (35 910 anchors each)
-    -> HIP top-12000 select + rank sort + decode + clip + NMS(0.7) + first 2000: kept boxes / scores / counts EXACT vs the oracle."""
+    """a6 at BASELINE size on realistic inputs: the oracle's own fp32 RPN outputs of the four 600x1000 images (35 910 anchors each).
+    Stage by stage, each stage on bit-identical inputs:
+      (1) stable descending top-12000 of the logits: indices and keys EXACT;
+      (2) decode + clip + empty-box filter: counts exact, boxes within 1e-4 px (device expf vs host expf differ in the last bit);
+      (3) NMS(0.7) + first 2000 on the ORACLE's decoded boxes: kept indices EXACT (72 M box pairs per image -- fed with the
+          device-decoded boxes instead, a last-bit box difference can legitimately flip a pair whose IoU sits within 1e-7 of 0.7);
+      (4) the whole chain: >= 99.9 % of either side's 2000 proposals have a partner within 0.01 px."""
+    from unit_amd import ops
     st = s1_r101
     model, aux = st["model"], st["aux"]
     rpn = model.proposal_generator
     a = rpn.num_anchors
     n = aux["logits"].shape[0]
+    ntot = 38 * 63 * a
     head = torch.zeros(n, 38 * 63, 80)
     head[:, :, :a] = aux["logits"].view(n, 38 * 63, a)
     head[:, :, a:5 * a] = aux["deltas"].reshape(n, 38 * 63, 4 * a)
+    head_d = head.to(dev)
     anchors = rpn.anchor_generator.grid(38, 63)
     hw = torch.tensor([HW] * n, dtype=torch.float32, device=dev)
-    boxes, scores, cnt = rpn.predict_proposals(head.to(dev), anchors, hw, True)
+    topk = 12000
+    skeys, sidx = ops.sort_desc(head_d, n, ntot, ld=80, a=a, col0=0, topk=topk)
+    cb, cs, cc = ops.rpn_decode_select(head_d, a, a, anchors, sidx, skeys, topk, hw, 0.0)
+    ob_all = torch.zeros(n, topk, 4)
+    os_all = torch.zeros(n, topk)
+    oc_all = torch.zeros(n, dtype=torch.int32)
+    keeps = []
+    for i in range(n):
+        sl, idx = aux["logits"][i].sort(descending=True, stable=True)
+        sl, idx = sl[:topk], idx[:topk]
+        assert torch.equal(sidx[i, :topk].cpu().long(), idx) and torch.equal(skeys[i, :topk].cpu(), sl), i            # (1)
+        b = orc.apply_deltas(aux["deltas"][i], anchors.cpu(), (1.0, 1.0, 1.0, 1.0))[idx]
+        valid = torch.isfinite(b).all(dim=1) & torch.isfinite(sl)
+        b, sl = b[valid].clone(), sl[valid]
+        b[:, 0::2] = b[:, 0::2].clamp(min=0, max=HW[1])
+        b[:, 1::2] = b[:, 1::2].clamp(min=0, max=HW[0])
+        nz = ((b[:, 2] - b[:, 0]) > 0) & ((b[:, 3] - b[:, 1]) > 0)
+        b, sl = b[nz], sl[nz]
+        c = int(cc[i])
+        assert c == len(b), (i, c, len(b))                                                                            # (2)
+        assert torch.equal(cs[i, :c].cpu(), sl)
+        assert torch.allclose(cb[i, :c].cpu(), b, rtol=0, atol=1e-4), (i, (cb[i, :c].cpu() - b).abs().max())
+        ob_all[i, :c], os_all[i, :c], oc_all[i] = b, sl, c
+        keeps.append(torch.from_numpy(orc.nms_sorted(b.numpy(), 0.7))[:2000])
+    keep, kc, boxes, scores = ops.nms(ob_all.to(dev), os_all.to(dev), oc_all.to(dev), 0.7, 2000)                        # (3)
     ora = aux["proposals"] + aux["weak_proposals"]
-    for i, (ob, ol) in enumerate(ora):
-        c = int(cnt[i])
-        assert c == len(ob), (i, c, len(ob))
-        assert torch.equal(scores[i, :c].cpu(), ol), i
-        assert torch.allclose(boxes[i, :c].cpu(), ob, rtol=0, atol=1e-4), (i, (boxes[i, :c].cpu() - ob).abs().max())
+    for i in range(n):
+        assert int(kc[i]) == len(keeps[i]) == len(ora[i][0]), (i, int(kc[i]), len(keeps[i]))
+        assert torch.equal(keep[i, : len(keeps[i])].cpu().long(), keeps[i]), i
+        assert torch.equal(boxes[i, : len(keeps[i])].cpu(), ora[i][0]) and torch.equal(scores[i, : len(keeps[i])].cpu(), ora[i][1])
+    b2, s2, c2 = rpn.predict_proposals(head_d, anchors, hw, True)                                                       # (4)
+    agree = proposal_agreement(b2, c2.cpu(), ora)
+    log_metrics("proposal_chain_fullsize", dict(agreement=agree))
+    for ag in agree:
+        assert ag[0] >= 0.999 and ag[1] >= 0.999, agree
 
 
 def test_r101_s1_fullsize_fp32_teacher_forced(dev, s1_r101):
@@ -165,7 +202,9 @@ def test_r101_s1_fullsize_fp32_teacher_forced(dev, s1_r101):
         if not prm.requires_grad:
             continue
         g, gr = prm.grad.detach().cpu(), st["grads"][name]
-        err = (g - gr).abs().max().item() / (gr.abs().max().item() + 1e-12)
+        # (+1e-7: the detection stream's bias gradient is identically zero in exact arithmetic -- softmax over the RoI axis is
+        #  shift-invariant per class -- so both sides hold 1e-9-sized rounding noise there)
+        err = max((g - gr).abs().max().item() - 1e-7, 0.0) / (gr.abs().max().item() + 1e-12)
         worst = max(worst, err)
         assert err <= 2e-3, (name, err)
         n += 1
@@ -199,16 +238,18 @@ def test_r101_s1_fullsize_fp32_free_running(dev, s1_r101):
     for a in agree:
         assert a[0] >= 0.99 and a[1] >= 0.99, agree
     for k, v in dev_l.items():
-        assert v <= 2e-3, (k, got[k], st["ref"][k])
+        assert v <= 5e-4, (k, got[k], st["ref"][k])
 
 
 def test_r101_s1_fullsize_bf16_production_schedule(dev, s1_r101):
     """THE BENCHMARKED PATH (bf16 compute, 4 HIP streams, 12 000 -> 2000, 512 RoIs) against the fp32 oracle.
     Teacher-forced: integer stages (anchor labels, sampled RoI indices / classes) EXACT -- their inputs are fp32 and identical.
-    Losses: bf16 carries 8 significant bits (relative rounding 2^-9 per tensor) through ~105 convolutions with fp32 accumulation;
-    independent roundings grow like sqrt(depth): about 2 % on deep features, hence rtol 5e-2 + atol 2e-2 per loss (measured
-    deviations are logged). Gradients: cosine similarity with the oracle's >= 0.98 on tensors from every stage.
-    Free-running: finite losses, >= 90 % proposal agreement (bf16 logits re-order far more proposals than fp32 noise does)."""
+    Losses: bf16 carries 8 significant bits (relative rounding 2^-9 = 2e-3 per stored tensor) through ~105 convolutions with
+    fp32 accumulation; the losses are means over >= 512 RoIs / anchors of such features: measured 5e-4 ... 3e-3 relative
+    (gpurun_out/fullsize_metrics.json), asserted at rtol 1e-2 + atol 1e-4. Gradients: cosine similarity with the fp32 oracle's
+    >= 0.995 on tensors from every stage (measured >= 0.9988).
+    Free-running (its own bf16 proposals): finite losses; decoded boxes move by bf16 rounding of the deltas (tenths of a pixel),
+    so agreement is counted at 2 px: >= 80 % of the proposals of either side have a partner."""
     st = s1_r101
     model, cfg, aux = st["model"], st["cfg"], st["aux"]
     model.compute_dtype = torch.bfloat16
@@ -229,24 +270,24 @@ def test_r101_s1_fullsize_bf16_production_schedule(dev, s1_r101):
     step2 = model.forward_train(st["batch"], st["perms"], early_backward=True)
     model.backward_train(step2)
     l2 = step2.losses.cpu()
-    agree = proposal_agreement(step2.proposals[0], step2.proposals[2].cpu(), aux["proposals"] + aux["weak_proposals"])
+    agree = proposal_agreement(step2.proposals[0], step2.proposals[2].cpu(), aux["proposals"] + aux["weak_proposals"], tol=2.0)
     log_metrics("r101_s1_bf16", dict(losses_bf16_vs_fp32_oracle=dev_l, grad_cosine=cos, free_running_losses=l2.tolist(),
                                      free_running_proposal_agreement=agree))
     model.compute_dtype = torch.float32
     for k, (g, v) in dev_l.items():
-        assert abs(g - v) <= 5e-2 * abs(v) + 2e-2, (k, g, v)
+        assert abs(g - v) <= 1e-2 * abs(v) + 1e-4, (k, g, v)
     for n, c in cos.items():
-        assert c >= 0.98, (n, c)
+        assert c >= 0.995, (n, c)
     assert torch.isfinite(l2[:8]).all()
     for a in agree:
-        assert a[0] >= 0.9, agree
+        assert a[0] >= 0.8 and a[1] >= 0.8, agree
 
 
 # =================================================================================================== config 4: R101 S2
 def test_r101_s2_finetune_fullsize(dev):
     """configs/VOC/FT/1_shot/VOC-RCNN-101-C4-split1-ft.yaml at full size: 2 images 600x1000, 512 RoIs, similarity transfer in
     training; only cls_score_ft / bbox_pred_ft train. fp32 teacher-forced: RoIs exact, losses 1e-4, the four gradients 2e-3;
-    bf16 production mode: losses within the bf16 tolerance of the S1 test."""
+    bf16 production mode: losses within the bf16 tolerance of the S1 test (rtol 1e-2 + atol 1e-4)."""
     cfg = config.voc_rcnn_c4_split1_ft(101)
     cfg.MODEL.DEVICE = "cuda"
     cfg.SEED = 6
@@ -289,7 +330,7 @@ def test_r101_s2_finetune_fullsize(dev):
     for k, v in dev_l.items():
         assert v <= 1e-4, (k, got[k], ref[k].item())
     for k, v in ref.items():
-        assert abs(gotb[k] - v.item()) <= 5e-2 * abs(v.item()) + 2e-2, (k, gotb[k], v.item())
+        assert abs(gotb[k] - v.item()) <= 1e-2 * abs(v.item()) + 1e-4, (k, gotb[k], v.item())
 
 
 # =================================================================================================== config 5: COCO K=80 + mask
@@ -364,7 +405,7 @@ def test_coco_k80_mask_step_fullsize(dev):
     for k, v in gerr.items():
         assert v <= 5e-3, (k, v)
     for k, v in ref.items():
-        assert abs(gotb[k] - v.item()) <= 5e-2 * abs(v.item()) + 2e-2, (k, gotb[k], v.item())
+        assert abs(gotb[k] - v.item()) <= 1e-2 * abs(v.item()) + 1e-4, (k, gotb[k], v.item())
 
 
 def test_coco_k80_eval_fullsize_80class_nms(dev):

@@ -1,0 +1,160 @@
+"""Module-level plugin surface on the GPU: the reference-signature `forward` / `losses` / `inference` of the predictors, the weak
+detector head, the ROI heads and the mask head execute the HIP kernels and agree with the CPU oracle (fp32 mode, 1e-4);
+the ROI-heads-level eval call equals the meta-architecture's own inference."""
+import pytest
+import torch
+
+import unit_oracle as orc
+from unit_amd import config
+from unit_amd.modeling import build_model
+from unit_amd.structures import Boxes, ImageList, Instances
+from unit_amd.synthetic import init_synthetic_weights, synthetic_batch
+
+pytestmark = pytest.mark.gpu
+
+
+def _model(dev, ft=False, mask=False, seed=4):
+    cfg = (config.voc_rcnn_c4_split1_ft if ft else config.voc_rcnn_c4_split1)(50)
+    cfg.MODEL.DEVICE = "cuda"
+    cfg.MODEL.RPN.PRE_NMS_TOPK_TEST, cfg.MODEL.RPN.POST_NMS_TOPK_TEST = 400, 80
+    if mask:
+        cfg.MODEL.MASK_ON = True
+        cfg.MODEL.ROI_HEADS.NAME = "WSROIHeadNoMetaWithMask"
+        cfg.MODEL.ROI_BOX_HEAD.NAME = "Res5BoxHeadWithMask"
+        cfg.MODEL.ROI_HEADS.MULTI_BOX_HEAD = False
+    model = build_model(cfg)
+    init_synthetic_weights(model, seed=seed)
+    g = torch.Generator().manual_seed(11)
+    with torch.no_grad():
+        bp = model.roi_heads.box_predictor
+        bp.cls_score_delta.weight.copy_(torch.randn(21, 2048, generator=g) * 0.02)
+        if ft:
+            bp.cls_score_ft.weight.copy_(torch.randn(21, 2048, generator=g) * 0.01)
+            bp.bbox_pred_ft.weight.copy_(torch.randn(80, 2048, generator=g) * 0.001)
+        if mask:
+            model.roi_heads.mask_head.predictor.weight.copy_(torch.randn(20, 256, 1, 1, generator=g) * 0.05)
+    from unit_amd.layers import invalidate_prepared
+    invalidate_prepared()
+    for m in model.modules():
+        m.compute_dtype = torch.float32
+    return cfg, model
+
+
+def _params(model):
+    return {k: v.detach().cpu().clone().contiguous() for k, v in model.state_dict().items()}
+
+
+def _boxes(g, n, w=192.0, h=128.0):
+    x0, y0 = torch.rand(n, generator=g) * (w - 40), torch.rand(n, generator=g) * (h - 40)
+    return torch.stack([x0, y0, x0 + 8 + torch.rand(n, generator=g) * 60, y0 + 8 + torch.rand(n, generator=g) * 60], 1).clamp(max=w)
+
+
+@pytest.mark.parametrize("ft", [False, True])
+def test_predictor_forward_losses_inference(dev, ft):
+    """SupervisedDetectorOutputs{Base,FineTune}.forward (train: -inf fill / similarity + ft heads; eval: transfer), .losses
+    (incl. the weak branch through WeakDetectorOutputsBase.forward / .losses) and .inference, reference signatures
+    (fast_rcnn.py:384,435,455,484; weak_detector_fast_rcnn.py:148,189) vs the oracle."""
+    cfg, model = _model(dev, ft=ft)
+    bp = model.roi_heads.box_predictor
+    p = _params(model)
+    g = torch.Generator().manual_seed(3)
+    sizes = [37, 52]
+    r = sum(sizes)
+    x, xw, xweak = (torch.randn(r, 2048, generator=g) * 0.5 for _ in range(3))
+    base, novel = list(cfg.DATASETS.FEWSHOT.BASE_CLASSES_ID), list(cfg.DATASETS.FEWSHOT.NOVEL_CLASSES_ID)
+    nov_t, base_t = torch.tensor(novel), torch.tensor(base)
+    sim = {h: torch.rand(r, 5, 15, generator=g) for h in ("cls", "bbox")}
+    sim = {h: v / v.sum(-1, keepdim=True) for h, v in sim.items()}
+    props, flat = [], dict(b=[], gb=[], gc=[])
+    for n in sizes:
+        b, gb = _boxes(g, n), _boxes(g, n)
+        gc = torch.tensor(base)[torch.randint(0, 15, (n,), generator=g)]
+        gc[torch.rand(n, generator=g) < 0.5] = 20
+        props.append(Instances((128, 192), proposal_boxes=Boxes(b.to(dev)), gt_boxes=Boxes(gb.to(dev)), gt_classes=gc.to(dev)))
+        flat["b"].append(b), flat["gb"].append(gb), flat["gc"].append(gc)
+    wprops = [Instances((128, 192), proposal_boxes=Boxes(_boxes(g, n).to(dev))) for n in sizes]
+    wtargets = [torch.tensor([3, 7, 7]), torch.tensor([12])]
+    # ---- training forward + losses
+    bp.train()
+    (scores, bbox), weak_ret = bp(x.to(dev), nov_t, base_t, supervised_branch_x_weak=xw.to(dev), x_weak=xweak.to(dev),
+                                  similarity={k: v.to(dev) for k, v in sim.items()} if ft else None)
+    rs, rb = orc.supervised_predictor_forward(x, xw, p, "roi_heads.box_predictor", novel, training=True, similarity=sim if ft else None,
+                                              base_classes=base, finetune=ft)
+    assert torch.equal(torch.isinf(scores.cpu()), torch.isinf(rs))
+    fin = torch.isfinite(rs)
+    assert torch.allclose(scores.cpu()[fin], rs[fin], rtol=1e-4, atol=1e-4) and torch.allclose(bbox.cpu(), rb, rtol=1e-4, atol=1e-4)
+    losses = bp.losses([scores, bbox], props, weak_predictions=weak_ret, weak_proposals=wprops, weak_targets=wtargets)
+    ref = orc.fast_rcnn_losses(rs, rb, torch.cat(flat["b"]), torch.cat(flat["gb"]), torch.cat(flat["gc"]))
+    cs, ds, oicr = orc.weak_head_forward_train(xweak, p, "roi_heads.box_predictor.weak_detector_head")
+    assert torch.allclose(weak_ret[0].cpu(), cs, rtol=1e-4, atol=1e-4) and torch.allclose(weak_ret[1].cpu(), ds, rtol=1e-4, atol=1e-4)
+    ref.update(orc.weak_losses(cs, ds, oicr, [w.proposal_boxes.tensor.cpu() for w in wprops], wtargets))
+    assert set(losses) == set(ref) == {"loss_cls", "loss_box_reg", "loss_im_cls", "loss_oicr_1", "loss_oicr_2", "loss_oicr_3"}
+    for k, v in ref.items():
+        assert abs(losses[k].item() - v.item()) <= 1e-4 * max(1.0, abs(v.item())), (k, losses[k].item(), v.item())
+    # ---- eval forward + inference
+    bp.eval()
+    (se, be), wr = bp(x.to(dev), nov_t, base_t, supervised_branch_x_weak=xw.to(dev), x_weak=None, similarity={k: v.to(dev) for k, v in sim.items()})
+    assert wr is None
+    es, eb = orc.supervised_predictor_forward(x, xw, p, "roi_heads.box_predictor", novel, training=False, similarity=sim, base_classes=base,
+                                              finetune=ft)
+    assert torch.allclose(se.cpu(), es, rtol=1e-4, atol=1e-4) and torch.allclose(be.cpu(), eb, rtol=1e-4, atol=1e-4)
+    res, inds = bp.inference([se, be], props)
+    o = 0
+    for i, n in enumerate(sizes):
+        probs = torch.softmax(es[o:o + n], -1)
+        boxes = orc.apply_deltas(eb[o:o + n], flat["b"][i], (10.0, 10.0, 5.0, 5.0))
+        b, s, c, rr = orc.fast_rcnn_inference_single(boxes, probs, (128, 192))
+        assert len(res[i]) == len(b) and len(b) > 0
+        assert torch.equal(res[i].pred_classes.cpu(), c) and torch.equal(inds[i].cpu(), rr)
+        assert torch.allclose(res[i].scores.cpu(), s, rtol=1e-4, atol=1e-5) and torch.allclose(res[i].pred_boxes.tensor.cpu(), b, rtol=1e-4, atol=1e-2)
+        o += n
+
+
+@pytest.mark.parametrize("mask", [False, True])
+def test_roi_heads_forward_eval_equals_meta_arch_inference(dev, mask):
+    """backbone(x) -> WSRPN.forward -> WSROIHead*.forward(images, features, proposals) with NCHW fp32 features and list[Instances]
+    proposals (the reference's plugin layout, roi_heads.py:553 / :783) == WeaklySupervisedRCNNNoMeta.inference(do_postprocess=False)."""
+    cfg, model = _model(dev, mask=mask)
+    model.eval()
+    model.compute_dtype = torch.float32
+    sup, _ = synthetic_batch(2, 0, hw=(128, 192), seed=8)
+    inp = [{"image": s["image"]} for s in sup]
+    whole = model.inference(inp, do_postprocess=False)
+    images = model.preprocess_image(inp)
+    feat_nhwc, _ = model.backbone.fwd(images.tensor)
+    from unit_amd import ops
+    features = {"res4": ops.nhwc_to_nchw(ops.cast(feat_nhwc, torch.float32))}
+    proposals, _ = model.proposal_generator(images, features)
+    out, extra = model.roi_heads(images, features, proposals)
+    assert extra == ({} if mask else None)
+    for a, b in zip(whole, out):
+        assert len(a) == len(b) > 0
+        assert torch.equal(a.pred_classes, b.pred_classes)
+        assert torch.allclose(a.scores, b.scores, rtol=1e-5, atol=1e-6) and torch.allclose(a.pred_boxes.tensor, b.pred_boxes.tensor, rtol=1e-5, atol=1e-3)
+        if mask:
+            assert torch.allclose(a.pred_masks, b.pred_masks, rtol=1e-4, atol=1e-5)
+    model.roi_heads.train()
+    with pytest.raises(RuntimeError, match="fused step"):
+        model.roi_heads(images, features, proposals, targets=[s["instances"] for s in sup])
+
+
+def test_mask_head_forward_eval(dev):
+    """MaskRCNNConvUpsampleHeadWithSimilarity.forward(x, instances, similarity, base_classes, novel_classes) (mask_head.py:16) on
+    NCHW fp32 res5 features vs the oracle's logits (transfer for novel predicted classes)."""
+    cfg, model = _model(dev, mask=True)
+    mh = model.roi_heads.mask_head
+    mh.eval()
+    p = _params(model)
+    g = torch.Generator().manual_seed(5)
+    r = 12
+    x = torch.randn(r, 2048, 7, 7, generator=g).relu()
+    base, novel = list(cfg.DATASETS.FEWSHOT.BASE_CLASSES_ID), list(cfg.DATASETS.FEWSHOT.NOVEL_CLASSES_ID)
+    cls = torch.tensor((novel + base)[:r])
+    sim = torch.rand(r, 5, 15, generator=g)
+    sim = sim / sim.sum(-1, keepdim=True)
+    inst = [Instances((128, 192), pred_classes=cls[:5].to(dev)), Instances((128, 192), pred_classes=cls[5:].to(dev))]
+    out = mh(x.to(dev), inst, similarity={"seg": sim.to(dev)}, base_classes=torch.tensor(base), novel_classes=torch.tensor(novel))
+    lg = orc.mask_head_logits(x, p, similarity=sim, base_classes=base, novel_classes=novel)
+    ref = lg[torch.arange(r), cls].sigmoid()
+    got = torch.cat([i.pred_masks for i in out])[:, 0].cpu()
+    assert got.shape == ref.shape and torch.allclose(got, ref, rtol=1e-3, atol=1e-4)

@@ -125,7 +125,8 @@ def test_autograd_surface_and_sgd(dev):
     model._ensure_ready()
     batch = model.pack_batch(sup, weak)
     perms = model.sampling_permutations(2, 8 * 12 * 15, cfg.MODEL.RPN.POST_NMS_TOPK_TRAIN + batch.gt_boxes.shape[1])
-    loss_dict = model(sup, weak_batched_inputs=weak, perms=perms)
+    model.next_perms = perms
+    loss_dict = model(sup, weak_batched_inputs=weak)
     assert set(loss_dict) == set(LOSS_NAMES)
     total = sum(loss_dict.values())
     for p in model.parameters():

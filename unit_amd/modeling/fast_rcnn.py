@@ -51,7 +51,7 @@ class WeakDetectorOutputsBase(nn.Module):
         self.group.prepare(dtype, version)
 
     # ---- a12: WeakDetectorOutputsBase.losses weak_detector_fast_rcnn.py:189-255 (fused fwd + gradient into `dy`)
-    def losses(self, lin, rois5, valid, rois_per_image, n_images, multihot, loss_out, grad_dtype, side_stream=None):
+    def fused_losses(self, lin, rois5, valid, rois_per_image, n_images, multihot, loss_out, grad_dtype, side_stream=None):
         """lin fp32 [Rw, kp] = fused Linear outputs on the weak RoIs. Returns dy [Rw, kp] (grad_dtype).
         Only OICR iteration 0 needs the MIL output x_r; iterations >= 1 take their pseudo-GT from softmax(oicr_{k-1} logits),
         which are forward outputs: with `side_stream` they run beside the (single-workgroup-per-image, latency-bound) MIL
@@ -82,6 +82,68 @@ class WeakDetectorOutputsBase(nn.Module):
             for it in range(1, self.oicr_iter):
                 oicr(it, None)
         return dy
+
+
+    # ---- plugin surface: the reference's signatures (weak_detector_fast_rcnn.py:148,167,189,270-306). Forward values only: the
+    # training gradient path is the fused step (fused_losses above), these are for evaluation / monitoring / module-level tests.
+    def _lin(self, x_weak):
+        dtype = getattr(self, "compute_dtype", torch.bfloat16)
+        self.prepare(dtype, getattr(self, "_version", 0))
+        return self.group.fwd(ops.cast(x_weak.contiguous(), dtype))
+
+    @torch.no_grad()
+    def forward(self, x_weak):
+        """:148-165 -> ([classifier_stream / T_cls, detection_stream / T_det, [oicr_k], [], None, None], None) in training,
+        `evaluation(x_weak)` otherwise"""
+        if not self.training:
+            return self.evaluation(x_weak)
+        lin, k = self._lin(x_weak), self.num_classes
+        cs = lin[:, self.col_cls:self.col_cls + k] / self.classifier_temp
+        ds = lin[:, self.col_det:self.col_det + k] / self.detector_temp
+        return [cs, ds, [lin[:, c:c + k + 1] for c in self.col_oicr], [], None, None], None
+
+    @torch.no_grad()
+    def evaluation(self, x_weak):
+        """:167-187 (OICR_ITER > 0, no regression branches) -> ([[oicr_k logits], zeros(R, 4K)], None)"""
+        lin, k = self._lin(x_weak), self.num_classes
+        return [[lin[:, c:c + k + 1] for c in self.col_oicr], torch.zeros((lin.shape[0], 4 * k), device=lin.device)], None
+
+    @torch.no_grad()
+    def losses(self, weak_predictions, weak_proposals, weak_targets):
+        """:189-255 -> {'loss_im_cls', 'loss_oicr_1..n'} (values; HIP kernels unit_wsddn_mil / unit_oicr_targets / unit_softmax_ce).
+        weak_predictions = forward()'s list, weak_proposals = list[Instances(proposal_boxes)], weak_targets = list[LongTensor]."""
+        cs, ds, oicr = weak_predictions[0], weak_predictions[1], weak_predictions[2]
+        k, dev = self.num_classes, cs.device
+        sizes = [len(p) for p in weak_proposals]
+        b, s = len(sizes), max(sizes)
+        kp = self.group.kp
+        lin = torch.zeros((b * s, kp), dtype=torch.float32, device=dev)
+        rois5 = torch.zeros((b * s, 5), dtype=torch.float32, device=dev)
+        valid = torch.full((b * s,), -1, dtype=torch.int32, device=dev)
+        multihot = torch.zeros((b, k), dtype=torch.uint8, device=dev)
+        o = 0
+        for i, (n, pr) in enumerate(zip(sizes, weak_proposals)):
+            rows = slice(i * s, i * s + n)
+            lin[rows, self.col_cls:self.col_cls + k] = cs[o:o + n].float() * self.classifier_temp
+            lin[rows, self.col_det:self.col_det + k] = ds[o:o + n].float() * self.detector_temp
+            for c, lg in zip(self.col_oicr, oicr):
+                lin[rows, c:c + k + 1] = lg[o:o + n].float()
+            rois5[rows, 0] = i
+            rois5[rows, 1:] = (pr.proposal_boxes.tensor if hasattr(pr.proposal_boxes, "tensor") else pr.proposal_boxes).to(dev)
+            valid[rows] = 0
+            multihot[i, weak_targets[i].long().to(dev)] = 1
+            o += n
+        loss = torch.zeros(1 + self.oicr_iter, dtype=torch.float32, device=dev)
+        self.fused_losses(lin, rois5, valid, s, b, multihot, loss, torch.float32)
+        out = {"loss_im_cls": loss[0]}
+        out.update({f"loss_oicr_{i + 1}": loss[1 + i] for i in range(self.oicr_iter)})
+        return out
+
+    def predict_probs(self, predictions, proposals):
+        """:280-287: sum_k softmax(oicr_k) split per image"""
+        scores, _ = predictions
+        p = sum(ops.softmax_rows(sc.contiguous().float(), self.num_classes + 1) for sc in scores)
+        return p.split([len(q) for q in proposals], dim=0)
 
 
 @FAST_RCNN_REGISTRY.register()
@@ -146,6 +208,112 @@ class SupervisedDetectorOutputsBase(nn.Module):
         ops.box_reg_loss(lin_sup, self.col_bbox, k, roi_cls, rois5, roi_gt, self.bbox_reg_weights, dy=dy, dcol0=self.col_bbox,
                          loss_out=loss_out[1:2])
         return dy, scores
+
+
+    # ---- plugin surface: the reference's signatures (fast_rcnn.py:384,435,455). Forward values only (see WeakDetectorOutputsBase).
+    def _roles(self, novel_classes, base_classes, dev):
+        key = (tuple(int(c) for c in novel_classes), tuple(int(c) for c in base_classes), dev)
+        if getattr(self, "_roles_key", None) != key:
+            k = self.num_classes
+            role, slot = torch.zeros(k, dtype=torch.int8), torch.zeros(k, dtype=torch.int32)
+            for i, c in enumerate(key[1]):
+                role[c], slot[c] = 1, i
+            for i, c in enumerate(key[0]):
+                role[c], slot[c] = 2, i
+            mask = torch.zeros(k, dtype=torch.uint8)
+            mask[list(key[0])] = 1
+            self._roles_t = dict(base=torch.tensor(key[1], dtype=torch.int32, device=dev), novel=torch.tensor(key[0], dtype=torch.int32, device=dev),
+                                 role=role.to(dev), slot=slot.to(dev), novel_mask=mask.to(dev))
+            self._roles_key = key
+        return self._roles_t
+
+    @torch.no_grad()
+    def forward(self, x, novel_classes, base_classes, supervised_branch_x_weak=None, x_weak=None, similarity=None):
+        """fast_rcnn.py:384-433 (Base) / :484-533 (FineTune) -> ([scores [R,K+1], bbox [R,4K]], weak_branch_return).
+        x: box-head features [R, D]; supervised_branch_x_weak: weak_box_head features of the same RoIs (None: x itself, :389-390);
+        similarity: {'cls': [R,n,b] | [n,b], 'bbox': ...} -- applied in eval (Base) / always (FineTune); training (Base) fills the
+        novel columns with -inf (:427-428)."""
+        if x is None:
+            raise NotImplementedError("x=None (train_only_weak) is outside the hot path (rcnn.py:433 default False)")
+        dtype = getattr(self, "compute_dtype", torch.bfloat16)
+        self.prepare(dtype, getattr(self, "_version", 0))
+        wh, k, dev = self.weak_detector_head, self.num_classes, x.device
+        t = self._roles(novel_classes, base_classes, dev)
+        xc = ops.cast(x.contiguous(), dtype)
+        lin_sup = self.group.fwd(xc)
+        lin_w = wh.group.fwd(xc if supervised_branch_x_weak is None else ops.cast(supervised_branch_x_weak.contiguous(), dtype))
+        transfer = similarity is not None and (self.finetune or not self.training)
+        if transfer or self.finetune:
+            r = x.shape[0]
+            sims = []
+            for h in ("cls", "bbox"):
+                sm = similarity[h] if transfer else None
+                if sm is not None and sm.dim() == 2:
+                    sm = sm[None].expand(r, -1, -1)
+                sims.append(sm.float().contiguous() if sm is not None else None)
+            ft = self.group_ft.fwd(xc) if self.finetune else None
+            scores, bbox = ops.transfer_predictions(lin_sup, self.col_cls, self.col_bbox, k, lin_w, wh.col_oicr[0], wh.oicr_iter, sims[0],
+                                                    sims[1], t["base"], t["novel"], t["role"], t["slot"], ft=ft, fccol0=self.col_cls,
+                                                    fbcol0=self.col_bbox)
+        else:
+            scores = ops.sup_scores(lin_sup, self.col_cls, lin_w, wh.col_oicr[0], wh.oicr_iter, k + 1,
+                                    t["novel_mask"] if self.training else None)
+            bbox = lin_sup[:, self.col_bbox:self.col_bbox + 4 * k]
+        weak_ret = None
+        if x_weak is not None:
+            weak_ret, _ = wh(x_weak)
+        return [scores, bbox], weak_ret
+
+    @torch.no_grad()
+    def losses(self, predictions, proposals, weak_predictions=None, weak_proposals=None, weak_targets=None, train_only_weak=False):
+        """fast_rcnn.py:435-453 -> {'loss_cls', 'loss_box_reg'} (+ the weak head's losses); proposals = list[Instances] with
+        proposal_boxes, gt_boxes, gt_classes (label_and_sample_proposals' output). Values; HIP kernels unit_softmax_ce / unit_box_reg_loss."""
+        out = {}
+        if not train_only_weak:
+            scores, bbox = predictions
+            dev, k = scores.device, self.num_classes
+            tb = lambda v: (v.tensor if hasattr(v, "tensor") else v)
+            pb = torch.cat([tb(p.proposal_boxes) for p in proposals]).to(dev).float()
+            gb = torch.cat([tb(p.gt_boxes) for p in proposals]).to(dev).float()
+            gc = torch.cat([p.gt_classes for p in proposals]).to(dev).int()
+            rois5 = torch.cat([torch.zeros((pb.shape[0], 1), device=dev), pb], 1)
+            out["loss_cls"] = ops.softmax_ce(scores.float().contiguous(), 0, k + 1, gc)[0]
+            out["loss_box_reg"] = ops.box_reg_loss(bbox.float().contiguous(), 0, k, gc, rois5, gb, self.bbox_reg_weights)[0]
+        if weak_predictions is not None:
+            out.update(self.weak_detector_head.losses(weak_predictions, weak_proposals, weak_targets))
+        return out
+
+    def predict_probs(self, predictions, proposals):
+        scores, _ = predictions
+        return ops.softmax_rows(scores.float().contiguous(), self.num_classes + 1).split([len(p) for p in proposals], dim=0)
+
+    @torch.no_grad()
+    def inference(self, predictions, proposals, tta=False):
+        """fast_rcnn.py:455-468 -> (list[Instances(pred_boxes, scores, pred_classes)], list[filter_inds]) (d2 fast_rcnn_inference:
+        softmax, drop bg, apply_deltas, clip, score > thresh, per-class NMS, top-k) on the device"""
+        if tta:
+            raise NotImplementedError("TTA is outside the hot path (SURVEY.md section 2)")
+        from .inference import pack_proposal_instances
+        from ..structures import Boxes, Instances
+        scores, bbox = predictions
+        dev, k = scores.device, self.num_classes
+        props, pcount = pack_proposal_instances(proposals, dev)
+        n, rcap = props.shape[0], props.shape[1]
+        probs = ops.softmax_rows(scores.float().contiguous(), k + 1)
+        pp = torch.zeros((n * rcap, k + 1), dtype=torch.float32, device=dev)
+        bb = torch.zeros((n * rcap, 4 * k), dtype=torch.float32, device=dev)
+        o = 0
+        for i, p in enumerate(proposals):      # ragged -> fixed slots (API boundary; the fused eval path never leaves fixed slots)
+            pp[i * rcap:i * rcap + len(p)], bb[i * rcap:i * rcap + len(p)] = probs[o:o + len(p)], bbox[o:o + len(p)].float()
+            o += len(p)
+        hw = torch.tensor([p.image_size for p in proposals], dtype=torch.float32).to(dev)
+        boxes, sc, cls, roi, cnt = ops.detections(pp, bb, props, pcount, hw, self.bbox_reg_weights, self.test_score_thresh,
+                                                  self.test_nms_thresh, self.test_topk_per_image)
+        res, inds = [], []
+        for i, c in enumerate(cnt.tolist()):
+            res.append(Instances(proposals[i].image_size, pred_boxes=Boxes(boxes[i, :c]), scores=sc[i, :c], pred_classes=cls[i, :c].long()))
+            inds.append(roi[i, :c].long())
+        return res, inds
 
 
 @FAST_RCNN_REGISTRY.register()

@@ -8,11 +8,15 @@ from .. import ops
 from ..structures import Boxes, Instances
 
 
+def _rh(m):
+    return getattr(m, "roi_heads", m)
+
+
 def class_roles(model):
-    """device-side index tables for the base->novel transfer (built once per device)."""
-    rh = model.roi_heads
+    """device-side index tables for the base->novel transfer (built once per device). `model`: the meta-architecture or its ROI heads."""
+    rh = _rh(model)
     cache = getattr(rh, "_role_cache", None)
-    dev = model.device
+    dev = next(rh.parameters()).device
     if cache is not None and cache["dev"] == dev:
         return cache
     k = rh.num_classes
@@ -31,37 +35,37 @@ def class_roles(model):
     return cache
 
 
-def similarity_matrices(model, lin_weak_on_box):
-    """WSROIHead.get_similarity_matrices roi_heads.py:245-336 ('Sum' combination of 'lingual' / 'visual' terms)."""
-    rh, bp = model.roi_heads, model.roi_heads.box_predictor
-    t = class_roles(model)
+def similarity_dict(model, lin_weak_on_box):
+    """WSROIHead.get_similarity_matrices roi_heads.py:245-336 ('Sum' combination of 'lingual' / 'visual' terms) -> {head: [R,n,b]}"""
+    rh = _rh(model)
+    bp = rh.box_predictor
+    t = class_roles(rh)
     wh = bp.weak_detector_head
     lingual = ops.embedding_similarity(bp.embeddings.weight, t["emb_novel"], t["emb_base"])       # fast_rcnn.py:376-382
-    sims = {}
+    sims, out = {}, {}
     for head, terms in rh.terms.items():
         key = ("lingual" in terms, "visual" in terms)
         if key not in sims:
             sims[key] = ops.similarity(lin_weak_on_box, wh.col_oicr[0], wh.oicr_iter, rh.num_classes + 1, t["base"], lingual,
                                        t["novel"].numel(), rh.visual_threshold, key[0], key[1])
-        sims[head] = sims[key]
-    return sims["cls"], sims["bbox"]
+        out[head] = sims[key]
+    return out
 
 
-@torch.no_grad()
-def inference(model, batched_inputs, do_postprocess=True):
-    model._ensure_ready()
-    rpn, rh, bp = model.proposal_generator, model.roi_heads, model.roi_heads.box_predictor
+def similarity_matrices(model, lin_weak_on_box):
+    d = similarity_dict(model, lin_weak_on_box)
+    return d["cls"], d["bbox"]
+
+
+def roi_heads_inference(rh, feat, props, pcount, hw, dt):
+    """eval branch of WSROIHead*.forward (roi_heads.py:585-591 / :796-801): _forward_box (:519-551) -> predictor eval transfer
+    (fast_rcnn.py:401-423) -> `inference` (:455-468, fast_rcnn_inference) -> forward_with_given_boxes (mask, :776-781).
+    feat NHWC [N,H,W,C] (compute dtype), props [N,P,4], pcount int32 [N], hw fp32 [N,2] (device)
+    -> boxes [N,topk,4], scores, classes, roi index, count [N], mask probabilities [N,topk,14,14] or None"""
+    bp = rh.box_predictor
     wh = bp.weak_detector_head
-    dt = model.compute_dtype
-    dev = model.device
-    imgs = [x["image"].to(dev).float() for x in batched_inputs]
-    x, sizes = ops.preprocess_images(imgs, model._pixel_mean, model._pixel_std, dt, 8, model.normalize_images)
-    feat, _ = model.backbone.fwd(x)
-    n, fh, fw, _ = feat.shape
-    anchors = rpn.anchor_generator.grid(fh, fw)
-    head, _ = rpn.rpn_head.fwd(feat)
-    hw = torch.tensor(sizes, dtype=torch.float32).to(dev)
-    props, pscores, pcount = rpn.predict_proposals(head, anchors, hw, False)
+    n = feat.shape[0]
+    dev = feat.device
     rcap = props.shape[1]
     rois5, _ = ops.first_k_rois(props, pcount, rcap, 0)
     pooled = rh.pool(feat, rois5)
@@ -70,11 +74,11 @@ def inference(model, batched_inputs, do_postprocess=True):
     lin_sup = bp.group.fwd(box_feat)
     lin_w_box = wh.group.fwd(box_feat)                       # visual similarity uses box_head features (roi_heads.py:250-252)
     lin_w_sup = wh.group.fwd(sup_weak) if rh.weak_box_head is not None else lin_w_box
-    sim_cls, sim_bbox = similarity_matrices(model, lin_w_box)
-    t = class_roles(model)
+    sims = similarity_dict(rh, lin_w_box)
+    t = class_roles(rh)
     ft = bp.group_ft.fwd(box_feat) if getattr(bp, "finetune", False) else None
     scores, bbox = ops.transfer_predictions(lin_sup, bp.col_cls, bp.col_bbox, rh.num_classes, lin_w_sup, wh.col_oicr[0], wh.oicr_iter,
-                                            sim_cls, sim_bbox, t["base"], t["novel"], t["role"], t["slot"], ft=ft,
+                                            sims["cls"], sims["bbox"], t["base"], t["novel"], t["role"], t["slot"], ft=ft,
                                             fccol0=bp.col_cls, fbcol0=bp.col_bbox)
     probs = ops.softmax_rows(scores, rh.num_classes + 1)
     boxes, sc, cls, roi, cnt = ops.detections(probs, bbox, props, pcount, hw, bp.bbox_reg_weights, bp.test_score_thresh,
@@ -88,15 +92,49 @@ def inference(model, batched_inputs, do_postprocess=True):
         _, dctx = rh.box_head.fwd(rh.pool(feat, det_rois), keep_map=True)
         sim_seg = None
         if "seg" in rh.terms:
-            key = ("lingual" in rh.terms["seg"], "visual" in rh.terms["seg"])
-            base_sim = sim_cls if key == ("lingual" in rh.terms["cls"], "visual" in rh.terms["cls"]) else \
-                ops.similarity(lin_w_box, wh.col_oicr[0], wh.oicr_iter, rh.num_classes + 1, t["base"],
-                               ops.embedding_similarity(bp.embeddings.weight, t["emb_novel"], t["emb_base"]), t["novel"].numel(),
-                               rh.visual_threshold, key[0], key[1])
             flat_idx = (torch.arange(n, device=dev)[:, None] * rcap + roi.clamp(min=0).long()).view(-1)
-            sim_seg = base_sim[flat_idx].contiguous()          # similarity['seg'][filter_inds] (roi_heads.py:768-771)
+            sim_seg = sims["seg"][flat_idx].contiguous()          # similarity['seg'][filter_inds] (roi_heads.py:768-771)
         mask_probs = mh.probs(dctx[1], cls.view(-1).contiguous(), sim_seg, t).view(n, topk, mh.mask_size, mh.mask_size)
+    return boxes, sc, cls, roi, cnt, mask_probs
+
+
+@torch.no_grad()
+def inference(model, batched_inputs, do_postprocess=True):
+    model._ensure_ready()
+    rpn, rh = model.proposal_generator, model.roi_heads
+    dt = model.compute_dtype
+    dev = model.device
+    imgs = [x["image"].to(dev).float() for x in batched_inputs]
+    x, sizes = ops.preprocess_images(imgs, model._pixel_mean, model._pixel_std, dt, 8, model.normalize_images)
+    feat, _ = model.backbone.fwd(x)
+    n, fh, fw, _ = feat.shape
+    anchors = rpn.anchor_generator.grid(fh, fw)
+    head, _ = rpn.rpn_head.fwd(feat)
+    hw = torch.tensor(sizes, dtype=torch.float32).to(dev)
+    if rpn is not None and "proposals" not in batched_inputs[0]:
+        props, pscores, pcount = rpn.predict_proposals(head, anchors, hw, False)
+    else:       # precomputed proposals (rcnn.py:533-536)
+        props, pcount = pack_proposal_instances([x["proposals"] for x in batched_inputs], dev)
+    boxes, sc, cls, roi, cnt, mask_probs = roi_heads_inference(rh, feat, props, pcount, hw, dt)
     out_hw = [(x.get("height", s[0]), x.get("width", s[1])) for x, s in zip(batched_inputs, sizes)]
+    return build_instances(boxes, sc, cls, roi, cnt, mask_probs, sizes, out_hw if do_postprocess else None)
+
+
+def pack_proposal_instances(proposals, dev):
+    """list[Instances(proposal_boxes)] -> (props [N,P,4] fp32, count int32 [N]) on the device"""
+    bs = [(p.proposal_boxes.tensor if hasattr(p.proposal_boxes, "tensor") else p.proposal_boxes).float() for p in proposals]
+    cap = max(max(len(b) for b in bs), 1)
+    props = torch.zeros((len(bs), cap, 4), dtype=torch.float32, device=dev)
+    for i, b in enumerate(bs):
+        props[i, : len(b)] = b.to(dev)
+    return props, torch.tensor([len(b) for b in bs], dtype=torch.int32).to(dev)
+
+
+def build_instances(boxes, sc, cls, roi, cnt, mask_probs, sizes, out_hw=None):
+    """device detections -> the reference's output format: list of {"instances": Instances} after `_postprocess` (rcnn.py:411-429)
+    when out_hw is given, else list of Instances in network-input coordinates (what ROI heads return)."""
+    dev = boxes.device
+    do_postprocess = out_hw is not None
     if do_postprocess:
         scale = torch.tensor([[o[1] / s[1], o[0] / s[0]] for o, s in zip(out_hw, sizes)], dtype=torch.float32).to(dev)
         ohw = torch.tensor(out_hw, dtype=torch.float32).to(dev)

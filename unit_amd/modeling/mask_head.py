@@ -129,6 +129,37 @@ class MaskRCNNConvUpsampleHeadWithSimilarity(nn.Module):
         return out
 
 
+    # ---- plugin surface: the reference's signature (mask_head.py:16 / :74). Eval executes the HIP path.
+    @torch.no_grad()
+    def forward(self, x, instances, similarity=None, base_classes=None, novel_classes=None):
+        """x: res5 features of the detections, NCHW fp32 [R,2048,7,7]; instances: list[Instances(pred_classes)];
+        similarity: {'seg': [R,n,b] | [n,b]} -> sets `pred_masks` [Ri,1,14,14] (mask_rcnn_inference) and returns the instances."""
+        if self.training:
+            raise RuntimeError("mask head in training mode: runs inside WeaklySupervisedRCNNNoMeta's fused step (fwd_train / bwd)")
+        dtype = getattr(self, "compute_dtype", torch.bfloat16)
+        self.prepare(dtype, getattr(self, "_version", 0))
+        dev = x.device
+        cls = torch.cat([i.pred_classes for i in instances]).to(dev).int().contiguous()
+        sim, roles = None, None
+        if similarity is not None and x.numel() > 0:
+            sim = similarity["seg"]
+            if sim.dim() == 2:
+                sim = sim[None].expand(x.shape[0], -1, -1)
+            sim = sim.float().contiguous()
+            k = self.num_classes
+            role, slot = torch.zeros(k, dtype=torch.int8), torch.zeros(k, dtype=torch.int32)
+            for i, c in enumerate(base_classes.tolist()):
+                role[c], slot[c] = 1, i
+            for i, c in enumerate(novel_classes.tolist()):
+                role[c], slot[c] = 2, i
+            roles = dict(base=base_classes.to(dev).int().contiguous(), novel=novel_classes.to(dev).int().contiguous(), role=role.to(dev),
+                         slot=slot.to(dev))
+        p = self.probs(ops.nchw_to_nhwc(x.float(), dtype=dtype), cls, sim, roles)
+        for inst, pr in zip(instances, p.split([len(i) for i in instances])):
+            inst.pred_masks = pr[:, None]
+        return instances
+
+
 def mask_targets(gt_masks, rois5, gt_index, cls, num_classes, m=14):
     """BitMasks.crop_and_resize for every slot: gt_masks u8 [B,Mcap,H,W] -> u8 [S,m,m]"""
     s = rois5.shape[0]

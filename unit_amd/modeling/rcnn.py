@@ -44,15 +44,21 @@ class _StepFn(torch.autograd.Function):
     """Exposes the explicit plan to torch.autograd as one node: forward has already run, backward runs the backward plan."""
 
     @staticmethod
-    def forward(ctx, anchor, model, step, loss_vec):
-        ctx.model, ctx.step = model, step
+    def forward(ctx, anchor, model, step, loss_vec, used_mask=None):
+        ctx.model, ctx.step, ctx.step_mask = model, step, used_mask
         return loss_vec.view_as(loss_vec)
 
     @staticmethod
     def backward(ctx, grad_losses):
-        # every loss enters the total with weight 1 (engine/defaults.py:280 `sum(loss_dict.values())`)
+        # every loss enters the total with weight 1 (engine/defaults.py:280 `sum(loss_dict.values())`): the backward plan has that
+        # baked in, so a trainer that scales or drops losses (AMP GradScaler, loss weights, a subset of the dict) is refused rather
+        # than silently given unscaled gradients. Losses the step did not produce are zero slots and may carry any weight.
+        used = torch.ones_like(grad_losses, dtype=torch.bool) if ctx.step_mask is None else ctx.step_mask
+        if not bool(torch.all(grad_losses[used] == 1.0)):
+            raise RuntimeError("WeaklySupervisedRCNNNoMeta: backward() expects d(total)/d(loss_i) == 1 for every returned loss "
+                               "(sum(loss_dict.values()).backward()); scaled / partial losses are not supported by the fused step")
         ctx.model.backward_train(ctx.step)
-        return torch.zeros(1, device=grad_losses.device), None, None, None
+        return torch.zeros(1, device=grad_losses.device), None, None, None, None
 
 
 @META_ARCH_REGISTRY.register()
@@ -438,7 +444,7 @@ class WeaklySupervisedRCNNNoMeta(nn.Module):
                 with torch.cuda.stream(sup_side) if sup_side is not None else contextlib.nullcontext():
                     c.dy_sup, c.scores = bp.sup_losses(lin_sup, lin_weak_all[:rs], c.roi_cls, c.rois[:rs], c.roi_gt, c.losses[0:2], dt)
         if rw > 0:
-            c.dy_weak = bp.weak_detector_head.losses(lin_weak_all[rs:], c.rois[rs:], c.weak_valid, s // rh.weak_divisor, n_weak,
+            c.dy_weak = bp.weak_detector_head.fused_losses(lin_weak_all[rs:], c.rois[rs:], c.weak_valid, s // rh.weak_divisor, n_weak,
                                                      batch.multihot, c.losses[2:6], dt,
                                                      side_stream=self._rpn_stream if self._streams_on() else None)
         if sup_side is not None:
@@ -610,7 +616,10 @@ class WeaklySupervisedRCNNNoMeta(nn.Module):
                 p.grad = st._view(st.grads, e["offset"], p)
 
     # ------------------------------------------------------------------ plugin surface
-    def forward(self, batched_inputs, weak_batched_inputs=None, return_similarity=False, train_only_weak=False, perms=None):
+    def forward(self, batched_inputs, weak_batched_inputs=None, return_similarity=False, train_only_weak=False):
+        """rcnn.py:433. (Tests that need reproducible sampling set `model.next_perms = {...}` before the call: the explicit-
+        permutation contract of the samplers, consumed once.)"""
+        perms, self.next_perms = getattr(self, "next_perms", None), None
         if not self.training:
             return self.inference(batched_inputs, return_similarity=return_similarity)
         if train_only_weak:
@@ -619,10 +628,11 @@ class WeaklySupervisedRCNNNoMeta(nn.Module):
         step = self.forward_train(batch, perms)
         if self._anchor is None or self._anchor.device != self.device:
             self._anchor = torch.zeros(1, device=self.device, requires_grad=True)
-        lv = _StepFn.apply(self._anchor, self, step, step.losses)
         names = LOSS_NAMES if batch.n_weak > 0 else [n for n in LOSS_NAMES if not (n.startswith("loss_oicr") or n == "loss_im_cls")]
         if step.mask_ctx is None:
             names = [n for n in names if n != "loss_mask"]
+        used = torch.tensor([n in names for n in LOSS_NAMES], device=self.device)
+        lv = _StepFn.apply(self._anchor, self, step, step.losses, used)
         return {n: lv[LOSS_NAMES.index(n)] for n in names}
 
     def train_step(self, batch, optimizer=None, perms=None):

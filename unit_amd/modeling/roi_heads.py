@@ -4,10 +4,14 @@ WSROIHeadFineTune (:594-644), plus the Detectron2 `label_and_sample_proposals` t
 Module / parameter names equal the reference's: `box_head`, `weak_box_head` (iff MULTI_BOX_HEAD), `box_predictor`.
 The whole RoI stage is sync-free: proposal / RoI counts stay in device int32 arrays, RoIs live in fixed 512-per-image
 slots (empty slots carry class -1 and contribute neither loss nor gradient)."""
+import torch
 from torch import nn
 
 from .. import ops
 from ..structures import FAST_RCNN_REGISTRY, ROI_BOX_HEAD_REGISTRY, ROI_HEADS_REGISTRY, ShapeSpec
+
+_FUSED = ("training runs inside WeaklySupervisedRCNNNoMeta's fused step (one explicit forward + backward plan over the HIP "
+          "kernels, no autograd graph through the ROI heads): call the meta-architecture / engine.TrainerNoMeta.run_step")
 
 VOC_CLASSES = ["aeroplane", "bicycle", "bird", "boat", "bottle", "bus", "car", "cat", "chair", "cow", "diningtable", "dog",
                "horse", "motorbike", "person", "pottedplant", "sheep", "sofa", "train", "tvmonitor"]
@@ -48,6 +52,7 @@ class WSROIHeadNoMeta(nn.Module):
         self.mask_on = cfg.MODEL.MASK_ON
         self.pool_mode = "strided"   # "full": materialise all 14x14 bins like the reference (parity tests)
         in_ch = input_shape["res4"].channels if input_shape else 1024
+        self.in_features, self.in_channels = list(rh.IN_FEATURES), in_ch
         pooled = ShapeSpec(channels=in_ch, height=self.pooler_resolution, width=self.pooler_resolution)
         self.box_head = ROI_BOX_HEAD_REGISTRY.get(cfg.MODEL.ROI_BOX_HEAD.NAME)(cfg, pooled)
         self.weak_box_head = ROI_BOX_HEAD_REGISTRY.get(cfg.MODEL.ROI_BOX_HEAD.NAME)(cfg, pooled) if rh.MULTI_BOX_HEAD else None
@@ -102,6 +107,46 @@ class WSROIHeadNoMeta(nn.Module):
                                  self.sampling_ratio, True)
 
 
+    # ---- plugin surface: the reference's signature (roi_heads.py:553). Eval executes the HIP path; training is the fused step.
+    def forward(self, images, features, proposals, targets=None, weak_images=None, weak_features=None, weak_proposals=None,
+                weak_targets=None, tta=False, return_similarity=False, train_only_weak=False, return_proposals=False):
+        """See WSROIHeadNoMeta.forward roi_heads.py:553-591. `features`: {"res4": NCHW fp32 [N,1024,H,W]} (the plugin layout) or
+        the NHWC activation of this framework's backbone; `proposals`: list[Instances] with `proposal_boxes`.
+        Eval: -> (list[Instances(pred_boxes, scores, pred_classes[, pred_masks])], None)."""
+        del images, weak_images
+        if self.training:
+            raise RuntimeError("WSROIHead*.forward in training mode: " + _FUSED)
+        if tta or return_similarity or return_proposals:
+            raise NotImplementedError("tta / return_similarity / return_proposals belong to the TTA and visualisation tools, "
+                                      "outside the hot path (SURVEY.md section 2)")
+        pred = self._forward_box(features, proposals)
+        return pred, (None if not self.mask_on else {})
+
+    def _feat_nhwc(self, features, dtype):
+        f = features[self.in_features[0]] if isinstance(features, dict) else features
+        if f.dim() == 4 and f.shape[1] == self.in_channels and f.shape[-1] != self.in_channels:
+            f = ops.nchw_to_nhwc(f.float(), dtype=dtype)
+        return f
+
+    @torch.no_grad()
+    def _forward_box(self, features, proposals, weak_features=None, weak_proposals=None, weak_targets=None, tta=False,
+                     return_similarity=False, train_only_weak=False, return_proposals=False):
+        """eval branch of roi_heads.py:496-551 (+ forward_with_given_boxes for the mask variants :776-781)"""
+        if self.training:
+            raise RuntimeError("WSROIHead*._forward_box in training mode: " + _FUSED)
+        from .inference import build_instances, pack_proposal_instances, roi_heads_inference
+        dtype = getattr(self, "compute_dtype", torch.bfloat16)
+        self.prepare(dtype, getattr(self, "_version", 0))
+        feat = self._feat_nhwc(features, dtype)
+        props, pcount = pack_proposal_instances(proposals, feat.device)
+        sizes = [p.image_size for p in proposals]
+        hw = torch.tensor(sizes, dtype=torch.float32).to(feat.device)
+        out = roi_heads_inference(self, feat, props, pcount, hw, dtype)
+        return build_instances(*out, sizes, None)
+
+    def forward_with_given_boxes(self, features, instances, similarity=None):
+        raise NotImplementedError("the mask head runs on the detections inside _forward_box (one device pass, no host round trip)")
+
     def pool_bwd_gather(self, dpooled, n_images, h, w, rois5, out, image_offset=0, addend=None, mask_ref=None):
         """deterministic gather-form RoIAlign backward fused with '+ RPN-branch gradient, * ReLU mask' (fixed RoI slots)."""
         _, step = self.pool_out
@@ -138,6 +183,17 @@ class WSROIHeadNoMetaWithMask(WSROIHeadNoMeta):
         super().prepare(dtype, version)
         if self.mask_head is not None:
             self.mask_head.prepare(dtype, version)
+
+    def forward(self, images, features, proposals, targets=None, weak_images=None, weak_features=None, weak_proposals=None,
+                weak_targets=None, tta=False, return_similarity=False, train_only_weak=False):
+        """roi_heads.py:783-822 (WSROIHeadNoMetaWithMask) / :909-952 (WSROIHeadWithMaskFineTune): eval -> (instances, {})"""
+        return super().forward(images, features, proposals, targets, weak_images, weak_features, weak_proposals, weak_targets, tta,
+                               return_similarity, train_only_weak)
+
+    def _forward_box(self, features, proposals, weak_features=None, weak_proposals=None, weak_targets=None, tta=False,
+                     return_similarity=False, train_only_weak=False):
+        return super()._forward_box(features, proposals, weak_features, weak_proposals, weak_targets, tta, return_similarity,
+                                    train_only_weak)
 
     @property
     def max_fg_per_image(self):

@@ -4,13 +4,40 @@ They are plain containers -- no arithmetic lives here."""
 import torch
 
 
+def _detectron2_registry(name):
+    """the real Detectron2 registry object of that name when `import detectron2` succeeds ("if real
+    detectron2 is importable, register into it instead"), else None. d2's `build_model` / `build_roi_heads` / ... look classes up
+    in THESE objects (call site in the reference: modeling/roi_heads/fast_rcnn.py:587-589 for UniT's own two registries, which
+    have no Detectron2 counterpart and stay local)."""
+    where = {"META_ARCH": ("detectron2.modeling", "META_ARCH_REGISTRY"), "BACKBONE": ("detectron2.modeling", "BACKBONE_REGISTRY"),
+             "PROPOSAL_GENERATOR": ("detectron2.modeling", "PROPOSAL_GENERATOR_REGISTRY"),
+             "ROI_HEADS": ("detectron2.modeling", "ROI_HEADS_REGISTRY"), "ROI_BOX_HEAD": ("detectron2.modeling", "ROI_BOX_HEAD_REGISTRY"),
+             "ROI_MASK_HEAD": ("detectron2.modeling", "ROI_MASK_HEAD_REGISTRY")}.get(name)
+    if where is None:
+        return None
+    try:
+        import importlib
+        return getattr(importlib.import_module(where[0]), where[1])
+    except Exception:       # detectron2 absent (this image) or too old to have the registry
+        return None
+
+
 class Registry:
     def __init__(self, name):
         self._name, self._map = name, {}
+        self._d2 = _detectron2_registry(name)
 
     def register(self, obj=None):
         def deco(o):
             self._map[o.__name__] = o
+            if self._d2 is not None:
+                # the MI355X class takes the plugin name: a later `import UniT.modeling` would collide, which is the point of a
+                # drop-in (INTEGRATION.md); a name Detectron2 itself already holds (build_resnet_backbone) is replaced
+                m = getattr(self._d2, "_obj_map", None)
+                if isinstance(m, dict):
+                    m[o.__name__] = o
+                else:
+                    self._d2.register(o)
             return o
         return deco(obj) if obj is not None else deco
 
