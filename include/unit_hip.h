@@ -84,7 +84,11 @@ int unit_frozen_bn_fold(const float* w, const float* b, const float* rm, const f
                         int C, void* stream);
 int unit_weight_prep(const float* w_krsc, const float* scale_k, int K, int R, int S, int C, int Cp, void* w_fwd, void* w_dgrad,
                      int dtype, void* stream);
-int unit_bias_grad(const void* dy, int dtype, int M, int K, int ld, float* db, int accumulate, void* stream);
+/* scratch (unit_bias_grad_scratch_bytes, may be NULL): tall bf16 inputs are summed per 512-row block into it and combined in block
+ * order (deterministic, parallel over rows); without it one workgroup per 256 columns walks all rows */
+size_t unit_bias_grad_scratch_bytes(int M, int K);
+int unit_bias_grad(const void* dy, int dtype, int M, int K, int ld, float* db, int accumulate, float* scratch, size_t scratch_bytes,
+                   void* stream);
 int unit_maxpool3x3s2_fwd(const void* x, void* y, int dtype, int N, int H, int W, int C, void* stream);
 /* Res5BoxHead.forward x.mean(dim=[2,3]): modeling/roi_heads/box_head.py:80 */
 int unit_global_avgpool_fwd(const void* x, void* y, int dtype, int R, int P, int C, void* stream);
@@ -180,6 +184,11 @@ int unit_wsddn_mil(const float* streams, int ld, int ccol0, int dcol0, int K, co
 int unit_oicr_targets(const float* src, int ld, int col0, int mode, int K, const float* rois5, const int* valid, int S, int B,
                       const unsigned char* multihot, float fg_thresh, float bg_thresh, int* labels, float* weights, void* stream);
 int unit_sum_losses(const float* losses, int n, float* out, void* stream);
+/* sampling permutations (d2 `subsample_labels` -> torch.randperm; call sites rpn.py:41, roi_heads.py:563): keys [B][n] = hash of
+ * (seed, *counter_dev, stream_id, b, i) as positive finite floats; `unit_sort_desc_stable` of them yields the permutation.
+ * The device-resident counter is advanced by unit_counter_bump (graph-replay safe). */
+int unit_perm_keys(unsigned long long seed, const long long* counter_dev, int stream_id, int B, int n, float* keys, void* stream);
+int unit_counter_bump(long long* counter_dev, long long delta, void* stream);
 
 /* ---- a14 base->novel similarity transfer: modeling/roi_heads/roi_heads.py:245-336, fast_rcnn.py:376-382,401-423,504-533 ---- */
 int unit_embedding_similarity(const float* emb, int ld, int dim, const int* novel_rows, int n_novel, const int* base_rows, int n_base,

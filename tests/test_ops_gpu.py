@@ -308,6 +308,47 @@ def test_pools_bias_misc(dev):
 
 
 # ------------------------------------------------------------------------------------------- anchors / matcher / sampling
+def test_bias_grad_tall_is_deterministic_and_exact(dev):
+    """the RPN conv bias gradient shape (9 576 rows x 1024 columns, bf16): row-block partial sums combined in block order ==
+    fp64 column sums within fp32 rounding, bit-identical from run to run, accumulate adds onto the previous value"""
+    o = ops()
+    x = (torch.randn(9576, 1024, generator=g(77)) * 0.1).bfloat16()
+    ref = x.double().sum(0)
+    xd = x.to(dev)
+    a = o.bias_grad(xd, 1024)
+    b = o.bias_grad(xd, 1024)
+    assert torch.equal(a, b)
+    assert torch.allclose(a.cpu().double(), ref, rtol=1e-5, atol=1e-4)
+    o.bias_grad(xd, 1024, out=a, accumulate=True)
+    assert torch.allclose(a.cpu().double(), 2 * ref, rtol=1e-5, atol=2e-4)
+    part = o.bias_grad(xd[:, :80].contiguous(), 75)          # RPN predictors: 75 live columns of an 80-wide row
+    assert torch.allclose(part.cpu().double(), ref[:75], rtol=1e-5, atol=1e-4)
+
+
+def test_random_permutations_kernel(dev):
+    """unit_perm_keys + stable sort: every row is a permutation of range(n); rows, streams and counter values give different
+    permutations; the same (seed, counter) reproduces; position of an element is roughly uniform"""
+    o = ops()
+    n = 35910
+    counter = torch.zeros(1, dtype=torch.int64, device=dev)
+    a = o.random_permutations(2, n, 7, counter, 0, dev)
+    a2 = o.random_permutations(2, n, 7, counter, 0, dev)
+    b = o.random_permutations(2, n, 7, counter, 1, dev)
+    o.counter_bump(counter)
+    c = o.random_permutations(2, n, 7, counter, 0, dev)
+    assert int(counter.item()) == 1
+    for t in (a, b, c):
+        assert t.dtype == torch.int32 and t.shape == (2, n)
+        assert torch.equal(t.long().sort(dim=1).values.cpu(), torch.arange(n).expand(2, n))
+    assert torch.equal(a, a2)
+    assert not torch.equal(a[0], a[1]) and not torch.equal(a, b) and not torch.equal(a, c)
+    pos = torch.empty(n, dtype=torch.float64)
+    pos[a[0].long().cpu()] = torch.arange(n, dtype=torch.float64)
+    assert abs(pos[: n // 2].mean().item() / n - 0.5) < 0.02            # first half of the indices lands anywhere
+    small = o.random_permutations(3, 2008, 1, counter, 1, dev)
+    assert torch.equal(small.long().sort(dim=1).values.cpu(), torch.arange(2008).expand(3, 2008))
+
+
 def test_anchor_grid(dev):
     o = ops()
     ref = orc.grid_anchors(38, 63)

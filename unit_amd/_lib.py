@@ -13,6 +13,7 @@ LIB_PATH = os.environ.get("UNIT_HIP_LIB") or os.path.join(HERE, "_build", "libun
 
 _CT = {
     "int": ctypes.c_int, "long": ctypes.c_long, "float": ctypes.c_float, "size_t": ctypes.c_size_t,
+    "long long": ctypes.c_longlong, "unsigned long long": ctypes.c_ulonglong, "unsigned": ctypes.c_uint,
 }
 
 
@@ -35,8 +36,8 @@ def parse_header(path=HEADER):
                 if "*" in a:
                     argtypes.append(ctypes.c_void_p)
                 else:
-                    ty = a.split()[-2] if len(a.split()) >= 2 else a
-                    argtypes.append(_CT[ty])
+                    words = a.split()[:-1] if len(a.split()) >= 2 else a.split()
+                    argtypes.append(_CT[" ".join(w for w in words if w != "const")])
         protos[name] = (restype, argtypes)
     return protos
 

@@ -245,13 +245,59 @@ __global__ void __launch_bounds__(256) bias_grad_vec_kernel(const bf16_t* __rest
     atomicAdd(db + c, s);
   }
 }
-extern "C" int unit_bias_grad(const void* dy, int dtype, int M, int K, int ld, float* db, int accumulate, void* stream) {
+// Tall inputs (the RPN conv bias: 9 576 rows x 1024 columns had FOUR workgroups walking all rows, 75-190 us): row blocks of
+// BG_ROWS rows write their column sums to scratch [row block][K] (bias_grad_vec_kernel with a partial pointer), then one thread
+// per column adds the row blocks in index order: a fixed summation order -> still bit-reproducible, 76 + 4 workgroups, ~10 us.
+#define BG_ROWS 512
+__global__ void __launch_bounds__(256) bias_grad_partial_kernel(const bf16_t* __restrict__ dy, int M, int K, int ld, float* __restrict__ part) {
+  __shared__ float red[8][257];
+  int cg = threadIdx.x & 31, rl = threadIdx.x >> 5;
+  int c0 = (blockIdx.x * 32 + cg) * 8;
+  int m0 = blockIdx.y * BG_ROWS, m1 = min(M, m0 + BG_ROWS);
+  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (c0 < K) {
+    for (int m = m0 + rl; m < m1; m += 8) {
+      bf16x8 v = *reinterpret_cast<const bf16x8*>(dy + (size_t)m * ld + c0);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[j] += (float)v[j];
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) red[rl][cg * 8 + j] = acc[j];
+  __syncthreads();
+  int c = blockIdx.x * 256 + threadIdx.x;
+  if (c < K) {
+    float s = 0.f;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) s += red[r][threadIdx.x];
+    part[(size_t)blockIdx.y * K + c] = s;
+  }
+}
+__global__ void bias_grad_combine_kernel(const float* __restrict__ part, int nblk, int K, float* __restrict__ db, int accumulate) {
+  int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= K) return;
+  float s = accumulate ? db[c] : 0.f;
+  for (int b = 0; b < nblk; ++b) s += part[(size_t)b * K + c];
+  db[c] = s;
+}
+extern "C" size_t unit_bias_grad_scratch_bytes(int M, int K) { return (size_t)cdiv(M, BG_ROWS) * (size_t)K * sizeof(float); }
+extern "C" int unit_bias_grad(const void* dy, int dtype, int M, int K, int ld, float* db, int accumulate, float* scratch,
+                              size_t scratch_bytes, void* stream) {
   hipStream_t st = (hipStream_t)stream;
+  if (dtype == UNIT_BF16 && ld % 8 == 0 && ((uintptr_t)dy % 16 == 0) && M > 2 * BG_ROWS && scratch &&
+      scratch_bytes >= unit_bias_grad_scratch_bytes(M, K)) {
+    int nblk = cdiv(M, BG_ROWS);
+    bias_grad_partial_kernel<<<dim3(cdiv(K, 256), nblk), 256, 0, st>>>((const bf16_t*)dy, M, K, ld, scratch);
+    UNIT_LAUNCH_CHECK();
+    bias_grad_combine_kernel<<<cdiv(K, 256), 256, 0, st>>>(scratch, nblk, K, db, accumulate);
+    UNIT_LAUNCH_CHECK();
+    return UNIT_OK;
+  }
   if (!accumulate) hipMemsetAsync(db, 0, sizeof(float) * K, st);
   if (M == 0) return UNIT_OK;
   if (dtype == UNIT_BF16 && ld % 8 == 0 && ((uintptr_t)dy % 16 == 0)) {
-    // up to 16 384 rows (every bias on the hot path: RPN head 9 576, predictors <= 2 048): one workgroup per 256 columns walks all
-    // rows, so each db[c] has a single adder and the sum is bit-reproducible; beyond that the row blocks add atomically
+    // up to 16 384 rows: one workgroup per 256 columns walks all rows, so each db[c] has a single adder and the sum is
+    // bit-reproducible; beyond that (and without scratch) the row blocks add atomically
     int rows = M <= 16384 ? M : 128;
     bias_grad_vec_kernel<<<dim3(cdiv(K, 256), cdiv(M, rows)), 256, 0, st>>>((const bf16_t*)dy, M, K, ld, db, rows);
     UNIT_LAUNCH_CHECK();
@@ -384,6 +430,42 @@ extern "C" int unit_nhwc_to_nchw(const void* x, int dtype, float* y, int N, int 
   hipStream_t st = (hipStream_t)stream;
   if (dtype == UNIT_BF16) nhwc_to_nchw_kernel<bf16_t><<<cdiv(total, 256), 256, 0, st>>>((const bf16_t*)x, y, N, C, H, W, Cp);
   else nhwc_to_nchw_kernel<float><<<cdiv(total, 256), 256, 0, st>>>((const float*)x, y, N, C, H, W, Cp);
+  UNIT_LAUNCH_CHECK();
+  return UNIT_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Sampling permutations without torch.randperm (d2 `subsample_labels` draws torch.randperm on the device: rocprim sorts + host
+// bookkeeping, and not capturable in a hipGraph). keys[b][i] = a counter-based hash of (seed, *counter, stream, b, i) laid out as
+// a POSITIVE FINITE float (31 random bits: positive floats order like their bit patterns); a stable descending sort of the keys
+// (unit_sort_desc_stable) is then a uniformly random permutation up to ~n^2 / 2^32 tied pairs. The step counter lives on the
+// device and is bumped by its own tiny launch, so that a captured graph draws fresh permutations on every replay.
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned long long mix64(unsigned long long z) {     // splitmix64 finaliser
+  z += 0x9E3779B97F4A7C15ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+__global__ void perm_keys_kernel(unsigned long long seed, const long long* __restrict__ counter, int stream_id, int n, float* __restrict__ keys) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  int b = blockIdx.y;
+  if (i >= n) return;
+  unsigned long long c = counter ? (unsigned long long)*counter : 0ull;
+  unsigned long long h = mix64(mix64(seed ^ (c * 0xD1342543DE82EF95ull)) ^ (((unsigned long long)(unsigned)stream_id << 40) | ((unsigned long long)(unsigned)b << 32) | (unsigned)i));
+  unsigned bits = (unsigned)(h >> 33);                          // 31 bits
+  if ((bits & 0x7F800000u) == 0x7F800000u) bits &= 0x7F7FFFFFu; // never inf / nan
+  keys[(size_t)b * n + i] = __uint_as_float(bits);
+}
+extern "C" int unit_perm_keys(unsigned long long seed, const long long* counter_dev, int stream_id, int B, int n, float* keys, void* stream) {
+  if (B == 0 || n == 0) return UNIT_OK;
+  perm_keys_kernel<<<dim3(cdiv(n, 256), B), 256, 0, (hipStream_t)stream>>>(seed, counter_dev, stream_id, n, keys);
+  UNIT_LAUNCH_CHECK();
+  return UNIT_OK;
+}
+__global__ void counter_bump_kernel(long long* c, long long d) { *c += d; }
+extern "C" int unit_counter_bump(long long* counter_dev, long long delta, void* stream) {
+  counter_bump_kernel<<<1, 1, 0, (hipStream_t)stream>>>(counter_dev, delta);
   UNIT_LAUNCH_CHECK();
   return UNIT_OK;
 }

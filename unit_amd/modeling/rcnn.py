@@ -236,14 +236,17 @@ class WeaklySupervisedRCNNNoMeta(nn.Module):
         return ImageList(t, sizes)
 
     def sampling_permutations(self, n_sup, n_anchor, n_roi_cap):
-        """RNG for subsample_labels: one permutation per image and per sampler (explicit-permutation contract)."""
+        """RNG for subsample_labels: one permutation per image and per sampler (explicit-permutation contract). Drawn on the
+        device by unit_perm_keys + the stable sort from (SEED + rank, a device-resident step counter): no torch.randperm, no
+        host state -- a captured step draws fresh permutations on every replay."""
         if self._gen is None:
-            self._gen = torch.Generator(device=self.device)
             seed = self.cfg.SEED if self.cfg.SEED >= 0 else 0
             rank = torch.distributed.get_rank() if torch.distributed.is_available() and torch.distributed.is_initialized() else 0
-            self._gen.manual_seed(seed + rank)
-        rpn = torch.stack([torch.randperm(n_anchor, device=self.device, generator=self._gen) for _ in range(n_sup)]).int()
-        roi = torch.stack([torch.randperm(n_roi_cap, device=self.device, generator=self._gen) for _ in range(n_sup)]).int()
+            self._gen = (seed + rank, torch.zeros(1, dtype=torch.int64, device=self.device))
+        seed, counter = self._gen
+        rpn = ops.random_permutations(n_sup, n_anchor, seed, counter, 0, self.device)
+        roi = ops.random_permutations(n_sup, n_roi_cap, seed, counter, 1, self.device)
+        ops.counter_bump(counter)
         return {"rpn": rpn, "roi": roi}
 
     # ------------------------------------------------------------------ the training step: forward plan

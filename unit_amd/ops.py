@@ -275,7 +275,9 @@ def bias_grad(dy2d, k, out=None, accumulate=False):
     m, ld = dy2d.shape
     if out is None:
         out = torch.empty(k, dtype=torch.float32, device=dy2d.device)
-    check(lib().unit_bias_grad(_p(dy2d), dt(dy2d.dtype), m, k, ld, _p(out), int(accumulate), _s()), "bias_grad")
+    nb = lib().unit_bias_grad_scratch_bytes(m, k) if m > 1024 else 0
+    ws = workspace(nb, dy2d.device, slot=3) if nb else None
+    check(lib().unit_bias_grad(_p(dy2d), dt(dy2d.dtype), m, k, ld, _p(out), int(accumulate), _p(ws), nb, _s()), "bias_grad")
     return out
 
 
@@ -374,6 +376,19 @@ def subsample_labels(labels, count, perm, num_samples, positive_fraction, bg_lab
                                       num_samples, max_pos, bg_label, _p(out_labels), _p(sidx), _p(counts), _s()),
           "subsample_labels")
     return out_labels, sidx, counts
+
+
+def random_permutations(b, n, seed, counter, stream_id, device):
+    """-> int32 [b, n]: one uniformly random permutation of range(n) per row, drawn from (seed, *counter, stream_id) by
+    unit_perm_keys + the stable descending sort (replaces torch.randperm in the step; `counter` is a device int64 scalar)"""
+    keys = torch.empty((b, n), dtype=torch.float32, device=device)
+    check(lib().unit_perm_keys(int(seed) & 0xFFFFFFFFFFFFFFFF, _p(counter), int(stream_id), b, n, _p(keys), _s()), "perm_keys")
+    _, idx = sort_desc(keys, b, n, topk=n)        # chip-wide select + rank form (the plain form is one workgroup per row)
+    return idx
+
+
+def counter_bump(counter, delta=1):
+    check(lib().unit_counter_bump(_p(counter), int(delta), _s()), "counter_bump")
 
 
 def box_encode(src, tgt, weights):
