@@ -199,6 +199,16 @@ int unit_transfer_predictions(const float* lin, int ld, int ccol0, int bcol0, in
                               const float* ft, int ldf, int fccol0, int fbcol0, const float* sim_cls, const float* sim_bbox,
                               const int* base_dev, int n_base, const int* novel_dev, int n_novel, const int8_t* role_dev,
                               const int* slot_dev, float* scores, int lds, float* bbox, int ldb, int R, void* stream);
+/* backward of the two above for the fine-tune configurations whose box head trains (COCO-RCNN-50-C4-split1-segm-ft.yaml; the reference
+ * computes the similarity with grad in training, roi_heads.py:852): dy = d(loss)/d[scores | bbox] in the ft heads' layout ->
+ * dlin (delta heads' layout, zero-filled first) and dsim [R][n_novel][n_base] (written); then dsim -> the OICR logit columns of dlin_weak */
+int unit_transfer_predictions_bwd(const void* dy, int dy_dtype, int ldd, int dccol0, int dbcol0, const float* lin, int ld, int ccol0,
+                                  int bcol0, int K, const float* sim_cls, const float* sim_bbox, const int* base_dev, int n_base,
+                                  const int* novel_dev, int n_novel, const int8_t* role_dev, const int* slot_dev, void* dlin, int ldl,
+                                  float* dsim, int R, void* stream);
+int unit_similarity_bwd(const float* lin_weak, int ld, int col0, int n_oicr, int ncls, const int* base_dev, int n_base,
+                        const float* lingual, int n_novel, float visual_threshold, int use_lingual, int use_visual, const float* dsim,
+                        void* dlin, int dlin_dtype, int ldl, int dcol0, int R, void* stream);
 /* ---- a15 detections: fast_rcnn.py:455-468 -> detectron2 fast_rcnn_inference; rcnn.py:411-429 detector_postprocess ---- */
 int unit_softmax_rows(const float* x, int ld, int ncls, float* y, int ldy, int R, void* stream);
 int unit_detection_candidates(const float* probs, int ldp, const float* deltas, int ldd, const float* props, const int* pcount, int B,
@@ -221,6 +231,13 @@ int unit_mask_targets(const unsigned char* gt_masks, int Mcap, int Hm, int Wm, c
                       int K, int S, int M, unsigned char* out, void* stream);
 int unit_mask_bce_loss(const float* logits, int K, int ldk, const int* cls, const unsigned char* targets, int S, int M, float gscale,
                        float* loss, void* dlogits, int d_dtype, void* stream);
+/* training form of the fine-tune mask head (mask_head.py:74-93 with similarity['seg'][fg], roi_heads.py:888-906): gt-class logit =
+ * transfer(predictor columns; sim[sim_rows[s]]) + predictor_delta column; loss + d(loss)/d(logits) of both column groups, and
+ * d(loss)/d(sim) ADDED into dsim[sim_rows[s]] (sim / dsim [R][n_novel][n_base]; NULL sim: no transfer) */
+int unit_mask_bce_loss_ft(const float* logits, int K, int ldk, int delta_col0, const int* cls, const unsigned char* targets,
+                          const float* sim, const int* sim_rows, const int* base_dev, int n_base, int n_novel, const int8_t* role_dev,
+                          const int* slot_dev, int S, int M, float gscale, float* loss, void* dlogits, int d_dtype, float* dsim,
+                          void* stream);
 /* delta_col0 >= 0: the logits carry K more columns from there (`predictor_delta` of MaskRCNNConvUpsampleHeadWithFineTune,
  * mask_head.py:39-94), added AFTER the base->novel transfer (:91); -1: none */
 int unit_mask_probs(const float* logits, int K, int ldk, int delta_col0, const int* cls, const float* sim, const int* base_dev, int n_base,

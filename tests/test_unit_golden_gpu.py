@@ -185,6 +185,58 @@ def test_similarity_kernels_vs_reference(dev):
         close(sim, ref, rtol=1e-5, atol=1e-6)
 
 
+def test_transfer_and_similarity_backward_vs_autograd(dev):
+    """unit_transfer_predictions_bwd + unit_similarity_bwd (the gradient path of the fine-tune configurations whose box head
+    trains) against torch autograd through the same forward arithmetic the reference runs (roi_heads.py:245-336 'Sum' of
+    lingual + visual; fast_rcnn.py:504-528), on the reference's own S20 / D20 tensors: d/d(delta heads' outputs), d/d(similarity),
+    d/d(OICR logits)."""
+    o = ops()
+    K, tag = 20, "F20"
+    x = T(f"{tag}/x")
+    P = {k[len(f"{tag}/param/"):]: T(k) for k in GOLD.files if k.startswith(f"{tag}/param/")}
+    r = x.shape[0]
+    lin = lambda inp, nm: inp @ P[nm + ".weight"].t() + P[nm + ".bias"]
+    kp = (5 * K + 1 + 7) // 8 * 8
+    wkp = (2 * K + 3 * (K + 1) + 7) // 8 * 8
+    lin_sup = torch.zeros(r, kp)
+    lin_sup[:, :K + 1], lin_sup[:, K + 1:5 * K + 1] = lin(x, "cls_score_delta"), lin(x, "bbox_pred_delta")
+    oc0 = 2 * K
+    lin_w = torch.zeros(r, wkp)
+    for k in range(3):
+        lin_w[:, oc0 + k * (K + 1): oc0 + (k + 1) * (K + 1)] = lin(x, f"weak_detector_head.oicr_predictors.{k}")
+    g = torch.Generator().manual_seed(5)
+    dy = torch.zeros(r, kp)
+    dy[:, :5 * K + 1] = torch.randn(r, 5 * K + 1, generator=g) * 0.1
+    emb = T("glove_mean")[torch.tensor(VOC_COCO_INDEXER)]
+    lingual = emb[torch.tensor(VOC_NOVEL)] @ emb[torch.tensor(VOC_BASE)].t()
+    base_t, nov_t = torch.tensor(VOC_BASE), torch.tensor(VOC_NOVEL)
+    # ---- torch autograd reference
+    ls = lin_sup.clone().requires_grad_(True)
+    lw = lin_w.clone().requires_grad_(True)
+    probs = torch.stack([lw[:, oc0 + k * (K + 1): oc0 + (k + 1) * (K + 1)] for k in range(3)], 0).mean(0)
+    vis = torch.softmax(probs, -1).index_select(1, base_t)
+    vis = vis / vis.sum(-1, keepdim=True).clamp(min=1e-9)
+    vis = torch.where(vis < 0.02, torch.zeros_like(vis), vis)
+    sim = (0.5 * torch.softmax(lingual, -1)).unsqueeze(0) + 0.5 * vis.unsqueeze(1)
+    sim = sim / sim.sum(-1, keepdim=True).clamp(min=1e-9)
+    sim.retain_grad()
+    sc = ls[:, :K + 1]
+    sc = sc + torch.zeros_like(sc).index_copy(1, nov_t, torch.bmm(sim, sc.index_select(1, base_t).unsqueeze(2)).squeeze(2))
+    bb = ls[:, K + 1:5 * K + 1].reshape(r, K, 4)
+    bbt = torch.zeros_like(bb).index_copy(1, nov_t, torch.bmm(sim, bb.index_select(1, base_t))).index_copy(1, base_t, bb.index_select(1, base_t))
+    loss = (sc * dy[:, :K + 1]).sum() + (bbt.reshape(r, 4 * K) * dy[:, K + 1:5 * K + 1]).sum()
+    loss.backward()
+    # ---- HIP
+    t = roles(K, VOC_BASE, VOC_NOVEL, dev)
+    sim_d = sim.detach().to(dev).contiguous()
+    dlin, dsim = o.transfer_predictions_bwd(dy.to(dev), 0, K + 1, lin_sup.to(dev), 0, K + 1, K, sim_d, sim_d, t, kp)
+    close(dsim, sim.grad, rtol=1e-4, atol=1e-6)
+    close(dlin.cpu()[:, :5 * K + 1], ls.grad[:, :5 * K + 1], rtol=1e-4, atol=1e-6)
+    dlw = o.similarity_bwd(lin_w.to(dev), oc0, 3, K + 1, t["base"], lingual.to(dev).contiguous(), len(VOC_NOVEL), 0.02, True, True, dsim, torch.float32)
+    close(dlw, lw.grad, rtol=1e-3, atol=1e-7)
+    assert float(lw.grad.abs().max()) > 1e-6
+
+
 def test_rpn_loss_kernel_vs_reference(dev):
     """unit_rpn_loss on the (h,w,a)-ordered head tensor against WSRPN.losses (rpn.py:55-101) and WSRPN.forward's flattening."""
     o = ops()
@@ -263,7 +315,7 @@ def _hip_step(name, dev):
     return cfg, model, step, dict(zip(LOSS_NAMES, step.losses.cpu().tolist()))
 
 
-@pytest.mark.parametrize("name", ["s1", "s1_single", "s2", "mask", "coco_mask"])
+@pytest.mark.parametrize("name", ["s1", "s1_single", "s2", "mask", "coco_mask", "mask_ft"])
 def test_hip_step_vs_reference_orchestration(dev, name):
     """The HIP training step (fp32 mode, production multi-stream schedule) against the losses, index decisions and gradients
     the REFERENCE's WeaklySupervisedRCNNNoMeta.forward produced on the same tiny inputs (K = 20 and K = 80; single / double

@@ -148,6 +148,173 @@ extern "C" int unit_transfer_predictions(const float* lin, int ld, int ccol0, in
   return UNIT_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Backward of the transfer (fine-tune configurations whose box head trains: COCO-RCNN-50-C4-split1-segm-ft.yaml). The reference
+// computes the similarity WITHOUT no_grad in training (roi_heads.py:852 -> :245-336), so d(loss) flows
+//   scores / bbox -> [delta heads' outputs (frozen weights, but their input is the trainable box head's feature), similarity]
+//   dlin_cls[r,c]    = dsc[r,c] + [c base] sum_j sim_cls[r,j,slot c] dsc[r,novel_j]
+//   dlin_bbox[r,c,:] = [c base] (dbb[r,c,:] + sum_j sim_bbox[r,j,slot c] dbb[r,novel_j,:])       (novel / other rows of the delta
+//                      head are overwritten by the transfer: no gradient)
+//   dsim[r,j,b]      = dsc[r,novel_j] lin_cls[r,base_b] + sum_k dbb[r,novel_j,k] lin_bbox[r,base_b,k]   (cls and bbox use the
+//                      same matrix when their term lists are equal; `dsim` is WRITTEN here, the mask head adds to it afterwards)
+// dy = d(loss)/d[scores | bbox] in the ft heads' column layout (dccol0 / dbcol0); dlin has the delta heads' layout.
+// ---------------------------------------------------------------------------------------------------
+template <typename TD>
+__global__ void transfer_bwd_kernel(const TD* __restrict__ dy, int ldd, int dccol0, int dbcol0, const float* __restrict__ lin, int ld,
+                                    int ccol0, int bcol0, int K, const float* __restrict__ sim_cls, const float* __restrict__ sim_bbox,
+                                    const int* __restrict__ base, int n_base, const int* __restrict__ novel, int n_novel,
+                                    const int8_t* __restrict__ role, const int* __restrict__ slot, TD* __restrict__ dlin, int ldl,
+                                    float* __restrict__ dsim, int R) {
+  int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  int ncls = K + 1;
+  int n1 = R * ncls, n2 = R * n_novel * n_base;
+  if (idx < n1) {
+    int r = idx / ncls, c = idx - r * ncls;
+    const TD* d = dy + (size_t)r * ldd;
+    float g = (float)d[dccol0 + c];
+    float gb[4] = {0.f, 0.f, 0.f, 0.f};
+    if (c < K && role[c] == 1) {
+      int sb = slot[c];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) gb[k] = (float)d[dbcol0 + 4 * c + k];
+      for (int j = 0; j < n_novel; ++j) {
+        int cn = novel[j];
+        size_t so = ((size_t)r * n_novel + j) * n_base + sb;
+        g += sim_cls[so] * (float)d[dccol0 + cn];
+        float wb = sim_bbox[so];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) gb[k] += wb * (float)d[dbcol0 + 4 * cn + k];
+      }
+    }
+    TD* o = dlin + (size_t)r * ldl;
+    o[ccol0 + c] = (TD)g;
+    if (c < K) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) o[bcol0 + 4 * c + k] = (TD)gb[k];
+    }
+  } else if (idx < n1 + n2) {
+    int t = idx - n1;
+    int r = t / (n_novel * n_base); int rem = t - r * n_novel * n_base; int j = rem / n_base, b = rem - j * n_base;
+    const TD* d = dy + (size_t)r * ldd;
+    const float* x = lin + (size_t)r * ld;
+    int cn = novel[j], cb = base[b];
+    float v = (float)d[dccol0 + cn] * x[ccol0 + cb];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v += (float)d[dbcol0 + 4 * cn + k] * x[bcol0 + 4 * cb + k];
+    dsim[t] = v;
+  }
+}
+extern "C" int unit_transfer_predictions_bwd(const void* dy, int dy_dtype, int ldd, int dccol0, int dbcol0, const float* lin, int ld,
+                                             int ccol0, int bcol0, int K, const float* sim_cls, const float* sim_bbox, const int* base_dev,
+                                             int n_base, const int* novel_dev, int n_novel, const int8_t* role_dev, const int* slot_dev,
+                                             void* dlin, int ldl, float* dsim, int R, void* stream) {
+  if (R == 0) return UNIT_OK;
+  long n = (long)R * (K + 1) + (long)R * n_novel * n_base;
+  hipStream_t st = (hipStream_t)stream;
+  (void)hipMemsetAsync(dlin, 0, (size_t)R * ldl * (dy_dtype == UNIT_BF16 ? 2 : 4), st);
+  if (dy_dtype == UNIT_BF16)
+    transfer_bwd_kernel<bf16_t><<<cdiv(n, 256), 256, 0, st>>>((const bf16_t*)dy, ldd, dccol0, dbcol0, lin, ld, ccol0, bcol0, K, sim_cls, sim_bbox,
+                                                            base_dev, n_base, novel_dev, n_novel, role_dev, slot_dev, (bf16_t*)dlin, ldl, dsim, R);
+  else
+    transfer_bwd_kernel<float><<<cdiv(n, 256), 256, 0, st>>>((const float*)dy, ldd, dccol0, dbcol0, lin, ld, ccol0, bcol0, K, sim_cls, sim_bbox,
+                                                          base_dev, n_base, novel_dev, n_novel, role_dev, slot_dev, (float*)dlin, ldl, dsim, R);
+  UNIT_LAUNCH_CHECK();
+  return UNIT_OK;
+}
+
+// Backward of similarity_kernel: dsim [R][n_novel][n_base] -> d(mean OICR logits) -> the n_oicr logit groups of `dlin` (each gets
+// 1 / n_oicr of it; the predictors' weights are frozen in every fine-tune yaml, the gradient continues into their input).
+//   S = u / T, u[j,b] = w L[j,b] + w v_b, T_j = max(sum_b u, 1e-9);  v_b = v'_b (>= thr) | 0,  v' = q[base] / max(sum q[base], 1e-9),
+//   q = softmax(p).   (the in-place zeroing of roi_heads.py:257 passes no gradient to the zeroed entries)
+template <typename TD>
+__global__ void similarity_bwd_kernel(const float* __restrict__ lin, int ld, int col0, int n_oicr, int ncls, const int* __restrict__ base,
+                                      int n_base, const float* __restrict__ lingual, int n_novel, float thr, int use_lingual,
+                                      int use_visual, const float* __restrict__ dsim, TD* __restrict__ dlin, int ldl, int dcol0, int R) {
+  int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= R || !use_visual) return;
+  float vis[DET_MAXC], vraw[DET_MAXC], dv[DET_MAXC];
+  const float* x = lin + (size_t)r * ld + col0;
+  float mx = -INFINITY;
+  for (int c = 0; c < ncls; ++c) {
+    float s = 0.f;
+    for (int k = 0; k < n_oicr; ++k) s += x[k * ncls + c];
+    mx = fmaxf(mx, s / (float)n_oicr);
+  }
+  float se = 0.f;
+  for (int c = 0; c < ncls; ++c) {
+    float s = 0.f;
+    for (int k = 0; k < n_oicr; ++k) s += x[k * ncls + c];
+    se += expf(s / (float)n_oicr - mx);
+  }
+  float tot = 0.f;
+  for (int b = 0; b < n_base; ++b) {
+    int c = base[b];
+    float s = 0.f;
+    for (int k = 0; k < n_oicr; ++k) s += x[k * ncls + c];
+    vraw[b] = expf(s / (float)n_oicr - mx) / se;          // q[base_b]
+    tot += vraw[b];
+  }
+  float totc = fmaxf(tot, 1e-9f);
+  for (int b = 0; b < n_base; ++b) { float v = vraw[b] / totc; vis[b] = v < thr ? 0.f : v; dv[b] = 0.f; }
+  float nterms = (float)(use_lingual + use_visual);
+  float wgt = 1.0f / nterms;
+  for (int j = 0; j < n_novel; ++j) {
+    float lmx = -INFINITY, lse = 0.f;
+    if (use_lingual) {
+      for (int b = 0; b < n_base; ++b) lmx = fmaxf(lmx, lingual[j * n_base + b]);
+      for (int b = 0; b < n_base; ++b) lse += expf(lingual[j * n_base + b] - lmx);
+    }
+    float T = 0.f;
+    for (int b = 0; b < n_base; ++b) {
+      float u = use_lingual ? wgt * (expf(lingual[j * n_base + b] - lmx) / lse) : 0.f;
+      T += u + wgt * vis[b];
+    }
+    float Tc = fmaxf(T, 1e-9f);
+    const float* g = dsim + ((size_t)r * n_novel + j) * n_base;
+    float dot = 0.f;                                      // sum_b G[j,b] S[j,b]
+    if (T >= 1e-9f) {
+      for (int b = 0; b < n_base; ++b) {
+        float u = (use_lingual ? wgt * (expf(lingual[j * n_base + b] - lmx) / lse) : 0.f) + wgt * vis[b];
+        dot += g[b] * (u / Tc);
+      }
+    }
+    for (int b = 0; b < n_base; ++b) dv[b] += wgt * (g[b] - dot) / Tc;       // d u[j,b] = (G - sum G S) / T  (T clamped: dot = 0)
+  }
+  // v_b = v'_b (kept) -> v'_b = w_b / tot
+  float dot2 = 0.f;
+  for (int b = 0; b < n_base; ++b) { if (vis[b] == 0.f) dv[b] = 0.f; }
+  if (tot >= 1e-9f) for (int b = 0; b < n_base; ++b) dot2 += dv[b] * (vraw[b] / totc);
+  // dq[c] for base columns, then dp = q (dq - sum q dq)
+  float sq = 0.f;
+  for (int b = 0; b < n_base; ++b) { dv[b] = (dv[b] - dot2) / totc; sq += vraw[b] * dv[b]; }     // dv now = dq[base_b]; sq = sum_c q_c dq_c
+  TD* o = dlin + (size_t)r * ldl + dcol0;
+  for (int c = 0; c < ncls; ++c) {
+    float s = 0.f;
+    for (int k = 0; k < n_oicr; ++k) s += x[k * ncls + c];
+    float q = expf(s / (float)n_oicr - mx) / se;
+    float dq = 0.f;
+    for (int b = 0; b < n_base; ++b) if (base[b] == c) dq = dv[b];
+    float dp = q * (dq - sq) / (float)n_oicr;
+    for (int k = 0; k < n_oicr; ++k) o[k * ncls + c] = (TD)dp;
+  }
+}
+extern "C" int unit_similarity_bwd(const float* lin_weak, int ld, int col0, int n_oicr, int ncls, const int* base_dev, int n_base,
+                                   const float* lingual, int n_novel, float visual_threshold, int use_lingual, int use_visual,
+                                   const float* dsim, void* dlin, int dlin_dtype, int ldl, int dcol0, int R, void* stream) {
+  UNIT_CHECK_ARG(n_base <= DET_MAXC, "similarity_bwd: more than 96 base classes");
+  if (R == 0) return UNIT_OK;
+  hipStream_t st = (hipStream_t)stream;
+  (void)hipMemsetAsync(dlin, 0, (size_t)R * ldl * (dlin_dtype == UNIT_BF16 ? 2 : 4), st);
+  if (dlin_dtype == UNIT_BF16)
+    similarity_bwd_kernel<bf16_t><<<cdiv(R, 64), 64, 0, st>>>(lin_weak, ld, col0, n_oicr, ncls, base_dev, n_base, lingual, n_novel, visual_threshold,
+                                                            use_lingual, use_visual, dsim, (bf16_t*)dlin, ldl, dcol0, R);
+  else
+    similarity_bwd_kernel<float><<<cdiv(R, 64), 64, 0, st>>>(lin_weak, ld, col0, n_oicr, ncls, base_dev, n_base, lingual, n_novel, visual_threshold,
+                                                           use_lingual, use_visual, dsim, (float*)dlin, ldl, dcol0, R);
+  UNIT_LAUNCH_CHECK();
+  return UNIT_OK;
+}
+
 // row softmax (predict_probs: F.softmax(scores, dim=-1))
 __global__ void softmax_rows_kernel(const float* __restrict__ x, int ld, int ncls, float* __restrict__ y, int ldy, int R) {
   int r = blockIdx.x * blockDim.x + threadIdx.x;

@@ -138,6 +138,97 @@ extern "C" int unit_mask_bce_loss(const float* logits, int K, int ldk, const int
   return UNIT_OK;
 }
 
+// MaskRCNNConvUpsampleHeadWithFineTune in TRAINING (mask_head.py:74-93 with similarity['seg'][fg], roi_heads.py:888-906):
+//   logit[s][c] = transfer(predictor)[c] + predictor_delta[c],  transfer = row[c] (c base) | sum_b sim[row_s][j][b] row[base_b] (c novel)
+// loss = mean BCE on the gt-class channel; emits d(loss)/d(logits) for BOTH column groups (the transferred gradient lands on the
+// base columns of `predictor`, whose weights are frozen but whose input is trainable) and ADDS d(loss)/d(sim) into
+// dsim[row_s][j][:] (each foreground RoI owns its row of dsim: plain adds, fixed order -> reproducible). One workgroup per fg slot.
+template <typename TD>
+__global__ void __launch_bounds__(256) mask_loss_ft_kernel(const float* __restrict__ logits, int K, int ldk, int delta_col0,
+                                                           const int* __restrict__ cls, const unsigned char* __restrict__ tgt,
+                                                           const float* __restrict__ sim, const int* __restrict__ rows,
+                                                           const int* __restrict__ base, int n_base, int n_novel,
+                                                           const int8_t* __restrict__ role, const int* __restrict__ slot, int S, int M,
+                                                           float gscale, float* __restrict__ loss, TD* __restrict__ dlogits,
+                                                           float* __restrict__ dsim) {
+  __shared__ float lds[8];
+  __shared__ float s_nfg;
+  int s = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  int P = M / 2, MM = M * M;
+  float cnt = 0.f;
+  for (int q = tid; q < S; q += 256) cnt += (cls[q] >= 0 && cls[q] < K) ? 1.f : 0.f;
+  cnt = wave_reduce_sum(cnt);
+  if (lane == 0) lds[wid] = cnt;
+  __syncthreads();
+  if (tid == 0) s_nfg = lds[0] + lds[1] + lds[2] + lds[3];
+  __syncthreads();
+  int c = cls[s];
+  if (c < 0 || c >= K) return;
+  float inv = 1.f / (s_nfg * (float)MM);
+  int rl = sim ? role[c] : 1;
+  const float* sm = (sim && rl == 2) ? sim + ((size_t)rows[s] * n_novel + slot[c]) * n_base : nullptr;
+  int i = tid;
+  bool act = i < MM;
+  float g = 0.f, acc = 0.f;
+  const float* row = nullptr;
+  size_t ro = 0;
+  if (act) {
+    int Y = i / M, X = i - Y * M;
+    ro = ((((size_t)s * P + (Y >> 1)) * P + (X >> 1)) * 4 + ((Y & 1) * 2 + (X & 1))) * ldk;
+    row = logits + ro;
+    float x;
+    if (sm) { x = 0.f; for (int b = 0; b < n_base; ++b) x += sm[b] * row[base[b]]; }
+    else x = (rl == 0) ? 0.f : row[c];
+    if (delta_col0 >= 0) x = x + row[delta_col0 + c];
+    float y = (float)tgt[(size_t)s * MM + i];
+    acc = fmaxf(x, 0.f) - x * y + log1pf(expf(-fabsf(x)));
+    g = (1.f / (1.f + expf(-x)) - y) * inv * gscale;
+    if (dlogits) {
+      TD* d = dlogits + ro;
+      if (delta_col0 >= 0) d[delta_col0 + c] = (TD)g;
+      if (sm) { for (int b = 0; b < n_base; ++b) d[base[b]] = (TD)(sm[b] * g); }
+      else if (rl != 0) d[c] = (TD)g;
+    }
+  }
+  // loss
+  acc = wave_reduce_sum(acc);
+  __syncthreads();
+  if (lane == 0) lds[wid] = acc;
+  __syncthreads();
+  if (tid == 0) atomicAdd(loss, (lds[0] + lds[1] + lds[2] + lds[3]) * inv);
+  // d sim[row_s][j][b] += sum_pixels g * row[base_b]
+  if (sm && dsim) {
+    float* ds = dsim + ((size_t)rows[s] * n_novel + slot[c]) * n_base;
+    for (int b = 0; b < n_base; ++b) {
+      float v = act ? g * row[base[b]] : 0.f;
+      v = wave_reduce_sum(v);
+      __syncthreads();
+      if (lane == 0) lds[wid] = v;
+      __syncthreads();
+      if (tid == 0) ds[b] += lds[0] + lds[1] + lds[2] + lds[3];
+    }
+  }
+}
+extern "C" int unit_mask_bce_loss_ft(const float* logits, int K, int ldk, int delta_col0, const int* cls, const unsigned char* targets,
+                                     const float* sim, const int* sim_rows, const int* base_dev, int n_base, int n_novel,
+                                     const int8_t* role_dev, const int* slot_dev, int S, int M, float gscale, float* loss, void* dlogits,
+                                     int d_dtype, float* dsim, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  (void)hipMemsetAsync(loss, 0, sizeof(float), st);
+  if (S == 0) return UNIT_OK;
+  UNIT_CHECK_ARG(M * M <= 256, "mask_bce_loss_ft: mask side > 16");
+  size_t esz = d_dtype == UNIT_BF16 ? 2 : 4;
+  if (dlogits) (void)hipMemsetAsync(dlogits, 0, (size_t)S * M * M * ldk * esz, st);
+  if (d_dtype == UNIT_BF16)
+    mask_loss_ft_kernel<bf16_t><<<S, 256, 0, st>>>(logits, K, ldk, delta_col0, cls, targets, sim, sim_rows, base_dev, n_base, n_novel, role_dev,
+                                                 slot_dev, S, M, gscale, loss, (bf16_t*)dlogits, dsim);
+  else
+    mask_loss_ft_kernel<float><<<S, 256, 0, st>>>(logits, K, ldk, delta_col0, cls, targets, sim, sim_rows, base_dev, n_base, n_novel, role_dev,
+                                                slot_dev, S, M, gscale, loss, (float*)dlogits, dsim);
+  UNIT_LAUNCH_CHECK();
+  return UNIT_OK;
+}
+
 // mask_rcnn_inference (+ the base->novel mask transfer of mask_head.py:18-31 for the predicted class):
 // prob[s][Y][X] = sigmoid(logit of pred class)  where for a novel class j: logit = sum_b sim[s][j][b] * logit[base_b];
 // delta_col0 >= 0: + logits[delta_col0 + c], the `predictor_delta` columns of MaskRCNNConvUpsampleHeadWithFineTune (mask_head.py:91)

@@ -35,8 +35,9 @@ def class_roles(model):
     return cache
 
 
-def similarity_dict(model, lin_weak_on_box):
-    """WSROIHead.get_similarity_matrices roi_heads.py:245-336 ('Sum' combination of 'lingual' / 'visual' terms) -> {head: [R,n,b]}"""
+def similarity_dict(model, lin_weak_on_box, want_ctx=False):
+    """WSROIHead.get_similarity_matrices roi_heads.py:245-336 ('Sum' combination of 'lingual' / 'visual' terms) -> {head: [R,n,b]}
+    (want_ctx: also the lingual matrix and the (use_lingual, use_visual) key of every head, for the backward)"""
     rh = _rh(model)
     bp = rh.box_predictor
     t = class_roles(rh)
@@ -49,6 +50,8 @@ def similarity_dict(model, lin_weak_on_box):
             sims[key] = ops.similarity(lin_weak_on_box, wh.col_oicr[0], wh.oicr_iter, rh.num_classes + 1, t["base"], lingual,
                                        t["novel"].numel(), rh.visual_threshold, key[0], key[1])
         out[head] = sims[key]
+    if want_ctx:
+        return out, lingual, {h: ("lingual" in tm, "visual" in tm) for h, tm in rh.terms.items()}
     return out
 
 

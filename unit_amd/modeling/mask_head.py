@@ -99,12 +99,22 @@ class MaskRCNNConvUpsampleHeadWithSimilarity(nn.Module):
         return y1, lg
 
     # ---- training: mask_rcnn_loss (mean BCE on the gt-class channel over all fg RoIs) + gradient w.r.t. the logits
-    def fwd_train(self, x, cls, targets, loss_out, grad_dtype):
+    def fwd_train(self, x, cls, targets, loss_out, grad_dtype, sim=None, sim_rows=None, roles=None, dsim=None):
+        """sim [R,n,b] + sim_rows int32 [S] (RoI row of every fg slot) + roles: the fine-tune configuration's training-time
+        transfer (roi_heads.py:888-906 -> mask_head.py:74-93); dsim [R,n,b] fp32 receives d(loss)/d(sim) of the fg rows (added)."""
         y1, lg = self.logits(x)
         s = x.shape[0]
         dlg = torch.empty((s * 196, self.pred.kp), dtype=grad_dtype, device=x.device)
-        check(lib().unit_mask_bce_loss(ops._p(lg), self.num_classes, self.pred.kp, ops._p(cls), ops._p(targets), s, self.mask_size, 1.0,
-                                       ops._p(loss_out), ops._p(dlg), ops.dt(grad_dtype), ops._s()), "mask_bce_loss")
+        if sim is None and not self.finetune:
+            check(lib().unit_mask_bce_loss(ops._p(lg), self.num_classes, self.pred.kp, ops._p(cls), ops._p(targets), s, self.mask_size, 1.0,
+                                           ops._p(loss_out), ops._p(dlg), ops.dt(grad_dtype), ops._s()), "mask_bce_loss")
+        else:
+            t = roles or {}
+            check(lib().unit_mask_bce_loss_ft(ops._p(lg), self.num_classes, self.pred.kp, self.delta_col0, ops._p(cls), ops._p(targets),
+                                              ops._p(sim), ops._p(sim_rows), ops._p(t.get("base")), t["base"].numel() if sim is not None else 0,
+                                              t["novel"].numel() if sim is not None else 0, ops._p(t.get("role")), ops._p(t.get("slot")), s,
+                                              self.mask_size, 1.0, ops._p(loss_out), ops._p(dlg), ops.dt(grad_dtype), ops._p(dsim), ops._s()),
+                  "mask_bce_loss_ft")
         return (x, y1, dlg)
 
     def bwd(self, ctx, need_dx=True):
@@ -114,7 +124,8 @@ class MaskRCNNConvUpsampleHeadWithSimilarity(nn.Module):
         s = x.shape[0]
         y1_2d = y1.view(s * 196, self.deconv.cout)
         dy1 = self.pred.bwd(y1_2d, dlg, need_dx=True, mask_ref=y1_2d).view(s, 7, 7, 4 * self.deconv.cout)
-        self.deconv.wgrad(x, dy1)
+        if self.deconv.weight.requires_grad:        # FREEZE_LAYERS.MASK_HEAD of the fine-tune yaml freezes deconv / predictor
+            self.deconv.wgrad(x, dy1)
         return dy1
 
     # ---- inference: mask_rcnn_inference (+ base->novel transfer of mask_head.py:18-31 for the predicted class)

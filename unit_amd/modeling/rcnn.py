@@ -112,7 +112,14 @@ class WeaklySupervisedRCNNNoMeta(nn.Module):
 
         mh = getattr(rh, "mask_head", None)
         if mh is not None:
-            fused("mask_head", "roi_heads.mask_head", [("predictor", mh.predictor)])
+            members = [("predictor", mh.predictor)] + ([("predictor_delta", mh.predictor_delta)] if getattr(mh, "finetune", False) else [])
+            if all(m.weight.requires_grad for _, m in members):
+                fused("mask_head", "roi_heads.mask_head", members)
+            else:       # fine-tune yaml: `predictor` frozen, `predictor_delta` trains (FREEZE_LAYERS.MASK_HEAD) -> plain slots
+                for n, m in members:
+                    if m.weight.requires_grad:
+                        groups.append(("mask_head", [(f"roi_heads.mask_head.{n}.weight", m.weight, True),
+                                                     (f"roi_heads.mask_head.{n}.bias", m.bias, True)], 0))
             if mh.deconv.weight.requires_grad:
                 groups.append(("mask_head", [("roi_heads.mask_head.deconv.weight", mh.deconv.weight, True),
                                              ("roi_heads.mask_head.deconv.bias", mh.deconv.bias, True)], 0))
@@ -405,8 +412,10 @@ class WeaklySupervisedRCNNNoMeta(nn.Module):
         # a16 mask head (roi_heads.py:691-710): un-pooled res5 map of the foreground RoIs -> deconv -> 1x1 -> mask BCE.
         # The sampler emits [fg..., bg...] per image, so the fg RoIs of image i are the first n_fg_i <= 128 slots of its block.
         c.mask_ctx = None
+        c.dsim_mask = None
         mh = getattr(rh, "mask_head", None)
-        if mh is not None and rs > 0 and batch.gt_masks is not None:
+
+        def run_mask(sim=None, roles=None):
             from .mask_head import gather_match_index, mask_targets
             fgc = rh.max_fg_per_image
             ymap = c.box_ctx[1]
@@ -417,7 +426,16 @@ class WeaklySupervisedRCNNNoMeta(nn.Module):
             cls_fg = torch.cat([c.roi_cls[sl] for sl in sel], 0)
             rois_fg = torch.cat([c.rois[sl] for sl in sel], 0)
             tgt = mask_targets(batch.gt_masks, rois_fg, torch.cat([gidx[sl] for sl in sel], 0), cls_fg, rh.num_classes, mh.mask_size)
-            c.mask_ctx = (mh.fwd_train(x_fg, cls_fg, tgt, c.losses[8:9], dt), sel)
+            kw = {}
+            if sim is not None:      # similarity['seg'][fg] (roi_heads.py:893-897): fg slot -> its RoI row
+                rows = torch.cat([torch.arange(sl.start, sl.stop, dtype=torch.int32) for sl in sel]).to(self.device, non_blocking=True)
+                c.dsim_mask = torch.zeros(sim.shape, dtype=torch.float32, device=self.device)
+                kw = dict(sim=sim, sim_rows=rows, roles=roles, dsim=c.dsim_mask)
+            c.mask_ctx = (mh.fwd_train(x_fg, cls_fg, tgt, c.losses[8:9], dt, **kw), sel)
+
+        mask_now = mh is not None and rs > 0 and batch.gt_masks is not None
+        if mask_now and not rh.finetune:
+            run_mask()
 
         # a10-a12 predictors + losses (+ gradients w.r.t. the Linear outputs)
         lin_weak_all = bp.weak_detector_head.group.fwd(wfeat_all)            # [rs+rw, 104] (oicr cols feed the sup scores)
@@ -426,19 +444,22 @@ class WeaklySupervisedRCNNNoMeta(nn.Module):
         if rs > 0:
             lin_sup = bp.group.fwd(c.box_feat)
             if getattr(bp, "finetune", False):
-                # a14 (roi_heads.py:595-644 + fast_rcnn.py:484-533): similarity transfer is active in TRAINING too
-                from .inference import class_roles, similarity_matrices
+                # a14 (roi_heads.py:595-644 / :826-870 + fast_rcnn.py:484-533): similarity transfer is active in TRAINING too
+                from .inference import class_roles, similarity_dict
                 frozen = not any(p.requires_grad for n, p in bp.named_parameters() if not n.split(".")[0].endswith("_ft"))
-                assert frozen and not box_trainable, "fine-tune step: everything but cls_score_ft / bbox_pred_ft must be frozen " \
-                                                     "(configs/VOC/FT/*/...-ft.yaml FREEZE_LAYERS)"
+                assert frozen, "fine-tune step: the delta / weak predictors must be frozen (FREEZE_LAYERS.FAST_RCNN of every *-ft.yaml)"
                 wh = bp.weak_detector_head
                 lin_ft = bp.group_ft.fwd(c.box_feat)
-                sim_cls, sim_bbox = similarity_matrices(self, wh.group.fwd(c.box_feat))
+                c.lin_w_box = wh.group.fwd(c.box_feat)
+                sims, lingual, keys = similarity_dict(self, c.lin_w_box, want_ctx=True)
                 t = class_roles(self)
                 c.scores, bbox = ops.transfer_predictions(lin_sup, bp.col_cls, bp.col_bbox, rh.num_classes, lin_weak_all[:rs], wh.col_oicr[0],
-                                                          wh.oicr_iter, sim_cls, sim_bbox, t["base"], t["novel"], t["role"], t["slot"],
+                                                          wh.oicr_iter, sims["cls"], sims["bbox"], t["base"], t["novel"], t["role"], t["slot"],
                                                           ft=lin_ft, fccol0=bp.col_cls, fbcol0=bp.col_bbox)
                 c.dy_sup = bp.ft_losses(c.scores, bbox, c.roi_cls, c.rois[:rs], c.roi_gt, c.losses[0:2], dt)
+                c.ft_ctx = (lin_sup, sims, lingual, keys, t)
+                if mask_now and rh.finetune:        # WSROIHeadWithMaskFineTune hands similarity['seg'][fg] to the mask head
+                    run_mask(sims.get("seg"), t)
             else:
                 # the supervised losses (5 small launches) do not depend on the weak chain: they run on the head stream beside it
                 sup_side = self._head_stream if (rw > 0 and self._streams_on()) else None
@@ -492,7 +513,23 @@ class WeaklySupervisedRCNNNoMeta(nn.Module):
 
         dbox = dweak = None
         if c.dy_sup is not None and getattr(bp, "finetune", False):
-            bp.group_ft.bwd(c.box_feat, c.dy_sup, need_dx=False)      # the only trainable tensors of the fine-tune step
+            # VOC fine-tune yaml: everything below the ft heads is frozen -> their weight gradients are all there is.
+            # COCO segm fine-tune yaml: the box head (and RPN) train -> the gradient continues through the ft heads, the frozen
+            # delta heads incl. the base->novel transfer, and the similarity (computed WITH grad in the reference, roi_heads.py:852)
+            # into the box head's features.
+            dbox = bp.group_ft.bwd(c.box_feat, c.dy_sup, need_dx=box_trainable)
+            if box_trainable:
+                lin_sup, sims, lingual, keys, t = c.ft_ctx
+                assert len(set(keys.values())) == 1, "fine-tune backward: one similarity matrix for all heads (equal FINETUNE_TERMS)"
+                ul, uv = next(iter(keys.values()))
+                wh = bp.weak_detector_head
+                dlin, dsim = ops.transfer_predictions_bwd(c.dy_sup, bp.col_cls, bp.col_bbox, lin_sup, bp.col_cls, bp.col_bbox, rh.num_classes,
+                                                          sims["cls"], sims["bbox"], t, bp.group.kp)
+                if c.dsim_mask is not None:
+                    dsim += c.dsim_mask
+                dlin_w = ops.similarity_bwd(c.lin_w_box, wh.col_oicr[0], wh.oicr_iter, rh.num_classes + 1, t["base"], lingual,
+                                            t["novel"].numel(), rh.visual_threshold, ul, uv, dsim, dt)
+                dbox = dbox + bp.group.bwd(c.box_feat, dlin, need_dx=True) + wh.group.bwd(c.box_feat, dlin_w, need_dx=True)
         elif c.dy_sup is not None:
             dbox = bp.group.bwd(c.box_feat, c.dy_sup, need_dx=box_trainable or bb_trainable)
         if c.dy_weak is not None:

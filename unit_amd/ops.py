@@ -623,6 +623,27 @@ def transfer_predictions(lin, ccol0, bcol0, k, weak, wcol0, n_oicr, sim_cls, sim
     return scores, bbox
 
 
+def transfer_predictions_bwd(dy, dccol0, dbcol0, lin, ccol0, bcol0, k, sim_cls, sim_bbox, t, ldl):
+    """backward of transfer_predictions w.r.t. the delta heads' outputs and the similarity -> (dlin [R, ldl] in dy's dtype, dsim fp32)"""
+    r = lin.shape[0]
+    dlin = torch.empty((r, ldl), dtype=dy.dtype, device=lin.device)
+    dsim = torch.empty(sim_cls.shape, dtype=torch.float32, device=lin.device)
+    check(lib().unit_transfer_predictions_bwd(_p(dy), dt(dy.dtype), dy.shape[1], dccol0, dbcol0, _p(lin), lin.shape[1], ccol0, bcol0, k,
+                                              _p(sim_cls), _p(sim_bbox), _p(t["base"]), t["base"].numel(), _p(t["novel"]), t["novel"].numel(),
+                                              _p(t["role"]), _p(t["slot"]), _p(dlin), ldl, _p(dsim), r, _s()), "transfer_predictions_bwd")
+    return dlin, dsim
+
+
+def similarity_bwd(lin_weak, col0, n_oicr, ncls, base_dev, lingual, n_novel, visual_threshold, use_lingual, use_visual, dsim, grad_dtype):
+    """backward of `similarity` -> d(loss)/d(lin_weak) [R, ld] (only the OICR logit columns are non-zero)"""
+    r, ld = lin_weak.shape
+    dlin = torch.empty((r, ld), dtype=grad_dtype, device=lin_weak.device)
+    check(lib().unit_similarity_bwd(_p(lin_weak), ld, col0, n_oicr, ncls, _p(base_dev), base_dev.numel(), _p(lingual), n_novel,
+                                    float(visual_threshold), int(use_lingual), int(use_visual), _p(dsim), _p(dlin), dt(grad_dtype), ld, col0, r,
+                                    _s()), "similarity_bwd")
+    return dlin
+
+
 def softmax_rows(x, ncls):
     y = torch.empty((x.shape[0], ncls), dtype=torch.float32, device=x.device)
     check(lib().unit_softmax_rows(_p(x), x.shape[1], ncls, _p(y), ncls, x.shape[0], _s()), "softmax_rows")
