@@ -1,0 +1,52 @@
+"""One rank of the 2-rank data-parallel rehearsal (tests/test_dp_gpu.py starts two of these as fresh child processes; both
+share cuda:0 and talk gloo through 127.0.0.1 -- the RCCL run differs only in the backend name).
+usage: python tests/dp_rehearsal_worker.py <rank> <world> <port> <out.pt> [bf16_buckets]"""
+import os
+import sys
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def rehearsal_cfg():
+    from unit_amd import config
+    cfg = config.voc_rcnn_c4_split1(50)
+    cfg.MODEL.DEVICE = "cuda"
+    cfg.MODEL.ROI_HEADS.BATCH_SIZE_PER_IMAGE = 32
+    cfg.MODEL.RPN.PRE_NMS_TOPK_TRAIN, cfg.MODEL.RPN.POST_NMS_TOPK_TRAIN = 600, 100
+    cfg.SEED = 11
+    return cfg
+
+
+def global_batch():
+    from unit_amd.synthetic import synthetic_batch
+    return synthetic_batch(4, 4, hw=(128, 192), seed=5, max_gt=4)
+
+
+def main():
+    rank, world, port, out = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], sys.argv[4]
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", port
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from unit_amd import engine
+    from unit_amd.modeling import build_model
+    from unit_amd.synthetic import init_synthetic_weights
+    cfg = rehearsal_cfg()
+    model = build_model(cfg)
+    init_synthetic_weights(model, seed=1 + rank)          # ranks start DIFFERENT: the initial broadcast must equalise them
+    model.train()
+    model.compute_dtype = torch.float32
+    tr = engine.TrainerNoMeta(cfg, model, bf16_buckets=(len(sys.argv) > 5 and sys.argv[5] == "bf16_buckets"))
+    sup, weak = global_batch()
+    losses = tr.run_step(engine.shard_batch(sup, rank, world), engine.shard_batch(weak, rank, world))
+    torch.cuda.synchronize()
+    torch.save({"params": model.store.params.cpu(), "losses": losses.cpu()}, out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

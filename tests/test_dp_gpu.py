@@ -1,0 +1,81 @@
+"""Data parallelism rehearsed on ONE MI355X: two ranks started as fresh child processes (never re-exec'ed from a process that
+has touched the GPU), both on cuda:0, gloo over 127.0.0.1. After one TrainerNoMeta.run_step both ranks hold identical
+parameters, equal to what ONE process gets from the sum of the two shards' gradients scaled by 1/2 (all-reduce SUM, 1/world in the
+SGD kernel: engine/defaults.py:256,285 + data/build.py:354-355 semantics) starting from rank 0's weights (initial broadcast)."""
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _run_ranks(tmp_path, extra=()):
+    port = str(_free_port())
+    outs = [str(tmp_path / f"rank{r}.pt") for r in range(2)]
+    procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "dp_rehearsal_worker.py"), str(r), "2", port, outs[r], *extra],
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(2)]
+    logs = [p.communicate(timeout=600)[0].decode(errors="replace") for p in procs]
+    for r, p in enumerate(procs):
+        assert p.returncode == 0, f"rank {r}:\n{logs[r][-3000:]}"
+    return [torch.load(o) for o in outs]
+
+
+def _single_process_reference(dev):
+    """rank 0's initial weights; gradients of shard 0 and shard 1 computed one after the other with the ranks' RNG streams
+    (SEED + rank); SUM, then the SGD kernel with grad_scale 1/2."""
+    import dp_rehearsal_worker as W
+    from unit_amd import engine
+    from unit_amd.modeling import build_model
+    from unit_amd.solver import FlatSGD
+    from unit_amd.synthetic import init_synthetic_weights
+    cfg = W.rehearsal_cfg()
+    model = build_model(cfg)
+    init_synthetic_weights(model, seed=1)
+    model.train()
+    model.compute_dtype = torch.float32
+    sup, weak = W.global_batch()
+    total = None
+    for r in range(2):
+        model._gen = (cfg.SEED + r, torch.zeros(1, dtype=torch.int64, device=dev))
+        batch = model.pack_batch(engine.shard_batch(sup, r, 2), engine.shard_batch(weak, r, 2))
+        step = model.forward_train(batch, early_backward=True)
+        model.backward_train(step)
+        torch.cuda.synchronize()
+        total = model.store.grads.clone() if total is None else total + model.store.grads
+    model.store.grads.copy_(total)
+    opt = FlatSGD(model, cfg, grad_scale=0.5)
+    opt.step()
+    torch.cuda.synchronize()
+    return model.store.params.cpu()
+
+
+def test_two_ranks_equal_single_process_on_summed_gradients(dev, tmp_path):
+    a, b = _run_ranks(tmp_path)
+    assert torch.equal(a["params"], b["params"]), "ranks diverged"
+    assert not torch.equal(a["losses"], b["losses"])            # different shards
+    ref = _single_process_reference(dev)
+    assert torch.allclose(a["params"], ref, rtol=1e-6, atol=1e-8), (a["params"] - ref).abs().max()
+
+
+def test_two_ranks_bf16_gradient_buckets(dev, tmp_path):
+    """bf16-compressed buckets (half the all-reduce bytes): the ranks still agree bit for bit, and the update stays within bf16
+    rounding of the fp32-bucket result (relative 2^-8 on each summed gradient, times lr)."""
+    a, b = _run_ranks(tmp_path, extra=("bf16_buckets",))
+    assert torch.equal(a["params"], b["params"])
+    ref = _single_process_reference(dev)
+    upd = (a["params"] - ref).abs().max().item()
+    assert upd <= 1e-4, upd

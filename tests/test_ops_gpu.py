@@ -228,6 +228,51 @@ def test_wgrad_ring128_kernel(dev, case):
     assert (got - ref).abs().max() <= 2e-3 * ref.abs().max()
 
 
+@pytest.mark.parametrize("case,tile", [((1024, 7, 7, 512, 512, 3, 1, 1), 16), ((1024, 7, 7, 512, 2048, 1, 1, 0), 16), ((1024, 7, 7, 2048, 512, 1, 1, 0), 16),
+                                       ((1024, 14, 14, 1024, 512, 1, 2, 0), 16), ((4, 38, 63, 1024, 1024, 3, 1, 1), 16),
+                                       ((4, 38, 63, 1024, 256, 1, 1, 0), 0), ((4, 38, 63, 256, 256, 3, 1, 1), 0), ((4, 38, 63, 256, 1024, 1, 1, 0), 0),
+                                       ((4, 75, 125, 128, 128, 3, 1, 1), 0), ((4, 75, 125, 128, 512, 1, 1, 0), 0)])
+def test_conv_hot_shapes_fp32_output_tight(dev, case, tile):
+    """the REAL hot shapes (Res5 on 1024 RoIs: M = 50 176; RPN / res4 / res3 on four 600x1000 images) through the kernels the
+    step uses (tile 16 = conv_igemm256_p8, 0 = the policy's LDS-DMA 4-wave kernel): bf16 operands, fp32 accumulation AND fp32
+    output, so the only difference to F.conv2d on the same bf16-rounded operands (fp32 math) is the summation order: 2e-4 relative
+    to the output scale. Checked on a random sample of output pixels (the full fp32 reference of M = 50 176 x K = 4608 costs seconds)."""
+    o = ops()
+    n, h, w, c, k, r, stride, pad = case
+    gen = g(91)
+    x = torch.randn(n, h, w, c, generator=gen).bfloat16()
+    wt = (torch.randn(k, r, r, c, generator=gen) / np.sqrt(c * r * r)).bfloat16()
+    y = o.conv2d(x.to(dev), wt.to(dev), k, r, r, stride, pad, out_dtype=torch.float32, tile_cfg=tile).cpu()
+    oh, ow = y.shape[1], y.shape[2]
+    idx = torch.randint(0, n, (24,), generator=gen).unique()
+    ref = F.conv2d(x[idx].float().permute(0, 3, 1, 2), wt.float().permute(0, 3, 1, 2), None, stride=stride, padding=pad).permute(0, 2, 3, 1)
+    got = y[idx][..., :k]
+    assert got.shape == ref.shape == (len(idx), oh, ow, k)
+    scale = ref.abs().max().item()
+    assert (got - ref).abs().max().item() <= 2e-4 * scale, ((got - ref).abs().max().item(), scale)
+
+
+@pytest.mark.parametrize("case", [(1024, 7, 7, 512, 512, 3, 1, 1), (1024, 7, 7, 512, 2048, 1, 1, 0), (4, 38, 63, 1024, 1024, 3, 1, 1),
+                                  (4, 38, 63, 256, 256, 3, 1, 1), (4, 38, 63, 1024, 256, 1, 1, 0)])
+def test_wgrad_hot_shapes_tight(dev, case):
+    """weight gradients of the hot shapes (conv_wgrad256_p8 / ring kernels, split-M slabs): fp32 output vs the fp64 contraction of
+    the same bf16-rounded operands on a random sample of output filters, 2e-4 of the gradient's scale."""
+    o = ops()
+    n, h, w, c, k, r, stride, pad = case
+    gen = g(92)
+    x = torch.randn(n, h, w, c, generator=gen).bfloat16()
+    oh, ow = o.conv_out_size(h, w, r, r, stride, pad)
+    dy = (torch.randn(n, oh, ow, k, generator=gen) * 0.1).bfloat16()
+    dw = o.conv2d_wgrad(x.to(dev), dy.to(dev), k, r, r, stride, pad).cpu()              # [K, R, S, C] fp32
+    ks = torch.randint(0, k, (6,), generator=gen).unique()
+    xd = F.unfold(x.double().permute(0, 3, 1, 2), r, padding=pad, stride=stride)          # [n, c*r*r, oh*ow]
+    xd = xd.view(n, c, r * r, oh * ow)
+    ref = torch.einsum("ncpl,nlk->kpc", xd, dy.double().view(n, oh * ow, k)[:, :, ks]).view(len(ks), r, r, c)
+    got = dw[ks].double()
+    scale = ref.abs().max().item()
+    assert (got - ref).abs().max().item() <= 2e-4 * scale, ((got - ref).abs().max().item(), scale)
+
+
 def test_wgrad_big_m(dev):
     """M spans many split-M chunks and is not a multiple of the staging step."""
     o = ops()

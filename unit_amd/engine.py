@@ -47,10 +47,10 @@ class EarlyUpdate:
 
 
 class TrainerNoMeta:
-    def __init__(self, cfg, model, data_iter=None, weak_data_iter=None, group=None, early_update=False):
+    def __init__(self, cfg, model, data_iter=None, weak_data_iter=None, group=None, early_update=False, bf16_buckets=False):
         self.cfg, self.model = cfg, model
         self.data_iter, self.weak_data_iter = data_iter, weak_data_iter
-        self.buckets = GradBuckets(model, group)
+        self.buckets = GradBuckets(model, group, bf16=bf16_buckets)
         self.buckets.broadcast_parameters()
         self.optimizer = FlatSGD(model, cfg, grad_scale=self.buckets.grad_scale)
         self.iter = 0

@@ -12,9 +12,26 @@ No per-step barrier, no per-step metric gather."""
 import torch.distributed as dist
 
 
+class _Widen:
+    """work handle of a bf16 bucket: after the collective, the reduced bf16 values are widened into the fp32 gradient slice
+    (on the waiting stream, ordered behind the collective by `wait()`); waiting twice is harmless"""
+
+    def __init__(self, work, buf, dst):
+        self.work, self.buf, self.dst = work, buf, dst
+
+    def wait(self):
+        if self.work is not None:
+            self.work.wait()
+            self.dst.copy_(self.buf)
+            self.work = None
+
+
 class GradBuckets:
-    def __init__(self, model, group=None, bucket_bytes=64 << 20):
-        self.model, self.group = model, group
+    def __init__(self, model, group=None, bucket_bytes=64 << 20, bf16=False):
+        """bf16: all-reduce a bf16 copy of every bucket (half the bytes over xGMI: 134 instead of 268 MB per step for R101 S1) and
+        widen the sum back into the fp32 gradient buffer; the ranks stay bit-identical (same reduced values everywhere), each
+        summed gradient carries a relative 2^-8 rounding. Off by default: one node's links move the fp32 buckets behind the backward."""
+        self.model, self.group, self.bf16 = model, group, bf16
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.bucket_elems = bucket_bytes // 4
         self._works = []
@@ -48,7 +65,13 @@ class GradBuckets:
             self._build()
         g = self.model.store.grads
         for a, b in self._plan.get(tag, []):
-            w = dist.all_reduce(g[a:b], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            if self.bf16:
+                from . import ops
+                import torch
+                buf = ops.cast(g[a:b], torch.bfloat16)
+                w = _Widen(dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True), buf, g[a:b])
+            else:
+                w = dist.all_reduce(g[a:b], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
             self._works.append(w)
             self._tag_works.setdefault(tag, []).append(w)
 
