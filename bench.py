@@ -24,6 +24,7 @@ sys.path.insert(0, ROOT)
 # algorithmic FLOPs per step per GPU, SURVEY.md section 8d (1 MAC = 2 FLOP; fwd + bwd of trainable convs)
 STEP_TFLOP = {("s1", 101): 12.70, ("s1", 50): 11.61, ("s0", 101): 5.69}
 MFMA_PEAK_TFLOPS = 2500.0   # dense bf16, MI355X_MICROARCH.md (never the 2:1-sparse figure)
+HBM_PEAK_GBS = 8000.0       # HBM3E spec, same guide (6.3 TB/s is what a float4 copy reaches)
 
 
 def parse():
@@ -82,9 +83,16 @@ def cpu_baseline(depth, variant):
                                 [x["instances"].gt_classes for x in weak] if weak else None, perms, ocfg)
     sum(losses.values()).backward()
     dt = time.time() - t0
+    # FLOP normalisation: the sample runs every conv of the step except that the three Res5 passes see a quarter of the
+    # RoIs -- R101 S1: 4 x 166.1 + 4 x 45.6 (+ backward 4 x 2 x 147.3 + 2 x 2 x 45.6) GFLOP in full, 7 x 1499 / 4 for the heads
+    full = STEP_TFLOP.get((variant, depth))
+    heads = {"s1": 7, "s0": 3}[variant] * 1.499
+    sample_tflop = round(full - heads * (1 - rois / 512.0), 2) if full else None
     return {"value": round(2.0 / dt, 4), "unit": "images/sec", "cores": cores, "kind": "port",
             "sample": f"oracle (PyTorch-CPU fp32 + C) S1 fwd+bwd, R{depth}-C4, 2 supervised + 2 weak 3x600x1000 images, "
-                      f"{rois} RoIs/image (1/4 of 512), {dt:.1f} s"}
+                      f"{rois} RoIs/image (1/4 of 512), {dt:.1f} s",
+            "sample_tflop": sample_tflop, "step_tflop": full, "cpu_tflops": round(sample_tflop / dt, 3) if sample_tflop else None,
+            "value_flop_normalised": round(2.0 / dt * sample_tflop / full, 4) if sample_tflop else None}
 
 
 def main():
@@ -219,17 +227,20 @@ def main():
                         "algorithmic_bytes_per_launch": round(sum(e[3] for e in ev) / len(ev))}
             key = next(k for k in ("conv_igemm256", "conv_igemm_dma", "conv_igemm") if prof.get(k))
             r = rate(prof, key)
-            traffic = None
+            traffic, tdoc = None, {}
             tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")     # written by tools/pmc_traffic.py from a
             if os.path.exists(tpath):                                     # rocprofv3 --pmc run of this same command
                 try:
-                    traffic = json.load(open(tpath)).get(key + "_kernel", {}).get("hbm_bytes_per_launch")
+                    tdoc = json.load(open(tpath))
+                    traffic = tdoc.get(key + "_kernel", {}).get("hbm_bytes_per_launch")
                 except Exception:
                     traffic = None
             out["roofline"] = {"kernel": ("conv_igemm256_p8_kernel" if key == "conv_igemm256" else key + "_kernel") +
                                          " (implicit-GEMM conv fwd/dgrad, bf16 MFMA 16x16x32, 256x256x64 LDS-DMA tiles)",
                                "bound": "mfma", "achieved": r["tflops"], "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                                "frac": round(r["tflops"] / MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
+                               "traffic_source": (f"profiles/pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this command "
+                                                  f"at commit {tdoc.get('_commit', 'unknown')} (not collected inside this run)") if traffic else None,
                                "launches_per_step": r["launches_per_step"], "avg_launch_us": r["avg_launch_us"],
                                "algorithmic_gflop_per_launch": r["gflop_per_launch"],
                                "algorithmic_bytes_per_launch": r["algorithmic_bytes_per_launch"],
@@ -237,6 +248,23 @@ def main():
                                                 f"around every launch ({dt_events / args.steps * 1e3:.2f} ms/step in that mode)",
                                "other_conv_kernels": {k2: rate(prof, k2) for k2 in ("conv_igemm_dma", "conv_igemm", "conv_wgrad")
                                                       if k2 != key and prof.get(k2)}}
+            # the HBM- / latency-bound kernels north_star names: RoIAlign (GB/s on algorithmic bytes = res4 maps once + pooled
+            # tensor once, strided 7x7 bins; bytes past the L2 from the same PMC file) and the proposal chain (us per launch)
+            def hbm(pr, k2, pmc_key):
+                ev = pr.get(k2) or []
+                if not ev:
+                    return None
+                tot = sum(e[0].elapsed_time(e[1]) for e in ev)
+                byt = sum(e[3] for e in ev) / len(ev)
+                us = tot / len(ev) * 1e3
+                pm = next((v for kk, v in tdoc.items() if isinstance(v, dict) and pmc_key in kk), {})
+                return {"launches_per_step": len(ev) // args.steps, "avg_launch_us": round(us, 1), "algorithmic_bytes_per_launch": round(byt),
+                        "achieved_gbs": round(byt / us / 1e3, 1), "frac_of_hbm_peak": round(byt / us / 1e3 / HBM_PEAK_GBS, 4),
+                        "pmc_bytes_per_launch": pm.get("hbm_bytes_per_launch")}
+            out["roofline"]["hbm_kernels"] = {"peak_gbs": HBM_PEAK_GBS, "roi_align_fwd": hbm(prof, "roi_align_fwd", "roi_align_fwd"),
+                                              "roi_align_bwd_gather": hbm(prof, "roi_align_bwd_gather", "roi_align_bwd_gather")}
+            out["roofline"]["latency_kernels_us"] = {k2: round(sum(e[0].elapsed_time(e[1]) for e in prof[k2]) / len(prof[k2]) * 1e3, 1)
+                                                     for k2 in ("sort_topk", "nms") if prof.get(k2)}
             if prof_insitu:
                 out["roofline"]["insitu"] = {k2: rate(prof_insitu, k2) for k2 in ("conv_igemm256", "conv_igemm_dma", "conv_igemm", "conv_wgrad")
                                              if prof_insitu.get(k2)}

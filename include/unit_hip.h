@@ -2,7 +2,11 @@
  * ubc-vision/UniT.  This is the drop-in boundary: every entry point is `extern "C"`, takes raw
  * device pointers + explicit shapes/strides + a caller-owned workspace, launches asynchronously on the given
  * hipStream_t (passed as void*), never allocates, never synchronises, never throws.  Return 0 on success, <0 on
- * error (unit_last_error() gives the message).  One process per GPU; the library keeps no global mutable state.
+ * error (unit_last_error() gives the message).  One process per GPU.  Process-wide state, all of it listed here: the last error
+ * string (thread-local); two kernel-selection switches for A/B runs (unit_wgrad_big_variant / unit_wgrad_mid_variant, default =
+ * the production kernels, not thread-safe, never touched by the step); `hipFuncSetAttribute` one-time flags of the kernels that
+ * need more than 64 KB of LDS. No operator result depends on call history; there is no allocator, cache or handle to thread
+ * through calls (which is why the `unit_ctx*` of SURVEY 8b was not needed).
  *
  * The reference reaches these operators through PyTorch's dispatcher into ATen/cuDNN, Detectron2 `_C` and torchvision;
  * each declaration cites the UniT call site (path under /root/reference) whose operator it replaces.

@@ -41,9 +41,13 @@ def _check_inference(model, cfg, image):
     out = model([{"image": image, "height": 128, "width": 192}])[0]["instances"]
     p = {k: v.detach().cpu().clone().contiguous() for k, v in model.state_dict().items()}
     b, s, c, r, _ = orc.inference(p, image, _ocfg(cfg), out_hw=(128, 192))
-    assert len(b) > 3 and len(out) == len(b)
-    assert torch.equal(out.pred_classes.cpu(), c)
-    assert torch.allclose(out.scores.cpu(), s, rtol=1e-4, atol=1e-5) and torch.allclose(out.pred_boxes.tensor.cpu(), b, rtol=1e-4, atol=2e-2)
+    # as sets (a detection whose score sits within fp32 noise of the 0.05 threshold, or a pair at the NMS threshold, may
+    # legitimately flip): >= 95 % of either side's detections have a partner of the same class, box within 0.05 px, score 1e-4
+    hb, hs, hc = out.pred_boxes.tensor.cpu(), out.scores.cpu(), out.pred_classes.cpu()
+    assert len(b) > 3 and abs(len(hb) - len(b)) <= 2
+    d = torch.cdist(hb.double(), b.double(), p=float("inf"))
+    ok = (d < 0.05) & (hc[:, None] == c[None, :]) & ((hs[:, None] - s[None, :]).abs() < 1e-4)
+    assert ok.any(1).float().mean() >= 0.95 and ok.any(0).float().mean() >= 0.95, (ok.any(1).float().mean(), ok.any(0).float().mean())
     return out
 
 

@@ -337,10 +337,24 @@ __global__ void sgd_kernel(float* __restrict__ p, const float* __restrict__ g, f
     }
   }
 }
+__global__ void sgd_scalar_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ buf, long n,
+                                  float lr, float momentum, float wd, float grad_scale, int first) {
+  long j = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n) return;
+  float d = g[j] * grad_scale + wd * p[j];
+  float b = first ? d : momentum * buf[j] + d;
+  buf[j] = b; p[j] = p[j] - lr * b;
+}
 extern "C" int unit_sgd_momentum(float* p, const float* g, float* buf, long n, float lr, float momentum, float wd,
                                  float grad_scale, int first_step, void* stream) {
   if (n == 0) return UNIT_OK;
-  UNIT_CHECK_ARG(((uintptr_t)p % 16 == 0) && ((uintptr_t)g % 16 == 0) && ((uintptr_t)buf % 16 == 0), "sgd: 16B alignment");
+  UNIT_CHECK_ARG(((uintptr_t)p % 4 == 0) && ((uintptr_t)g % 4 == 0) && ((uintptr_t)buf % 4 == 0), "sgd: 4B alignment");
+  if (((uintptr_t)p % 16) || ((uintptr_t)g % 16) || ((uintptr_t)buf % 16)) {
+    // a hyper-parameter segment that starts inside a packed fused head (flat.py segments()): small, one element per thread
+    sgd_scalar_kernel<<<cdiv(n, 256), 256, 0, (hipStream_t)stream>>>(p, g, buf, n, lr, momentum, wd, grad_scale, first_step);
+    UNIT_LAUNCH_CHECK();
+    return UNIT_OK;
+  }
   sgd_kernel<<<cdiv(cdiv(n, 4), 256), 256, 0, (hipStream_t)stream>>>(p, g, buf, n, lr, momentum, wd, grad_scale, first_step);
   UNIT_LAUNCH_CHECK();
   return UNIT_OK;

@@ -81,9 +81,12 @@ class FlatStore:
     def segments(self, hyper_fn):
         """Groups contiguous entries with equal hyper-parameters: [(offset, numel, hyper)] (padding included)."""
         segs = []
-        for e in self.entries:
+        for i, e in enumerate(self.entries):
             h = hyper_fn(e["name"], e["param"])
-            end = _align(e["offset"] + e["numel"], 4)
+            # the end is rounded up to 4 elements only into PADDING: fused heads (pad_after=False) are packed back to back, and a
+            # neighbour with other hyper-parameters must not be swept twice (unit_sgd_momentum takes unaligned ranges)
+            nxt = self.entries[i + 1]["offset"] if i + 1 < len(self.entries) else self.size
+            end = min(_align(e["offset"] + e["numel"], 4), max(nxt, e["offset"] + e["numel"]))
             if segs and segs[-1][2] == h and segs[-1][0] + segs[-1][1] >= e["offset"] - self.ALIGN:
                 o, n, _ = segs[-1]
                 segs[-1] = (o, end - o, h)

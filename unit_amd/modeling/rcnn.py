@@ -510,6 +510,12 @@ class WeaklySupervisedRCNNNoMeta(nn.Module):
         feat = c.feat
         bb_trainable = self.backbone.first_trainable_stage() < 3
         box_trainable = c.box_ctx is not None
+        # A step without a weak (or without a supervised) batch produces no gradient for the heads that only that batch feeds. torch
+        # leaves such parameters' .grad at None and SGD skips them (weight decay included); here every gradient lives in the flat
+        # buffer the optimizer sweeps, so those ranges are cleared instead of carrying the previous step's values into the update
+        # (and, data parallel, into another all-reduce).
+        if c.dy_weak is None or c.dy_sup is None:
+            self._clear_unproduced(c)
 
         dbox = dweak = None
         if c.dy_sup is not None and getattr(bp, "finetune", False):
@@ -634,6 +640,23 @@ class WeaklySupervisedRCNNNoMeta(nn.Module):
         if side is not None:
             torch.cuda.current_stream().wait_stream(side)
         ops.WGRAD_STREAM = None
+
+    def _clear_unproduced(self, c):
+        rh, bp = self.roi_heads, self.roi_heads.box_predictor
+        mods = []
+        if c.dy_weak is None:
+            mods += [bp.weak_detector_head.classifier_stream, bp.weak_detector_head.detection_stream] + list(bp.weak_detector_head.oicr_predictors)
+            if rh.weak_box_head is not None:
+                mods.append(rh.weak_box_head)
+        if c.dy_sup is None:
+            mods += [bp.cls_score_delta, bp.bbox_pred_delta, self.proposal_generator.rpn_head] + \
+                    ([bp.cls_score_ft, bp.bbox_pred_ft] if getattr(bp, "finetune", False) else [])
+            if rh.weak_box_head is not None:
+                mods.append(rh.box_head)          # (single-head configurations: box_head also serves the weak RoIs)
+        for m in mods:
+            for p in m.parameters():
+                if p.requires_grad and p.grad is not None:
+                    p.grad.zero_()
 
     def _streams_on(self):
         """HIP-stream overlap (independent Res5 heads, weight-gradient kernels) -- on by default on the GPU."""

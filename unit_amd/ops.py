@@ -78,6 +78,28 @@ WGRAD_ACCUMULATE = False
 PROFILER = None
 
 
+class _timed:
+    """`with _timed("name", flops, bytes):` -- when bench.py has set PROFILER, brackets the launches inside with a HIP-event pair on
+    the launch stream and files (e0, e1, flops, algorithmic bytes) under `name`; free otherwise"""
+
+    def __init__(self, name, flops=0.0, nbytes=0.0):
+        self.name, self.flops, self.nbytes = name, flops, nbytes
+
+    def __enter__(self):
+        self.prof = PROFILER
+        if self.prof is not None:
+            self.e0 = torch.cuda.Event(enable_timing=True)
+            self.e0.record()
+        return self
+
+    def __exit__(self, *exc):
+        if self.prof is not None:
+            e1 = torch.cuda.Event(enable_timing=True)
+            e1.record()
+            self.prof.setdefault(self.name, []).append((self.e0, e1, self.flops, self.nbytes))
+        return False
+
+
 def workspace(nbytes, device, slot=0):
     """scratch buffer for the kernels that need one; one buffer per (slot, HIP stream): the step runs the RPN-loss branch,
     the proposal chain and the weight gradients on different streams at the same time, and scratch must never be shared
@@ -419,9 +441,10 @@ def sort_desc(src, b, n, ld=1, a=1, col0=0, batch_stride=None, topk=None, min_ex
     nb = lib().unit_sort_workspace_bytes(b, n)
     ws = workspace(nb, dev)
     if topk is not None:
-        check(lib().unit_sort_desc_stable_topk(_p(src), batch_stride, ld, a, col0, b, n, int(topk),
-                                               float("-inf") if min_exclusive is None else float(min_exclusive), _p(keys), _p(idx),
-                                               _p(ws), ws.numel(), _s()), "sort_desc_stable_topk")
+        with _timed("sort_topk", 0.0, b * n * 4.0):
+            check(lib().unit_sort_desc_stable_topk(_p(src), batch_stride, ld, a, col0, b, n, int(topk),
+                                                   float("-inf") if min_exclusive is None else float(min_exclusive), _p(keys), _p(idx),
+                                                   _p(ws), ws.numel(), _s()), "sort_desc_stable_topk")
         return keys, idx
     check(lib().unit_sort_desc_stable(_p(src), batch_stride, ld, a, col0, b, n, _p(keys), _p(idx), _p(ws), ws.numel(), _s()),
           "sort_desc_stable")
@@ -452,8 +475,9 @@ def nms(boxes_sorted, scores_sorted, count, thresh, max_keep):
     osc = torch.empty((b, max_keep), dtype=torch.float32, device=dev)
     nb = lib().unit_nms_workspace_bytes(b, cap)
     ws = workspace(nb, dev)
-    check(lib().unit_nms(_p(boxes_sorted), _p(scores_sorted), _p(count), b, cap, float(thresh), max_keep, _p(keep), _p(kc), _p(ob),
-                         _p(osc), _p(ws), ws.numel(), _s()), "nms")
+    with _timed("nms", 0.0, b * cap * 20.0):
+        check(lib().unit_nms(_p(boxes_sorted), _p(scores_sorted), _p(count), b, cap, float(thresh), max_keep, _p(keep), _p(kc), _p(ob),
+                             _p(osc), _p(ws), ws.numel(), _s()), "nms")
     return keep, kc, ob, osc
 
 
@@ -503,8 +527,11 @@ def roi_align(feat, rois, pooled_size=14, out_size=None, bin_step=1, spatial_sca
     out_size = out_size or pooled_size
     if out is None:
         out = torch.empty((r, out_size, out_size, c), dtype=feat.dtype, device=feat.device)
-    check(lib().unit_roi_align_fwd(_p(feat), dt(feat.dtype), n, h, w, c, _p(rois), _p(roi_count), r, pooled_size, out_size, bin_step,
-                                   float(spatial_scale), sampling_ratio, int(aligned), _p(out), _s()), "roi_align_fwd")
+    # algorithmic bytes: the maps once + the pooled tensor once; `ref` = the reference-equivalent full 14x14 output
+    es = feat.element_size()
+    with _timed("roi_align_fwd", 0.0, (feat.numel() + r * out_size * out_size * c) * es):
+        check(lib().unit_roi_align_fwd(_p(feat), dt(feat.dtype), n, h, w, c, _p(rois), _p(roi_count), r, pooled_size, out_size, bin_step,
+                                       float(spatial_scale), sampling_ratio, int(aligned), _p(out), _s()), "roi_align_fwd")
     return out
 
 
@@ -526,10 +553,12 @@ def roi_align_bwd_gather(gout, n_images, h, w, rois, out, pooled_size=14, bin_st
     r, out_size, c = gout.shape[0], gout.shape[1], gout.shape[3]
     nb = lib().unit_roi_align_bwd_gather_workspace_bytes(r)
     ws = workspace(nb, gout.device, slot=1)
-    check(lib().unit_roi_align_bwd_gather(_p(gout), dt(gout.dtype), n_images, h, w, c, _p(rois), _p(roi_count), r, rois_per_image,
-                                          image_offset, pooled_size, out_size, bin_step, float(spatial_scale), sampling_ratio,
-                                          int(aligned), _p(addend), addend_images, _p(mask_ref), _p(out), dt(out.dtype), _p(ws),
-                                          ws.numel(), _s()), "roi_align_bwd_gather")
+    nb_alg = gout.numel() * gout.element_size() + out.numel() * out.element_size() * (1 + (addend is not None) + (mask_ref is not None))
+    with _timed("roi_align_bwd_gather", 0.0, nb_alg):
+        check(lib().unit_roi_align_bwd_gather(_p(gout), dt(gout.dtype), n_images, h, w, c, _p(rois), _p(roi_count), r, rois_per_image,
+                                              image_offset, pooled_size, out_size, bin_step, float(spatial_scale), sampling_ratio,
+                                              int(aligned), _p(addend), addend_images, _p(mask_ref), _p(out), dt(out.dtype), _p(ws),
+                                              ws.numel(), _s()), "roi_align_bwd_gather")
     return out
 
 

@@ -52,10 +52,26 @@ class GradBuckets:
         self._plan, self._store = plan, st
 
     def broadcast_parameters(self, src=0):
-        """initial parameter broadcast from rank 0 (DDP does this at construction)."""
+        """initial broadcast of the module state from rank 0 (DDP does this at construction, buffers included): the flat trainable
+        buffer in one collective, every other floating-point tensor of the state dict (frozen stem / res2 weights, FrozenBN
+        statistics, embeddings) packed into a second one."""
         if self.world > 1:
+            import torch
+            from .layers import invalidate_prepared
             self.model._ensure_ready()
-            dist.broadcast(self.model.store.params, src, group=self.group)
+            st = self.model.store
+            dist.broadcast(st.params, src, group=self.group)
+            inside = {id(e["param"]) for e in st.entries}
+            rest = [t for _, t in sorted(self.model.state_dict(keep_vars=True).items()) if id(t) not in inside and t.is_floating_point()]
+            if rest:
+                flat = torch.cat([t.detach().reshape(-1).float() for t in rest])
+                dist.broadcast(flat, src, group=self.group)
+                o = 0
+                with torch.no_grad():
+                    for t in rest:
+                        t.copy_(flat[o:o + t.numel()].view(t.shape))
+                        o += t.numel()
+            invalidate_prepared()          # frozen layers fold / cast their weights once: redo it from the broadcast values
             self.model.version += 1
 
     def ready(self, tag):
