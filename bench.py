@@ -39,6 +39,8 @@ def parse():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-overlap", action="store_true", help="single HIP stream for the whole run (profiling aid: every "
                     "kernel's rocprof duration is then that kernel alone)")
+    ap.add_argument("--graph", action="store_true", help="capture the whole step in a hipGraph and replay it (engine.GraphedStep; "
+                    "single process only)")
     ap.add_argument("--early-update", action="store_true", help="per-bucket optimizer updates beside the backward instead of one "
                     "update after it (engine.EarlyUpdate; measured 18.56 vs 18.43 ms per step: off by default)")
     return ap.parse_args()
@@ -149,14 +151,19 @@ def main():
         opt.step()
         return step.losses
 
-    for _ in range(args.warmup):
-        one_step()
+    timed_step = one_step
+    if args.graph and world == 1 and early is None:
+        from unit_amd.engine import GraphedStep
+        gs = GraphedStep(model, opt, warmup_steps=max(1, args.warmup - 2))      # the last warm-up steps already replay the graph
+        timed_step = lambda: gs.run(packed=batch)
+    for _ in range(max(args.warmup, 3 if args.graph else 0)):
+        timed_step()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        losses = one_step()
+        losses = timed_step()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -205,7 +212,7 @@ def main():
             "metric": "images/sec (fwd+bwd+SGD) R101-C4 VOC 600x1000 bs=2/GPU" if args.depth == 101 else f"images/sec R{args.depth}-C4",
             "value": round(value, 3), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": args.dtype, "data": "synthetic",
+            "dtype": args.dtype, "data": "synthetic", "launch": "hipGraph replay" if (args.graph and world == 1) else "eager",
             "config": {"workload": f"UniT base-training step {args.variant.upper()} (TrainerNoMeta.run_step): ResNet-{args.depth}-C4, "
                                    f"VOC split1 K=20, 2 supervised + {n_weak} weak 3x600x1000 images per GPU, 512 RoIs/image, "
                                    "two Res5 heads, RPN 12000->2000, all 8 losses, SGD momentum",

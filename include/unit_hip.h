@@ -253,8 +253,10 @@ int unit_paste_masks(const float* probs, const float* boxes, const unsigned char
                      unsigned char* out, void* stream);
 
 /* ---- K18 SGD momentum (solver/build.py:110-112) ---- */
+/* lr_dev (may be NULL): device float holding the step's learning rate; `lr` is then the parameter group's multiplier (a captured
+ * hipGraph of the step follows the LR schedule: the host rewrites that one float before every replay) */
 int unit_sgd_momentum(float* p, const float* g, float* buf, long n, float lr, float momentum, float wd, float grad_scale,
-                      int first_step, void* stream);
+                      int first_step, const float* lr_dev, void* stream);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,65 @@
+"""The whole training step captured in a hipGraph (engine.GraphedStep) against the eager step: same losses every iteration, same
+parameters after several iterations with changing data, fresh sampling permutations on every replay, learning-rate schedule
+followed without re-capture."""
+import pytest
+import torch
+
+from unit_amd import config, engine
+from unit_amd.modeling import build_model
+from unit_amd.solver import FlatSGD
+from unit_amd.synthetic import init_synthetic_weights, synthetic_batch
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup(seed=3):
+    cfg = config.voc_rcnn_c4_split1(50)
+    cfg.MODEL.DEVICE = "cuda"
+    cfg.MODEL.ROI_HEADS.BATCH_SIZE_PER_IMAGE = 32
+    cfg.MODEL.RPN.PRE_NMS_TOPK_TRAIN, cfg.MODEL.RPN.POST_NMS_TOPK_TRAIN = 600, 100
+    cfg.SOLVER.WARMUP_ITERS = 4           # the learning rate changes on every one of the test's iterations
+    cfg.SEED = seed
+    model = build_model(cfg)
+    init_synthetic_weights(model, seed=1)
+    model.train()
+    return cfg, model
+
+
+def test_graphed_step_equals_eager_step(dev):
+    data = [synthetic_batch(2, 2, hw=(128, 192), seed=50 + i, max_gt=4) for i in range(3)]
+    order = [0, 1, 2, 1, 0, 2]
+    # eager reference: same packing capacity, same device-resident learning rate
+    cfg, m1 = _setup()
+    o1 = FlatSGD(m1, cfg)
+    ref_losses = []
+    for i in order:
+        b = m1.pack_batch(*data[i], gt_capacity=engine.GraphedStep.GT_CAPACITY)
+        o1._bind()
+        o1.use_device_lr(m1.device)
+        step = m1.forward_train(b, early_backward=True)
+        m1.backward_train(step)
+        o1.step()
+        ref_losses.append(step.losses.clone())
+    torch.cuda.synchronize()
+    # graphed: two eager warm-up iterations, capture at the third, replays afterwards (with OTHER data than at capture)
+    cfg, m2 = _setup()
+    o2 = FlatSGD(m2, cfg)
+    gs = engine.GraphedStep(m2, o2, warmup_steps=2)
+    got = []
+    for i in order:
+        got.append(gs.run(*data[i]).clone())
+    torch.cuda.synchronize()
+    assert len(gs.graphs) == 1 and o2.iter == o1.iter == len(order)
+    for k, (a, b) in enumerate(zip(got, ref_losses)):
+        assert torch.isfinite(a).all()
+        assert torch.allclose(a, b, rtol=1e-5, atol=1e-6), (k, a.tolist(), b.tolist())
+    assert torch.allclose(m2.store.params, m1.store.params, rtol=1e-5, atol=1e-7)
+    assert not torch.equal(got[1], got[3])          # same data, later weights / other permutations: the replay is not a recording
+    # the trainer switch
+    cfg, m3 = _setup()
+    tr = engine.TrainerNoMeta(cfg, m3, use_graph=True)
+    for i in order:
+        l3 = tr.run_step(*data[i])
+    torch.cuda.synchronize()
+    assert tr.graphed is not None and len(tr.graphed.graphs) == 1
+    assert torch.allclose(m3.store.params, m1.store.params, rtol=1e-5, atol=1e-7)

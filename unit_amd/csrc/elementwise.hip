@@ -315,10 +315,13 @@ extern "C" int unit_bias_grad(const void* dy, int dtype, int M, int K, int ld, f
 // K18  SGD momentum on flat fp32 buffers (torch.optim.SGD semantics: solver/build.py:110-112):
 //   g = grad + wd*p ; buf = momentum*buf + g ; p -= lr*buf        (first step: buf = g, via buf init 0 + momentum*0)
 // ---------------------------------------------------------------------------------------------------
+// lr_dev (optional): the step's learning rate lives in device memory and `lr` is only the parameter group's multiplier -- a captured
+// hipGraph of the step then follows the warm-up / multi-step schedule without being re-captured (the host writes one float per step)
 __global__ void sgd_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ buf, long n,
-                           float lr, float momentum, float wd, float grad_scale, int first) {
+                           float lr, float momentum, float wd, float grad_scale, int first, const float* __restrict__ lr_dev) {
   long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
   if (i >= n) return;
+  if (lr_dev) lr = lr * *lr_dev;
   if (i + 4 <= n) {
     f32x4 pv = *reinterpret_cast<f32x4*>(p + i), gv = *reinterpret_cast<const f32x4*>(g + i);
     f32x4 bv = *reinterpret_cast<f32x4*>(buf + i);
@@ -338,24 +341,25 @@ __global__ void sgd_kernel(float* __restrict__ p, const float* __restrict__ g, f
   }
 }
 __global__ void sgd_scalar_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ buf, long n,
-                                  float lr, float momentum, float wd, float grad_scale, int first) {
+                                  float lr, float momentum, float wd, float grad_scale, int first, const float* __restrict__ lr_dev) {
   long j = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= n) return;
+  if (lr_dev) lr = lr * *lr_dev;
   float d = g[j] * grad_scale + wd * p[j];
   float b = first ? d : momentum * buf[j] + d;
   buf[j] = b; p[j] = p[j] - lr * b;
 }
 extern "C" int unit_sgd_momentum(float* p, const float* g, float* buf, long n, float lr, float momentum, float wd,
-                                 float grad_scale, int first_step, void* stream) {
+                                 float grad_scale, int first_step, const float* lr_dev, void* stream) {
   if (n == 0) return UNIT_OK;
   UNIT_CHECK_ARG(((uintptr_t)p % 4 == 0) && ((uintptr_t)g % 4 == 0) && ((uintptr_t)buf % 4 == 0), "sgd: 4B alignment");
   if (((uintptr_t)p % 16) || ((uintptr_t)g % 16) || ((uintptr_t)buf % 16)) {
     // a hyper-parameter segment that starts inside a packed fused head (flat.py segments()): small, one element per thread
-    sgd_scalar_kernel<<<cdiv(n, 256), 256, 0, (hipStream_t)stream>>>(p, g, buf, n, lr, momentum, wd, grad_scale, first_step);
+    sgd_scalar_kernel<<<cdiv(n, 256), 256, 0, (hipStream_t)stream>>>(p, g, buf, n, lr, momentum, wd, grad_scale, first_step, lr_dev);
     UNIT_LAUNCH_CHECK();
     return UNIT_OK;
   }
-  sgd_kernel<<<cdiv(cdiv(n, 4), 256), 256, 0, (hipStream_t)stream>>>(p, g, buf, n, lr, momentum, wd, grad_scale, first_step);
+  sgd_kernel<<<cdiv(cdiv(n, 4), 256), 256, 0, (hipStream_t)stream>>>(p, g, buf, n, lr, momentum, wd, grad_scale, first_step, lr_dev);
   UNIT_LAUNCH_CHECK();
   return UNIT_OK;
 }

@@ -46,8 +46,81 @@ class EarlyUpdate:
             torch.cuda.current_stream().wait_stream(self.stream)
 
 
+class GraphedStep:
+    """One whole training step -- forward plan, backward plan, optimizer update, weight re-preparation: ~650 launches on four HIP
+    streams -- captured ONCE into a hipGraph (torch.cuda.CUDAGraph is hipGraph on ROCm) and replayed: the host cost of a step drops
+    from ~10 ms of Python / ctypes enqueue to a few copies into static input buffers plus one graph launch.
+
+    What makes the step capturable: nothing in it syncs with or branches on the host (proposal / RoI counts stay in device
+    arrays), the sampling permutations come from a device-resident counter (`unit_perm_keys`), the learning rate is read from
+    device memory (`FlatSGD.use_device_lr`), the side streams fork from and rejoin the capturing stream, and the per-stream
+    workspaces / weight-gradient slabs are cached objects. Shapes are static per graph: one graph per (image sizes, GT capacity,
+    weak-label presence) key, all sharing one memory pool (only one runs at a time).
+    Single process only: with world > 1 the bucket all-reduces are launched from inside the backward plan, and RCCL collectives
+    inside a capture could not be rehearsed on the 1-GPU boxes this was built on -- TrainerNoMeta keeps the eager path there."""
+
+    GT_CAPACITY = 32
+
+    def __init__(self, model, optimizer, warmup_steps=2):
+        import torch
+        self.model, self.optimizer, self.warmup_steps = model, optimizer, warmup_steps
+        self.graphs = {}          # key -> (graph, static PackedBatch, losses tensor)
+        self.pool = None
+        self.eager_left = warmup_steps
+        self._torch = torch
+
+    def _body(self, batch):
+        step = self.model.forward_train(batch, early_backward=True)
+        self.model.backward_train(step)
+        self.optimizer.step()
+        return step.losses
+
+    @staticmethod
+    def _refill(static, fresh):
+        for a, b in zip(static.images, fresh.images):
+            a.copy_(b, non_blocking=True)
+        static.gt_boxes.copy_(fresh.gt_boxes, non_blocking=True)
+        static.gt_classes.copy_(fresh.gt_classes, non_blocking=True)
+        static.gt_count.copy_(fresh.gt_count, non_blocking=True)
+        if static.multihot is not None:
+            static.multihot.copy_(fresh.multihot, non_blocking=True)
+        if static.gt_masks is not None:
+            static.gt_masks.copy_(fresh.gt_masks, non_blocking=True)
+
+    def run(self, base_data=None, classifier_data=None, packed=None):
+        """one step on (base_data, classifier_data) -- or on an already packed, device-resident batch -- returns the device loss
+        vector (a static tensor of the graph: read it before the next run)"""
+        torch = self._torch
+        model, opt = self.model, self.optimizer
+        fresh = packed if packed is not None else model.pack_batch(base_data, classifier_data, gt_capacity=self.GT_CAPACITY)
+        opt._bind()
+        opt.use_device_lr(model.device)          # (re)writes the scheduled learning rate of this iteration into device memory
+        if self.eager_left > 0:            # the first steps run eagerly: they allocate the cached workspaces / slabs / streams
+            self.eager_left -= 1
+            return self._body(fresh)
+        key = fresh.key()
+        ent = self.graphs.get(key)
+        if ent is None:
+            static = fresh.clone()
+            g = torch.cuda.CUDAGraph()
+            it, first = opt.iter, opt._first
+            torch.cuda.synchronize()
+            with torch.cuda.graph(g, pool=self.pool):
+                losses = self._body(static)
+            opt.iter, opt._first = it, first            # the capture only recorded the launches: nothing has run yet
+            self.pool = self.pool or g.pool()
+            ent = self.graphs[key] = (g, static, losses)
+        else:
+            self._refill(ent[1], fresh)
+        ent[0].replay()
+        opt.iter += 1
+        opt._first = False
+        return ent[2]
+
+
 class TrainerNoMeta:
-    def __init__(self, cfg, model, data_iter=None, weak_data_iter=None, group=None, early_update=False, bf16_buckets=False):
+    def __init__(self, cfg, model, data_iter=None, weak_data_iter=None, group=None, early_update=False, bf16_buckets=False,
+                 use_graph=False):
         self.cfg, self.model = cfg, model
         self.data_iter, self.weak_data_iter = data_iter, weak_data_iter
         self.buckets = GradBuckets(model, group, bf16=bf16_buckets)
@@ -56,6 +129,7 @@ class TrainerNoMeta:
         self.iter = 0
         self.last_losses = None
         self.early = EarlyUpdate(model, self.buckets, self.optimizer) if early_update else None
+        self.graphed = GraphedStep(model, self.optimizer) if (use_graph and self.buckets.world == 1 and not early_update) else None
 
     def run_step(self, base_data=None, classifier_data=None):
         assert self.model.training, "[TrainerNoMeta] model was changed to eval mode!"
@@ -63,6 +137,10 @@ class TrainerNoMeta:
             base_data = next(self.data_iter)
         if classifier_data is None and self.weak_data_iter is not None:
             classifier_data = next(self.weak_data_iter)
+        if self.graphed is not None:
+            self.iter += 1
+            self.last_losses = self.graphed.run(base_data, classifier_data)
+            return self.last_losses
         batch = self.model.pack_batch(base_data, classifier_data)
         step = self.model.forward_train(batch, early_backward=True)
         self.model.backward_train(step)          # buckets' all-reduces are launched from inside (on_grad_ready)

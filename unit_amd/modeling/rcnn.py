@@ -39,6 +39,16 @@ class PackedBatch:
     def n_weak(self):
         return len(self.images) - self.n_sup
 
+    def clone(self):
+        """own copies of every buffer (the static inputs of a captured step must not alias the caller's tensors)"""
+        c = lambda t: None if t is None else t.clone()
+        return PackedBatch([im.clone() for im in self.images], c(self.gt_boxes), c(self.gt_classes), c(self.gt_count), self.n_sup,
+                           c(self.multihot), c(self.gt_masks))
+
+    def key(self):
+        return (tuple(tuple(im.shape[-2:]) for im in self.images), self.n_sup, tuple(self.gt_boxes.shape), self.multihot is not None,
+                None if self.gt_masks is None else tuple(self.gt_masks.shape))
+
 
 class _StepFn(torch.autograd.Function):
     """Exposes the explicit plan to torch.autograd as one node: forward has already run, backward runs the backward plan."""
@@ -197,7 +207,9 @@ class WeaklySupervisedRCNNNoMeta(nn.Module):
         self.roi_heads.prepare(dt, v)
 
     # ------------------------------------------------------------------ inputs
-    def pack_batch(self, batched_inputs, weak_batched_inputs=None):
+    def pack_batch(self, batched_inputs, weak_batched_inputs=None, gt_capacity=None):
+        """gt_capacity: fixed number of GT slots per image (a multiple of 8, >= the largest image's count) -- static shapes for a
+        captured step; default: the batch's own maximum rounded up to 8"""
         dev = self.device
         sup = batched_inputs or []
         weak = weak_batched_inputs or []
@@ -211,6 +223,9 @@ class WeaklySupervisedRCNNNoMeta(nn.Module):
             gtc.append(inst.gt_classes)
         mcap = max([len(b) for b in gtb] + [1])
         mcap = (mcap + 7) // 8 * 8
+        if gt_capacity is not None:
+            assert gt_capacity % 8 == 0 and gt_capacity >= mcap, (gt_capacity, mcap)
+            mcap = gt_capacity
         gt_boxes = torch.zeros((max(n, 1), mcap, 4), dtype=torch.float32)
         gt_classes = torch.zeros((max(n, 1), mcap), dtype=torch.int64)
         for i in range(n):
@@ -343,7 +358,7 @@ class WeaklySupervisedRCNNNoMeta(nn.Module):
         elif n_sup > 0:
             c.rpn_losses = c.losses[6:8]
             rpn_branch()
-        hw = torch.tensor(sizes, dtype=torch.float32).to(self.device, non_blocking=True)
+        hw = self._sizes_on_device(sizes)
         if proposals is not None:
             props, pscores, pcount = proposals
         elif not split:
@@ -428,7 +443,7 @@ class WeaklySupervisedRCNNNoMeta(nn.Module):
             tgt = mask_targets(batch.gt_masks, rois_fg, torch.cat([gidx[sl] for sl in sel], 0), cls_fg, rh.num_classes, mh.mask_size)
             kw = {}
             if sim is not None:      # similarity['seg'][fg] (roi_heads.py:893-897): fg slot -> its RoI row
-                rows = torch.cat([torch.arange(sl.start, sl.stop, dtype=torch.int32) for sl in sel]).to(self.device, non_blocking=True)
+                rows = self._const_on_device(("fg_rows", n_sup, s, fgc), lambda: torch.cat([torch.arange(sl.start, sl.stop, dtype=torch.int32) for sl in sel]))
                 c.dsim_mask = torch.zeros(sim.shape, dtype=torch.float32, device=self.device)
                 kw = dict(sim=sim, sim_rows=rows, roles=roles, dsim=c.dsim_mask)
             c.mask_ctx = (mh.fwd_train(x_fg, cls_fg, tgt, c.losses[8:9], dt, **kw), sel)
@@ -640,6 +655,19 @@ class WeaklySupervisedRCNNNoMeta(nn.Module):
         if side is not None:
             torch.cuda.current_stream().wait_stream(side)
         ops.WGRAD_STREAM = None
+
+    def _const_on_device(self, key, make):
+        """small host-built constants of the step (image sizes, slot tables) are uploaded once per distinct value: no pageable
+        host-to-device copy inside the step -- which a hipGraph capture of the step could not contain"""
+        cache = self.__dict__.setdefault("_dev_consts", {})
+        t = cache.get(key)
+        if t is None or t.device != self.device:
+            t = make().to(self.device)
+            cache[key] = t
+        return t
+
+    def _sizes_on_device(self, sizes):
+        return self._const_on_device(("hw", tuple(sizes)), lambda: torch.tensor(sizes, dtype=torch.float32))
 
     def _clear_unproduced(self, c):
         rh, bp = self.roi_heads, self.roi_heads.box_predictor

@@ -735,6 +735,6 @@ def sum_losses(losses, out=None):
     return out
 
 
-def sgd_momentum(p, g, buf, lr, momentum, weight_decay, grad_scale=1.0, first_step=False):
+def sgd_momentum(p, g, buf, lr, momentum, weight_decay, grad_scale=1.0, first_step=False, lr_dev=None):
     check(lib().unit_sgd_momentum(_p(p), _p(g), _p(buf), p.numel(), float(lr), float(momentum), float(weight_decay), float(grad_scale),
-                                  int(first_step), _s()), "sgd_momentum")
+                                  int(first_step), _p(lr_dev), _s()), "sgd_momentum")

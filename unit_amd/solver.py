@@ -55,6 +55,7 @@ class FlatSGD:
         self._segments = None
         self._buf = None
         self._early = set()
+        self._lr_dev = None       # device-resident learning rate (engine.GraphedStep): the launches then carry only the group multiplier
 
     def _bind(self):
         st = self.model.store
@@ -72,12 +73,21 @@ class FlatSGD:
 
     def _apply(self, st, lo, hi):
         """SGD-momentum on the flat range [lo, hi), cut at the hyper-parameter segment borders (solver/build.py:85-107 groups)"""
-        lr = self.schedule(self.iter)
+        lr = self.schedule(self.iter) if self._lr_dev is None else 1.0
         for off, n, (lr_mult, wd) in self._segments:
             a, b = max(off, lo), min(off + n, hi)
             if a < b:
                 ops.sgd_momentum(st.params[a:b], st.grads[a:b], self._buf[a:b], lr * lr_mult, self.momentum, wd,
-                                 self.grad_scale, first_step=self._first)
+                                 self.grad_scale, first_step=self._first, lr_dev=self._lr_dev)
+
+    def use_device_lr(self, device):
+        """keep the scheduled learning rate in a device float that `write_lr()` refreshes (one tiny fill launch per step)"""
+        if self._lr_dev is None:
+            self._lr_dev = torch.zeros(1, dtype=torch.float32, device=device)
+        self.write_lr()
+
+    def write_lr(self):
+        self._lr_dev.fill_(self.schedule(self.iter))
 
     def step_tag(self, tag):
         """update the parameters of one gradient bucket as soon as its gradients are final (called from the backward plan on the
