@@ -1,6 +1,6 @@
 """One rank of the 2-rank data-parallel rehearsal (tests/test_dp_gpu.py starts two of these as fresh child processes; both
 share cuda:0 and talk gloo through 127.0.0.1 -- the RCCL run differs only in the backend name).
-usage: python tests/dp_rehearsal_worker.py <rank> <world> <port> <out.pt> [bf16_buckets]"""
+usage: python tests/dp_rehearsal_worker.py <rank> <world> <port> <out.pt> [fp32|bf16_buckets|graph|eager] [steps]"""
 import os
 import sys
 
@@ -39,9 +39,24 @@ def main():
     init_synthetic_weights(model, seed=1 + rank)          # ranks start DIFFERENT: the initial broadcast must equalise them
     model.train()
     model.compute_dtype = torch.float32
-    tr = engine.TrainerNoMeta(cfg, model, bf16_buckets=(len(sys.argv) > 5 and sys.argv[5] == "bf16_buckets"))
+    mode = sys.argv[5] if len(sys.argv) > 5 else "fp32"
+    steps = int(sys.argv[6]) if len(sys.argv) > 6 else 1
+    tr = engine.TrainerNoMeta(cfg, model, bf16_buckets=(mode == "bf16_buckets"), use_graph=(mode == "graph"))
+    if mode == "eager":          # the graphed trainer's packing capacity and device-resident learning rate, launched eagerly
+        tr.optimizer._bind()
     sup, weak = global_batch()
-    losses = tr.run_step(engine.shard_batch(sup, rank, world), engine.shard_batch(weak, rank, world))
+    for _ in range(steps):
+        if mode == "eager":
+            tr.optimizer.use_device_lr(model.device)
+            batch = model.pack_batch(engine.shard_batch(sup, rank, world), engine.shard_batch(weak, rank, world),
+                                     gt_capacity=engine.GraphedStep.GT_CAPACITY)
+            step = model.forward_train(batch, early_backward=True)
+            model.backward_train(step)
+            tr.buckets.finish()
+            tr.optimizer.step()
+            losses = step.losses
+        else:
+            losses = tr.run_step(engine.shard_batch(sup, rank, world), engine.shard_batch(weak, rank, world))
     torch.cuda.synchronize()
     torch.save({"params": model.store.params.cpu(), "losses": losses.cpu()}, out)
     dist.barrier()

@@ -79,3 +79,15 @@ def test_two_ranks_bf16_gradient_buckets(dev, tmp_path):
     ref = _single_process_reference(dev)
     upd = (a["params"] - ref).abs().max().item()
     assert upd <= 1e-4, upd
+
+
+def test_two_ranks_graphed_step(dev, tmp_path):
+    """engine.GraphedStep under data parallelism (graph A: forward + backward, one eager all-reduce of the flat gradient buffer,
+    graph B: optimizer): two eager warm-up steps, the capture, two replays == five eager steps with per-bucket all-reduces."""
+    g0, g1 = _run_ranks(tmp_path, extra=("graph", "5"))
+    assert torch.equal(g0["params"], g1["params"]), "ranks diverged"
+    (tmp_path / "e").mkdir()
+    e0, e1 = _run_ranks(tmp_path / "e", extra=("eager", "5"))
+    assert torch.equal(e0["params"], e1["params"])
+    assert torch.allclose(g0["losses"], e0["losses"], rtol=1e-5, atol=1e-6), (g0["losses"], e0["losses"])
+    assert torch.allclose(g0["params"], e0["params"], rtol=1e-5, atol=1e-7), (g0["params"] - e0["params"]).abs().max()

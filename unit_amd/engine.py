@@ -56,24 +56,51 @@ class GraphedStep:
     device memory (`FlatSGD.use_device_lr`), the side streams fork from and rejoin the capturing stream, and the per-stream
     workspaces / weight-gradient slabs are cached objects. Shapes are static per graph: one graph per (image sizes, GT capacity,
     weak-label presence) key, all sharing one memory pool (only one runs at a time).
-    Single process only: with world > 1 the bucket all-reduces are launched from inside the backward plan, and RCCL collectives
-    inside a capture could not be rehearsed on the 1-GPU boxes this was built on -- TrainerNoMeta keeps the eager path there."""
+    Data parallel (`buckets` with world > 1): collectives are kept OUT of the captures -- RCCL inside a hipGraph could not be rehearsed
+    on the 1-GPU boxes this was built on. The step becomes graph A (forward + backward, no per-bucket hook), ONE eager all-reduce
+    of the whole flat gradient buffer, graph B (optimizer + weight re-preparation): the host cost of a graphed step, but the
+    all-reduce no longer hides behind the backward (268 MB over xGMI, ~1-2 ms exposed). Which side of that trade wins on an 8-GPU
+    host depends on how many cores each rank gets; the eager overlapped path stays the default (TrainerNoMeta(use_graph=False))."""
 
     GT_CAPACITY = 32
 
-    def __init__(self, model, optimizer, warmup_steps=2):
+    def __init__(self, model, optimizer, warmup_steps=2, buckets=None):
         import torch
         self.model, self.optimizer, self.warmup_steps = model, optimizer, warmup_steps
-        self.graphs = {}          # key -> (graph, static PackedBatch, losses tensor)
+        self.buckets = buckets if (buckets is not None and buckets.world > 1) else None
+        self.graphs = {}          # key -> (graph | (graph A, graph B), static PackedBatch, losses tensor)
         self.pool = None
-        self.eager_left = warmup_steps
+        self.eager_left = max(1, warmup_steps)          # the very first step initialises the momentum buffers (another SGD launch flag)
         self._torch = torch
 
-    def _body(self, batch):
+    def _fwd_bwd(self, batch):
         step = self.model.forward_train(batch, early_backward=True)
         self.model.backward_train(step)
-        self.optimizer.step()
         return step.losses
+
+    def _body(self, batch):
+        losses = self._fwd_bwd(batch)
+        if self.buckets is not None:
+            self.buckets.finish()          # (eager warm-up steps only: the per-bucket all-reduces launched from inside the backward)
+        self.optimizer.step()
+        self._join_side_streams()
+        return losses
+
+    def _join_side_streams(self):
+        """every side stream that forked from the capturing stream must be back on it when the capture ends; the plan joins each
+        fork where its results are consumed, this is the belt to those braces (three event waits, nothing to wait for)"""
+        torch = self._torch
+        cur = torch.cuda.current_stream()
+        if not torch.cuda.is_current_stream_capturing():
+            return
+        for name in ("_head_stream", "_wgrad_stream", "_rpn_stream"):
+            s = getattr(self.model, name, None)
+            if s is None:
+                continue
+            with torch.cuda.stream(s):
+                forked = torch.cuda.is_current_stream_capturing()
+            if forked:
+                cur.wait_stream(s)
 
     @staticmethod
     def _refill(static, fresh):
@@ -105,14 +132,32 @@ class GraphedStep:
             g = torch.cuda.CUDAGraph()
             it, first = opt.iter, opt._first
             torch.cuda.synchronize()
-            with torch.cuda.graph(g, pool=self.pool):
-                losses = self._body(static)
+            if self.buckets is None:
+                with torch.cuda.graph(g, pool=self.pool):
+                    losses = self._body(static)
+            else:
+                hook, model.on_grad_ready = model.on_grad_ready, None          # no collective inside the capture
+                try:
+                    with torch.cuda.graph(g, pool=self.pool):
+                        losses = self._fwd_bwd(static)
+                        self._join_side_streams()
+                finally:
+                    model.on_grad_ready = hook
+                g2 = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g2, pool=g.pool()):
+                    opt.step()
+                g = (g, g2)
             opt.iter, opt._first = it, first            # the capture only recorded the launches: nothing has run yet
-            self.pool = self.pool or g.pool()
+            self.pool = self.pool or (g[0] if isinstance(g, tuple) else g).pool()
             ent = self.graphs[key] = (g, static, losses)
         else:
             self._refill(ent[1], fresh)
-        ent[0].replay()
+        if isinstance(ent[0], tuple):
+            ent[0][0].replay()
+            self.buckets.reduce_all()
+            ent[0][1].replay()
+        else:
+            ent[0].replay()
         opt.iter += 1
         opt._first = False
         return ent[2]
@@ -129,7 +174,7 @@ class TrainerNoMeta:
         self.iter = 0
         self.last_losses = None
         self.early = EarlyUpdate(model, self.buckets, self.optimizer) if early_update else None
-        self.graphed = GraphedStep(model, self.optimizer) if (use_graph and self.buckets.world == 1 and not early_update) else None
+        self.graphed = GraphedStep(model, self.optimizer, buckets=self.buckets) if (use_graph and not early_update) else None
 
     def run_step(self, base_data=None, classifier_data=None):
         assert self.model.training, "[TrainerNoMeta] model was changed to eval mode!"

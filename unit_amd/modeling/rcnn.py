@@ -325,6 +325,9 @@ class WeaklySupervisedRCNNNoMeta(nn.Module):
         perm_ready = None
         if perms is None:
             if side_rpn:
+                # fork first: work on a stream that has not joined the capturing stream would run at capture time instead of
+                # being recorded (engine.GraphedStep); eagerly the draw just queues behind the backbone, off the critical path
+                self._rpn_stream.wait_stream(torch.cuda.current_stream())
                 with torch.cuda.stream(self._rpn_stream):
                     perms = self.sampling_permutations(n_sup, anchors.shape[0], n_roi_cap)
                     perm_ready = torch.cuda.Event()

@@ -76,7 +76,7 @@ class ConvPlan:
         """called right after a conv's split-M slabs were enqueued on the current stream. accumulate: the slabs hold a SECOND
         contribution to the same gradient (ragged supervised / weak batches run the backbone twice, rcnn.py): the caller has
         flushed the first one (`reduce()`), this one is added on top."""
-        key = torch.cuda.current_stream().cuda_stream if self.model.device.type == "cuda" else 0
+        key = ops.raw_stream(self.model.device.index) if self.model.device.type == "cuda" else 0
         lst = self._pending.setdefault(key, [0, []])
         slab = conv._slab if slab is None else slab
         splits = conv._splits if splits is None else splits

@@ -91,6 +91,21 @@ class GradBuckets:
             self._works.append(w)
             self._tag_works.setdefault(tag, []).append(w)
 
+    def reduce_all(self):
+        """ONE all-reduce of the whole flat gradient buffer on the current stream's timeline (engine.GraphedStep: the collectives
+        stay outside the captured graphs)"""
+        if self.world == 1:
+            return
+        g = self.model.store.grads
+        if self.bf16:
+            from . import ops
+            import torch
+            buf = ops.cast(g, torch.bfloat16)
+            dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group)
+            g.copy_(buf)
+        else:
+            dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.group)
+
     def wait_tag(self, tag):
         """make the CURRENT stream wait for the all-reduces of one bucket (early per-bucket optimizer update)"""
         for w in self._tag_works.pop(tag, []):
