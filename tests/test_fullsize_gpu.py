@@ -335,8 +335,8 @@ def test_r101_s2_finetune_fullsize(dev):
 
 
 # =================================================================================================== config 5: COCO K=80 + mask
-def _coco_model(dev, seed):
-    cfg = config.coco_rcnn_c4_split1_segm(50)
+def _coco_model(dev, seed, depth=50):
+    cfg = config.coco_rcnn_c4_split1_segm(depth)
     cfg.MODEL.DEVICE = "cuda"
     cfg.SEED = 7
     model = build_model(cfg)
@@ -364,12 +364,13 @@ def _ellipses(sup):
     return masks
 
 
-def test_coco_k80_mask_step_fullsize(dev):
-    """BASELINE config 5 (COCO-RCNN-50-C4-split1-segm.yaml): K = 80, 60 base / 20 novel classes, ONE Res5 head serving the
+@pytest.mark.parametrize("depth", [50, 101])
+def test_coco_k80_mask_step_fullsize(dev, depth):
+    """BASELINE config 5 (the reference ships COCO-RCNN-50-C4-split1-segm.yaml; BASELINE.json names the R101 variant of it): K = 80, 60 base / 20 novel classes, ONE Res5 head serving the
     supervised and the weak RoIs, mask head on the <= 128 fg RoIs per image; 2 + 2 images 600x1000. fp32 teacher-forced:
     RoIs exact, all nine losses (incl. loss_mask) 1e-4, gradients of the mask head / Res5 / backbone 5e-3 of their max;
     bf16 production mode within the bf16 tolerance."""
-    cfg, model = _coco_model(dev, 5)
+    cfg, model = _coco_model(dev, 5, depth)
     model.train()
     model.compute_dtype = torch.float32
     sup, weak = synthetic_batch(2, 2, hw=HW, num_classes=80, base_ids=list(cfg.DATASETS.FEWSHOT.BASE_CLASSES_ID), seed=9)
@@ -399,7 +400,7 @@ def test_coco_k80_mask_step_fullsize(dev):
     stepb = model.forward_train(batch, perms, early_backward=True, proposals=props)
     model.backward_train(stepb)
     gotb = dict(zip(LOSS_NAMES, stepb.losses.cpu().tolist()))
-    log_metrics("coco_k80_mask_step", dict(loss_rel_dev_fp32=dev_l, grad_rel_to_max=gerr, bf16={k: (gotb[k], v.item()) for k, v in ref.items()}))
+    log_metrics(f"coco_k80_mask_step_r{depth}", dict(loss_rel_dev_fp32=dev_l, grad_rel_to_max=gerr, bf16={k: (gotb[k], v.item()) for k, v in ref.items()}))
     assert ref["loss_mask"].item() > 0.1
     for k, v in dev_l.items():
         assert v <= 1e-4, (k, got[k], ref[k].item())
