@@ -59,6 +59,25 @@ int unit_conv2d_fwd(const void* x, const void* w, void* y, const float* bias, co
 int unit_conv2d_fwd_big(const void* x, const void* w, void* y, const float* bias, const void* residual, const void* mask_ref,
                         int out_dtype, int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int OH, int OW, int ldy,
                         int oy_mul, int OHf, int OWf, int relu, int variant, void* stream);
+/* unit_conv2d_fwd_big (variant 8, stride 1, plain output layout, bf16 in / out) with an extended epilogue -- any of:
+ *   relu_bits    out: one bit per output element, (stored value) > 0, unit_relu_bits_bytes(M, ldy) bytes, ldy % 64 == 0. Layout = the
+ *                     epilogue's own order (one 16-byte store per lane and 128-row x 64-channel wave tile): 16-byte word
+ *                     [(m / 128) * (ldy / 64) + n / 64][lane], lane = (m % 8) * 8 + (n % 64) / 8, bit ((m % 128) / 8) * 8 + n % 8;
+ *   mask_bits    in : same layout and geometry; the output is zeroed where the bit is clear (instead of a bf16 mask_ref tensor);
+ *   pool_partial out: global average pool over `pool_rows` (>= 44) consecutive output rows fused into the conv -- the
+ *                     x.mean(dim=[2,3]) of Res5BoxHead (/root/reference/modeling/roi_heads/box_head.py:80) without writing the
+ *                     res5 map: fp32 [ceil(M/128)][4][ldy] partial sums (unit_conv_pool_partial_floats), folded per RoI in a fixed
+ *                     order by unit_pool_finish (no atomics: bit-reproducible). y may be NULL when pool_partial is given.
+ * unit_avgpool_bwd_bits: g[m][n] = bit(roi_offset * rows + m, n) ? dfeat[m / rows][n] / rows : 0 for R RoIs starting at RoI
+ * `roi_offset` of the map the bits belong to: the backward of (average pool o ReLU) from relu_bits (= unit_global_avgpool_bwd_relu
+ * without reading the map). */
+size_t unit_conv_pool_partial_floats(int M, int ldy);
+size_t unit_relu_bits_bytes(int M, int ldy);
+int unit_conv2d_fwd_big_ex(const void* x, const void* w, void* y, const float* bias, const void* residual, const unsigned char* mask_bits,
+                           unsigned char* relu_bits, float* pool_partial, int pool_rows, int N, int H, int W, int C, int K, int R, int S,
+                           int pad, int ldy, int relu, void* stream);
+int unit_pool_finish(const float* partial, int R, int rows, int ldy, int K, void* out, int ldo, int out_dtype, void* stream);
+int unit_avgpool_bwd_bits(const void* dfeat, const unsigned char* bits, int R, int roi_offset, int rows, int C, void* g, void* stream);
 /* mid-size variant (4 waves, LDS-DMA, two workgroups per CU) for the backbone layers; bf16 inputs, C % 64 == 0;
  * tile: 0 = 128x128, 1 = 64 pixels x 128 channels, 2 = 128 x 64, 3 = 128x128 with in-workgroup split-K (few-tile layers) */
 int unit_conv2d_fwd_mid(const void* x, const void* w, void* y, const float* bias, const void* residual, const void* mask_ref,

@@ -901,3 +901,58 @@ def test_conv_halo7_kernel(dev, case):
     y2 = o.conv2d(xd, wd, k, 3, 3, 1, 1, bias=bias.to(dev), residual=res.to(dev), mask_ref=msk.to(dev), relu=True, ldy=ldy, tile_cfg=14)
     y1 = o.conv2d(xd, wd, k, 3, 3, 1, 1, bias=bias.to(dev), residual=res.to(dev), mask_ref=msk.to(dev), relu=True, ldy=ldy, tile_cfg=13)
     assert torch.allclose(y2.float().cpu()[..., :k], y1.float().cpu()[..., :k], rtol=2e-2, atol=2e-2)
+
+
+@pytest.mark.parametrize("rois,c,k", [(37, 128, 256), (5, 64, 192), (1024, 512, 2048)])
+def test_conv_fused_pool_and_relu_bits(dev, rois, c, k):
+    """unit_conv2d_fwd_big_ex: the average pool over each RoI's 49 bins, the ReLU bit mask and the bit-mask input fused into the conv
+    epilogue against the separate kernels (same arithmetic per element: map and bits EXACT; pooled sums differ only in fp32
+    association) and against torch fp32."""
+    from unit_amd import ops as o
+    g = torch.Generator().manual_seed(rois + c)
+    x = (torch.randn(rois, 7, 7, c, generator=g)).to(dev).bfloat16()
+    w = (torch.randn(k, 1, 1, c, generator=g) * (1.0 / c) ** 0.5).to(dev).bfloat16()
+    res = torch.randn(rois, 7, 7, k, generator=g).to(dev).bfloat16()
+    bias = (torch.randn(k, generator=g) * 0.1).to(dev)
+    y_ref = o.conv2d(x, w, k, 1, 1, 1, 0, bias=bias, residual=res, relu=True, tile_cfg=16)
+    pooled_ref = o.global_avgpool(y_ref)
+    y, bits, pooled = o.conv2d_ex(x, w, k, 1, 1, 0, bias=bias, residual=res, relu=True, want_bits=True, pool_rows=49, want_y=True)
+    assert torch.equal(y, y_ref)
+    assert torch.equal(bits.unpack(), (y_ref.float() > 0).view(rois, 49, k))
+    exact = y_ref.float().view(rois, 49, k).mean(1)
+    assert torch.allclose(pooled.float(), exact, rtol=2 ** -8, atol=1e-6)              # one bf16 rounding of the exact mean
+    assert torch.allclose(pooled.float(), pooled_ref.float(), rtol=2 ** -7, atol=1e-6)
+    # without the map
+    y2, bits2, pooled2 = o.conv2d_ex(x, w, k, 1, 1, 0, bias=bias, residual=res, relu=True, want_bits=True, pool_rows=49, want_y=False)
+    assert y2 is None and torch.equal(bits2.unpack(), bits.unpack()) and torch.equal(pooled2, pooled)
+    # torch fp32 on the same bf16 operands
+    t = torch.nn.functional.conv2d(x.float().permute(0, 3, 1, 2), w.float().permute(0, 3, 1, 2), bias) + res.float().permute(0, 3, 1, 2)
+    t = torch.relu(t).mean(dim=[2, 3])
+    assert torch.allclose(pooled.float(), t, rtol=2e-2, atol=2e-2)
+    # bit mask as an input == bf16 mask tensor as an input
+    dy = torch.randn(rois, 7, 7, c, generator=g).to(dev).bfloat16()
+    a = o.conv2d(dy, w, k, 1, 1, 1, 0, residual=res, mask_ref=y_ref, tile_cfg=16)
+    b, _, _ = o.conv2d_ex(dy, w, k, 1, 1, 0, residual=res, mask_bits=bits)
+    assert torch.equal(a, b)
+    # backward of (pool o relu) from the bits
+    df = torch.randn(rois, k, generator=g).to(dev).bfloat16()
+    want = o.global_avgpool_bwd_relu(df, y_ref)
+    assert torch.equal(o.avgpool_bwd_bits(df, bits, 7, 7), want)
+    lo = rois // 3                                                  # a slice of the RoIs (the weak head backpropagates its weak half)
+    assert torch.equal(o.avgpool_bwd_bits(df[lo:].contiguous(), bits[lo:], 7, 7), want[lo:])
+
+
+def test_conv_fused_pool_is_reproducible(dev):
+    """two launches, one fed from a dirty allocator state: identical pooled features and bit masks (no atomics, no uninitialised reads)"""
+    from unit_amd import ops as o
+    g = torch.Generator().manual_seed(4)
+    for rois in (64, 96, 7):
+        x = torch.randn(rois, 7, 7, 512, generator=g).to(dev).bfloat16()
+        w = (torch.randn(2048, 1, 1, 512, generator=g) * 0.04).to(dev).bfloat16()
+        res = torch.randn(rois, 7, 7, 2048, generator=g).to(dev).bfloat16()
+        _, b0, p0 = o.conv2d_ex(x, w, 2048, 1, 1, 0, residual=res, relu=True, want_bits=True, pool_rows=49, want_y=False)
+        junk = [torch.full((1 << 22,), float("nan"), device=dev) for _ in range(4)]
+        del junk
+        _, b1, p1 = o.conv2d_ex(x, w, 2048, 1, 1, 0, residual=res, relu=True, want_bits=True, pool_rows=49, want_y=False)
+        assert torch.equal(p0, p1) and torch.equal(b0.unpack(), b1.unpack())
+        assert torch.isfinite(p0.float()).all()

@@ -20,15 +20,39 @@ template <int FA> struct EpiCfg {
   static constexpr int BYTES = 16 * PITCH;      // scratch per wave
 };
 
+// Optional extras of the epilogue (EX = true instantiations; conv_igemm256p8.hip):
+//   relu_bits   : one bit per output element, (stored value) > 0, in the epilogue's own order so that a lane writes its 16 rows x 8
+//                 channels as ONE 16-byte store per wave tile (byte stores, one per row pass, cost as many store instructions as the
+//                 map itself did): 16-byte word [(m / 128) * (ldy / 64) + n / 64][lane], lane = (m % 8) * 8 + (n % 64) / 8,
+//                 bit ((m % 128) / 8) * 8 + n % 8 of the word (relu_bit_index() below). 1/16 of the bytes of the bf16 map.
+//   mask_bits   : the same layout as an INPUT: v = bit ? v : 0 (dgrad epilogue on the same geometry), replaces mask_ref.
+//   pool_partial: per-RoI channel sums of the (bf16-rounded) outputs, for a global average pool over `pool_rows` consecutive
+//                 rows (49 = 7x7 bins) fused into the conv: fp32 [wave tile of FB*16 rows][segment 0..3][ldy], a wave tile's rows
+//                 cover at most 4 RoIs; unit_pool_finish adds the <= 2 pieces of a RoI in fixed order. Deterministic (no atomics).
+//                 With y == nullptr the output tensor itself is never written.
+// (m, n) -> (16-byte word index, bit inside the word) of relu_bits for an [M][ldy] map, ldy % 64 == 0
+__host__ __device__ __forceinline__ void relu_bit_index(long m, int n, int ldy, long& word, int& bit) {
+  word = ((m >> 7) * (ldy >> 6) + (n >> 6)) * 64 + ((m & 7) * 8 + ((n & 63) >> 3));
+  bit = (int)((m & 127) >> 3) * 8 + (n & 7);
+}
+
+struct EpiExtra {
+  unsigned char* relu_bits;
+  const unsigned char* mask_bits;
+  float* pool_partial;
+  int pool_rows;
+};
+
 // acc[a][b] = 16x16 tile (channels a*16.., pixel rows b*16..) of this wave; m_w / n_w = first pixel row / channel of the
 // wave tile; scr = this wave's scratch (EpiCfg<FA>::BYTES, 16-B aligned). Requires p.ldy % 8 == 0.
-template <int FA, int FB, typename Args>
-__device__ __forceinline__ void epilogue_rows_bf16(const f32x4 (&acc)[FA][FB], char* scr, int m_w, int n_w, const Args& p, int lane) {
+// EX: `pool` = this wave's 8 KB LDS area [4 segments][8 row classes][64 channels] fp32 (FA == 4 only); plain output layout only.
+template <int FA, int FB, bool EX, typename Args>
+__device__ __forceinline__ void epilogue_rows_bf16_impl(const f32x4 (&acc)[FA][FB], char* scr, float* pool, int m_w, int n_w, const Args& p, int lane) {
   typedef EpiCfg<FA> E;
   bf16_t* __restrict__ Y = (bf16_t*)p.y;
   const bf16_t* __restrict__ Rz = (const bf16_t*)p.residual;
-  const bf16_t* __restrict__ Mk = (const bf16_t*)p.mask_ref;
-  const bool plain = (p.oy_mul == 1 && p.OHf == p.OH && p.OWf == p.OW);
+  const bf16_t* __restrict__ Mk = EX ? nullptr : (const bf16_t*)p.mask_ref;
+  const bool plain = EX || (p.oy_mul == 1 && p.OHf == p.OH && p.OWf == p.OW);
   const int frow = lane & 15, fq = lane >> 4;
   const int rr = lane / E::LPR, c0 = (lane % E::LPR) * 8;
   const int n = n_w + c0;
@@ -36,6 +60,37 @@ __device__ __forceinline__ void epilogue_rows_bf16(const f32x4 (&acc)[FA][FB], c
   float bias8[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) bias8[j] = (p.bias && n + j < p.K) ? p.bias[n + j] : 0.f;
+
+  const unsigned char* __restrict__ Mb = nullptr;
+  unsigned char* __restrict__ Rb = nullptr;
+  float* __restrict__ Pp = nullptr;
+  int prow = 1, roi0 = 0, cur_roi = 0, nxt_edge = 0;
+  long bword = 0;
+  u32x4 mw = {0u, 0u, 0u, 0u}, rw = {0u, 0u, 0u, 0u};
+  float run[8];
+  if constexpr (EX) {
+    static_assert(FA == 4, "pooling epilogue: 64-channel wave tiles");
+    static_assert(FB <= 8 && E::NP == 2, "bit words: 16 row passes of 8 rows per wave tile");
+    Mb = p.ex.mask_bits; Rb = p.ex.relu_bits; Pp = p.ex.pool_partial; prow = p.ex.pool_rows > 0 ? p.ex.pool_rows : 1;
+    bword = (((long)(m_w >> 7)) * (p.ldy >> 6) + (n_w >> 6)) * 64 + lane;          // this lane's word of the wave tile (m_w % 128 == 0)
+    if (Mb && n_ok && m_w < p.M) mw = reinterpret_cast<const u32x4*>(Mb)[bword];
+    if (Pp) {
+      f32x4 z = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int i = 0; i < 8; ++i) *reinterpret_cast<f32x4*>(pool + (i * 64 + lane) * 4) = z;      // 4 x 8 x 64 floats
+      roi0 = m_w / prow;
+      int m_first = m_w + rr;                       // this lane's first row
+      cur_roi = m_first / prow;
+      nxt_edge = (cur_roi + 1) * prow;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) run[j] = 0.f;
+    }
+  }
+  auto flush = [&]() {
+    float* d = pool + (((cur_roi - roi0) * 8 + rr) * 64 + c0);
+    *reinterpret_cast<f32x4*>(d) = f32x4{run[0], run[1], run[2], run[3]};
+    *reinterpret_cast<f32x4*>(d + 4) = f32x4{run[4], run[5], run[6], run[7]};
+  };
 
   struct Pre { long off[E::NP]; bool ok[E::NP]; bf16x8 res[E::NP], msk[E::NP]; };
   auto prefetch = [&](int b, Pre& q) {
@@ -82,11 +137,62 @@ __device__ __forceinline__ void epilogue_rows_bf16(const f32x4 (&acc)[FA][FB], c
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] = (float)cur.msk[h][j] > 0.f ? v[j] : 0.f;
       }
+      if constexpr (EX) {
+        if (Mb) {
+          unsigned mbits = mw[(b * 2 + h) >> 2] >> (((b * 2 + h) & 3) * 8);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[j] = ((mbits >> j) & 1u) ? v[j] : 0.f;
+        }
+      }
       bf16x8 o;
 #pragma unroll
       for (int j = 0; j < 8; ++j) o[j] = (bf16_t)v[j];
-      if (cur.ok[h]) *reinterpret_cast<bf16x8*>(Y + cur.off[h]) = o;
+      if constexpr (EX) {
+        if (Rb && cur.ok[h]) {
+          unsigned bits = 0;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) bits |= ((float)o[j] > 0.f ? 1u : 0u) << j;      // the stored (rounded) value, as a mask_ref read would see it
+          rw[(b * 2 + h) >> 2] |= bits << (((b * 2 + h) & 3) * 8);
+        }
+        if (Pp && cur.ok[h]) {
+          int m = m_w + b * 16 + r;
+          if (m >= nxt_edge) {                     // this lane's rows entered the next RoI (rows only grow: at most 3 times)
+            flush();
+            cur_roi = m / prow; nxt_edge = (cur_roi + 1) * prow;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) run[j] = 0.f;
+          }
+#pragma unroll
+          for (int j = 0; j < 8; ++j) run[j] += (float)o[j];
+        }
+        if (Y && cur.ok[h]) *reinterpret_cast<bf16x8*>(Y + cur.off[h]) = o;
+      } else {
+        if (cur.ok[h]) *reinterpret_cast<bf16x8*>(Y + cur.off[h]) = o;
+      }
     }
     if (b + 1 < FB) cur = nxt;
   }
+  if constexpr (EX) {
+    if (Rb && n_ok && m_w < p.M) reinterpret_cast<u32x4*>(Rb)[bword] = rw;      // (a wave tile past the last row owns no word)
+    if (Pp) {
+      if (n_ok && m_w + rr < p.M) flush();
+      // row classes -> one sum per (segment, channel), fixed order; lane = channel of the wave tile
+      int last_row = m_w + FB * 16 - 1; if (last_row >= p.M) last_row = p.M - 1;
+      int nseg = last_row >= m_w ? last_row / prow - roi0 + 1 : 0;
+      long wt = (long)(m_w / (FB * 16));
+      if (n_w + lane < p.ldy) {
+        for (int sgm = 0; sgm < nseg; ++sgm) {
+          float t = 0.f;
+#pragma unroll
+          for (int q = 0; q < 8; ++q) t += pool[(sgm * 8 + q) * 64 + lane];
+          Pp[(wt * 4 + sgm) * p.ldy + n_w + lane] = t;
+        }
+      }
+    }
+  }
+}
+
+template <int FA, int FB, typename Args>
+__device__ __forceinline__ void epilogue_rows_bf16(const f32x4 (&acc)[FA][FB], char* scr, int m_w, int n_w, const Args& p, int lane) {
+  epilogue_rows_bf16_impl<FA, FB, false>(acc, scr, nullptr, m_w, n_w, p, lane);
 }

@@ -3,6 +3,8 @@
 #pragma once
 #include "common.h"
 
+#include "conv_epilogue.h"
+
 struct Conv256Args {
   const void* x; const void* w; void* y;
   const float* bias; const void* residual; const void* mask_ref;
@@ -14,6 +16,8 @@ struct Conv256Args {
   int Kgemm, M;
   int tiles_m, tiles_n;
   unsigned x_bytes, w_bytes;
+  EpiExtra ex;      // conv_epilogue.h; all-null unless launched through unit_conv2d_fwd_big_ex
+  int ex_on;
 };
 
 // LDS image of an operand stage: [row][128 B = 64 k]; 16-B chunks XOR-swizzled with (row>>1)&7 (applied to the SOURCE

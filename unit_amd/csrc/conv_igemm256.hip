@@ -594,6 +594,7 @@ extern "C" int unit_conv2d_fwd_big(const void* x, const void* w, void* y, const 
   size_t xb = (size_t)N * H * W * C * 2, wb = (size_t)K * R * S * C * 2;
   UNIT_CHECK_ARG(xb < 0xFFFFFFF0ull && wb < 0xFFFFFFF0ull, "conv_big: operand larger than 4 GiB");
   a.x_bytes = (unsigned)xb; a.w_bytes = (unsigned)wb;
+  a.ex = EpiExtra{nullptr, nullptr, nullptr, 0}; a.ex_on = 0;
   if (a.M == 0 || K == 0) return UNIT_OK;
   hipStream_t st = (hipStream_t)stream;
   // variant 0 / 4: one barrier per k-tile, 256-row tiles; 3: 224-row tiles; 5: 224 or 256 rows, whichever needs fewer
@@ -646,4 +647,95 @@ extern "C" int unit_conv2d_fwd_big(const void* x, const void* w, void* y, const 
   }
   unit_set_error("conv_big: unsupported out dtype");
   return UNIT_ERR_UNSUPPORTED;
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Conv with the extended epilogue (conv_epilogue.h EpiExtra): 1x1 / 3x3 stride-1 bf16 conv on the phase-interleaved 256x256
+// kernel with any of  (a) relu_bits out: one bit per output element, (b) mask_bits in instead of a bf16 mask tensor,
+// (c) pool_partial: global average pool over `pool_rows` consecutive output rows fused into the epilogue; y may then be null.
+// Reference: box_head.py:80 (x.mean(dim=[2,3]) after the last Res5 block) and the ReLU backward of the Bottleneck outputs.
+extern "C" size_t unit_conv_pool_partial_floats(int M, int ldy) { return (size_t)cdiv(M, 128) * 4 * (size_t)ldy; }
+
+extern "C" int unit_conv2d_fwd_big_ex(const void* x, const void* w, void* y, const float* bias, const void* residual,
+                                      const unsigned char* mask_bits, unsigned char* relu_bits, float* pool_partial, int pool_rows,
+                                      int N, int H, int W, int C, int K, int R, int S, int pad, int ldy, int relu, void* stream) {
+  UNIT_CHECK_ARG(C % 64 == 0, "conv_big_ex: C must be a multiple of 64");
+  UNIT_CHECK_ARG(ldy % 8 == 0 && ldy >= K, "conv_big_ex: ldy must be a multiple of 8 and >= K");
+  UNIT_CHECK_ARG(y != nullptr || pool_partial != nullptr, "conv_big_ex: no output requested");
+  UNIT_CHECK_ARG((mask_bits == nullptr && relu_bits == nullptr) || ldy % 64 == 0, "conv_big_ex: bit masks need ldy % 64 == 0");
+  UNIT_CHECK_ARG(pool_partial == nullptr || pool_rows >= 44, "conv_big_ex: a 128-row wave tile must span at most 4 pooling segments");
+  UNIT_CHECK_ARG(((uintptr_t)x % 16 == 0) && ((uintptr_t)w % 16 == 0) && ((uintptr_t)y % 16 == 0), "conv_big_ex: 16B alignment");
+  int OH = H + 2 * pad - R + 1, OW = W + 2 * pad - S + 1;
+  UNIT_CHECK_ARG(OH > 0 && OW > 0, "conv_big_ex: empty output");
+  Conv256Args a;
+  a.x = x; a.w = w; a.y = y; a.bias = bias; a.residual = residual; a.mask_ref = nullptr;
+  a.N = N; a.H = H; a.W = W; a.C = C; a.K = K; a.R = R; a.S = S; a.stride = 1; a.pad = pad;
+  a.OH = OH; a.OW = OW; a.ldy = ldy; a.oy_mul = 1; a.OHf = OH; a.OWf = OW; a.relu = relu;
+  a.Kgemm = R * S * C; a.M = N * OH * OW;
+  size_t xb = (size_t)N * H * W * C * 2, wb = (size_t)K * R * S * C * 2;
+  UNIT_CHECK_ARG(xb < 0xFFFFFFF0ull && wb < 0xFFFFFFF0ull, "conv_big_ex: operand larger than 4 GiB");
+  a.x_bytes = (unsigned)xb; a.w_bytes = (unsigned)wb;
+  a.ex = EpiExtra{relu_bits, mask_bits, pool_partial, pool_rows}; a.ex_on = 1;
+  if (a.M == 0 || K == 0) return UNIT_OK;
+  return unit_conv256_p8_launch(a, UNIT_BF16, true, false, (hipStream_t)stream);
+}
+
+// pooled[r][n] = (1 / rows) * sum of the partial sums of RoI r: its rows [r*rows, (r+1)*rows) lie in at most two 128-row wave tiles
+template <typename T>
+__global__ void pool_finish_kernel(const float* __restrict__ part, int R, int rows, int ldy, int K, T* __restrict__ out, int ldo) {
+  int r = blockIdx.x;
+  int w0 = (r * rows) / 128, w1 = (r * rows + rows - 1) / 128;
+  float inv = (float)rows;                     // divided, not multiplied by a reciprocal: unit_global_avgpool_fwd's arithmetic
+  for (int n = threadIdx.x; n < K; n += blockDim.x) {
+    float t = 0.f;
+    for (int wt = w0; wt <= w1; ++wt) {
+      int seg = r - (wt * 128) / rows;
+      t += part[((size_t)wt * 4 + seg) * ldy + n];
+    }
+    out[(size_t)r * ldo + n] = (T)(t / inv);
+  }
+}
+
+extern "C" int unit_pool_finish(const float* partial, int R, int rows, int ldy, int K, void* out, int ldo, int out_dtype, void* stream) {
+  UNIT_CHECK_ARG(rows >= 44 && rows <= 128, "pool_finish: 44 <= rows <= 128");
+  if (R == 0) return UNIT_OK;
+  hipStream_t st = (hipStream_t)stream;
+  if (out_dtype == UNIT_BF16) pool_finish_kernel<bf16_t><<<R, 256, 0, st>>>(partial, R, rows, ldy, K, (bf16_t*)out, ldo);
+  else pool_finish_kernel<float><<<R, 256, 0, st>>>(partial, R, rows, ldy, K, (float*)out, ldo);
+  UNIT_LAUNCH_CHECK();
+  return UNIT_OK;
+}
+
+// g[m][n] = bit(m0 + m, n) ? dfeat[m / rows][n] / rows : 0 -- backward of (global average pool o ReLU) from the bit mask the fused
+// forward left behind (replaces unit_global_avgpool_bwd_relu's read of the whole output map). m0 = first row of this slice inside
+// the map the bits were written for (the weak head backpropagates only its weak RoIs).
+__global__ void avgpool_bwd_bits_kernel(const bf16_t* __restrict__ dfeat, const unsigned char* __restrict__ bits, long M, long m0, int rows,
+                                        int C, bf16_t* __restrict__ g) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;          // one lane = 8 channels of one row
+  int cb = C / 8;
+  if (i >= M * cb) return;
+  long m = i / cb; int c0 = (int)(i - m * cb) * 8;
+  long word; int bit;
+  relu_bit_index(m0 + m, c0, C, word, bit);
+  unsigned b = bits[word * 16 + (bit >> 3)];
+  bf16x8 d = *reinterpret_cast<const bf16x8*>(dfeat + (m / rows) * C + c0);
+  float inv = (float)rows;
+  bf16x8 o;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) o[j] = (bf16_t)(((b >> j) & 1u) ? (float)d[j] / inv : 0.f);      // = unit_global_avgpool_bwd_relu's arithmetic
+  *reinterpret_cast<bf16x8*>(g + m * C + c0) = o;
+}
+
+extern "C" size_t unit_relu_bits_bytes(int M, int ldy) { return (size_t)cdiv(M, 128) * 128 * (size_t)(ldy / 8); }
+
+extern "C" int unit_avgpool_bwd_bits(const void* dfeat, const unsigned char* bits, int R, int roi_offset, int rows, int C, void* g, void* stream) {
+  UNIT_CHECK_ARG(C % 64 == 0, "avgpool_bwd_bits: C % 64");
+  long M = (long)R * rows;
+  if (M == 0) return UNIT_OK;
+  long n = M * (C / 8);
+  avgpool_bwd_bits_kernel<<<(unsigned)cdiv(n, 256L), 256, 0, (hipStream_t)stream>>>((const bf16_t*)dfeat, bits, M, (long)roi_offset * rows, rows, C,
+                                                                                    (bf16_t*)g);
+  UNIT_LAUNCH_CHECK();
+  return UNIT_OK;
 }

@@ -313,6 +313,13 @@ __global__ void __launch_bounds__(512, 2) conv_igemm256_p8_kernel(Conv256Args p)
   if constexpr (sizeof(TO) == 2) {
     if ((p.ldy & 7) == 0) {          // row-major epilogue through a wave-private LDS scratch (conv_epilogue.h)
       __syncthreads();               // every wave is done with the operand stages
+      if constexpr (RM) {
+        if (p.ex_on) {               // fused average pool / ReLU bit mask / bit-mask input (unit_conv2d_fwd_big_ex)
+          epilogue_rows_bf16_impl<4, FBT, true>(acc, smem + wid * EpiCfg<4>::BYTES, (float*)(smem + 36864 + wid * 8192), m0 + wm * (FBT * 16),
+                                                n0 + wn * 64, p, lane);
+          return;
+        }
+      }
       epilogue_rows_bf16<4, FBT>(acc, smem + wid * EpiCfg<4>::BYTES, m0 + wm * (FBT * 16), n0 + wn * 64, p, lane);
       return;
     }

@@ -158,11 +158,19 @@ class BottleneckBlock(nn.Module):
     def convs(self):
         return [c for c in (self.conv1, self.conv2, self.conv3, self.shortcut) if c is not None]
 
-    def fwd(self, x, save=False, stride=None):
+    def fwd(self, x, save=False, stride=None, pool_rows=0):
+        """pool_rows > 0 (last block of a Res5 head): the block's output map is only ever averaged over each RoI's `pool_rows` bins
+        (box_head.py:80) and, in the backward, tested for > 0 -- conv3's epilogue then produces the pooled features and a bit mask
+        and never writes the map: returns ((pooled, bits | None), ctx) instead of (map, ctx)"""
         st = self.stride if stride is None else stride
         y1 = self.conv1.fwd(x, relu=True, stride=st)
         y2 = self.conv2.fwd(y1, relu=True)
         sc = self.shortcut.fwd(x, stride=st) if self.shortcut is not None else x
+        if pool_rows:
+            c3 = self.conv3
+            _, bits, pooled = ops.conv2d_ex(y2, c3.wf, c3.cout, 1, 1, 0, bias=c3.shift, residual=sc, relu=True, want_bits=save,
+                                            pool_rows=pool_rows, want_y=False)
+            return (pooled, bits), ((x, y1, y2, st) if save else None)
         out = self.conv3.fwd(y2, relu=True, residual=sc)
         return out, ((x, y1, y2, st) if save else None)
 
@@ -190,10 +198,11 @@ class ResStage(nn.Sequential):
         blocks = [BottleneckBlock(cin if i == 0 else cout, cout, bottleneck, first_stride if i == 0 else 1) for i in range(num_blocks)]
         super().__init__(*blocks)
 
-    def fwd(self, x, save=False, first_stride=None):
+    def fwd(self, x, save=False, first_stride=None, pool_rows=0):
         ctxs = []
         for i, b in enumerate(self):
-            x, c = b.fwd(x, save, stride=first_stride if i == 0 else None)
+            last = i == len(self) - 1
+            x, c = b.fwd(x, save, stride=first_stride if i == 0 else None, **({"pool_rows": pool_rows} if (last and pool_rows) else {}))
             ctxs.append(c)
         return x, ctxs
 

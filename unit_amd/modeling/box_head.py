@@ -44,6 +44,14 @@ class Res5BoxHead(nn.Module):
         Res5BoxHeadWithMask hands the un-pooled map to the mask head, roi_heads.py:691-710, and its mean to the predictor,
         roi_heads.py:735-744)."""
         first_stride = 1 if pooled.shape[1] == 7 else 2
+        last = self.res5[-1].conv3
+        if (ops.FUSE_EPILOGUE and self.do_mean and not keep_map and pooled.shape[0] > 0
+                and ops.conv_ex_supported(pooled.dtype, last.cin, last.cout)):
+            # the res5 map is consumed only by the mean (forward) and as a ReLU mask (backward): conv3's epilogue of the last block
+            # emits the pooled features and one bit per element instead of the map (ctx[1] is then an ops.ReluBits)
+            bins = (pooled.shape[1] // first_stride) * (pooled.shape[2] // first_stride)
+            (feat, bits), ctxs = self.res5.fwd(pooled, save=save, first_stride=first_stride, pool_rows=bins)
+            return feat, ((ctxs, bits) if save else None)
         y, ctxs = self.res5.fwd(pooled, save=save, first_stride=first_stride)
         return ops.global_avgpool(y), ((ctxs, y) if (save or keep_map) else None)
 
@@ -54,7 +62,12 @@ class Res5BoxHead(nn.Module):
         if row_slice is not None:
             y = y[row_slice]
             ctxs = [tuple(t[row_slice] if torch.is_tensor(t) else t for t in c) for c in ctxs]
-        g = ops.global_avgpool_bwd_relu(dfeat, y)
+        if isinstance(y, ops.ReluBits):          # fused forward: y is the ReLU bit mask of the map
+            assert map_grad_hook is None
+            side = int(round(y.bins ** 0.5))
+            g = ops.avgpool_bwd_bits(dfeat, y, side, side)
+        else:
+            g = ops.global_avgpool_bwd_relu(dfeat, y)
         if map_grad_hook is not None:
             map_grad_hook(g, y)
         return self.res5.bwd(ctxs, g, need_dx=True, mask_input=False)

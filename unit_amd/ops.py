@@ -5,6 +5,7 @@ dtype bookkeeping. Every arithmetic step is one of the hand-written HIP kernels;
 a missing extension or a CPU tensor raises.
 """
 import ctypes
+import os
 import math
 
 import torch
@@ -225,6 +226,81 @@ def conv2d(x, w, k, r, s, stride=1, pad=0, bias=None, residual=None, mask_ref=No
         prof.setdefault("conv_igemm256" if (big and mid < 0) else ("conv_igemm_dma" if mid >= 0 else "conv_igemm"), []).append(
             (e0, e1, 2.0 * n * oh * ow * k * r * s * c, nbytes))
     return out
+
+
+FUSE_EPILOGUE = os.environ.get("UNIT_FUSE_EPILOGUE", "1") != "0"          # Res5 heads: average pool + ReLU bit mask inside the last conv's epilogue (conv2d_ex); False = separate kernels
+
+
+def conv_ex_supported(dtype, c, ldy):
+    return dtype == torch.bfloat16 and c % 64 == 0 and ldy % 64 == 0
+
+
+class ReluBits:
+    """(map > 0) of an [R, bins, C] activation as one bit per element in the conv epilogue's order (include/unit_hip.h,
+    unit_conv2d_fwd_big_ex); `self[a:b]` = the RoIs a..b of it (same storage, RoI offset)."""
+
+    def __init__(self, data, r, bins, c, roi0=0):
+        self.data, self.r, self.bins, self.c, self.roi0 = data, r, bins, c, roi0
+
+    def __getitem__(self, sl):
+        start, stop, step = sl.indices(self.r)
+        assert step == 1
+        return ReluBits(self.data, stop - start, self.bins, self.c, self.roi0 + start)
+
+    def unpack(self):
+        """-> bool [r, bins, c] (tests)"""
+        dev = self.data.device
+        m = torch.arange(self.roi0 * self.bins, (self.roi0 + self.r) * self.bins, device=dev).view(-1, 1)
+        n = torch.arange(self.c, device=dev).view(1, -1)
+        word = ((m >> 7) * (self.c >> 6) + (n >> 6)) * 64 + ((m & 7) * 8 + ((n & 63) >> 3))
+        byte = self.data[word * 16 + ((m & 127) >> 3)]
+        return ((byte.int() >> (n & 7)) & 1).bool().view(self.r, self.bins, self.c)
+
+
+def conv2d_ex(x, w, k, r, s, pad=0, bias=None, residual=None, relu=False, mask_bits=None, want_bits=False, pool_rows=0, want_y=True):
+    """stride-1 bf16 conv on the 256x256 kernel with the extended epilogue (unit_conv2d_fwd_big_ex): returns (y | None, ReluBits |
+    None, pooled [N, k] | None). pool_rows: must be OH*OW -- global average pool of each image (= RoI) fused; want_y=False then
+    skips writing the map. mask_bits: ReluBits of an [N, OH*OW, k] map (RoI offset 0)."""
+    n, h, wd, c = x.shape
+    oh, ow = conv_out_size(h, wd, r, s, 1, pad)
+    ldy = k
+    assert conv_ex_supported(x.dtype, c, ldy), "conv2d_ex: bf16, C % 64 == 0, K % 8 == 0"
+    m = n * oh * ow
+    y = torch.empty((n, oh, ow, ldy), dtype=x.dtype, device=x.device) if want_y else None
+    bits = None
+    if want_bits:
+        bits = ReluBits(torch.empty(lib().unit_relu_bits_bytes(m, ldy), dtype=torch.uint8, device=x.device), n, oh * ow, k)
+    if mask_bits is not None:
+        assert mask_bits.roi0 == 0 and mask_bits.r * mask_bits.bins == m and mask_bits.c == k
+    part = None
+    if pool_rows:
+        assert pool_rows == oh * ow
+        part = torch.empty(lib().unit_conv_pool_partial_floats(m, ldy), dtype=torch.float32, device=x.device)
+    prof = PROFILER
+    if prof is not None:
+        e0 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+    check(lib().unit_conv2d_fwd_big_ex(_p(x), _p(w), _p(y), _p(bias), _p(residual), _p(mask_bits.data if mask_bits is not None else None),
+                                       _p(bits.data if bits is not None else None), _p(part), pool_rows,
+                                       n, h, wd, c, k, r, s, pad, ldy, int(relu), _s()), "unit_conv2d_fwd_big_ex")
+    if prof is not None:
+        e1 = torch.cuda.Event(enable_timing=True)
+        e1.record()
+        nbytes = (x.numel() + w.numel()) * 2 + m * ldy * 2 * (int(want_y) + (residual is not None)) + (m * ldy // 8) * (int(want_bits) + (mask_bits is not None))
+        prof.setdefault("conv_igemm256", []).append((e0, e1, 2.0 * m * k * r * s * c, nbytes))
+    pooled = None
+    if pool_rows:
+        pooled = torch.empty((n, k), dtype=x.dtype, device=x.device)
+        check(lib().unit_pool_finish(_p(part), n, pool_rows, ldy, k, _p(pooled), k, dt(x.dtype), _s()), "unit_pool_finish")
+    return y, bits, pooled
+
+
+def avgpool_bwd_bits(dfeat, bits, ph, pw):
+    """dfeat [R,C] bf16, bits: ReluBits of R RoIs -> g [R,PH,PW,C] = bit ? dfeat / (PH*PW) : 0"""
+    assert bits.bins == ph * pw and bits.r == dfeat.shape[0] and bits.c == dfeat.shape[1]
+    g = torch.empty((bits.r, ph, pw, bits.c), dtype=dfeat.dtype, device=dfeat.device)
+    check(lib().unit_avgpool_bwd_bits(_p(dfeat), _p(bits.data), bits.r, bits.roi0, bits.bins, bits.c, _p(g), _s()), "avgpool_bwd_bits")
+    return g
 
 
 def wgrad_big_variant(v):
