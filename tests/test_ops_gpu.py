@@ -956,3 +956,38 @@ def test_conv_fused_pool_is_reproducible(dev):
         _, b1, p1 = o.conv2d_ex(x, w, 2048, 1, 1, 0, residual=res, relu=True, want_bits=True, pool_rows=49, want_y=False)
         assert torch.equal(p0, p1) and torch.equal(b0.unpack(), b1.unpack())
         assert torch.isfinite(p0.float()).all()
+
+
+@pytest.mark.parametrize("rois,lo", [(128, 0), (256, 128), (40, 13)])
+def test_res5_head_fused_epilogues_equal_separate_kernels(dev, rois, lo):
+    """Res5BoxHead in bf16 with the fused epilogues (average pool + ReLU bit masks inside the convs) against the same head with the
+    separate kernels: pooled features within one bf16 rounding (fp32 association of the 49-row sums), and -- fed the same feature
+    gradient -- a BIT-IDENTICAL backward (bit masks == (map > 0); RoI slice offsets that are / are not whole 128-row wave tiles)."""
+    from unit_amd import ops as o
+    from unit_amd.modeling.box_head import Res5BoxHead
+    torch.manual_seed(0)
+    head = Res5BoxHead().to(dev)
+    for c in (c for b in head.res5 for c in b.convs()):
+        c.norm.weight.uniform_(0.5, 1.5)
+        c.norm.bias.uniform_(-0.2, 0.2)
+    head.prepare(torch.bfloat16, 0)
+    pooled = torch.randn(rois, 7, 7, 1024, device=dev).bfloat16()
+    dfeat = (torch.randn(rois - lo, 2048, device=dev) * 0.1).bfloat16()
+    out = {}
+    was = o.FUSE_EPILOGUE
+    try:
+        for fuse in (True, False):
+            o.FUSE_EPILOGUE = fuse
+            for p in head.parameters():
+                p.grad = None
+            feat, ctx = head.fwd(pooled, save=True)
+            assert isinstance(ctx[1], o.ReluBits) == fuse
+            dpool = head.bwd(ctx, dfeat, row_slice=slice(lo, rois) if lo else None)
+            out[fuse] = (feat, dpool, {n: p.grad.clone() for n, p in head.named_parameters() if p.grad is not None})
+    finally:
+        o.FUSE_EPILOGUE = was
+    assert torch.allclose(out[True][0].float(), out[False][0].float(), rtol=2 ** -7, atol=1e-6)
+    assert torch.equal(out[True][1], out[False][1])
+    assert out[True][2].keys() == out[False][2].keys() and len(out[True][2]) >= 10
+    for n, g in out[True][2].items():
+        assert torch.equal(g, out[False][2][n]), n

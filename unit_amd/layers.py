@@ -90,9 +90,15 @@ class Conv2d(_EpochOnLoad):
         return ops.conv2d(x, self.wf, self.cout, self.k, self.k, st, self.pad, bias=self.shift, residual=residual, relu=relu,
                           out_dtype=out_dtype)
 
-    def dgrad(self, dy, in_hw, mask_ref=None, residual=None, stride=None):
-        """d(loss)/d(input) [N,H,W,cin]; 1x1 stride-2: strided scatter into a zeroed full-resolution tensor."""
+    def dgrad(self, dy, in_hw, mask_ref=None, residual=None, stride=None, mask_bits=None):
+        """d(loss)/d(input) [N,H,W,cin]; 1x1 stride-2: strided scatter into a zeroed full-resolution tensor.
+        mask_bits: ops.ReluBits of the input (what mask_ref > 0 would give) -- read instead of mask_ref where the 256x256 kernel's
+        extended epilogue applies (1/16 of the mask bytes: 218 -> 180 us for the 512 -> 2048 dgrad + residual of a Res5 block)"""
         st = self.stride if stride is None else stride
+        if st == 1 and mask_bits is not None and ops.conv_ex_supported(dy.dtype, self.cout, self.cin):
+            mb = mask_bits.aligned()
+            if mb is not None:
+                return ops.conv2d_ex(dy, self.wd, self.cin, self.k, self.k, self.k - 1 - self.pad, residual=residual, mask_bits=mb)[0]
         if st == 1:
             return ops.conv2d(dy, self.wd, self.cin, self.k, self.k, 1, self.k - 1 - self.pad, residual=residual, mask_ref=mask_ref)
         assert self.k == 1, "strided dgrad is only needed for the 1x1 stride-2 convs of C4 ResNets"
@@ -158,7 +164,7 @@ class BottleneckBlock(nn.Module):
     def convs(self):
         return [c for c in (self.conv1, self.conv2, self.conv3, self.shortcut) if c is not None]
 
-    def fwd(self, x, save=False, stride=None, pool_rows=0):
+    def fwd(self, x, save=False, stride=None, pool_rows=0, x_bits=None, out_bits=False):
         """pool_rows > 0 (last block of a Res5 head): the block's output map is only ever averaged over each RoI's `pool_rows` bins
         (box_head.py:80) and, in the backward, tested for > 0 -- conv3's epilogue then produces the pooled features and a bit mask
         and never writes the map: returns ((pooled, bits | None), ctx) instead of (map, ctx)"""
@@ -170,12 +176,16 @@ class BottleneckBlock(nn.Module):
             c3 = self.conv3
             _, bits, pooled = ops.conv2d_ex(y2, c3.wf, c3.cout, 1, 1, 0, bias=c3.shift, residual=sc, relu=True, want_bits=save,
                                             pool_rows=pool_rows, want_y=False)
-            return (pooled, bits), ((x, y1, y2, st) if save else None)
+            return (pooled, bits), ((x, y1, y2, st, x_bits) if save else None)
+        if out_bits:       # the next block's backward reads (out > 0) as bits (Conv2d.dgrad mask_bits)
+            c3 = self.conv3
+            out, bits, _ = ops.conv2d_ex(y2, c3.wf, c3.cout, 1, 1, 0, bias=c3.shift, residual=sc, relu=True, want_bits=True)
+            return (out, bits), ((x, y1, y2, st, x_bits) if save else None)
         out = self.conv3.fwd(y2, relu=True, residual=sc)
-        return out, ((x, y1, y2, st) if save else None)
+        return out, ((x, y1, y2, st, x_bits) if save else None)
 
     def bwd(self, ctx, g, need_dx=True, mask_input=True):
-        x, y1, y2, st = ctx
+        x, y1, y2, st, x_bits = ctx
         self.conv3.wgrad(y2, g)
         dy2 = self.conv3.dgrad(g, y2.shape[1:3], mask_ref=y2)
         self.conv2.wgrad(y1, dy2)
@@ -190,7 +200,7 @@ class BottleneckBlock(nn.Module):
             dsc = self.shortcut.dgrad(g, hw, stride=st)
         else:
             dsc = g
-        return self.conv1.dgrad(dy1, hw, mask_ref=x if mask_input else None, residual=dsc, stride=st)
+        return self.conv1.dgrad(dy1, hw, mask_ref=x if mask_input else None, residual=dsc, stride=st, mask_bits=x_bits if mask_input else None)
 
 
 class ResStage(nn.Sequential):
@@ -198,11 +208,18 @@ class ResStage(nn.Sequential):
         blocks = [BottleneckBlock(cin if i == 0 else cout, cout, bottleneck, first_stride if i == 0 else 1) for i in range(num_blocks)]
         super().__init__(*blocks)
 
-    def fwd(self, x, save=False, first_stride=None, pool_rows=0):
+    def fwd(self, x, save=False, first_stride=None, pool_rows=0, out_bits=False):
+        """pool_rows / out_bits (Res5 heads, bf16): see BottleneckBlock.fwd -- the last block returns (pooled, bits) instead of its map;
+        the blocks before it also leave a ReLU bit mask of their output for the next block's backward"""
         ctxs = []
+        x_bits = None
         for i, b in enumerate(self):
             last = i == len(self) - 1
-            x, c = b.fwd(x, save, stride=first_stride if i == 0 else None, **({"pool_rows": pool_rows} if (last and pool_rows) else {}))
+            ob = out_bits and not last and ops.conv_ex_supported(x.dtype, b.conv3.cin, b.conv3.cout) and (i > 0 or (first_stride or b.stride) == 1)
+            x, c = b.fwd(x, save, stride=first_stride if i == 0 else None, pool_rows=pool_rows if last else 0, x_bits=x_bits, out_bits=ob)
+            x_bits = None
+            if ob:
+                x, x_bits = x
             ctxs.append(c)
         return x, ctxs
 

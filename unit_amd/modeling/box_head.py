@@ -50,7 +50,7 @@ class Res5BoxHead(nn.Module):
             # the res5 map is consumed only by the mean (forward) and as a ReLU mask (backward): conv3's epilogue of the last block
             # emits the pooled features and one bit per element instead of the map (ctx[1] is then an ops.ReluBits)
             bins = (pooled.shape[1] // first_stride) * (pooled.shape[2] // first_stride)
-            (feat, bits), ctxs = self.res5.fwd(pooled, save=save, first_stride=first_stride, pool_rows=bins)
+            (feat, bits), ctxs = self.res5.fwd(pooled, save=save, first_stride=first_stride, pool_rows=bins, out_bits=save)
             return feat, ((ctxs, bits) if save else None)
         y, ctxs = self.res5.fwd(pooled, save=save, first_stride=first_stride)
         return ops.global_avgpool(y), ((ctxs, y) if (save or keep_map) else None)
@@ -61,7 +61,7 @@ class Res5BoxHead(nn.Module):
         ctxs, y = ctx
         if row_slice is not None:
             y = y[row_slice]
-            ctxs = [tuple(t[row_slice] if torch.is_tensor(t) else t for t in c) for c in ctxs]
+            ctxs = [tuple(t[row_slice] if (torch.is_tensor(t) or isinstance(t, ops.ReluBits)) else t for t in c) for c in ctxs]
         if isinstance(y, ops.ReluBits):          # fused forward: y is the ReLU bit mask of the map
             assert map_grad_hook is None
             side = int(round(y.bins ** 0.5))

@@ -247,6 +247,14 @@ class ReluBits:
         assert step == 1
         return ReluBits(self.data, stop - start, self.bins, self.c, self.roi0 + start)
 
+    def aligned(self):
+        """the same RoIs as a ReluBits with RoI offset 0 (what a conv epilogue can read as mask_bits), or None when the offset is not
+        a whole number of 128-row wave tiles"""
+        m0 = self.roi0 * self.bins
+        if m0 % 128:
+            return None
+        return self if m0 == 0 else ReluBits(self.data[(m0 // 128) * (self.c // 64) * 1024:], self.r, self.bins, self.c, 0)
+
     def unpack(self):
         """-> bool [r, bins, c] (tests)"""
         dev = self.data.device
