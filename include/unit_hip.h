@@ -68,6 +68,10 @@ int unit_conv2d_fwd_big(const void* x, const void* w, void* y, const float* bias
  *                     x.mean(dim=[2,3]) of Res5BoxHead (/root/reference/modeling/roi_heads/box_head.py:80) without writing the
  *                     res5 map: fp32 [ceil(M/128)][4][ldy] partial sums (unit_conv_pool_partial_floats), folded per RoI in a fixed
  *                     order by unit_pool_finish (no atomics: bit-reproducible). y may be NULL when pool_partial is given.
+ *   x2 / C2         : a second input tensor of the same N, H, W for a 1x1 conv over the channel concatenation [x | x2], w = [K][C + C2], C2 a
+ *                     multiple of C: out = relu(conv3(y2) + shortcut(x)) of a Bottleneck block (detectron2 BottleneckBlock.forward,
+ *                     reached from box_head.py:65-75) as ONE GEMM -- the shortcut's output is never written and never read back as
+ *                     the residual; likewise conv1's dgrad + the shortcut's dgrad.
  * unit_avgpool_bwd_bits: g[m][n] = bit(roi_offset * rows + m, n) ? dfeat[m / rows][n] / rows : 0 for R RoIs starting at RoI
  * `roi_offset` of the map the bits belong to: the backward of (average pool o ReLU) from relu_bits (= unit_global_avgpool_bwd_relu
  * without reading the map). */
@@ -75,7 +79,7 @@ size_t unit_conv_pool_partial_floats(int M, int ldy);
 size_t unit_relu_bits_bytes(int M, int ldy);
 int unit_conv2d_fwd_big_ex(const void* x, const void* w, void* y, const float* bias, const void* residual, const unsigned char* mask_bits,
                            unsigned char* relu_bits, float* pool_partial, int pool_rows, int N, int H, int W, int C, int K, int R, int S,
-                           int pad, int ldy, int relu, void* stream);
+                           int pad, int ldy, int relu, const void* x2, int C2, void* stream);
 int unit_pool_finish(const float* partial, int R, int rows, int ldy, int K, void* out, int ldo, int out_dtype, void* stream);
 int unit_avgpool_bwd_bits(const void* dfeat, const unsigned char* bits, int R, int roi_offset, int rows, int C, void* g, void* stream);
 /* mid-size variant (4 waves, LDS-DMA, two workgroups per CU) for the backbone layers; bf16 inputs, C % 64 == 0;

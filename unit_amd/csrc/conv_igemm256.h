@@ -18,6 +18,9 @@ struct Conv256Args {
   unsigned x_bytes, w_bytes;
   EpiExtra ex;      // conv_epilogue.h; all-null unless launched through unit_conv2d_fwd_big_ex
   int ex_on;
+  // second input tensor of a 1x1 conv (conv_igemm256p8.hip only): k-tiles >= cb_split read x2 [M][ratio2 * cb_split * 64] -- the
+  // GEMM [x | x2] . [w_a ; w_b] in one launch (Bottleneck conv3 + shortcut; conv1 dgrad + shortcut dgrad). C = total channels.
+  const void* x2; unsigned x2_bytes; int cb_split, ratio2;
 };
 
 // LDS image of an operand stage: [row][128 B = 64 k]; 16-B chunks XOR-swizzled with (row>>1)&7 (applied to the SOURCE

@@ -595,6 +595,7 @@ extern "C" int unit_conv2d_fwd_big(const void* x, const void* w, void* y, const 
   UNIT_CHECK_ARG(xb < 0xFFFFFFF0ull && wb < 0xFFFFFFF0ull, "conv_big: operand larger than 4 GiB");
   a.x_bytes = (unsigned)xb; a.w_bytes = (unsigned)wb;
   a.ex = EpiExtra{nullptr, nullptr, nullptr, 0}; a.ex_on = 0;
+  a.x2 = nullptr; a.x2_bytes = 0; a.cb_split = 0; a.ratio2 = 1;
   if (a.M == 0 || K == 0) return UNIT_OK;
   hipStream_t st = (hipStream_t)stream;
   // variant 0 / 4: one barrier per k-tile, 256-row tiles; 3: 224-row tiles; 5: 224 or 256 rows, whichever needs fewer
@@ -659,8 +660,13 @@ extern "C" size_t unit_conv_pool_partial_floats(int M, int ldy) { return (size_t
 
 extern "C" int unit_conv2d_fwd_big_ex(const void* x, const void* w, void* y, const float* bias, const void* residual,
                                       const unsigned char* mask_bits, unsigned char* relu_bits, float* pool_partial, int pool_rows,
-                                      int N, int H, int W, int C, int K, int R, int S, int pad, int ldy, int relu, void* stream) {
-  UNIT_CHECK_ARG(C % 64 == 0, "conv_big_ex: C must be a multiple of 64");
+                                      int N, int H, int W, int C, int K, int R, int S, int pad, int ldy, int relu, const void* x2, int C2,
+                                      void* stream) {
+  // x2 != NULL: 1x1 conv over the channel concatenation [x (C channels) | x2 (C2 channels)] of two tensors of the same N, H, W;
+  // w = [K][C + C2]. C2 must be a multiple of C.
+  UNIT_CHECK_ARG(x2 == nullptr || (R == 1 && S == 1 && pad == 0 && C2 > 0 && C2 % C == 0 && ((uintptr_t)x2 % 16 == 0)),
+                 "conv_big_ex: a second input needs a 1x1 conv and C2 a multiple of C");
+  UNIT_CHECK_ARG(C % 64 == 0 && (x2 == nullptr || C2 % 64 == 0), "conv_big_ex: C must be a multiple of 64");
   UNIT_CHECK_ARG(ldy % 8 == 0 && ldy >= K, "conv_big_ex: ldy must be a multiple of 8 and >= K");
   UNIT_CHECK_ARG(y != nullptr || pool_partial != nullptr, "conv_big_ex: no output requested");
   UNIT_CHECK_ARG((mask_bits == nullptr && relu_bits == nullptr) || ldy % 64 == 0, "conv_big_ex: bit masks need ldy % 64 == 0");
@@ -670,12 +676,14 @@ extern "C" int unit_conv2d_fwd_big_ex(const void* x, const void* w, void* y, con
   UNIT_CHECK_ARG(OH > 0 && OW > 0, "conv_big_ex: empty output");
   Conv256Args a;
   a.x = x; a.w = w; a.y = y; a.bias = bias; a.residual = residual; a.mask_ref = nullptr;
-  a.N = N; a.H = H; a.W = W; a.C = C; a.K = K; a.R = R; a.S = S; a.stride = 1; a.pad = pad;
+  const int Ct = C + (x2 ? C2 : 0);
+  a.N = N; a.H = H; a.W = W; a.C = Ct; a.K = K; a.R = R; a.S = S; a.stride = 1; a.pad = pad;
   a.OH = OH; a.OW = OW; a.ldy = ldy; a.oy_mul = 1; a.OHf = OH; a.OWf = OW; a.relu = relu;
-  a.Kgemm = R * S * C; a.M = N * OH * OW;
-  size_t xb = (size_t)N * H * W * C * 2, wb = (size_t)K * R * S * C * 2;
-  UNIT_CHECK_ARG(xb < 0xFFFFFFF0ull && wb < 0xFFFFFFF0ull, "conv_big_ex: operand larger than 4 GiB");
+  a.Kgemm = R * S * Ct; a.M = N * OH * OW;
+  size_t xb = (size_t)N * H * W * C * 2, wb = (size_t)K * R * S * Ct * 2, x2b = x2 ? (size_t)N * H * W * C2 * 2 : 0;
+  UNIT_CHECK_ARG(xb < 0xFFFFFFF0ull && wb < 0xFFFFFFF0ull && x2b < 0xFFFFFFF0ull, "conv_big_ex: operand larger than 4 GiB");
   a.x_bytes = (unsigned)xb; a.w_bytes = (unsigned)wb;
+  a.x2 = x2; a.x2_bytes = (unsigned)x2b; a.cb_split = C / 64; a.ratio2 = x2 ? C2 / C : 1;
   a.ex = EpiExtra{relu_bits, mask_bits, pool_partial, pool_rows}; a.ex_on = 1;
   if (a.M == 0 || K == 0) return UNIT_OK;
   return unit_conv256_p8_launch(a, UNIT_BF16, true, false, (hipStream_t)stream);

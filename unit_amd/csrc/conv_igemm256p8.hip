@@ -63,6 +63,10 @@ __global__ void __launch_bounds__(512, 2) conv_igemm256_p8_kernel(Conv256Args p)
   const bf16_t* __restrict__ Wt = (const bf16_t*)p.w;
   __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(X), 0, (int)p.x_bytes, 0x00020000);
   __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(Wt), 0, (int)p.w_bytes, 0x00020000);
+  // dual-source 1x1 conv (Conv256Args::x2): the first cb_split 64-channel blocks of the k extent come from x (row pitch Cx), the rest from x2
+  const bool dual = p.x2 != nullptr;
+  const int Cx = dual ? p.cb_split * 64 : p.C;
+  __amdgpu_buffer_rsrc_t rsX2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>((const bf16_t*)(dual ? p.x2 : p.x)), 0, (int)(dual ? p.x2_bytes : p.x_bytes), 0x00020000);
   constexpr unsigned OOB = 0xFFFFFFF0u;
 
   int tid = threadIdx.x, lane = tid & 63;
@@ -74,6 +78,7 @@ __global__ void __launch_bounds__(512, 2) conv_igemm256_p8_kernel(Conv256Args p)
   // staging descriptors: half q (0,1), piece j (0,1) of this wave = half-tile rows R0 = (j*8 + wid)*8 .. +8 ; lane -> row
   // R0 + lrow, LDS chunk lc (lane-linear), SOURCE chunk lc ^ ((row>>1)&7)
   int x_ih0[4], x_iw0[4]; unsigned x_off0[4], w_off[4];
+  const unsigned sw16 = (unsigned)((lc ^ ((((wid * 8 + lrow) >> 1)) & 7)) * 16);      // = sw * 16 of every piece of this lane (j * 64 rows do not change (R >> 1) & 7)
 #pragma unroll
   for (int q = 0; q < 2; ++q)
 #pragma unroll
@@ -85,7 +90,7 @@ __global__ void __launch_bounds__(512, 2) conv_igemm256_p8_kernel(Conv256Args p)
       int mm = ok ? m : 0;
       int ow = mm % p.OW; int t = mm / p.OW; int oh = t % p.OH; int n = t / p.OH;
       int ih0 = oh * p.stride - p.pad, iw0 = ow * p.stride - p.pad;
-      x_off0[q * 2 + j] = ((unsigned)n * (unsigned)(p.H * p.W * p.C) + (unsigned)((ih0 * p.W + iw0) * p.C + sw * 8)) * 2u;  // tap (0,0), wraps for negative ih0/iw0
+      x_off0[q * 2 + j] = ((unsigned)n * (unsigned)(p.H * p.W * Cx) + (unsigned)((ih0 * p.W + iw0) * Cx + sw * 8)) * 2u;  // tap (0,0), wraps for negative ih0/iw0
       x_ih0[q * 2 + j] = ok ? ih0 : -(1 << 20);                    // rows past M fail the bounds test of every tap
       x_iw0[q * 2 + j] = iw0;
       int nn = n0 + (R >> 5) * 64 + q * 32 + (R & 31);
@@ -98,7 +103,7 @@ __global__ void __launch_bounds__(512, 2) conv_igemm256_p8_kernel(Conv256Args p)
   unsigned st_kx = 0, st_kw = 0;
   auto st_advance = [&]() {
     if (++st_s == p.S) { st_s = 0; if (++st_r == p.R) { st_r = 0; ++st_cb; } }
-    st_kx = (unsigned)((st_r * p.W + st_s) * p.C + st_cb * BK) * 2u;
+    st_kx = (unsigned)((st_r * p.W + st_s) * Cx + st_cb * BK) * 2u;
     st_kw = (unsigned)((st_r * p.S + st_s) * p.C + st_cb * BK) * 2u;
   };
   auto stage_x = [&](int q, int d) {
@@ -107,6 +112,10 @@ __global__ void __launch_bounds__(512, 2) conv_igemm256_p8_kernel(Conv256Args p)
     for (int j = 0; j < 2; ++j) {
       int ih = x_ih0[q * 2 + j] + st_r, iw = x_iw0[q * 2 + j] + st_s;
       bool ok = (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
+      if (dual && st_cb >= p.cb_split) {      // (scalar branch) the row of x2: same pixel, ratio2 times the pitch; the 16-B chunk swizzle term stays
+        unsigned o2 = (x_off0[q * 2 + j] - sw16) * (unsigned)p.ratio2 + sw16 + (unsigned)((st_cb - p.cb_split) * BK) * 2u;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX2, (lds_void*)(base + (j * 8 + wid) * 1024), 16, ok ? o2 : OOB, 0, 0, 0);
+      } else
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, (lds_void*)(base + (j * 8 + wid) * 1024), 16, ok ? x_off0[q * 2 + j] + st_kx : OOB, 0, 0, 0);
     }
   };

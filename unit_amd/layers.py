@@ -171,6 +171,12 @@ class BottleneckBlock(nn.Module):
         st = self.stride if stride is None else stride
         y1 = self.conv1.fwd(x, relu=True, stride=st)
         y2 = self.conv2.fwd(y1, relu=True)
+        if self._dual_ok(x, y2, st) and not pool_rows:
+            # relu(conv3(y2) + shortcut(x)) as ONE GEMM over [y2 | x] . [W3 ; Wsc]: the shortcut's 2048-channel output is neither
+            # written nor read back as conv3's residual (what a conv epilogue READS is what it waits for)
+            wcat, bcat = self._cat_weights("fwd")
+            out, bits, _ = ops.conv2d_ex(y2, wcat, self.conv3.cout, 1, 1, 0, bias=bcat, relu=True, want_bits=out_bits, x2=x)
+            return ((out, bits) if out_bits else out), ((x, y1, y2, st, x_bits) if save else None)
         sc = self.shortcut.fwd(x, stride=st) if self.shortcut is not None else x
         if pool_rows:
             c3 = self.conv3
@@ -184,6 +190,33 @@ class BottleneckBlock(nn.Module):
         out = self.conv3.fwd(y2, relu=True, residual=sc)
         return out, ((x, y1, y2, st, x_bits) if save else None)
 
+    def _dual_ok(self, x, y2, st):
+        """conv3 + shortcut (forward) and conv1 dgrad + shortcut dgrad (backward) can run as dual-input GEMMs: the Res5 heads' first block
+        in bf16 on the stride-2-subsampled RoIAlign output (every conv of the block is then stride 1)"""
+        return (ops.FUSE_EPILOGUE and getattr(self, "allow_dual", False) and self.shortcut is not None and st == 1
+                and x.dtype == torch.bfloat16 and x.shape[:3] == y2.shape[:3] and x.shape[0] > 0
+                and ops.conv_ex_supported(x.dtype, self.conv3.cin, self.conv3.cout) and self.shortcut.cin % self.conv3.cin == 0
+                and self.shortcut.cout % self.conv1.cout == 0 and self.conv1.cout % 64 == 0 and self.conv1.cin % 64 == 0)
+
+    def _cat_weights(self, which):
+        """[W3 | Wsc] (forward) / [W1^T ; Wsc^T] in dgrad layout (backward) from the prepared per-conv weights: a 6 MB device copy per
+        use, the prepared copies are refreshed by the optimizer's multi-tensor prep"""
+        a, b = (self.conv3, self.shortcut) if which == "fwd" else (self.conv1, self.shortcut)
+        wa, wb = (a.wf, b.wf) if which == "fwd" else (a.wd, b.wd)
+        k = wa.shape[0]
+        buf = getattr(self, "_wcat_" + which, None)
+        if buf is None or buf.dtype != wa.dtype or buf.device != wa.device:
+            buf = torch.empty((k, 1, 1, wa.shape[-1] + wb.shape[-1]), dtype=wa.dtype, device=wa.device)
+            setattr(self, "_wcat_" + which, buf)
+        torch.cat([wa.reshape(k, -1), wb.reshape(k, -1)], dim=1, out=buf.view(k, -1))
+        bias = None
+        if which == "fwd":
+            src = getattr(self, "_bcat_src", (None, None))
+            if src[0] is not a.shift or src[1] is not b.shift:
+                self._bcat, self._bcat_src = a.shift + b.shift, (a.shift, b.shift)
+            bias = self._bcat
+        return buf, bias
+
     def bwd(self, ctx, g, need_dx=True, mask_input=True):
         x, y1, y2, st, x_bits = ctx
         self.conv3.wgrad(y2, g)
@@ -196,6 +229,9 @@ class BottleneckBlock(nn.Module):
         if not need_dx:
             return None
         hw = x.shape[1:3]
+        if self._dual_ok(x, y2, st) and not mask_input and g.dtype == torch.bfloat16:
+            wcat, _ = self._cat_weights("bwd")          # dx = [dy1 | g] . [W1^T ; Wsc^T]
+            return ops.conv2d_ex(dy1, wcat, self.conv1.cin, 1, 1, 0, x2=g)[0]
         if self.shortcut is not None:
             dsc = self.shortcut.dgrad(g, hw, stride=st)
         else:

@@ -23,6 +23,7 @@ class Res5BoxHead(nn.Module):
         width = (cfg.MODEL.RESNETS.NUM_GROUPS * cfg.MODEL.RESNETS.WIDTH_PER_GROUP) if cfg is not None else 64
         self.out_channels = r2 * 8
         self.res5 = ResStage(3, self.out_channels // 2, self.out_channels, width * 8, 2)
+        self.res5[0].allow_dual = True          # conv3 + shortcut (and their dgrads) as one dual-input GEMM where the 256x256 kernel applies
         if cfg is not None:
             for name, p in self.named_parameters():   # box_head.py: _freeze_layers by first name component
                 if any(layer == name.split(".")[0] for layer in cfg.MODEL.FREEZE_LAYERS.BOX_HEAD):

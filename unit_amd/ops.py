@@ -265,11 +265,16 @@ class ReluBits:
         return ((byte.int() >> (n & 7)) & 1).bool().view(self.r, self.bins, self.c)
 
 
-def conv2d_ex(x, w, k, r, s, pad=0, bias=None, residual=None, relu=False, mask_bits=None, want_bits=False, pool_rows=0, want_y=True):
+def conv2d_ex(x, w, k, r, s, pad=0, bias=None, residual=None, relu=False, mask_bits=None, want_bits=False, pool_rows=0, want_y=True, x2=None):
     """stride-1 bf16 conv on the 256x256 kernel with the extended epilogue (unit_conv2d_fwd_big_ex): returns (y | None, ReluBits |
     None, pooled [N, k] | None). pool_rows: must be OH*OW -- global average pool of each image (= RoI) fused; want_y=False then
-    skips writing the map. mask_bits: ReluBits of an [N, OH*OW, k] map (RoI offset 0)."""
+    skips writing the map. mask_bits: ReluBits of an [N, OH*OW, k] map (RoI offset 0). x2 [N,H,W,C2]: second input of a 1x1 conv over
+    the channel concatenation [x | x2] with w = [k][1][1][C + C2] (C2 a multiple of C)."""
     n, h, wd, c = x.shape
+    c2 = 0
+    if x2 is not None:
+        c2 = x2.shape[3]
+        assert r == 1 and s == 1 and pad == 0 and x2.shape[:3] == x.shape[:3] and c2 % c == 0 and x2.dtype == x.dtype and w.shape[-1] == c + c2
     oh, ow = conv_out_size(h, wd, r, s, 1, pad)
     ldy = k
     assert conv_ex_supported(x.dtype, c, ldy), "conv2d_ex: bf16, C % 64 == 0, K % 8 == 0"
@@ -290,12 +295,13 @@ def conv2d_ex(x, w, k, r, s, pad=0, bias=None, residual=None, relu=False, mask_b
         e0.record()
     check(lib().unit_conv2d_fwd_big_ex(_p(x), _p(w), _p(y), _p(bias), _p(residual), _p(mask_bits.data if mask_bits is not None else None),
                                        _p(bits.data if bits is not None else None), _p(part), pool_rows,
-                                       n, h, wd, c, k, r, s, pad, ldy, int(relu), _s()), "unit_conv2d_fwd_big_ex")
+                                       n, h, wd, c, k, r, s, pad, ldy, int(relu), _p(x2), c2, _s()), "unit_conv2d_fwd_big_ex")
     if prof is not None:
         e1 = torch.cuda.Event(enable_timing=True)
         e1.record()
-        nbytes = (x.numel() + w.numel()) * 2 + m * ldy * 2 * (int(want_y) + (residual is not None)) + (m * ldy // 8) * (int(want_bits) + (mask_bits is not None))
-        prof.setdefault("conv_igemm256", []).append((e0, e1, 2.0 * m * k * r * s * c, nbytes))
+        nbytes = (x.numel() + w.numel() + (x2.numel() if x2 is not None else 0)) * 2 + m * ldy * 2 * (int(want_y) + (residual is not None)) \
+            + (m * ldy // 8) * (int(want_bits) + (mask_bits is not None))
+        prof.setdefault("conv_igemm256", []).append((e0, e1, 2.0 * m * k * r * s * (c + c2), nbytes))
     pooled = None
     if pool_rows:
         pooled = torch.empty((n, k), dtype=x.dtype, device=x.device)
