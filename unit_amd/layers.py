@@ -193,7 +193,7 @@ class BottleneckBlock(nn.Module):
     def _dual_ok(self, x, y2, st):
         """conv3 + shortcut (forward) and conv1 dgrad + shortcut dgrad (backward) can run as dual-input GEMMs: the Res5 heads' first block
         in bf16 on the stride-2-subsampled RoIAlign output (every conv of the block is then stride 1)"""
-        return (ops.FUSE_EPILOGUE and getattr(self, "allow_dual", False) and self.shortcut is not None and st == 1
+        return (ops.FUSE_EPILOGUE and ops.FUSE_DUAL and getattr(self, "allow_dual", False) and self.shortcut is not None and st == 1
                 and x.dtype == torch.bfloat16 and x.shape[:3] == y2.shape[:3] and x.shape[0] > 0
                 and ops.conv_ex_supported(x.dtype, self.conv3.cin, self.conv3.cout) and self.shortcut.cin % self.conv3.cin == 0
                 and self.shortcut.cout % self.conv1.cout == 0 and self.conv1.cout % 64 == 0 and self.conv1.cin % 64 == 0)

@@ -231,6 +231,9 @@ def conv2d(x, w, k, r, s, stride=1, pad=0, bias=None, residual=None, mask_ref=No
 FUSE_EPILOGUE = os.environ.get("UNIT_FUSE_EPILOGUE", "1") != "0"          # Res5 heads: average pool + ReLU bit mask inside the last conv's epilogue (conv2d_ex); False = separate kernels
 
 
+FUSE_DUAL = os.environ.get("UNIT_FUSE_DUAL", "1") != "0"          # first Res5 block: conv3 + shortcut (and their dgrads) as dual-input GEMMs
+
+
 def conv_ex_supported(dtype, c, ldy):
     return dtype == torch.bfloat16 and c % 64 == 0 and ldy % 64 == 0
 
