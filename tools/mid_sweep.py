@@ -1,5 +1,5 @@
 """Tile sweep of the 4-wave LDS-DMA conv kernels on the backbone shapes: python tools/mid_sweep.py
-tile_cfg 7 = 128x128 (2 stages), 8 = 64 pixels x 128 channels (3 stages), 9 = 128 x 64, 16 = 256x256 p8; 0 = what the policy picks"""
+tile_cfg 7 = 128x128 (2 stages), 8 = 64 pixels x 128 channels (3 stages), 9 = 128 x 64, 19 / 20 = 96 x 128 (3 / 2 stages), 16 = 256x256 p8; 0 = what the policy picks"""
 import sys
 
 import torch
@@ -20,7 +20,7 @@ for name, n, h, w, c, k, r, st, pad in SH:
     res = torch.randn(n, oh, ow, k, device=dev).bfloat16() if "+res" in name else None
     flops = 2.0 * n * oh * ow * k * r * r * c
     line = f"{name:26s}"
-    for tile in (1, 2, 3, 4, 7, 8):
+    for tile in (0, 7, 8, 19, 20):
         try:
             ms = timeit(lambda: o.conv2d(x, wt, k, r, r, st, pad, relu=True, residual=res, tile_cfg=tile), iters=30)
             line += f" | {tile:2d}: {ms * 1e3:6.1f} us"

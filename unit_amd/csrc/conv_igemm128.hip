@@ -476,7 +476,7 @@ extern "C" int unit_conv2d_fwd_mid(const void* x, const void* w, void* y, const 
   UNIT_CHECK_ARG(OH == (H + 2 * pad - R) / stride + 1 && OW == (W + 2 * pad - S) / stride + 1, "conv_mid: OH/OW mismatch");
   UNIT_CHECK_ARG((OH - 1) * oy_mul < OHf && (OW - 1) * oy_mul < OWf, "conv_mid: output scatter out of range");
   UNIT_CHECK_ARG(((uintptr_t)x % 16 == 0) && ((uintptr_t)w % 16 == 0) && ((uintptr_t)y % 16 == 0), "conv_mid: 16B alignment");
-  UNIT_CHECK_ARG(tile >= 0 && tile <= 3, "conv_mid: tile must be 0..3");
+  UNIT_CHECK_ARG(tile >= 0 && tile <= 5, "conv_mid: tile must be 0..5");
   ConvDmaArgs a;
   a.x = x; a.w = w; a.y = y; a.bias = bias; a.residual = residual; a.mask_ref = mask_ref;
   a.N = N; a.H = H; a.W = W; a.C = C; a.K = K; a.R = R; a.S = S; a.stride = stride; a.pad = pad;
@@ -491,12 +491,16 @@ extern "C" int unit_conv2d_fwd_mid(const void* x, const void* w, void* y, const 
     if (tile == 3) return launch_ksplit<bf16_t>(a, st);
     if (tile == 0) return launch_dma<bf16_t, 128, 128, 2>(a, st);
     if (tile == 1) return launch_dma<bf16_t, 64, 128, 3>(a, st);
+    if (tile == 4) return launch_dma<bf16_t, 96, 128, 3>(a, st);      // 100 x 2 workgroups on the res4 1x1 -> 256 layers: one round, one per CU
+    if (tile == 5) return launch_dma<bf16_t, 96, 128, 2>(a, st);
     return launch_dma<bf16_t, 128, 64, 3>(a, st);
   }
   if (out_dtype == UNIT_F32) {
     if (tile == 3) return launch_ksplit<float>(a, st);
     if (tile == 0) return launch_dma<float, 128, 128, 2>(a, st);
     if (tile == 1) return launch_dma<float, 64, 128, 3>(a, st);
+    if (tile == 4) return launch_dma<float, 96, 128, 3>(a, st);
+    if (tile == 5) return launch_dma<float, 96, 128, 2>(a, st);
     return launch_dma<float, 128, 64, 3>(a, st);
   }
   unit_set_error("conv_mid: unsupported out dtype");

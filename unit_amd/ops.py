@@ -63,6 +63,9 @@ def _big_tile_default(dtype, m, k, c, kgemm):
 _NO_MID = bool(int(__import__("os").environ.get("UNIT_NO_MID_TILE", "0")))   # A/B switch for tools/ and debugging
 
 
+_MID96 = int(os.environ.get("UNIT_MID96", "0"))      # 0: off; 1: 96x128 tiles where tools/mid_sweep.py found them faster in isolation; 2: only the two-per-CU form
+
+
 def _mid_tile_default(dtype, m, k, c, kgemm):
     """-1: use the register-staged conv_igemm.hip kernel; 0..3: LDS-DMA 4-wave kernel with that tile (csrc/conv_igemm128.hip).
     Measured on the backbone shapes (tools/microbench.py): 128x64 for 64-channel outputs, 128x128 when that tiling still
@@ -72,6 +75,15 @@ def _mid_tile_default(dtype, m, k, c, kgemm):
     if k <= 64:
         return 2
     tiles = ((m + 127) // 128) * ((k + 127) // 128)
+    if _MID96:
+        # 96-row tiles (tools/mid_sweep.py, profiles/r02_exp_mid_sweep_96_row_tiles.txt): the res4 1x1 -> 256 layers become 100 x 2 = 200
+        # workgroups, one round with one workgroup per CU (14.9 vs 15.6 us; 3x3: 26.7 vs 27.9); between one and 2.5 rounds of 128x128
+        # tiles the 2-stage 96x128 form (two workgroups per CU) wins: res3 512 -> 128 12.7 vs 15.4 us, 3x3 19.6 vs 22.1, res4 256 -> 1024 16.6 vs 17.8
+        if tiles < 256:
+            return (4 if ((m + 95) // 96) * ((k + 127) // 128) <= 256 else 1) if _MID96 == 1 else 1
+        if tiles <= 640:
+            return 5
+        return 0
     return 0 if tiles >= 256 else 1      # tools/mid_sweep.py: res3 (293 tiles) 22.4 vs 26.2 us with 128x128; res4 (150) 27.5 vs 32.9 with 64x128
 
 
@@ -201,8 +213,8 @@ def conv2d(x, w, k, r, s, stride=1, pad=0, bias=None, residual=None, mask_ref=No
         e0.record()
     big = tile_cfg in (5, 6, 11, 12, 13, 14, 15, 16, 17, 18) or (tile_cfg == 0 and BIG_TILE_POLICY(x.dtype, n * oh * ow, k, c, r * s * c))
     mid = -1
-    if tile_cfg in (7, 8, 9, 10):
-        mid = tile_cfg - 7
+    if tile_cfg in (7, 8, 9, 10, 19, 20):
+        mid = {19: 4, 20: 5}.get(tile_cfg, tile_cfg - 7)
     elif tile_cfg == 0 and not big:
         mid = MID_TILE_POLICY(x.dtype, n * oh * ow, k, c, r * s * c)
     if mid >= 0:
