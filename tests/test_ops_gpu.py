@@ -1031,3 +1031,34 @@ def test_conv_dual_input_is_the_sum_of_two_convs(dev):
         assert torch.allclose(y.float().view(-1, k), ref, rtol=2 ** -7, atol=2e-3)
         two = o.conv2d(a, wa, k, 1, 1, 1, 0, bias=bias, residual=o.conv2d(b, wb, k, 1, 1, 1, 0, tile_cfg=16), relu=True, tile_cfg=16)
         assert torch.allclose(y.float(), two.float(), rtol=2 ** -6, atol=2e-2)
+
+
+def test_conv_ex_rejects_what_it_cannot_do(dev):
+    """the extended conv entry fails loudly (status + unit_last_error -> UnitLibError) instead of computing something else"""
+    from unit_amd import ops as o
+    from unit_amd._lib import UnitLibError, check, lib
+    x = torch.zeros(4, 7, 7, 64, device=dev, dtype=torch.bfloat16)
+    w = torch.zeros(128, 1, 1, 64, device=dev, dtype=torch.bfloat16)
+    y = torch.zeros(4, 7, 7, 128, device=dev, dtype=torch.bfloat16)
+    part = torch.zeros(4 * 4 * 128, device=dev)
+
+    def call(**kw):
+        a = dict(y=y, relu_bits=None, pool=None, pool_rows=0, c=64, k=128, r=1, pad=0, ldy=128, x2=None, c2=0)
+        a.update(kw)
+        check(lib().unit_conv2d_fwd_big_ex(o._p(x), o._p(w), o._p(a["y"]), None, None, None, o._p(a["relu_bits"]), o._p(a["pool"]), a["pool_rows"],
+                                           4, 7, 7, a["c"], a["k"], a["r"], a["r"], a["pad"], a["ldy"], 0, o._p(a["x2"]), a["c2"], o._s()), "ex")
+
+    call()                                                          # the plain call is fine
+    with pytest.raises(UnitLibError):
+        call(y=None)                                                # no output at all
+    with pytest.raises(UnitLibError):
+        call(pool=part, pool_rows=7)                                # a 128-row wave tile would span more than 4 pooling segments
+    with pytest.raises(UnitLibError):
+        call(ldy=132)                                               # ldy % 8
+    with pytest.raises(UnitLibError):
+        call(relu_bits=torch.zeros(8192, device=dev, dtype=torch.uint8), k=96, ldy=96)      # bit masks need ldy % 64 == 0
+    with pytest.raises(UnitLibError):
+        call(x2=x, c2=96)                                           # second input: C2 must be a multiple of C
+    with pytest.raises(UnitLibError):
+        call(x2=x, c2=64, r=3, pad=1)                               # second input: 1x1 only
+    torch.cuda.synchronize()
