@@ -98,6 +98,7 @@ class WeaklySupervisedRCNNNoMeta(nn.Module):
         self.use_multi_tensor_plan = True
         self.plan = None
         self.overlap_streams = True
+        self.split_weak_head = __import__("os").environ.get("UNIT_SPLIT_WEAK", "1") != "0"     # forward plan: weak_box_head as two 1024-RoI passes
 
     @property
     def device(self):
@@ -403,6 +404,7 @@ class WeaklySupervisedRCNNNoMeta(nn.Module):
         multi = rh.weak_box_head is not None
         box_trainable = any(p.requires_grad for p in rh.box_head.parameters())
         c.head_overlap = False
+        c.weak_ctx_rows = slice(rs, rs + rw)         # rows of the weak RoIs inside weak_box_head's saved context
         if multi:
             if rs > 0 and self._streams_on() and getattr(rh, "mask_head", None) is None:
                 # the two Res5 heads are independent: run box_head on its own HIP stream so that its workgroups fill the
@@ -412,7 +414,21 @@ class WeaklySupervisedRCNNNoMeta(nn.Module):
                 pooled.record_stream(s1)
                 with torch.cuda.stream(s1):
                     c.box_feat, c.box_ctx = rh.box_head.fwd(pooled[:rs], save=box_trainable)
-                wfeat_all, c.weak_ctx = rh.weak_box_head.fwd(pooled, save=(rw > 0))
+                if self.split_weak_head and rw > 0:
+                    # three equal chains (box_head, weak_box_head on the supervised RoIs without saving, weak_box_head on the weak RoIs)
+                    # on three streams instead of a 1 : 2 pair: they end together and their 392-tile launches pack into whole rounds
+                    s3 = self._wgrad_stream              # idle during the forward plan
+                    s3.wait_stream(main)
+                    pooled.record_stream(s3)
+                    with torch.cuda.stream(s3):
+                        f_sup, _ = rh.weak_box_head.fwd(pooled[:rs], save=False)
+                    f_weak, c.weak_ctx = rh.weak_box_head.fwd(pooled[rs:], save=True)
+                    main.wait_stream(s3)
+                    f_sup.record_stream(main)
+                    wfeat_all = torch.cat([f_sup, f_weak], 0)
+                    c.weak_ctx_rows = None               # the context covers exactly the weak RoIs
+                else:
+                    wfeat_all, c.weak_ctx = rh.weak_box_head.fwd(pooled, save=(rw > 0))
                 main.wait_stream(s1)
                 c.box_feat.record_stream(main)
                 c.head_overlap = True
@@ -581,7 +597,7 @@ class WeaklySupervisedRCNNNoMeta(nn.Module):
                 dbox.record_stream(s1)
                 with torch.cuda.stream(s1):
                     dpool_sup = rh.box_head.bwd(c.box_ctx, dbox)
-                dpool_weak = rh.weak_box_head.bwd(c.weak_ctx, dweak, row_slice=slice(rs, rs + rw))
+                dpool_weak = rh.weak_box_head.bwd(c.weak_ctx, dweak, row_slice=c.weak_ctx_rows)
                 main.wait_stream(s1)
                 dpool_sup.record_stream(main)
                 done("box_head")
@@ -591,7 +607,7 @@ class WeaklySupervisedRCNNNoMeta(nn.Module):
                     dpool_sup = rh.box_head.bwd(c.box_ctx, dbox, map_grad_hook=mask_hook)
                     done("box_head")
                 if dweak is not None:
-                    dpool_weak = rh.weak_box_head.bwd(c.weak_ctx, dweak, row_slice=slice(rs, rs + rw))
+                    dpool_weak = rh.weak_box_head.bwd(c.weak_ctx, dweak, row_slice=c.weak_ctx_rows)
                     done("weak_box_head")
         else:
             parts = [t for t in (dbox, dweak) if t is not None]
