@@ -232,8 +232,13 @@ class Registry:
             return deco
         self._obj_map[obj.__name__] = obj
 
+        return obj
+
     def get(self, name):
         return self._obj_map[name]
+
+    def __contains__(self, name):
+        return name in self._obj_map
 
 
 def configurable(init_func=None, *, from_config=None):
@@ -479,17 +484,19 @@ def install():
     _mod("detectron2.modeling.box_regression").Box2BoxTransform = Box2BoxTransform
     m = _mod("detectron2.modeling")
     m.ROI_HEADS_REGISTRY, m.META_ARCH_REGISTRY = Registry("ROI_HEADS"), Registry("META_ARCH")
+    m.BACKBONE_REGISTRY, m.PROPOSAL_GENERATOR_REGISTRY = Registry("BACKBONE"), Registry("PROPOSAL_GENERATOR")
+    m.ROI_BOX_HEAD_REGISTRY, m.ROI_MASK_HEAD_REGISTRY = Registry("ROI_BOX_HEAD"), Registry("ROI_MASK_HEAD")
     m.GeneralizedRCNN = type("GeneralizedRCNN", (nn.Module,), {})
     m = _mod("detectron2.modeling.proposal_generator")
-    m.PROPOSAL_GENERATOR_REGISTRY, m.RPN = Registry("PROPOSAL_GENERATOR"), RPN
+    m.PROPOSAL_GENERATOR_REGISTRY, m.RPN = _mod("detectron2.modeling").PROPOSAL_GENERATOR_REGISTRY, RPN
     m = _mod("detectron2.modeling.roi_heads")
     m.StandardROIHeads = StandardROIHeads
     m.Res5ROIHeads = type("Res5ROIHeads", (nn.Module,), {})
     m = _mod("detectron2.modeling.roi_heads.fast_rcnn")
     m.FastRCNNOutputLayers, m.FastRCNNOutputs = FastRCNNOutputLayers, FastRCNNOutputs
     m = _mod("detectron2.modeling.roi_heads.mask_head")
-    m.ROI_MASK_HEAD_REGISTRY, m.MaskRCNNConvUpsampleHead = Registry("ROI_MASK_HEAD"), MaskRCNNConvUpsampleHead
-    _mod("detectron2.modeling.roi_heads.box_head").ROI_BOX_HEAD_REGISTRY = Registry("ROI_BOX_HEAD")
+    m.ROI_MASK_HEAD_REGISTRY, m.MaskRCNNConvUpsampleHead = _mod("detectron2.modeling").ROI_MASK_HEAD_REGISTRY, MaskRCNNConvUpsampleHead
+    _mod("detectron2.modeling.roi_heads.box_head").ROI_BOX_HEAD_REGISTRY = _mod("detectron2.modeling").ROI_BOX_HEAD_REGISTRY
     m = _mod("detectron2.data")
     m.MetadataCatalog = _MetadataCatalog
     _MetadataCatalog.table["voc_stub_train"] = _Metadata(VOC_THING_CLASSES)

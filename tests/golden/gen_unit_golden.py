@@ -564,8 +564,17 @@ def main_unit():
     print("wrote", OUT_UNIT, len(out), "arrays", os.path.getsize(OUT_UNIT), "bytes")
 
 
-if __name__ == "__main__":
+def main(out_dir=None):
+    """writes unit_golden.npz and ref_step_golden.npz into `out_dir` (default: next to this script)"""
+    global OUT_UNIT, OUT_STEP
+    if out_dir is not None:
+        os.makedirs(out_dir, exist_ok=True)
+        OUT_UNIT, OUT_STEP = os.path.join(out_dir, "unit_golden.npz"), os.path.join(out_dir, "ref_step_golden.npz")
     main_unit()
     load_meta_arch()
     import gen_ref_step
     gen_ref_step.main(sys.modules[__name__])
+
+
+if __name__ == "__main__":
+    main(sys.argv[1] if len(sys.argv) > 1 else None)

@@ -104,27 +104,34 @@ def test_same_registry_names_as_the_reference():
         assert name in getattr(S, reg), (name, reg)
 
 
-def test_registers_into_detectron2_when_importable(monkeypatch):
-    """a stand-in `detectron2.modeling` exposing Registry objects (what `import detectron2` provides): after (re-)importing the
-    package every hot-path class is retrievable from DETECTRON2's registries -- which is where d2's build_model / build_roi_heads /
-    build_box_head look (lookup site in the reference: modeling/roi_heads/fast_rcnn.py:587-589)."""
+def test_registers_into_detectron2_on_request_only(monkeypatch):
+    """a stand-in `detectron2.modeling` exposing Registry objects (what `import detectron2` provides): importing the package does NOT
+    touch them; after the explicit `structures.register_into_detectron2()` every hot-path class is retrievable from DETECTRON2's
+    registries -- which is where d2's build_model / build_roi_heads / build_box_head look (lookup site in the reference:
+    modeling/roi_heads/fast_rcnn.py:587-589) -- through their public `register` only, and a name Detectron2 already holds
+    (build_resnet_backbone) is left alone unless overwrite=True."""
     class FakeRegistry:
         def __init__(self, name):
             self._name, self._obj_map = name, {}
 
         def register(self, obj=None):
+            assert obj.__name__ not in self._obj_map, "duplicate registration"      # Detectron2's own check
             self._obj_map[obj.__name__] = obj
             return obj
 
         def get(self, name):
             return self._obj_map[name]
+
+        def __contains__(self, name):
+            return name in self._obj_map
     d2 = types.ModuleType("detectron2")
     d2m = types.ModuleType("detectron2.modeling")
-    names = ["META_ARCH_REGISTRY", "BACKBONE_REGISTRY", "PROPOSAL_GENERATOR_REGISTRY", "ROI_HEADS_REGISTRY", "ROI_BOX_HEAD_REGISTRY",
-             "ROI_MASK_HEAD_REGISTRY"]
+    names = ["META_ARCH_REGISTRY", "BACKBONE_REGISTRY", "PROPOSAL_GENERATOR_REGISTRY", "ROI_HEADS_REGISTRY", "ROI_BOX_HEAD_REGISTRY"]
     for n in names:
         setattr(d2m, n, FakeRegistry(n))
-    d2m.BACKBONE_REGISTRY._obj_map["build_resnet_backbone"] = object()        # Detectron2's own builder is replaced
+    d2m.ROI_MASK_HEAD_REGISTRY = type("ROI_MASK_HEAD_REGISTRY", (), {})      # a placeholder CLASS (partial stub): must be ignored, not called
+    theirs = object()
+    d2m.BACKBONE_REGISTRY._obj_map["build_resnet_backbone"] = theirs
     d2.modeling = d2m
     monkeypatch.setitem(sys.modules, "detectron2", d2)
     monkeypatch.setitem(sys.modules, "detectron2.modeling", d2m)
@@ -133,9 +140,18 @@ def test_registers_into_detectron2_when_importable(monkeypatch):
         monkeypatch.delitem(sys.modules, k)
     try:
         M = importlib.import_module("unit_amd.modeling")
+        S = importlib.import_module("unit_amd.structures")
+        assert all(not getattr(d2m, n)._obj_map or n == "BACKBONE_REGISTRY" for n in names)      # the import alone registered nothing
+        with pytest.warns(UserWarning, match="build_resnet_backbone"):
+            rep = S.register_into_detectron2()
+        assert rep["skipped"] == ["BACKBONE.build_resnet_backbone"]
+        assert d2m.BACKBONE_REGISTRY.get("build_resnet_backbone") is theirs
         for name, reg in REGISTRY_OF.items():
-            if hasattr(d2m, reg):
+            if reg in names and name != "build_resnet_backbone":
                 assert d2m.__dict__[reg].get(name) is getattr(M, name), (name, reg)
+        rep = S.register_into_detectron2(overwrite=True)
+        assert "BACKBONE.build_resnet_backbone" in rep["registered"]
+        assert d2m.BACKBONE_REGISTRY.get("build_resnet_backbone") is M.build_resnet_backbone
         from unit_amd import config
         cfg = config.voc_rcnn_c4_split1(50)
         cfg.MODEL.DEVICE = "cpu"
@@ -145,3 +161,10 @@ def test_registers_into_detectron2_when_importable(monkeypatch):
         for k in [k for k in sys.modules if k == "unit_amd.structures" or k.startswith("unit_amd.modeling")]:
             del sys.modules[k]
         sys.modules.update(saved)
+
+
+def test_register_into_detectron2_without_detectron2_raises():
+    from unit_amd import structures as S
+    import unit_amd.modeling  # noqa: F401
+    with pytest.raises(RuntimeError, match="not importable"):
+        S.register_into_detectron2()

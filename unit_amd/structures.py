@@ -5,10 +5,10 @@ import torch
 
 
 def _detectron2_registry(name):
-    """the real Detectron2 registry object of that name when `import detectron2` succeeds ("if real
-    detectron2 is importable, register into it instead"), else None. d2's `build_model` / `build_roi_heads` / ... look classes up
-    in THESE objects (call site in the reference: modeling/roi_heads/fast_rcnn.py:587-589 for UniT's own two registries, which
-    have no Detectron2 counterpart and stay local)."""
+    """the real Detectron2 registry object of that name when `import detectron2` succeeds, else None. d2's `build_model` /
+    `build_roi_heads` / ... look classes up in THESE objects (call site in the reference: modeling/roi_heads/fast_rcnn.py:587-589
+    for UniT's own two registries, which have no Detectron2 counterpart and stay local). Anything that is not a registry INSTANCE
+    with a callable `register` (e.g. a placeholder class of a partial stub) is ignored."""
     where = {"META_ARCH": ("detectron2.modeling", "META_ARCH_REGISTRY"), "BACKBONE": ("detectron2.modeling", "BACKBONE_REGISTRY"),
              "PROPOSAL_GENERATOR": ("detectron2.modeling", "PROPOSAL_GENERATOR_REGISTRY"),
              "ROI_HEADS": ("detectron2.modeling", "ROI_HEADS_REGISTRY"), "ROI_BOX_HEAD": ("detectron2.modeling", "ROI_BOX_HEAD_REGISTRY"),
@@ -17,27 +17,25 @@ def _detectron2_registry(name):
         return None
     try:
         import importlib
-        return getattr(importlib.import_module(where[0]), where[1])
+        reg = getattr(importlib.import_module(where[0]), where[1])
     except Exception:       # detectron2 absent (this image) or too old to have the registry
         return None
+    if isinstance(reg, type) or not callable(getattr(reg, "register", None)) or not hasattr(reg, "__contains__"):
+        return None
+    return reg
+
+
+_ALL_REGISTRIES = []
 
 
 class Registry:
     def __init__(self, name):
         self._name, self._map = name, {}
-        self._d2 = _detectron2_registry(name)
+        _ALL_REGISTRIES.append(self)
 
     def register(self, obj=None):
         def deco(o):
             self._map[o.__name__] = o
-            if self._d2 is not None:
-                # the MI355X class takes the plugin name: a later `import UniT.modeling` would collide, which is the point of a
-                # drop-in; a name Detectron2 itself already holds (build_resnet_backbone) is replaced
-                m = getattr(self._d2, "_obj_map", None)
-                if isinstance(m, dict):
-                    m[o.__name__] = o
-                else:
-                    self._d2.register(o)
             return o
         return deco(obj) if obj is not None else deco
 
@@ -58,6 +56,38 @@ ROI_BOX_HEAD_REGISTRY = Registry("ROI_BOX_HEAD")
 ROI_MASK_HEAD_REGISTRY = Registry("ROI_MASK_HEAD")
 FAST_RCNN_REGISTRY = Registry("FAST_RCNN_REGISTRY")
 WEAK_DETECTOR_FAST_RCNN_REGISTRY = Registry("WEAK_DETECTOR_FAST_RCNN")
+
+
+def register_into_detectron2(overwrite=False):
+    """EXPLICIT opt-in: mirror every class registered here into Detectron2's own registries, through their public
+    `register` only. A name Detectron2 (or an already imported UniT.modeling) holds is left alone and reported, unless
+    `overwrite=True`, in which case the existing entry is replaced for this process. Returns {"registered": [...], "skipped": [...]};
+    raises if detectron2 is not importable."""
+    import warnings
+    done, skipped, found = [], [], False
+    for r in _ALL_REGISTRIES:
+        d2 = _detectron2_registry(r._name)
+        if d2 is None:
+            continue
+        found = True
+        for name, obj in r._map.items():
+            if name in d2:
+                if not overwrite:
+                    skipped.append(f"{r._name}.{name}")
+                    continue
+                m = getattr(d2, "_obj_map", None)
+                if not isinstance(m, dict):
+                    skipped.append(f"{r._name}.{name}")
+                    continue
+                m.pop(name)
+            d2.register(obj)
+            done.append(f"{r._name}.{name}")
+    if not found:
+        raise RuntimeError("register_into_detectron2: detectron2's registries are not importable")
+    if skipped:
+        warnings.warn("unit_amd: names already registered in Detectron2 were left alone: " + ", ".join(skipped)
+                      + " (import unit_amd.modeling INSTEAD of UniT.modeling, or pass overwrite=True)")
+    return {"registered": done, "skipped": skipped}
 
 
 class ShapeSpec:
