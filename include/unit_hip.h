@@ -55,11 +55,13 @@ int unit_conv2d_fwd(const void* x, const void* w, void* y, const float* bias, co
  * variant: 0 = default (= 8); 8 = four phases per k-tile, half-tile staging under a counted vmcnt, fragment reads inside the
  * MFMA sections (csrc/conv_igemm256p8.hip); 7 = 8 without the reads-in-MFMA step; 9 = 8 on 224-row tiles; 10 = 224 or 256
  * rows, whichever needs fewer rounds x rows; 4 = two-stage loop (csrc/conv_igemm256.hip), 1 / 2 / 3 / 5 / 6 = its ping-pong,
- * 4 x 32-k, 224-row, auto-row and shared-input-super-tile (3x3 s1 p1 on 7x7 maps) forms. All variants: identical results. */
+ * 4 x 32-k, 224-row, auto-row and shared-input-super-tile (3x3 s1 p1 on 7x7 maps) forms: identical results bit for bit.
+ * 11 = the schedule of 8 on v_mfma_f32_32x32x16_bf16 (csrc/conv_igemm256p8m.hip): same fp32 accumulation, another summation order
+ * inside a k-tile (equal to the others within fp32 rounding of the accumulation, not bit for bit). */
 int unit_conv2d_fwd_big(const void* x, const void* w, void* y, const float* bias, const void* residual, const void* mask_ref,
                         int out_dtype, int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int OH, int OW, int ldy,
                         int oy_mul, int OHf, int OWf, int relu, int variant, void* stream);
-/* unit_conv2d_fwd_big (variant 8, stride 1, plain output layout, bf16 in / out) with an extended epilogue -- any of:
+/* unit_conv2d_fwd_big (variant 0 = default, 8 or 11; stride 1, plain output layout, bf16 in / out) with an extended epilogue -- any of:
  *   relu_bits    out: one bit per output element, (stored value) > 0, unit_relu_bits_bytes(M, ldy) bytes, ldy % 64 == 0. Layout = the
  *                     epilogue's own order (one 16-byte store per lane and 128-row x 64-channel wave tile): 16-byte word
  *                     [(m / 128) * (ldy / 64) + n / 64][lane], lane = (m % 8) * 8 + (n % 64) / 8, bit ((m % 128) / 8) * 8 + n % 8;
@@ -79,7 +81,7 @@ size_t unit_conv_pool_partial_floats(int M, int ldy);
 size_t unit_relu_bits_bytes(int M, int ldy);
 int unit_conv2d_fwd_big_ex(const void* x, const void* w, void* y, const float* bias, const void* residual, const unsigned char* mask_bits,
                            unsigned char* relu_bits, float* pool_partial, int pool_rows, int N, int H, int W, int C, int K, int R, int S,
-                           int pad, int ldy, int relu, const void* x2, int C2, void* stream);
+                           int pad, int ldy, int relu, const void* x2, int C2, int variant, void* stream);
 int unit_pool_finish(const float* partial, int R, int rows, int ldy, int K, void* out, int ldo, int out_dtype, void* stream);
 int unit_avgpool_bwd_bits(const void* dfeat, const unsigned char* bits, int R, int roi_offset, int rows, int C, void* g, void* stream);
 /* mid-size variant (4 waves, LDS-DMA, two workgroups per CU) for the backbone layers; bf16 inputs, C % 64 == 0;

@@ -200,6 +200,43 @@ def test_conv_p8_kernel(dev, case, cfg):
     assert torch.equal(yf.cpu()[..., :k], y5.cpu()[..., :k])
 
 
+@pytest.mark.parametrize("case", [(3, 30, 33, 256, 256, 3, 1, 1), (1, 38, 63, 128, 75, 1, 1, 0), (2, 9, 9, 64, 40, 1, 1, 0), (70, 7, 7, 64, 512, 3, 1, 1),
+                                  (2, 19, 23, 64, 320, 1, 2, 0), (11, 7, 7, 192, 264, 3, 1, 1)])
+def test_conv_p8_m32_kernel(dev, case):
+    """the p8 schedule on v_mfma_f32_32x32x16_bf16 (tile_cfg 21 = variant 11, conv_igemm256p8m.hip) == F.conv2d incl. padding, partial
+    tiles, one / two / many k-tiles, K not a multiple of 256, residual + ReLU + mask epilogue, strided-scatter form, fp32 output. Its
+    k-summation order differs from the 16x16x32 kernels', so they are compared at fp32-accumulation tolerance, not bit for bit:
+    fp32 outputs 1e-5 of the output scale apart, bf16 outputs at most one bf16 ulp on the few elements whose rounding flips."""
+    o = ops()
+    n, h, w, c, k, r, stride, pad = case
+    gen = g(23)
+    x = torch.randn(n, c, h, w, generator=gen).bfloat16().float()
+    wt = (torch.randn(k, c, r, r, generator=gen) / np.sqrt(c * r * r)).bfloat16().float()
+    bias = torch.randn(k, generator=gen)
+    ref = F.conv2d(x, wt, bias, stride=stride, padding=pad)
+    xd, wd = nhwc(x).to(dev).bfloat16(), krsc(wt).to(dev).bfloat16()
+    ldy = (k + 7) // 8 * 8
+    yf = o.conv2d(xd, wd, k, r, r, stride, pad, bias=bias.to(dev), out_dtype=torch.float32, tile_cfg=21)
+    got = nchw(yf.cpu()[..., :k])
+    scale = ref.abs().max().item()
+    assert (got - ref).abs().max().item() <= 2e-5 * scale, ((got - ref).abs().max().item(), scale)
+    y16 = o.conv2d(xd, wd, k, r, r, stride, pad, bias=bias.to(dev), out_dtype=torch.float32, tile_cfg=16)
+    assert (yf.cpu()[..., :k] - y16.cpu()[..., :k]).abs().max().item() <= 1e-5 * scale
+    res = torch.randn(n, ref.shape[2], ref.shape[3], ldy, generator=gen).bfloat16()
+    msk = torch.randn(n, ref.shape[2], ref.shape[3], ldy, generator=gen).bfloat16()
+    y2 = o.conv2d(xd, wd, k, r, r, stride, pad, bias=bias.to(dev), residual=res.to(dev), mask_ref=msk.to(dev), relu=True, ldy=ldy, tile_cfg=21)
+    y1 = o.conv2d(xd, wd, k, r, r, stride, pad, bias=bias.to(dev), residual=res.to(dev), mask_ref=msk.to(dev), relu=True, ldy=ldy, tile_cfg=16)
+    a, b = y2.float().cpu()[..., :k], y1.float().cpu()[..., :k]
+    assert torch.allclose(a, b, rtol=2 ** -7, atol=1e-6) and (a != b).float().mean().item() < 2e-3, ((a - b).abs().max(), (a != b).float().mean())
+    want = torch.relu(ref.permute(0, 2, 3, 1) + res.float()[..., :k]) * (msk.float()[..., :k] > 0)
+    assert torch.allclose(a, want, rtol=2e-2, atol=2e-2)
+    if stride == 1 and r == 1:
+        oh, ow = ref.shape[2], ref.shape[3]
+        s5 = o.conv2d(xd, wd, k, 1, 1, 1, 0, scatter=(2, 2 * oh, 2 * ow), ldy=ldy, tile_cfg=21).float().cpu()
+        s1 = o.conv2d(xd, wd, k, 1, 1, 1, 0, scatter=(2, 2 * oh, 2 * ow), ldy=ldy, tile_cfg=16).float().cpu()
+        assert torch.equal(s5[:, 1::2], s1[:, 1::2]) and torch.allclose(s5, s1, rtol=2 ** -7, atol=1e-6)
+
+
 @pytest.mark.parametrize("case", [(4, 38, 63, 256, 256, 3, 1, 1), (4, 38, 63, 1024, 256, 1, 1, 0), (2, 75, 125, 128, 128, 3, 1, 1),
                                   (3, 40, 50, 256, 512, 1, 2, 0), (5, 7, 9, 128, 256, 3, 1, 1), (1, 33, 40, 384, 128, 1, 1, 0)])
 def test_wgrad_ring128_kernel(dev, case):
@@ -230,11 +267,13 @@ def test_wgrad_ring128_kernel(dev, case):
 
 @pytest.mark.parametrize("case,tile", [((1024, 7, 7, 512, 512, 3, 1, 1), 16), ((1024, 7, 7, 512, 2048, 1, 1, 0), 16), ((1024, 7, 7, 2048, 512, 1, 1, 0), 16),
                                        ((1024, 14, 14, 1024, 512, 1, 2, 0), 16), ((4, 38, 63, 1024, 1024, 3, 1, 1), 16),
+                                       ((1024, 7, 7, 512, 512, 3, 1, 1), 21), ((1024, 7, 7, 512, 2048, 1, 1, 0), 21), ((1024, 7, 7, 2048, 512, 1, 1, 0), 21),
+                                       ((1024, 14, 14, 1024, 512, 1, 2, 0), 21), ((4, 38, 63, 1024, 1024, 3, 1, 1), 21),
                                        ((4, 38, 63, 1024, 256, 1, 1, 0), 0), ((4, 38, 63, 256, 256, 3, 1, 1), 0), ((4, 38, 63, 256, 1024, 1, 1, 0), 0),
                                        ((4, 75, 125, 128, 128, 3, 1, 1), 0), ((4, 75, 125, 128, 512, 1, 1, 0), 0)])
 def test_conv_hot_shapes_fp32_output_tight(dev, case, tile):
     """the REAL hot shapes (Res5 on 1024 RoIs: M = 50 176; RPN / res4 / res3 on four 600x1000 images) through the kernels the
-    step uses (tile 16 = conv_igemm256_p8, 0 = the policy's LDS-DMA 4-wave kernel): bf16 operands, fp32 accumulation AND fp32
+    step uses (tile 16 = conv_igemm256_p8, 21 = its 32x32x16-MFMA form, 0 = the policy's LDS-DMA 4-wave kernel): bf16 operands, fp32 accumulation AND fp32
     output, so the only difference to F.conv2d on the same bf16-rounded operands (fp32 math) is the summation order: 2e-4 relative
     to the output scale. Checked on a random sample of output pixels (the full fp32 reference of M = 50 176 x K = 4608 costs seconds)."""
     o = ops()
@@ -903,8 +942,9 @@ def test_conv_halo7_kernel(dev, case):
     assert torch.allclose(y2.float().cpu()[..., :k], y1.float().cpu()[..., :k], rtol=2e-2, atol=2e-2)
 
 
+@pytest.mark.parametrize("variant", [8, 11])
 @pytest.mark.parametrize("rois,c,k", [(37, 128, 256), (5, 64, 192), (1024, 512, 2048)])
-def test_conv_fused_pool_and_relu_bits(dev, rois, c, k):
+def test_conv_fused_pool_and_relu_bits(dev, rois, c, k, variant):
     """unit_conv2d_fwd_big_ex: the average pool over each RoI's 49 bins, the ReLU bit mask and the bit-mask input fused into the conv
     epilogue against the separate kernels (same arithmetic per element: map and bits EXACT; pooled sums differ only in fp32
     association) and against torch fp32."""
@@ -914,16 +954,17 @@ def test_conv_fused_pool_and_relu_bits(dev, rois, c, k):
     w = (torch.randn(k, 1, 1, c, generator=g) * (1.0 / c) ** 0.5).to(dev).bfloat16()
     res = torch.randn(rois, 7, 7, k, generator=g).to(dev).bfloat16()
     bias = (torch.randn(k, generator=g) * 0.1).to(dev)
-    y_ref = o.conv2d(x, w, k, 1, 1, 1, 0, bias=bias, residual=res, relu=True, tile_cfg=16)
+    tile = {8: 16, 11: 21}[variant]           # the plain launch of the same kernel (16x16x32 / 32x32x16 MFMA): same accumulation order
+    y_ref = o.conv2d(x, w, k, 1, 1, 1, 0, bias=bias, residual=res, relu=True, tile_cfg=tile)
     pooled_ref = o.global_avgpool(y_ref)
-    y, bits, pooled = o.conv2d_ex(x, w, k, 1, 1, 0, bias=bias, residual=res, relu=True, want_bits=True, pool_rows=49, want_y=True)
+    y, bits, pooled = o.conv2d_ex(x, w, k, 1, 1, 0, bias=bias, residual=res, relu=True, want_bits=True, pool_rows=49, want_y=True, variant=variant)
     assert torch.equal(y, y_ref)
     assert torch.equal(bits.unpack(), (y_ref.float() > 0).view(rois, 49, k))
     exact = y_ref.float().view(rois, 49, k).mean(1)
     assert torch.allclose(pooled.float(), exact, rtol=2 ** -8, atol=1e-6)              # one bf16 rounding of the exact mean
     assert torch.allclose(pooled.float(), pooled_ref.float(), rtol=2 ** -7, atol=1e-6)
     # without the map
-    y2, bits2, pooled2 = o.conv2d_ex(x, w, k, 1, 1, 0, bias=bias, residual=res, relu=True, want_bits=True, pool_rows=49, want_y=False)
+    y2, bits2, pooled2 = o.conv2d_ex(x, w, k, 1, 1, 0, bias=bias, residual=res, relu=True, want_bits=True, pool_rows=49, want_y=False, variant=variant)
     assert y2 is None and torch.equal(bits2.unpack(), bits.unpack()) and torch.equal(pooled2, pooled)
     # torch fp32 on the same bf16 operands
     t = torch.nn.functional.conv2d(x.float().permute(0, 3, 1, 2), w.float().permute(0, 3, 1, 2), bias) + res.float().permute(0, 3, 1, 2)
@@ -931,8 +972,8 @@ def test_conv_fused_pool_and_relu_bits(dev, rois, c, k):
     assert torch.allclose(pooled.float(), t, rtol=2e-2, atol=2e-2)
     # bit mask as an input == bf16 mask tensor as an input
     dy = torch.randn(rois, 7, 7, c, generator=g).to(dev).bfloat16()
-    a = o.conv2d(dy, w, k, 1, 1, 1, 0, residual=res, mask_ref=y_ref, tile_cfg=16)
-    b, _, _ = o.conv2d_ex(dy, w, k, 1, 1, 0, residual=res, mask_bits=bits)
+    a = o.conv2d(dy, w, k, 1, 1, 1, 0, residual=res, mask_ref=y_ref, tile_cfg=tile)
+    b, _, _ = o.conv2d_ex(dy, w, k, 1, 1, 0, residual=res, mask_bits=bits, variant=variant)
     assert torch.equal(a, b)
     # backward of (pool o relu) from the bits
     df = torch.randn(rois, k, generator=g).to(dev).bfloat16()

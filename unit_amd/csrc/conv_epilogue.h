@@ -11,13 +11,13 @@
 #pragma once
 #include "common.h"
 
-template <int FA> struct EpiCfg {
+template <int FA, int RB = 16> struct EpiCfg {
   static constexpr int CH = FA * 16;            // channels of the wave tile
   static constexpr int LPR = CH / 8;            // lanes per row (8 channels each)
   static constexpr int RPP = 64 / LPR;          // rows per pass
-  static constexpr int NP = 16 / RPP;           // passes per 16-row block
+  static constexpr int NP = RB / RPP;           // passes per RB-row block (RB = 16: 16x16 MFMA accumulators, 32: 32x32)
   static constexpr int PITCH = CH * 4 + 16;     // bytes per scratch row (fp32 + 16 B pad: rows land on different banks)
-  static constexpr int BYTES = 16 * PITCH;      // scratch per wave
+  static constexpr int BYTES = RB * PITCH;      // scratch per wave
 };
 
 // Optional extras of the epilogue (EX = true instantiations; conv_igemm256p8.hip):
@@ -43,17 +43,19 @@ struct EpiExtra {
   int pool_rows;
 };
 
-// acc[a][b] = 16x16 tile (channels a*16.., pixel rows b*16..) of this wave; m_w / n_w = first pixel row / channel of the
-// wave tile; scr = this wave's scratch (EpiCfg<FA>::BYTES, 16-B aligned). Requires p.ldy % 8 == 0.
+// The wave tile is FA*16 channels x FB*16 pixel rows, handed over in blocks of RB rows: put_block(b, scr) writes the fp32 values of
+// rows b*RB .. b*RB+RB-1 into the scratch as [row][channel] with pitch EpiCfg::PITCH (whatever the MFMA accumulator layout is);
+// m_w / n_w = first pixel row / channel of the wave tile; scr = this wave's scratch (EpiCfg<FA, RB>::BYTES, 16-B aligned).
+// Requires p.ldy % 8 == 0.
 // EX: `pool` = this wave's 8 KB LDS area [4 segments][8 row classes][64 channels] fp32 (FA == 4 only); plain output layout only.
-template <int FA, int FB, bool EX, typename Args>
-__device__ __forceinline__ void epilogue_rows_bf16_impl(const f32x4 (&acc)[FA][FB], char* scr, float* pool, int m_w, int n_w, const Args& p, int lane) {
-  typedef EpiCfg<FA> E;
+template <int FA, int FB, bool EX, int RB, typename Put, typename Args>
+__device__ __forceinline__ void epilogue_rows_bf16_blocks(Put put_block, char* scr, float* pool, int m_w, int n_w, const Args& p, int lane) {
+  typedef EpiCfg<FA, RB> E;
+  constexpr int NBLK = FB * 16 / RB;
   bf16_t* __restrict__ Y = (bf16_t*)p.y;
   const bf16_t* __restrict__ Rz = (const bf16_t*)p.residual;
   const bf16_t* __restrict__ Mk = EX ? nullptr : (const bf16_t*)p.mask_ref;
   const bool plain = EX || (p.oy_mul == 1 && p.OHf == p.OH && p.OWf == p.OW);
-  const int frow = lane & 15, fq = lane >> 4;
   const int rr = lane / E::LPR, c0 = (lane % E::LPR) * 8;
   const int n = n_w + c0;
   const bool n_ok = n < p.ldy;
@@ -70,7 +72,7 @@ __device__ __forceinline__ void epilogue_rows_bf16_impl(const f32x4 (&acc)[FA][F
   float run[8];
   if constexpr (EX) {
     static_assert(FA == 4, "pooling epilogue: 64-channel wave tiles");
-    static_assert(FB <= 8 && E::NP == 2, "bit words: 16 row passes of 8 rows per wave tile");
+    static_assert(FB <= 8 && E::RPP == 8, "bit words: 16 row passes of 8 rows per wave tile");
     Mb = p.ex.mask_bits; Rb = p.ex.relu_bits; Pp = p.ex.pool_partial; prow = p.ex.pool_rows > 0 ? p.ex.pool_rows : 1;
     bword = (((long)(m_w >> 7)) * (p.ldy >> 6) + (n_w >> 6)) * 64 + lane;          // this lane's word of the wave tile (m_w % 128 == 0)
     if (Mb && n_ok && m_w < p.M) mw = reinterpret_cast<const u32x4*>(Mb)[bword];
@@ -96,7 +98,7 @@ __device__ __forceinline__ void epilogue_rows_bf16_impl(const f32x4 (&acc)[FA][F
   auto prefetch = [&](int b, Pre& q) {
 #pragma unroll
     for (int h = 0; h < E::NP; ++h) {
-      int m = m_w + b * 16 + h * E::RPP + rr;
+      int m = m_w + b * RB + h * E::RPP + rr;
       q.ok[h] = n_ok && m < p.M;
       int mm = q.ok[h] ? m : 0;
       if (plain) q.off[h] = (long)mm * p.ldy + n;
@@ -112,12 +114,10 @@ __device__ __forceinline__ void epilogue_rows_bf16_impl(const f32x4 (&acc)[FA][F
   Pre cur;
   prefetch(0, cur);
 #pragma unroll
-  for (int b = 0; b < FB; ++b) {
+  for (int b = 0; b < NBLK; ++b) {
     Pre nxt;
-    if (b + 1 < FB) prefetch(b + 1, nxt);
-#pragma unroll
-    for (int a = 0; a < FA; ++a)
-      *reinterpret_cast<f32x4*>(scr + frow * E::PITCH + (a * 16 + fq * 4) * 4) = acc[a][b];
+    if (b + 1 < NBLK) prefetch(b + 1, nxt);
+    put_block(b, scr);
 #pragma unroll
     for (int h = 0; h < E::NP; ++h) {
       int r = h * E::RPP + rr;
@@ -139,7 +139,7 @@ __device__ __forceinline__ void epilogue_rows_bf16_impl(const f32x4 (&acc)[FA][F
       }
       if constexpr (EX) {
         if (Mb) {
-          unsigned mbits = mw[(b * 2 + h) >> 2] >> (((b * 2 + h) & 3) * 8);
+          unsigned mbits = mw[(b * E::NP + h) >> 2] >> (((b * E::NP + h) & 3) * 8);
 #pragma unroll
           for (int j = 0; j < 8; ++j) v[j] = ((mbits >> j) & 1u) ? v[j] : 0.f;
         }
@@ -152,10 +152,10 @@ __device__ __forceinline__ void epilogue_rows_bf16_impl(const f32x4 (&acc)[FA][F
           unsigned bits = 0;
 #pragma unroll
           for (int j = 0; j < 8; ++j) bits |= ((float)o[j] > 0.f ? 1u : 0u) << j;      // the stored (rounded) value, as a mask_ref read would see it
-          rw[(b * 2 + h) >> 2] |= bits << (((b * 2 + h) & 3) * 8);
+          rw[(b * E::NP + h) >> 2] |= bits << (((b * E::NP + h) & 3) * 8);
         }
         if (Pp && cur.ok[h]) {
-          int m = m_w + b * 16 + r;
+          int m = m_w + b * RB + r;
           if (m >= nxt_edge) {                     // this lane's rows entered the next RoI (rows only grow: at most 3 times)
             flush();
             cur_roi = m / prow; nxt_edge = (cur_roi + 1) * prow;
@@ -170,7 +170,7 @@ __device__ __forceinline__ void epilogue_rows_bf16_impl(const f32x4 (&acc)[FA][F
         if (cur.ok[h]) *reinterpret_cast<bf16x8*>(Y + cur.off[h]) = o;
       }
     }
-    if (b + 1 < FB) cur = nxt;
+    if (b + 1 < NBLK) cur = nxt;
   }
   if constexpr (EX) {
     if (Rb && n_ok && m_w < p.M) reinterpret_cast<u32x4*>(Rb)[bword] = rw;      // (a wave tile past the last row owns no word)
@@ -192,7 +192,38 @@ __device__ __forceinline__ void epilogue_rows_bf16_impl(const f32x4 (&acc)[FA][F
   }
 }
 
+// 16x16 MFMA accumulators: acc[a][b] = 16x16 tile (channels a*16.., pixel rows b*16..); lane holds 4 consecutive channels of row lane & 15
+template <int FA, int FB, bool EX, typename Args>
+__device__ __forceinline__ void epilogue_rows_bf16_impl(const f32x4 (&acc)[FA][FB], char* scr, float* pool, int m_w, int n_w, const Args& p, int lane) {
+  typedef EpiCfg<FA, 16> E;
+  const int frow = lane & 15, fq = lane >> 4;
+  auto put = [&](int b, char* sc) {
+#pragma unroll
+    for (int a = 0; a < FA; ++a)
+      *reinterpret_cast<f32x4*>(sc + frow * E::PITCH + (a * 16 + fq * 4) * 4) = acc[a][b];
+  };
+  epilogue_rows_bf16_blocks<FA, FB, EX, 16>(put, scr, pool, m_w, n_w, p, lane);
+}
+
 template <int FA, int FB, typename Args>
 __device__ __forceinline__ void epilogue_rows_bf16(const f32x4 (&acc)[FA][FB], char* scr, int m_w, int n_w, const Args& p, int lane) {
   epilogue_rows_bf16_impl<FA, FB, false>(acc, scr, nullptr, m_w, n_w, p, lane);
+}
+
+// 32x32 MFMA accumulators (v_mfma_f32_32x32x16_bf16, A = channels, B = pixels): acc[a][b] = 32 channels a*32.. x 32 pixel rows
+// b*32..; lane holds, for row lane & 31, the channels 8*g + 4*(lane >> 5) + (0..3) in registers 4g .. 4g+3 (g = 0..3)
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+template <int FA2, int FB2, bool EX, typename Args>
+__device__ __forceinline__ void epilogue_rows32_bf16_impl(const f32x16 (&acc)[FA2][FB2], char* scr, float* pool, int m_w, int n_w, const Args& p, int lane) {
+  typedef EpiCfg<FA2 * 2, 32> E;
+  const int frow = lane & 31, fh = lane >> 5;
+  auto put = [&](int b, char* sc) {
+#pragma unroll
+    for (int a = 0; a < FA2; ++a)
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        *reinterpret_cast<f32x4*>(sc + frow * E::PITCH + (a * 32 + g * 8 + fh * 4) * 4) =
+            f32x4{acc[a][b][g * 4], acc[a][b][g * 4 + 1], acc[a][b][g * 4 + 2], acc[a][b][g * 4 + 3]};
+  };
+  epilogue_rows_bf16_blocks<FA2 * 2, FB2 * 2, EX, 32>(put, scr, pool, m_w, n_w, p, lane);
 }

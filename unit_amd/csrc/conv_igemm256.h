@@ -50,3 +50,7 @@ template <> struct O4<bf16_t> {
 
 // conv_igemm256p8.hip: the 8-phase (4 per k-tile) schedule of the same tile
 int unit_conv256_p8_launch(Conv256Args& a, int out_dtype, bool reads_in_mfma, bool rows224, hipStream_t st);
+// conv_igemm256p8m.hip: the same schedule on v_mfma_f32_32x32x16_bf16 (256-row tiles)
+int unit_conv256_p8m_launch(Conv256Args& a, int out_dtype, hipStream_t st);
+// 1 = the 32x32x16 kernel is what variant 0 of unit_conv2d_fwd_big / unit_conv2d_fwd_big_ex launches (UNIT_P8M_DEFAULT)
+int unit_conv256_use_m32();

@@ -8,6 +8,9 @@
 // chunk (chunk ^= (row>>1)&7) and undone in the fragment reads. Two 64 KB LDS buffers: the DMA of k-tile t+1 is in flight
 // while k-tile t is multiplied; one vmcnt(0)+barrier per k-tile.  Requires C % 64 == 0 (every layer except the stem).
 #include "conv_igemm256.h"
+#ifndef UNIT_P8M_DEFAULT
+#define UNIT_P8M_DEFAULT 0
+#endif
 #include "conv_epilogue.h"
 
 // diagnostic builds only (tools/exp256.sh): 1 = no operand DMA after the first k-tile (MFMA + LDS-read bound of the loop),
@@ -577,6 +580,9 @@ static int launch256(Conv256Args& a, hipStream_t st) {
   return UNIT_OK;
 }
 
+// which MFMA shape variant 0 means for the p8 schedule (compile-time: no process state; callers A/B through the variant argument)
+int unit_conv256_use_m32() { return UNIT_P8M_DEFAULT; }
+
 // Same contract as unit_conv2d_fwd (include/unit_hip.h) restricted to bf16 inputs and C % 64 == 0.
 extern "C" int unit_conv2d_fwd_big(const void* x, const void* w, void* y, const float* bias, const void* residual,
                                    const void* mask_ref, int out_dtype, int N, int H, int W, int C, int K, int R, int S, int stride,
@@ -627,6 +633,8 @@ extern "C" int unit_conv2d_fwd_big(const void* x, const void* w, void* y, const 
       long c256 = (long)cdiv((long)cdiv(a.M, 256) * n_tiles, 256) * 256, c224 = (long)cdiv((long)cdiv(a.M, 224) * n_tiles, 256) * 224;
       r224 = c224 < c256;
     }
+    // 11 (and 0 when UNIT_P8M_DEFAULT is 1): the variant-8 schedule on v_mfma_f32_32x32x16_bf16 (conv_igemm256p8m.hip)
+    if (variant == 11 || (variant == 0 && p8 == 2 && !r224 && unit_conv256_use_m32())) return unit_conv256_p8m_launch(a, out_dtype, st);
     if (variant >= 7 && variant <= 10 || (variant == 0 && p8))
       return unit_conv256_p8_launch(a, out_dtype, variant >= 8 || (variant == 0 && p8 == 2), r224, st);
   }
@@ -661,7 +669,8 @@ extern "C" size_t unit_conv_pool_partial_floats(int M, int ldy) { return (size_t
 extern "C" int unit_conv2d_fwd_big_ex(const void* x, const void* w, void* y, const float* bias, const void* residual,
                                       const unsigned char* mask_bits, unsigned char* relu_bits, float* pool_partial, int pool_rows,
                                       int N, int H, int W, int C, int K, int R, int S, int pad, int ldy, int relu, const void* x2, int C2,
-                                      void* stream) {
+                                      int variant, void* stream) {
+  UNIT_CHECK_ARG(variant == 0 || variant == 8 || variant == 11, "conv_big_ex: variant 0 (default), 8 (16x16x32 MFMA) or 11 (32x32x16 MFMA)");
   // x2 != NULL: 1x1 conv over the channel concatenation [x (C channels) | x2 (C2 channels)] of two tensors of the same N, H, W;
   // w = [K][C + C2]. C2 must be a multiple of C.
   UNIT_CHECK_ARG(x2 == nullptr || (R == 1 && S == 1 && pad == 0 && C2 > 0 && C2 % C == 0 && ((uintptr_t)x2 % 16 == 0)),
@@ -686,6 +695,7 @@ extern "C" int unit_conv2d_fwd_big_ex(const void* x, const void* w, void* y, con
   a.x2 = x2; a.x2_bytes = (unsigned)x2b; a.cb_split = C / 64; a.ratio2 = x2 ? C2 / C : 1;
   a.ex = EpiExtra{relu_bits, mask_bits, pool_partial, pool_rows}; a.ex_on = 1;
   if (a.M == 0 || K == 0) return UNIT_OK;
+  if (variant == 11 || (variant == 0 && unit_conv256_use_m32())) return unit_conv256_p8m_launch(a, UNIT_BF16, (hipStream_t)stream);
   return unit_conv256_p8_launch(a, UNIT_BF16, true, false, (hipStream_t)stream);
 }
 

@@ -211,7 +211,7 @@ def conv2d(x, w, k, r, s, stride=1, pad=0, bias=None, residual=None, mask_ref=No
     if prof is not None:
         e0 = torch.cuda.Event(enable_timing=True)
         e0.record()
-    big = tile_cfg in (5, 6, 11, 12, 13, 14, 15, 16, 17, 18) or (tile_cfg == 0 and BIG_TILE_POLICY(x.dtype, n * oh * ow, k, c, r * s * c))
+    big = tile_cfg in (5, 6, 11, 12, 13, 14, 15, 16, 17, 18, 21) or (tile_cfg == 0 and BIG_TILE_POLICY(x.dtype, n * oh * ow, k, c, r * s * c))
     mid = -1
     if tile_cfg in (7, 8, 9, 10, 19, 20):
         mid = {19: 4, 20: 5}.get(tile_cfg, tile_cfg - 7)
@@ -224,7 +224,7 @@ def conv2d(x, w, k, r, s, stride=1, pad=0, bias=None, residual=None, mask_ref=No
     elif big:
         check(lib().unit_conv2d_fwd_big(_p(x), _p(w), _p(out), _p(bias), _p(residual), _p(mask_ref), dt(out_dtype),
                                         n, h, wd, c, k, r, s, stride, pad, oh, ow, ldy, oy_mul, ohf, owf, int(relu),
-                                        BIG_TILE_VARIANT if tile_cfg == 0 else {5: 0, 6: 1, 11: 2, 12: 3, 13: 4, 14: 6, 15: 7, 16: 8, 17: 9, 18: 10}[tile_cfg], _s()),
+                                        BIG_TILE_VARIANT if tile_cfg == 0 else {5: 0, 6: 1, 11: 2, 12: 3, 13: 4, 14: 6, 15: 7, 16: 8, 17: 9, 18: 10, 21: 11}[tile_cfg], _s()),
               "unit_conv2d_fwd_big")
     else:
         check(lib().unit_conv2d_fwd(_p(x), _p(w), _p(out), _p(bias), _p(residual), _p(mask_ref), dt(x.dtype), dt(out_dtype),
@@ -280,13 +280,15 @@ class ReluBits:
         return ((byte.int() >> (n & 7)) & 1).bool().view(self.r, self.bins, self.c)
 
 
-def conv2d_ex(x, w, k, r, s, pad=0, bias=None, residual=None, relu=False, mask_bits=None, want_bits=False, pool_rows=0, want_y=True, x2=None):
+def conv2d_ex(x, w, k, r, s, pad=0, bias=None, residual=None, relu=False, mask_bits=None, want_bits=False, pool_rows=0, want_y=True, x2=None, variant=0):
     """stride-1 bf16 conv on the 256x256 kernel with the extended epilogue (unit_conv2d_fwd_big_ex): returns (y | None, ReluBits |
     None, pooled [N, k] | None). pool_rows: must be OH*OW -- global average pool of each image (= RoI) fused; want_y=False then
     skips writing the map. mask_bits: ReluBits of an [N, OH*OW, k] map (RoI offset 0). x2 [N,H,W,C2]: second input of a 1x1 conv over
     the channel concatenation [x | x2] with w = [k][1][1][C + C2] (C2 a multiple of C)."""
     n, h, wd, c = x.shape
     c2 = 0
+    if variant == 0 and BIG_TILE_VARIANT in (8, 11):
+        variant = BIG_TILE_VARIANT
     if x2 is not None:
         c2 = x2.shape[3]
         assert r == 1 and s == 1 and pad == 0 and x2.shape[:3] == x.shape[:3] and c2 % c == 0 and x2.dtype == x.dtype and w.shape[-1] == c + c2
@@ -310,7 +312,7 @@ def conv2d_ex(x, w, k, r, s, pad=0, bias=None, residual=None, relu=False, mask_b
         e0.record()
     check(lib().unit_conv2d_fwd_big_ex(_p(x), _p(w), _p(y), _p(bias), _p(residual), _p(mask_bits.data if mask_bits is not None else None),
                                        _p(bits.data if bits is not None else None), _p(part), pool_rows,
-                                       n, h, wd, c, k, r, s, pad, ldy, int(relu), _p(x2), c2, _s()), "unit_conv2d_fwd_big_ex")
+                                       n, h, wd, c, k, r, s, pad, ldy, int(relu), _p(x2), c2, int(variant), _s()), "unit_conv2d_fwd_big_ex")
     if prof is not None:
         e1 = torch.cuda.Event(enable_timing=True)
         e1.record()
