@@ -56,6 +56,9 @@ int unit_conv2d_fwd(const void* x, const void* w, void* y, const float* bias, co
  * MFMA sections (csrc/conv_igemm256p8.hip); 7 = 8 without the reads-in-MFMA step; 9 = 8 on 224-row tiles; 10 = 224 or 256
  * rows, whichever needs fewer rounds x rows; 4 = two-stage loop (csrc/conv_igemm256.hip), 1 / 2 / 3 / 5 / 6 = its ping-pong,
  * 4 x 32-k, 224-row, auto-row and shared-input-super-tile (3x3 s1 p1 on 7x7 maps) forms: identical results bit for bit.
+ * 8 (and 0) on a 3x3 stride-1 pad-1 conv over a small map (the Res5 heads' conv2 and its dgrad on 7x7) cut the output into tiles of
+ * ONE output position x 256 images and skip the filter taps that read only zero padding there (18 % of the k-tiles); 12 = 8 without that
+ * (same results bit for bit).
  * 11 = the schedule of 8 on v_mfma_f32_32x32x16_bf16 (csrc/conv_igemm256p8m.hip): same fp32 accumulation, another summation order
  * inside a k-tile (equal to the others within fp32 rounding of the accumulation, not bit for bit). */
 int unit_conv2d_fwd_big(const void* x, const void* w, void* y, const float* bias, const void* residual, const void* mask_ref,

@@ -200,6 +200,35 @@ def test_conv_p8_kernel(dev, case, cfg):
     assert torch.equal(yf.cpu()[..., :k], y5.cpu()[..., :k])
 
 
+@pytest.mark.parametrize("case", [(1024, 7, 7, 128, 512), (300, 7, 7, 64, 264), (1030, 7, 7, 64, 256), (513, 5, 9, 128, 128), (256, 3, 3, 64, 72), (700, 1, 7, 64, 256)])
+def test_conv_position_major_tiles_skip_padding_taps(dev, case):
+    """3x3 s1 p1 convs on small maps with many images (conv2 of the Res5 blocks and its dgrad: 7x7 bins x 1024 RoIs) run on tiles of
+    ONE output position x 256 images and skip the filter taps that only read zero padding (tile_cfg 16 / 0); tile_cfg 22 forces the
+    row-major tiles. The skipped k-tiles added exact zeros: outputs are BIT-IDENTICAL, with and without the residual / ReLU / mask
+    epilogue, for image counts that are not multiples of 256, non-square maps and partial channel tiles; both equal F.conv2d."""
+    o = ops()
+    n, h, w, c, k = case
+    gen = g(n + c)
+    x = torch.randn(n, h, w, c, generator=gen).bfloat16()
+    wt = (torch.randn(k, 3, 3, c, generator=gen) / np.sqrt(9 * c)).bfloat16()
+    bias = torch.randn(k, generator=gen)
+    ldy = (k + 7) // 8 * 8
+    xd, wd = x.to(dev), wt.to(dev)
+    y_pm = o.conv2d(xd, wd, k, 3, 3, 1, 1, bias=bias.to(dev), ldy=ldy, tile_cfg=16)
+    y_rm = o.conv2d(xd, wd, k, 3, 3, 1, 1, bias=bias.to(dev), ldy=ldy, tile_cfg=22)
+    assert torch.equal(y_pm[..., :k], y_rm[..., :k])
+    sel = torch.randint(0, n, (16,), generator=gen).unique()
+    ref = F.conv2d(x[sel].float().permute(0, 3, 1, 2), wt.float().permute(0, 3, 1, 2), bias, padding=1).permute(0, 2, 3, 1)
+    assert torch.allclose(y_pm.cpu()[sel][..., :k].float(), ref, rtol=2e-2, atol=3e-2)
+    res = torch.randn(n, h, w, ldy, generator=gen).bfloat16().to(dev)
+    msk = torch.randn(n, h, w, ldy, generator=gen).bfloat16().to(dev)
+    a = o.conv2d(xd, wd, k, 3, 3, 1, 1, bias=bias.to(dev), residual=res, mask_ref=msk, relu=True, ldy=ldy, tile_cfg=16)
+    b = o.conv2d(xd, wd, k, 3, 3, 1, 1, bias=bias.to(dev), residual=res, mask_ref=msk, relu=True, ldy=ldy, tile_cfg=22)
+    assert torch.equal(a[..., :k], b[..., :k])
+    d = o.conv2d(xd, wd, k, 3, 3, 1, 1, tile_cfg=0)                                    # what the step launches
+    assert torch.equal(d, o.conv2d(xd, wd, k, 3, 3, 1, 1, tile_cfg=22))
+
+
 @pytest.mark.parametrize("case", [(3, 30, 33, 256, 256, 3, 1, 1), (1, 38, 63, 128, 75, 1, 1, 0), (2, 9, 9, 64, 40, 1, 1, 0), (70, 7, 7, 64, 512, 3, 1, 1),
                                   (2, 19, 23, 64, 320, 1, 2, 0), (11, 7, 7, 192, 264, 3, 1, 1)])
 def test_conv_p8_m32_kernel(dev, case):

@@ -21,7 +21,7 @@ for name, n, h, w, c, k, r, st, pad in SH:
     flops = 2.0 * n * oh * ow * k * r * r * c
     ref = None
     line = f"{name:32s}"
-    for tile in (13, 16, 21, 16, 21):
+    for tile in (22, 16, 22, 16, 21):
         try:
             y = o.conv2d(x, wt, k, r, r, st, pad, relu=True, residual=res, tile_cfg=tile)
             ms = timeit(lambda: o.conv2d(x, wt, k, r, r, st, pad, relu=True, residual=res, tile_cfg=tile))

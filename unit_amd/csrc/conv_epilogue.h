@@ -11,6 +11,21 @@
 #pragma once
 #include "common.h"
 
+// Position-class tiles (conv_igemm256p8.hip, Conv256Args::pm): the rows of a 3x3 s1 p1 "same" conv over small maps are regrouped by
+// the CLASS of their output position -- rectangles of positions that see the same set of in-map filter taps (interior, four edges, four
+// corners) -- image-major inside a class: class row i = image i / np, position (oh0 + (i % np) / cw, ow0 + (i % np) % cw).
+struct PmClass { int tile0, np, oh0, nh, ow0, cw; };      // tiles [tile0, next class's tile0) ; np = nh * cw positions
+struct PmRows {                                           // rows of one tile: class row i0 + (row of the tile)
+  int i0, np, oh0, ow0, cw, OW, OHW, N;
+  __device__ __forceinline__ bool map(int row, int& img, int& oh, int& ow) const {
+    int i = i0 + row;
+    img = i / np;
+    int q = i - img * np, dh = q / cw;
+    oh = oh0 + dh; ow = ow0 + (q - dh * cw);
+    return img < N;
+  }
+};
+
 template <int FA, int RB = 16> struct EpiCfg {
   static constexpr int CH = FA * 16;            // channels of the wave tile
   static constexpr int LPR = CH / 8;            // lanes per row (8 channels each)
@@ -48,8 +63,10 @@ struct EpiExtra {
 // m_w / n_w = first pixel row / channel of the wave tile; scr = this wave's scratch (EpiCfg<FA, RB>::BYTES, 16-B aligned).
 // Requires p.ldy % 8 == 0.
 // EX: `pool` = this wave's 8 KB LDS area [4 segments][8 row classes][64 channels] fp32 (FA == 4 only); plain output layout only.
-template <int FA, int FB, bool EX, int RB, typename Put, typename Args>
-__device__ __forceinline__ void epilogue_rows_bf16_blocks(Put put_block, char* scr, float* pool, int m_w, int n_w, const Args& p, int lane) {
+// PM: position-class tiles: m_w = the wave's first row INSIDE its tile, `rows` maps a tile row to (image, position); the stored row is
+// image * OH*OW + position.
+template <int FA, int FB, bool EX, int RB, bool PM = false, typename Put, typename Args>
+__device__ __forceinline__ void epilogue_rows_bf16_blocks(Put put_block, char* scr, float* pool, int m_w, int n_w, const Args& p, int lane, const PmRows* rows = nullptr) {
   typedef EpiCfg<FA, RB> E;
   constexpr int NBLK = FB * 16 / RB;
   bf16_t* __restrict__ Y = (bf16_t*)p.y;
@@ -101,6 +118,11 @@ __device__ __forceinline__ void epilogue_rows_bf16_blocks(Put put_block, char* s
       int m = m_w + b * RB + h * E::RPP + rr;
       q.ok[h] = n_ok && m < p.M;
       int mm = q.ok[h] ? m : 0;
+      if constexpr (PM) {
+        int img, oh, ow;
+        q.ok[h] = rows->map(m, img, oh, ow) && n_ok;
+        q.off[h] = ((long)(q.ok[h] ? img : 0) * rows->OHW + oh * rows->OW + ow) * p.ldy + n;
+      } else
       if (plain) q.off[h] = (long)mm * p.ldy + n;
       else {
         int ow = mm % p.OW; int t = mm / p.OW; int oh = t % p.OH; int nimg = t / p.OH;
@@ -193,8 +215,9 @@ __device__ __forceinline__ void epilogue_rows_bf16_blocks(Put put_block, char* s
 }
 
 // 16x16 MFMA accumulators: acc[a][b] = 16x16 tile (channels a*16.., pixel rows b*16..); lane holds 4 consecutive channels of row lane & 15
-template <int FA, int FB, bool EX, typename Args>
-__device__ __forceinline__ void epilogue_rows_bf16_impl(const f32x4 (&acc)[FA][FB], char* scr, float* pool, int m_w, int n_w, const Args& p, int lane) {
+template <int FA, int FB, bool EX, bool PM = false, typename Args>
+__device__ __forceinline__ void epilogue_rows_bf16_impl(const f32x4 (&acc)[FA][FB], char* scr, float* pool, int m_w, int n_w, const Args& p, int lane,
+                                                        const PmRows* rows = nullptr) {
   typedef EpiCfg<FA, 16> E;
   const int frow = lane & 15, fq = lane >> 4;
   auto put = [&](int b, char* sc) {
@@ -202,7 +225,7 @@ __device__ __forceinline__ void epilogue_rows_bf16_impl(const f32x4 (&acc)[FA][F
     for (int a = 0; a < FA; ++a)
       *reinterpret_cast<f32x4*>(sc + frow * E::PITCH + (a * 16 + fq * 4) * 4) = acc[a][b];
   };
-  epilogue_rows_bf16_blocks<FA, FB, EX, 16>(put, scr, pool, m_w, n_w, p, lane);
+  epilogue_rows_bf16_blocks<FA, FB, EX, 16, PM>(put, scr, pool, m_w, n_w, p, lane, rows);
 }
 
 template <int FA, int FB, typename Args>

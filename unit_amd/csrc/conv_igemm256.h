@@ -21,6 +21,13 @@ struct Conv256Args {
   // second input tensor of a 1x1 conv (conv_igemm256p8.hip only): k-tiles >= cb_split read x2 [M][ratio2 * cb_split * 64] -- the
   // GEMM [x | x2] . [w_a ; w_b] in one launch (Bottleneck conv3 + shortcut; conv1 dgrad + shortcut dgrad). C = total channels.
   const void* x2; unsigned x2_bytes; int cb_split, ratio2;
+  // position-class tiles (conv_igemm256p8.hip, RM schedule, 3x3 s1 p1 "same" convs on small maps: conv2 of the Res5 blocks and its
+  // dgrad on 7x7 bins): pm_ncls > 0 = the rows are regrouped by position class (conv_epilogue.h PmClass; classes sorted by their
+  // number of in-map taps, heaviest first) so that a filter tap is inside the map for ALL rows of a tile or for none -- the k-tiles of
+  // taps that only read zero padding (18 % of them on 7x7) are skipped, staging and MFMAs alike. Those k-tiles added exact zeros:
+  // results are bit-identical.
+  int pm_ncls;
+  PmClass pm_cls[9];
 };
 
 // LDS image of an operand stage: [row][128 B = 64 k]; 16-B chunks XOR-swizzled with (row>>1)&7 (applied to the SOURCE

@@ -580,6 +580,43 @@ static int launch256(Conv256Args& a, hipStream_t st) {
   return UNIT_OK;
 }
 
+// Position classes of a 3x3 s1 p1 "same" conv (Conv256Args::pm_cls): the map rows split into runs with the same in-map tap rows
+// (first row / middle rows / last row; fewer for maps of 1 or 2 rows), the columns likewise; a class = a row run x a column run.
+// Sorted by taps, heaviest first (the kernel starts the heavy tiles first). Leaves pm_ncls = 0 when the row-major tiles need fewer
+// k-tiles (few images: every class is padded to whole 256-row tiles).
+static void build_position_classes(Conv256Args& a) {
+  struct Run { int lo, n, taps; };
+  auto runs = [](int L, Run (&out)[3]) {
+    int cnt = 0;
+    for (int o = 0; o < L; ++o) {
+      int t0 = o > 0 ? 0 : 1, t1 = o < L - 1 ? 2 : 1;                       // in-map taps [t0, t1] of output index o (pad 1)
+      if (cnt > 0) {
+        int p = out[cnt - 1].lo, q0 = p > 0 ? 0 : 1, q1 = p < L - 1 ? 2 : 1;
+        if (q0 == t0 && q1 == t1) { ++out[cnt - 1].n; continue; }
+      }
+      out[cnt++] = Run{o, 1, t1 - t0 + 1};
+    }
+    return cnt;
+  };
+  Run rr[3], cc[3];
+  int nr = runs(a.OH, rr), nc = runs(a.OW, cc);
+  struct Cls { PmClass c; int taps; long tiles; } cls[9];
+  int n = 0;
+  for (int i = 0; i < nr; ++i)
+    for (int j = 0; j < nc; ++j) {
+      Cls k; k.c = PmClass{0, rr[i].n * cc[j].n, rr[i].lo, rr[i].n, cc[j].lo, cc[j].n}; k.taps = rr[i].taps * cc[j].taps;
+      k.tiles = cdiv((long)a.N * k.c.np, 256);
+      cls[n++] = k;
+    }
+  for (int i = 1; i < n; ++i)                                                // insertion sort, taps descending (stable)
+    for (int j = i; j > 0 && cls[j].taps > cls[j - 1].taps; --j) { Cls t = cls[j]; cls[j] = cls[j - 1]; cls[j - 1] = t; }
+  long ktiles = 0, tiles = 0;
+  for (int i = 0; i < n; ++i) { cls[i].c.tile0 = (int)tiles; tiles += cls[i].tiles; ktiles += cls[i].tiles * cls[i].taps; }
+  if (ktiles * 100 >= (long)cdiv(a.M, 256) * 9 * 95) return;
+  a.pm_ncls = n; a.tiles_m = (int)tiles;
+  for (int i = 0; i < n; ++i) a.pm_cls[i] = cls[i].c;
+}
+
 // which MFMA shape variant 0 means for the p8 schedule (compile-time: no process state; callers A/B through the variant argument)
 int unit_conv256_use_m32() { return UNIT_P8M_DEFAULT; }
 
@@ -601,7 +638,7 @@ extern "C" int unit_conv2d_fwd_big(const void* x, const void* w, void* y, const 
   UNIT_CHECK_ARG(xb < 0xFFFFFFF0ull && wb < 0xFFFFFFF0ull, "conv_big: operand larger than 4 GiB");
   a.x_bytes = (unsigned)xb; a.w_bytes = (unsigned)wb;
   a.ex = EpiExtra{nullptr, nullptr, nullptr, 0}; a.ex_on = 0;
-  a.x2 = nullptr; a.x2_bytes = 0; a.cb_split = 0; a.ratio2 = 1;
+  a.x2 = nullptr; a.x2_bytes = 0; a.cb_split = 0; a.ratio2 = 1; a.pm_ncls = 0;
   if (a.M == 0 || K == 0) return UNIT_OK;
   hipStream_t st = (hipStream_t)stream;
   // variant 0 / 4: one barrier per k-tile, 256-row tiles; 3: 224-row tiles; 5: 224 or 256 rows, whichever needs fewer
@@ -635,8 +672,17 @@ extern "C" int unit_conv2d_fwd_big(const void* x, const void* w, void* y, const 
     }
     // 11 (and 0 when UNIT_P8M_DEFAULT is 1): the variant-8 schedule on v_mfma_f32_32x32x16_bf16 (conv_igemm256p8m.hip)
     if (variant == 11 || (variant == 0 && p8 == 2 && !r224 && unit_conv256_use_m32())) return unit_conv256_p8m_launch(a, out_dtype, st);
-    if (variant >= 7 && variant <= 10 || (variant == 0 && p8))
-      return unit_conv256_p8_launch(a, out_dtype, variant >= 8 || (variant == 0 && p8 == 2), r224, st);
+    // 12: variant 8 with row-major tiles even where position-major tiles apply (A/B and bit-identity tests)
+    if (variant == 12) return unit_conv256_p8_launch(a, out_dtype, true, false, st);
+    if (variant >= 7 && variant <= 10 || (variant == 0 && p8)) {
+      bool rm = variant >= 8 || (variant == 0 && p8 == 2);
+      // position-class tiles (Conv256Args::pm_ncls): 3x3 s1 p1 conv on a small map, plain bf16 output, when skipping the all-padding
+      // taps saves more k-tiles than padding every class to whole tiles costs
+      if (rm && !r224 && (variant == 0 || variant == 8) && out_dtype == UNIT_BF16 && (ldy & 7) == 0 && R == 3 && S == 3 && stride == 1 &&
+          pad == 1 && OH == H && OW == W && oy_mul == 1 && OHf == OH && OWf == OW && H * W <= 4096 && (size_t)N * H * W * ldy * 2 < 0xFFFFFFF0ull)
+        build_position_classes(a);
+      return unit_conv256_p8_launch(a, out_dtype, rm, r224, st);
+    }
   }
   bool rows224 = variant == 3;
   if (variant == 5) {
@@ -692,7 +738,7 @@ extern "C" int unit_conv2d_fwd_big_ex(const void* x, const void* w, void* y, con
   size_t xb = (size_t)N * H * W * C * 2, wb = (size_t)K * R * S * Ct * 2, x2b = x2 ? (size_t)N * H * W * C2 * 2 : 0;
   UNIT_CHECK_ARG(xb < 0xFFFFFFF0ull && wb < 0xFFFFFFF0ull && x2b < 0xFFFFFFF0ull, "conv_big_ex: operand larger than 4 GiB");
   a.x_bytes = (unsigned)xb; a.w_bytes = (unsigned)wb;
-  a.x2 = x2; a.x2_bytes = (unsigned)x2b; a.cb_split = C / 64; a.ratio2 = x2 ? C2 / C : 1;
+  a.x2 = x2; a.x2_bytes = (unsigned)x2b; a.cb_split = C / 64; a.ratio2 = x2 ? C2 / C : 1; a.pm_ncls = 0;
   a.ex = EpiExtra{relu_bits, mask_bits, pool_partial, pool_rows}; a.ex_on = 1;
   if (a.M == 0 || K == 0) return UNIT_OK;
   if (variant == 11 || (variant == 0 && unit_conv256_use_m32())) return unit_conv256_p8m_launch(a, UNIT_BF16, (hipStream_t)stream);

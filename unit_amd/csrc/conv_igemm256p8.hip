@@ -52,11 +52,27 @@ __global__ void __launch_bounds__(512, 2) conv_igemm256_p8_kernel(Conv256Args p)
 
   int nwg = p.tiles_m * p.tiles_n;
   int bid = blockIdx.x;
-  {
+  const bool pm = RM && B1 == 4 && p.pm_ncls > 0;
+  int tile_n, tile_m;
+  PmRows pmr = {0, 1, 0, 0, 1, p.OW, p.OH * p.OW, p.N};
+  int pm_nh = 1;
+  if (pm) {
+    // position-class tiles (Conv256Args::pm_ncls): workgroup b runs on XCD b % 8; XCD x takes the row tiles x, x + 8, ... in that
+    // order -- heaviest classes first on every XCD -- and all channel tiles of a row tile one after the other (they share its rows
+    // through that XCD's L2)
+    int xcd = bid % 8, loc = bid / 8;
+    tile_n = loc % p.tiles_n; tile_m = (loc / p.tiles_n) * 8 + xcd;
+    if (tile_m >= p.tiles_m) return;
+    int c = 0;
+    while (c + 1 < p.pm_ncls && tile_m >= p.pm_cls[c + 1].tile0) ++c;
+    const PmClass& k = p.pm_cls[c];
+    pmr.i0 = (tile_m - k.tile0) * BM; pmr.np = k.np; pmr.oh0 = k.oh0; pmr.ow0 = k.ow0; pmr.cw = k.cw;
+    pm_nh = k.nh;
+  } else {
     int q = nwg / 8, r = nwg % 8, xcd = bid % 8, loc = bid / 8;
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+    tile_n = bid % p.tiles_n; tile_m = bid / p.tiles_n;
   }
-  int tile_n = bid % p.tiles_n, tile_m = bid / p.tiles_n;
   int m0 = tile_m * BM, n0 = tile_n * BN;
 
   const bf16_t* __restrict__ X = (const bf16_t*)p.x;
@@ -89,6 +105,10 @@ __global__ void __launch_bounds__(512, 2) conv_igemm256_p8_kernel(Conv256Args p)
       bool ok = m < p.M && (q == 0 || (R & 63) < B1 * 16);
       int mm = ok ? m : 0;
       int ow = mm % p.OW; int t = mm / p.OW; int oh = t % p.OH; int n = t / p.OH;
+      if (pm) {                                  // row of the tile -> (image, position) of its class
+        ok = pmr.map(m - m0, n, oh, ow);
+        if (!ok) n = 0;
+      }
       int ih0 = oh * p.stride - p.pad, iw0 = ow * p.stride - p.pad;
       x_off0[q * 2 + j] = ((unsigned)n * (unsigned)(p.H * p.W * Cx) + (unsigned)((ih0 * p.W + iw0) * Cx + sw * 8)) * 2u;  // tap (0,0), wraps for negative ih0/iw0
       x_ih0[q * 2 + j] = ok ? ih0 : -(1 << 20);                    // rows past M fail the bounds test of every tap
@@ -99,10 +119,16 @@ __global__ void __launch_bounds__(512, 2) conv_igemm256_p8_kernel(Conv256Args p)
 
   // k-tile order: channel block outermost, the R*S taps innermost (conv_igemm256.hip). (cb, r, s) of the k-tile that the
   // staging is currently working on, and the two byte offsets derived from them, live in scalar registers.
-  int st_cb = 0, st_r = 0, st_s = 0;
-  unsigned st_kx = 0, st_kw = 0;
+  // taps of this tile: all of them, or (position-major tiles) those inside the map at the tile's position -- wave-uniform scalars
+  int r_lo = 0, r_hi = p.R - 1, s_lo = 0, s_hi = p.S - 1;
+  if (pm) {                                      // the same for every position of the class (that is what makes it a class)
+    r_lo = max(0, p.pad - pmr.oh0); r_hi = min(p.R - 1, p.H - 1 + p.pad - (pmr.oh0 + pm_nh - 1));
+    s_lo = max(0, p.pad - pmr.ow0); s_hi = min(p.S - 1, p.W - 1 + p.pad - (pmr.ow0 + pmr.cw - 1));
+  }
+  int st_cb = 0, st_r = r_lo, st_s = s_lo;
+  unsigned st_kx = (unsigned)((st_r * p.W + st_s) * Cx) * 2u, st_kw = (unsigned)((st_r * p.S + st_s) * p.C) * 2u;
   auto st_advance = [&]() {
-    if (++st_s == p.S) { st_s = 0; if (++st_r == p.R) { st_r = 0; ++st_cb; } }
+    if (++st_s > s_hi) { st_s = s_lo; if (++st_r > r_hi) { st_r = r_lo; ++st_cb; } }
     st_kx = (unsigned)((st_r * p.W + st_s) * Cx + st_cb * BK) * 2u;
     st_kw = (unsigned)((st_r * p.S + st_s) * p.C + st_cb * BK) * 2u;
   };
@@ -134,7 +160,7 @@ __global__ void __launch_bounds__(512, 2) conv_igemm256_p8_kernel(Conv256Args p)
 #pragma unroll
     for (int b = 0; b < FBT; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  const int nk = p.Kgemm / BK;
+  const int nk = pm ? (p.C / BK) * (r_hi - r_lo + 1) * (s_hi - s_lo + 1) : p.Kgemm / BK;
   const int frow = lane & 15, fq = lane >> 4;
   // per-lane fragment offsets inside a half-tile, k-substep 0 (substep 1 = ^ 64); tile rows b*16 / a*16 add b*2048 / a*2048
   const int fsw = (fq ^ ((frow >> 1) & 7)) << 4;
@@ -329,6 +355,12 @@ __global__ void __launch_bounds__(512, 2) conv_igemm256_p8_kernel(Conv256Args p)
           return;
         }
       }
+      if constexpr (RM && B1 == 4) {
+        if (pm) {
+          epilogue_rows_bf16_impl<4, FBT, false, true>(acc, smem + wid * EpiCfg<4>::BYTES, nullptr, wm * (FBT * 16), n0 + wn * 64, p, lane, &pmr);
+          return;
+        }
+      }
       epilogue_rows_bf16<4, FBT>(acc, smem + wid * EpiCfg<4>::BYTES, m0 + wm * (FBT * 16), n0 + wn * 64, p, lane);
       return;
     }
@@ -377,14 +409,21 @@ __global__ void __launch_bounds__(512, 2) conv_igemm256_p8_kernel(Conv256Args p)
 
 template <typename TO, bool RM, int B1>
 static int launch256_p8(Conv256Args& a, hipStream_t st) {
-  a.tiles_m = cdiv(a.M, 32 * (4 + B1)); a.tiles_n = cdiv(a.K, 256);
+  if (a.pm_ncls == 0) a.tiles_m = cdiv(a.M, 32 * (4 + B1));
+  a.tiles_n = cdiv(a.K, 256);
+  int grid = a.tiles_m * a.tiles_n;
+  if (a.pm_ncls > 0) {
+    if (!RM || B1 != 4) { unit_set_error("conv_big: position-class tiles need the 256-row RM schedule"); return UNIT_ERR_UNSUPPORTED; }
+    // a.tiles_m was set with the class table; the grid is padded to whole groups of 8 row tiles (one per XCD)
+    grid = cdiv(a.tiles_m, 8) * 8 * a.tiles_n;
+  }
   size_t lds = 8 * 128 * 128;
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)conv_igemm256_p8_kernel<TO, RM, B1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
-  conv_igemm256_p8_kernel<TO, RM, B1><<<a.tiles_m * a.tiles_n, 512, lds, st>>>(a);
+  conv_igemm256_p8_kernel<TO, RM, B1><<<grid, 512, lds, st>>>(a);
   UNIT_LAUNCH_CHECK();
   return UNIT_OK;
 }

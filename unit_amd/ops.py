@@ -211,7 +211,7 @@ def conv2d(x, w, k, r, s, stride=1, pad=0, bias=None, residual=None, mask_ref=No
     if prof is not None:
         e0 = torch.cuda.Event(enable_timing=True)
         e0.record()
-    big = tile_cfg in (5, 6, 11, 12, 13, 14, 15, 16, 17, 18, 21) or (tile_cfg == 0 and BIG_TILE_POLICY(x.dtype, n * oh * ow, k, c, r * s * c))
+    big = tile_cfg in (5, 6, 11, 12, 13, 14, 15, 16, 17, 18, 21, 22) or (tile_cfg == 0 and BIG_TILE_POLICY(x.dtype, n * oh * ow, k, c, r * s * c))
     mid = -1
     if tile_cfg in (7, 8, 9, 10, 19, 20):
         mid = {19: 4, 20: 5}.get(tile_cfg, tile_cfg - 7)
@@ -224,7 +224,7 @@ def conv2d(x, w, k, r, s, stride=1, pad=0, bias=None, residual=None, mask_ref=No
     elif big:
         check(lib().unit_conv2d_fwd_big(_p(x), _p(w), _p(out), _p(bias), _p(residual), _p(mask_ref), dt(out_dtype),
                                         n, h, wd, c, k, r, s, stride, pad, oh, ow, ldy, oy_mul, ohf, owf, int(relu),
-                                        BIG_TILE_VARIANT if tile_cfg == 0 else {5: 0, 6: 1, 11: 2, 12: 3, 13: 4, 14: 6, 15: 7, 16: 8, 17: 9, 18: 10, 21: 11}[tile_cfg], _s()),
+                                        BIG_TILE_VARIANT if tile_cfg == 0 else {5: 0, 6: 1, 11: 2, 12: 3, 13: 4, 14: 6, 15: 7, 16: 8, 17: 9, 18: 10, 21: 11, 22: 12}[tile_cfg], _s()),
               "unit_conv2d_fwd_big")
     else:
         check(lib().unit_conv2d_fwd(_p(x), _p(w), _p(out), _p(bias), _p(residual), _p(mask_ref), dt(x.dtype), dt(out_dtype),
