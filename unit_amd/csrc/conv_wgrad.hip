@@ -202,7 +202,7 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ partial, int split
 
 // conv_wgrad256.hip: 256x256 LDS-DMA kernel for the big-M bf16 layers (same slab layout)
 extern "C" int unit_wgrad_use_big(int in_dtype, long M, int K, int C, int RS);
-extern "C" int unit_wgrad_big_splits(long M, int tiles);
+extern "C" int unit_wgrad_big_splits(long M, int tiles, int R, int S, int OHW);
 extern "C" int unit_conv2d_wgrad_big_launch(const void* x, const void* dy, float* partial, int N, int H, int W, int C, int K, int R, int S,
                                             int stride, int pad, int OH, int OW, int ldy, size_t workspace_bytes, void* stream);
 
@@ -240,7 +240,7 @@ static int choose_splits(int M, int tiles, int ms) {
 extern "C" size_t unit_conv2d_wgrad_workspace_bytes(int in_dtype, int N, int OH, int OW, int K, int R, int S, int C) {
   long M = (long)N * OH * OW;
   int Kgemm = R * S * C;
-  if (unit_wgrad_use_big(in_dtype, M, K, C, R * S)) return (size_t)unit_wgrad_big_splits(M, (Kgemm / 256) * (K / 256)) * K * Kgemm * sizeof(float);
+  if (unit_wgrad_use_big(in_dtype, M, K, C, R * S)) return (size_t)unit_wgrad_big_splits(M, (Kgemm / 256) * (K / 256), R, S, OH * OW) * K * Kgemm * sizeof(float);
   int tiles = cdiv(Kgemm, 128) * cdiv(K, 128);
   int splits = choose_splits((int)M, tiles, in_dtype == UNIT_BF16 ? 64 : 32);
   return (size_t)splits * K * Kgemm * sizeof(float);
@@ -291,7 +291,7 @@ extern "C" int unit_conv2d_wgrad(const void* x, const void* dy, float* dw, const
     b.x = a.x; b.dy = a.dy; b.partial = a.partial; b.N = a.N; b.H = a.H; b.W = a.W; b.C = a.C; b.K = a.K; b.R = a.R; b.S = a.S;
     b.stride = a.stride; b.pad = a.pad; b.OH = a.OH; b.OW = a.OW; b.ldy = a.ldy; b.Kgemm = a.Kgemm; b.M = a.M;
     b.tiles_k = a.tiles_k; b.tiles_n = a.tiles_n; b.splits = a.splits; b.m_per_split = a.m_per_split;
-    b.x_bytes = a.x_bytes; b.dy_bytes = a.dy_bytes; b.magic_ohw = a.magic_ohw; b.magic_ow = a.magic_ow; b.OHW = a.OHW; b.use_magic = a.use_magic;
+    b.x_bytes = a.x_bytes; b.dy_bytes = a.dy_bytes; b.magic_ohw = a.magic_ohw; b.magic_ow = a.magic_ow; b.OHW = a.OHW; b.use_magic = a.use_magic; b.valid_only = 0;
     int rc = unit_wgrad128_ring_launch(b, st);
     if (rc != UNIT_OK) return rc;
   } else if (in_dtype == UNIT_BF16) {
@@ -316,7 +316,7 @@ extern "C" int unit_conv2d_wgrad(const void* x, const void* dy, float* dw, const
 // number of split-M slabs unit_conv2d_wgrad writes for this shape (slab s at workspace + s*K*R*S*C floats)
 extern "C" int unit_conv2d_wgrad_splits(int in_dtype, int N, int OH, int OW, int K, int R, int S, int C) {
   long M = (long)N * OH * OW;
-  if (unit_wgrad_use_big(in_dtype, M, K, C, R * S)) return unit_wgrad_big_splits(M, (R * S * C / 256) * (K / 256));
+  if (unit_wgrad_use_big(in_dtype, M, K, C, R * S)) return unit_wgrad_big_splits(M, (R * S * C / 256) * (K / 256), R, S, OH * OW);
   int tiles = cdiv(R * S * C, 128) * cdiv(K, 128);
   return choose_splits((int)M, tiles, in_dtype == UNIT_BF16 ? 64 : 32);
 }

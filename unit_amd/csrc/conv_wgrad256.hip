@@ -163,7 +163,15 @@ extern "C" int unit_wgrad_use_big(int in_dtype, long M, int K, int C, int RS) {
   return M >= 16384 || (M >= 8192 && tiles >= 96);
 }
 
-extern "C" int unit_wgrad_big_splits(long M, int tiles) {
+// 3x3 convs on small maps get one spare slab: the valid-only contraction of conv_wgrad256p8.hip deals its workgroups to the filter
+// taps unevenly (Wgrad256Args::valid_only); where that path does not apply the spare is simply one more split
+extern "C" int unit_wgrad_big_splits_base(long M, int tiles);
+extern "C" int unit_wgrad_big_splits(long M, int tiles, int R, int S, int OHW) {
+  int s = unit_wgrad_big_splits_base(M, tiles);
+  return (R == 3 && S == 3 && OHW <= 512) ? s + 1 : s;
+}
+
+extern "C" int unit_wgrad_big_splits_base(long M, int tiles) {
   // one workgroup per CU (128 KB of LDS): 256 slots per round; >= 8 staged steps per split. Cost model (us): a workgroup
   // needs ~6 us of fixed time plus ~1.3 us per 64-pixel step; the grid runs in rounds of 256 workgroups; every workgroup
   // writes a 256 KB fp32 slab that the reduction reads back (~2 x 256 KB at ~4 TB/s).
@@ -196,13 +204,18 @@ extern "C" int unit_conv2d_wgrad_big_launch(const void* x, const void* dy, float
   a.magic_ohw = a.OHW > 1 ? (unsigned)((0x100000000ull + a.OHW - 1) / (unsigned long long)a.OHW) : 0xFFFFFFFFu;
   a.magic_ow = OW > 1 ? (unsigned)((0x100000000ull + OW - 1) / (unsigned long long)OW) : 0xFFFFFFFFu;
   a.tiles_k = a.Kgemm / 256; a.tiles_n = K / 256;
-  a.splits = unit_wgrad_big_splits(a.M, a.tiles_k * a.tiles_n);
+  a.splits = unit_wgrad_big_splits(a.M, a.tiles_k * a.tiles_n, R, S, OH * OW);
   int mps = cdiv(a.M, a.splits);
   a.m_per_split = cdiv(mps, 64) * 64;
   size_t need = (size_t)a.splits * K * a.Kgemm * sizeof(float);
   if (workspace_bytes < need) { unit_set_error("wgrad_big: workspace too small"); return UNIT_ERR_WORKSPACE; }
   int variant = g_wgrad_big_variant;
-  if (variant == 3) variant = ((R == 1 && S == 1 && stride == 1 && pad == 0) || OH * OW <= 1024) ? 0 : 2;
+  a.valid_only = 0;
+  if (variant == 3) {
+    variant = ((R == 1 && S == 1 && stride == 1 && pad == 0) || OH * OW <= 1024) ? 0 : 2;
+    // 3x3 s1 p1 "same" conv on a small map: contract only over the pixels whose tap lies inside the map (Wgrad256Args::valid_only)
+    if (variant == 0 && R == 3 && S == 3 && stride == 1 && pad == 1 && OH == H && OW == W && OH * OW <= 512) a.valid_only = 1;
+  }
   if (variant == 0) {
     int rc = unit_wgrad256_p8_launch(a, (hipStream_t)stream);
     return rc == UNIT_OK ? a.splits : rc;

@@ -32,15 +32,87 @@ __global__ void __launch_bounds__(512, 2) conv_wgrad256_p8_kernel(Wgrad256Args p
   // the tiles of one or two split-M slabs. They walk the same pixel rows at the same pace, so an x / dy row block is
   // fetched from HBM once per XCD and then served to the other tiles of the slab out of that XCD's 4 MB L2.
   int bid = blockIdx.x;
-  {
+  const bool vo = p.valid_only != 0;
+  int tile_k, tile_n, split;
+  // valid_only (Wgrad256Args): the contraction index of a tile runs over (image, valid output position of ITS filter tap) instead of
+  // all pixels; valid positions = rows v_oh0 .. of the map, columns v_ow0 .. of v_cw (nv per image). The taps differ in work (36 / 42
+  // / 49 positions on 7x7) and the grid is one round of workgroups, so with the same split count for every tap the centre tap would
+  // set the time: the p.splits slabs include one spare, and 9 * (p.splits - 1) workgroup slots per (channel block, n tile) are dealt to
+  // the taps in proportion to their positions (7 x 7, 8 slabs: corners 6, edges 7, centre 8 splits -> 6.0 / 6.0 / 6.1 positions per
+  // split instead of 49 / 7). A workgroup past its tap's count ("filler") only leaves its slab tile zero.
+  int v_oh0 = 0, v_ow0 = 0, v_cw = p.OW, nv = p.OHW, Meff = p.M, mps = p.m_per_split;
+  if (!vo) {
     int nwg = gridDim.x, q = nwg / 8, r = nwg % 8, xcd = bid % 8, loc = bid / 8;
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+    tile_k = bid % p.tiles_k; int tt = bid / p.tiles_k;
+    tile_n = tt % p.tiles_n; split = tt / p.tiles_n;
+  } else {
+    const int ntap = p.R * p.S, ncb = p.tiles_k / ntap;
+    int nh[3], nw[3], sum_h = 0, sum_w = 0;
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+      nh[t] = max(0, min(p.OH - 1, p.H - 1 + p.pad - t) - max(0, p.pad - t) + 1);
+      nw[t] = max(0, min(p.OW - 1, p.W - 1 + p.pad - t) - max(0, p.pad - t) + 1);
+      sum_h += nh[t]; sum_w += nw[t];
+    }
+    const int tot = sum_h * sum_w, slots = ntap * max(1, p.splits - 1);
+    int stt[9], sum_st = 0;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      int v = nh[t / 3] * nw[t % 3];
+      stt[t] = max(1, min(p.splits, (slots * v + tot / 2) / tot));
+      sum_st += stt[t];
+    }
+    // id map: real work first on every XCD (workgroup b runs on XCD b % 8 and the XCD's workgroups start in id order), fillers last;
+    // real items ordered split-major (split j of every tap that has one, all n tiles and channel blocks: they walk about the same
+    // pixel rows at the same pace -- shared through the XCD's L2), each XCD a contiguous run of them
+    const int per = p.tiles_n * ncb;
+    const int RI = per * sum_st, nwg = gridDim.x;
+    const int xcd = bid % 8, loc = bid / 8;
+    const int start_r = xcd * (RI / 8) + min(xcd, RI % 8), real_x = RI / 8 + (xcd < RI % 8 ? 1 : 0);
+    const int start_t = xcd * (nwg / 8) + min(xcd, nwg % 8);
+    int tap = 0, cb = 0;
+    if (loc < real_x) {
+      int L = start_r + loc, j = 0;
+      for (;; ++j) {
+        int act = 0;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) act += stt[t] > j ? 1 : 0;
+        if (L < per * act) {
+          tile_n = L / (ncb * act); int rem = L - tile_n * (ncb * act);
+          int a = rem / ncb; cb = rem - a * ncb;
+#pragma unroll
+          for (int t = 8; t >= 0; --t) { int before = 0; for (int u = 0; u < t; ++u) before += stt[u] > j ? 1 : 0; if (stt[t] > j && before == a) tap = t; }
+          break;
+        }
+        L -= per * act;
+      }
+      split = j;
+    } else {
+      int z = (start_t - start_r) + (loc - real_x);
+      tile_n = 0; split = p.splits;             // (overwritten below; z always lands in a tap)
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        int cnt = (p.splits - stt[t]) * per;
+        if (z >= 0 && z < cnt) {
+          int jj = z / per, rem = z - jj * per;
+          split = stt[t] + jj; tile_n = rem / ncb; cb = rem - tile_n * ncb; tap = t;
+          z = -1;
+        } else if (z >= 0) z -= cnt;
+      }
+    }
+    tile_k = tap * ncb + cb;
+    int kr_ = tap / p.S, ks_ = tap - kr_ * p.S;
+    v_oh0 = max(0, p.pad - kr_); v_ow0 = max(0, p.pad - ks_);
+    v_cw = nw[ks_]; nv = nh[kr_] * v_cw;
+    Meff = p.N * nv;
+    int st = stt[tap];
+    mps = ((Meff + st - 1) / st + 63) / 64 * 64;
+    if (split >= st) Meff = 0;
   }
-  int tile_k = bid % p.tiles_k; int tt = bid / p.tiles_k;
-  int tile_n = tt % p.tiles_n; int split = tt / p.tiles_n;
   int k0 = tile_k * 256, n0 = tile_n * 256;
-  int m_begin = split * p.m_per_split, m_end = min(p.M, m_begin + p.m_per_split);
   int rs = k0 / p.C, ch0 = k0 - rs * p.C, kr = rs / p.S, ksx = rs - kr * p.S;
+  int m_begin = min(Meff, split * mps), m_end = min(Meff, m_begin + mps);
 
   const bf16_t* __restrict__ X = (const bf16_t*)p.x;
   const bf16_t* __restrict__ DY = (const bf16_t*)p.dy;
@@ -72,20 +144,23 @@ __global__ void __launch_bounds__(512, 2) conv_wgrad256_p8_kernel(Wgrad256Args p
   // incrementally (+64 pixels per step) and a small LDS table maps the pixel to its input offset for THIS workgroup's filter
   // tap ((ih*W + iw)*C, or -1 outside the map). Table after the operand stages (OHW <= 1024 entries; larger maps divide).
   int* tab = reinterpret_cast<int*>(smem + 2 * BUF);
+  int* tabd = tab + 512;                          // valid_only: position index -> output pixel of the dy row (OHW <= 512 then)
   const bool use_tab = !pointwise && p.OHW <= 1024;
   int xn[2] = {0, 0}, xp[2] = {0, 0};
-  const int adv_q = MS / p.OHW, adv_r = MS - adv_q * p.OHW;
+  const int adv_q = MS / nv, adv_r = MS - adv_q * nv;
   if (use_tab) {
-    for (int px = tid; px < p.OHW; px += 512) {
-      int oh = px / p.OW, ow = px - oh * p.OW;
+    for (int px = tid; px < nv; px += 512) {
+      int oh = px / v_cw, ow = px - oh * v_cw;
+      oh += v_oh0; ow += v_ow0;
       int ih = oh * p.stride - p.pad + kr, iw = ow * p.stride - p.pad + ksx;
       tab[px] = ((unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W) ? (ih * p.W + iw) * p.C : -1;
+      if (vo) tabd[px] = oh * p.OW + ow;
     }
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       unsigned um = (unsigned)(m_begin + s_row[j]);
-      unsigned n = um / (unsigned)p.OHW;
-      xn[j] = (int)n; xp[j] = (int)(um - n * (unsigned)p.OHW);
+      unsigned n = um / (unsigned)nv;
+      xn[j] = (int)n; xp[j] = (int)(um - n * (unsigned)nv);
     }
     __syncthreads();
   }
@@ -93,7 +168,7 @@ __global__ void __launch_bounds__(512, 2) conv_wgrad256_p8_kernel(Wgrad256Args p
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       xn[j] += adv_q; xp[j] += adv_r;
-      if (xp[j] >= p.OHW) { xp[j] -= p.OHW; xn[j] += 1; }
+      if (xp[j] >= nv) { xp[j] -= nv; xn[j] += 1; }
     }
   };
   auto stage_x = [&](int q, int d, int mstep) {
@@ -136,10 +211,19 @@ __global__ void __launch_bounds__(512, 2) conv_wgrad256_p8_kernel(Wgrad256Args p
   };
   auto stage_d = [&](int q, int d, int mstep) {
     char* base = smem + d * BUF + (q ? SD1 : SD0);
+    int tv[2] = {0, 0};
+    if (vo) {                                     // the dy row of (image xn, valid position xp): table lookup, as stage_x
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        unsigned a = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const char*)(tabd + xp[j]);
+        asm volatile("ds_read_b32 %0, %1" : "=v"(tv[j]) : "v"(a) : "memory");
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(tv[0]), "+v"(tv[1]) :: "memory");
+    }
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       int m = mstep + s_row[j];
-      unsigned doff = ((unsigned)m * (unsigned)p.ldy + dcol[q]) * 2u;
+      unsigned doff = ((unsigned)(vo ? xn[j] * p.OHW + tv[j] : m) * (unsigned)p.ldy + dcol[q]) * 2u;
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsD, (lds_void_w*)(base + (j * 8 + wid) * 1024), 16, m < m_end ? doff : OOB, 0, 0, 0);
     }
   };
