@@ -49,7 +49,7 @@ def main():
         if mode == "eager":
             tr.optimizer.use_device_lr(model.device)
             batch = model.pack_batch(engine.shard_batch(sup, rank, world), engine.shard_batch(weak, rank, world),
-                                     gt_capacity=engine.GraphedStep.GT_CAPACITY)
+                                     gt_buckets=engine.GraphedStep.GT_BUCKETS)
             step = model.forward_train(batch, early_backward=True)
             model.backward_train(step)
             tr.buckets.finish()

@@ -33,7 +33,7 @@ def test_graphed_step_equals_eager_step(dev):
     o1 = FlatSGD(m1, cfg)
     ref_losses = []
     for i in order:
-        b = m1.pack_batch(*data[i], gt_capacity=engine.GraphedStep.GT_CAPACITY)
+        b = m1.pack_batch(*data[i], gt_buckets=engine.GraphedStep.GT_BUCKETS)
         o1._bind()
         o1.use_device_lr(m1.device)
         step = m1.forward_train(b, early_backward=True)
@@ -63,3 +63,44 @@ def test_graphed_step_equals_eager_step(dev):
     torch.cuda.synchronize()
     assert tr.graphed is not None and len(tr.graphed.graphs) == 1
     assert torch.allclose(m3.store.params, m1.store.params, rtol=1e-5, atol=1e-7)
+
+
+def test_graphed_step_new_keys_after_warmup(dev):
+    """image sizes and ground-truth counts change from batch to batch in real training: a key first seen AFTER the warm-up steps (other
+    image size; an image with more boxes than the 32-slot bucket) runs its first step eagerly -- its host-built constants are uploaded
+    and its workspaces sized outside any capture -- is captured at its second occurrence, and the graphs of the earlier keys keep
+    replaying correctly afterwards (workspaces that grew meanwhile are never freed). Losses and parameters equal the eager run."""
+    small = [synthetic_batch(2, 2, hw=(96, 128), seed=70 + i, max_gt=3) for i in range(2)]
+    big = [synthetic_batch(2, 2, hw=(160, 224), seed=80 + i, max_gt=4) for i in range(2)]
+    crowded = [synthetic_batch(2, 2, hw=(96, 128), seed=sd, max_gt=40) for sd in (91, 102)]
+    assert all(max(len(x["instances"].gt_classes) for x in c[0]) > 32 for c in crowded)
+    seq = [small[0], small[1], small[0], big[0], small[1], big[1], crowded[0], big[0], crowded[1], small[0], crowded[0], big[1]]
+    cfg, m1 = _setup()
+    o1 = FlatSGD(m1, cfg)
+    ref = []
+    for d in seq:
+        b = m1.pack_batch(*d, gt_buckets=engine.GraphedStep.GT_BUCKETS)
+        o1._bind()
+        o1.use_device_lr(m1.device)
+        step = m1.forward_train(b, early_backward=True)
+        m1.backward_train(step)
+        o1.step()
+        ref.append(step.losses.clone())
+    torch.cuda.synchronize()
+    cfg, m2 = _setup()
+    o2 = FlatSGD(m2, cfg)
+    gs = engine.GraphedStep(m2, o2, warmup_steps=2)
+    got = [gs.run(*d).clone() for d in seq]
+    torch.cuda.synchronize()
+    assert len(gs.graphs) == 3 and len(gs.seen) == 3          # small, big, crowded (64-slot bucket)
+    for k, (a, b) in enumerate(zip(got, ref)):
+        assert torch.isfinite(a).all()
+        assert torch.allclose(a, b, rtol=1e-5, atol=1e-6), (k, a.tolist(), b.tolist())
+    assert torch.allclose(m2.store.params, m1.store.params, rtol=1e-5, atol=1e-7)
+
+
+def test_pack_batch_rejects_a_capacity_that_does_not_hold_the_batch(dev):
+    cfg, m = _setup()
+    sup, weak = synthetic_batch(1, 1, hw=(96, 128), seed=5, max_gt=40)
+    with pytest.raises(ValueError, match="gt_capacity"):
+        m.pack_batch(sup, weak, gt_capacity=8)

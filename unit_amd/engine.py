@@ -55,20 +55,25 @@ class GraphedStep:
     arrays), the sampling permutations come from a device-resident counter (`unit_perm_keys`), the learning rate is read from
     device memory (`FlatSGD.use_device_lr`), the side streams fork from and rejoin the capturing stream, and the per-stream
     workspaces / weight-gradient slabs are cached objects. Shapes are static per graph: one graph per (image sizes, GT capacity,
-    weak-label presence) key, all sharing one memory pool (only one runs at a time).
+    weak-label presence) key, all sharing one memory pool (only one runs at a time). A key is captured the SECOND time it is seen:
+    its first step runs eagerly, which uploads the key's host-built constants (image sizes, slot tables) and sizes the per-stream
+    workspaces outside any capture (a pageable host-to-device copy cannot be captured, and a workspace that grew during a capture
+    would free scratch whose address an earlier graph replays into -- ops.workspace is grow-only for the same reason). Images with
+    more ground-truth boxes than a capacity bucket move to the next bucket (GT_BUCKETS), which is part of the key.
     Data parallel (`buckets` with world > 1): collectives are kept OUT of the captures -- RCCL inside a hipGraph could not be rehearsed
     on the 1-GPU boxes this was built on. The step becomes graph A (forward + backward, no per-bucket hook), ONE eager all-reduce
     of the whole flat gradient buffer, graph B (optimizer + weight re-preparation): the host cost of a graphed step, but the
     all-reduce no longer hides behind the backward (268 MB over xGMI, ~1-2 ms exposed). Which side of that trade wins on an 8-GPU
     host depends on how many cores each rank gets; the eager overlapped path stays the default (TrainerNoMeta(use_graph=False))."""
 
-    GT_CAPACITY = 32
+    GT_BUCKETS = (32, 64, 128, 256)
 
     def __init__(self, model, optimizer, warmup_steps=2, buckets=None):
         import torch
         self.model, self.optimizer, self.warmup_steps = model, optimizer, warmup_steps
         self.buckets = buckets if (buckets is not None and buckets.world > 1) else None
         self.graphs = {}          # key -> (graph | (graph A, graph B), static PackedBatch, losses tensor)
+        self.seen = set()         # keys that have run one eager step (constants uploaded, workspaces sized)
         self.pool = None
         self.eager_left = max(1, warmup_steps)          # the very first step initialises the momentum buffers (another SGD launch flag)
         self._torch = torch
@@ -119,13 +124,14 @@ class GraphedStep:
         vector (a static tensor of the graph: read it before the next run)"""
         torch = self._torch
         model, opt = self.model, self.optimizer
-        fresh = packed if packed is not None else model.pack_batch(base_data, classifier_data, gt_capacity=self.GT_CAPACITY)
+        fresh = packed if packed is not None else model.pack_batch(base_data, classifier_data, gt_buckets=self.GT_BUCKETS)
         opt._bind()
         opt.use_device_lr(model.device)          # (re)writes the scheduled learning rate of this iteration into device memory
-        if self.eager_left > 0:            # the first steps run eagerly: they allocate the cached workspaces / slabs / streams
-            self.eager_left -= 1
-            return self._body(fresh)
         key = fresh.key()
+        if self.eager_left > 0 or key not in self.seen:   # the first steps, and the first step of every new key, run eagerly
+            self.eager_left = max(0, self.eager_left - 1)
+            self.seen.add(key)
+            return self._body(fresh)
         ent = self.graphs.get(key)
         if ent is None:
             static = fresh.clone()

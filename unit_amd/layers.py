@@ -200,21 +200,25 @@ class BottleneckBlock(nn.Module):
 
     def _cat_weights(self, which):
         """[W3 | Wsc] (forward) / [W1^T ; Wsc^T] in dgrad layout (backward) from the prepared per-conv weights: a 6 MB device copy per
-        use, the prepared copies are refreshed by the optimizer's multi-tensor prep"""
+        use, the prepared copies are refreshed by the optimizer's multi-tensor prep. One buffer (and one summed bias) PER HIP STREAM:
+        the Res5 forward runs the same head on two streams at once (rcnn.py forward plan) -- a shared buffer would be rewritten by one
+        stream while the other stream's GEMM reads it, and a bias filled on one stream could be read on the other before it is there."""
         a, b = (self.conv3, self.shortcut) if which == "fwd" else (self.conv1, self.shortcut)
         wa, wb = (a.wf, b.wf) if which == "fwd" else (a.wd, b.wd)
         k = wa.shape[0]
-        buf = getattr(self, "_wcat_" + which, None)
+        sid = ops.raw_stream(wa.device.index) if wa.device.type == "cuda" else 0
+        bufs = self.__dict__.setdefault("_wcat_" + which, {})
+        buf = bufs.get(sid)
         if buf is None or buf.dtype != wa.dtype or buf.device != wa.device:
-            buf = torch.empty((k, 1, 1, wa.shape[-1] + wb.shape[-1]), dtype=wa.dtype, device=wa.device)
-            setattr(self, "_wcat_" + which, buf)
+            buf = bufs[sid] = torch.empty((k, 1, 1, wa.shape[-1] + wb.shape[-1]), dtype=wa.dtype, device=wa.device)
         torch.cat([wa.reshape(k, -1), wb.reshape(k, -1)], dim=1, out=buf.view(k, -1))
         bias = None
         if which == "fwd":
-            src = getattr(self, "_bcat_src", (None, None))
-            if src[0] is not a.shift or src[1] is not b.shift:
-                self._bcat, self._bcat_src = a.shift + b.shift, (a.shift, b.shift)
-            bias = self._bcat
+            cache = self.__dict__.setdefault("_bcat", {})
+            ent = cache.get(sid)
+            if ent is None or ent[1] is not a.shift or ent[2] is not b.shift:
+                ent = cache[sid] = (a.shift + b.shift, a.shift, b.shift)
+            bias = ent[0]
         return buf, bias
 
     def bwd(self, ctx, g, need_dx=True, mask_input=True):

@@ -208,9 +208,10 @@ class WeaklySupervisedRCNNNoMeta(nn.Module):
         self.roi_heads.prepare(dt, v)
 
     # ------------------------------------------------------------------ inputs
-    def pack_batch(self, batched_inputs, weak_batched_inputs=None, gt_capacity=None):
+    def pack_batch(self, batched_inputs, weak_batched_inputs=None, gt_capacity=None, gt_buckets=None):
         """gt_capacity: fixed number of GT slots per image (a multiple of 8, >= the largest image's count) -- static shapes for a
-        captured step; default: the batch's own maximum rounded up to 8"""
+        captured step; gt_buckets: ascending capacities, the smallest one that holds the batch is taken (beyond the last: the next
+        multiple of it); default: the batch's own maximum rounded up to 8"""
         dev = self.device
         sup = batched_inputs or []
         weak = weak_batched_inputs or []
@@ -224,8 +225,12 @@ class WeaklySupervisedRCNNNoMeta(nn.Module):
             gtc.append(inst.gt_classes)
         mcap = max([len(b) for b in gtb] + [1])
         mcap = (mcap + 7) // 8 * 8
+        if gt_buckets:
+            fit = [b for b in gt_buckets if b >= mcap]
+            gt_capacity = fit[0] if fit else (mcap + gt_buckets[-1] - 1) // gt_buckets[-1] * gt_buckets[-1]
         if gt_capacity is not None:
-            assert gt_capacity % 8 == 0 and gt_capacity >= mcap, (gt_capacity, mcap)
+            if gt_capacity % 8 != 0 or gt_capacity < mcap:
+                raise ValueError(f"pack_batch: gt_capacity {gt_capacity} must be a multiple of 8 and hold the {mcap} ground-truth slots of this batch")
             mcap = gt_capacity
         gt_boxes = torch.zeros((max(n, 1), mcap, 4), dtype=torch.float32)
         gt_classes = torch.zeros((max(n, 1), mcap), dtype=torch.int64)

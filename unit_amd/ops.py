@@ -124,6 +124,9 @@ class _timed:
         return False
 
 
+_WS_RETIRED = []
+
+
 def workspace(nbytes, device, slot=0):
     """scratch buffer for the kernels that need one; one buffer per (slot, HIP stream): the step runs the RPN-loss branch,
     the proposal chain and the weight gradients on different streams at the same time, and scratch must never be shared
@@ -131,6 +134,8 @@ def workspace(nbytes, device, slot=0):
     key = (device, slot, raw_stream(device.index) if device.type == "cuda" else 0)
     w = _WS.get(key)
     if w is None or w.numel() < nbytes:
+        if w is not None:
+            _WS_RETIRED.append(w)      # grow-only: a captured hipGraph (engine.GraphedStep) may have this address baked into its launches
         w = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
         _WS[key] = w
     return w
@@ -373,6 +378,8 @@ def conv2d_wgrad_partial(x, dy, k, r, s, stride, pad, slab=None):
     oh, ow = conv_out_size(h, wd, r, s, stride, pad)
     nbytes = lib().unit_conv2d_wgrad_workspace_bytes(dt(x.dtype), n, oh, ow, k, r, s, c)
     if slab is None or slab.numel() < nbytes:
+        if slab is not None:
+            _WS_RETIRED.append(slab)       # grow-only, as workspace(): a captured step may replay into the old slab
         slab = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
     splits = lib().unit_conv2d_wgrad_splits(dt(x.dtype), n, oh, ow, k, r, s, c)
     ldy = dy.shape[-1]
