@@ -70,14 +70,16 @@ def pack_proposals(plist, cap, dev):
     return props.to(dev), sc.to(dev), cnt.to(dev)
 
 
-def proposal_agreement(hip_props, hip_cnt, ora, tol=1e-2):
-    """fraction of the HIP proposals of each image that are (within `tol` px in every coordinate) proposals of the oracle, and vice
-    versa"""
+def proposal_agreement(hip_props, hip_cnt, ora, tol=1e-2, rel=0.0):
+    """fraction of the HIP proposals of each image that are (within `tol` px -- or `rel` times the box's longer side, whichever is
+    larger -- in every coordinate) proposals of the oracle, and vice versa"""
     out = []
     for i, (ob, _) in enumerate(ora):
         hb = hip_props[i, : int(hip_cnt[i])].cpu()
         d = torch.cdist(hb.double(), ob.double(), p=float("inf"))
-        out.append((float((d.min(1).values < tol).float().mean()), float((d.min(0).values < tol).float().mean()), len(hb), len(ob)))
+        th = torch.clamp((hb[:, 2:] - hb[:, :2]).max(1).values.double() * rel, min=tol)
+        to = torch.clamp((ob[:, 2:] - ob[:, :2]).max(1).values.double() * rel, min=tol)
+        out.append((float((d.min(1).values < th).float().mean()), float((d.min(0).values < to).float().mean()), len(hb), len(ob)))
     return out
 
 
@@ -246,12 +248,13 @@ def test_r101_s1_fullsize_bf16_production_schedule(dev, s1_r101):
     Teacher-forced: integer stages (anchor labels, sampled RoI indices / classes) EXACT -- their inputs are fp32 and identical.
     Losses: bf16 carries 8 significant bits (relative rounding 2^-9 = 2e-3 per stored tensor) through ~105 convolutions with
     fp32 accumulation; the losses are means over >= 512 RoIs / anchors of such features: measured 5e-4 ... 3e-3 relative
-    (gpurun_out/fullsize_metrics.json), asserted at rtol 1e-2 + atol 1e-4. Gradients: cosine similarity with the fp32 oracle's
-    >= 0.995 on tensors from every stage (measured >= 0.9988).
-    Free-running (its own bf16 proposals): finite losses only. With RANDOM-INIT weights the 35 910 objectness logits of an image are
-    nearly tied, so bf16 rounding re-draws which 12 000 survive the top-k and who wins each NMS cluster: only about a third of the
-    2000 proposals have a partner within 2 px in the fp32 oracle's set (logged, not asserted -- it says nothing about a trained
-    detector, whose logits are spread out); the RoI-independent losses of that run still equal the teacher-forced ones."""
+    (gpurun_out/fullsize_metrics.json), asserted at rtol 6e-3 + atol 1e-4. Gradients: cosine similarity with the fp32 oracle's
+    >= 0.9975 on tensors from every stage (measured >= 0.9988).
+    Free-running (its own bf16 proposals): finite losses only. With RANDOM-INIT weights the anchor deltas have a standard deviation of
+    5.8 (boxes blown up by e^4, clipped to slivers), so a bf16 error of 0.04 in a delta moves a box edge by tens of pixels: only about a
+    third of the 2000 proposals have a partner within 2 px in the fp32 oracle's set although 99 % of them are the same anchors (logged,
+    not asserted -- it says nothing about a trained detector, whose deltas are a few tenths: test_r101_s1_bf16_keeps_the_proposals_of_a_trained_like_rpn asserts that case); the
+    RoI-independent losses of that run still equal the teacher-forced ones."""
     st = s1_r101
     model, cfg, aux = st["model"], st["cfg"], st["aux"]
     model.compute_dtype = torch.bfloat16
@@ -277,11 +280,79 @@ def test_r101_s1_fullsize_bf16_production_schedule(dev, s1_r101):
                                      free_running_proposal_agreement=agree))
     model.compute_dtype = torch.float32
     for k, (g, v) in dev_l.items():
-        assert abs(g - v) <= 1e-2 * abs(v) + 1e-4, (k, g, v)
+        assert abs(g - v) <= 6e-3 * abs(v) + 1e-4, (k, g, v)          # measured 5e-4 ... 3e-3 relative
     for n, c in cos.items():
-        assert c >= 0.995, (n, c)
+        assert c >= 0.9975, (n, c)                                    # measured >= 0.9988 (1 - c: twice the measured deviation)
     assert torch.isfinite(l2[:8]).all()
     assert abs(float(l2[6]) - got["loss_rpn_cls"]) <= 1e-6 and abs(float(l2[7]) - got["loss_rpn_loc"]) <= 1e-6
+
+
+def test_r101_s1_bf16_keeps_the_proposals_of_a_trained_like_rpn(dev, s1_r101):
+    """bf16 keeps the INTEGER decisions of the free-running path once the RPN outputs look like a trained detector's. What makes the
+    random-init fixture re-draw two thirds of its proposals in bf16 is not the selection but the geometry (tools/bf16_proposal_probe.py,
+    profiles/r03_bf16_proposal_probe.txt): its objectness logits are well spread (std 4.5; bf16 keeps 99.3 % of the top-12000 and, fed the
+    oracle's deltas, 99 % of the 2000 proposals), but its anchor deltas have a standard deviation of 5.8 -- boxes blown up by up to
+    e^4.1, clipped to slivers -- so that a bf16 error of 0.04 in dw moves a box edge by tens of pixels. A trained RPN regresses deltas of
+    a few tenths. Here the two predictor layers (weights and biases) are scaled so that the per-image logit standard deviation is 2.5 and
+    the delta standard deviation 0.3 -- the fp32 oracle's outputs scale by exactly those factors -- and the benchmarked bf16 4-stream
+    step runs on its OWN proposals: per supervised image >= 92 % of the 2000 proposals have a partner within 2 px in the fp32 oracle's
+    set and vice versa (measured 94.0 %; the same 94.0 % with the tolerance widened to 1 % of the box's longer side, so the remaining
+    6 % are not box precision but other NMS survivors -- a pair whose IoU sits next to 0.7, or two neighbours whose scores swap, flips a
+    keep decision and its cluster with it), and >= 92 % of the sampled RoIs are proposals or ground-truth boxes of the oracle's list
+    (measured 94.2 %). WHICH 512 of them are sampled is not comparable: the sampler draws list INDICES from a permutation
+    (subsample_labels), so one proposal that differs early in the score-sorted list shifts every later index (25 % identical picks)."""
+    st = s1_r101
+    model, cfg, aux = st["model"], st["cfg"], st["aux"]
+    rpn = model.proposal_generator
+    n = aux["logits"].shape[0]
+    f = float(2.5 / aux["logits"].std(dim=1).min())
+    g = float(0.3 / aux["deltas"].std())
+    obj, dlt = rpn.rpn_head.objectness_logits, rpn.rpn_head.anchor_deltas
+    saved = [t.detach().clone() for t in (obj.weight, obj.bias, dlt.weight, dlt.bias)]
+    try:
+        with torch.no_grad():
+            obj.weight.mul_(f); obj.bias.mul_(f); dlt.weight.mul_(g); dlt.bias.mul_(g)
+        model.version += 1                       # prepared bf16 copies are re-made from the changed parameters
+        model.compute_dtype = torch.bfloat16
+        step = model.forward_train(st["batch"], st["perms"], early_backward=True)
+        model.backward_train(step)
+        losses = step.losses.cpu()
+        props, cnt = step.proposals[0][:n].cpu(), step.proposals[2][:n].cpu()
+        rois, roi_cls = step.rois.cpu(), step.roi_cls.cpu()
+    finally:
+        with torch.no_grad():
+            for t, v in zip((obj.weight, obj.bias, dlt.weight, dlt.bias), saved):
+                t.copy_(v)
+        model.version += 1
+        model.compute_dtype = torch.float32
+    assert torch.isfinite(losses[:8]).all()
+    anchors = rpn.anchor_generator.grid(38, 63).cpu()
+    logits, deltas = aux["logits"] * f, aux["deltas"] * g
+    assert float(logits.std(dim=1).min()) >= 2.0
+    ora = orc.find_top_rpn_proposals(anchors, logits, deltas, [HW] * n, 0.7, cfg.MODEL.RPN.PRE_NMS_TOPK_TRAIN, cfg.MODEL.RPN.POST_NMS_TOPK_TRAIN)
+    agree = proposal_agreement(props, cnt, ora, tol=2.0)
+    agree_rel = proposal_agreement(props, cnt, ora, tol=2.0, rel=0.01)
+    s = cfg.MODEL.ROI_HEADS.BATCH_SIZE_PER_IMAGE
+    sup = st["sup"]
+    smp = orc.label_and_sample_proposals(ora, [x["instances"].gt_boxes.tensor for x in sup], [x["instances"].gt_classes for x in sup],
+                                         [x.long().cpu() for x in st["perms"]["roi"]], cfg.MODEL.ROI_HEADS.NUM_CLASSES, s)
+    same, member = [], []
+    for i, sm in enumerate(smp):
+        mine = rois[i * s:(i + 1) * s, 1:][roi_cls[i * s:(i + 1) * s] >= 0]
+        d = torch.cdist(mine.double(), sm["boxes"].double(), p=float("inf"))
+        same.append((float((d.min(1).values < 2.0).float().mean()), float((d.min(0).values < 2.0).float().mean()), len(mine), len(sm["boxes"])))
+        pool = torch.cat([ora[i][0], sup[i]["instances"].gt_boxes.tensor], 0)
+        dm = torch.cdist(mine.double(), pool.double(), p=float("inf")).min(1).values
+        member.append(float((dm < torch.clamp((mine[:, 2:] - mine[:, :2]).max(1).values.double() * 0.01, min=2.0)).float().mean()))
+    log_metrics("r101_s1_bf16_trained_like_rpn", dict(logit_scale=f, delta_scale=g, logit_std=logits.std(dim=1).tolist(), delta_std=float(deltas.std()),
+                                                      free_running_proposal_agreement_2px=agree, free_running_proposal_agreement_2px_or_1pct=agree_rel,
+                                                      identical_sampled_roi_fraction=same, sampled_rois_that_are_oracle_proposals=member))
+    for a in agree:
+        assert a[0] >= 0.92 and a[1] >= 0.92, agree
+    for a in agree_rel:
+        assert a[0] >= 0.92 and a[1] >= 0.92, agree_rel
+    for m in member:
+        assert m >= 0.92, member
 
 
 # =================================================================================================== config 4: R101 S2
@@ -432,7 +503,7 @@ def test_coco_k80_eval_fullsize_80class_nms(dev):
     ncand = int((aux["probs"][:, :-1] > thr).sum())
     hb, hs, hc = out.pred_boxes.tensor.cpu(), out.scores.cpu(), out.pred_classes.cpu()
     d = torch.cdist(hb.double(), b.double(), p=float("inf"))
-    ok = (d < 0.05) & (hc[:, None] == c[None, :]) & ((hs[:, None] - s[None, :]).abs() < 1e-4)
+    ok = (d < 0.25e-4 * max(out_hw)) & (hc[:, None] == c[None, :]) & ((hs[:, None] - s[None, :]).abs() < 1e-4)    # boxes: 0.05 px = 2.5e-5 of the coordinate scale
     f_h, f_o = float(ok.any(1).float().mean()), float(ok.any(0).float().mean())
     log_metrics("coco_k80_eval", dict(candidates=ncand, hip=len(hb), oracle=len(b), matched_hip=f_h, matched_oracle=f_o,
                                       classes=len(set(c.tolist()))))

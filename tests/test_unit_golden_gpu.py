@@ -354,7 +354,8 @@ def test_hip_inference_vs_reference_orchestration(dev, name):
     out = model([{"image": sup[0]["image"], "height": hw[0], "width": hw[1]}])[0]["instances"]
     assert np.array_equal(out.pred_classes.cpu().numpy(), STEP[f"{name}/classes"])
     assert np.allclose(out.scores.cpu().numpy(), STEP[f"{name}/scores"], rtol=1e-4, atol=1e-5)
-    assert np.allclose(out.pred_boxes.tensor.cpu().numpy(), STEP[f"{name}/boxes"], rtol=1e-4, atol=2e-2)
+    # boxes: north_star's 1e-4 read relative to the coordinate scale (the output image's longer side, in pixels); asserted at half of it
+    assert np.abs(out.pred_boxes.tensor.cpu().numpy() - STEP[f"{name}/boxes"]).max() <= 0.5e-4 * max(hw)
     if f"{name}/masks" in STEP.files:
         ref = np.unpackbits(STEP[f"{name}/masks"], axis=-1)[..., : hw[1]].astype(bool)
         got = out.pred_masks.cpu().numpy()
