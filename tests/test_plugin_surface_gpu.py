@@ -83,7 +83,11 @@ def test_predictor_forward_losses_inference(dev, ft):
     assert torch.equal(torch.isinf(scores.cpu()), torch.isinf(rs))
     fin = torch.isfinite(rs)
     assert torch.allclose(scores.cpu()[fin], rs[fin], rtol=1e-4, atol=1e-4) and torch.allclose(bbox.cpu(), rb, rtol=1e-4, atol=1e-4)
-    losses = bp.losses([scores, bbox], props, weak_predictions=weak_ret, weak_proposals=wprops, weak_targets=wtargets)
+    from unit_amd.modeling import fast_rcnn as _fr
+    _fr._WARNED_VALUES_ONLY[0] = False
+    with pytest.warns(RuntimeWarning, match="without an autograd graph"):       # values only: training runs through the fused step
+        losses = bp.losses([scores, bbox], props, weak_predictions=weak_ret, weak_proposals=wprops, weak_targets=wtargets)
+    assert all(not v.requires_grad for v in losses.values())
     ref = orc.fast_rcnn_losses(rs, rb, torch.cat(flat["b"]), torch.cat(flat["gb"]), torch.cat(flat["gc"]))
     cs, ds, oicr = orc.weak_head_forward_train(xweak, p, "roi_heads.box_predictor.weak_detector_head")
     assert torch.allclose(weak_ret[0].cpu(), cs, rtol=1e-4, atol=1e-4) and torch.allclose(weak_ret[1].cpu(), ds, rtol=1e-4, atol=1e-4)
@@ -133,9 +137,32 @@ def test_roi_heads_forward_eval_equals_meta_arch_inference(dev, mask):
         assert torch.allclose(a.scores, b.scores, rtol=1e-5, atol=1e-6) and torch.allclose(a.pred_boxes.tensor, b.pred_boxes.tensor, rtol=1e-5, atol=1e-3)
         if mask:
             assert torch.allclose(a.pred_masks, b.pred_masks, rtol=1e-4, atol=1e-5)
+    if mask:
+        # the two halves of the reference's eval forward, called by hand (roi_heads.py:817-821): _forward_box -> (detections without
+        # masks, the 'seg' similarity rows of those detections), forward_with_given_boxes -> the same masks as the fused pass
+        rh = model.roi_heads
+        det, sim = rh._forward_box(features, proposals)
+        assert all(not d.has("pred_masks") for d in det) and sim["seg"].shape[0] == sum(len(d) for d in det)
+        again = rh.forward_with_given_boxes(features, det, similarity=sim)
+        for a, b in zip(whole, again):
+            assert torch.allclose(a.pred_masks, b.pred_masks, rtol=1e-4, atol=1e-5)
+        # other boxes than the detector's own: masks of jittered boxes differ, shapes hold; the similarity rows are mandatory here
+        g = torch.Generator().manual_seed(2)
+        given = [Instances(d.image_size, pred_boxes=Boxes((d.pred_boxes.tensor.cpu() + torch.rand(len(d), 4, generator=g) * 6).to(dev)),
+                           pred_classes=d.pred_classes) for d in det]
+        out2 = rh.forward_with_given_boxes(features, given, similarity=sim)
+        assert all(o.pred_masks.shape == (len(o), 1, 14, 14) and torch.isfinite(o.pred_masks).all() for o in out2)
+        assert not torch.allclose(out2[0].pred_masks, whole[0].pred_masks, atol=1e-4)
+        with pytest.raises(ValueError, match="similarity"):
+            rh.forward_with_given_boxes(features, given)
+    else:
+        det = model.roi_heads._forward_box(features, proposals)
+        assert model.roi_heads.forward_with_given_boxes(features, det) is det          # no mask head: instances come back unchanged
     model.roi_heads.train()
     with pytest.raises(RuntimeError, match="fused step"):
         model.roi_heads(images, features, proposals, targets=[s["instances"] for s in sup])
+    with pytest.raises(RuntimeError, match="inference-only"):
+        model.roi_heads.forward_with_given_boxes(features, det)
 
 
 def test_mask_head_forward_eval(dev):

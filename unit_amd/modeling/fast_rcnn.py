@@ -7,6 +7,8 @@ Parameter names equal the reference's (`cls_score_delta`, `bbox_pred_delta`, `cl
 All Linear layers that share an input run as one fused GEMM (LinearGroup); the loss kernels emit loss + gradient."""
 import os
 
+import warnings
+
 import torch
 from torch import nn
 
@@ -19,6 +21,19 @@ def _freeze_by_first_component(module, layers):
     for name, p in module.named_parameters():
         if any(layer == name.split(".")[0] for layer in layers):
             p.requires_grad = False
+
+
+_WARNED_VALUES_ONLY = [False]
+
+
+def _warn_values_only(who):
+    """the module-level `forward` / `losses` of the predictors run the HIP kernels under no_grad: in training mode they return VALUES
+    (for monitoring and the module-level parity tests) that carry no autograd graph -- a trainer that composes these modules itself and
+    calls `.backward()` on their losses would update nothing. Training runs through the fused step."""
+    if not _WARNED_VALUES_ONLY[0]:
+        _WARNED_VALUES_ONLY[0] = True
+        warnings.warn(f"{who}.losses in training mode returns loss VALUES without an autograd graph; gradients come from the fused step "
+                      "(WeaklySupervisedRCNNNoMeta.forward / TrainerNoMeta.run_step), see INTEGRATION.md", RuntimeWarning, stacklevel=3)
 
 
 @WEAK_DETECTOR_FAST_RCNN_REGISTRY.register()
@@ -112,6 +127,8 @@ class WeakDetectorOutputsBase(nn.Module):
     def losses(self, weak_predictions, weak_proposals, weak_targets):
         """:189-255 -> {'loss_im_cls', 'loss_oicr_1..n'} (values; HIP kernels unit_wsddn_mil / unit_oicr_targets / unit_softmax_ce).
         weak_predictions = forward()'s list, weak_proposals = list[Instances(proposal_boxes)], weak_targets = list[LongTensor]."""
+        if self.training:
+            _warn_values_only(type(self).__name__)
         cs, ds, oicr = weak_predictions[0], weak_predictions[1], weak_predictions[2]
         k, dev = self.num_classes, cs.device
         sizes = [len(p) for p in weak_proposals]
@@ -268,6 +285,8 @@ class SupervisedDetectorOutputsBase(nn.Module):
     def losses(self, predictions, proposals, weak_predictions=None, weak_proposals=None, weak_targets=None, train_only_weak=False):
         """fast_rcnn.py:435-453 -> {'loss_cls', 'loss_box_reg'} (+ the weak head's losses); proposals = list[Instances] with
         proposal_boxes, gt_boxes, gt_classes (label_and_sample_proposals' output). Values; HIP kernels unit_softmax_ce / unit_box_reg_loss."""
+        if self.training:
+            _warn_values_only(type(self).__name__)
         out = {}
         if not train_only_weak:
             scores, bbox = predictions

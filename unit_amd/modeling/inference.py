@@ -60,11 +60,13 @@ def similarity_matrices(model, lin_weak_on_box):
     return d["cls"], d["bbox"]
 
 
-def roi_heads_inference(rh, feat, props, pcount, hw, dt):
+def roi_heads_inference(rh, feat, props, pcount, hw, dt, with_mask=True, want_similarity=False):
     """eval branch of WSROIHead*.forward (roi_heads.py:585-591 / :796-801): _forward_box (:519-551) -> predictor eval transfer
     (fast_rcnn.py:401-423) -> `inference` (:455-468, fast_rcnn_inference) -> forward_with_given_boxes (mask, :776-781).
     feat NHWC [N,H,W,C] (compute dtype), props [N,P,4], pcount int32 [N], hw fp32 [N,2] (device)
-    -> boxes [N,topk,4], scores, classes, roi index, count [N], mask probabilities [N,topk,14,14] or None"""
+    -> boxes [N,topk,4], scores, classes, roi index, count [N], mask probabilities [N,topk,14,14] or None
+    with_mask=False: the box half only (the reference's `_forward_box`); want_similarity: additionally the rows of the 'seg' similarity
+    matrix of the detections, [N*topk, ...] (similarity['seg'][filter_inds], roi_heads.py:768-771), or None without a 'seg' term"""
     bp = rh.box_predictor
     wh = bp.weak_detector_head
     n = feat.shape[0]
@@ -89,16 +91,24 @@ def roi_heads_inference(rh, feat, props, pcount, hw, dt):
     # a16 eval: forward_with_given_boxes (roi_heads.py:776-781) -> mask head on the detected boxes (before postprocess)
     mask_probs = None
     mh = getattr(rh, "mask_head", None)
-    if mh is not None:
+    sim_seg = None
+    if mh is not None and "seg" in rh.terms and (with_mask or want_similarity):
+        flat_idx = (torch.arange(n, device=dev)[:, None] * rcap + roi.clamp(min=0).long()).view(-1)
+        sim_seg = sims["seg"][flat_idx].contiguous()          # similarity['seg'][filter_inds] (roi_heads.py:768-771)
+    if mh is not None and with_mask:
         topk = boxes.shape[1]
         det_rois = torch.cat([torch.arange(n, device=dev, dtype=torch.float32).repeat_interleave(topk)[:, None], boxes.view(-1, 4)], 1)
-        _, dctx = rh.box_head.fwd(rh.pool(feat, det_rois), keep_map=True)
-        sim_seg = None
-        if "seg" in rh.terms:
-            flat_idx = (torch.arange(n, device=dev)[:, None] * rcap + roi.clamp(min=0).long()).view(-1)
-            sim_seg = sims["seg"][flat_idx].contiguous()          # similarity['seg'][filter_inds] (roi_heads.py:768-771)
-        mask_probs = mh.probs(dctx[1], cls.view(-1).contiguous(), sim_seg, t).view(n, topk, mh.mask_size, mh.mask_size)
+        mask_probs = mask_probs_on_boxes(rh, feat, det_rois, cls.view(-1).contiguous(), sim_seg).view(n, topk, mh.mask_size, mh.mask_size)
+    if want_similarity:
+        return boxes, sc, cls, roi, cnt, mask_probs, sim_seg
     return boxes, sc, cls, roi, cnt, mask_probs
+
+
+def mask_probs_on_boxes(rh, feat, rois5, classes, sim_seg):
+    """forward_with_given_boxes / _forward_mask eval (roi_heads.py:691-710, :776-781): box pooler + box head on the GIVEN boxes, mask
+    head on the res5 maps, probability of each box's class (base->novel transfer through sim_seg rows). -> [R, 14, 14]"""
+    _, dctx = rh.box_head.fwd(rh.pool(feat, rois5), keep_map=True)
+    return rh.mask_head.probs(dctx[1], classes, sim_seg, class_roles(rh))
 
 
 @torch.no_grad()

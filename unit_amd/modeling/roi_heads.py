@@ -144,8 +144,46 @@ class WSROIHeadNoMeta(nn.Module):
         out = roi_heads_inference(self, feat, props, pcount, hw, dtype)
         return build_instances(*out, sizes, None)
 
+    @torch.no_grad()
     def forward_with_given_boxes(self, features, instances, similarity=None):
-        raise NotImplementedError("the mask head runs on the detections inside _forward_box (one device pass, no host round trip)")
+        """roi_heads.py:776-781: `_forward_mask` on given detections. instances: list[Instances] with `pred_boxes` and `pred_classes`
+        (network-input coordinates); similarity: {"seg": tensor [sum of len(instances), novel, base]} -- the rows `_forward_box` returned
+        for these detections -- required when the head has a 'seg' similarity term. Sets `pred_masks` [R, 1, 14, 14] (probabilities of
+        each box's class, what mask_rcnn_inference leaves) and returns the instances. Without a mask head: returns them unchanged."""
+        if self.training:
+            raise RuntimeError("forward_with_given_boxes is inference-only (roi_heads.py:777 asserts not self.training)")
+        if not (instances and instances[0].has("pred_boxes") and instances[0].has("pred_classes")):
+            raise ValueError("forward_with_given_boxes: instances need pred_boxes and pred_classes (roi_heads.py:778)")
+        mh = getattr(self, "mask_head", None)
+        if mh is None:
+            return instances
+        from .inference import mask_probs_on_boxes
+        dtype = getattr(self, "compute_dtype", torch.bfloat16)
+        self.prepare(dtype, getattr(self, "_version", 0))
+        feat = self._feat_nhwc(features, dtype)
+        boxes = [(i.pred_boxes.tensor if hasattr(i.pred_boxes, "tensor") else i.pred_boxes).float().to(feat.device) for i in instances]
+        counts = [len(b) for b in boxes]
+        if sum(counts) == 0:
+            for i in instances:
+                i.pred_masks = torch.zeros((0, 1, mh.mask_size, mh.mask_size), dtype=torch.float32, device=feat.device)
+            return instances
+        idx = torch.cat([torch.full((c, 1), float(k), device=feat.device) for k, c in enumerate(counts)])
+        rois5 = torch.cat([idx, torch.cat(boxes)], 1).contiguous()
+        cls = torch.cat([i.pred_classes.to(feat.device) for i in instances]).to(torch.int32).contiguous()
+        sim_seg = None
+        if "seg" in self.terms:
+            if similarity is None or similarity.get("seg") is None:
+                raise ValueError("forward_with_given_boxes: this mask head transfers base -> novel masks through similarity['seg'] "
+                                 "(one row per given detection, as _forward_box returns them)")
+            sim_seg = similarity["seg"].to(feat.device).float().contiguous()
+            if sim_seg.shape[0] != sum(counts):
+                raise ValueError(f"similarity['seg'] has {sim_seg.shape[0]} rows for {sum(counts)} detections")
+        probs = mask_probs_on_boxes(self, feat, rois5, cls, sim_seg)
+        o = 0
+        for i, c in zip(instances, counts):
+            i.pred_masks = probs[o:o + c][:, None]
+            o += c
+        return instances
 
     def pool_bwd_gather(self, dpooled, n_images, h, w, rois5, out, image_offset=0, addend=None, mask_ref=None):
         """deterministic gather-form RoIAlign backward fused with '+ RPN-branch gradient, * ReLU mask' (fixed RoI slots)."""
@@ -186,14 +224,39 @@ class WSROIHeadNoMetaWithMask(WSROIHeadNoMeta):
 
     def forward(self, images, features, proposals, targets=None, weak_images=None, weak_features=None, weak_proposals=None,
                 weak_targets=None, tta=False, return_similarity=False, train_only_weak=False):
-        """roi_heads.py:783-822 (WSROIHeadNoMetaWithMask) / :909-952 (WSROIHeadWithMaskFineTune): eval -> (instances, {})"""
-        return super().forward(images, features, proposals, targets, weak_images, weak_features, weak_proposals, weak_targets, tta,
-                               return_similarity, train_only_weak)
+        """roi_heads.py:783-822 (WSROIHeadNoMetaWithMask) / :909-952 (WSROIHeadWithMaskFineTune): eval -> (instances, {}), as the
+        reference does it: `_forward_box`, then `forward_with_given_boxes` on its detections with its similarity rows (the fused
+        `model.inference` makes the same two passes without the host round trip in between)"""
+        del images, weak_images
+        if self.training:
+            raise RuntimeError("WSROIHead*.forward in training mode: " + _FUSED)
+        if tta or return_similarity:
+            raise NotImplementedError("tta / return_similarity belong to the TTA and visualisation tools, outside the hot path "
+                                      "(SURVEY.md section 2)")
+        pred, similarity = self._forward_box(features, proposals)
+        return self.forward_with_given_boxes(features, pred, similarity=similarity), {}
 
+    @torch.no_grad()
     def _forward_box(self, features, proposals, weak_features=None, weak_proposals=None, weak_targets=None, tta=False,
                      return_similarity=False, train_only_weak=False):
-        return super()._forward_box(features, proposals, weak_features, weak_proposals, weak_targets, tta, return_similarity,
-                                    train_only_weak)
+        """eval branch of roi_heads.py:712-773: -> (pred_instances without masks, {"seg": similarity rows of the detections})"""
+        if self.training:
+            raise RuntimeError("WSROIHead*._forward_box in training mode: " + _FUSED)
+        from .inference import build_instances, pack_proposal_instances, roi_heads_inference
+        dtype = getattr(self, "compute_dtype", torch.bfloat16)
+        self.prepare(dtype, getattr(self, "_version", 0))
+        feat = self._feat_nhwc(features, dtype)
+        props, pcount = pack_proposal_instances(proposals, feat.device)
+        sizes = [p.image_size for p in proposals]
+        hw = torch.tensor(sizes, dtype=torch.float32).to(feat.device)
+        boxes, sc, cls, roi, cnt, _, sim = roi_heads_inference(self, feat, props, pcount, hw, dtype, with_mask=False, want_similarity=True)
+        inst = build_instances(boxes, sc, cls, roi, cnt, None, sizes, None)
+        similarity = None
+        if sim is not None:
+            topk = boxes.shape[1]
+            rows = torch.cat([torch.arange(c, device=sim.device) + k * topk for k, c in enumerate(len(i) for i in inst)]) if inst else None
+            similarity = {"seg": sim[rows] if rows is not None and rows.numel() else sim[:0]}
+        return inst, similarity
 
     @property
     def max_fg_per_image(self):
