@@ -159,6 +159,7 @@ def main():
         timed_step = lambda: gs.run(packed=batch)
     for _ in range(max(args.warmup, 3 if args.graph else 0)):
         timed_step()
+    buckets.exposed_events = [] if world > 1 else None          # two event records per step around the bucket waits
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -170,6 +171,10 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    exposed_ms = 0.0
+    if buckets.exposed_events:
+        exposed_ms = sum(a.elapsed_time(b) for a, b in buckets.exposed_events) / args.steps
+    buckets.exposed_events = None
     # roofline passes (outside the `value` timing: ~650 extra HIP-event records per step perturb it by a few per cent):
     # the same K steps again with a HIP-event pair around every conv launch, recorded on the launch stream --
     #  (1) on ONE stream (overlap off): an event interval is then that kernel alone -> `achieved`
@@ -201,11 +206,29 @@ def main():
             ops.PROFILER = None
     if world > 1:
         dist.barrier()
+    host_ms = t_host / args.steps * 1e3
     if world > 1:
-        t = torch.tensor([dt], device=dev)
+        t = torch.tensor([dt, host_ms, exposed_ms], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        dt, host_ms, exposed_ms = (float(v) for v in t.tolist())
     assert torch.isfinite(losses).all(), f"non-finite losses {losses}"
+    # the same step in fp32 parity mode (the reference's arithmetic precision), a secondary figure: N = 1 only, after everything else
+    fp32_mode = None
+    if world == 1 and args.dtype == "bf16" and not args.no_roofline and not args.graph:
+        model.compute_dtype = torch.float32
+        one_step()
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        k32 = max(2, min(5, args.steps))
+        for _ in range(k32):
+            l32 = one_step()
+        torch.cuda.synchronize()
+        ms32 = (time.perf_counter() - t2) / k32 * 1e3
+        fp32_mode = {"ms_per_step": round(ms32, 2), "images_per_sec": round(2e3 / ms32, 2), "steps": k32,
+                     "note": "same workload with fp32 activations / weights / MFMA-free fp32 kernels (the parity mode the full-size tests "
+                             "run against the oracle); not the headline"}
+        assert torch.isfinite(l32).all()
+        model.compute_dtype = torch.bfloat16
 
     if rank == 0:
         ms = dt / args.steps * 1e3
@@ -215,7 +238,8 @@ def main():
             "value": round(value, 3), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.dtype, "data": "synthetic", "launch": ("hipGraph replay" if world == 1 else "hipGraph replay (forward+backward | eager all-reduce | optimizer)") if (args.graph and early is None) else "eager",
-            "host_enqueue_ms_per_step": round(t_host / args.steps * 1e3, 3),
+            "host_enqueue_ms_per_step": round(host_ms, 3),      # max over ranks
+            "allreduce_exposed_ms": round(exposed_ms, 3),       # max over ranks: compute-stream time inside GradBuckets.finish() per step
             "config": {"workload": f"UniT base-training step {args.variant.upper()} (TrainerNoMeta.run_step): ResNet-{args.depth}-C4, "
                                    f"VOC split1 K=20, 2 supervised + {n_weak} weak 3x600x1000 images per GPU, 512 RoIs/image, "
                                    "two Res5 heads, RPN 12000->2000, all 8 losses, SGD momentum",
@@ -268,9 +292,13 @@ def main():
                 byt = sum(e[3] for e in ev) / len(ev)
                 us = tot / len(ev) * 1e3
                 pm = next((v for kk, v in tdoc.items() if isinstance(v, dict) and pmc_key in kk), {})
+                ref = sum((e[4] or 0) for e in ev) / len(ev)
                 return {"launches_per_step": len(ev) // args.steps, "avg_launch_us": round(us, 1), "algorithmic_bytes_per_launch": round(byt),
                         "achieved_gbs": round(byt / us / 1e3, 1), "frac_of_hbm_peak": round(byt / us / 1e3 / HBM_PEAK_GBS, 4),
-                        "pmc_bytes_per_launch": pm.get("hbm_bytes_per_launch")}
+                        "pmc_bytes_per_launch": pm.get("hbm_bytes_per_launch"),
+                        # the bytes the reference's full 14x14 ROIAlignV2 grid would move for the same RoIs, and the rate that is
+                        "reference_equivalent_bytes_per_launch": round(ref) if ref else None,
+                        "reference_equivalent_gbs": round(ref / us / 1e3, 1) if ref else None}
             out["roofline"]["hbm_kernels"] = {"peak_gbs": HBM_PEAK_GBS, "roi_align_fwd": hbm(prof, "roi_align_fwd", "roi_align_fwd"),
                                               "roi_align_bwd_gather": hbm(prof, "roi_align_bwd_gather", "roi_align_bwd_gather")}
             out["roofline"]["latency_kernels_us"] = {k2: round(sum(e[0].elapsed_time(e[1]) for e in prof[k2]) / len(prof[k2]) * 1e3, 1)
@@ -280,6 +308,8 @@ def main():
                                              if prof_insitu.get(k2)}
                 out["roofline"]["insitu"]["note"] = ("same events under the production schedule (Res5 heads on two streams, wgrad on a "
                                                      "third): an interval includes the time the launch shares the chip")
+        if fp32_mode is not None:
+            out["fp32_mode"] = fp32_mode
         if not args.no_cpu_baseline and world == 1:
             # bounded: the oracle runs in a child process with a wall-clock limit (never part of the timed region)
             import subprocess

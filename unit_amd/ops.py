@@ -106,8 +106,8 @@ class _timed:
     """`with _timed("name", flops, bytes):` -- when bench.py has set PROFILER, brackets the launches inside with a HIP-event pair on
     the launch stream and files (e0, e1, flops, algorithmic bytes) under `name`; free otherwise"""
 
-    def __init__(self, name, flops=0.0, nbytes=0.0):
-        self.name, self.flops, self.nbytes = name, flops, nbytes
+    def __init__(self, name, flops=0.0, nbytes=0.0, ref_bytes=None):
+        self.name, self.flops, self.nbytes, self.ref_bytes = name, flops, nbytes, ref_bytes
 
     def __enter__(self):
         self.prof = PROFILER
@@ -120,7 +120,7 @@ class _timed:
         if self.prof is not None:
             e1 = torch.cuda.Event(enable_timing=True)
             e1.record()
-            self.prof.setdefault(self.name, []).append((self.e0, e1, self.flops, self.nbytes))
+            self.prof.setdefault(self.name, []).append((self.e0, e1, self.flops, self.nbytes, self.ref_bytes))
         return False
 
 
@@ -654,7 +654,9 @@ def roi_align(feat, rois, pooled_size=14, out_size=None, bin_step=1, spatial_sca
         out = torch.empty((r, out_size, out_size, c), dtype=feat.dtype, device=feat.device)
     # algorithmic bytes: the maps once + the pooled tensor once; `ref` = the reference-equivalent full 14x14 output
     es = feat.element_size()
-    with _timed("roi_align_fwd", 0.0, (feat.numel() + r * out_size * out_size * c) * es):
+    # ref_bytes: what the reference's ROIAlignV2 call moves for the same RoIs -- the full pooled_size x pooled_size grid (roi_heads.py:499:
+    # 14 x 14), of which the strided mode materialises only the bins Res5's stride-2 1x1 convs read
+    with _timed("roi_align_fwd", 0.0, (feat.numel() + r * out_size * out_size * c) * es, (feat.numel() + r * pooled_size * pooled_size * c) * es):
         check(lib().unit_roi_align_fwd(_p(feat), dt(feat.dtype), n, h, w, c, _p(rois), _p(roi_count), r, pooled_size, out_size, bin_step,
                                        float(spatial_scale), sampling_ratio, int(aligned), _p(out), _s()), "roi_align_fwd")
     return out
@@ -679,7 +681,7 @@ def roi_align_bwd_gather(gout, n_images, h, w, rois, out, pooled_size=14, bin_st
     nb = lib().unit_roi_align_bwd_gather_workspace_bytes(r)
     ws = workspace(nb, gout.device, slot=1)
     nb_alg = gout.numel() * gout.element_size() + out.numel() * out.element_size() * (1 + (addend is not None) + (mask_ref is not None))
-    with _timed("roi_align_bwd_gather", 0.0, nb_alg):
+    with _timed("roi_align_bwd_gather", 0.0, nb_alg, nb_alg + (pooled_size * pooled_size - out_size * out_size) * r * c * gout.element_size()):
         check(lib().unit_roi_align_bwd_gather(_p(gout), dt(gout.dtype), n_images, h, w, c, _p(rois), _p(roi_count), r, rois_per_image,
                                               image_offset, pooled_size, out_size, bin_step, float(spatial_scale), sampling_ratio,
                                               int(aligned), _p(addend), addend_images, _p(mask_ref), _p(out), dt(out.dtype), _p(ws),

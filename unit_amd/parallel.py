@@ -37,6 +37,7 @@ class GradBuckets:
         self._works = []
         self._tag_works = {}
         self._plan = None
+        self.exposed_events = None      # bench.py: a list -> finish() brackets its waits with a HIP-event pair on the compute stream
         model.on_grad_ready = self.ready if self.world > 1 else None    # single process: nothing to launch per bucket
 
     def _build(self):
@@ -112,9 +113,18 @@ class GradBuckets:
             w.wait()
 
     def finish(self):
-        """make the compute stream wait for every outstanding bucket (no host sync)."""
+        """make the compute stream wait for every outstanding bucket (no host sync). With `exposed_events` set, the time the compute
+        stream spends in these waits -- the part of the all-reduce that did NOT hide behind the backward -- is event-timed."""
+        ev = None
+        if self.exposed_events is not None and self._works:
+            import torch
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record()
         for w in self._works:
             w.wait()
+        if ev is not None:
+            ev[1].record()
+            self.exposed_events.append(ev)
         self._works = []
         self._tag_works = {}
 
