@@ -200,6 +200,50 @@ def test_conv_p8_kernel(dev, case, cfg):
     assert torch.equal(yf.cpu()[..., :k], y5.cpu()[..., :k])
 
 
+@pytest.mark.parametrize("code", [142, 152, 162, 172, 182, 144, 154, 164, 1152, 1154, 4152])
+@pytest.mark.parametrize("case", [(4, 38, 63, 1024, 256, 1, 1, 0), (4, 38, 63, 256, 256, 3, 1, 1), (2, 19, 23, 64, 320, 1, 2, 0), (3, 30, 33, 256, 200, 3, 1, 1),
+                                  (1, 9, 9, 64, 40, 1, 1, 0), (4, 38, 63, 256, 1024, 1, 1, 0)])
+def test_conv_loader_consumer_kernel(dev, case, code):
+    """persistent loader / consumer workgroups (conv_igemm_lc.hip; code = 100 + 10 * BM/16 + BN/64, + 1000 eight loader waves, + 4000
+    four ring slots): several tiles per workgroup, one / many k-steps per tile, padding, stride 2, ragged last pixel tile, channel
+    counts that are not multiples of the tile, residual + ReLU + mask epilogue -- BIT-IDENTICAL to the 4-wave LDS-DMA kernel (same
+    k order, same MFMA order, same epilogue), which the other tests pin to F.conv2d."""
+    o = ops()
+    n, h, w, c, k, r, stride, pad = case
+    gen = g(7 + code)
+    x = torch.randn(n, h, w, c, generator=gen).bfloat16().to(dev)
+    wt = (torch.randn(k, r, r, c, generator=gen) / np.sqrt(c * r * r)).bfloat16().to(dev)
+    bias = torch.randn(k, generator=gen).to(dev)
+    ldy = (k + 7) // 8 * 8
+    oh, ow = o.conv_out_size(h, w, r, r, stride, pad)
+    res = torch.randn(n, oh, ow, ldy, generator=gen).bfloat16().to(dev)
+    msk = torch.randn(n, oh, ow, ldy, generator=gen).bfloat16().to(dev)
+    a = o.conv2d(x, wt, k, r, r, stride, pad, bias=bias, ldy=ldy, tile_cfg=code)
+    b = o.conv2d(x, wt, k, r, r, stride, pad, bias=bias, ldy=ldy, tile_cfg=7)
+    assert torch.equal(a[..., :k], b[..., :k])
+    a = o.conv2d(x, wt, k, r, r, stride, pad, bias=bias, residual=res, mask_ref=msk, relu=True, ldy=ldy, tile_cfg=code)
+    b = o.conv2d(x, wt, k, r, r, stride, pad, bias=bias, residual=res, mask_ref=msk, relu=True, ldy=ldy, tile_cfg=7)
+    assert torch.equal(a[..., :k], b[..., :k])
+    ref = F.conv2d(x.float().permute(0, 3, 1, 2).cpu(), wt.float().permute(0, 3, 1, 2).cpu(), bias.cpu(), stride=stride, padding=pad).permute(0, 2, 3, 1)
+    got = o.conv2d(x, wt, k, r, r, stride, pad, bias=bias, ldy=ldy, tile_cfg=code).float().cpu()[..., :k]
+    assert torch.allclose(got, ref, rtol=2e-2, atol=8e-2)
+
+
+def test_conv_policy_picks_the_loader_consumer_kernel_for_res4(dev):
+    """what the step launches for the res4 shapes (tile_cfg 0) equals the explicit 4-wave kernel bit for bit, and the policy does
+    route them to the loader / consumer kernel"""
+    o = ops()
+    assert o.MID_TILE_POLICY(torch.bfloat16, 4 * 38 * 63, 256, 1024, 1024) == 152
+    assert o.MID_TILE_POLICY(torch.bfloat16, 4 * 38 * 63, 256, 256, 9 * 256) == 152
+    assert o.MID_TILE_POLICY(torch.bfloat16, 4 * 38 * 63, 1024, 256, 256) < 100           # four k-steps per tile: stays on the 4-wave tiles
+    gen = g(5)
+    x = torch.randn(4, 38, 63, 1024, generator=gen).bfloat16().to(dev)
+    wt = (torch.randn(256, 1, 1, 1024, generator=gen) / 32).bfloat16().to(dev)
+    assert torch.equal(o.conv2d(x, wt, 256, 1, 1, relu=True), o.conv2d(x, wt, 256, 1, 1, relu=True, tile_cfg=8))
+    yf = o.conv2d(x, wt, 256, 1, 1, out_dtype=torch.float32)                               # fp32 output: not the lc kernel's, still served
+    assert yf.dtype == torch.float32 and torch.allclose(yf, o.conv2d(x, wt, 256, 1, 1, out_dtype=torch.float32, tile_cfg=8))
+
+
 @pytest.mark.parametrize("case", [(1024, 7, 7, 128, 512), (300, 7, 7, 64, 264), (1030, 7, 7, 64, 256), (513, 5, 9, 128, 128), (256, 3, 3, 64, 72), (700, 1, 7, 64, 256)])
 def test_conv_position_major_tiles_skip_padding_taps(dev, case):
     """3x3 s1 p1 convs on small maps with many images (conv2 of the Res5 blocks and its dgrad: 7x7 bins x 1024 RoIs) run on tiles of

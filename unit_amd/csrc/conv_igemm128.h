@@ -1,0 +1,20 @@
+// conv_igemm128.h -- argument block shared by the mid-size LDS-DMA conv kernels (conv_igemm128.hip: 4-wave tiles, two workgroups per
+// CU; conv_igemm_lc.hip: persistent loader / consumer workgroups)
+#pragma once
+#include "common.h"
+
+struct ConvDmaArgs {
+  const void* x; const void* w; void* y;
+  const float* bias; const void* residual; const void* mask_ref;
+  int N, H, W, C;
+  int K, R, S, stride, pad;
+  int OH, OW;
+  int ldy, oy_mul, OHf, OWf;
+  int relu;
+  int Kgemm, M;
+  int tiles_m, tiles_n;
+  unsigned x_bytes, w_bytes;
+};
+
+// conv_igemm_lc.hip: tile code = 100 + 10 * (BM / 16) + (BN / 64)   (BM 64..128 pixels, BN 128 or 256 channels)
+int unit_conv_lc_launch(ConvDmaArgs& a, int out_dtype, int code, hipStream_t st);

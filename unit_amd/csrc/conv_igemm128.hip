@@ -16,18 +16,7 @@
 #define UNIT_DBGMID 0
 #endif
 
-struct ConvDmaArgs {
-  const void* x; const void* w; void* y;
-  const float* bias; const void* residual; const void* mask_ref;
-  int N, H, W, C;
-  int K, R, S, stride, pad;
-  int OH, OW;
-  int ldy, oy_mul, OHf, OWf;
-  int relu;
-  int Kgemm, M;
-  int tiles_m, tiles_n;
-  unsigned x_bytes, w_bytes;
-};
+#include "conv_igemm128.h"
 
 __device__ __forceinline__ int swz128(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
 
@@ -476,7 +465,7 @@ extern "C" int unit_conv2d_fwd_mid(const void* x, const void* w, void* y, const 
   UNIT_CHECK_ARG(OH == (H + 2 * pad - R) / stride + 1 && OW == (W + 2 * pad - S) / stride + 1, "conv_mid: OH/OW mismatch");
   UNIT_CHECK_ARG((OH - 1) * oy_mul < OHf && (OW - 1) * oy_mul < OWf, "conv_mid: output scatter out of range");
   UNIT_CHECK_ARG(((uintptr_t)x % 16 == 0) && ((uintptr_t)w % 16 == 0) && ((uintptr_t)y % 16 == 0), "conv_mid: 16B alignment");
-  UNIT_CHECK_ARG(tile >= 0 && tile <= 5, "conv_mid: tile must be 0..5");
+  UNIT_CHECK_ARG((tile >= 0 && tile <= 5) || tile >= 100, "conv_mid: tile must be 0..5 or a loader / consumer tile code (>= 100)");
   ConvDmaArgs a;
   a.x = x; a.w = w; a.y = y; a.bias = bias; a.residual = residual; a.mask_ref = mask_ref;
   a.N = N; a.H = H; a.W = W; a.C = C; a.K = K; a.R = R; a.S = S; a.stride = stride; a.pad = pad;
@@ -487,6 +476,7 @@ extern "C" int unit_conv2d_fwd_mid(const void* x, const void* w, void* y, const 
   a.x_bytes = (unsigned)xb; a.w_bytes = (unsigned)wb;
   if (a.M == 0 || K == 0) return UNIT_OK;
   hipStream_t st = (hipStream_t)stream;
+  if (tile >= 100) return unit_conv_lc_launch(a, out_dtype, tile, st);       // persistent loader / consumer workgroups (conv_igemm_lc.hip)
   if (out_dtype == UNIT_BF16) {
     if (tile == 3) return launch_ksplit<bf16_t>(a, st);
     if (tile == 0) return launch_dma<bf16_t, 128, 128, 2>(a, st);

@@ -1,0 +1,264 @@
+// conv_igemm_lc.hip -- implicit-GEMM convolution (forward / dgrad) for the backbone layers as PERSISTENT workgroups of four LOADER
+// waves and four CONSUMER waves on an LDS ring (MI355X_MICROARCH.md "ring-gemm"), one workgroup per CU.
+//
+// Why: the 4-wave kernel of conv_igemm128.hip (every wave issues its own LDS-DMA pieces, then its fragment reads, then its MFMAs,
+// one barrier per k-step) spends ~1450 cycles on a k-step whose MFMAs take 256: an LDS-DMA piece (`buffer_load_dwordx4 ... lds`,
+// 1 KB) occupies the issuing wave for 60-185 cycles, six of them per wave and k-step, serial with the wave's own reads and MFMAs
+// (DESIGN.md section 8). At M = 9 576 pixels (res4 on four 600x1000 images) a layer is 150-600 such tiles of 4-36 k-steps: the
+// launch is its pipeline fill, its serial k-steps and its drain.
+// Here the roles are split by wave: waves 4-7 (one per SIMD) do nothing but issue LDS-DMA pieces into an NS-slot ring, D = NS-1
+// k-steps ahead, under a counted vmcnt; waves 0-3 (one per SIMD) do nothing but read fragments and multiply -- a SIMD's matrix pipe
+// and its DMA issue port are fed by different waves at the same time. The workgroup is persistent: it walks a contiguous run of
+// output tiles, and because the loaders' cursor runs ahead across tile boundaries, the first k-steps of the next tile land while
+// the consumers write the previous tile's outputs (no per-tile pipeline fill or drain).
+//
+// Tile = BM pixels x BN channels x 64 k, BM = FB*16 in {64 .. 128}, BN = FA*64 in {128, 256}; consumer c owns all BM pixels x the
+// FA*16 channels c*FA*16 .. of the tile (acc[FA][FB], v_mfma_f32_16x16x32_bf16). The tile shape is chosen per layer so that the
+// tile count is a little under a multiple of the 256 CUs (M = 9 576, 256 channels: 80 x 128 -> 240 tiles).
+// LDS: NS slots of [X: XR rows][W: BN rows] x 128 B (XR = BM rounded up to 32: every loader issues the same number of pieces per
+// k-step -- the counted vmcnt needs a compile-time count -- and the rows past BM are zero pieces nobody reads), then the consumers'
+// wave-private epilogue scratch. Same LDS image / source-side XOR swizzle / k order (channel block outermost, taps innermost) /
+// MFMA order / epilogue as conv_igemm128.hip: results are bit-identical to it.
+//
+// Synchronisation: ONE s_barrier per k-step, executed by all eight waves (G = tiles * k-steps of them in all). Global k-step g
+// lives in slot g % NS.
+//   loader   : [prologue: issue steps 0 .. D-1, wait until step 0 has landed]
+//              loop g: barrier(g) ; issue step g+D into slot (g+D) % NS = (g-1) % NS ; s_waitcnt vmcnt(P*(D-1)) -> step g+1 landed
+//   consumer : loop g: barrier(g) ; read the fragments of slot g % NS ; MFMAs ; [last k-step of a tile: epilogue]
+//   RAW: barrier(g) follows the loaders' wait for step g.   WAR: slot (g-1) % NS was read in iteration g-1, its reads retired before
+//   that iteration's MFMAs, i.e. before the consumers reached barrier(g); the loaders overwrite it after barrier(g).
+#include "conv_igemm128.h"
+#include "conv_epilogue.h"
+
+typedef __attribute__((address_space(3))) void lds_void_lc;
+
+template <int N> __device__ __forceinline__ void wait_vmcnt() {
+  static_assert(N >= 0 && N <= 40, "vmcnt immediate");
+#define LC_W(n) else if constexpr (N == n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
+  if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  LC_W(1); LC_W(2); LC_W(3); LC_W(4); LC_W(5); LC_W(6); LC_W(7); LC_W(8); LC_W(9); LC_W(10); LC_W(11); LC_W(12); LC_W(13); LC_W(14);
+  LC_W(15); LC_W(16); LC_W(17); LC_W(18); LC_W(19); LC_W(20); LC_W(21); LC_W(22); LC_W(23); LC_W(24); LC_W(25); LC_W(26); LC_W(27);
+  LC_W(28); LC_W(29); LC_W(30); LC_W(31); LC_W(32); LC_W(33); LC_W(34); LC_W(35); LC_W(36); LC_W(37); LC_W(38); LC_W(39); LC_W(40);
+#undef LC_W
+}
+
+template <int FB, int FA, int NL, int NSMAX = 3> struct LcCfg {
+  static constexpr int BM = FB * 16, BN = FA * 64;
+  static constexpr int XP = BM / 8, WP = BN / 8, TP = XP + WP;     // LDS-DMA pieces (8 rows x 128 B) per k-step: X, W, all
+  static constexpr int XPL = (XP + NL - 1) / NL, WPL = (WP + NL - 1) / NL;      // at most so many per loader wave
+  static constexpr int XR = BM;                                     // X rows of a slot
+  static constexpr int SLOT = (XR + BN) * 128;
+  static constexpr int THREADS = (4 + NL) * 64;
+  static constexpr int SCR = 4 * EpiCfg<FA>::BYTES;
+  static constexpr int NS = ((160 * 1024 - SCR) / SLOT >= NSMAX) ? NSMAX : (160 * 1024 - SCR) / SLOT;
+  static constexpr int LDS = NS * SLOT + SCR;
+  static_assert((160 * 1024 - SCR) / SLOT >= 3, "three ring slots must fit the 160 KB of LDS");
+};
+
+template <int FB, int FA, int NL, int NSMAX = 3>
+__global__ void __launch_bounds__((4 + NL) * 64) conv_igemm_lc_kernel(ConvDmaArgs p) {
+  typedef LcCfg<FB, FA, NL, NSMAX> Cf;
+  constexpr int BM = Cf::BM, BN = Cf::BN, BK = 64;
+  constexpr int XP = Cf::XP, WP = Cf::WP, TP = Cf::TP, XPL = Cf::XPL, WPL = Cf::WPL, XR = Cf::XR, SLOT = Cf::SLOT, NS = Cf::NS;
+  constexpr int D = NS - 1, PLO = TP / NL, NHI = TP % NL;           // loaders 0 .. NHI-1 issue PLO + 1 pieces per k-step, the others PLO
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  // this workgroup's run of tiles: the XCD-aware id map of the other conv kernels (workgroup b runs on XCD b % 8; an XCD's
+  // workgroups get neighbouring runs: the channel tiles of a pixel block share its rows through that XCD's L2), then an even split
+  const int total = p.tiles_m * p.tiles_n, nwg = gridDim.x;
+  int bid = blockIdx.x;
+  {
+    int q = nwg / 8, r = nwg % 8, xcd = bid % 8, loc = bid / 8;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+  }
+  const int tq = total / nwg, tr = total % nwg;
+  const int t_first = bid * tq + min(bid, tr), t_count = tq + (bid < tr ? 1 : 0);
+  const int nk = p.Kgemm / BK;
+  const int G = t_count * nk;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+  if (wid >= 4) {
+    // ------------------------------------------------------------------------------------------------ loader waves
+    const int l = wid - 4;
+    const bf16_t* __restrict__ X = (const bf16_t*)p.x;
+    const bf16_t* __restrict__ Wt = (const bf16_t*)p.w;
+    __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(X), 0, (int)p.x_bytes, 0x00020000);
+    __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(Wt), 0, (int)p.w_bytes, 0x00020000);
+    constexpr unsigned OOB = 0xFFFFFFF0u;
+    const int lrow = lane >> 3, lc = lane & 7;
+    const int RS = p.R * p.S;
+    // The TP pieces of a k-step (X pieces 0 .. XP-1, then the W pieces) are dealt round-robin to the NL loaders: X piece i*NL + l, W piece
+    // i*NL + lw with XP + lw = l (mod NL); piece = 8 rows: lane -> row + lrow, LDS chunk lc (lane-linear image), SOURCE chunk
+    // lc ^ ((row >> 1) & 7)
+    const int lw = (l + NL - XP % NL) % NL;
+    // (arrays of fixed size: hipcc's host pass silently drops a kernel instantiation whose lambdas capture arrays sized by a template-
+    // dependent constant -- the launch stub then is an undefined symbol, conv_igemm128.hip has the same note)
+    static_assert(XPL <= 4 && WPL <= 8, "staging tables");
+    int x_ih0[4], x_iw0[4]; unsigned x_base[4]; bool x_ok[4]; int x_q[4];
+    unsigned w_off[8]; bool w_ok[8];
+    int cur_t = 0, cur_kt = 0, cur_cb = 0, cur_rs = 0;
+    auto setup_tile = [&](int t) {
+      int id = t_first + t;
+      int tile_n = id % p.tiles_n, tile_m = id / p.tiles_n;
+      int m0 = tile_m * BM, n0 = tile_n * BN;
+#pragma unroll
+      for (int i = 0; i < XPL; ++i) {
+        int row = (i * NL + l) * 8 + lrow;
+        x_q[i] = lc ^ ((row >> 1) & 7);
+        int m = m0 + row;
+        x_ok[i] = row < BM && m < p.M;
+        int mm = x_ok[i] ? m : 0;
+        int ow = mm % p.OW; int tt = mm / p.OW; int oh = tt % p.OH; int n = tt / p.OH;
+        x_ih0[i] = oh * p.stride - p.pad; x_iw0[i] = ow * p.stride - p.pad;
+        x_base[i] = (unsigned)n * (unsigned)(p.H * p.W * p.C);
+      }
+#pragma unroll
+      for (int i = 0; i < WPL; ++i) {
+        int row = (i * NL + lw) * 8 + lrow;
+        int q = lc ^ ((row >> 1) & 7);
+        int nn = n0 + row;
+        w_ok[i] = row < BN && nn < p.K;
+        w_off[i] = ((unsigned)(w_ok[i] ? nn : 0) * (unsigned)p.Kgemm + (unsigned)q * 8u) * 2u;
+      }
+    };
+    // issue the k-step at the cursor into `slot`, advance the cursor (k order: channel block outermost, the R*S taps innermost)
+    auto issue = [&](int slot) {
+      int ch0 = cur_cb * BK, k0 = cur_rs * p.C + ch0, r = cur_rs / p.S, s = cur_rs - r * p.S;
+      char* base = smem + slot * SLOT;
+#pragma unroll
+      for (int i = 0; i < XPL; ++i) {
+        if (i * NL + l >= XP) continue;             // (wave-uniform)
+        int R0 = (i * NL + l) * 8;
+        int ih = x_ih0[i] + r, iw = x_iw0[i] + s;
+        bool ok = x_ok[i] && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
+        unsigned off = (x_base[i] + (unsigned)((ih * p.W + iw) * p.C + ch0 + x_q[i] * 8)) * 2u;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, (lds_void_lc*)(base + R0 * 128), 16, ok ? off : OOB, 0, 0, 0);
+      }
+#pragma unroll
+      for (int i = 0; i < WPL; ++i) {
+        if (i * NL + lw >= WP) continue;
+        int R0 = (i * NL + lw) * 8;
+        unsigned off = w_off[i] + (unsigned)k0 * 2u;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (lds_void_lc*)(base + XR * 128 + R0 * 128), 16, w_ok[i] ? off : OOB, 0, 0, 0);
+      }
+      if (++cur_rs == RS) { cur_rs = 0; ++cur_cb; }
+      if (++cur_kt == nk) {
+        cur_kt = 0; cur_cb = 0; cur_rs = 0;
+        if (++cur_t < t_count) setup_tile(cur_t);
+      }
+    };
+    setup_tile(0);
+    int issued = 0, islot = 0;
+    for (; issued < D && issued < G; ++issued) { issue(islot); islot = islot + 1 == NS ? 0 : islot + 1; }
+    const bool hi = l < NHI;                        // this loader issues PLO + 1 pieces per k-step
+    auto wait_ahead = [&]() {                       // all but the youngest D-1 k-steps of this wave's pieces have landed
+      if (hi) wait_vmcnt<(PLO + 1) * (D - 1)>(); else wait_vmcnt<PLO * (D - 1)>();
+    };
+    if (G >= D) wait_ahead(); else wait_vmcnt<0>();
+    for (int g = 0; g < G; ++g) {
+      __builtin_amdgcn_s_barrier();
+      if (issued < G) {
+        issue(islot); islot = islot + 1 == NS ? 0 : islot + 1; ++issued;
+        wait_ahead();
+      } else {
+        wait_vmcnt<0>();
+      }
+    }
+    return;
+  }
+
+  // -------------------------------------------------------------------------------------------------- consumer waves
+  const int c = wid;
+  const int frow = lane & 15, fq = lane >> 4;
+  // fragment offsets inside a slot (k-substep 0; substep 1 = chunk + 4 = byte offset ^ 64)
+  static_assert(FB <= 8 && FA <= 4, "fragment tables");
+  int offx[8], offw[4];
+#pragma unroll
+  for (int b = 0; b < FB; ++b) { int row = b * 16 + frow; offx[b] = row * 128 + ((fq ^ ((row >> 1) & 7)) << 4); }
+#pragma unroll
+  for (int a = 0; a < FA; ++a) { int row = c * FA * 16 + a * 16 + frow; offw[a] = XR * 128 + row * 128 + ((fq ^ ((row >> 1) & 7)) << 4); }
+  char* scr = smem + NS * SLOT + c * EpiCfg<FA>::BYTES;
+  int slot = 0;
+  for (int t = 0; t < t_count; ++t) {
+    int id = t_first + t;
+    int tile_n = id % p.tiles_n, tile_m = id / p.tiles_n;
+    f32x4 acc[FA][FB];
+#pragma unroll
+    for (int a = 0; a < FA; ++a)
+#pragma unroll
+      for (int b = 0; b < FB; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int kt = 0; kt < nk; ++kt) {
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      const char* base = smem + slot * SLOT;
+      i32x4 fa[2][FA], fb[2][FB];
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+        for (int a = 0; a < FA; ++a) fa[ks][a] = *reinterpret_cast<const i32x4*>(base + (offw[a] ^ (ks * 64)));
+#pragma unroll
+        for (int b = 0; b < FB; ++b) fb[ks][b] = *reinterpret_cast<const i32x4*>(base + (offx[b] ^ (ks * 64)));
+      }
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int a = 0; a < FA; ++a)
+#pragma unroll
+          for (int b = 0; b < FB; ++b)
+            acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fa[ks][a]), __builtin_bit_cast(bf16x8, fb[ks][b]), acc[a][b], 0, 0, 0);
+      __builtin_amdgcn_s_setprio(0);
+      slot = slot + 1 == NS ? 0 : slot + 1;
+    }
+    // this wave's BM x FA*16 block through its private scratch, row-major (conv_epilogue.h); the loaders are already D k-steps
+    // into the next tile
+    epilogue_rows_bf16<FA, FB>(acc, scr, tile_m * BM, tile_n * BN + c * FA * 16, p, lane);
+  }
+}
+
+template <int FB, int FA, int NL, int NSMAX = 3>
+static int launch_lc(ConvDmaArgs& a, hipStream_t st) {
+  typedef LcCfg<FB, FA, NL, NSMAX> Cf;
+  a.tiles_m = cdiv(a.M, Cf::BM); a.tiles_n = cdiv(a.K, Cf::BN);
+  int total = a.tiles_m * a.tiles_n;
+  int grid = total < 256 ? total : 256;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)conv_igemm_lc_kernel<FB, FA, NL, NSMAX>, hipFuncAttributeMaxDynamicSharedMemorySize, Cf::LDS);
+    attr_set = true;
+  }
+  conv_igemm_lc_kernel<FB, FA, NL, NSMAX><<<grid, Cf::THREADS, Cf::LDS, st>>>(a);
+  UNIT_LAUNCH_CHECK();
+  return UNIT_OK;
+}
+
+int unit_conv_lc_launch(ConvDmaArgs& a, int out_dtype, int code, hipStream_t st) {
+  if (out_dtype != UNIT_BF16 || (a.ldy & 7) != 0) { unit_set_error("conv_lc: bf16 output with ldy % 8 == 0 only"); return UNIT_ERR_UNSUPPORTED; }
+  // code = 100 + 10 * (BM / 16) + BN / 64  [+ 1000: eight loader waves instead of four; + 4000: four ring slots instead of three].
+  // Measured on the res4 shapes (tools/lc_sweep.py, profiles/r03_exp_loader_consumer.txt): neither a deeper ring (3 / 4 / 5 / 6 slots)
+  // nor eight loaders change the time -- a k-step costs what its (BM + BN) * 128 bytes cost at the CU's intake from L2 / Infinity Cache
+  // (~27 B/clk) -- so the default is the smallest footprint: three slots, four loaders.
+  switch (code) {
+    case 142: return launch_lc<4, 2, 4>(a, st);
+    case 152: return launch_lc<5, 2, 4>(a, st);
+    case 162: return launch_lc<6, 2, 4>(a, st);
+    case 172: return launch_lc<7, 2, 4>(a, st);
+    case 182: return launch_lc<8, 2, 4>(a, st);
+    case 144: return launch_lc<4, 4, 4>(a, st);
+    case 154: return launch_lc<5, 4, 4>(a, st);
+    case 164: return launch_lc<6, 4, 4>(a, st);
+    case 1142: return launch_lc<4, 2, 8>(a, st);
+    case 1152: return launch_lc<5, 2, 8>(a, st);
+    case 1162: return launch_lc<6, 2, 8>(a, st);
+    case 1172: return launch_lc<7, 2, 8>(a, st);
+    case 1182: return launch_lc<8, 2, 8>(a, st);
+    case 1144: return launch_lc<4, 4, 8>(a, st);
+    case 1154: return launch_lc<5, 4, 8>(a, st);
+    case 4152: return launch_lc<5, 2, 4, 4>(a, st);
+    case 4142: return launch_lc<4, 2, 4, 4>(a, st);
+  }
+  unit_set_error("conv_lc: tile code must be 100 + 10 * (BM / 16) + BN / 64 with BM 64..128 x BN 128, or BM 64..96 x BN 256");
+  return UNIT_ERR_UNSUPPORTED;
+}

@@ -63,11 +63,32 @@ def _big_tile_default(dtype, m, k, c, kgemm):
 _NO_MID = bool(int(__import__("os").environ.get("UNIT_NO_MID_TILE", "0")))   # A/B switch for tools/ and debugging
 
 
+_NO_LC = bool(int(os.environ.get("UNIT_NO_LC", "0")))      # A/B switch: 1 = never the persistent loader / consumer conv kernel (csrc/conv_igemm_lc.hip)
 _MID96 = int(os.environ.get("UNIT_MID96", "0"))      # 0: off; 1: 96x128 tiles where tools/mid_sweep.py found them faster in isolation; 2: only the two-per-CU form
 
 
+def lc_tile_code(m, k, kgemm):
+    """tile of the persistent loader / consumer kernel (csrc/conv_igemm_lc.hip) for an [m pixels] x [k channels] x [kgemm] layer:
+    100 + 10 * (BM / 16) + BN / 64. A workgroup's time is its tiles x k-steps x the (BM + BN) * 128 bytes a k-step stages (the CU's
+    intake is what bounds it) plus an epilogue per tile; the grid is one workgroup per CU. (M = 9 576, 256 channels: 80 x 128 = 240
+    tiles, one per CU, measured best of the eight shapes; 1024 channels: 80 x 256.)"""
+    best = None
+    for fb, fa in ((4, 2), (5, 2), (6, 2), (7, 2), (8, 2), (4, 4), (5, 4), (6, 4)):
+        bm, bn = fb * 16, fa * 64
+        tiles = ((m + bm - 1) // bm) * ((k + bn - 1) // bn)
+        per_wg = (tiles + 255) // 256
+        cost = per_wg * ((kgemm // 64) * (bm + bn) + 0.5 * bm * bn / 64.0)
+        if best is None or cost < best[0]:
+            best = (cost, 100 + 10 * fb + fa)
+    return best[1]
+
+
 def _mid_tile_default(dtype, m, k, c, kgemm):
-    """-1: use the register-staged conv_igemm.hip kernel; 0..3: LDS-DMA 4-wave kernel with that tile (csrc/conv_igemm128.hip).
+    """-1: use the register-staged conv_igemm.hip kernel; 0..5: LDS-DMA 4-wave kernel with that tile (csrc/conv_igemm128.hip);
+    >= 100: persistent loader / consumer workgroups (csrc/conv_igemm_lc.hip, `lc_tile_code`) -- the layers with a long contraction
+    and few output tiles (res4 and the res3 -> res4 transition on four 600x1000 images: 1x1 1024 -> 256 15.0 -> 11.9 us, 3x3 256 -> 256
+    26.8 -> 18.9 us, tools/lc_sweep.py); short contractions (K = 256 -> 1024: four k-steps per tile) and the large res2 / res3 maps stay
+    on the 4-wave tiles, which measured equal or better there.
     Measured on the backbone shapes (tools/microbench.py): 128x64 for 64-channel outputs, 128x128 when that tiling still
     gives every CU a workgroup or two, 64x128 below that."""
     if dtype != torch.bfloat16 or c % 64 != 0 or k < 64 or _NO_MID:
@@ -75,6 +96,8 @@ def _mid_tile_default(dtype, m, k, c, kgemm):
     if k <= 64:
         return 2
     tiles = ((m + 127) // 128) * ((k + 127) // 128)
+    if not _NO_LC and kgemm >= 512 and tiles <= 640 and k % 8 == 0:
+        return lc_tile_code(m, k, kgemm)
     if _MID96:
         # 96-row tiles (tools/mid_sweep.py, profiles/r02_exp_mid_sweep_96_row_tiles.txt): the res4 1x1 -> 256 layers become 100 x 2 = 200
         # workgroups, one round with one workgroup per CU (14.9 vs 15.6 us; 3x3: 26.7 vs 27.9); between one and 2.5 rounds of 128x128
@@ -218,10 +241,18 @@ def conv2d(x, w, k, r, s, stride=1, pad=0, bias=None, residual=None, mask_ref=No
         e0.record()
     big = tile_cfg in (5, 6, 11, 12, 13, 14, 15, 16, 17, 18, 21, 22) or (tile_cfg == 0 and BIG_TILE_POLICY(x.dtype, n * oh * ow, k, c, r * s * c))
     mid = -1
-    if tile_cfg in (7, 8, 9, 10, 19, 20):
+    if tile_cfg >= 100:          # persistent loader / consumer workgroups: 100 + 10 * (BM / 16) + BN / 64 (csrc/conv_igemm_lc.hip)
+        mid = tile_cfg
+    elif tile_cfg in (7, 8, 9, 10, 19, 20):
         mid = {19: 4, 20: 5}.get(tile_cfg, tile_cfg - 7)
     elif tile_cfg == 0 and not big:
         mid = MID_TILE_POLICY(x.dtype, n * oh * ow, k, c, r * s * c)
+        if mid >= 100 and (out_dtype != torch.bfloat16 or ldy % 8 != 0):        # the loader / consumer kernel writes bf16 rows of 16-byte vectors
+            was, globals()["_NO_LC"] = _NO_LC, True
+            try:
+                mid = MID_TILE_POLICY(x.dtype, n * oh * ow, k, c, r * s * c)
+            finally:
+                globals()["_NO_LC"] = was
     if mid >= 0:
         check(lib().unit_conv2d_fwd_mid(_p(x), _p(w), _p(out), _p(bias), _p(residual), _p(mask_ref), dt(out_dtype),
                                         n, h, wd, c, k, r, s, stride, pad, oh, ow, ldy, oy_mul, ohf, owf, int(relu), mid, _s()),
