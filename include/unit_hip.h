@@ -3,9 +3,8 @@
  * device pointers + explicit shapes/strides + a caller-owned workspace, launches asynchronously on the given
  * hipStream_t (passed as void*), never allocates, never synchronises, never throws.  Return 0 on success, <0 on
  * error (unit_last_error() gives the message).  One process per GPU.  Process-wide state, all of it listed here: the last error
- * string (thread-local); two kernel-selection switches for A/B runs (unit_wgrad_big_variant / unit_wgrad_mid_variant, default =
- * the production kernels, not thread-safe, never touched by the step); `hipFuncSetAttribute` one-time flags of the kernels that
- * need more than 64 KB of LDS. No operator result depends on call history; there is no allocator, cache or handle to thread
+ * string (thread-local); `hipFuncSetAttribute` one-time flags of the kernels that need more than 64 KB of LDS. Which kernel serves
+ * a call is decided per call (explicit `variant` / `tile` arguments, 0 = the production policy): there is no kernel-selection state. No operator result depends on call history; there is no allocator, cache or handle to thread
  * through calls (which is why the `unit_ctx*` of SURVEY 8b was not needed).
  *
  * The reference reaches these operators through PyTorch's dispatcher into ATen/cuDNN, Detectron2 `_C` and torchvision;
@@ -93,21 +92,20 @@ int unit_conv2d_fwd_mid(const void* x, const void* w, void* y, const float* bias
                         int out_dtype, int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int OH, int OW, int ldy,
                         int oy_mul, int OHf, int OWf, int relu, int tile, void* stream);
 size_t unit_conv2d_wgrad_workspace_bytes(int in_dtype, int N, int OH, int OW, int K, int R, int S, int C);
+/* variant: 0 = production policy. Big-M bf16 layers (C % 256 == 0, K % 256 == 0, M >= 16384) use a 256x256 tile: policy = the
+ * phase-interleaved schedule (csrc/conv_wgrad256p8.hip) for pointwise layers and maps of <= 1024 pixels -- on 3x3 s1 p1 convs over maps
+ * of <= 512 pixels contracting only over the pixels whose filter tap lies inside the map (18 % fewer steps on 7x7; equal to the full
+ * contraction within fp32 rounding, deterministic) -- and a ring of four 32-pixel stages (csrc/conv_wgrad256r.hip) otherwise;
+ * 1 = two-stage loop (csrc/conv_wgrad256.hip), 2 = the ring, 3 = the phase-interleaved schedule over ALL pixels: same slabs bit for bit.
+ * All other layers use a 128x128 tile: policy = LDS-DMA ring kernel for bf16 layers with C % 128 == 0 and K % 128 == 0
+ * (csrc/conv_wgrad128r.hip); 4 = the register-staged kernel everywhere (csrc/conv_wgrad.hip): same slabs bit for bit. */
 int unit_conv2d_wgrad(const void* x, const void* dy, float* dw, const float* scale_k, int in_dtype, int N, int H, int W, int C,
-                      int K, int R, int S, int stride, int pad, int OH, int OW, int ldy, int accumulate, void* workspace,
+                      int K, int R, int S, int stride, int pad, int OH, int OW, int ldy, int accumulate, int variant, void* workspace,
                       size_t workspace_bytes, void* stream);
 /* dw == NULL: unit_conv2d_wgrad leaves unit_conv2d_wgrad_splits() partial slabs in the workspace (no reduction); the
  * multi-tensor kernels below reduce all layers of a gradient bucket / refresh all prepared weight copies in ONE launch.
  * descs_dev: array of {const float* partial, *scale; void* wf, *wd; long offset; int splits,K,R,S,C,block0} (64 B each) */
 int unit_conv2d_wgrad_splits(int in_dtype, int N, int OH, int OW, int K, int R, int S, int C);
-/* big-M bf16 layers (C % 256 == 0, K % 256 == 0, M >= 16384) use a 256x256 tile: 3 (default) = phase-interleaved schedule
- * (csrc/conv_wgrad256p8.hip) for pointwise layers and maps of <= 1024 pixels, ring of four 32-pixel stages (csrc/conv_wgrad256r.hip) otherwise; 0 / 2 force
- * one of them, 1 = two-stage loop (csrc/conv_wgrad256.hip); same slabs bit for bit. Process-wide, not thread-safe. */
-int unit_wgrad_big_variant(int v);
-/* 128x128 tile (all other layers): 0 (default) = LDS-DMA ring kernel for bf16 layers with C % 128 == 0 and K % 128 == 0
- * (csrc/conv_wgrad128r.hip), 1 = register-staged kernel everywhere (csrc/conv_wgrad.hip); same slabs bit for bit. Returns the
- * previous setting. */
-int unit_wgrad_mid_variant(int v);   /* returns the previous setting */
 size_t unit_tensor_desc_bytes(void);
 int unit_multi_wgrad_reduce(const void* descs_dev, int n, int total_blocks, float* grads_flat, void* stream);
 int unit_multi_weight_prep(const void* descs_dev, int n, int total_blocks, const float* params_flat, int dtype, void* stream);

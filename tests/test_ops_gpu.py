@@ -326,13 +326,8 @@ def test_wgrad_ring128_kernel(dev, case):
     y.backward(dy)
     ref = wt.grad
     xd, dyd = nhwc(x).to(dev).bfloat16(), nhwc(dy).to(dev).bfloat16()
-    prev = o.wgrad_mid_variant(0)
-    try:
-        dw0 = o.conv2d_wgrad(xd, dyd, k, r, r, stride, pad)
-        o.wgrad_mid_variant(1)
-        dw1 = o.conv2d_wgrad(xd, dyd, k, r, r, stride, pad)
-    finally:
-        o.wgrad_mid_variant(prev)
+    dw0 = o.conv2d_wgrad(xd, dyd, k, r, r, stride, pad)
+    dw1 = o.conv2d_wgrad(xd, dyd, k, r, r, stride, pad, variant=4)          # the register-staged kernel
     assert torch.equal(dw0.cpu(), dw1.cpu())
     got = dw0.cpu().permute(0, 3, 1, 2)
     assert (got - ref).abs().max() <= 2e-3 * ref.abs().max()
@@ -420,28 +415,21 @@ def test_wgrad_big_tile_kernel(dev, case):
     assert torch.allclose(got, ref, rtol=2e-2, atol=2e-2 * ref.abs().max().item()), (got - ref).abs().max() / ref.abs().max()
     # tight check against the 128x128 kernel's summation (same bf16 products, fp32 accumulation: only the order differs)
     assert (got - ref).abs().max() <= 2e-3 * ref.abs().max()
-    # the other schedules of the 256x256 tile (0 = phase-interleaved, 1 = two-stage, 2 = ring of four 32-pixel stages) accumulate
+    # the other schedules of the 256x256 tile (variant 3 = phase-interleaved, 1 = two-stage, 2 = ring of four 32-pixel stages) accumulate
     # in the same order: identical bits -- except for 3x3 s1 p1 convs on small maps, where the default contracts only over the pixels
     # whose filter tap lies inside the map (Wgrad256Args::valid_only: 18 % fewer steps on 7x7; the skipped rows were exact zeros, the
     # fp32 partial sums associate differently): equal within fp32 rounding of the accumulation
     valid_only = r == 3 and stride == 1 and pad == 1 and h * w <= 512
-    prev = o.wgrad_big_variant(0)
-    try:
-        outs = []
-        for v in (0, 1, 2):
-            o.wgrad_big_variant(v)
-            outs.append(o.conv2d_wgrad(nhwc(x).to(dev).bfloat16(), nhwc(dy).to(dev).bfloat16(), k, r, r, stride, pad, scale=scale.to(dev)).cpu())
-        assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
-        if valid_only:
-            assert not torch.equal(dw.cpu(), outs[0])                       # the default did take the other path
-            assert (dw.cpu() - outs[0]).abs().max() <= 2e-5 * ref.abs().max()
-        else:
-            assert torch.equal(dw.cpu(), outs[0])
-        o.wgrad_big_variant(3)
-        again = o.conv2d_wgrad(nhwc(x).to(dev).bfloat16(), nhwc(dy).to(dev).bfloat16(), k, r, r, stride, pad, scale=scale.to(dev)).cpu()
-        assert torch.equal(dw.cpu(), again)                                 # deterministic
-    finally:
-        o.wgrad_big_variant(prev)
+    outs = [o.conv2d_wgrad(nhwc(x).to(dev).bfloat16(), nhwc(dy).to(dev).bfloat16(), k, r, r, stride, pad, scale=scale.to(dev), variant=v).cpu()
+            for v in (3, 1, 2)]
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    if valid_only:
+        assert not torch.equal(dw.cpu(), outs[0])                       # the default did take the other path
+        assert (dw.cpu() - outs[0]).abs().max() <= 2e-5 * ref.abs().max()
+    else:
+        assert torch.equal(dw.cpu(), outs[0])
+    again = o.conv2d_wgrad(nhwc(x).to(dev).bfloat16(), nhwc(dy).to(dev).bfloat16(), k, r, r, stride, pad, scale=scale.to(dev)).cpu()
+    assert torch.equal(dw.cpu(), again)                                 # deterministic
 
 
 def test_pools_bias_misc(dev):
@@ -1170,12 +1158,15 @@ def test_conv_ex_rejects_what_it_cannot_do(dev):
     part = torch.zeros(4 * 4 * 128, device=dev)
 
     def call(**kw):
-        a = dict(y=y, relu_bits=None, pool=None, pool_rows=0, c=64, k=128, r=1, pad=0, ldy=128, x2=None, c2=0)
+        a = dict(y=y, relu_bits=None, pool=None, pool_rows=0, c=64, k=128, r=1, pad=0, ldy=128, x2=None, c2=0, variant=0)
         a.update(kw)
         check(lib().unit_conv2d_fwd_big_ex(o._p(x), o._p(w), o._p(a["y"]), None, None, None, o._p(a["relu_bits"]), o._p(a["pool"]), a["pool_rows"],
-                                           4, 7, 7, a["c"], a["k"], a["r"], a["r"], a["pad"], a["ldy"], 0, o._p(a["x2"]), a["c2"], o._s()), "ex")
+                                           4, 7, 7, a["c"], a["k"], a["r"], a["r"], a["pad"], a["ldy"], 0, o._p(a["x2"]), a["c2"], a["variant"], o._s()), "ex")
 
     call()                                                          # the plain call is fine
+    call(variant=11)                                                # ... also on the 32x32x16-MFMA kernel
+    with pytest.raises(UnitLibError):
+        call(variant=5)                                             # not a variant of this entry
     with pytest.raises(UnitLibError):
         call(y=None)                                                # no output at all
     with pytest.raises(UnitLibError):

@@ -35,18 +35,15 @@ for (n, h, w, c, k, r, st, pad) in WG:
     x = torch.randn(n, h, w, c, device=dev).bfloat16()
     oh, ow = o.conv_out_size(h, w, r, r, st, pad)
     dy = torch.randn(n, oh, ow, k, device=dev).bfloat16()
-    o.wgrad_big_variant(1)
-    ref = o.conv2d_wgrad(x, dy, k, r, r, st, pad).clone()
-    for v in (0, 2):
-        o.wgrad_big_variant(v)
+    ref = o.conv2d_wgrad(x, dy, k, r, r, st, pad, variant=1).clone()
+    for v in (3, 2):
         for i in range(reps):
             with torch.cuda.stream(side):
                 noise_a.mul_(1.0001)
-            dw = o.conv2d_wgrad(x, dy, k, r, r, st, pad)
+            dw = o.conv2d_wgrad(x, dy, k, r, r, st, pad, variant=v)
             if not torch.equal(dw, ref):
                 bad += 1
                 print("wgrad mismatch", (n, h, w, c, k, r, st, pad), v, i, (dw - ref).abs().max().item())
-    o.wgrad_big_variant(3)
     torch.cuda.synchronize()
     print("wgrad", (n, h, w, c, k, r, st, pad), "ok" if bad == 0 else f"bad={bad}")
 print("reps", reps, "mismatches", bad)

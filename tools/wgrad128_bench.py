@@ -18,12 +18,10 @@ for name, n, h, w, c, k, r, st, pad in SH:
     flops = 2.0 * n * oh * ow * k * r * r * c
     line = f"{name:26s}"
     ref = None
-    for v in (1, 0):
-        o.wgrad_mid_variant(v)
-        slab, sp = o.conv2d_wgrad_partial(x, dy, k, r, r, st, pad)
-        ms = timeit(lambda: o.conv2d_wgrad_partial(x, dy, k, r, r, st, pad))
+    for v in (4, 0):                   # unit_conv2d_wgrad variants: 4 = register-staged kernel, 0 = policy (LDS-DMA ring)
+        slab, sp = o.conv2d_wgrad_partial(x, dy, k, r, r, st, pad, variant=v)
+        ms = timeit(lambda: o.conv2d_wgrad_partial(x, dy, k, r, r, st, pad, variant=v))
         if ref is None:
             ref = slab.clone()
         line += f" | v{v}: {ms * 1e3:7.1f} us {flops / ms / 1e9:6.0f} TF splits {sp} equal {torch.equal(ref, slab)}"
-    o.wgrad_mid_variant(0)
     print(line)

@@ -1,4 +1,4 @@
-"""A/B of the 256x256 weight-gradient kernels (0 = phase-interleaved, 1 = two-stage, 2 = ring of four 32-pixel stages) on the Res5 shapes: python tools/wgrad_bench.py"""
+"""A/B of the 256x256 weight-gradient kernels (variant 3 = phase-interleaved, 1 = two-stage, 2 = ring of four 32-pixel stages, 0 = policy) on the Res5 shapes: python tools/wgrad_bench.py"""
 import sys
 
 import torch
@@ -18,12 +18,10 @@ for name, n, h, w, c, k, r, st, pad in SH:
     flops = 2.0 * n * oh * ow * k * r * r * c
     line = f"{name:26s}"
     ref = None
-    for v in (2, 0, 3, 0, 3):
-        o.wgrad_big_variant(v)
-        slab, sp = o.conv2d_wgrad_partial(x, dy, k, r, r, st, pad)
-        ms = timeit(lambda: o.conv2d_wgrad_partial(x, dy, k, r, r, st, pad))
+    for v in (2, 3, 0, 3, 0):          # unit_conv2d_wgrad variants: 2 = ring, 3 = phase-interleaved over all pixels, 0 = policy (valid-only on 3x3 small maps)
+        slab, sp = o.conv2d_wgrad_partial(x, dy, k, r, r, st, pad, variant=v)
+        ms = timeit(lambda: o.conv2d_wgrad_partial(x, dy, k, r, r, st, pad, variant=v))
         if ref is None:
             ref = slab.clone()
-        line += f" | v{v}: {ms * 1e3:7.1f} us {flops / ms / 1e9:6.0f} TF splits {sp} equal {torch.equal(ref, slab)}"       # 3 = default (valid-only contraction on 3x3 small maps)
-    o.wgrad_big_variant(3)
+        line += f" | v{v}: {ms * 1e3:7.1f} us {flops / ms / 1e9:6.0f} TF splits {sp} equal {torch.equal(ref, slab)}"
     print(line)

@@ -204,16 +204,12 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ partial, int split
 extern "C" int unit_wgrad_use_big(int in_dtype, long M, int K, int C, int RS);
 extern "C" int unit_wgrad_big_splits(long M, int tiles, int R, int S, int OHW);
 extern "C" int unit_conv2d_wgrad_big_launch(const void* x, const void* dy, float* partial, int N, int H, int W, int C, int K, int R, int S,
-                                            int stride, int pad, int OH, int OW, int ldy, size_t workspace_bytes, void* stream);
+                                            int stride, int pad, int OH, int OW, int ldy, int variant, size_t workspace_bytes, void* stream);
 
-// 0 (default): LDS-DMA ring kernel (conv_wgrad128r.hip) where it applies (bf16, C % 128 == 0, K % 128 == 0); 1: the register-staged
-// kernel below everywhere. Isolated the two are equal on the backbone shapes (tools/wgrad128_bench.py: 18.2 vs 18.5 us, 31.9 vs
-// 30.4 us; RPN 3x3 306 vs 284 us -- at M = 9 576 these launches are bound by their fp32 slab store and input streaming, not by the
-// loop's load latency); inside the step the ring form is 0.05-0.1 ms ahead on the same box (18.36 vs 18.44-18.48 ms).
-// UNIT_WGRAD_MID_VARIANT overrides the default.
-static int g_wgrad_mid_variant = []{ const char* e = getenv("UNIT_WGRAD_MID_VARIANT"); return e ? atoi(e) : 0; }();
-extern "C" int unit_wgrad_mid_variant(int v) { int old = g_wgrad_mid_variant; g_wgrad_mid_variant = v; return old; }
-
+// 128x128 tile: the LDS-DMA ring kernel (conv_wgrad128r.hip) where it applies (bf16, C % 128 == 0, K % 128 == 0), variant 4 = the
+// register-staged kernel below everywhere. Isolated the two are equal on the backbone shapes (tools/wgrad128_bench.py: 18.2 vs 18.5 us,
+// 31.9 vs 30.4 us; RPN 3x3 306 vs 284 us -- at M = 9 576 these launches are bound by their fp32 slab store and input streaming, not by
+// the loop's load latency); inside the step the ring form is 0.05-0.1 ms ahead on the same box (18.36 vs 18.44-18.48 ms).
 static int choose_splits(int M, int tiles, int ms) {
   // 2 workgroups of this kernel are co-resident per CU (72 KB LDS each): 512 slots per "round" on 256 CUs. Pick the
   // split count whose grid fills whole rounds best (tile quantisation), preferring fewer splits (less slab traffic).
@@ -249,7 +245,8 @@ extern "C" size_t unit_conv2d_wgrad_workspace_bytes(int in_dtype, int N, int OH,
 // x [N,H,W,C], dy [M][ldy] (pixels of the conv's OUTPUT grid, row-major), dw fp32 [K][R][S][C].
 extern "C" int unit_conv2d_wgrad(const void* x, const void* dy, float* dw, const float* scale_k, int in_dtype, int N,
                                  int H, int W, int C, int K, int R, int S, int stride, int pad, int OH, int OW, int ldy,
-                                 int accumulate, void* workspace, size_t workspace_bytes, void* stream) {
+                                 int accumulate, int variant, void* workspace, size_t workspace_bytes, void* stream) {
+  UNIT_CHECK_ARG(variant >= 0 && variant <= 4, "wgrad: variant 0..4");
   int epc = in_dtype == UNIT_BF16 ? 8 : 4;
   UNIT_CHECK_ARG(C % epc == 0 && K % epc == 0 && ldy % epc == 0, "wgrad: C, K, ldy must be multiples of 8 (bf16) / 4 (fp32)");
   UNIT_CHECK_ARG(((uintptr_t)x % 16 == 0) && ((uintptr_t)dy % 16 == 0) && ((uintptr_t)dw % 16 == 0), "wgrad: 16B alignment");
@@ -269,7 +266,8 @@ extern "C" int unit_conv2d_wgrad(const void* x, const void* dy, float* dw, const
   a.magic_ow = OW > 1 ? (unsigned)((0x100000000ull + OW - 1) / (unsigned long long)OW) : 0xFFFFFFFFu;
   hipStream_t st = (hipStream_t)stream;
   if (unit_wgrad_use_big(in_dtype, a.M, K, C, R * S)) {
-    int sp = unit_conv2d_wgrad_big_launch(x, dy, (float*)workspace, N, H, W, C, K, R, S, stride, pad, OH, OW, ldy, workspace_bytes, stream);
+    int sp = unit_conv2d_wgrad_big_launch(x, dy, (float*)workspace, N, H, W, C, K, R, S, stride, pad, OH, OW, ldy, variant <= 3 ? variant : 0,
+                                          workspace_bytes, stream);
     if (sp < 0) return sp;
     if (dw == nullptr) return UNIT_OK;
     long KKb = (long)K * a.Kgemm;
@@ -286,7 +284,7 @@ extern "C" int unit_conv2d_wgrad(const void* x, const void* dy, float* dw, const
   if (workspace_bytes < need) { unit_set_error("wgrad: workspace too small"); return UNIT_ERR_WORKSPACE; }
   int grid = a.tiles_k * a.tiles_n * a.splits;
   // bf16 layers whose tiles are full (every trainable backbone / RPN conv): LDS-DMA ring kernel (conv_wgrad128r.hip), same slabs
-  if (in_dtype == UNIT_BF16 && C % 128 == 0 && K % 128 == 0 && g_wgrad_mid_variant == 0) {
+  if (in_dtype == UNIT_BF16 && C % 128 == 0 && K % 128 == 0 && variant != 4) {
     Wgrad256Args b;
     b.x = a.x; b.dy = a.dy; b.partial = a.partial; b.N = a.N; b.H = a.H; b.W = a.W; b.C = a.C; b.K = a.K; b.R = a.R; b.S = a.S;
     b.stride = a.stride; b.pad = a.pad; b.OH = a.OH; b.OW = a.OW; b.ldy = a.ldy; b.Kgemm = a.Kgemm; b.M = a.M;

@@ -151,8 +151,6 @@ __global__ void __launch_bounds__(512, 2) conv_wgrad256_kernel(Wgrad256Args p) {
 // it had just issued, so no schedule could prefetch, the loop looked "bound by miss latency" (147 us -> 81 us with the DMA
 // removed) and the interleaved schedules measured SLOWER than the two-stage loop. With the wait gone (tools/wgrad_bench.py):
 // 512->2048: two-stage 139 -> 121 us, ring 115, interleaved 113; 2048->512: 139 -> 126 / 112 / 103 us.
-static int g_wgrad_big_variant = 3;
-extern "C" int unit_wgrad_big_variant(int v) { int old = g_wgrad_big_variant; g_wgrad_big_variant = v; return old; }
 
 // shared with conv_wgrad.hip: which kernel handles a shape, and with how many split-M slabs
 extern "C" int unit_wgrad_use_big(int in_dtype, long M, int K, int C, int RS) {
@@ -190,7 +188,7 @@ extern "C" int unit_wgrad_big_splits_base(long M, int tiles) {
 }
 
 extern "C" int unit_conv2d_wgrad_big_launch(const void* x, const void* dy, float* partial, int N, int H, int W, int C, int K, int R, int S,
-                                            int stride, int pad, int OH, int OW, int ldy, size_t workspace_bytes, void* stream) {
+                                            int stride, int pad, int OH, int OW, int ldy, int variant, size_t workspace_bytes, void* stream) {
   Wgrad256Args a;
   a.x = x; a.dy = dy; a.partial = partial;
   a.N = N; a.H = H; a.W = W; a.C = C; a.K = K; a.R = R; a.S = S; a.stride = stride; a.pad = pad; a.OH = OH; a.OW = OW;
@@ -209,14 +207,14 @@ extern "C" int unit_conv2d_wgrad_big_launch(const void* x, const void* dy, float
   a.m_per_split = cdiv(mps, 64) * 64;
   size_t need = (size_t)a.splits * K * a.Kgemm * sizeof(float);
   if (workspace_bytes < need) { unit_set_error("wgrad_big: workspace too small"); return UNIT_ERR_WORKSPACE; }
-  int variant = g_wgrad_big_variant;
+  // variant (include/unit_hip.h): 0 = policy, 1 = two-stage, 2 = ring, 3 = phase-interleaved over all pixels
   a.valid_only = 0;
-  if (variant == 3) {
-    variant = ((R == 1 && S == 1 && stride == 1 && pad == 0) || OH * OW <= 1024) ? 0 : 2;
-    // 3x3 s1 p1 "same" conv on a small map: contract only over the pixels whose tap lies inside the map (Wgrad256Args::valid_only)
-    if (variant == 0 && R == 3 && S == 3 && stride == 1 && pad == 1 && OH == H && OW == W && OH * OW <= 512) a.valid_only = 1;
-  }
   if (variant == 0) {
+    variant = ((R == 1 && S == 1 && stride == 1 && pad == 0) || OH * OW <= 1024) ? 3 : 2;
+    // 3x3 s1 p1 "same" conv on a small map: contract only over the pixels whose tap lies inside the map (Wgrad256Args::valid_only)
+    if (variant == 3 && R == 3 && S == 3 && stride == 1 && pad == 1 && OH == H && OW == W && OH * OW <= 512) a.valid_only = 1;
+  }
+  if (variant == 3) {
     int rc = unit_wgrad256_p8_launch(a, (hipStream_t)stream);
     return rc == UNIT_OK ? a.splits : rc;
   }

@@ -370,17 +370,7 @@ def avgpool_bwd_bits(dfeat, bits, ph, pw):
     return g
 
 
-def wgrad_big_variant(v):
-    """schedule of the 256x256 weight-gradient tile: 3 = auto (default), 0 = phase-interleaved, 1 = two-stage, 2 = ring; returns the previous one"""
-    return lib().unit_wgrad_big_variant(int(v))
-
-
-def wgrad_mid_variant(v):
-    """128x128 weight-gradient tile: 0 = LDS-DMA ring kernel where it applies (default), 1 = register-staged kernel; returns the previous one"""
-    return lib().unit_wgrad_mid_variant(int(v))
-
-
-def conv2d_wgrad(x, dy, k, r, s, stride=1, pad=0, scale=None, out=None, accumulate=False, ldy=None):
+def conv2d_wgrad(x, dy, k, r, s, stride=1, pad=0, scale=None, out=None, accumulate=False, ldy=None, variant=0):
     """x [N,H,W,C], dy [N,OH,OW,ldy] -> dw fp32 [k,r,s,C] (scale[k] folded)."""
     n, h, wd, c = x.shape
     oh, ow = conv_out_size(h, wd, r, s, stride, pad)
@@ -394,7 +384,7 @@ def conv2d_wgrad(x, dy, k, r, s, stride=1, pad=0, scale=None, out=None, accumula
         e0 = torch.cuda.Event(enable_timing=True)
         e0.record()
     check(lib().unit_conv2d_wgrad(_p(x), _p(dy), _p(out), _p(scale), dt(x.dtype), n, h, wd, c, k, r, s, stride, pad, oh, ow,
-                                  ldy, int(accumulate), _p(ws), ws.numel(), _s()), "unit_conv2d_wgrad")
+                                  ldy, int(accumulate), int(variant), _p(ws), ws.numel(), _s()), "unit_conv2d_wgrad")
     if prof is not None:
         e1 = torch.cuda.Event(enable_timing=True)
         e1.record()
@@ -403,7 +393,7 @@ def conv2d_wgrad(x, dy, k, r, s, stride=1, pad=0, scale=None, out=None, accumula
     return out
 
 
-def conv2d_wgrad_partial(x, dy, k, r, s, stride, pad, slab=None):
+def conv2d_wgrad_partial(x, dy, k, r, s, stride, pad, slab=None, variant=0):
     """split-M partial slabs only (no reduction): returns (slab uint8 tensor, n_splits); slab i = floats [i*k*r*s*C, ...)."""
     n, h, wd, c = x.shape
     oh, ow = conv_out_size(h, wd, r, s, stride, pad)
@@ -419,7 +409,7 @@ def conv2d_wgrad_partial(x, dy, k, r, s, stride, pad, slab=None):
         e0 = torch.cuda.Event(enable_timing=True)
         e0.record()
     check(lib().unit_conv2d_wgrad(_p(x), _p(dy), None, None, dt(x.dtype), n, h, wd, c, k, r, s, stride, pad, oh, ow, dy.shape[-1], 0,
-                                  _p(slab), slab.numel(), _s()), "unit_conv2d_wgrad(partial)")
+                                  int(variant), _p(slab), slab.numel(), _s()), "unit_conv2d_wgrad(partial)")
     if prof is not None:
         e1 = torch.cuda.Event(enable_timing=True)
         e1.record()
