@@ -14,13 +14,20 @@
 // Position-class tiles (conv_igemm256p8.hip, Conv256Args::pm): the rows of a 3x3 s1 p1 "same" conv over small maps are regrouped by
 // the CLASS of their output position -- rectangles of positions that see the same set of in-map filter taps (interior, four edges, four
 // corners) -- image-major inside a class: class row i = image i / np, position (oh0 + (i % np) / cw, ow0 + (i % np) % cw).
-struct PmClass { int tile0, np, oh0, nh, ow0, cw; };      // tiles [tile0, next class's tile0) ; np = nh * cw positions
+// x / d for 0 <= x with x * d < 2^32, magic = ceil(2^32 / d) (d >= 2; d == 1: magic 0 -> plain path): exact -- the quotient estimate
+// exceeds x / d by less than 1 / d. The conv kernels' tile set-up is a chain of integer divisions by run-time constants (~25 instructions
+// each without this): in-kernel stamps put the set-up at 2-3 k cycles of a 42 k-cycle 512 -> 2048 tile (profiles/r03_exp_p8_tile_stamps.txt).
+__host__ __device__ __forceinline__ unsigned div_magic(unsigned d) { return d > 1 ? (unsigned)((0x100000000ull + d - 1) / d) : 0u; }
+__device__ __forceinline__ unsigned fast_div(unsigned x, unsigned d, unsigned magic) { return magic ? __umulhi(x, magic) : (d > 1 ? x / d : x); }
+
+struct PmClass { int tile0, np, oh0, nh, ow0, cw; unsigned magic_np, magic_cw; };      // tiles [tile0, next class's tile0) ; np = nh * cw positions
 struct PmRows {                                           // rows of one tile: class row i0 + (row of the tile)
   int i0, np, oh0, ow0, cw, OW, OHW, N;
+  unsigned magic_np, magic_cw;
   __device__ __forceinline__ bool map(int row, int& img, int& oh, int& ow) const {
     int i = i0 + row;
-    img = i / np;
-    int q = i - img * np, dh = q / cw;
+    img = (int)fast_div((unsigned)i, (unsigned)np, magic_np);
+    int q = i - img * np, dh = (int)fast_div((unsigned)q, (unsigned)cw, magic_cw);
     oh = oh0 + dh; ow = ow0 + (q - dh * cw);
     return img < N;
   }
@@ -65,8 +72,14 @@ struct EpiExtra {
 // EX: `pool` = this wave's 8 KB LDS area [4 segments][8 row classes][64 channels] fp32 (FA == 4 only); plain output layout only.
 // PM: position-class tiles: m_w = the wave's first row INSIDE its tile, `rows` maps a tile row to (image, position); the stored row is
 // image * OH*OW + position.
+#ifdef UNIT_EPI_STAMP      // diagnostic build only (tools/epi_stamp.sh): s_memtime stamps of one wave around the epilogue's steps
+#define EPI_STAMP(i) do { if (stamp) stamp[(i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define EPI_STAMP(i) do { } while (0)
+#endif
 template <int FA, int FB, bool EX, int RB, bool PM = false, typename Put, typename Args>
-__device__ __forceinline__ void epilogue_rows_bf16_blocks(Put put_block, char* scr, float* pool, int m_w, int n_w, const Args& p, int lane, const PmRows* rows = nullptr) {
+__device__ __forceinline__ void epilogue_rows_bf16_blocks(Put put_block, char* scr, float* pool, int m_w, int n_w, const Args& p, int lane, const PmRows* rows = nullptr,
+                                                          unsigned long long* stamp = nullptr) {
   typedef EpiCfg<FA, RB> E;
   constexpr int NBLK = FB * 16 / RB;
   bf16_t* __restrict__ Y = (bf16_t*)p.y;
@@ -135,6 +148,7 @@ __device__ __forceinline__ void epilogue_rows_bf16_blocks(Put put_block, char* s
 
   Pre cur;
   prefetch(0, cur);
+  EPI_STAMP(0);
 #pragma unroll
   for (int b = 0; b < NBLK; ++b) {
     Pre nxt;
@@ -193,6 +207,7 @@ __device__ __forceinline__ void epilogue_rows_bf16_blocks(Put put_block, char* s
       }
     }
     if (b + 1 < NBLK) cur = nxt;
+    EPI_STAMP(1 + b);
   }
   if constexpr (EX) {
     if (Rb && n_ok && m_w < p.M) reinterpret_cast<u32x4*>(Rb)[bword] = rw;      // (a wave tile past the last row owns no word)
@@ -217,7 +232,7 @@ __device__ __forceinline__ void epilogue_rows_bf16_blocks(Put put_block, char* s
 // 16x16 MFMA accumulators: acc[a][b] = 16x16 tile (channels a*16.., pixel rows b*16..); lane holds 4 consecutive channels of row lane & 15
 template <int FA, int FB, bool EX, bool PM = false, typename Args>
 __device__ __forceinline__ void epilogue_rows_bf16_impl(const f32x4 (&acc)[FA][FB], char* scr, float* pool, int m_w, int n_w, const Args& p, int lane,
-                                                        const PmRows* rows = nullptr) {
+                                                        const PmRows* rows = nullptr, unsigned long long* stamp = nullptr) {
   typedef EpiCfg<FA, 16> E;
   const int frow = lane & 15, fq = lane >> 4;
   auto put = [&](int b, char* sc) {
@@ -225,7 +240,7 @@ __device__ __forceinline__ void epilogue_rows_bf16_impl(const f32x4 (&acc)[FA][F
     for (int a = 0; a < FA; ++a)
       *reinterpret_cast<f32x4*>(sc + frow * E::PITCH + (a * 16 + fq * 4) * 4) = acc[a][b];
   };
-  epilogue_rows_bf16_blocks<FA, FB, EX, 16, PM>(put, scr, pool, m_w, n_w, p, lane, rows);
+  epilogue_rows_bf16_blocks<FA, FB, EX, 16, PM>(put, scr, pool, m_w, n_w, p, lane, rows, stamp);
 }
 
 template <int FA, int FB, typename Args>

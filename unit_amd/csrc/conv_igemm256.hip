@@ -580,6 +580,13 @@ static int launch256(Conv256Args& a, hipStream_t st) {
   return UNIT_OK;
 }
 
+static void set_div_magics(Conv256Args& a) {
+  unsigned long long mx = (unsigned long long)(a.M + 512) * (unsigned long long)(a.OW > a.OH ? a.OW : a.OH);
+  bool ok = mx < 0xFFFFFFFFull;
+  a.magic_ow = ok ? div_magic((unsigned)a.OW) : 0u;
+  a.magic_oh = ok ? div_magic((unsigned)a.OH) : 0u;
+}
+
 // Position classes of a 3x3 s1 p1 "same" conv (Conv256Args::pm_cls): the map rows split into runs with the same in-map tap rows
 // (first row / middle rows / last row; fewer for maps of 1 or 2 rows), the columns likewise; a class = a row run x a column run.
 // Sorted by taps, heaviest first (the kernel starts the heavy tiles first). Leaves pm_ncls = 0 when the row-major tiles need fewer
@@ -604,7 +611,9 @@ static void build_position_classes(Conv256Args& a) {
   int n = 0;
   for (int i = 0; i < nr; ++i)
     for (int j = 0; j < nc; ++j) {
-      Cls k; k.c = PmClass{0, rr[i].n * cc[j].n, rr[i].lo, rr[i].n, cc[j].lo, cc[j].n}; k.taps = rr[i].taps * cc[j].taps;
+      Cls k; k.c = PmClass{0, rr[i].n * cc[j].n, rr[i].lo, rr[i].n, cc[j].lo, cc[j].n, 0u, 0u}; k.taps = rr[i].taps * cc[j].taps;
+      // (class row index i < N * np + 256; i * np < 2^32 is what fast_div needs)
+      if (((unsigned long long)a.N * k.c.np + 256ull) * (unsigned long long)k.c.np < 0xFFFFFFFFull) { k.c.magic_np = div_magic(k.c.np); k.c.magic_cw = div_magic(k.c.cw); }
       k.tiles = cdiv((long)a.N * k.c.np, 256);
       cls[n++] = k;
     }
@@ -639,6 +648,7 @@ extern "C" int unit_conv2d_fwd_big(const void* x, const void* w, void* y, const 
   a.x_bytes = (unsigned)xb; a.w_bytes = (unsigned)wb;
   a.ex = EpiExtra{nullptr, nullptr, nullptr, 0}; a.ex_on = 0;
   a.x2 = nullptr; a.x2_bytes = 0; a.cb_split = 0; a.ratio2 = 1; a.pm_ncls = 0;
+  set_div_magics(a);
   if (a.M == 0 || K == 0) return UNIT_OK;
   hipStream_t st = (hipStream_t)stream;
   // variant 0 / 4: one barrier per k-tile, 256-row tiles; 3: 224-row tiles; 5: 224 or 256 rows, whichever needs fewer
@@ -739,6 +749,7 @@ extern "C" int unit_conv2d_fwd_big_ex(const void* x, const void* w, void* y, con
   UNIT_CHECK_ARG(xb < 0xFFFFFFF0ull && wb < 0xFFFFFFF0ull && x2b < 0xFFFFFFF0ull, "conv_big_ex: operand larger than 4 GiB");
   a.x_bytes = (unsigned)xb; a.w_bytes = (unsigned)wb;
   a.x2 = x2; a.x2_bytes = (unsigned)x2b; a.cb_split = C / 64; a.ratio2 = x2 ? C2 / C : 1; a.pm_ncls = 0;
+  set_div_magics(a);
   a.ex = EpiExtra{relu_bits, mask_bits, pool_partial, pool_rows}; a.ex_on = 1;
   if (a.M == 0 || K == 0) return UNIT_OK;
   if (variant == 11 || (variant == 0 && unit_conv256_use_m32())) return unit_conv256_p8m_launch(a, UNIT_BF16, (hipStream_t)stream);

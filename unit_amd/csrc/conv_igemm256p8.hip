@@ -35,6 +35,19 @@
 #define UNIT_DBGP8 0
 #endif
 
+#ifdef UNIT_EPI_STAMP
+// diagnostic build (tools/epi_stamp.sh): wave 0 of every 97th workgroup stamps s_memtime at kernel entry [0], first barrier [1], end of the
+// main loop [2], after the __syncthreads in front of the epilogue [3], before the first block [4], after block b [5 + b], end [13];
+// [14] = blockIdx.x, [15] = s_memrealtime at entry (100 MHz)
+__device__ unsigned long long g_stamp[32 * 16];
+extern "C" int unit_debug_read_stamps(unsigned long long* host_out) {
+  return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_stamp), sizeof(unsigned long long) * 32 * 16, 0, hipMemcpyDeviceToHost);
+}
+#define P8_STAMP(i) do { if (stamp) stamp[(i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define P8_STAMP(i) do { } while (0)
+#endif
+
 #define MFMA_BF16(A, B, C) __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, A), __builtin_bit_cast(bf16x8, B), C, 0, 0, 0)
 
 // B1 = 16-row pixel blocks of the SECOND quadrant row of a wave (the first always has 4): 4 -> 256-row tiles, 3 -> 224-row
@@ -54,7 +67,7 @@ __global__ void __launch_bounds__(512, 2) conv_igemm256_p8_kernel(Conv256Args p)
   int bid = blockIdx.x;
   const bool pm = RM && B1 == 4 && p.pm_ncls > 0;
   int tile_n, tile_m;
-  PmRows pmr = {0, 1, 0, 0, 1, p.OW, p.OH * p.OW, p.N};
+  PmRows pmr = {0, 1, 0, 0, 1, p.OW, p.OH * p.OW, p.N, 0u, 0u};
   int pm_nh = 1;
   if (pm) {
     // position-class tiles (Conv256Args::pm_ncls): workgroup b runs on XCD b % 8; XCD x takes the row tiles x, x + 8, ... in that
@@ -67,6 +80,7 @@ __global__ void __launch_bounds__(512, 2) conv_igemm256_p8_kernel(Conv256Args p)
     while (c + 1 < p.pm_ncls && tile_m >= p.pm_cls[c + 1].tile0) ++c;
     const PmClass& k = p.pm_cls[c];
     pmr.i0 = (tile_m - k.tile0) * BM; pmr.np = k.np; pmr.oh0 = k.oh0; pmr.ow0 = k.ow0; pmr.cw = k.cw;
+    pmr.magic_np = k.magic_np; pmr.magic_cw = k.magic_cw;
     pm_nh = k.nh;
   } else {
     int q = nwg / 8, r = nwg % 8, xcd = bid % 8, loc = bid / 8;
@@ -89,8 +103,17 @@ __global__ void __launch_bounds__(512, 2) conv_igemm256_p8_kernel(Conv256Args p)
   int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   int wm = wid >> 2, wn = wid & 3;
   const int grp = wm;                          // waves 4-7 run half a phase behind waves 0-3
+  unsigned long long* stamp = nullptr;
+#ifdef UNIT_EPI_STAMP
+  if (tid == 0 && blockIdx.x % 97 == 0 && blockIdx.x / 97 < 32) {
+    stamp = g_stamp + (blockIdx.x / 97) * 16;
+    stamp[14] = blockIdx.x; stamp[15] = __builtin_amdgcn_s_memrealtime();
+  }
+#endif
+  P8_STAMP(0);
   int lrow = lane >> 3, lc = lane & 7;
 
+  const bool pointwise = p.R == 1 && p.S == 1 && p.stride == 1 && p.pad == 0;      // (the bounds test of the single tap then only sees x_ih0 = 0 or the "past M" marker)
   // staging descriptors: half q (0,1), piece j (0,1) of this wave = half-tile rows R0 = (j*8 + wid)*8 .. +8 ; lane -> row
   // R0 + lrow, LDS chunk lc (lane-linear), SOURCE chunk lc ^ ((row>>1)&7)
   int x_ih0[4], x_iw0[4]; unsigned x_off0[4], w_off[4];
@@ -104,13 +127,21 @@ __global__ void __launch_bounds__(512, 2) conv_igemm256_p8_kernel(Conv256Args p)
       int m = m0 + (R >> 6) * (FBT * 16) + q * 64 + (R & 63);
       bool ok = m < p.M && (q == 0 || (R & 63) < B1 * 16);
       int mm = ok ? m : 0;
-      int ow = mm % p.OW; int t = mm / p.OW; int oh = t % p.OH; int n = t / p.OH;
+      int ow, oh, n;
       if (pm) {                                  // row of the tile -> (image, position) of its class
         ok = pmr.map(m - m0, n, oh, ow);
         if (!ok) n = 0;
+      } else if (pointwise) {                    // 1x1 s1 p0: input pixel = output pixel m; written as "image 0, row 0, column m" of a one-row map
+        n = 0; oh = 0; ow = 0;
+      } else {
+        unsigned t = fast_div((unsigned)mm, (unsigned)p.OW, p.magic_ow);
+        ow = mm - (int)t * p.OW;
+        n = (int)fast_div(t, (unsigned)p.OH, p.magic_oh);
+        oh = (int)t - n * p.OH;
       }
       int ih0 = oh * p.stride - p.pad, iw0 = ow * p.stride - p.pad;
-      x_off0[q * 2 + j] = ((unsigned)n * (unsigned)(p.H * p.W * Cx) + (unsigned)((ih0 * p.W + iw0) * Cx + sw * 8)) * 2u;  // tap (0,0), wraps for negative ih0/iw0
+      x_off0[q * 2 + j] = pointwise ? ((unsigned)mm * (unsigned)Cx + (unsigned)(sw * 8)) * 2u
+                                    : ((unsigned)n * (unsigned)(p.H * p.W * Cx) + (unsigned)((ih0 * p.W + iw0) * Cx + sw * 8)) * 2u;  // tap (0,0), wraps for negative ih0/iw0
       x_ih0[q * 2 + j] = ok ? ih0 : -(1 << 20);                    // rows past M fail the bounds test of every tap
       x_iw0[q * 2 + j] = iw0;
       int nn = n0 + (R >> 5) * 64 + q * 32 + (R & 31);
@@ -246,6 +277,7 @@ __global__ void __launch_bounds__(512, 2) conv_igemm256_p8_kernel(Conv256Args p)
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     P8_BAR();
+    P8_STAMP(1);
     read_w(smem + SW0, fw0);
     read_x(smem + SX0);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -347,7 +379,9 @@ __global__ void __launch_bounds__(512, 2) conv_igemm256_p8_kernel(Conv256Args p)
 
   if constexpr (sizeof(TO) == 2) {
     if ((p.ldy & 7) == 0) {          // row-major epilogue through a wave-private LDS scratch (conv_epilogue.h)
+      P8_STAMP(2);
       __syncthreads();               // every wave is done with the operand stages
+      P8_STAMP(3);
       if constexpr (RM) {
         if (p.ex_on) {               // fused average pool / ReLU bit mask / bit-mask input (unit_conv2d_fwd_big_ex)
           epilogue_rows_bf16_impl<4, FBT, true>(acc, smem + wid * EpiCfg<4>::BYTES, (float*)(smem + 36864 + wid * 8192), m0 + wm * (FBT * 16),
@@ -361,7 +395,8 @@ __global__ void __launch_bounds__(512, 2) conv_igemm256_p8_kernel(Conv256Args p)
           return;
         }
       }
-      epilogue_rows_bf16<4, FBT>(acc, smem + wid * EpiCfg<4>::BYTES, m0 + wm * (FBT * 16), n0 + wn * 64, p, lane);
+      epilogue_rows_bf16_impl<4, FBT, false>(acc, smem + wid * EpiCfg<4>::BYTES, nullptr, m0 + wm * (FBT * 16), n0 + wn * 64, p, lane, nullptr, stamp ? stamp + 4 : nullptr);
+      P8_STAMP(13);
       return;
     }
   }
