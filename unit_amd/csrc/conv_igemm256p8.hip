@@ -70,14 +70,20 @@ __global__ void __launch_bounds__(512, 2) conv_igemm256_p8_kernel(Conv256Args p)
   PmRows pmr = {0, 1, 0, 0, 1, p.OW, p.OH * p.OW, p.N, 0u, 0u};
   int pm_nh = 1;
   if (pm) {
-    // position-class tiles (Conv256Args::pm_ncls): workgroup b runs on XCD b % 8; XCD x takes the row tiles x, x + 8, ... in that
-    // order -- heaviest classes first on every XCD -- and all channel tiles of a row tile one after the other (they share its rows
-    // through that XCD's L2)
+    // position-class tiles (Conv256Args::pm_ncls): workgroup b runs on XCD b % 8. The tiles of a class are ordered by image, and XCD x
+    // takes the x-th eighth of EVERY class -- the interior, edge and corner tiles of the same images, whose filter taps read the same
+    // input pixels, go through one L2 -- heaviest classes first, and all channel tiles of a row tile one after the other.
     int xcd = bid % 8, loc = bid / 8;
-    tile_n = loc % p.tiles_n; tile_m = (loc / p.tiles_n) * 8 + xcd;
-    if (tile_m >= p.tiles_m) return;
-    int c = 0;
-    while (c + 1 < p.pm_ncls && tile_m >= p.pm_cls[c + 1].tile0) ++c;
+    tile_n = loc % p.tiles_n;
+    int idx = loc / p.tiles_n, c = 0;
+    tile_m = -1;
+    for (; c < p.pm_ncls; ++c) {
+      int t0 = p.pm_cls[c].tile0, tc = (c + 1 < p.pm_ncls ? p.pm_cls[c + 1].tile0 : p.tiles_m) - t0;
+      int lo = (xcd * tc + 7) / 8, hi = ((xcd + 1) * tc + 7) / 8;
+      if (idx < hi - lo) { tile_m = t0 + lo + idx; break; }
+      idx -= hi - lo;
+    }
+    if (tile_m < 0) return;
     const PmClass& k = p.pm_cls[c];
     pmr.i0 = (tile_m - k.tile0) * BM; pmr.np = k.np; pmr.oh0 = k.oh0; pmr.ow0 = k.ow0; pmr.cw = k.cw;
     pmr.magic_np = k.magic_np; pmr.magic_cw = k.magic_cw;
@@ -449,8 +455,17 @@ static int launch256_p8(Conv256Args& a, hipStream_t st) {
   int grid = a.tiles_m * a.tiles_n;
   if (a.pm_ncls > 0) {
     if (!RM || B1 != 4) { unit_set_error("conv_big: position-class tiles need the 256-row RM schedule"); return UNIT_ERR_UNSUPPORTED; }
-    // a.tiles_m was set with the class table; the grid is padded to whole groups of 8 row tiles (one per XCD)
-    grid = cdiv(a.tiles_m, 8) * 8 * a.tiles_n;
+    // a.tiles_m was set with the class table; every XCD gets an eighth of every class (rounded): the grid holds the longest such list
+    int most = 0;
+    for (int x = 0; x < 8; ++x) {
+      int cnt = 0;
+      for (int c = 0; c < a.pm_ncls; ++c) {
+        int tc = (c + 1 < a.pm_ncls ? a.pm_cls[c + 1].tile0 : a.tiles_m) - a.pm_cls[c].tile0;
+        cnt += ((x + 1) * tc + 7) / 8 - (x * tc + 7) / 8;
+      }
+      most = cnt > most ? cnt : most;
+    }
+    grid = most * 8 * a.tiles_n;
   }
   size_t lds = 8 * 128 * 128;
   static bool attr_set = false;
