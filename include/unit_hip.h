@@ -106,6 +106,10 @@ int unit_conv2d_wgrad(const void* x, const void* dy, float* dw, const float* sca
  * multi-tensor kernels below reduce all layers of a gradient bucket / refresh all prepared weight copies in ONE launch.
  * descs_dev: array of {const float* partial, *scale; void* wf, *wd; long offset; int splits,K,R,S,C,block0} (64 B each) */
 int unit_conv2d_wgrad_splits(int in_dtype, int N, int OH, int OW, int K, int R, int S, int C);
+/* stream fork / join without host-side event objects: everything enqueued on `waiter` after this call waits for everything enqueued on
+ * `signaller` before it (the reference reaches this through torch.cuda.Stream.wait_stream / Event; here the step forks ~100 weight-gradient
+ * launches per step to a side stream: engine/defaults.py:279-284's backward has no such structure, it is the explicit plan's own). */
+int unit_stream_wait_stream(void* waiter, void* signaller);
 size_t unit_tensor_desc_bytes(void);
 int unit_multi_wgrad_reduce(const void* descs_dev, int n, int total_blocks, float* grads_flat, void* stream);
 int unit_multi_weight_prep(const void* descs_dev, int n, int total_blocks, const float* params_flat, int dtype, void* stream);

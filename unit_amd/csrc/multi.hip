@@ -109,3 +109,30 @@ extern "C" int unit_multi_weight_prep(const void* descs_dev, int n, int total_bl
   UNIT_LAUNCH_CHECK();
   return UNIT_OK;
 }
+
+
+// ---------------------------------------------------------------------------------------------------------------------
+// unit_stream_wait_stream: make everything enqueued on `waiter` from now on wait for everything enqueued on `signaller` so far
+// (hipEventRecord + hipStreamWaitEvent on an event of a small ring). The step forks ~100 weight-gradient launches per step onto a
+// side stream; through torch.cuda.Event / Stream objects each fork cost the host ~25 us of Python (a quarter of the step's enqueue
+// time), this is one C call. Works inside a stream capture (the record / wait pair becomes a graph edge). One process per GPU,
+// called from one thread; an event is reused only 1024 forks later.
+static hipEvent_t g_fork_events[1024];
+static bool g_fork_events_ready = false;
+static unsigned g_fork_next = 0;
+
+extern "C" int unit_stream_wait_stream(void* waiter, void* signaller) {
+  if (waiter == signaller) return UNIT_OK;
+  if (!g_fork_events_ready) {
+    for (int i = 0; i < 1024; ++i) {
+      hipError_t e = hipEventCreateWithFlags(&g_fork_events[i], hipEventDisableTiming);
+      if (e != hipSuccess) { unit_set_error(hipGetErrorString(e)); return UNIT_ERR_LAUNCH; }
+    }
+    g_fork_events_ready = true;
+  }
+  hipEvent_t ev = g_fork_events[g_fork_next++ & 1023];
+  hipError_t e = hipEventRecord(ev, (hipStream_t)signaller);
+  if (e == hipSuccess) e = hipStreamWaitEvent((hipStream_t)waiter, ev, 0);
+  if (e != hipSuccess) { unit_set_error(hipGetErrorString(e)); return UNIT_ERR_LAUNCH; }
+  return UNIT_OK;
+}

@@ -127,13 +127,10 @@ class Conv2d(_EpochOnLoad):
                 return
             # weight gradients depend on nothing downstream: run them on a side HIP stream so that they fill the CUs the
             # dgrad chain leaves idle (tile-quantisation tails, the small res3/res4 grids); joined before the bucket's reduce
-            main = torch.cuda.current_stream()
-            ev = torch.cuda.Event()
-            ev.record(main)
-            side.wait_event(ev)
+            ops.stream_wait_stream(side)          # side waits for what the current stream has enqueued so far (one C call)
             x.record_stream(side)
             dy.record_stream(side)
-            with torch.cuda.stream(side):
+            with ops.on_stream(side):             # (no torch stream switch: ~100 of these per step)
                 launch()
             return
         g = self.weight.grad

@@ -35,9 +35,15 @@ def _p(t):
 _raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
 
 
+_STREAM_OVERRIDE = []          # stack of raw HIP stream handles: `on_stream` below
+
+
 def raw_stream(device_index=None):
-    """the current HIP stream's handle as an int. torch.cuda.current_stream() builds a Stream object through several Python
-    layers (~4 us, ~750 calls per step = a quarter of the step's host time); the raw getter is one C call"""
+    """the HIP stream the next launch goes to, as an int: the innermost `on_stream` handle, else torch's current stream.
+    torch.cuda.current_stream() builds a Stream object through several Python layers (~4 us, ~750 calls per step = a quarter of
+    the step's host time); the raw getter is one C call"""
+    if _STREAM_OVERRIDE:
+        return _STREAM_OVERRIDE[-1]
     if _raw_stream is None:
         return torch.cuda.current_stream().cuda_stream
     return _raw_stream(torch.cuda.current_device() if device_index is None else device_index)
@@ -45,6 +51,39 @@ def raw_stream(device_index=None):
 
 def _s():
     return ctypes.c_void_p(raw_stream())
+
+
+class on_stream:
+    """`with on_stream(side):` -- the C-ABI launches inside go to the torch.cuda.Stream `side` WITHOUT switching torch's current stream
+    (torch.cuda.stream() costs ~15 us of Python per enter / exit, and the step forks ~100 weight-gradient launches per step). Only for
+    blocks that launch through this module and allocate nothing whose lifetime depends on the stream; while bench.py's event profiler
+    is on, it degrades to torch.cuda.stream (the profiler records torch events on the current stream)."""
+
+    def __init__(self, stream):
+        self.stream = stream
+        self.ctx = None
+
+    def __enter__(self):
+        if PROFILER is not None or torch.cuda.is_current_stream_capturing():
+            self.ctx = torch.cuda.stream(self.stream)
+            self.ctx.__enter__()
+        else:
+            _STREAM_OVERRIDE.append(self.stream.cuda_stream)
+        return self
+
+    def __exit__(self, *exc):
+        if self.ctx is not None:
+            self.ctx.__exit__(*exc)
+        else:
+            _STREAM_OVERRIDE.pop()
+        return False
+
+
+def stream_wait_stream(waiter, signaller_raw=None):
+    """everything enqueued on torch.cuda.Stream `waiter` from now on waits for what is on the stream with raw handle `signaller_raw`
+    (default: the current launch stream) so far: one C call (unit_stream_wait_stream) instead of Event() + record + wait_event"""
+    sig = raw_stream() if signaller_raw is None else signaller_raw
+    check(lib().unit_stream_wait_stream(ctypes.c_void_p(waiter.cuda_stream), ctypes.c_void_p(sig)), "unit_stream_wait_stream")
 
 
 _WS = {}
@@ -218,6 +257,9 @@ def conv_out_size(h, w, r, s, stride, pad):
     return (h + 2 * pad - r) // stride + 1, (w + 2 * pad - s) // stride + 1
 
 
+_POLICY_CACHE = {}
+
+
 def conv2d(x, w, k, r, s, stride=1, pad=0, bias=None, residual=None, mask_ref=None, relu=False, out_dtype=None,
            out=None, ldy=None, scatter=None, tile_cfg=0):
     """x [N,H,W,C] NHWC ; w [k][r][s][C] (same dtype). Returns y [N,OH,OW,ldy] (or writes the strided scatter target).
@@ -239,9 +281,16 @@ def conv2d(x, w, k, r, s, stride=1, pad=0, bias=None, residual=None, mask_ref=No
     if prof is not None:
         e0 = torch.cuda.Event(enable_timing=True)
         e0.record()
-    big = tile_cfg in (5, 6, 11, 12, 13, 14, 15, 16, 17, 18, 21, 22) or (tile_cfg == 0 and BIG_TILE_POLICY(x.dtype, n * oh * ow, k, c, r * s * c))
+    if tile_cfg == 0:          # the two policy functions cost ~5 us per call (the loader / consumer tile search): cached per shape
+        pkey = (x.dtype, n * oh * ow, k, c, r * s * c, out_dtype, ldy % 8, BIG_TILE_POLICY, MID_TILE_POLICY, _NO_LC)
+        pol = _POLICY_CACHE.get(pkey)
+    else:
+        pkey = pol = None
+    big = tile_cfg in (5, 6, 11, 12, 13, 14, 15, 16, 17, 18, 21, 22) or (tile_cfg == 0 and (pol[0] if pol is not None else BIG_TILE_POLICY(x.dtype, n * oh * ow, k, c, r * s * c)))
     mid = -1
-    if tile_cfg >= 100:          # persistent loader / consumer workgroups: 100 + 10 * (BM / 16) + BN / 64 (csrc/conv_igemm_lc.hip)
+    if pol is not None:
+        mid = pol[1]
+    elif tile_cfg >= 100:          # persistent loader / consumer workgroups: 100 + 10 * (BM / 16) + BN / 64 (csrc/conv_igemm_lc.hip)
         mid = tile_cfg
     elif tile_cfg in (7, 8, 9, 10, 19, 20):
         mid = {19: 4, 20: 5}.get(tile_cfg, tile_cfg - 7)
@@ -253,6 +302,8 @@ def conv2d(x, w, k, r, s, stride=1, pad=0, bias=None, residual=None, mask_ref=No
                 mid = MID_TILE_POLICY(x.dtype, n * oh * ow, k, c, r * s * c)
             finally:
                 globals()["_NO_LC"] = was
+    if pkey is not None and pol is None:
+        _POLICY_CACHE[pkey] = (big, mid)
     if mid >= 0:
         check(lib().unit_conv2d_fwd_mid(_p(x), _p(w), _p(out), _p(bias), _p(residual), _p(mask_ref), dt(out_dtype),
                                         n, h, wd, c, k, r, s, stride, pad, oh, ow, ldy, oy_mul, ohf, owf, int(relu), mid, _s()),
