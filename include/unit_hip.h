@@ -86,8 +86,13 @@ int unit_conv2d_fwd_big_ex(const void* x, const void* w, void* y, const float* b
                            int pad, int ldy, int relu, const void* x2, int C2, int variant, void* stream);
 int unit_pool_finish(const float* partial, int R, int rows, int ldy, int K, void* out, int ldo, int out_dtype, void* stream);
 int unit_avgpool_bwd_bits(const void* dfeat, const unsigned char* bits, int R, int roi_offset, int rows, int C, void* g, void* stream);
-/* mid-size variant (4 waves, LDS-DMA, two workgroups per CU) for the backbone layers; bf16 inputs, C % 64 == 0;
- * tile: 0 = 128x128, 1 = 64 pixels x 128 channels, 2 = 128 x 64, 3 = 128x128 with in-workgroup split-K (few-tile layers) */
+/* mid-size variants for the backbone layers; bf16 inputs, C % 64 == 0.
+ * tile 0..5 (4 waves, LDS-DMA, two workgroups per CU, csrc/conv_igemm128.hip): 0 = 128x128, 1 = 64 pixels x 128 channels, 2 = 128 x 64,
+ * 3 = 128x128 with in-workgroup split-K (few-tile layers), 4 / 5 = 96 x 128 with three / two LDS stages;
+ * tile >= 100 (csrc/conv_igemm_lc.hip): ONE persistent workgroup per CU of four LDS-DMA loader waves and four MFMA consumer waves on a
+ * three-slot LDS ring, walking a contiguous run of output tiles: 100 + 10 * (BM / 16) + BN / 64 with BM 64..128 x BN 128 or BM 64..96 x
+ * BN 256 (+ 1000: eight loader waves; + 4000: four ring slots -- measured no faster); bf16 output with ldy % 8 == 0. Same results
+ * bit for bit as tiles 0..5. For the layers with a long contraction and few output tiles (res4 on four 600x1000 images). */
 int unit_conv2d_fwd_mid(const void* x, const void* w, void* y, const float* bias, const void* residual, const void* mask_ref,
                         int out_dtype, int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int OH, int OW, int ldy,
                         int oy_mul, int OHf, int OWf, int relu, int tile, void* stream);
