@@ -157,3 +157,20 @@ def test_presets_equal_the_reference_yaml_files_when_present():
         c = config.get_cfg()
         c.merge_from_file(os.path.join(root, y))
         assert diff(c, preset) == [], (y, diff(c, preset))
+
+
+def test_loader_consumer_tile_choice_is_host_arithmetic():
+    """ops.lc_tile_code (the tile of csrc/conv_igemm_lc.hip per layer) minimises (tiles per CU) x (BM + BN) + an epilogue term over the
+    eight instantiated tiles; the values the res4 shapes get are the ones measured fastest on the device (profiles/r03_exp_loader_consumer.txt)."""
+    from unit_amd import ops
+    m = 4 * 38 * 63
+    assert ops.lc_tile_code(m, 256, 1024) == 152          # 80 x 128: 240 tiles, one per CU
+    assert ops.lc_tile_code(m, 256, 9 * 256) == 152
+    assert ops.lc_tile_code(m, 1024, 512) == 154          # 80 x 256: 480 tiles, two per CU
+    for code in (ops.lc_tile_code(mm, k, kg) for mm in (100, 4788, 9576, 37500) for k in (64, 128, 256, 1024) for kg in (512, 2304)):
+        fb, fa = (code - 100) // 10, (code - 100) % 10
+        assert fa in (2, 4) and 4 <= fb <= (8 if fa == 2 else 6)
+    import torch
+    # short contractions and big maps stay on the 4-wave tiles
+    assert ops.MID_TILE_POLICY(torch.bfloat16, m, 1024, 256, 256) < 100
+    assert ops.MID_TILE_POLICY(torch.bfloat16, 4 * 150 * 250, 256, 64, 576) < 100

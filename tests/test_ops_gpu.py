@@ -1180,3 +1180,26 @@ def test_conv_ex_rejects_what_it_cannot_do(dev):
     with pytest.raises(UnitLibError):
         call(x2=x, c2=64, r=3, pad=1)                               # second input: 1x1 only
     torch.cuda.synchronize()
+
+
+def test_stream_wait_stream_orders_two_streams(dev):
+    """unit_stream_wait_stream(waiter, signaller): work enqueued on `waiter` afterwards sees everything enqueued on `signaller` before --
+    a long chain of dependent launches on one stream, its result consumed on another without any torch event; and the launch-stream
+    override (`ops.on_stream`) sends C-ABI launches to a side stream without switching torch's current stream."""
+    o = ops()
+    a, b = torch.cuda.Stream(), torch.cuda.Stream()
+    x = torch.zeros(1 << 24, device=dev)
+    for rep in range(5):
+        x.zero_()
+        torch.cuda.synchronize()
+        with torch.cuda.stream(a):
+            for _ in range(40):
+                x.add_(1.0)                                  # ~40 launches of 64 MB each: still running when b is told to wait
+        o.stream_wait_stream(b, a.cuda_stream)
+        cur = torch.cuda.current_stream()
+        with o.on_stream(b):
+            assert torch.cuda.current_stream() == cur           # torch's stream did not change
+            y = o.cast(x, torch.bfloat16)                       # a C-ABI launch: goes to b, behind the wait
+        b.synchronize()
+        assert float(y.float().min()) == 40.0 and float(y.float().max()) == 40.0, rep
+    torch.cuda.synchronize()
