@@ -111,6 +111,23 @@ int unit_conv2d_wgrad(const void* x, const void* dy, float* dw, const float* sca
  * multi-tensor kernels below reduce all layers of a gradient bucket / refresh all prepared weight copies in ONE launch.
  * descs_dev: array of {const float* partial, *scale; void* wf, *wd; long offset; int splits,K,R,S,C,block0} (64 B each) */
 int unit_conv2d_wgrad_splits(int in_dtype, int N, int OH, int OW, int K, int R, int S, int C);
+/* The weight gradients of SEVERAL layers in one grid (csrc/conv_wgrad128r.hip): the layers of a gradient bucket -- 18 convs for six
+ * res4 blocks, 9 576 pixels and 16-36 tiles each -- launched one by one need ~17 split-M slabs apiece to fill 256 CUs (9-step loops,
+ * 17 slabs to reduce); launched together they have 408 tiles: one slab per layer and 150-step loops. The reference reaches these
+ * through autograd's per-layer cudnn wgrad calls (engine/defaults.py:279-284 `losses.backward()`); grouping them is this plan's own.
+ * Eligible (unit_conv2d_wgrad_group_supported): bf16, C % 128 == 0, K % 128 == 0, not a layer of the 256x256 tile.
+ * unit_conv2d_wgrad_group_plan fills pr[i].splits for the launch (splits_hint > 0: that many for the layer with the most pixels, the
+ * others in proportion); slab s of layer i is written at pr[i].partial + s*K*R*S*C floats, the layout unit_conv2d_wgrad(dw = NULL)
+ * leaves (unit_multi_wgrad_reduce folds them). Per layer the result equals unit_conv2d_wgrad's with the same split count bit for bit. */
+typedef struct UnitWgradProblem {
+  const void* x; const void* dy; void* partial;
+  int N, H, W, C, K, R, S, stride, pad, OH, OW, ldy;
+  int splits, reserved;
+} UnitWgradProblem;
+size_t unit_wgrad_problem_bytes(void);
+int unit_conv2d_wgrad_group_supported(int in_dtype, int N, int OH, int OW, int K, int R, int S, int C);
+int unit_conv2d_wgrad_group_plan(UnitWgradProblem* pr, int n, int splits_hint);
+int unit_conv2d_wgrad_group(const UnitWgradProblem* pr, int n, int in_dtype, void* stream);
 /* stream fork / join without host-side event objects: everything enqueued on `waiter` after this call waits for everything enqueued on
  * `signaller` before it (the reference reaches this through torch.cuda.Stream.wait_stream / Event; here the step forks ~100 weight-gradient
  * launches per step to a side stream: engine/defaults.py:279-284's backward has no such structure, it is the explicit plan's own). */

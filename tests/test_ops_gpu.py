@@ -333,6 +333,86 @@ def test_wgrad_ring128_kernel(dev, case):
     assert (got - ref).abs().max() <= 2e-3 * ref.abs().max()
 
 
+GROUP_CASES = [(4, 38, 63, 256, 256, 3, 1, 1), (4, 38, 63, 1024, 256, 1, 1, 0), (2, 75, 125, 128, 128, 3, 1, 1), (3, 40, 50, 256, 512, 1, 2, 0),
+               (5, 7, 9, 128, 256, 3, 1, 1), (1, 33, 40, 384, 128, 1, 1, 0), (4, 38, 63, 256, 1024, 1, 1, 0)]
+
+
+def _group_inputs(o, dev, cases, seed):
+    gen = g(seed)
+    items = []
+    for n, h, w, c, k, r, stride, pad in cases:
+        oh, ow = o.conv_out_size(h, w, r, r, stride, pad)
+        x = torch.randn(n, h, w, c, generator=gen).bfloat16().to(dev)
+        dy = (torch.randn(n, oh, ow, k, generator=gen) * 0.25).bfloat16().to(dev)
+        items.append((x, dy, k, r, r, stride, pad))
+    return items
+
+
+def _fold(slab, splits, k, r, c):
+    return slab.view(torch.float32)[:splits * k * r * r * c].view(splits, k, r, r, c)
+
+
+@pytest.mark.parametrize("hint", [0, 1, 3, 7])
+def test_wgrad_group_launch(dev, hint):
+    """the weight gradients of several layers from ONE grid (conv_wgrad128_group_kernel: units of (layer, split) dealt to the XCDs):
+    every layer's slabs sum to what the per-layer launch gives (fp32 association differs with the split count: 2e-5 of the
+    gradient's scale), whatever split count the plan or the caller picks; mixed 1x1 / 3x3 / stride-2 / narrow-map layers."""
+    o = ops()
+    items = _group_inputs(o, dev, GROUP_CASES, 41)
+    for x, dy, k, r, s, stride, pad in items:
+        assert o.wgrad_group_supported(x, dy, k, r, s, stride, pad)
+    res = o.conv2d_wgrad_group(items, splits_hint=hint)
+    torch.cuda.synchronize()
+    assert len(res) == len(items)
+    if hint == 1:
+        assert all(sp == 1 for _, sp in res)
+    for (x, dy, k, r, s, stride, pad), (slab, sp) in zip(items, res):
+        got = _fold(slab, sp, k, r, x.shape[-1]).sum(0).cpu()
+        ref = o.conv2d_wgrad(x, dy, k, r, s, stride, pad).cpu()
+        scale = ref.abs().max().item()
+        assert (got - ref).abs().max().item() <= 2e-5 * scale, ((got - ref).abs().max().item(), scale, sp)
+
+
+def test_wgrad_group_single_layer_is_the_per_layer_kernel_bit_for_bit(dev):
+    """a group of ONE layer with the per-layer split count writes the slabs unit_conv2d_wgrad(dw = NULL) writes, bit for bit (same
+    tile function, same pixel ranges)"""
+    o = ops()
+    for case in GROUP_CASES[:4]:
+        (x, dy, k, r, s, stride, pad), = _group_inputs(o, dev, [case], 43)
+        slab0, sp0 = o.conv2d_wgrad_partial(x, dy, k, r, s, stride, pad)
+        (slab1, sp1), = o.conv2d_wgrad_group([(x, dy, k, r, s, stride, pad)], splits_hint=sp0)
+        assert sp1 == sp0
+        a, b = _fold(slab0, sp0, k, r, x.shape[-1]), _fold(slab1, sp1, k, r, x.shape[-1])
+        assert torch.equal(a, b)
+
+
+def test_wgrad_group_more_layers_than_one_launch_holds(dev):
+    """30 layers / > 128 units: the library splits the list into several grids; results per layer unchanged; slabs are reused"""
+    o = ops()
+    cases = [(2, 20, 24 + (i % 5), 128 * (1 + i % 2), 128 * (1 + (i // 2) % 2), 1 + 2 * (i % 2), 1, i % 2) for i in range(30)]
+    items = _group_inputs(o, dev, cases, 47)
+    res = o.conv2d_wgrad_group(items, splits_hint=6)
+    res2 = o.conv2d_wgrad_group(items, [sl for sl, _ in res], splits_hint=6)
+    assert all(a[0].data_ptr() == b[0].data_ptr() for a, b in zip(res, res2))
+    for (x, dy, k, r, s, stride, pad), (slab, sp) in zip(items, res2):
+        got = _fold(slab, sp, k, r, x.shape[-1]).sum(0).cpu()
+        ref = o.conv2d_wgrad(x, dy, k, r, s, stride, pad).cpu()
+        assert (got - ref).abs().max().item() <= 2e-5 * ref.abs().max().item()
+
+
+def test_wgrad_group_rejects_ineligible_layers(dev):
+    o = ops()
+    x = torch.randn(2, 8, 8, 64, device=dev).bfloat16()
+    dy = torch.randn(2, 8, 8, 128, device=dev).bfloat16()
+    assert not o.wgrad_group_supported(x, dy, 128, 1, 1, 1, 0)                      # C % 128 != 0
+    xf = torch.randn(2, 8, 8, 128, device=dev)
+    assert not o.wgrad_group_supported(xf, xf, 128, 1, 1, 1, 0)                     # fp32
+    xb = torch.randn(1024, 7, 7, 512, device=dev).bfloat16()
+    assert not o.wgrad_group_supported(xb, xb, 512, 3, 3, 1, 1)                     # a layer of the 256x256 tile
+    with pytest.raises(Exception):
+        o.conv2d_wgrad_group([(x, dy, 128, 1, 1, 1, 0)])
+
+
 @pytest.mark.parametrize("case,tile", [((1024, 7, 7, 512, 512, 3, 1, 1), 16), ((1024, 7, 7, 512, 2048, 1, 1, 0), 16), ((1024, 7, 7, 2048, 512, 1, 1, 0), 16),
                                        ((1024, 14, 14, 1024, 512, 1, 2, 0), 16), ((4, 38, 63, 1024, 1024, 3, 1, 1), 16),
                                        ((1024, 7, 7, 512, 512, 3, 1, 1), 21), ((1024, 7, 7, 512, 2048, 1, 1, 0), 21), ((1024, 7, 7, 2048, 512, 1, 1, 0), 21),

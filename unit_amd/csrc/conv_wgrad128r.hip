@@ -25,15 +25,11 @@ __device__ __forceinline__ bf16x8 tr_frag128(const char* tile, int col0, int lan
   return __builtin_bit_cast(bf16x8, v);
 }
 
+// one 128 x 128 tile of dW over the pixels of one split (p may live in the kernel-argument segment: every field read is uniform)
 template <int NS>
-__global__ void __launch_bounds__(256, 2) conv_wgrad128_ring_kernel(Wgrad256Args p) {
+__device__ __forceinline__ void wgrad128_ring_tile(const Wgrad256Args& p, int tile_k, int tile_n, int split, char* smem) {
   constexpr int MS = 32;
   constexpr int TILE = MS * 256;               // 8 KB per operand per stage
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-
-  int bid = blockIdx.x;
-  int tile_k = bid % p.tiles_k; int t = bid / p.tiles_k;
-  int tile_n = t % p.tiles_n; int split = t / p.tiles_n;
   int k0 = tile_k * 128, n0 = tile_n * 128;
   int m_begin = split * p.m_per_split, m_end = min(p.M, m_begin + p.m_per_split);
   int rs = k0 / p.C, ch0 = k0 - rs * p.C, kr = rs / p.S, ksx = rs - kr * p.S;
@@ -158,6 +154,64 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad128_ring_kernel(Wgrad256Args
       *reinterpret_cast<f32x4*>(out + (size_t)n * p.Kgemm + k) = acc[a][b];
     }
   }
+}
+
+template <int NS>
+__global__ void __launch_bounds__(256, 2) conv_wgrad128_ring_kernel(Wgrad256Args p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  int bid = blockIdx.x;
+  int tile_k = bid % p.tiles_k; int t = bid / p.tiles_k;
+  wgrad128_ring_tile<NS>(p, tile_k, t % p.tiles_n, t / p.tiles_n, smem);
+}
+
+// ---- grouped launch: the weight gradients of SEVERAL layers in one grid (include/unit_hip.h: unit_conv2d_wgrad_group).
+// Why: a res4 layer has M = 9 576 pixels and 16-36 tiles -- launched alone it needs ~17 split-M slabs to fill the chip, so a
+// workgroup runs 9 steps between a cold start and a 64 KB slab store, and the reduction reads 17 slabs back (17-29 us per layer for
+// 5-11 GFLOP, 100 launches per step). The layers of a gradient bucket (18 of them for six res4 blocks) have 408 tiles between them:
+// one grid, ONE slab per layer, 150-step loops. A "unit" = (layer, split): its tiles read the same pixel rows, so a unit is dealt
+// to ONE XCD (workgroup b runs on XCD b % 8) and its rows come through that XCD's L2 once; the host deals units to XCDs
+// longest-first (conv_wgrad.hip).
+__device__ __forceinline__ int pin(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ const void* pin_ptr(const void* q) {
+  unsigned long long u = (unsigned long long)(uintptr_t)q;
+  unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)u), hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(u >> 32));
+  return (const void*)(uintptr_t)(((unsigned long long)hi << 32) | lo);
+}
+
+template <int NS>
+__global__ void __launch_bounds__(256, 2) conv_wgrad128_group_kernel(WgradGroupArgs g) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  int nu = g.n_units[xcd];
+  if (slot >= (int)g.unit_start[xcd][nu]) return;
+  int u = 0;
+  for (int i = 1; i < nu; ++i)
+    if (slot >= (int)g.unit_start[xcd][i]) u = i;
+  unsigned code = g.unit_code[xcd][u];
+  // the layer's arguments into SGPRs ONCE: read in place, hipcc re-loads fields from the argument segment inside the pixel loop, and
+  // every such s_load is followed by an lgkmcnt(0) wait that also drains the LDS reads in flight
+  const Wgrad256Args& src = g.p[code & 0xFF];
+  Wgrad256Args p;
+  p.x = pin_ptr(src.x); p.dy = pin_ptr(src.dy); p.partial = (float*)pin_ptr(src.partial);
+  p.N = pin(src.N); p.H = pin(src.H); p.W = pin(src.W); p.C = pin(src.C); p.K = pin(src.K); p.R = pin(src.R); p.S = pin(src.S);
+  p.stride = pin(src.stride); p.pad = pin(src.pad); p.OH = pin(src.OH); p.OW = pin(src.OW); p.ldy = pin(src.ldy);
+  p.Kgemm = pin(src.Kgemm); p.M = pin(src.M); p.tiles_k = pin(src.tiles_k); p.tiles_n = pin(src.tiles_n); p.splits = pin(src.splits);
+  p.m_per_split = pin(src.m_per_split); p.x_bytes = (unsigned)pin((int)src.x_bytes); p.dy_bytes = (unsigned)pin((int)src.dy_bytes);
+  p.magic_ohw = (unsigned)pin((int)src.magic_ohw); p.magic_ow = (unsigned)pin((int)src.magic_ow); p.OHW = pin(src.OHW);
+  p.use_magic = pin(src.use_magic); p.valid_only = 0;
+  int t = slot - (int)g.unit_start[xcd][u];
+  wgrad128_ring_tile<NS>(p, t % p.tiles_k, t / p.tiles_k, (int)(code >> 8), smem);
+}
+
+int unit_wgrad128_group_launch(const WgradGroupArgs& g, int slots_per_xcd, hipStream_t st) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)conv_wgrad128_group_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 2 * 32 * 256);
+    attr_set = true;
+  }
+  conv_wgrad128_group_kernel<4><<<slots_per_xcd * 8, 256, 4 * 2 * 32 * 256, st>>>(g);
+  UNIT_LAUNCH_CHECK();
+  return UNIT_OK;
 }
 
 int unit_wgrad128_ring_launch(const Wgrad256Args& a, hipStream_t st) {

@@ -21,6 +21,19 @@ struct Wgrad256Args {
   int valid_only;
 };
 
+// grouped launch of the 128x128 ring kernel (conv_wgrad128r.hip): up to 24 layers, their (layer, split) units dealt to the 8 XCDs.
+// Passed BY VALUE (3.6 KB of the 4 KB kernel-argument segment): the operand pointers change every step, a device-side table
+// would cost a host-to-device copy per launch.
+constexpr int WG_GROUP_MAX_PROBLEMS = 24;
+constexpr int WG_GROUP_MAX_UNITS = 16;           // per XCD
+struct WgradGroupArgs {
+  Wgrad256Args p[WG_GROUP_MAX_PROBLEMS];
+  unsigned short unit_start[8][WG_GROUP_MAX_UNITS + 1];   // per XCD: first workgroup slot of unit i ([n_units] = the XCD's total)
+  unsigned short unit_code[8][WG_GROUP_MAX_UNITS];        // problem | split << 8
+  int n_units[8];
+};
+int unit_wgrad128_group_launch(const WgradGroupArgs& g, int slots_per_xcd, hipStream_t st);
+
 typedef __attribute__((address_space(3))) void lds_void_w;
 typedef __attribute__((ext_vector_type(8))) short s16x8_w;
 

@@ -114,6 +114,8 @@ class Conv2d(_EpochOnLoad):
             # unit_multi_wgrad_reduce launch per bucket folds them into the flat gradient buffer later
             side = ops.WGRAD_STREAM
             which = "_slab2" if acc else "_slab"
+            if self._plan.defer_wgrad(self, x, dy, st, acc):
+                return       # small-M layer: goes out with the rest of its gradient bucket in one grouped launch (multi.py)
 
             def launch():
                 slab, splits = ops.conv2d_wgrad_partial(x, dy, self.cout, self.k, self.k, st, self.pad, getattr(self, which, None))

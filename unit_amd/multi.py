@@ -3,6 +3,7 @@
 `unit_multi_weight_prep` launch after the optimizer refreshes every trainable conv's bf16 forward / dgrad copies.
 Replaces ~220 launch-bound per-layer kernels per step (csrc/multi.hip)."""
 import ctypes
+import os
 
 import torch
 
@@ -50,6 +51,11 @@ class ConvPlan:
         # the 256 MB Infinity Cache between the wgrad kernel that wrote them and the reduction that reads them back.
         self._pending = {}
         self.flush_bytes = 96 << 20
+        # weight gradients waiting for a grouped launch (csrc/conv_wgrad128r.hip: conv_wgrad128_group_kernel): the small-M layers of
+        # a gradient bucket go out as ONE grid at the bucket boundary instead of one under-filled, many-slab launch per layer
+        self.group_wgrads = not bool(int(os.environ.get("UNIT_NO_WGRAD_GROUP", "0")))      # A/B switch for tools/
+        self.group_splits_hint = 0          # tools/: > 0 overrides the library's split choice
+        self._deferred = []                 # (conv, x, dy, stride, accumulate, raw stream that produced x / dy)
 
     def _build(self, convs, with_partial, entries=None):
         """entries (reduce tables): [(conv, slab tensor, signed splits)]; splits < 0 = accumulate onto the gradient"""
@@ -85,6 +91,39 @@ class ConvPlan:
         if lst[0] >= self.flush_bytes:
             self._flush(key)
 
+    def defer_wgrad(self, conv, x, dy, stride, accumulate):
+        """queue a layer's weight gradient for the next grouped launch; False = not eligible (the caller launches it itself)"""
+        if not self.group_wgrads or not ops.wgrad_group_supported(x, dy, conv.cout, conv.k, conv.k, stride, conv.pad):
+            return False
+        self._deferred.append((conv, x, dy, stride, accumulate, ops.raw_stream()))
+        return True
+
+    def launch_deferred(self):
+        """one grouped launch for the queued layers, on the current launch stream (the side stream inside `backward_train`'s
+        bucket callback), ordered after the streams that produced their operands"""
+        items = self._deferred
+        if not items:
+            return
+        self._deferred = []
+        cur = ops.raw_stream()
+        for prod in {it[5] for it in items}:
+            if prod != cur:
+                check(lib().unit_stream_wait_stream(ctypes.c_void_p(cur), ctypes.c_void_p(prod)), "unit_stream_wait_stream")
+        side = ops.WGRAD_STREAM
+        if side is not None and side.cuda_stream == cur:
+            for _, x, dy, _, _, prod in items:
+                if prod != cur:
+                    x.record_stream(side)
+                    dy.record_stream(side)
+        which = ["_slab2" if it[4] else "_slab" for it in items]
+        res = ops.conv2d_wgrad_group([(x, dy, m.cout, m.k, m.k, st, m.pad) for m, x, dy, st, _, _ in items],
+                                     [getattr(it[0], w, None) for it, w in zip(items, which)], self.group_splits_hint)
+        for (m, _, _, _, acc, _), w, (slab, splits) in zip(items, which, res):
+            setattr(m, w, slab)
+            if not acc:
+                m._splits = splits
+            self.note_wgrad(m, slab, splits, accumulate=acc)
+
     def _flush(self, key):
         lst = self._pending.get(key)
         if not lst or not lst[1]:
@@ -101,6 +140,7 @@ class ConvPlan:
     def reduce(self, tag=None):
         """grads[flat] = scale * sum(slabs) for every conv whose slabs are still pending (call at a bucket boundary, on a
         stream that is ordered after every stream that produced them, before the bucket's all-reduce)."""
+        self.launch_deferred()
         for key in list(self._pending):
             self._flush(key)
 

@@ -469,6 +469,53 @@ def conv2d_wgrad_partial(x, dy, k, r, s, stride, pad, slab=None, variant=0):
     return slab, splits
 
 
+class WgradProblem(ctypes.Structure):
+    """include/unit_hip.h: UnitWgradProblem"""
+    _fields_ = [("x", ctypes.c_void_p), ("dy", ctypes.c_void_p), ("partial", ctypes.c_void_p)] + \
+               [(f, ctypes.c_int) for f in ("N", "H", "W", "C", "K", "R", "S", "stride", "pad", "OH", "OW", "ldy", "splits", "reserved")]
+
+
+def wgrad_group_supported(x, dy, k, r, s, stride, pad):
+    """may this layer's weight gradient go into a grouped launch (csrc/conv_wgrad128r.hip)?"""
+    n, h, wd, c = x.shape
+    oh, ow = conv_out_size(h, wd, r, s, stride, pad)
+    return x.dtype == torch.bfloat16 and bool(lib().unit_conv2d_wgrad_group_supported(dt(x.dtype), n, oh, ow, k, r, s, c))
+
+
+def conv2d_wgrad_group(items, slabs=None, splits_hint=0):
+    """split-M partial slabs of SEVERAL layers from one launch (unit_conv2d_wgrad_group). items: [(x, dy, k, r, s, stride, pad)];
+    slabs: per item a uint8 tensor to reuse or None. Returns [(slab, n_splits)]; slab i of a layer = floats [i*k*r*s*C, ...) as
+    conv2d_wgrad_partial leaves them."""
+    n_items = len(items)
+    if n_items == 0:
+        return []
+    assert ctypes.sizeof(WgradProblem) == lib().unit_wgrad_problem_bytes()
+    pr = (WgradProblem * n_items)()
+    flops = nbytes = 0
+    for i, (x, dy, k, r, s, stride, pad) in enumerate(items):
+        n, h, wd, c = x.shape
+        oh, ow = conv_out_size(h, wd, r, s, stride, pad)
+        q = pr[i]
+        q.x, q.dy = x.data_ptr(), dy.data_ptr()
+        q.N, q.H, q.W, q.C, q.K, q.R, q.S, q.stride, q.pad, q.OH, q.OW, q.ldy = n, h, wd, c, k, r, s, stride, pad, oh, ow, dy.shape[-1]
+        flops += 2.0 * n * oh * ow * k * r * s * c
+        nbytes += (x.numel() + n * oh * ow * dy.shape[-1]) * 2 + 4 * k * r * s * c
+    check(lib().unit_conv2d_wgrad_group_plan(pr, n_items, int(splits_hint)), "unit_conv2d_wgrad_group_plan")
+    out = []
+    for i, (x, dy, k, r, s, stride, pad) in enumerate(items):
+        need = pr[i].splits * k * r * s * x.shape[-1] * 4
+        slab = slabs[i] if slabs is not None else None
+        if slab is None or slab.numel() < need:
+            if slab is not None:
+                _WS_RETIRED.append(slab)       # grow-only (conv2d_wgrad_partial)
+            slab = torch.empty(need, dtype=torch.uint8, device=x.device)
+        pr[i].partial = slab.data_ptr()
+        out.append((slab, pr[i].splits))
+    with _timed("conv_wgrad", flops, nbytes):
+        check(lib().unit_conv2d_wgrad_group(pr, n_items, dt(torch.bfloat16), _s()), "unit_conv2d_wgrad_group")
+    return out
+
+
 def frozen_bn_fold(weight, bias, running_mean, running_var, eps=1e-5):
     c = weight.numel()
     scale = torch.empty(c, dtype=torch.float32, device=weight.device)
