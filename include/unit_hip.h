@@ -115,14 +115,17 @@ int unit_conv2d_wgrad_splits(int in_dtype, int N, int OH, int OW, int K, int R, 
  * res4 blocks, 9 576 pixels and 16-36 tiles each -- launched one by one need ~17 split-M slabs apiece to fill 256 CUs (9-step loops,
  * 17 slabs to reduce); launched together they have 408 tiles: one slab per layer and 150-step loops. The reference reaches these
  * through autograd's per-layer cudnn wgrad calls (engine/defaults.py:279-284 `losses.backward()`); grouping them is this plan's own.
- * Eligible (unit_conv2d_wgrad_group_supported): bf16, C % 128 == 0, K % 128 == 0, not a layer of the 256x256 tile.
- * unit_conv2d_wgrad_group_plan fills pr[i].splits for the launch (splits_hint > 0: that many for the layer with the most pixels, the
+ * Eligible (unit_conv2d_wgrad_group_supported != 0): bf16, C % 128 == 0, K % 128 == 0; returns the tile kind: 2 = 256x256 tiles
+ * (csrc/conv_wgrad256p8.hip; C % 256 == 0, K % 256 == 0, >= 2048 pixels: the Res5 / RPN / res4 layers -- a Res5 head's ten layers in one
+ * grid need 3-4 slabs each instead of 8-16), 1 = 128x128 ring tiles. One call launches one grid per kind (more if the list is long).
+ * unit_conv2d_wgrad_group_plan fills pr[i].kind and pr[i].splits for the launch (splits_hint > 0: that many for the layer with the most pixels, the
  * others in proportion); slab s of layer i is written at pr[i].partial + s*K*R*S*C floats, the layout unit_conv2d_wgrad(dw = NULL)
- * leaves (unit_multi_wgrad_reduce folds them). Per layer the result equals unit_conv2d_wgrad's with the same split count bit for bit. */
+ * leaves (unit_multi_wgrad_reduce folds them). Per layer, kind 1 equals unit_conv2d_wgrad's 128x128 path with the same split count bit for bit; kind 2 contracts
+ * 3x3 s1 p1 layers on maps of <= 512 pixels only over in-map pixels with the same split count for every filter tap. */
 typedef struct UnitWgradProblem {
   const void* x; const void* dy; void* partial;
   int N, H, W, C, K, R, S, stride, pad, OH, OW, ldy;
-  int splits, reserved;
+  int splits, kind;      /* filled by unit_conv2d_wgrad_group_plan: split-M slabs of the layer; tile kind 1 = 128x128, 2 = 256x256 */
 } UnitWgradProblem;
 size_t unit_wgrad_problem_bytes(void);
 int unit_conv2d_wgrad_group_supported(int in_dtype, int N, int OH, int OW, int K, int R, int S, int C);

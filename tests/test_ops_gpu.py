@@ -334,7 +334,11 @@ def test_wgrad_ring128_kernel(dev, case):
 
 
 GROUP_CASES = [(4, 38, 63, 256, 256, 3, 1, 1), (4, 38, 63, 1024, 256, 1, 1, 0), (2, 75, 125, 128, 128, 3, 1, 1), (3, 40, 50, 256, 512, 1, 2, 0),
-               (5, 7, 9, 128, 256, 3, 1, 1), (1, 33, 40, 384, 128, 1, 1, 0), (4, 38, 63, 256, 1024, 1, 1, 0)]
+               (5, 7, 9, 128, 256, 3, 1, 1), (1, 33, 40, 384, 128, 1, 1, 0), (4, 38, 63, 256, 1024, 1, 1, 0),
+               # 256x256 tiles: Res5-like (3x3 on 7x7 bins: in-map pixels only; pointwise; stride 2), a 3x3 on a map wider than the table
+               (400, 7, 7, 256, 256, 3, 1, 1), (340, 7, 7, 512, 256, 1, 1, 0), (350, 14, 14, 256, 512, 1, 2, 0), (1, 70, 80, 256, 256, 3, 1, 1),
+               (401, 5, 9, 256, 512, 3, 1, 1)]
+GROUP_KIND1 = [(2, 75, 125, 128, 128, 3, 1, 1), (3, 40, 50, 256, 512, 1, 2, 0), (5, 7, 9, 128, 256, 3, 1, 1), (1, 33, 40, 384, 128, 1, 1, 0)]
 
 
 def _group_inputs(o, dev, cases, seed):
@@ -374,10 +378,10 @@ def test_wgrad_group_launch(dev, hint):
 
 
 def test_wgrad_group_single_layer_is_the_per_layer_kernel_bit_for_bit(dev):
-    """a group of ONE layer with the per-layer split count writes the slabs unit_conv2d_wgrad(dw = NULL) writes, bit for bit (same
-    tile function, same pixel ranges)"""
+    """a group of ONE 128x128-tile layer with the per-layer split count writes the slabs unit_conv2d_wgrad(dw = NULL) writes, bit for
+    bit (same tile function, same pixel ranges)"""
     o = ops()
-    for case in GROUP_CASES[:4]:
+    for case in GROUP_KIND1:
         (x, dy, k, r, s, stride, pad), = _group_inputs(o, dev, [case], 43)
         slab0, sp0 = o.conv2d_wgrad_partial(x, dy, k, r, s, stride, pad)
         (slab1, sp1), = o.conv2d_wgrad_group([(x, dy, k, r, s, stride, pad)], splits_hint=sp0)
@@ -407,8 +411,8 @@ def test_wgrad_group_rejects_ineligible_layers(dev):
     assert not o.wgrad_group_supported(x, dy, 128, 1, 1, 1, 0)                      # C % 128 != 0
     xf = torch.randn(2, 8, 8, 128, device=dev)
     assert not o.wgrad_group_supported(xf, xf, 128, 1, 1, 1, 0)                     # fp32
-    xb = torch.randn(1024, 7, 7, 512, device=dev).bfloat16()
-    assert not o.wgrad_group_supported(xb, xb, 512, 3, 3, 1, 1)                     # a layer of the 256x256 tile
+    xb = torch.randn(64, 7, 7, 512, device=dev).bfloat16()
+    assert o.wgrad_group_supported(xb, xb, 512, 3, 3, 1, 1)                         # a layer of the 256x256 tiles
     with pytest.raises(Exception):
         o.conv2d_wgrad_group([(x, dy, 128, 1, 1, 1, 0)])
 

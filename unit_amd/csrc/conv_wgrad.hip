@@ -319,64 +319,106 @@ extern "C" int unit_conv2d_wgrad_splits(int in_dtype, int N, int OH, int OW, int
   return choose_splits((int)M, tiles, in_dtype == UNIT_BF16 ? 64 : 32);
 }
 
-// ---- grouped launch (conv_wgrad128r.hip: conv_wgrad128_group_kernel) ------------------------------------------------------------
+// ---- grouped launches (conv_wgrad128r.hip: conv_wgrad128_group_kernel; conv_wgrad256p8.hip: conv_wgrad256_group_kernel) -------------
 // mirrors include/unit_hip.h
 struct UnitWgradProblem {
   const void* x; const void* dy; void* partial;
   int N, H, W, C, K, R, S, stride, pad, OH, OW, ldy;
-  int splits, reserved;
+  int splits, kind;
 };
 extern "C" size_t unit_wgrad_problem_bytes(void) { return sizeof(UnitWgradProblem); }
 
+// 0 = not eligible; 1 = 128x128 ring tiles; 2 = 256x256 phase-interleaved tiles (half the operand bytes per flop; needs enough pixels
+// for a few 64-pixel steps per split)
 extern "C" int unit_conv2d_wgrad_group_supported(int in_dtype, int N, int OH, int OW, int K, int R, int S, int C) {
   if (in_dtype != UNIT_BF16 || (C % 128) != 0 || (K % 128) != 0) return 0;
   long M = (long)N * OH * OW;
   if (M <= 0 || M > 0x7FFFFFFFl) return 0;
+  if ((C % 256) == 0 && (K % 256) == 0 && M >= 2048 && (R * S * C / 256) * (K / 256) <= 4096) return 2;
   if ((R * S * C / 128) * (K / 128) > 4096) return 0;
-  return unit_wgrad_use_big(in_dtype, M, K, C, R * S) ? 0 : 1;
+  return 1;
 }
 
-// split counts of the layers of one grouped launch. All workgroups of the grid should run about the same number of pixels, so layer p
-// gets s_p ~ s_ref * M_p / M_max slabs; s_ref by the cost model of choose_splits() over the whole grid (512 workgroup slots per
-// round, ~4 us fixed + ~1 us per 64 pixels per workgroup, two 64 KB slab transfers per workgroup at ~4 TB/s).
+static bool group_valid_only(const UnitWgradProblem& q) {
+  return q.R == 3 && q.S == 3 && q.stride == 1 && q.pad == 1 && q.OH == q.H && q.OW == q.W && q.OH * q.OW <= 512;
+}
+
+// split counts of the layers of a grouped launch, per tile kind. All workgroups of a grid should run about the same number of pixels, so
+// layer p gets s_p ~ s_ref * M_p / M_max slabs;
+//  kind 1 (two workgroups per CU): s_ref from choose_splits()'s cost model over the whole grid: rounds of 512 slots, ~4 us fixed + ~1 us
+//  per 64 pixels per workgroup, two transfers of every workgroup's 64 KB slab tile at ~4 TB/s;
+//  kind 2 (one per CU, long loops): the measured rule below.
 extern "C" int unit_conv2d_wgrad_group_plan(UnitWgradProblem* pr, int n, int splits_hint) {
   UNIT_CHECK_ARG(pr != nullptr && n > 0, "wgrad_group_plan: no problems");
-  long mmax = 1;
   for (int i = 0; i < n; ++i) {
-    long M = (long)pr[i].N * pr[i].OH * pr[i].OW;
-    if (M > mmax) mmax = M;
+    pr[i].kind = unit_conv2d_wgrad_group_supported(UNIT_BF16, pr[i].N, pr[i].OH, pr[i].OW, pr[i].K, pr[i].R, pr[i].S, pr[i].C);
+    UNIT_CHECK_ARG(pr[i].kind != 0, "wgrad_group_plan: layer not eligible (unit_conv2d_wgrad_group_supported)");
   }
-  auto splits_of = [&](int i, int sref) {
-    long M = (long)pr[i].N * pr[i].OH * pr[i].OW;
-    long s = (M * sref + mmax / 2) / mmax;
-    long maxs = (M + 255) / 256;              // >= 4 staged 64-pixel steps per split
-    if (s > maxs) s = maxs;
-    if (s < 1) s = 1;
-    if (s > 64) s = 64;
-    return (int)s;
-  };
-  int best = 1; double best_cost = 1e30;
-  int lo = splits_hint > 0 ? splits_hint : 1, hi = splits_hint > 0 ? splits_hint : 32;
-  for (int sref = lo; sref <= hi; ++sref) {
-    long wgs = 0, units = 0;
-    for (int i = 0; i < n; ++i) {
-      int s = splits_of(i, sref);
-      wgs += (long)(pr[i].R * pr[i].S * pr[i].C / 128) * (pr[i].K / 128) * s;
-      units += s;
+  // a few 256x256 tiles alone cannot fill 256 CUs with long loops (res3's one 256 -> 512 shortcut: 2 tiles): they join the 128x128 grid
+  long tiles2 = 0;
+  for (int i = 0; i < n; ++i)
+    if (pr[i].kind == 2) tiles2 += (long)(pr[i].R * pr[i].S * pr[i].C / 256) * (pr[i].K / 256);
+  if (tiles2 < 64)
+    for (int i = 0; i < n; ++i)
+      if (pr[i].kind == 2) pr[i].kind = 1;
+  for (int kind = 1; kind <= 2; ++kind) {
+    long mmax = 0;
+    for (int i = 0; i < n; ++i)
+      if (pr[i].kind == kind) { long M = (long)pr[i].N * pr[i].OH * pr[i].OW; if (M > mmax) mmax = M; }
+    if (mmax == 0) continue;
+    const int T = kind == 2 ? 256 : 128;
+    auto splits_of = [&](int i, int sref) {
+      long M = (long)pr[i].N * pr[i].OH * pr[i].OW;
+      long s = (M * sref + mmax / 2) / mmax;
+      long maxs = (M + 255) / 256;              // >= 4 staged 64-pixel steps per split
+      if (s > maxs) s = maxs;
+      if (s < 1) s = 1;
+      if (s > 64) s = 64;
+      return (int)s;
+    };
+    int best = 1;
+    if (splits_hint > 0) best = splits_hint;
+    else if (kind == 1) {
+      double best_cost = 1e30;
+      for (int sref = 1; sref <= 32; ++sref) {
+        long wgs = 0;
+        for (int i = 0; i < n; ++i)
+          if (pr[i].kind == kind) wgs += (long)(pr[i].R * pr[i].S * pr[i].C / T) * (pr[i].K / T) * splits_of(i, sref);
+        long rounds = (wgs + 511) / 512;
+        double cost = rounds * (4.0 + 1.0 * ((double)mmax / sref) / 64.0) + (double)wgs * 2.0 * 65536.0 / 4.0e6;
+        if (cost < best_cost) { best_cost = cost; best = sref; }
+      }
+    } else {
+      // measured (tools/wgrad_group_bench.py): a Res5 head (236 tiles, 784 steps) runs 1.62 ms with 1-2 slabs per layer, 1.49-1.55 with
+      // 3-8 (units of 16-36 tiles quantise badly on an XCD's 32 CUs until there are several rounds of them); a res4 bucket (102 tiles,
+      // 150 steps) 315 / 177 / 219 / 176 / 191 / 209 us with 1 / 2 / 3 / 4 / 6 / 8. So: at least three rounds of workgroups if that
+      // leaves >= 48 steps per workgroup, else the fullest single round.
+      long tiles = 0;
+      for (int i = 0; i < n; ++i)
+        if (pr[i].kind == kind) tiles += (long)(pr[i].R * pr[i].S * pr[i].C / T) * (pr[i].K / T);
+      long smax = (mmax / 64) / 48;
+      if (smax < 1) smax = 1;
+      long s3 = (768 + tiles - 1) / tiles;
+      if (s3 <= smax) best = (int)s3;
+      else {
+        long one = 256 / tiles;
+        best = (int)(one >= 1 && one < smax ? one : smax);
+      }
+      if (best > 64) best = 64;
     }
-    long rounds = (wgs + 511) / 512;
-    double cost = rounds * (4.0 + 1.0 * ((double)mmax / sref) / 64.0) + (double)wgs * 2.0 * 65536.0 / 4.0e6;
-    if (cost < best_cost) { best_cost = cost; best = sref; }
+    for (int i = 0; i < n; ++i)
+      if (pr[i].kind == kind) pr[i].splits = splits_of(i, best);
   }
-  for (int i = 0; i < n; ++i) pr[i].splits = splits_of(i, best);
   return UNIT_OK;
 }
 
 static int wgrad_group_fill(const UnitWgradProblem& q, Wgrad256Args& b) {
-  UNIT_CHECK_ARG(q.C % 128 == 0 && q.K % 128 == 0 && q.ldy % 8 == 0, "wgrad_group: C, K must be multiples of 128, ldy of 8");
+  const int T = q.kind == 2 ? 256 : 128;
+  UNIT_CHECK_ARG(q.kind == 1 || q.kind == 2, "wgrad_group: kind 1 / 2 (unit_conv2d_wgrad_group_plan)");
+  UNIT_CHECK_ARG(q.C % T == 0 && q.K % T == 0 && q.ldy % 8 == 0, "wgrad_group: C, K must be multiples of the tile, ldy of 8");
   UNIT_CHECK_ARG(((uintptr_t)q.x % 16 == 0) && ((uintptr_t)q.dy % 16 == 0) && ((uintptr_t)q.partial % 16 == 0) && q.partial != nullptr,
                  "wgrad_group: 16B alignment");
-  UNIT_CHECK_ARG(q.splits >= 1 && q.splits <= 255, "wgrad_group: splits 1..255 (unit_conv2d_wgrad_group_plan)");
+  UNIT_CHECK_ARG(q.splits >= 1 && q.splits <= WG_GROUP_MAX_SPLITS, "wgrad_group: splits 1..127 (unit_conv2d_wgrad_group_plan)");
   b.x = q.x; b.dy = q.dy; b.partial = (float*)q.partial;
   b.N = q.N; b.H = q.H; b.W = q.W; b.C = q.C; b.K = q.K; b.R = q.R; b.S = q.S; b.stride = q.stride; b.pad = q.pad; b.OH = q.OH; b.OW = q.OW;
   b.ldy = q.ldy; b.Kgemm = q.R * q.S * q.C; b.M = q.N * q.OH * q.OW;
@@ -388,69 +430,90 @@ static int wgrad_group_fill(const UnitWgradProblem& q, Wgrad256Args& b) {
   b.use_magic = ((unsigned long long)(b.M + 64) * (unsigned long long)b.OHW < 0xFFFFFFFFull) ? 1 : 0;
   b.magic_ohw = b.OHW > 1 ? (unsigned)((0x100000000ull + b.OHW - 1) / (unsigned long long)b.OHW) : 0xFFFFFFFFu;
   b.magic_ow = q.OW > 1 ? (unsigned)((0x100000000ull + q.OW - 1) / (unsigned long long)q.OW) : 0xFFFFFFFFu;
-  b.tiles_k = b.Kgemm / 128; b.tiles_n = q.K / 128;
+  b.tiles_k = b.Kgemm / T; b.tiles_n = q.K / T;
   b.splits = q.splits;
   b.m_per_split = cdiv(cdiv(b.M, q.splits), 64) * 64;
-  b.valid_only = 0;
+  b.valid_only = (q.kind == 2 && group_valid_only(q)) ? 1 : 0;
   UNIT_CHECK_ARG(b.tiles_k * b.tiles_n <= 4096, "wgrad_group: more than 4096 tiles in one layer");
   return UNIT_OK;
 }
 
-// x / dy / partial as unit_conv2d_wgrad(dw = NULL) takes them, for n layers at once; pr[i].splits from unit_conv2d_wgrad_group_plan.
+static int units_of(const UnitWgradProblem& q) { return q.splits * ((q.kind == 2 && group_valid_only(q)) ? 9 : 1); }
+
+// x / dy / partial as unit_conv2d_wgrad(dw = NULL) takes them, for n layers at once; pr[i].splits / kind from unit_conv2d_wgrad_group_plan.
 // Slab s of layer i at partial + s*K*R*S*C floats, same layout as unit_conv2d_wgrad's (unit_multi_wgrad_reduce folds them).
 extern "C" int unit_conv2d_wgrad_group(const UnitWgradProblem* pr, int n, int in_dtype, void* stream) {
   UNIT_CHECK_ARG(in_dtype == UNIT_BF16, "wgrad_group: bf16 only");
   UNIT_CHECK_ARG(pr != nullptr && n >= 0, "wgrad_group: no problems");
-  static WgradGroupArgs g;         // 3.6 KB; filled and passed by value (launches are serialised by the caller's GIL / one host thread per GPU)
-  int i0 = 0;
-  while (i0 < n) {
-    // one launch: as many consecutive problems as fit WG_GROUP_MAX_PROBLEMS and 8 * WG_GROUP_MAX_UNITS units
-    int cnt = 0, units = 0;
-    while (i0 + cnt < n && cnt < WG_GROUP_MAX_PROBLEMS && units + pr[i0 + cnt].splits <= 8 * WG_GROUP_MAX_UNITS) {
-      int rc = wgrad_group_fill(pr[i0 + cnt], g.p[cnt]);
-      if (rc != UNIT_OK) return rc;
-      units += pr[i0 + cnt].splits;
-      ++cnt;
-    }
-    UNIT_CHECK_ARG(cnt > 0, "wgrad_group: a layer with more than 128 splits");
-    // units (layer, split), heaviest first, each to the least-loaded XCD that still has a free unit entry
-    struct U { long w; int p, s, tiles; };
-    static U us[8 * WG_GROUP_MAX_UNITS];
-    int nu = 0;
-    for (int p = 0; p < cnt; ++p) {
-      const Wgrad256Args& a = g.p[p];
-      for (int s = 0; s < a.splits; ++s) {
-        int mb = s * a.m_per_split, me = a.M < mb + a.m_per_split ? a.M : mb + a.m_per_split;
-        int tiles = a.tiles_k * a.tiles_n;
-        us[nu++] = U{(long)tiles * (me > mb ? me - mb : 0), p, s, tiles};
+  static WgradGroupArgs g;         // 3.4 KB; filled and passed by value (one host thread per GPU launches)
+  struct U { long w; int p, tap, s, tiles; };
+  static U us[8 * WG_GROUP_MAX_UNITS];
+  for (int kind = 2; kind >= 1; --kind) {           // the long 256-tile grid first
+    int i0 = 0;
+    while (i0 < n) {
+      // one launch: the next problems of this kind that fit WG_GROUP_MAX_PROBLEMS and the unit table
+      int cnt = 0, units = 0, i = i0;
+      for (; i < n; ++i) {
+        if (pr[i].kind != kind) continue;
+        if (cnt == WG_GROUP_MAX_PROBLEMS || units + units_of(pr[i]) > 8 * WG_GROUP_MAX_UNITS) break;
+        int rc = wgrad_group_fill(pr[i], g.p[cnt]);
+        if (rc != UNIT_OK) return rc;
+        units += units_of(pr[i]);
+        ++cnt;
       }
+      if (cnt == 0) {
+        UNIT_CHECK_ARG(i >= n, "wgrad_group: a layer with more units than one grid holds");
+        break;
+      }
+      i0 = i;
+      // units, heaviest first, each to the least-loaded XCD that still has a free unit entry
+      int nu = 0;
+      for (int p = 0; p < cnt; ++p) {
+        const Wgrad256Args& a = g.p[p];
+        if (a.valid_only) {
+          int ncb = a.tiles_k / 9;
+          for (int tap = 0; tap < 9; ++tap) {
+            int kr = tap / 3, ks = tap % 3;
+            int nh = a.OH - (kr == 1 ? 0 : 1), nw = a.OW - (ks == 1 ? 0 : 1);      // 3x3 s1 p1 "same": the border taps lose a row / column
+            if (nh < 0) nh = 0;
+            if (nw < 0) nw = 0;
+            long meff = (long)a.N * nh * nw;
+            for (int sp = 0; sp < a.splits; ++sp) us[nu++] = U{(long)a.tiles_n * ncb * (meff / a.splits + 1), p, tap, sp, a.tiles_n * ncb};
+          }
+        } else {
+          for (int sp = 0; sp < a.splits; ++sp) {
+            int mb = sp * a.m_per_split, me = a.M < mb + a.m_per_split ? a.M : mb + a.m_per_split;
+            int tiles = a.tiles_k * a.tiles_n;
+            us[nu++] = U{(long)tiles * (me > mb ? me - mb : 0), p, 0, sp, tiles};
+          }
+        }
+      }
+      for (int a = 1; a < nu; ++a) {           // insertion sort, stable, descending weight (<= 192 entries)
+        U v = us[a]; int b = a - 1;
+        while (b >= 0 && us[b].w < v.w) { us[b + 1] = us[b]; --b; }
+        us[b + 1] = v;
+      }
+      long load[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      int slots[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      for (int x = 0; x < 8; ++x) g.n_units[x] = 0;
+      for (int a = 0; a < nu; ++a) {
+        int bx = -1;
+        for (int x = 0; x < 8; ++x)
+          if (g.n_units[x] < WG_GROUP_MAX_UNITS && (bx < 0 || load[x] < load[bx])) bx = x;
+        int k = g.n_units[bx]++;
+        g.unit_start[bx][k] = (unsigned short)slots[bx];
+        g.unit_code[bx][k] = (unsigned short)(us[a].p | (us[a].tap << 5) | (us[a].s << 9));
+        slots[bx] += us[a].tiles; load[bx] += us[a].w;
+        UNIT_CHECK_ARG(slots[bx] < 65536, "wgrad_group: more than 65535 workgroups on one XCD");
+      }
+      int most = 0;
+      for (int x = 0; x < 8; ++x) {
+        g.unit_start[x][g.n_units[x]] = (unsigned short)slots[x];
+        if (slots[x] > most) most = slots[x];
+      }
+      int rc = kind == 2 ? unit_wgrad256_group_launch(g, most, (hipStream_t)stream) : unit_wgrad128_group_launch(g, most, (hipStream_t)stream);
+      if (rc != UNIT_OK) return rc;
     }
-    for (int a = 1; a < nu; ++a) {           // insertion sort, stable, descending weight (<= 128 entries)
-      U v = us[a]; int b = a - 1;
-      while (b >= 0 && us[b].w < v.w) { us[b + 1] = us[b]; --b; }
-      us[b + 1] = v;
-    }
-    long load[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    int slots[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    for (int x = 0; x < 8; ++x) g.n_units[x] = 0;
-    for (int a = 0; a < nu; ++a) {
-      int bx = -1;
-      for (int x = 0; x < 8; ++x)
-        if (g.n_units[x] < WG_GROUP_MAX_UNITS && (bx < 0 || load[x] < load[bx])) bx = x;
-      int k = g.n_units[bx]++;
-      g.unit_start[bx][k] = (unsigned short)slots[bx];
-      g.unit_code[bx][k] = (unsigned short)(us[a].p | (us[a].s << 8));
-      slots[bx] += us[a].tiles; load[bx] += us[a].w;
-      UNIT_CHECK_ARG(slots[bx] < 65536, "wgrad_group: more than 65535 workgroups on one XCD");
-    }
-    int most = 0;
-    for (int x = 0; x < 8; ++x) {
-      g.unit_start[x][g.n_units[x]] = (unsigned short)slots[x];
-      if (slots[x] > most) most = slots[x];
-    }
-    int rc = unit_wgrad128_group_launch(g, most, (hipStream_t)stream);
-    if (rc != UNIT_OK) return rc;
-    i0 += cnt;
   }
   return UNIT_OK;
 }

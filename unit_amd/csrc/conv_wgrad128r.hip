@@ -190,7 +190,7 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad128_group_kernel(WgradGroupA
   unsigned code = g.unit_code[xcd][u];
   // the layer's arguments into SGPRs ONCE: read in place, hipcc re-loads fields from the argument segment inside the pixel loop, and
   // every such s_load is followed by an lgkmcnt(0) wait that also drains the LDS reads in flight
-  const Wgrad256Args& src = g.p[code & 0xFF];
+  const Wgrad256Args& src = g.p[code & 31];
   Wgrad256Args p;
   p.x = pin_ptr(src.x); p.dy = pin_ptr(src.dy); p.partial = (float*)pin_ptr(src.partial);
   p.N = pin(src.N); p.H = pin(src.H); p.W = pin(src.W); p.C = pin(src.C); p.K = pin(src.K); p.R = pin(src.R); p.S = pin(src.S);
@@ -200,7 +200,7 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad128_group_kernel(WgradGroupA
   p.magic_ohw = (unsigned)pin((int)src.magic_ohw); p.magic_ow = (unsigned)pin((int)src.magic_ow); p.OHW = pin(src.OHW);
   p.use_magic = pin(src.use_magic); p.valid_only = 0;
   int t = slot - (int)g.unit_start[xcd][u];
-  wgrad128_ring_tile<NS>(p, t % p.tiles_k, t / p.tiles_k, (int)(code >> 8), smem);
+  wgrad128_ring_tile<NS>(p, t % p.tiles_k, t / p.tiles_k, (int)(code >> 9), smem);
 }
 
 int unit_wgrad128_group_launch(const WgradGroupArgs& g, int slots_per_xcd, hipStream_t st) {

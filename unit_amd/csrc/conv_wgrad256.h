@@ -21,18 +21,22 @@ struct Wgrad256Args {
   int valid_only;
 };
 
-// grouped launch of the 128x128 ring kernel (conv_wgrad128r.hip): up to 24 layers, their (layer, split) units dealt to the 8 XCDs.
-// Passed BY VALUE (3.6 KB of the 4 KB kernel-argument segment): the operand pointers change every step, a device-side table
+// grouped launches (conv_wgrad128r.hip: 128x128 ring tiles; conv_wgrad256p8.hip: 256x256 phase-interleaved tiles): up to 20 layers,
+// their units -- (layer, split), or (layer, filter tap, split) for valid_only layers -- dealt to the 8 XCDs.
+// Passed BY VALUE (3.4 KB of the 4 KB kernel-argument segment): the operand pointers change every step, a device-side table
 // would cost a host-to-device copy per launch.
-constexpr int WG_GROUP_MAX_PROBLEMS = 24;
-constexpr int WG_GROUP_MAX_UNITS = 16;           // per XCD
+constexpr int WG_GROUP_MAX_PROBLEMS = 20;
+constexpr int WG_GROUP_MAX_UNITS = 24;           // per XCD
+constexpr int WG_GROUP_MAX_SPLITS = 127;
 struct WgradGroupArgs {
   Wgrad256Args p[WG_GROUP_MAX_PROBLEMS];
   unsigned short unit_start[8][WG_GROUP_MAX_UNITS + 1];   // per XCD: first workgroup slot of unit i ([n_units] = the XCD's total)
-  unsigned short unit_code[8][WG_GROUP_MAX_UNITS];        // problem | split << 8
+  unsigned short unit_code[8][WG_GROUP_MAX_UNITS];        // problem (5 bits) | filter tap << 5 (4 bits) | split << 9
   int n_units[8];
 };
+static_assert(sizeof(WgradGroupArgs) <= 4000, "kernel-argument segment is 4 KB");
 int unit_wgrad128_group_launch(const WgradGroupArgs& g, int slots_per_xcd, hipStream_t st);
+int unit_wgrad256_group_launch(const WgradGroupArgs& g, int slots_per_xcd, hipStream_t st);
 
 typedef __attribute__((address_space(3))) void lds_void_w;
 typedef __attribute__((ext_vector_type(8))) short s16x8_w;

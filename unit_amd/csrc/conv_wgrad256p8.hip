@@ -22,94 +22,15 @@
 // vmcnt wait). Same m permutation inside a fragment and same accumulation order as conv_wgrad256.hip: bit-identical slabs.
 #include "conv_wgrad256.h"
 
-__global__ void __launch_bounds__(512, 2) conv_wgrad256_p8_kernel(Wgrad256Args p) {
+// one 256 x 256 tile of dW over the pixels [split * mps, +mps) of a contraction of Meff rows. vo (Wgrad256Args::valid_only): the rows are
+// (image, valid output position of the tile's filter tap): positions = rows v_oh0.. of the map, columns v_ow0.. of v_cw, nv per image.
+// TABN: entries of the pixel -> input offset table behind the operand stages (maps of up to TABN pixels avoid per-row divisions).
+template <int TABN>
+__device__ __forceinline__ void wgrad256_p8_tile(const Wgrad256Args& p, int tile_k, int tile_n, int split, const bool vo, int v_oh0, int v_ow0,
+                                                 int v_cw, int nv, int Meff, int mps, char* smem) {
   constexpr int MS = 64;
   constexpr int HALF = MS * 256;               // 16 KB
   constexpr int SX0 = 0, SD0 = HALF, SD1 = 2 * HALF, SX1 = 3 * HALF, BUF = 4 * HALF;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-
-  // XCD-aware remap (workgroup b runs on XCD b % 8): every XCD gets a contiguous chunk of (split, tile_n, tile_k) ids, i.e.
-  // the tiles of one or two split-M slabs. They walk the same pixel rows at the same pace, so an x / dy row block is
-  // fetched from HBM once per XCD and then served to the other tiles of the slab out of that XCD's 4 MB L2.
-  int bid = blockIdx.x;
-  const bool vo = p.valid_only != 0;
-  int tile_k, tile_n, split;
-  // valid_only (Wgrad256Args): the contraction index of a tile runs over (image, valid output position of ITS filter tap) instead of
-  // all pixels; valid positions = rows v_oh0 .. of the map, columns v_ow0 .. of v_cw (nv per image). The taps differ in work (36 / 42
-  // / 49 positions on 7x7) and the grid is one round of workgroups, so with the same split count for every tap the centre tap would
-  // set the time: the p.splits slabs include one spare, and 9 * (p.splits - 1) workgroup slots per (channel block, n tile) are dealt to
-  // the taps in proportion to their positions (7 x 7, 8 slabs: corners 6, edges 7, centre 8 splits -> 6.0 / 6.0 / 6.1 positions per
-  // split instead of 49 / 7). A workgroup past its tap's count ("filler") only leaves its slab tile zero.
-  int v_oh0 = 0, v_ow0 = 0, v_cw = p.OW, nv = p.OHW, Meff = p.M, mps = p.m_per_split;
-  if (!vo) {
-    int nwg = gridDim.x, q = nwg / 8, r = nwg % 8, xcd = bid % 8, loc = bid / 8;
-    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
-    tile_k = bid % p.tiles_k; int tt = bid / p.tiles_k;
-    tile_n = tt % p.tiles_n; split = tt / p.tiles_n;
-  } else {
-    const int ntap = p.R * p.S, ncb = p.tiles_k / ntap;
-    int nh[3], nw[3], sum_h = 0, sum_w = 0;
-#pragma unroll
-    for (int t = 0; t < 3; ++t) {
-      nh[t] = max(0, min(p.OH - 1, p.H - 1 + p.pad - t) - max(0, p.pad - t) + 1);
-      nw[t] = max(0, min(p.OW - 1, p.W - 1 + p.pad - t) - max(0, p.pad - t) + 1);
-      sum_h += nh[t]; sum_w += nw[t];
-    }
-    const int tot = sum_h * sum_w, slots = ntap * max(1, p.splits - 1);
-    int stt[9], sum_st = 0;
-#pragma unroll
-    for (int t = 0; t < 9; ++t) {
-      int v = nh[t / 3] * nw[t % 3];
-      stt[t] = max(1, min(p.splits, (slots * v + tot / 2) / tot));
-      sum_st += stt[t];
-    }
-    // id map: real work first on every XCD (workgroup b runs on XCD b % 8 and the XCD's workgroups start in id order), fillers last;
-    // real items ordered split-major (split j of every tap that has one, all n tiles and channel blocks: they walk about the same
-    // pixel rows at the same pace -- shared through the XCD's L2), each XCD a contiguous run of them
-    const int per = p.tiles_n * ncb;
-    const int RI = per * sum_st, nwg = gridDim.x;
-    const int xcd = bid % 8, loc = bid / 8;
-    const int start_r = xcd * (RI / 8) + min(xcd, RI % 8), real_x = RI / 8 + (xcd < RI % 8 ? 1 : 0);
-    const int start_t = xcd * (nwg / 8) + min(xcd, nwg % 8);
-    int tap = 0, cb = 0;
-    if (loc < real_x) {
-      int L = start_r + loc, j = 0;
-      for (;; ++j) {
-        int act = 0;
-#pragma unroll
-        for (int t = 0; t < 9; ++t) act += stt[t] > j ? 1 : 0;
-        if (L < per * act) {
-          tile_n = L / (ncb * act); int rem = L - tile_n * (ncb * act);
-          int a = rem / ncb; cb = rem - a * ncb;
-#pragma unroll
-          for (int t = 8; t >= 0; --t) { int before = 0; for (int u = 0; u < t; ++u) before += stt[u] > j ? 1 : 0; if (stt[t] > j && before == a) tap = t; }
-          break;
-        }
-        L -= per * act;
-      }
-      split = j;
-    } else {
-      int z = (start_t - start_r) + (loc - real_x);
-      tile_n = 0; split = p.splits;             // (overwritten below; z always lands in a tap)
-#pragma unroll
-      for (int t = 0; t < 9; ++t) {
-        int cnt = (p.splits - stt[t]) * per;
-        if (z >= 0 && z < cnt) {
-          int jj = z / per, rem = z - jj * per;
-          split = stt[t] + jj; tile_n = rem / ncb; cb = rem - tile_n * ncb; tap = t;
-          z = -1;
-        } else if (z >= 0) z -= cnt;
-      }
-    }
-    tile_k = tap * ncb + cb;
-    int kr_ = tap / p.S, ks_ = tap - kr_ * p.S;
-    v_oh0 = max(0, p.pad - kr_); v_ow0 = max(0, p.pad - ks_);
-    v_cw = nw[ks_]; nv = nh[kr_] * v_cw;
-    Meff = p.N * nv;
-    int st = stt[tap];
-    mps = ((Meff + st - 1) / st + 63) / 64 * 64;
-    if (split >= st) Meff = 0;
-  }
   int k0 = tile_k * 256, n0 = tile_n * 256;
   int rs = k0 / p.C, ch0 = k0 - rs * p.C, kr = rs / p.S, ksx = rs - kr * p.S;
   int m_begin = min(Meff, split * mps), m_end = min(Meff, m_begin + mps);
@@ -145,7 +66,7 @@ __global__ void __launch_bounds__(512, 2) conv_wgrad256_p8_kernel(Wgrad256Args p
   // tap ((ih*W + iw)*C, or -1 outside the map). Table after the operand stages (OHW <= 1024 entries; larger maps divide).
   int* tab = reinterpret_cast<int*>(smem + 2 * BUF);
   int* tabd = tab + 512;                          // valid_only: position index -> output pixel of the dy row (OHW <= 512 then)
-  const bool use_tab = !pointwise && p.OHW <= 1024;
+  const bool use_tab = !pointwise && p.OHW <= TABN;
   int xn[2] = {0, 0}, xp[2] = {0, 0};
   const int adv_q = MS / nv, adv_r = MS - adv_q * nv;
   if (use_tab) {
@@ -378,6 +299,95 @@ __global__ void __launch_bounds__(512, 2) conv_wgrad256_p8_kernel(Wgrad256Args p
 #endif
 }
 
+
+__global__ void __launch_bounds__(512, 2) conv_wgrad256_p8_kernel(Wgrad256Args p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  // XCD-aware remap (workgroup b runs on XCD b % 8): every XCD gets a contiguous chunk of (split, tile_n, tile_k) ids, i.e.
+  // the tiles of one or two split-M slabs. They walk the same pixel rows at the same pace, so an x / dy row block is
+  // fetched from HBM once per XCD and then served to the other tiles of the slab out of that XCD's 4 MB L2.
+  int bid = blockIdx.x;
+  const bool vo = p.valid_only != 0;
+  int tile_k, tile_n, split;
+  // valid_only (Wgrad256Args): the contraction index of a tile runs over (image, valid output position of ITS filter tap) instead of
+  // all pixels; valid positions = rows v_oh0 .. of the map, columns v_ow0 .. of v_cw (nv per image). The taps differ in work (36 / 42
+  // / 49 positions on 7x7) and the grid is one round of workgroups, so with the same split count for every tap the centre tap would
+  // set the time: the p.splits slabs include one spare, and 9 * (p.splits - 1) workgroup slots per (channel block, n tile) are dealt to
+  // the taps in proportion to their positions (7 x 7, 8 slabs: corners 6, edges 7, centre 8 splits -> 6.0 / 6.0 / 6.1 positions per
+  // split instead of 49 / 7). A workgroup past its tap's count ("filler") only leaves its slab tile zero.
+  int v_oh0 = 0, v_ow0 = 0, v_cw = p.OW, nv = p.OHW, Meff = p.M, mps = p.m_per_split;
+  if (!vo) {
+    int nwg = gridDim.x, q = nwg / 8, r = nwg % 8, xcd = bid % 8, loc = bid / 8;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+    tile_k = bid % p.tiles_k; int tt = bid / p.tiles_k;
+    tile_n = tt % p.tiles_n; split = tt / p.tiles_n;
+  } else {
+    const int ntap = p.R * p.S, ncb = p.tiles_k / ntap;
+    int nh[3], nw[3], sum_h = 0, sum_w = 0;
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+      nh[t] = max(0, min(p.OH - 1, p.H - 1 + p.pad - t) - max(0, p.pad - t) + 1);
+      nw[t] = max(0, min(p.OW - 1, p.W - 1 + p.pad - t) - max(0, p.pad - t) + 1);
+      sum_h += nh[t]; sum_w += nw[t];
+    }
+    const int tot = sum_h * sum_w, slots = ntap * max(1, p.splits - 1);
+    int stt[9], sum_st = 0;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      int v = nh[t / 3] * nw[t % 3];
+      stt[t] = max(1, min(p.splits, (slots * v + tot / 2) / tot));
+      sum_st += stt[t];
+    }
+    // id map: real work first on every XCD (workgroup b runs on XCD b % 8 and the XCD's workgroups start in id order), fillers last;
+    // real items ordered split-major (split j of every tap that has one, all n tiles and channel blocks: they walk about the same
+    // pixel rows at the same pace -- shared through the XCD's L2), each XCD a contiguous run of them
+    const int per = p.tiles_n * ncb;
+    const int RI = per * sum_st, nwg = gridDim.x;
+    const int xcd = bid % 8, loc = bid / 8;
+    const int start_r = xcd * (RI / 8) + min(xcd, RI % 8), real_x = RI / 8 + (xcd < RI % 8 ? 1 : 0);
+    const int start_t = xcd * (nwg / 8) + min(xcd, nwg % 8);
+    int tap = 0, cb = 0;
+    if (loc < real_x) {
+      int L = start_r + loc, j = 0;
+      for (;; ++j) {
+        int act = 0;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) act += stt[t] > j ? 1 : 0;
+        if (L < per * act) {
+          tile_n = L / (ncb * act); int rem = L - tile_n * (ncb * act);
+          int a = rem / ncb; cb = rem - a * ncb;
+#pragma unroll
+          for (int t = 8; t >= 0; --t) { int before = 0; for (int u = 0; u < t; ++u) before += stt[u] > j ? 1 : 0; if (stt[t] > j && before == a) tap = t; }
+          break;
+        }
+        L -= per * act;
+      }
+      split = j;
+    } else {
+      int z = (start_t - start_r) + (loc - real_x);
+      tile_n = 0; split = p.splits;             // (overwritten below; z always lands in a tap)
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        int cnt = (p.splits - stt[t]) * per;
+        if (z >= 0 && z < cnt) {
+          int jj = z / per, rem = z - jj * per;
+          split = stt[t] + jj; tile_n = rem / ncb; cb = rem - tile_n * ncb; tap = t;
+          z = -1;
+        } else if (z >= 0) z -= cnt;
+      }
+    }
+    tile_k = tap * ncb + cb;
+    int kr_ = tap / p.S, ks_ = tap - kr_ * p.S;
+    v_oh0 = max(0, p.pad - kr_); v_ow0 = max(0, p.pad - ks_);
+    v_cw = nw[ks_]; nv = nh[kr_] * v_cw;
+    Meff = p.N * nv;
+    int st = stt[tap];
+    mps = ((Meff + st - 1) / st + 63) / 64 * 64;
+    if (split >= st) Meff = 0;
+  }
+  wgrad256_p8_tile<1024>(p, tile_k, tile_n, split, vo, v_oh0, v_ow0, v_cw, nv, Meff, mps, smem);
+}
+
 int unit_wgrad256_p8_launch(const Wgrad256Args& a, hipStream_t st) {
   size_t lds = 8 * 64 * 256 + 4096;      // operand stages + the pixel -> input offset table
   static bool attr_set = false;
@@ -386,6 +396,64 @@ int unit_wgrad256_p8_launch(const Wgrad256Args& a, hipStream_t st) {
     attr_set = true;
   }
   conv_wgrad256_p8_kernel<<<a.tiles_k * a.tiles_n * a.splits, 512, lds, st>>>(a);
+  UNIT_LAUNCH_CHECK();
+  return UNIT_OK;
+}
+
+// ---- grouped launch (include/unit_hip.h: unit_conv2d_wgrad_group): the 256x256 tiles of SEVERAL layers in one grid. A unit = the tiles of
+// one (layer, split) -- for valid_only layers of one (layer, filter tap, split): they contract over the same rows -- dealt to ONE XCD by
+// the host (conv_wgrad.hip), longest first. With the layers of a Res5 head in one grid every layer needs 3-4 split-M slabs instead of
+// 8-16 (launched alone, 16 tiles have to become 256 workgroups): a quarter of the slab traffic, 200-step loops; the res4 layers of a
+// gradient bucket get 256x256 tiles at all (half the operand bytes per flop of the 128x128 ring kernel).
+__device__ __forceinline__ int pinw(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ const void* pinw_ptr(const void* q) {
+  unsigned long long u = (unsigned long long)(uintptr_t)q;
+  unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)u), hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(u >> 32));
+  return (const void*)(uintptr_t)(((unsigned long long)hi << 32) | lo);
+}
+
+__global__ void __launch_bounds__(512, 2) conv_wgrad256_group_kernel(WgradGroupArgs g) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  int nu = g.n_units[xcd];
+  if (slot >= (int)g.unit_start[xcd][nu]) return;
+  int u = 0;
+  for (int i = 1; i < nu; ++i)
+    if (slot >= (int)g.unit_start[xcd][i]) u = i;
+  unsigned code = g.unit_code[xcd][u];
+  const Wgrad256Args& src = g.p[code & 31];     // into SGPRs once (conv_wgrad128r.hip)
+  Wgrad256Args p;
+  p.x = pinw_ptr(src.x); p.dy = pinw_ptr(src.dy); p.partial = (float*)pinw_ptr(src.partial);
+  p.N = pinw(src.N); p.H = pinw(src.H); p.W = pinw(src.W); p.C = pinw(src.C); p.K = pinw(src.K); p.R = pinw(src.R); p.S = pinw(src.S);
+  p.stride = pinw(src.stride); p.pad = pinw(src.pad); p.OH = pinw(src.OH); p.OW = pinw(src.OW); p.ldy = pinw(src.ldy);
+  p.Kgemm = pinw(src.Kgemm); p.M = pinw(src.M); p.tiles_k = pinw(src.tiles_k); p.tiles_n = pinw(src.tiles_n); p.splits = pinw(src.splits);
+  p.m_per_split = pinw(src.m_per_split); p.x_bytes = (unsigned)pinw((int)src.x_bytes); p.dy_bytes = (unsigned)pinw((int)src.dy_bytes);
+  p.magic_ohw = (unsigned)pinw((int)src.magic_ohw); p.magic_ow = (unsigned)pinw((int)src.magic_ow); p.OHW = pinw(src.OHW);
+  p.use_magic = pinw(src.use_magic); p.valid_only = pinw(src.valid_only);
+  int t = slot - (int)g.unit_start[xcd][u];
+  int tap = (int)((code >> 5) & 15), split = (int)(code >> 9);
+  if (p.valid_only) {
+    int ncb = p.tiles_k / (p.R * p.S);
+    int kr_ = tap / p.S, ks_ = tap - kr_ * p.S;
+    int nh = max(0, min(p.OH - 1, p.H - 1 + p.pad - kr_) - max(0, p.pad - kr_) + 1);
+    int nw = max(0, min(p.OW - 1, p.W - 1 + p.pad - ks_) - max(0, p.pad - ks_) + 1);
+    int Meff = p.N * nh * nw;
+    int mps = ((Meff + p.splits - 1) / p.splits + 63) / 64 * 64;
+    int tile_n = t / ncb, cb = t - tile_n * ncb;
+    wgrad256_p8_tile<4096>(p, tap * ncb + cb, tile_n, split, true, max(0, p.pad - kr_), max(0, p.pad - ks_), nw, nh * nw, Meff, mps, smem);
+  } else {
+    wgrad256_p8_tile<4096>(p, t % p.tiles_k, t / p.tiles_k, split, false, 0, 0, p.OW, p.OHW, p.M, p.m_per_split, smem);
+  }
+}
+
+int unit_wgrad256_group_launch(const WgradGroupArgs& g, int slots_per_xcd, hipStream_t st) {
+  size_t lds = 8 * 64 * 256 + 4 * 4096;      // operand stages + a 4096-entry pixel -> input offset table
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)conv_wgrad256_group_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  conv_wgrad256_group_kernel<<<slots_per_xcd * 8, 512, lds, st>>>(g);
   UNIT_LAUNCH_CHECK();
   return UNIT_OK;
 }

@@ -54,7 +54,7 @@ class ConvPlan:
         # weight gradients waiting for a grouped launch (csrc/conv_wgrad128r.hip: conv_wgrad128_group_kernel): the small-M layers of
         # a gradient bucket go out as ONE grid at the bucket boundary instead of one under-filled, many-slab launch per layer
         self.group_wgrads = not bool(int(os.environ.get("UNIT_NO_WGRAD_GROUP", "0")))      # A/B switch for tools/
-        self.group_splits_hint = 0          # tools/: > 0 overrides the library's split choice
+        self.group_splits_hint = int(os.environ.get("UNIT_WGRAD_GROUP_SPLITS", "0"))      # tools/: > 0 overrides the library's split choice
         self._deferred = []                 # (conv, x, dy, stride, accumulate, raw stream that produced x / dy)
 
     def _build(self, convs, with_partial, entries=None):

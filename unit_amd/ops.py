@@ -472,7 +472,7 @@ def conv2d_wgrad_partial(x, dy, k, r, s, stride, pad, slab=None, variant=0):
 class WgradProblem(ctypes.Structure):
     """include/unit_hip.h: UnitWgradProblem"""
     _fields_ = [("x", ctypes.c_void_p), ("dy", ctypes.c_void_p), ("partial", ctypes.c_void_p)] + \
-               [(f, ctypes.c_int) for f in ("N", "H", "W", "C", "K", "R", "S", "stride", "pad", "OH", "OW", "ldy", "splits", "reserved")]
+               [(f, ctypes.c_int) for f in ("N", "H", "W", "C", "K", "R", "S", "stride", "pad", "OH", "OW", "ldy", "splits", "kind")]
 
 
 def wgrad_group_supported(x, dy, k, r, s, stride, pad):
