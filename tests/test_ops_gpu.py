@@ -404,6 +404,33 @@ def test_wgrad_group_more_layers_than_one_launch_holds(dev):
         assert (got - ref).abs().max().item() <= 2e-5 * ref.abs().max().item()
 
 
+def test_wgrad_group_tile_kinds(dev):
+    """the plan's tile kinds: Res5-sized layers get 256x256 tiles, a lone two-tile layer joins the 128x128 grid, 128-channel layers
+    always do; a Res5-like group alone (3x3 valid-only + pointwise + stride 2) sums to the per-layer result"""
+    o = ops()
+    import ctypes
+    def kinds(cases, hint=0):
+        pr = (o.WgradProblem * len(cases))()
+        for q, (n, h, w, c, k, r, stride, pad) in zip(pr, cases):
+            oh, ow = o.conv_out_size(h, w, r, r, stride, pad)
+            q.N, q.H, q.W, q.C, q.K, q.R, q.S, q.stride, q.pad, q.OH, q.OW, q.ldy = n, h, w, c, k, r, r, stride, pad, oh, ow, k
+        assert o.lib().unit_conv2d_wgrad_group_plan(pr, len(cases), hint) == 0
+        return [(q.kind, q.splits) for q in pr]
+    res5 = [(1024, 14, 14, 1024, 512, 1, 2, 0), (1024, 7, 7, 512, 512, 3, 1, 1), (1024, 7, 7, 512, 2048, 1, 1, 0)]
+    assert [k for k, _ in kinds(res5)] == [2, 2, 2]
+    assert kinds([(4, 150, 250, 256, 512, 1, 2, 0)])[0][0] == 1                     # 2 tiles of 256: the 128x128 grid
+    assert [k for k, _ in kinds([(4, 75, 125, 128, 128, 3, 1, 1), (4, 38, 63, 256, 256, 3, 1, 1), (4, 38, 63, 1024, 256, 1, 1, 0), (4, 38, 63, 256, 1024, 1, 1, 0)])] == [1, 2, 2, 2]
+    bucket = [(4, 38, 63, 1024, 256, 1, 1, 0), (4, 38, 63, 256, 256, 3, 1, 1), (4, 38, 63, 256, 1024, 1, 1, 0)] * 6
+    assert all(ks == (2, 2) for ks in kinds(bucket))                                # the fullest single round of 256 workgroups
+    small = [(300, 7, 7, 512, 256, 1, 1, 0), (300, 7, 7, 256, 256, 3, 1, 1), (300, 14, 14, 512, 512, 1, 2, 0), (300, 7, 7, 256, 512, 1, 1, 0)]
+    items = _group_inputs(o, dev, small, 53)
+    res = o.conv2d_wgrad_group(items)
+    for (x, dy, k, r, s, stride, pad), (slab, sp) in zip(items, res):
+        got = _fold(slab, sp, k, r, x.shape[-1]).sum(0).cpu()
+        ref = o.conv2d_wgrad(x, dy, k, r, s, stride, pad).cpu()
+        assert (got - ref).abs().max().item() <= 2e-5 * ref.abs().max().item()
+
+
 def test_wgrad_group_rejects_ineligible_layers(dev):
     o = ops()
     x = torch.randn(2, 8, 8, 64, device=dev).bfloat16()

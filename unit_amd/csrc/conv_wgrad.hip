@@ -358,7 +358,7 @@ extern "C" int unit_conv2d_wgrad_group_plan(UnitWgradProblem* pr, int n, int spl
   long tiles2 = 0;
   for (int i = 0; i < n; ++i)
     if (pr[i].kind == 2) tiles2 += (long)(pr[i].R * pr[i].S * pr[i].C / 256) * (pr[i].K / 256);
-  if (tiles2 < 64)
+  if (tiles2 < 16)
     for (int i = 0; i < n; ++i)
       if (pr[i].kind == 2) pr[i].kind = 1;
   for (int kind = 1; kind <= 2; ++kind) {
