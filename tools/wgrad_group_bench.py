@@ -1,10 +1,10 @@
 """Grouped weight-gradient launches vs one launch per layer, isolated (HIP events, L2-cold-ish: operands of ~1 GB rotate):
-python tools/wgrad_group_bench.py [res5|res4|res3]"""
+python tools/wgrad_group_bench.py [res5|res4|res3] [split hints ...]"""
 import sys
 
 import torch
 
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 from unit_amd import ops
 
 
@@ -58,7 +58,8 @@ def main():
     sp = [ops.lib().unit_conv2d_wgrad_splits(ops.dt(torch.bfloat16), x.shape[0], dy.shape[1], dy.shape[2], k, r, s, x.shape[-1]) for x, dy, k, r, s, _, _ in items]
     print(f"{which}: {len(items)} layers, {flops / 1e9:.0f} GFLOP")
     print(f"  one launch per layer   {t:8.1f} us  {flops / t / 1e6:7.1f} TF/s   splits {sp}")
-    for hint in (0, 1, 2, 3, 4, 6, 8):
+    hints = [int(a) for a in sys.argv[2:]] or [0, 1, 2, 3, 4, 6, 8]
+    for hint in hints:
         gs = [None] * len(items)
         out = ops.conv2d_wgrad_group(items, gs, splits_hint=hint)
         gs = [o[0] for o in out]

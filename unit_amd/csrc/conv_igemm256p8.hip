@@ -27,6 +27,9 @@
 //        t+1 by either group comes after the barrier that ends that interval.
 // Same swizzle / k order / accumulation order / epilogue as conv_igemm256.hip: results are bit-identical to it.
 #include "conv_igemm256.h"
+#ifndef UNIT_P8_FINE_WAIT
+#define UNIT_P8_FINE_WAIT 0      // 1: one counted vmcnt wait per half-tile instead of one per k-tile / step (tools/exp_wait.sh: measured 1-8 % slower)
+#endif
 #include "conv_epilogue.h"
 
 // diagnostic builds only (tools/exp_p8.sh): 1 = no LDS-DMA inside the loop, 2 = MFMAs replaced by one VALU add per fragment,
@@ -250,6 +253,9 @@ __global__ void __launch_bounds__(512, 2) conv_igemm256_p8_kernel(Conv256Args p)
     //        W1(t): M(t, 0) -> L(t, 3): 3.
     //   RAW: vmcnt in L(t, 2) of both groups (two half-tiles younger than k-tile t+1 may stay in flight); first read of
     //        k-tile t+1 in M(t, 3), which for either group starts after the barrier that ends the later group's L(t, 2).
+    //        (UNIT_P8_FINE_WAIT=1: every half-tile waited for separately, with the four half-tiles issued after it still in flight, one
+    //        phase before the MFMA section that reads it -- X1(t+1) then has four phases to land instead of two. Measured 1-8 % SLOWER
+    //        on every Res5 / RPN shape, profiles/r03_exp_fine_vmcnt.txt: the loop is not waiting for that half-tile.)
     i32x4 fxb[B1][2];
     auto read_xb = [&](const char* half) {
 #pragma unroll
@@ -296,6 +302,10 @@ __global__ void __launch_bounds__(512, 2) conv_igemm256_p8_kernel(Conv256Args p)
       // phase 0
       if (n1) stage_x(1, d ^ 1);
       st_advance();
+#if UNIT_P8_FINE_WAIT
+      if (n1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");      // X1(t) landed (read in M(t, 1)); X0, W0, W1, X1 of t+1 younger
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
       P8_BAR();
       P8_MM(0, 0, fw0, fx, 4, 4, read_w(buf + SW1, fw1));
       P8_BAR();
@@ -305,17 +315,32 @@ __global__ void __launch_bounds__(512, 2) conv_igemm256_p8_kernel(Conv256Args p)
       P8_MM(0, 1, fw1, fx, 4, 2 * B1, read_xb(buf + SX1));
       P8_BAR();
       // phase 2
+#if UNIT_P8_FINE_WAIT
+      if (n2) {
+        stage_w(0, d);
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");             // X0, W0 of t+1 landed (read in M(t, 3)); W1, X1 of t+1, X0, W0 of t+2 younger
+      } else if (n1) {
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");             // W1, X1 of t+1 younger
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+#else
       if (n2) {
         stage_w(0, d);
         asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
       } else {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       }
+#endif
       P8_BAR();
       P8_MM(1, 0, fw0, fxb, B1, 0, (void)0);
       P8_BAR();
       // phase 3 (after the last k-tile the reads fetch stale, in-bounds LDS that nobody uses)
       if (n2) stage_w(1, d);
+#if UNIT_P8_FINE_WAIT
+      if (n2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");       // W1(t+1) landed (read in M(t+1, 0)); X1(t+1), X0, W0, W1 of t+2 younger
+      else if (n1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");  // X1(t+1) younger
+#endif
       P8_BAR();
       P8_MM(1, 1, fw1, fxb, B1, 12, read_w(bnx + SW0, fw0); read_x(bnx + SX0));
       P8_BAR();

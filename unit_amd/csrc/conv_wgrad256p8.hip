@@ -19,8 +19,11 @@
 //   phase 3: stage D1(t+2) ; quadrant (1,1) = fxb x fd1 || read X0(t+1) -> fx, D0(t+1) -> fd0
 // WAR / RAW distances are those of conv_igemm256p8.hip (reads retired by lgkmcnt(0) before the barrier that ends their
 // MFMA section; a slot is restaged >= 2 phases after its last read; first read of step t+1 one phase after both groups'
-// vmcnt wait). Same m permutation inside a fragment and same accumulation order as conv_wgrad256.hip: bit-identical slabs.
+// vmcnt wait; UNIT_P8_FINE_WAIT as there). Same m permutation inside a fragment and same accumulation order as conv_wgrad256.hip: bit-identical slabs.
 #include "conv_wgrad256.h"
+#ifndef UNIT_P8_FINE_WAIT
+#define UNIT_P8_FINE_WAIT 0      // 1: one counted vmcnt wait per half-tile instead of one per k-tile / step (tools/exp_wait.sh: measured 1-8 % slower)
+#endif
 
 // one 256 x 256 tile of dW over the pixels [split * mps, +mps) of a contraction of Meff rows. vo (Wgrad256Args::valid_only): the rows are
 // (image, valid output position of the tile's filter tap): positions = rows v_oh0.. of the map, columns v_ow0.. of v_cw, nv per image.
@@ -186,12 +189,12 @@ __device__ __forceinline__ void wgrad256_p8_tile(const Wgrad256Args& p, int tile
       _Pragma("unroll") for (int sub = 0; sub < 2; ++sub) FD[b][sub] = frag(HALFP, offd[b], sub); \
   } while (0)
 #define W8_BAR() do { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); } while (0)
-#if defined(UNIT_DBGW8) && UNIT_DBGW8 == 3
+#if defined(UNIT_DBGW8) && (UNIT_DBGW8 & 4)
 #define W8_FMA(ACC, A, B) do { if (b == 0) ACC += __builtin_bit_cast(f32x4, A); if (a == 0) ACC += __builtin_bit_cast(f32x4, B); } while (0)
 #else
 #define W8_FMA(ACC, A, B) ACC = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A, B, ACC, 0, 0, 0)
 #endif
-#if defined(UNIT_DBGW8) && UNIT_DBGW8 == 4
+#if defined(UNIT_DBGW8) && (UNIT_DBGW8 & 8)
 #define W8_RD(stmt) do { if (t == 0) { stmt; } } while (0)
 #else
 #define W8_RD(stmt) do { stmt; } while (0)
@@ -234,7 +237,7 @@ __device__ __forceinline__ void wgrad256_p8_tile(const Wgrad256Args& p, int tile
       const int d = t & 1;
       const char* buf = smem + d * BUF;
       const char* bnx = smem + (d ^ 1) * BUF;
-#if defined(UNIT_DBGW8) && UNIT_DBGW8 == 2
+#if defined(UNIT_DBGW8) && (UNIT_DBGW8 & 2)
       const bool n1 = false, n2 = false;
 #else
       const bool n1 = t + 1 < nsteps, n2 = t + 2 < nsteps;
@@ -242,6 +245,10 @@ __device__ __forceinline__ void wgrad256_p8_tile(const Wgrad256Args& p, int tile
       // phase 0
       if (n1) stage_x(1, d ^ 1, mst);
       mst += MS; x_advance();
+#if UNIT_P8_FINE_WAIT
+      if (n1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");      // X1(t) landed (read in M(t, 1)); X0, D0, D1, X1 of t+1 younger
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
       W8_BAR();
       W8_MM(0, 0, fx, fd0, 8, 1, W8_RD(W8_READ_D(buf + SD1, fd1)));
       W8_BAR();
@@ -251,17 +258,32 @@ __device__ __forceinline__ void wgrad256_p8_tile(const Wgrad256Args& p, int tile
       W8_MM(0, 1, fx, fd1, 16, 1, W8_RD(W8_READ_X(buf + SX1, fxb)));
       W8_BAR();
       // phase 2
+#if UNIT_P8_FINE_WAIT
+      if (n2) {
+        stage_d(0, d, mst);
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");             // X0, D0 of t+1 landed (read in M(t, 3)); D1, X1 of t+1, X0, D0 of t+2 younger
+      } else if (n1) {
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");             // D1, X1 of t+1 younger
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+#else
       if (n2) {
         stage_d(0, d, mst);
         asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
       } else {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       }
+#endif
       W8_BAR();
       W8_MM(1, 0, fxb, fd0, 0, 0, (void)0);
       W8_BAR();
       // phase 3 (after the last step the reads fetch stale, in-bounds LDS that nobody uses)
       if (n2) stage_d(1, d, mst);
+#if UNIT_P8_FINE_WAIT
+      if (n2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");       // D1(t+1) landed (read in M(t+1, 0)); X1(t+1), X0, D0, D1 of t+2 younger
+      else if (n1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");  // X1(t+1) younger
+#endif
       W8_BAR();
       W8_MM(1, 1, fxb, fd1, 24, 2, W8_RD(W8_READ_D(bnx + SD0, fd0); W8_READ_X(bnx + SX0, fx)));
       W8_BAR();
@@ -278,7 +300,7 @@ __device__ __forceinline__ void wgrad256_p8_tile(const Wgrad256Args& p, int tile
   // epilogue: D[row = k][col = n] -> partial[split][n][k..k+3]
   float* out = p.partial + (size_t)split * p.K * p.Kgemm;
   int fq = lane >> 4, fr = lane & 15;
-#if defined(UNIT_DBGW8) && UNIT_DBGW8 == 1
+#if defined(UNIT_DBGW8) && (UNIT_DBGW8 & 1)
   // diagnostic build only (tools/exp_w8.sh): one store per lane instead of 32 -- what does the slab store cost?
   f32x4 ssum = acc[0][0];
 #pragma unroll
