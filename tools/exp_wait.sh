@@ -1,11 +1,12 @@
 #!/bin/bash
 # A/B of the counted vmcnt waits of the phase-interleaved 256x256 kernels (conv_igemm256p8.hip, conv_wgrad256p8.hip): one wait per
 # k-tile (the production schedule) vs one per half-tile (UNIT_P8_FINE_WAIT=1). `tools/exp_wait.sh build` here, `tools/exp_wait.sh` on the GPU box.
+EXPFLAGS=${EXPFLAGS:--DUNIT_P8_FINE_WAIT=1}
 if [ "$1" = build ]; then
   python3 -c "import __graft_entry__ as g; g.build()"
   mkdir -p unit_amd/_build/waitexp
   for f in conv_igemm256p8 conv_wgrad256p8; do
-    /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fPIC -ffp-contract=off -std=c++17 -Wno-unused-value -DUNIT_P8_FINE_WAIT=1 -c unit_amd/csrc/$f.hip -o unit_amd/_build/waitexp/$f.o || exit 1
+    /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fPIC -ffp-contract=off -std=c++17 -Wno-unused-value $EXPFLAGS -c unit_amd/csrc/$f.hip -o unit_amd/_build/waitexp/$f.o || exit 1
   done
   objs=$(ls unit_amd/_build/*.o | grep -v "conv_igemm256p8.o\|conv_wgrad256p8.o")
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o unit_amd/_build/waitexp/libunit_hip.so $objs unit_amd/_build/waitexp/*.o || exit 1

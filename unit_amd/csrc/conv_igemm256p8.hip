@@ -27,6 +27,9 @@
 //        t+1 by either group comes after the barrier that ends that interval.
 // Same swizzle / k order / accumulation order / epilogue as conv_igemm256.hip: results are bit-identical to it.
 #include "conv_igemm256.h"
+#ifndef UNIT_P8_RD_PER
+#define UNIT_P8_RD_PER 1        // fragment reads per MFMA gap inside the MFMA sections of phases 1 and 3 (tools/exp_wait.sh)
+#endif
 #ifndef UNIT_P8_FINE_WAIT
 #define UNIT_P8_FINE_WAIT 0      // 1: one counted vmcnt wait per half-tile instead of one per k-tile / step (tools/exp_wait.sh: measured 1-8 % slower)
 #endif
@@ -264,7 +267,7 @@ __global__ void __launch_bounds__(512, 2) conv_igemm256_p8_kernel(Conv256Args p)
         fxb[b][1] = *reinterpret_cast<const i32x4*>(half + b * 2048 + (offx ^ 64));
       }
     };
-#define P8_MM(QX, QW, FW, FX, NB, NR, READS)                                             \
+#define P8_MM(QX, QW, FW, FX, NB, NR, PER, READS)                                        \
     do {                                                                                 \
       __builtin_amdgcn_s_setprio(1);                                                     \
       READS;                                                                             \
@@ -272,11 +275,11 @@ __global__ void __launch_bounds__(512, 2) conv_igemm256_p8_kernel(Conv256Args p)
         _Pragma("unroll") for (int a = 0; a < 2; ++a)                                    \
           _Pragma("unroll") for (int b = 0; b < (NB); ++b)                               \
             acc[(QW) * 2 + a][(QX) * 4 + b] = MFMA_BF16(FW[a][ks], FX[b][ks], acc[(QW) * 2 + a][(QX) * 4 + b]); \
-      _Pragma("unroll") for (int i = 0; i < (NR); ++i) {                                 \
+      _Pragma("unroll") for (int i = 0; i < (NR) / (PER); ++i) {                         \
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                               \
-        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                               \
+        __builtin_amdgcn_sched_group_barrier(0x100, (PER), 0);                           \
       }                                                                                  \
-      if (4 * (NB) - (NR) > 0) __builtin_amdgcn_sched_group_barrier(0x008, 4 * (NB) - (NR) > 0 ? 4 * (NB) - (NR) : 1, 0); \
+      if (4 * (NB) - (NR) / (PER) > 0) __builtin_amdgcn_sched_group_barrier(0x008, 4 * (NB) - (NR) / (PER) > 0 ? 4 * (NB) - (NR) / (PER) : 1, 0); \
       __builtin_amdgcn_s_setprio(0);                                                     \
       if ((NR) > 0) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                   \
     } while (0)
@@ -307,12 +310,12 @@ __global__ void __launch_bounds__(512, 2) conv_igemm256_p8_kernel(Conv256Args p)
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
       P8_BAR();
-      P8_MM(0, 0, fw0, fx, 4, 4, read_w(buf + SW1, fw1));
+      P8_MM(0, 0, fw0, fx, 4, 4, 1, read_w(buf + SW1, fw1));
       P8_BAR();
       // phase 1
       if (n2) stage_x(0, d);
       P8_BAR();
-      P8_MM(0, 1, fw1, fx, 4, 2 * B1, read_xb(buf + SX1));
+      P8_MM(0, 1, fw1, fx, 4, 2 * B1, UNIT_P8_RD_PER, read_xb(buf + SX1));
       P8_BAR();
       // phase 2
 #if UNIT_P8_FINE_WAIT
@@ -333,7 +336,7 @@ __global__ void __launch_bounds__(512, 2) conv_igemm256_p8_kernel(Conv256Args p)
       }
 #endif
       P8_BAR();
-      P8_MM(1, 0, fw0, fxb, B1, 0, (void)0);
+      P8_MM(1, 0, fw0, fxb, B1, 0, 1, (void)0);
       P8_BAR();
       // phase 3 (after the last k-tile the reads fetch stale, in-bounds LDS that nobody uses)
       if (n2) stage_w(1, d);
@@ -342,7 +345,7 @@ __global__ void __launch_bounds__(512, 2) conv_igemm256_p8_kernel(Conv256Args p)
       else if (n1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");  // X1(t+1) younger
 #endif
       P8_BAR();
-      P8_MM(1, 1, fw1, fxb, B1, 12, read_w(bnx + SW0, fw0); read_x(bnx + SX0));
+      P8_MM(1, 1, fw1, fxb, B1, 12, UNIT_P8_RD_PER, read_w(bnx + SW0, fw0); read_x(bnx + SX0));
       P8_BAR();
     }
     if (grp == 0) P8_BAR();

@@ -21,6 +21,11 @@
 // MFMA section; a slot is restaged >= 2 phases after its last read; first read of step t+1 one phase after both groups'
 // vmcnt wait; UNIT_P8_FINE_WAIT as there). Same m permutation inside a fragment and same accumulation order as conv_wgrad256.hip: bit-identical slabs.
 #include "conv_wgrad256.h"
+#ifndef UNIT_W8_PER0
+#define UNIT_W8_PER0 1          // transposing fragment reads per MFMA gap in phases 0 / 1 / 3 (tools/exp_wait.sh)
+#define UNIT_W8_PER1 1
+#define UNIT_W8_PER3 2
+#endif
 #ifndef UNIT_P8_FINE_WAIT
 #define UNIT_P8_FINE_WAIT 0      // 1: one counted vmcnt wait per half-tile instead of one per k-tile / step (tools/exp_wait.sh: measured 1-8 % slower)
 #endif
@@ -250,12 +255,12 @@ __device__ __forceinline__ void wgrad256_p8_tile(const Wgrad256Args& p, int tile
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
       W8_BAR();
-      W8_MM(0, 0, fx, fd0, 8, 1, W8_RD(W8_READ_D(buf + SD1, fd1)));
+      W8_MM(0, 0, fx, fd0, 8, UNIT_W8_PER0, W8_RD(W8_READ_D(buf + SD1, fd1)));
       W8_BAR();
       // phase 1
       if (n2) stage_x(0, d, mst);
       W8_BAR();
-      W8_MM(0, 1, fx, fd1, 16, 1, W8_RD(W8_READ_X(buf + SX1, fxb)));
+      W8_MM(0, 1, fx, fd1, 16, UNIT_W8_PER1, W8_RD(W8_READ_X(buf + SX1, fxb)));
       W8_BAR();
       // phase 2
 #if UNIT_P8_FINE_WAIT
@@ -285,7 +290,7 @@ __device__ __forceinline__ void wgrad256_p8_tile(const Wgrad256Args& p, int tile
       else if (n1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");  // X1(t+1) younger
 #endif
       W8_BAR();
-      W8_MM(1, 1, fxb, fd1, 24, 2, W8_RD(W8_READ_D(bnx + SD0, fd0); W8_READ_X(bnx + SX0, fx)));
+      W8_MM(1, 1, fxb, fd1, 24, UNIT_W8_PER3, W8_RD(W8_READ_D(bnx + SD0, fd0); W8_READ_X(bnx + SX0, fx)));
       W8_BAR();
     }
     if (grp == 0) W8_BAR();
