@@ -431,6 +431,20 @@ def test_wgrad_group_tile_kinds(dev):
         assert (got - ref).abs().max().item() <= 2e-5 * ref.abs().max().item()
 
 
+def test_wgrad_group_layers_with_more_tiles_than_an_xcd_has_slots(dev):
+    """a layer's tiles are dealt to the XCDs in chunks of at most one XCD's workgroup slots (the RPN's 3x3 1024 -> 1024: 144 tiles of 256,
+    576 of 128): every tile of every slab is still written exactly once"""
+    o = ops()
+    cases = [(2, 38, 63, 1024, 1024, 3, 1, 1), (1, 20, 24, 1024, 1024, 3, 1, 1), (2, 40, 50, 512, 1024, 1, 1, 0)]
+    for hint in (0, 3):
+        items = _group_inputs(o, dev, cases, 59)
+        res = o.conv2d_wgrad_group(items, splits_hint=hint)
+        for (x, dy, k, r, s, stride, pad), (slab, sp) in zip(items, res):
+            got = _fold(slab, sp, k, r, x.shape[-1]).sum(0).cpu()
+            ref = o.conv2d_wgrad(x, dy, k, r, s, stride, pad).cpu()
+            assert (got - ref).abs().max().item() <= 2e-5 * ref.abs().max().item()
+
+
 def test_wgrad_group_rejects_ineligible_layers(dev):
     o = ops()
     x = torch.randn(2, 8, 8, 64, device=dev).bfloat16()

@@ -1,5 +1,5 @@
 """Grouped weight-gradient launches vs one launch per layer, isolated (HIP events, L2-cold-ish: operands of ~1 GB rotate):
-python tools/wgrad_group_bench.py [res5|res4|res3] [split hints ...]"""
+python tools/wgrad_group_bench.py [res5|res4|res3|rpn] [split hints ...]"""
 import sys
 
 import torch
@@ -18,6 +18,8 @@ def layers_of(which):
     elif which == "res4":     # a six-block gradient bucket of res4 on four 600x1000 images
         for _ in range(6):
             L += [(4, 38, 63, 1024, 256, 1, 1, 0), (4, 38, 63, 256, 256, 3, 1, 1), (4, 38, 63, 256, 1024, 1, 1, 0)]
+    elif which == "rpn":      # the RPN's 3x3 conv on the two supervised images
+        L += [(2, 38, 63, 1024, 1024, 3, 1, 1)]
     else:                     # res3: four blocks
         L += [(4, 150, 250, 256, 128, 1, 2, 0), (4, 75, 125, 128, 128, 3, 1, 1), (4, 75, 125, 128, 512, 1, 1, 0), (4, 150, 250, 256, 512, 1, 2, 0)]
         for _ in range(3):

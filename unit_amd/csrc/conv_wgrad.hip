@@ -347,7 +347,7 @@ static bool group_valid_only(const UnitWgradProblem& q) {
 // layer p gets s_p ~ s_ref * M_p / M_max slabs;
 //  kind 1 (two workgroups per CU): s_ref from choose_splits()'s cost model over the whole grid: rounds of 512 slots, ~4 us fixed + ~1 us
 //  per 64 pixels per workgroup, two transfers of every workgroup's 64 KB slab tile at ~4 TB/s;
-//  kind 2 (one per CU, long loops): the measured rule below.
+//  kind 2 (one per CU): rounds of 256 slots with the constants measured below.
 extern "C" int unit_conv2d_wgrad_group_plan(UnitWgradProblem* pr, int n, int splits_hint) {
   UNIT_CHECK_ARG(pr != nullptr && n > 0, "wgrad_group_plan: no problems");
   for (int i = 0; i < n; ++i) {
@@ -389,22 +389,25 @@ extern "C" int unit_conv2d_wgrad_group_plan(UnitWgradProblem* pr, int n, int spl
         if (cost < best_cost) { best_cost = cost; best = sref; }
       }
     } else {
-      // measured (tools/wgrad_group_bench.py): a Res5 head (236 tiles, 784 steps) runs 1.62 ms with 1-2 slabs per layer, 1.49-1.55 with
-      // 3-8 (units of 16-36 tiles quantise badly on an XCD's 32 CUs until there are several rounds of them); a res4 bucket (102 tiles,
-      // 150 steps) 315 / 177 / 219 / 176 / 191 / 209 us with 1 / 2 / 3 / 4 / 6 / 8. So: at least three rounds of workgroups if that
-      // leaves >= 48 steps per workgroup, else the fullest single round.
+      // rounds of 256 workgroups (one per CU), each ~12 us of fixed time (launch ramp, first loads, 256 KB slab store) + ~2.2 us per
+      // 64-pixel step when every CU streams. Fits tools/wgrad_group_bench.py within a few percent where the loops are short -- a res4
+      // bucket (102 tiles, 150 steps): 315 / 177 / 219 / 176 / 191 / 209 us measured with 1 / 2 / 3 / 4 / 6 / 8 slabs per layer, model 342 /
+      // 177 / 244 / 188 / 201 / 212; the RPN's 3x3 (144 tiles, 75 steps): 180 / 188 / 134 measured with 1 / 2 / 3, model 177 / 188 / 134.
+      // For the long loops of a Res5 head (236 tiles, 784 steps) the model is flat (1.74-1.82 ms) while 3-8 slabs measured 5-8 % faster
+      // than 1-2 (1.49-1.55 against 1.62 ms: units of 16-36 tiles quantise on an XCD's 32 CUs until there are several rounds of them):
+      // of the split counts within 3 % of the model's best, the largest. At least 24 steps per workgroup.
       long tiles = 0;
       for (int i = 0; i < n; ++i)
         if (pr[i].kind == kind) tiles += (long)(pr[i].R * pr[i].S * pr[i].C / T) * (pr[i].K / T);
-      long smax = (mmax / 64) / 48;
+      double steps = (double)((mmax + 63) / 64), tmin = 1e30;
+      int smax = (int)(steps / 24.0);
       if (smax < 1) smax = 1;
-      long s3 = (768 + tiles - 1) / tiles;
-      if (s3 <= smax) best = (int)s3;
-      else {
-        long one = 256 / tiles;
-        best = (int)(one >= 1 && one < smax ? one : smax);
-      }
-      if (best > 64) best = 64;
+      if (smax > 64) smax = 64;
+      // (a round counts as full at 90 % of its slots: the units are dealt to the XCDs by weight, not evenly by workgroup count)
+      auto model = [&](int sref) { return ceil((double)(tiles * sref) / (0.9 * 256.0)) * (12.0 + 2.2 * steps / sref); };
+      for (int sref = 1; sref <= smax; ++sref) tmin = model(sref) < tmin ? model(sref) : tmin;
+      for (int sref = 1; sref <= smax; ++sref)
+        if (model(sref) <= 1.03 * tmin) best = sref;
     }
     for (int i = 0; i < n; ++i)
       if (pr[i].kind == kind) pr[i].splits = splits_of(i, best);
@@ -438,7 +441,23 @@ static int wgrad_group_fill(const UnitWgradProblem& q, Wgrad256Args& b) {
   return UNIT_OK;
 }
 
-static int units_of(const UnitWgradProblem& q) { return q.splits * ((q.kind == 2 && group_valid_only(q)) ? 9 : 1); }
+// units of a layer: one per split (x 9 filter taps for valid_only layers), each cut into chunks of at most one XCD's workgroup slots
+// (32 CUs: one 256x256 workgroup or two 128x128 ones per CU) -- whole rows of k tiles (they share the dy columns) where a row fits
+static int unit_chunk(int tiles_k, int tiles, int kind) {
+  const int L = kind == 2 ? 32 : 64;
+  if (tiles <= L + L / 4) return tiles;
+  return tiles_k <= L ? tiles_k * (L / tiles_k) : L;
+}
+static int units_of(const UnitWgradProblem& q) {
+  const int T = q.kind == 2 ? 256 : 128;
+  int tiles_k = q.R * q.S * q.C / T, tiles_n = q.K / T;
+  if (q.kind == 2 && group_valid_only(q)) {
+    int per = tiles_n * (tiles_k / 9), c = unit_chunk(tiles_k / 9, per, q.kind);
+    return q.splits * 9 * cdiv(per, c);
+  }
+  int c = unit_chunk(tiles_k, tiles_k * tiles_n, q.kind);
+  return q.splits * cdiv(tiles_k * tiles_n, c);
+}
 
 // x / dy / partial as unit_conv2d_wgrad(dw = NULL) takes them, for n layers at once; pr[i].splits / kind from unit_conv2d_wgrad_group_plan.
 // Slab s of layer i at partial + s*K*R*S*C floats, same layout as unit_conv2d_wgrad's (unit_multi_wgrad_reduce folds them).
@@ -446,7 +465,7 @@ extern "C" int unit_conv2d_wgrad_group(const UnitWgradProblem* pr, int n, int in
   UNIT_CHECK_ARG(in_dtype == UNIT_BF16, "wgrad_group: bf16 only");
   UNIT_CHECK_ARG(pr != nullptr && n >= 0, "wgrad_group: no problems");
   static WgradGroupArgs g;         // 3.4 KB; filled and passed by value (one host thread per GPU launches)
-  struct U { long w; int p, tap, s, tiles; };
+  struct U { long w; int p, tap, s, tiles, tile0; };
   static U us[8 * WG_GROUP_MAX_UNITS];
   for (int kind = 2; kind >= 1; --kind) {           // the long 256-tile grid first
     int i0 = 0;
@@ -471,20 +490,27 @@ extern "C" int unit_conv2d_wgrad_group(const UnitWgradProblem* pr, int n, int in
       for (int p = 0; p < cnt; ++p) {
         const Wgrad256Args& a = g.p[p];
         if (a.valid_only) {
-          int ncb = a.tiles_k / 9;
+          int ncb = a.tiles_k / 9, per = a.tiles_n * ncb, ch = unit_chunk(ncb, per, kind);
           for (int tap = 0; tap < 9; ++tap) {
             int kr = tap / 3, ks = tap % 3;
             int nh = a.OH - (kr == 1 ? 0 : 1), nw = a.OW - (ks == 1 ? 0 : 1);      // 3x3 s1 p1 "same": the border taps lose a row / column
             if (nh < 0) nh = 0;
             if (nw < 0) nw = 0;
             long meff = (long)a.N * nh * nw;
-            for (int sp = 0; sp < a.splits; ++sp) us[nu++] = U{(long)a.tiles_n * ncb * (meff / a.splits + 1), p, tap, sp, a.tiles_n * ncb};
+            for (int sp = 0; sp < a.splits; ++sp)
+              for (int t0 = 0; t0 < per; t0 += ch) {
+                int nt = per - t0 < ch ? per - t0 : ch;
+                us[nu++] = U{(long)nt * (meff / a.splits + 1), p, tap, sp, nt, t0};
+              }
           }
         } else {
+          int tiles = a.tiles_k * a.tiles_n, ch = unit_chunk(a.tiles_k, tiles, kind);
           for (int sp = 0; sp < a.splits; ++sp) {
             int mb = sp * a.m_per_split, me = a.M < mb + a.m_per_split ? a.M : mb + a.m_per_split;
-            int tiles = a.tiles_k * a.tiles_n;
-            us[nu++] = U{(long)tiles * (me > mb ? me - mb : 0), p, 0, sp, tiles};
+            for (int t0 = 0; t0 < tiles; t0 += ch) {
+              int nt = tiles - t0 < ch ? tiles - t0 : ch;
+              us[nu++] = U{(long)nt * (me > mb ? me - mb : 0), p, 0, sp, nt, t0};
+            }
           }
         }
       }
@@ -503,6 +529,7 @@ extern "C" int unit_conv2d_wgrad_group(const UnitWgradProblem* pr, int n, int in
         int k = g.n_units[bx]++;
         g.unit_start[bx][k] = (unsigned short)slots[bx];
         g.unit_code[bx][k] = (unsigned short)(us[a].p | (us[a].tap << 5) | (us[a].s << 9));
+        g.unit_tile0[bx][k] = (unsigned short)us[a].tile0;
         slots[bx] += us[a].tiles; load[bx] += us[a].w;
         UNIT_CHECK_ARG(slots[bx] < 65536, "wgrad_group: more than 65535 workgroups on one XCD");
       }

@@ -199,7 +199,7 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad128_group_kernel(WgradGroupA
   p.m_per_split = pin(src.m_per_split); p.x_bytes = (unsigned)pin((int)src.x_bytes); p.dy_bytes = (unsigned)pin((int)src.dy_bytes);
   p.magic_ohw = (unsigned)pin((int)src.magic_ohw); p.magic_ow = (unsigned)pin((int)src.magic_ow); p.OHW = pin(src.OHW);
   p.use_magic = pin(src.use_magic); p.valid_only = 0;
-  int t = slot - (int)g.unit_start[xcd][u];
+  int t = slot - (int)g.unit_start[xcd][u] + (int)g.unit_tile0[xcd][u];
   wgrad128_ring_tile<NS>(p, t % p.tiles_k, t / p.tiles_k, (int)(code >> 9), smem);
 }
 

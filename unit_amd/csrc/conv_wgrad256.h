@@ -22,7 +22,8 @@ struct Wgrad256Args {
 };
 
 // grouped launches (conv_wgrad128r.hip: 128x128 ring tiles; conv_wgrad256p8.hip: 256x256 phase-interleaved tiles): up to 20 layers,
-// their units -- (layer, split), or (layer, filter tap, split) for valid_only layers -- dealt to the 8 XCDs.
+// their units -- the tiles of a (layer, split), or (layer, filter tap, split) for valid_only layers, in chunks of at most one XCD's
+// workgroup slots -- dealt to the 8 XCDs.
 // Passed BY VALUE (3.4 KB of the 4 KB kernel-argument segment): the operand pointers change every step, a device-side table
 // would cost a host-to-device copy per launch.
 constexpr int WG_GROUP_MAX_PROBLEMS = 20;
@@ -32,6 +33,8 @@ struct WgradGroupArgs {
   Wgrad256Args p[WG_GROUP_MAX_PROBLEMS];
   unsigned short unit_start[8][WG_GROUP_MAX_UNITS + 1];   // per XCD: first workgroup slot of unit i ([n_units] = the XCD's total)
   unsigned short unit_code[8][WG_GROUP_MAX_UNITS];        // problem (5 bits) | filter tap << 5 (4 bits) | split << 9
+  unsigned short unit_tile0[8][WG_GROUP_MAX_UNITS];       // first tile of the unit within its (layer [, tap], split): layers with more
+                                                          // tiles than an XCD has workgroup slots are cut into several units
   int n_units[8];
 };
 static_assert(sizeof(WgradGroupArgs) <= 4000, "kernel-argument segment is 4 KB");

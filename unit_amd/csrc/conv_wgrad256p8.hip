@@ -457,7 +457,7 @@ __global__ void __launch_bounds__(512, 2) conv_wgrad256_group_kernel(WgradGroupA
   p.m_per_split = pinw(src.m_per_split); p.x_bytes = (unsigned)pinw((int)src.x_bytes); p.dy_bytes = (unsigned)pinw((int)src.dy_bytes);
   p.magic_ohw = (unsigned)pinw((int)src.magic_ohw); p.magic_ow = (unsigned)pinw((int)src.magic_ow); p.OHW = pinw(src.OHW);
   p.use_magic = pinw(src.use_magic); p.valid_only = pinw(src.valid_only);
-  int t = slot - (int)g.unit_start[xcd][u];
+  int t = slot - (int)g.unit_start[xcd][u] + (int)g.unit_tile0[xcd][u];
   int tap = (int)((code >> 5) & 15), split = (int)(code >> 9);
   if (p.valid_only) {
     int ncb = p.tiles_k / (p.R * p.S);

@@ -114,8 +114,12 @@ class Conv2d(_EpochOnLoad):
             # unit_multi_wgrad_reduce launch per bucket folds them into the flat gradient buffer later
             side = ops.WGRAD_STREAM
             which = "_slab2" if acc else "_slab"
+            if self.bias is not None and self.bias.requires_grad:       # (a conv without FrozenBN: the RPN's 3x3)
+                if self.bias.grad is None:
+                    self.bias.grad = torch.zeros_like(self.bias.data)
+                ops.bias_grad(dy.reshape(-1, dy.shape[-1]), self.cout, out=self.bias.grad, accumulate=acc)
             if self._plan.defer_wgrad(self, x, dy, st, acc):
-                return       # small-M layer: goes out with the rest of its gradient bucket in one grouped launch (multi.py)
+                return       # goes out with the rest of its gradient bucket in one grouped launch (multi.py)
 
             def launch():
                 slab, splits = ops.conv2d_wgrad_partial(x, dy, self.cout, self.k, self.k, st, self.pad, getattr(self, which, None))
@@ -320,6 +324,7 @@ class LinearGroup:
         for m in members:  # Linear, or a 1x1 Conv2d (weight [out,in,1,1]) such as the RPN predictors
             if not hasattr(m, "out_features"):
                 m.out_features = m.weight.shape[0]
+            m._in_linear_group = True          # multi.ConvPlan: not a conv of the multi-tensor plan
         self.cin = members[0].weight.shape[1]
         self.cols = []
         c = 0

@@ -12,6 +12,7 @@ from ._lib import check, lib
 from .layers import _FROZEN_EPOCH, Conv2d
 
 ELEMS_PER_BLOCK = 1024
+_NO_BIAS_CONVS = bool(int(os.environ.get("UNIT_PLAN_NO_BIAS_CONVS", "0")))      # A/B switch for tools/: the RPN's 3x3 conv outside the plan
 
 
 class TensorDesc(ctypes.Structure):
@@ -37,7 +38,9 @@ class ConvPlan:
                     tag_of[id(e["param"])] = tag
         for name, m in model.named_modules():
             if isinstance(m, Conv2d) and m.weight.requires_grad and id(m.weight) in off and m.cin_pad == m.cin and m.weight.dim() == 4 \
-                    and (m.cin * m.k * m.k) % 4 == 0 and m.norm is not None:
+                    and (m.cin * m.k * m.k) % 4 == 0 and not getattr(m, "_in_linear_group", False) \
+                    and (m.norm is not None or not _NO_BIAS_CONVS):
+                # (FrozenBN convs and plain bias convs -- the RPN's 3x3; the 1x1 convs evaluated as Linear layers go through LinearGroup)
                 m._plan = self
                 m._flat_offset = off[id(m.weight)]
                 m._slab = None
