@@ -381,6 +381,35 @@ def test_early_bucket_update_is_bit_identical(dev):
     assert torch.allclose(outs[0][2], outs[1][2], rtol=1e-5, atol=1e-7), (outs[0][2].tolist(), outs[1][2].tolist())
 
 
+def test_optimizer_tail_overlap_is_bit_identical(dev):
+    """TrainerNoMeta(overlap_tail=True): the end of a step (last weight gradients, SGD, weight re-preparation) stays on the
+    weight-gradient stream while the next step's frozen layers start; the main stream joins before its first trainable layer, and
+    state_dict() joins too. Same parameters / momentum / losses after three steps as the joined schedule."""
+    from unit_amd import engine
+    outs = []
+    for overlap in (False, True):
+        cfg = small_cfg()
+        model = build_model(cfg)
+        init_synthetic_weights(model, seed=3)
+        model.train()
+        torch.manual_seed(0)
+        torch.cuda.manual_seed(0)
+        tr = engine.TrainerNoMeta(cfg, model, overlap_tail=overlap)
+        assert model.overlap_optimizer_tail == overlap
+        for it in range(3):
+            sup, weak = synthetic_batch(2, 2, hw=(128, 192), seed=7 + it, max_gt=4)
+            losses = tr.run_step(sup, weak)
+            assert (model._tail_pending is not None) == overlap
+        sd = model.state_dict()                     # joins the pending tail on the current stream
+        assert model._tail_pending is None
+        w = sd["backbone.res4.0.conv1.weight"].clone()
+        torch.cuda.synchronize()
+        outs.append((model.store.params.clone(), tr.optimizer._buf.clone(), losses.clone(), w))
+    assert torch.allclose(outs[0][0], outs[1][0], rtol=1e-6, atol=1e-9) and torch.allclose(outs[0][1], outs[1][1], rtol=1e-5, atol=1e-9)
+    assert torch.allclose(outs[0][2], outs[1][2], rtol=1e-5, atol=1e-7), (outs[0][2].tolist(), outs[1][2].tolist())
+    assert torch.allclose(outs[0][3], outs[1][3], rtol=1e-6, atol=1e-9)
+
+
 def test_s1_step_vs_committed_golden(dev):
     """HIP path (fp32 mode) against the committed end-to-end fixture tests/golden/step_golden.npz -- no oracle run here."""
     import importlib.util

@@ -171,8 +171,12 @@ class GraphedStep:
 
 class TrainerNoMeta:
     def __init__(self, cfg, model, data_iter=None, weak_data_iter=None, group=None, early_update=False, bf16_buckets=False,
-                 use_graph=False):
+                 use_graph=False, overlap_tail=False):
+        """overlap_tail: the end of a step (last weight gradients, all-reduce waits, SGD, weight re-preparation) stays on the model's
+        weight-gradient stream and overlaps the next step's preprocessing / frozen layers (GeneralizedRCNN.overlap_optimizer_tail);
+        read parameters between steps only after model.join_optimizer_tail() (state_dict() does it)."""
         self.cfg, self.model = cfg, model
+        model.overlap_optimizer_tail = bool(overlap_tail) and not early_update and not use_graph
         self.data_iter, self.weak_data_iter = data_iter, weak_data_iter
         self.buckets = GradBuckets(model, group, bf16=bf16_buckets)
         self.buckets.broadcast_parameters()

@@ -55,11 +55,15 @@ class ResNet(nn.Module):
         return 3
 
     # ---- explicit forward / backward on NHWC activations
-    def fwd(self, x, save=False):
+    def fwd(self, x, save=False, before_trainable=None):
+        """before_trainable: called once, before the first stage whose weights train (GeneralizedRCNN.optimizer_tail: the frozen
+        stem / res2 of a step may run beside the previous step's optimizer update)"""
         x = self.stem.fwd(x)
         ft = self.first_trainable_stage()
         ctx = []
         for i, st in enumerate((self.res2, self.res3, self.res4)):
+            if i == ft and before_trainable is not None:
+                before_trainable()
             x, c = st.fwd(x, save=save and i >= ft)
             ctx.append(c)
         return x, ctx

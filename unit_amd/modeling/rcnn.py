@@ -97,6 +97,12 @@ class WeaklySupervisedRCNNNoMeta(nn.Module):
         self.on_bucket_final = None  # optimizer hook (tag, stream): the bucket's gradients are final once `stream` reaches this point
         self.use_multi_tensor_plan = True
         self.plan = None
+        # opt-in (bench.py, TrainerNoMeta(overlap_tail=True)): the end of a step -- last gradient bucket's weight gradients, their
+        # reduction, the data-parallel all-reduce waits, SGD, weight re-preparation -- stays on the weight-gradient stream and the NEXT
+        # step's preprocessing / frozen stem / res2 run beside it; the main stream joins before its first trainable layer. Whoever reads
+        # parameters or gradients on another stream in between calls join_optimizer_tail() first (state_dict() and inference do).
+        self.overlap_optimizer_tail = False
+        self._tail_pending = None
         self.overlap_streams = True
         self.split_weak_head = __import__("os").environ.get("UNIT_SPLIT_WEAK", "1") != "0"     # forward plan: weak_box_head as two 1024-RoI passes
 
@@ -306,14 +312,15 @@ class WeaklySupervisedRCNNNoMeta(nn.Module):
         feat_w = head_w = anchors_w = None
         if not split:
             x, sizes = ops.preprocess_images(batch.images, self._pixel_mean, self._pixel_std, dt, 8, self.normalize_images)
-            feat, c.bb_ctx = self.backbone.fwd(x, save=True)
+            feat, c.bb_ctx = self.backbone.fwd(x, save=True, before_trainable=self.join_optimizer_tail)
         else:
             xa, sa = ops.preprocess_images(batch.images[:n_sup], self._pixel_mean, self._pixel_std, dt, 8, self.normalize_images)
             xb, sb = ops.preprocess_images(batch.images[n_sup:], self._pixel_mean, self._pixel_std, dt, 8, self.normalize_images)
             sizes = sa + sb
-            feat, c.bb_ctx = self.backbone.fwd(xa, save=True)          # `feat` = supervised images only
+            feat, c.bb_ctx = self.backbone.fwd(xa, save=True, before_trainable=self.join_optimizer_tail)          # `feat` = supervised images only
             feat_w, c.bb_ctx_w = self.backbone.fwd(xb, save=True)
             anchors_w = rpn.anchor_generator.grid(feat_w.shape[1], feat_w.shape[2])
+        self.join_optimizer_tail()          # (a fully frozen backbone never called it)
         c.image_sizes = sizes
         c.feat, c.feat_w = feat, feat_w
         n, fh, fw, fc = feat.shape
@@ -677,8 +684,34 @@ class WeaklySupervisedRCNNNoMeta(nn.Module):
                 finally:
                     ops.WGRAD_ACCUMULATE = False
         if side is not None:
-            torch.cuda.current_stream().wait_stream(side)
+            if self.overlap_optimizer_tail and not torch.cuda.is_current_stream_capturing():
+                side.wait_stream(torch.cuda.current_stream())      # the optimizer needs every gradient the main stream produced
+                self._tail_pending = side
+            else:
+                torch.cuda.current_stream().wait_stream(side)
         ops.WGRAD_STREAM = None
+
+    @contextlib.contextmanager
+    def optimizer_tail(self):
+        """stream context for what follows backward_train() in a step (GradBuckets.finish, FlatSGD.step enter it themselves): the
+        weight-gradient stream while a tail is pending (overlap_optimizer_tail), the current stream otherwise"""
+        s = self._tail_pending
+        if s is None:
+            yield
+        else:
+            with torch.cuda.stream(s):
+                yield
+
+    def join_optimizer_tail(self):
+        """the current stream waits for a pending optimizer tail (no-op without one)"""
+        s = self._tail_pending
+        if s is not None:
+            torch.cuda.current_stream().wait_stream(s)
+            self._tail_pending = None
+
+    def state_dict(self, *args, **kwargs):
+        self.join_optimizer_tail()
+        return super().state_dict(*args, **kwargs)
 
     def _const_on_device(self, key, make):
         """small host-built constants of the step (image sizes, slot tables) are uploaded once per distinct value: no pageable
@@ -760,6 +793,7 @@ class WeaklySupervisedRCNNNoMeta(nn.Module):
 
     def inference(self, batched_inputs, detected_instances=None, do_postprocess=True, return_similarity=False):
         from .inference import inference as _inf
+        self.join_optimizer_tail()
         return _inf(self, batched_inputs, do_postprocess)
 
 

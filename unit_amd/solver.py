@@ -99,6 +99,13 @@ class FlatSGD:
                 self._early.add((a, b))
 
     def step(self):
+        tail = getattr(self.model, "optimizer_tail", None)
+        if tail is None:
+            return self._step()
+        with tail():          # the weight-gradient stream while the model overlaps the end of the step with the next one (rcnn.py)
+            return self._step()
+
+    def _step(self):
         st = self._bind()
         if self._early:
             done = sorted(self._early)
