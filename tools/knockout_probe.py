@@ -23,7 +23,7 @@ def run(tag, patch=None, steps=20):
     sup, weak = synthetic_batch(2, 2, seed=100)
     batch = model.pack_batch(sup, weak)
     opt = FlatSGD(model, cfg)
-    undo = patch() if patch else None
+    undo = (patch(model) if patch.__code__.co_argcount else patch()) if patch else None
 
     def step():
         s = model.forward_train(batch, early_backward=True)
@@ -50,24 +50,25 @@ def ko_wgrad():
 
 
 def ko_wgrad_big():
-    orig = ops.conv2d_wgrad_partial
-    def f(x, dy, k, r, s, stride, pad, slab=None, variant=0):
-        n, h, w, c = x.shape
-        if lib_use_big(x, dy, k, r, s, c):
-            nb = ops.lib().unit_conv2d_wgrad_workspace_bytes(ops.dt(x.dtype), n, dy.shape[1], dy.shape[2], k, r, s, c)
-            if slab is None or slab.numel() < nb:
-                slab = torch.zeros(nb, dtype=torch.uint8, device=x.device)
-            return slab, ops.lib().unit_conv2d_wgrad_splits(ops.dt(x.dtype), n, dy.shape[1], dy.shape[2], k, r, s, c)
-        return orig(x, dy, k, r, s, stride, pad, slab, variant)
-    def lib_use_big(x, dy, k, r, s, c):
-        m = dy.shape[0] * dy.shape[1] * dy.shape[2]
-        return c % 256 == 0 and k % 256 == 0 and m >= 16384
-    ops.conv2d_wgrad_partial = f
-    return lambda: setattr(ops, "conv2d_wgrad_partial", orig)
+    orig = layers.Conv2d.wgrad
+
+    def f(self, x, dy, stride=None):
+        if dy.shape[0] * dy.shape[1] * dy.shape[2] >= 16384:       # the Res5 heads' layers (1024 RoIs x 49 bins)
+            return None
+        return orig(self, x, dy, stride)
+    layers.Conv2d.wgrad = f
+    return lambda: setattr(layers.Conv2d, "wgrad", orig)
 
 
-base = run("baseline")
+def ungrouped(model):
+    model.plan.group_wgrads = False
+    return lambda: setattr(model.plan, "group_wgrads", True)
+
+
+base = run("baseline (grouped weight gradients)")
+u = run("one launch per layer (round-2 schedule)", ungrouped)
 a = run("no weight-gradient kernels at all", ko_wgrad)
-b = run("no 256x256 (Res5 / RPN) weight-gradient kernels", ko_wgrad_big)
+b = run("no Res5-head weight-gradient kernels", ko_wgrad_big)
 base2 = run("baseline again")
-print(f"all wgrad in the step: {0.5 * (base + base2) - a:.2f} ms ; Res5 / RPN wgrad: {0.5 * (base + base2) - b:.2f} ms")
+m = 0.5 * (base + base2)
+print(f"weight gradients inside the step: grouped {m - a:.2f} ms (Res5 heads {m - b:.2f}); one launch per layer {u - a:.2f} ms")

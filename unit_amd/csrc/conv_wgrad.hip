@@ -464,9 +464,9 @@ static int units_of(const UnitWgradProblem& q) {
 extern "C" int unit_conv2d_wgrad_group(const UnitWgradProblem* pr, int n, int in_dtype, void* stream) {
   UNIT_CHECK_ARG(in_dtype == UNIT_BF16, "wgrad_group: bf16 only");
   UNIT_CHECK_ARG(pr != nullptr && n >= 0, "wgrad_group: no problems");
-  static WgradGroupArgs g;         // 3.4 KB; filled and passed by value (one host thread per GPU launches)
+  static thread_local WgradGroupArgs g;         // 3.8 KB; filled and passed by value
   struct U { long w; int p, tap, s, tiles, tile0; };
-  static U us[8 * WG_GROUP_MAX_UNITS];
+  static thread_local U us[8 * WG_GROUP_MAX_UNITS];
   for (int kind = 2; kind >= 1; --kind) {           // the long 256-tile grid first
     int i0 = 0;
     while (i0 < n) {
