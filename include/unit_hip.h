@@ -182,8 +182,11 @@ int unit_box_decode(const float* deltas, int ld, int col0, int K, const float* b
 size_t unit_sort_workspace_bytes(int B, int n);
 int unit_sort_desc_stable(const float* src, long batch_stride, int ld, int A, int col0, int B, int n, float* out_keys, int* out_idx,
                           void* workspace, size_t workspace_bytes, void* stream);
-/* top-k form (chip-wide select + rank sort): only the first min(topk, #keys > min_exclusive) entries of each output row are
- * defined; pass -INFINITY to rank every key */
+/* top-k form (chip-wide select + rank sort): the first min(topk, #keys > min_exclusive) entries of each output row are the ranked
+ * keys (NaN keys are never ranked: torch.topk would put them first and detectron2's find_top_rpn_proposals then drops them as
+ * non-finite or, in training, raises "Training has diverged" -- here TrainerNoMeta.loss_dict() raises on the NaN losses instead); every
+ * entry that is not a ranked candidate holds index -1 / key -INFINITY (unit_rpn_decode_select skips negative indices); pass -INFINITY
+ * to rank every key */
 int unit_sort_desc_stable_topk(const float* src, long batch_stride, int ld, int A, int col0, int B, int n, int topk,
                                float min_exclusive, float* out_keys, int* out_idx, void* workspace, size_t workspace_bytes,
                                void* stream);

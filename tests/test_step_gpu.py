@@ -381,6 +381,44 @@ def test_early_bucket_update_is_bit_identical(dev):
     assert torch.allclose(outs[0][2], outs[1][2], rtol=1e-5, atol=1e-7), (outs[0][2].tolist(), outs[1][2].tolist())
 
 
+def test_diverged_model_raises_instead_of_faulting_the_device(dev):
+    """NaN in the RPN's parameters (a diverged run): torch.topk would rank NaN scores first and detectron2's find_top_rpn_proposals
+    then raises FloatingPointError; here NaN scores are never ranked, every unranked slot of the sorted list holds index -1 (no stale
+    memory reaches the decode kernel's gathers -- this faulted the GPU before round 3), the step runs to its end and
+    TrainerNoMeta.loss_dict() raises detectron2's `_detect_anomaly` error (engine/defaults.py:281) on the NaN losses."""
+    from unit_amd import engine, ops
+    from unit_amd.layers import invalidate_prepared
+    src = torch.randn(2, 900, device=dev)
+    src[0, ::3] = float("nan")
+    src[1, 5:] = float("nan")
+    keys, idx = ops.sort_desc(src, 2, 900, topk=800)
+    torch.cuda.synchronize()
+    for b, nvalid in ((0, 600), (1, 5)):
+        good = idx[b, :nvalid].long()
+        assert torch.equal(src[b][good], torch.sort(src[b][~torch.isnan(src[b])], descending=True).values)
+        assert (idx[b, nvalid:] == -1).all() and torch.isinf(keys[b, nvalid:]).all()
+    cfg = small_cfg()
+    model = build_model(cfg)
+    init_synthetic_weights(model, seed=3)
+    model.train()
+    tr = engine.TrainerNoMeta(cfg, model)
+    sup, weak = synthetic_batch(2, 2, hw=(128, 192), seed=7, max_gt=4)
+    tr.run_step(sup, weak)
+    assert all(math.isfinite(v) for v in tr.loss_dict().values())
+    with torch.no_grad():
+        for n, p in model.named_parameters():
+            if "proposal_generator" in n and p.dim() > 1:
+                p.data[0].fill_(float("nan"))
+    model.version += 1
+    invalidate_prepared()
+    for _ in range(2):
+        tr.run_step(sup, weak)
+    torch.cuda.synchronize()                      # the device survived
+    with pytest.raises(FloatingPointError, match="Loss became infinite or NaN"):
+        tr.loss_dict()
+    assert not all(math.isfinite(v) for v in tr.loss_dict(detect_anomaly=False).values())
+
+
 def test_optimizer_tail_overlap_is_bit_identical(dev):
     """TrainerNoMeta(overlap_tail=True): the end of a step (last weight gradients, SGD, weight re-preparation) stays on the
     weight-gradient stream while the next step's frozen layers start; the main stream joins before its first trainable layer, and

@@ -1,5 +1,6 @@
 """What does a component cost INSIDE the multi-stream step? Runs the S1 R101 step with a component knocked out (results are garbage,
 timing is not) -- python tools/knockout_probe.py"""
+import os
 import sys
 import time
 
@@ -23,12 +24,24 @@ def run(tag, patch=None, steps=20):
     sup, weak = synthetic_batch(2, 2, seed=100)
     batch = model.pack_batch(sup, weak)
     opt = FlatSGD(model, cfg)
-    undo = (patch(model) if patch.__code__.co_argcount else patch()) if patch else None
 
     def step():
         s = model.forward_train(batch, early_backward=True)
         model.backward_train(s)
         opt.step()
+    step()                               # (the multi-tensor plan exists from the first step on)
+    undo = (patch(model) if patch.__code__.co_argcount else patch()) if patch else None
+    if patch is not None and patch is not ungrouped:
+        model.store.grads.zero_()        # knocked-out layers would otherwise re-apply the first step's gradients every step until the weights overflow
+    if os.environ.get("KO_DEBUG"):
+        for i in range(3):
+            torch.cuda.synchronize(); print("step", i, "start", flush=True)
+            s_ = model.forward_train(batch, early_backward=True)
+            torch.cuda.synchronize(); print("  forward ok", flush=True)
+            model.backward_train(s_)
+            torch.cuda.synchronize(); print("  backward ok", flush=True)
+            opt.step()
+            torch.cuda.synchronize(); print("  optimizer ok", flush=True)
     for _ in range(5):
         step()
     torch.cuda.synchronize()
@@ -65,6 +78,10 @@ def ungrouped(model):
     return lambda: setattr(model.plan, "group_wgrads", True)
 
 
+if len(sys.argv) > 1:          # one variant only (debugging): a = no weight gradients, b = no Res5-head ones, u = ungrouped
+    {"a": lambda: run("no weight-gradient kernels at all", ko_wgrad), "b": lambda: run("no Res5-head weight-gradient kernels", ko_wgrad_big),
+     "u": lambda: run("one launch per layer", ungrouped)}[sys.argv[1]]()
+    sys.exit(0)
 base = run("baseline (grouped weight gradients)")
 u = run("one launch per layer (round-2 schedule)", ungrouped)
 a = run("no weight-gradient kernels at all", ko_wgrad)

@@ -66,7 +66,14 @@ def lib():
     return _lib
 
 
+_DEBUG_SYNC = bool(int(os.environ.get("UNIT_DEBUG_SYNC", "0")))      # diagnostic: name every launch and wait for it (finds the kernel behind a GPU fault)
+
+
 def check(status, what=""):
     if status != 0:
         msg = lib().unit_last_error()
         raise UnitLibError(f"{what} failed with status {status}: {msg.decode() if msg else ''}")
+    if _DEBUG_SYNC:
+        import sys
+        print("[unit]", what, file=sys.stderr, flush=True)
+        torch.cuda.synchronize()

@@ -225,7 +225,7 @@ extern "C" int unit_sort_desc_stable(const float* src, long batch_stride, int ld
 //  (2) group_rank_kernel (64 candidates per workgroup): rank(i) = start of its group + #{j in the group : cand_j < cand_i} on the
 //      unique 64-bit composites (ties broken by ascending original index = the stable order); writes out[rank]. The groups
 //      hold a few hundred candidates (16 bins per octave of score), so this is ~1/50 of the all-pairs count it replaces
-//      (rank_sort_kernel, kept for reference: 85 us for 4 x 12 000). Entries beyond Nc are left untouched.
+//      (rank_sort_kernel, kept for reference: 85 us for 4 x 12 000). Entries beyond Nc get index -1 / score -inf.
 // ---------------------------------------------------------------------------------------------------
 #define SEL_BINS 8192
 __global__ void __launch_bounds__(1024) topk_select_kernel(const float* __restrict__ src, long bstride, int ld, int A, int col0, int n,
@@ -299,6 +299,13 @@ __global__ void __launch_bounds__(256) group_rank_kernel(const unsigned long lon
   int b = blockIdx.y;
   int nc = cand_count[b];
   int i0 = blockIdx.x * 64;
+  // entries that are no candidates (NaN scores, scores <= min_exclusive; with finite scores: those past the bin of the topk-th) get
+  // index -1 / score -inf instead of staying unwritten: a consumer that reads `topk` entries (unit_rpn_decode_select skips index < 0)
+  // must never see stale memory when a diverged model leaves fewer than topk valid scores
+  if (threadIdx.x < 64 && i0 + (int)threadIdx.x >= nc && i0 + (int)threadIdx.x < n) {
+    out_keys[(size_t)b * n + i0 + threadIdx.x] = -__builtin_inff();
+    out_idx[(size_t)b * n + i0 + threadIdx.x] = -1;
+  }
   if (i0 >= nc) return;
   int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const unsigned long long* c = cand + (size_t)b * n;
@@ -336,6 +343,10 @@ __global__ void __launch_bounds__(256) rank_sort_kernel(const unsigned long long
   int b = blockIdx.y;
   int nc = cand_count[b];
   int i0 = blockIdx.x * 64;
+  if (threadIdx.x < 64 && i0 + (int)threadIdx.x >= nc && i0 + (int)threadIdx.x < n) {      // (group_rank_kernel)
+    out_keys[(size_t)b * n + i0 + threadIdx.x] = -__builtin_inff();
+    out_idx[(size_t)b * n + i0 + threadIdx.x] = -1;
+  }
   if (i0 >= nc) return;
   int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const unsigned long long* c = cand + (size_t)b * n;

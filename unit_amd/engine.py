@@ -207,10 +207,18 @@ class TrainerNoMeta:
         self.last_losses = step.losses
         return step.losses
 
-    def loss_dict(self):
-        """host copy of the last step's losses (one sync; call sparingly)."""
+    def loss_dict(self, detect_anomaly=True):
+        """host copy of the last step's losses (one sync; call sparingly). detect_anomaly: the reference checks the summed loss of
+        EVERY step on the host (`self._detect_anomaly(losses, loss_dict)`, engine/defaults.py:281 -> detectron2 SimpleTrainer:
+        FloatingPointError) -- a device sync per step. Here the step never syncs; the same error is raised when the losses are
+        fetched. A diverged model cannot fault the device in between: non-finite RPN scores are never ranked, non-finite boxes are
+        dropped (csrc/sort_nms.hip, csrc/boxes.hip), ReLU epilogues squash NaN (fmaxf)."""
+        import math
         vals = self.last_losses.cpu().tolist()
-        return dict(zip(LOSS_NAMES, vals))
+        d = dict(zip(LOSS_NAMES, vals))
+        if detect_anomaly and not all(math.isfinite(v) for v in vals):
+            raise FloatingPointError(f"Loss became infinite or NaN at iteration={self.iter}!\nloss_dict = {d}")
+        return d
 
 
 class TrainerFineTune(TrainerNoMeta):
