@@ -91,7 +91,9 @@ int unit_avgpool_bwd_bits(const void* dfeat, const unsigned char* bits, int R, i
  * 3 = 128x128 with in-workgroup split-K (few-tile layers), 4 / 5 = 96 x 128 with three / two LDS stages;
  * tile >= 100 (csrc/conv_igemm_lc.hip): ONE persistent workgroup per CU of four LDS-DMA loader waves and four MFMA consumer waves on a
  * three-slot LDS ring, walking a contiguous run of output tiles: 100 + 10 * (BM / 16) + BN / 64 with BM 64..128 x BN 128 or BM 64..96 x
- * BN 256 (+ 1000: eight loader waves; + 4000: four ring slots -- measured no faster); bf16 output with ldy % 8 == 0. Same results
+ * BN 256 (+ 1000: eight loader waves; + 4000: four ring slots -- measured no faster; + 2000, BM 64..96 x BN 128: TWO workgroups per CU on
+ * a two-slot ring, for layers with two or more tiles per CU -- one's epilogue beside the other's k-steps: 7-20 % faster in isolation
+ * on such layers, no gain inside the step, not used by the policy); bf16 output with ldy % 8 == 0. Same results
  * bit for bit as tiles 0..5. For the layers with a long contraction and few output tiles (res4 on four 600x1000 images). */
 int unit_conv2d_fwd_mid(const void* x, const void* w, void* y, const float* bias, const void* residual, const void* mask_ref,
                         int out_dtype, int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int OH, int OW, int ldy,

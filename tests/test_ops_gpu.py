@@ -200,12 +200,12 @@ def test_conv_p8_kernel(dev, case, cfg):
     assert torch.equal(yf.cpu()[..., :k], y5.cpu()[..., :k])
 
 
-@pytest.mark.parametrize("code", [142, 152, 162, 172, 182, 144, 154, 164, 1152, 1154, 4152])
+@pytest.mark.parametrize("code", [142, 152, 162, 172, 182, 144, 154, 164, 1152, 1154, 4152, 2142, 2152, 2162])
 @pytest.mark.parametrize("case", [(4, 38, 63, 1024, 256, 1, 1, 0), (4, 38, 63, 256, 256, 3, 1, 1), (2, 19, 23, 64, 320, 1, 2, 0), (3, 30, 33, 256, 200, 3, 1, 1),
                                   (1, 9, 9, 64, 40, 1, 1, 0), (4, 38, 63, 256, 1024, 1, 1, 0)])
 def test_conv_loader_consumer_kernel(dev, case, code):
     """persistent loader / consumer workgroups (conv_igemm_lc.hip; code = 100 + 10 * BM/16 + BN/64, + 1000 eight loader waves, + 4000
-    four ring slots): several tiles per workgroup, one / many k-steps per tile, padding, stride 2, ragged last pixel tile, channel
+    four ring slots, + 2000 two workgroups per CU on a two-slot ring): several tiles per workgroup, one / many k-steps per tile, padding, stride 2, ragged last pixel tile, channel
     counts that are not multiples of the tile, residual + ReLU + mask epilogue -- BIT-IDENTICAL to the 4-wave LDS-DMA kernel (same
     k order, same MFMA order, same epilogue), which the other tests pin to F.conv2d."""
     o = ops()

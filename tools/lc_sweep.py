@@ -15,6 +15,8 @@ SH = [("res4 1x1 1024->256", 4, 38, 63, 1024, 256, 1, 1, 0, None), ("res4 3x3 25
       ("res4.0 sc 512->1024 s2", 4, 75, 125, 512, 1024, 1, 2, 0, None), ("res2 1x1 64->256 +res", 4, 150, 250, 64, 256, 1, 1, 0, "res"),
       ("res2 3x3 64->64", 4, 150, 250, 64, 64, 3, 1, 1, None), ("res2 1x1 256->64", 4, 150, 250, 256, 64, 1, 1, 0, None)]
 CODES = [0, 152, 1152, 1142, 1162, 1172, 1182, 154, 1154, 1144, 0] if len(sys.argv) > 1 else [0, 142, 152, 162, 172, 182, 144, 154, 164, 0]
+if len(sys.argv) > 1 and sys.argv[1] == "two":          # the two-workgroups-per-CU form (two ring slots)
+    CODES = [0, 152, 2142, 2152, 2162, 0]
 dev = torch.device("cuda:0")
 for name, n, h, w, c, k, r, st, pad, extra in SH:
     x = torch.randn(n, h, w, c, device=dev).bfloat16()

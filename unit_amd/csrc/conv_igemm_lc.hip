@@ -52,7 +52,9 @@ template <int FB, int FA, int NL, int NSMAX = 3> struct LcCfg {
   static constexpr int SCR = 4 * EpiCfg<FA>::BYTES;
   static constexpr int NS = ((160 * 1024 - SCR) / SLOT >= NSMAX) ? NSMAX : (160 * 1024 - SCR) / SLOT;
   static constexpr int LDS = NS * SLOT + SCR;
-  static_assert((160 * 1024 - SCR) / SLOT >= 3, "three ring slots must fit the 160 KB of LDS");
+  static_assert((160 * 1024 - SCR) / SLOT >= (NSMAX < 3 ? NSMAX : 3), "the ring slots must fit the 160 KB of LDS");
+  // NSMAX == 2: two slots, at most 80 KB -- TWO workgroups per CU (code + 2000): the epilogue of one beside the k-steps of the other
+  static_assert(NSMAX != 2 || LDS <= 80 * 1024, "two-per-CU form: 80 KB of LDS per workgroup");
 };
 
 template <int FB, int FA, int NL, int NSMAX = 3>
@@ -223,7 +225,8 @@ static int launch_lc(ConvDmaArgs& a, hipStream_t st) {
   typedef LcCfg<FB, FA, NL, NSMAX> Cf;
   a.tiles_m = cdiv(a.M, Cf::BM); a.tiles_n = cdiv(a.K, Cf::BN);
   int total = a.tiles_m * a.tiles_n;
-  int grid = total < 256 ? total : 256;
+  const int slots = NSMAX == 2 ? 512 : 256;          // persistent workgroups: one per CU, two with the two-slot ring
+  int grid = total < slots ? total : slots;
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)conv_igemm_lc_kernel<FB, FA, NL, NSMAX>, hipFuncAttributeMaxDynamicSharedMemorySize, Cf::LDS);
@@ -256,6 +259,9 @@ int unit_conv_lc_launch(ConvDmaArgs& a, int out_dtype, int code, hipStream_t st)
     case 1182: return launch_lc<8, 2, 8>(a, st);
     case 1144: return launch_lc<4, 4, 8>(a, st);
     case 1154: return launch_lc<5, 4, 8>(a, st);
+    case 2142: return launch_lc<4, 2, 4, 2>(a, st);
+    case 2152: return launch_lc<5, 2, 4, 2>(a, st);
+    case 2162: return launch_lc<6, 2, 4, 2>(a, st);
     case 4152: return launch_lc<5, 2, 4, 4>(a, st);
     case 4142: return launch_lc<4, 2, 4, 4>(a, st);
   }

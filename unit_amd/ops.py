@@ -102,6 +102,7 @@ def _big_tile_default(dtype, m, k, c, kgemm):
 _NO_MID = bool(int(__import__("os").environ.get("UNIT_NO_MID_TILE", "0")))   # A/B switch for tools/ and debugging
 
 
+_LC_TWO = bool(int(os.environ.get("UNIT_LC_TWO", "0")))      # A/B switch: 1 = the two-workgroups-per-CU form of the loader / consumer kernel where it won in isolation
 _NO_LC = bool(int(os.environ.get("UNIT_NO_LC", "0")))      # A/B switch: 1 = never the persistent loader / consumer conv kernel (csrc/conv_igemm_lc.hip)
 _MID96 = int(os.environ.get("UNIT_MID96", "0"))      # 0: off; 1: 96x128 tiles where tools/mid_sweep.py found them faster in isolation; 2: only the two-per-CU form
 
@@ -135,6 +136,14 @@ def _mid_tile_default(dtype, m, k, c, kgemm):
     if k <= 64:
         return 2
     tiles = ((m + 127) // 128) * ((k + 127) // 128)
+    # two loader / consumer workgroups per CU on a two-slot ring (code + 2000; off unless UNIT_LC_TWO=1): where every CU has two or more
+    # 80 x 128 tiles, one workgroup's epilogue runs beside the other's k-steps. Isolated (tools/lc_sweep.py two): res4 256 -> 1024
+    # 17.3 -> 16.0 us, res3 512 -> 128 14.4 -> 12.8, res3 3x3 21.9 -> 17.6 (with one tile per CU -- res4 -> 256 layers -- the three-slot
+    # one-per-CU form stays ahead, with two k-steps per tile -- res3 128 -> 512 -- the 4-wave kernel, the 1024-wide transition layer is a
+    # tie). In the step: 16.31 ms without vs 16.35 ms with it (three alternating runs each) -- not enabled.
+    t80 = ((m + 79) // 80) * ((k + 127) // 128)
+    if not _NO_LC and _LC_TWO and k % 8 == 0 and kgemm >= 256 and 384 <= t80 <= 1024 and not (kgemm >= 512 and k >= 1024):
+        return 2152
     if not _NO_LC and kgemm >= 512 and tiles <= 640 and k % 8 == 0:
         return lc_tile_code(m, k, kgemm)
     if _MID96:
