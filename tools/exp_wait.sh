@@ -5,10 +5,11 @@ EXPFLAGS=${EXPFLAGS:--DUNIT_P8_FINE_WAIT=1}
 if [ "$1" = build ]; then
   python3 -c "import __graft_entry__ as g; g.build()"
   mkdir -p unit_amd/_build/waitexp
-  for f in conv_igemm256p8 conv_wgrad256p8; do
+  for f in ${EXPFILES:-conv_igemm256p8 conv_wgrad256p8}; do
     /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fPIC -ffp-contract=off -std=c++17 -Wno-unused-value $EXPFLAGS -c unit_amd/csrc/$f.hip -o unit_amd/_build/waitexp/$f.o || exit 1
   done
-  objs=$(ls unit_amd/_build/*.o | grep -v "conv_igemm256p8.o\|conv_wgrad256p8.o")
+  objs=""
+  for o in unit_amd/_build/*.o; do b=$(basename $o .o); case " ${EXPFILES:-conv_igemm256p8 conv_wgrad256p8} " in *" $b "*) ;; *) objs="$objs $o";; esac; done
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o unit_amd/_build/waitexp/libunit_hip.so $objs unit_amd/_build/waitexp/*.o || exit 1
   exit 0
 fi

@@ -77,6 +77,31 @@ struct EpiExtra {
 #else
 #define EPI_STAMP(i) do { } while (0)
 #endif
+// the epilogue's global accesses: a residual / mask segment is read once, an output segment is written once and read by a LATER kernel.
+// UNIT_EPI_NT: 2 (default) = the residual / mask loads are non-temporal, so that they do not push the operand tiles (weights, the pixel
+// rows the other channel tiles of the XCD are about to read) out of the 4 MB L2 -- FETCH_SIZE of a 512 -> 2048 launch is 3x its operands;
+// 1 = the stores too, 3 = the stores only, 0 = none. Same values in every form. Measured (profiles/r03_exp_epilogue_nontemporal.txt): with
+// loads AND stores the Res5 / RPN launches are 2-7 % faster in isolation (512 -> 2048 + residual 173 -> 161 us) but the step is not (the
+// consumers of the outputs then miss the Infinity Cache); loads only: step 16.40 -> 16.30 ms over five alternating runs.
+#ifndef UNIT_EPI_NT
+#define UNIT_EPI_NT 2
+#endif
+typedef __attribute__((ext_vector_type(4))) int epi_i32x4;
+__device__ __forceinline__ bf16x8 epi_load8(const bf16_t* q) {
+#if UNIT_EPI_NT == 1 || UNIT_EPI_NT == 2
+  return __builtin_bit_cast(bf16x8, __builtin_nontemporal_load(reinterpret_cast<const epi_i32x4*>(q)));
+#else
+  return *reinterpret_cast<const bf16x8*>(q);
+#endif
+}
+__device__ __forceinline__ void epi_store8(bf16_t* q, bf16x8 v) {
+#if UNIT_EPI_NT == 1 || UNIT_EPI_NT == 3
+  __builtin_nontemporal_store(__builtin_bit_cast(epi_i32x4, v), reinterpret_cast<epi_i32x4*>(q));
+#else
+  *reinterpret_cast<bf16x8*>(q) = v;
+#endif
+}
+
 template <int FA, int FB, bool EX, int RB, bool PM = false, typename Put, typename Args>
 __device__ __forceinline__ void epilogue_rows_bf16_blocks(Put put_block, char* scr, float* pool, int m_w, int n_w, const Args& p, int lane, const PmRows* rows = nullptr,
                                                           unsigned long long* stamp = nullptr) {
@@ -141,8 +166,8 @@ __device__ __forceinline__ void epilogue_rows_bf16_blocks(Put put_block, char* s
         int ow = mm % p.OW; int t = mm / p.OW; int oh = t % p.OH; int nimg = t / p.OH;
         q.off[h] = (((long)nimg * p.OHf + (long)oh * p.oy_mul) * p.OWf + (long)ow * p.oy_mul) * p.ldy + n;
       }
-      if (Rz && q.ok[h]) q.res[h] = *reinterpret_cast<const bf16x8*>(Rz + q.off[h]);
-      if (Mk && q.ok[h]) q.msk[h] = *reinterpret_cast<const bf16x8*>(Mk + q.off[h]);
+      if (Rz && q.ok[h]) q.res[h] = epi_load8(Rz + q.off[h]);
+      if (Mk && q.ok[h]) q.msk[h] = epi_load8(Mk + q.off[h]);
     }
   };
 
@@ -201,9 +226,9 @@ __device__ __forceinline__ void epilogue_rows_bf16_blocks(Put put_block, char* s
 #pragma unroll
           for (int j = 0; j < 8; ++j) run[j] += (float)o[j];
         }
-        if (Y && cur.ok[h]) *reinterpret_cast<bf16x8*>(Y + cur.off[h]) = o;
+        if (Y && cur.ok[h]) epi_store8(Y + cur.off[h], o);
       } else {
-        if (cur.ok[h]) *reinterpret_cast<bf16x8*>(Y + cur.off[h]) = o;
+        if (cur.ok[h]) epi_store8(Y + cur.off[h], o);
       }
     }
     if (b + 1 < NBLK) cur = nxt;
