@@ -151,7 +151,11 @@ __device__ __forceinline__ void wgrad128_ring_tile(const Wgrad256Args& p, int ti
 #pragma unroll
     for (int a = 0; a < 4; ++a) {
       int k = k0 + wk * 64 + a * 16 + fq * 4;
+#if UNIT_SLAB_NT
+      __builtin_nontemporal_store(acc[a][b], reinterpret_cast<f32x4*>(out + (size_t)n * p.Kgemm + k));     // read back once, by a later kernel
+#else
       *reinterpret_cast<f32x4*>(out + (size_t)n * p.Kgemm + k) = acc[a][b];
+#endif
     }
   }
 }

@@ -2,6 +2,9 @@
 // conv_wgrad256p8.hip: four phases per 64-pixel step, half-tile staging under a counted vmcnt).
 #pragma once
 #include "common.h"
+#ifndef UNIT_SLAB_NT
+#define UNIT_SLAB_NT 0      // 1: the fp32 slab tiles are stored non-temporal (tools/exp_wait.sh)
+#endif
 
 struct Wgrad256Args {
   const void* x; const void* dy; float* partial;
