@@ -27,6 +27,12 @@
 //        t+1 by either group comes after the barrier that ends that interval.
 // Same swizzle / k order / accumulation order / epilogue as conv_igemm256.hip: results are bit-identical to it.
 #include "conv_igemm256.h"
+#ifndef UNIT_P8_X_AUX
+#define UNIT_P8_X_AUX 0       // cache policy of the LDS-DMA loads (buffer instruction aux bits; 2 = nt): pixel rows / weights (tools/exp_wait.sh)
+#endif
+#ifndef UNIT_P8_W_AUX
+#define UNIT_P8_W_AUX 0
+#endif
 #ifndef UNIT_P8_RD_PER
 #define UNIT_P8_RD_PER 1        // fragment reads per MFMA gap inside the MFMA sections of phases 1 and 3 (tools/exp_wait.sh)
 #endif
@@ -183,9 +189,9 @@ __global__ void __launch_bounds__(512, 2) conv_igemm256_p8_kernel(Conv256Args p)
       bool ok = (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
       if (dual && st_cb >= p.cb_split) {      // (scalar branch) the row of x2: same pixel, ratio2 times the pitch; the 16-B chunk swizzle term stays
         unsigned o2 = (x_off0[q * 2 + j] - sw16) * (unsigned)p.ratio2 + sw16 + (unsigned)((st_cb - p.cb_split) * BK) * 2u;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX2, (lds_void*)(base + (j * 8 + wid) * 1024), 16, ok ? o2 : OOB, 0, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX2, (lds_void*)(base + (j * 8 + wid) * 1024), 16, ok ? o2 : OOB, 0, 0, UNIT_P8_X_AUX);
       } else
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, (lds_void*)(base + (j * 8 + wid) * 1024), 16, ok ? x_off0[q * 2 + j] + st_kx : OOB, 0, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, (lds_void*)(base + (j * 8 + wid) * 1024), 16, ok ? x_off0[q * 2 + j] + st_kx : OOB, 0, 0, UNIT_P8_X_AUX);
     }
   };
   auto stage_w = [&](int q, int d) {
@@ -193,7 +199,7 @@ __global__ void __launch_bounds__(512, 2) conv_igemm256_p8_kernel(Conv256Args p)
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       unsigned o = w_off[q * 2 + j];
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (lds_void*)(base + (j * 8 + wid) * 1024), 16, o == OOB ? OOB : o + st_kw, 0, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (lds_void*)(base + (j * 8 + wid) * 1024), 16, o == OOB ? OOB : o + st_kw, 0, 0, UNIT_P8_W_AUX);
     }
   };
 

@@ -21,6 +21,9 @@
 // MFMA section; a slot is restaged >= 2 phases after its last read; first read of step t+1 one phase after both groups'
 // vmcnt wait; UNIT_P8_FINE_WAIT as there). Same m permutation inside a fragment and same accumulation order as conv_wgrad256.hip: bit-identical slabs.
 #include "conv_wgrad256.h"
+#ifndef UNIT_W8_AUX
+#define UNIT_W8_AUX 0          // cache policy of the LDS-DMA loads (2 = nt; tools/exp_wait.sh)
+#endif
 #ifndef UNIT_W8_PER0
 #define UNIT_W8_PER0 1          // transposing fragment reads per MFMA gap in phases 0 / 1 / 3 (tools/exp_wait.sh)
 #define UNIT_W8_PER1 1
@@ -135,7 +138,7 @@ __device__ __forceinline__ void wgrad256_p8_tile(const Wgrad256Args& p, int tile
         ok = ok && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
         xoff = ((unsigned)n * (unsigned)(p.H * p.W * p.C) + (unsigned)((ih * p.W + iw) * p.C) + xcol[q]) * 2u;
       }
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, (lds_void_w*)(base + (j * 8 + wid) * 1024), 16, ok ? xoff : OOB, 0, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, (lds_void_w*)(base + (j * 8 + wid) * 1024), 16, ok ? xoff : OOB, 0, 0, UNIT_W8_AUX);
     }
   };
   auto stage_d = [&](int q, int d, int mstep) {
@@ -153,7 +156,7 @@ __device__ __forceinline__ void wgrad256_p8_tile(const Wgrad256Args& p, int tile
     for (int j = 0; j < 2; ++j) {
       int m = mstep + s_row[j];
       unsigned doff = ((unsigned)(vo ? xn[j] * p.OHW + tv[j] : m) * (unsigned)p.ldy + dcol[q]) * 2u;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsD, (lds_void_w*)(base + (j * 8 + wid) * 1024), 16, m < m_end ? doff : OOB, 0, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsD, (lds_void_w*)(base + (j * 8 + wid) * 1024), 16, m < m_end ? doff : OOB, 0, 0, UNIT_W8_AUX);
     }
   };
 
