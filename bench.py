@@ -241,7 +241,7 @@ def main():
             "metric": "images/sec (fwd+bwd+SGD) R101-C4 VOC 600x1000 bs=2/GPU" if args.depth == 101 else f"images/sec R{args.depth}-C4",
             "value": round(value, 3), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": args.dtype, "data": "synthetic", "launch": ("hipGraph replay" if world == 1 else "hipGraph replay (forward+backward | eager all-reduce | optimizer)") if (args.graph and early is None) else "eager",
+            "dtype": args.dtype, "data": "synthetic", "launch": ("hipGraph replay" if world == 1 else "hipGraph replay (one graph per gradient-bucket stage, the bucket all-reduces launched between the replays | optimizer graph)") if (args.graph and early is None) else "eager",
             "host_enqueue_ms_per_step": round(host_ms, 3),      # max over ranks
             "allreduce_exposed_ms": round(exposed_ms, 3),       # max over ranks: compute-stream time inside GradBuckets.finish() per step
             "config": {"workload": f"UniT base-training step {args.variant.upper()} (TrainerNoMeta.run_step): ResNet-{args.depth}-C4, "

@@ -1,6 +1,7 @@
 """One rank of the 2-rank data-parallel rehearsal (tests/test_dp_gpu.py starts two of these as fresh child processes; both
 share cuda:0 and talk gloo through 127.0.0.1 -- the RCCL run differs only in the backend name).
-usage: python tests/dp_rehearsal_worker.py <rank> <world> <port> <out.pt> [fp32|bf16_buckets|graph|eager] [steps]"""
+usage: python tests/dp_rehearsal_worker.py <rank> <world> <port> <out.pt> [fp32|bf16_buckets|graph|graph_whole|eager] [steps]
+(graph = one graph per gradient-bucket stage with the bucket all-reduces between the replays; graph_whole = one graph + one all-reduce)"""
 import os
 import sys
 
@@ -41,7 +42,8 @@ def main():
     model.compute_dtype = torch.float32
     mode = sys.argv[5] if len(sys.argv) > 5 else "fp32"
     steps = int(sys.argv[6]) if len(sys.argv) > 6 else 1
-    tr = engine.TrainerNoMeta(cfg, model, bf16_buckets=(mode == "bf16_buckets"), use_graph=(mode == "graph"))
+    tr = engine.TrainerNoMeta(cfg, model, bf16_buckets=(mode == "bf16_buckets"), use_graph=mode in ("graph", "graph_whole"),
+                              graph_per_bucket=(mode == "graph"))
     if mode == "eager":          # the graphed trainer's packing capacity and device-resident learning rate, launched eagerly
         tr.optimizer._bind()
     sup, weak = global_batch()
@@ -58,7 +60,11 @@ def main():
         else:
             losses = tr.run_step(engine.shard_batch(sup, rank, world), engine.shard_batch(weak, rank, world))
     torch.cuda.synchronize()
-    torch.save({"params": model.store.params.cpu(), "losses": losses.cpu()}, out)
+    nseg = 0
+    if tr.graphed is not None and tr.graphed.graphs:
+        g = next(iter(tr.graphed.graphs.values()))[0]
+        nseg = len(g[0]) if (isinstance(g, tuple) and isinstance(g[0], list)) else 1
+    torch.save({"params": model.store.params.cpu(), "losses": losses.cpu(), "graph_segments": nseg}, out)
     dist.barrier()
     dist.destroy_process_group()
 

@@ -81,11 +81,15 @@ def test_two_ranks_bf16_gradient_buckets(dev, tmp_path):
     assert upd <= 1e-4, upd
 
 
-def test_two_ranks_graphed_step(dev, tmp_path):
-    """engine.GraphedStep under data parallelism (graph A: forward + backward, one eager all-reduce of the flat gradient buffer,
-    graph B: optimizer): two eager warm-up steps, the capture, two replays == five eager steps with per-bucket all-reduces."""
-    g0, g1 = _run_ranks(tmp_path, extra=("graph", "5"))
+@pytest.mark.parametrize("mode", ["graph", "graph_whole"])
+def test_two_ranks_graphed_step(dev, tmp_path, mode):
+    """engine.GraphedStep under data parallelism -- "graph": the forward + backward as one graph per gradient-bucket stage with each
+    bucket's all-reduce launched between two replays (overlapping the rest of the backward), then the optimizer graph; "graph_whole":
+    one graph, one all-reduce of the flat gradient buffer, optimizer graph. Two eager warm-up steps, the capture, two replays == five
+    eager steps with per-bucket all-reduces."""
+    g0, g1 = _run_ranks(tmp_path, extra=(mode, "5"))
     assert torch.equal(g0["params"], g1["params"]), "ranks diverged"
+    assert (g0["graph_segments"] >= 4) if mode == "graph" else (g0["graph_segments"] == 1), g0["graph_segments"]
     (tmp_path / "e").mkdir()
     e0, e1 = _run_ranks(tmp_path / "e", extra=("eager", "5"))
     assert torch.equal(e0["params"], e1["params"])

@@ -69,7 +69,11 @@ def lib():
 _DEBUG_SYNC = bool(int(os.environ.get("UNIT_DEBUG_SYNC", "0")))      # diagnostic: name every launch and wait for it (finds the kernel behind a GPU fault)
 
 
+LAUNCHES = [0]          # number of successful C-ABI calls so far (engine.GraphedStep: did anything go into the running capture?)
+
+
 def check(status, what=""):
+    LAUNCHES[0] += 1
     if status != 0:
         msg = lib().unit_last_error()
         raise UnitLibError(f"{what} failed with status {status}: {msg.decode() if msg else ''}")

@@ -61,17 +61,25 @@ class GraphedStep:
     would free scratch whose address an earlier graph replays into -- ops.workspace is grow-only for the same reason). Images with
     more ground-truth boxes than a capacity bucket move to the next bucket (GT_BUCKETS), which is part of the key.
     Data parallel (`buckets` with world > 1): collectives are kept OUT of the captures -- RCCL inside a hipGraph could not be rehearsed
-    on the 1-GPU boxes this was built on. The step becomes graph A (forward + backward, no per-bucket hook), ONE eager all-reduce
-    of the whole flat gradient buffer, graph B (optimizer + weight re-preparation): the host cost of a graphed step, but the
-    all-reduce no longer hides behind the backward (268 MB over xGMI, ~1-2 ms exposed). Which side of that trade wins on an 8-GPU
-    host depends on how many cores each rank gets; the eager overlapped path stays the default (TrainerNoMeta(use_graph=False))."""
+    on the 1-GPU boxes this was built on. per_bucket=True (default): the forward + backward become a CHAIN of graphs cut at every
+    gradient-bucket boundary (`_capture_segments`: ~10 graphs sharing one pool) and each bucket's all-reduce is launched eagerly
+    between two replays, so the collectives overlap the rest of the backward as in eager mode at the host cost of a graphed step
+    (~10 replays + ~10 collective launches); then the bucket waits and graph B (optimizer + weight re-preparation). Every cut joins
+    the side streams into the capturing stream (a fork cannot span two captures): the weight gradients of a bucket finish before
+    the next bucket's dgrad chain starts. per_bucket=False: graph A (forward + backward, no per-bucket hook), ONE eager all-reduce of
+    the whole flat gradient buffer (268 MB over xGMI, ~1-2 ms exposed), graph B. The eager overlapped path stays the default
+    (TrainerNoMeta(use_graph=False))."""
 
     GT_BUCKETS = (32, 64, 128, 256)
 
-    def __init__(self, model, optimizer, warmup_steps=2, buckets=None):
+    def __init__(self, model, optimizer, warmup_steps=2, buckets=None, per_bucket=True):
+        """per_bucket (data parallel only): capture the forward + backward as ONE GRAPH PER GRADIENT-BUCKET STAGE (heads | Res5 heads | RPN |
+        res4 a-d | res3) and launch each bucket's all-reduce eagerly between the replays, so that the collectives overlap the rest
+        of the backward as in eager mode; False: one graph, one all-reduce of the whole flat gradient buffer after it"""
         import torch
         self.model, self.optimizer, self.warmup_steps = model, optimizer, warmup_steps
         self.buckets = buckets if (buckets is not None and buckets.world > 1) else None
+        self.per_bucket = per_bucket
         self.graphs = {}          # key -> (graph | (graph A, graph B), static PackedBatch, losses tensor)
         self.seen = set()         # keys that have run one eager step (constants uploaded, workspaces sized)
         self.pool = None
@@ -107,6 +115,50 @@ class GraphedStep:
             if forked:
                 cur.wait_stream(s)
 
+    def _capture_segments(self, static):
+        """forward + backward captured as a chain of graphs that share one memory pool, cut at every gradient-bucket boundary: the
+        model's `on_grad_ready(tag)` hook (called from the backward plan right after the bucket's slab reduction, on the
+        weight-gradient stream) joins every forked stream into the capturing stream, ends the running capture and begins the next
+        one. -> ([(graph, tags)], losses, pool); replay in order, launching `buckets.ready(tag)` for the tags of each graph after it."""
+        torch = self._torch
+        model = self.model
+        cap = torch.cuda.Stream(model.device)
+        cap.wait_stream(torch.cuda.current_stream())
+        segs, state = [], {"g": None, "pool": self.pool if self.pool is not None else torch.cuda.graph_pool_handle()}
+
+        from ._lib import LAUNCHES
+
+        def begin():
+            g = torch.cuda.CUDAGraph()
+            g.capture_begin(pool=state["pool"])
+            state["g"], state["n0"], state["tags"] = g, LAUNCHES[0], []
+
+        def split(tag):
+            state["tags"].append(tag)
+            if LAUNCHES[0] == state["n0"]:
+                return          # nothing was launched since the last cut (two buckets that end together): their all-reduces go out together
+            here = torch.cuda.current_stream()
+            with torch.cuda.stream(cap):
+                self._join_side_streams()
+                state["g"].capture_end()
+                segs.append((state["g"], tuple(state["tags"])))
+                begin()
+            if here.cuda_stream != cap.cuda_stream:
+                here.wait_stream(cap)          # the caller goes on enqueueing on `here`: it belongs to the new capture now
+
+        hook, model.on_grad_ready = model.on_grad_ready, split
+        try:
+            with torch.cuda.stream(cap):
+                begin()
+                losses = self._fwd_bwd(static)
+                self._join_side_streams()
+                state["g"].capture_end()
+                segs.append((state["g"], tuple(state["tags"])))
+        finally:
+            model.on_grad_ready = hook
+        torch.cuda.current_stream().wait_stream(cap)
+        return segs, losses, state["pool"]
+
     @staticmethod
     def _refill(static, fresh):
         for a, b in zip(static.images, fresh.images):
@@ -141,6 +193,12 @@ class GraphedStep:
             if self.buckets is None:
                 with torch.cuda.graph(g, pool=self.pool):
                     losses = self._body(static)
+            elif self.per_bucket:
+                segs, losses, pool = self._capture_segments(static)          # collectives stay outside the captures, between them
+                g2 = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g2, pool=pool):
+                    opt.step()
+                g = (segs, g2)
             else:
                 hook, model.on_grad_ready = model.on_grad_ready, None          # no collective inside the capture
                 try:
@@ -154,11 +212,21 @@ class GraphedStep:
                     opt.step()
                 g = (g, g2)
             opt.iter, opt._first = it, first            # the capture only recorded the launches: nothing has run yet
-            self.pool = self.pool or (g[0] if isinstance(g, tuple) else g).pool()
+            if isinstance(g, tuple) and isinstance(g[0], list):
+                self.pool = self.pool or pool
+            else:
+                self.pool = self.pool or (g[0] if isinstance(g, tuple) else g).pool()
             ent = self.graphs[key] = (g, static, losses)
         else:
             self._refill(ent[1], fresh)
-        if isinstance(ent[0], tuple):
+        if isinstance(ent[0], tuple) and isinstance(ent[0][0], list):
+            for seg, tags in ent[0][0]:
+                seg.replay()
+                for tag in tags:
+                    self.buckets.ready(tag)          # asynchronous all-reduce of the bucket, ordered after the replay just launched
+            self.buckets.finish()
+            ent[0][1].replay()
+        elif isinstance(ent[0], tuple):
             ent[0][0].replay()
             self.buckets.reduce_all()
             ent[0][1].replay()
@@ -171,7 +239,7 @@ class GraphedStep:
 
 class TrainerNoMeta:
     def __init__(self, cfg, model, data_iter=None, weak_data_iter=None, group=None, early_update=False, bf16_buckets=False,
-                 use_graph=False, overlap_tail=False):
+                 use_graph=False, overlap_tail=False, graph_per_bucket=True):
         """overlap_tail: the end of a step (last weight gradients, all-reduce waits, SGD, weight re-preparation) stays on the model's
         weight-gradient stream and overlaps the next step's preprocessing / frozen layers (GeneralizedRCNN.overlap_optimizer_tail);
         read parameters between steps only after model.join_optimizer_tail() (state_dict() does it)."""
@@ -184,7 +252,7 @@ class TrainerNoMeta:
         self.iter = 0
         self.last_losses = None
         self.early = EarlyUpdate(model, self.buckets, self.optimizer) if early_update else None
-        self.graphed = GraphedStep(model, self.optimizer, buckets=self.buckets) if (use_graph and not early_update) else None
+        self.graphed = GraphedStep(model, self.optimizer, buckets=self.buckets, per_bucket=graph_per_bucket) if (use_graph and not early_update) else None
 
     def run_step(self, base_data=None, classifier_data=None):
         assert self.model.training, "[TrainerNoMeta] model was changed to eval mode!"
