@@ -785,21 +785,38 @@ extern "C" int unit_pool_finish(const float* partial, int R, int rows, int ldy, 
 // g[m][n] = bit(m0 + m, n) ? dfeat[m / rows][n] / rows : 0 -- backward of (global average pool o ReLU) from the bit mask the fused
 // forward left behind (replaces unit_global_avgpool_bwd_relu's read of the whole output map). m0 = first row of this slice inside
 // the map the bits were written for (the weak head backpropagates only its weak RoIs).
-__global__ void avgpool_bwd_bits_kernel(const bf16_t* __restrict__ dfeat, const unsigned char* __restrict__ bits, long M, long m0, int rows,
+__global__ void avgpool_bwd_bits_kernel(const bf16_t* __restrict__ dfeat, const unsigned char* __restrict__ bits, long R, long m0, int rows,
                                         int C, bf16_t* __restrict__ g) {
-  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;          // one lane = 8 channels of one row
-  int cb = C / 8;
-  if (i >= M * cb) return;
-  long m = i / cb; int c0 = (int)(i - m * cb) * 8;
-  long word; int bit;
-  relu_bit_index(m0 + m, c0, C, word, bit);
-  unsigned b = bits[word * 16 + (bit >> 3)];
-  bf16x8 d = *reinterpret_cast<const bf16x8*>(dfeat + (m / rows) * C + c0);
+  // one lane = 8 channels of SEVEN consecutive bins of one RoI: one IEEE division per channel for the seven outputs (the kernel was
+  // VALU-heavy with one per output element), seven bit bytes in flight, then seven non-temporal 16-byte stores (the 205 MB map is
+  // written once and read by later kernels: 73 -> 5x us at the Res5 size, tools/avgpool_bits_bench.py)
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int cb = C / 8, ng = (rows + 6) / 7;
+  if (i >= R * ng * cb) return;
+  long t = i / cb; int c0 = (int)(i - t * cb) * 8;
+  long roi = t / ng; int r0 = (int)(t - roi * ng) * 7;
+  bf16x8 d = *reinterpret_cast<const bf16x8*>(dfeat + roi * C + c0);
   float inv = (float)rows;
-  bf16x8 o;
+  bf16x8 q;
 #pragma unroll
-  for (int j = 0; j < 8; ++j) o[j] = (bf16_t)(((b >> j) & 1u) ? (float)d[j] / inv : 0.f);      // = unit_global_avgpool_bwd_relu's arithmetic
-  *reinterpret_cast<bf16x8*>(g + m * C + c0) = o;
+  for (int j = 0; j < 8; ++j) q[j] = (bf16_t)((float)d[j] / inv);      // = unit_global_avgpool_bwd_relu's arithmetic
+  const bf16_t zero = (bf16_t)0.f;
+  unsigned b[7];
+#pragma unroll
+  for (int u = 0; u < 7; ++u) {
+    long word; int bit;
+    relu_bit_index(m0 + roi * rows + min(r0 + u, rows - 1), c0, C, word, bit);
+    b[u] = bits[word * 16 + (bit >> 3)];
+  }
+#pragma unroll
+  for (int u = 0; u < 7; ++u) {
+    if (r0 + u >= rows) break;
+    bf16x8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = ((b[u] >> j) & 1u) ? q[j] : zero;
+    typedef __attribute__((ext_vector_type(4))) int i4;
+    __builtin_nontemporal_store(__builtin_bit_cast(i4, o), reinterpret_cast<i4*>(g + (roi * rows + r0 + u) * C + c0));
+  }
 }
 
 extern "C" size_t unit_relu_bits_bytes(int M, int ldy) { return (size_t)cdiv(M, 128) * 128 * (size_t)(ldy / 8); }
@@ -808,8 +825,8 @@ extern "C" int unit_avgpool_bwd_bits(const void* dfeat, const unsigned char* bit
   UNIT_CHECK_ARG(C % 64 == 0, "avgpool_bwd_bits: C % 64");
   long M = (long)R * rows;
   if (M == 0) return UNIT_OK;
-  long n = M * (C / 8);
-  avgpool_bwd_bits_kernel<<<(unsigned)cdiv(n, 256L), 256, 0, (hipStream_t)stream>>>((const bf16_t*)dfeat, bits, M, (long)roi_offset * rows, rows, C,
+  long n = (long)R * ((rows + 6) / 7) * (C / 8);
+  avgpool_bwd_bits_kernel<<<(unsigned)cdiv(n, 256L), 256, 0, (hipStream_t)stream>>>((const bf16_t*)dfeat, bits, (long)R, (long)roi_offset * rows, rows, C,
                                                                                     (bf16_t*)g);
   UNIT_LAUNCH_CHECK();
   return UNIT_OK;
