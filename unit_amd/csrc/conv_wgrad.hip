@@ -394,8 +394,8 @@ extern "C" int unit_conv2d_wgrad_group_plan(UnitWgradProblem* pr, int n, int spl
       // bucket (102 tiles, 150 steps): 315 / 177 / 219 / 176 / 191 / 209 us measured with 1 / 2 / 3 / 4 / 6 / 8 slabs per layer, model 342 /
       // 177 / 244 / 188 / 201 / 212; the RPN's 3x3 (144 tiles, 75 steps): 180 / 188 / 134 measured with 1 / 2 / 3, model 177 / 188 / 134.
       // For the long loops of a Res5 head (236 tiles, 784 steps) the model is flat (1.74-1.82 ms) while 3-8 slabs measured 5-8 % faster
-      // than 1-2 (1.49-1.55 against 1.62 ms: units of 16-36 tiles quantise on an XCD's 32 CUs until there are several rounds of them):
-      // of the split counts within 3 % of the model's best, the largest. At least 24 steps per workgroup.
+      // than 1-2 (1.49-1.55 against 1.62 ms: units of 16-36 tiles quantise on an XCD's 32 CUs until there are several rounds of them).
+      // At least 24 steps per workgroup.
       long tiles = 0;
       for (int i = 0; i < n; ++i)
         if (pr[i].kind == kind) tiles += (long)(pr[i].R * pr[i].S * pr[i].C / T) * (pr[i].K / T);
@@ -405,9 +405,14 @@ extern "C" int unit_conv2d_wgrad_group_plan(UnitWgradProblem* pr, int n, int spl
       if (smax > 64) smax = 64;
       // (a round counts as full at 90 % of its slots: the units are dealt to the XCDs by weight, not evenly by workgroup count)
       auto model = [&](int sref) { return ceil((double)(tiles * sref) / (0.9 * 256.0)) * (12.0 + 2.2 * steps / sref); };
-      for (int sref = 1; sref <= smax; ++sref) tmin = model(sref) < tmin ? model(sref) : tmin;
+      int argmin = 1;
       for (int sref = 1; sref <= smax; ++sref)
-        if (model(sref) <= 1.03 * tmin) best = sref;
+        if (model(sref) < tmin) { tmin = model(sref); argmin = sref; }
+      // every slab is read back by the reduction (a Res5 head: 60 MB each): of the split counts within 3 % of the best, the SMALLEST that
+      // still gives 2.5 rounds of workgroups (3 slabs per layer for a Res5 head: 1 522 us against 1 541 with 5); none such: the model's best
+      best = argmin;
+      for (int sref = smax; sref >= 1; --sref)
+        if (model(sref) <= 1.03 * tmin && tiles * sref >= 640) best = sref;
     }
     for (int i = 0; i < n; ++i)
       if (pr[i].kind == kind) pr[i].splits = splits_of(i, best);
