@@ -292,6 +292,8 @@ class WeaklySupervisedRCNNNoMeta(nn.Module):
         reference's `"proposals" in batched_inputs[0]` branch (rcnn.py:474-481); the RPN still trains on its own outputs."""
         self._ensure_ready()
         self._early_backward = early_backward
+        if self.plan is not None:
+            self.plan.begin_step()          # nothing a previous (interrupted) step queued may leak into this one
         rpn, rh, bp = self.proposal_generator, self.roi_heads, self.roi_heads.box_predictor
         dt = self.compute_dtype
         c = type("StepCtx", (), {})()

@@ -94,6 +94,12 @@ class ConvPlan:
         if lst[0] >= self.flush_bytes:
             self._flush(key)
 
+    def begin_step(self):
+        """called at the start of every training forward (the early RPN backward queues weight gradients during it): nothing queued
+        by an earlier, interrupted step may leak into this one"""
+        self._deferred = []
+        self._pending = {}
+
     def defer_wgrad(self, conv, x, dy, stride, accumulate):
         """queue a layer's weight gradient for the next grouped launch; False = not eligible (the caller launches it itself)"""
         if not self.group_wgrads or not ops.wgrad_group_supported(x, dy, conv.cout, conv.k, conv.k, stride, conv.pad):
