@@ -174,3 +174,34 @@ def test_loader_consumer_tile_choice_is_host_arithmetic():
     # short contractions and big maps stay on the 4-wave tiles
     assert ops.MID_TILE_POLICY(torch.bfloat16, m, 1024, 256, 256) < 100
     assert ops.MID_TILE_POLICY(torch.bfloat16, 4 * 150 * 250, 256, 64, 576) < 100
+
+
+def test_wgrad_group_plan_is_host_arithmetic():
+    """unit_conv2d_wgrad_group_plan (tile kind and split count of every layer of a grouped weight-gradient launch) runs on the host:
+    Res5-sized layers get 256x256 tiles and 3 slabs, a res4 gradient bucket 2, the RPN's 3x3 conv 3; 128-channel layers and a lone
+    two-tile layer go to the 128x128 grid; ineligible layers are refused (csrc/conv_wgrad.hip, profiles/r03_exp_grouped_wgrad.txt)."""
+    from unit_amd import ops
+
+    def plan(cases, hint=0):
+        pr = (ops.WgradProblem * len(cases))()
+        for q, (n, h, w, c, k, r, stride, pad) in zip(pr, cases):
+            oh, ow = ops.conv_out_size(h, w, r, r, stride, pad)
+            q.N, q.H, q.W, q.C, q.K, q.R, q.S, q.stride, q.pad, q.OH, q.OW, q.ldy = n, h, w, c, k, r, r, stride, pad, oh, ow, k
+        rc = ops.lib().unit_conv2d_wgrad_group_plan(pr, len(cases), hint)
+        return rc, [(q.kind, q.splits) for q in pr]
+
+    n = 1024
+    head = [(n, 14, 14, 1024, 512, 1, 2, 0), (n, 7, 7, 512, 512, 3, 1, 1), (n, 7, 7, 512, 2048, 1, 1, 0), (n, 14, 14, 1024, 2048, 1, 2, 0)] + \
+           [(n, 7, 7, 2048, 512, 1, 1, 0), (n, 7, 7, 512, 512, 3, 1, 1), (n, 7, 7, 512, 2048, 1, 1, 0)] * 2
+    assert plan(head) == (0, [(2, 3)] * 10)
+    bucket = [(4, 38, 63, 1024, 256, 1, 1, 0), (4, 38, 63, 256, 256, 3, 1, 1), (4, 38, 63, 256, 1024, 1, 1, 0)] * 6
+    assert plan(bucket) == (0, [(2, 2)] * 18)
+    assert plan([(2, 38, 63, 1024, 1024, 3, 1, 1)]) == (0, [(2, 3)])
+    assert plan(bucket, hint=5)[1] == [(2, 5)] * 18                                  # the caller's split count
+    assert plan([(4, 150, 250, 256, 512, 1, 2, 0)])[1][0][0] == 1                    # two 256x256 tiles alone: the 128x128 grid
+    res3 = [(4, 75, 125, 512, 128, 1, 1, 0), (4, 75, 125, 128, 128, 3, 1, 1), (4, 75, 125, 128, 512, 1, 1, 0)] * 3
+    rc, ks = plan(res3)
+    assert rc == 0 and all(k == 1 for k, _ in ks) and len({sp for _, sp in ks}) == 1 and 2 <= ks[0][1] <= 16
+    assert plan([(2, 8, 8, 64, 128, 1, 1, 0)])[0] != 0                                # C % 128 != 0: not eligible
+    assert ops.lib().unit_conv2d_wgrad_group_supported(ops.dt(torch.bfloat16), 4, 38, 63, 256, 1, 1, 1024) == 2
+    assert ops.lib().unit_conv2d_wgrad_group_supported(ops.dt(torch.float32), 4, 38, 63, 256, 1, 1, 1024) == 0
