@@ -679,6 +679,8 @@ extern "C" int unit_conv2d_fwd_big(const void* x, const void* w, void* y, const 
       long n_tiles = cdiv(K, 256);
       long c256 = (long)cdiv((long)cdiv(a.M, 256) * n_tiles, 256) * 256, c224 = (long)cdiv((long)cdiv(a.M, 224) * n_tiles, 256) * 224;
       r224 = c224 < c256;
+      // (not where the position-class tiles apply: they need 256 rows and gain more)
+      if (variant == 0 && R == 3 && S == 3 && stride == 1 && pad == 1 && OH == H && OW == W && H * W <= 4096) r224 = false;
     }
     // 11 (and 0 when UNIT_P8M_DEFAULT is 1): the variant-8 schedule on v_mfma_f32_32x32x16_bf16 (conv_igemm256p8m.hip)
     if (variant == 11 || (variant == 0 && p8 == 2 && !r224 && unit_conv256_use_m32())) return unit_conv256_p8m_launch(a, out_dtype, st);
