@@ -44,4 +44,9 @@ for i in range(3):
     l = step()
     torch.cuda.synchronize()
     print("poisoned step", i, l.tolist(), flush=True)
+model.eval()
+with torch.no_grad():
+    out = model.inference(sup)
+torch.cuda.synchronize()
+print("inference on the poisoned model:", [len(o["instances"]) for o in out], "detections")
 print("survived")
