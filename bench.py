@@ -44,6 +44,9 @@ def parse():
                     "drops, the device runs the replay ~2.5 %% slower than the eager four-stream schedule: off by default")
     ap.add_argument("--early-update", action="store_true", help="per-bucket optimizer updates beside the backward instead of one "
                     "update after it (engine.EarlyUpdate; measured 18.56 vs 18.43 ms per step: off by default)")
+    ap.add_argument("--high-priority", action="store_true", help="run the steps on a high-priority HIP stream instead of PyTorch's default stream "
+                    "(GeneralizedRCNN.high_priority_stream: the forward / dgrad chain ahead of the weight-gradient and head side streams; measured "
+                    "between -0.17 and +0.05 ms per step over four A/B series: inside the noise, off by default)")
     ap.add_argument("--tail-overlap", action="store_true", help="let the end of a step (last weight gradients, SGD, weight re-preparation) "
                     "overlap the next step's frozen layers instead of joining the weight-gradient stream first "
                     "(GeneralizedRCNN.overlap_optimizer_tail; measured 119.3 vs 121.4 images/s at N=1: off by default)")
@@ -155,6 +158,10 @@ def main():
             early.join()
         opt.step()
         return step.losses
+
+    if args.high_priority and not (args.no_overlap or args.graph):
+        torch.cuda.synchronize()
+        torch.cuda.set_stream(model.high_priority_stream())          # the step's main chain ahead of the side streams it forks (rcnn.py)
 
     timed_step = one_step
     if args.graph and early is None:

@@ -419,6 +419,34 @@ def test_diverged_model_raises_instead_of_faulting_the_device(dev):
     assert not all(math.isfinite(v) for v in tr.loss_dict(detect_anomaly=False).values())
 
 
+def test_high_priority_step_stream_is_bit_identical(dev):
+    """TrainerNoMeta(high_priority=True) makes a high-priority HIP stream the thread's current stream and runs the steps there: same
+    parameters / momentum / losses as on the default stream."""
+    from unit_amd import engine
+    outs = []
+    default = torch.cuda.current_stream()
+    try:
+        for hp in (False, True):
+            cfg = small_cfg()
+            model = build_model(cfg)
+            init_synthetic_weights(model, seed=3)
+            model.train()
+            torch.manual_seed(0)
+            torch.cuda.manual_seed(0)
+            tr = engine.TrainerNoMeta(cfg, model, high_priority=hp)
+            assert (torch.cuda.current_stream() != default) == hp
+            for it in range(3):
+                sup, weak = synthetic_batch(2, 2, hw=(128, 192), seed=7 + it, max_gt=4)
+                losses = tr.run_step(sup, weak)
+            outs.append((model.store.params.clone(), tr.optimizer._buf.clone(), losses.clone()))
+            torch.cuda.synchronize()
+    finally:
+        torch.cuda.synchronize()
+        torch.cuda.set_stream(default)
+    assert torch.allclose(outs[0][0], outs[1][0], rtol=1e-6, atol=1e-9) and torch.allclose(outs[0][1], outs[1][1], rtol=1e-5, atol=1e-9)
+    assert torch.allclose(outs[0][2], outs[1][2], rtol=1e-5, atol=1e-7), (outs[0][2].tolist(), outs[1][2].tolist())
+
+
 def test_optimizer_tail_overlap_is_bit_identical(dev):
     """TrainerNoMeta(overlap_tail=True): the end of a step (last weight gradients, SGD, weight re-preparation) stays on the
     weight-gradient stream while the next step's frozen layers start; the main stream joins before its first trainable layer, and

@@ -239,11 +239,18 @@ class GraphedStep:
 
 class TrainerNoMeta:
     def __init__(self, cfg, model, data_iter=None, weak_data_iter=None, group=None, early_update=False, bf16_buckets=False,
-                 use_graph=False, overlap_tail=False, graph_per_bucket=True):
+                 use_graph=False, overlap_tail=False, graph_per_bucket=True, high_priority=False):
         """overlap_tail: the end of a step (last weight gradients, all-reduce waits, SGD, weight re-preparation) stays on the model's
         weight-gradient stream and overlaps the next step's preprocessing / frozen layers (GeneralizedRCNN.overlap_optimizer_tail);
         read parameters between steps only after model.join_optimizer_tail() (state_dict() does it)."""
         self.cfg, self.model = cfg, model
+        if high_priority and model.device.type == "cuda":
+            # the steps' main chain ahead of the side streams the plan forks (GeneralizedRCNN.high_priority_stream). This makes the
+            # high-priority stream the calling thread's CURRENT stream from here on -- whatever the caller enqueues next is ordered
+            # behind the steps; work it has on other streams is not.
+            import torch
+            torch.cuda.synchronize()
+            torch.cuda.set_stream(model.high_priority_stream())
         model.overlap_optimizer_tail = bool(overlap_tail) and not early_update and not use_graph
         self.data_iter, self.weak_data_iter = data_iter, weak_data_iter
         self.buckets = GradBuckets(model, group, bf16=bf16_buckets)
