@@ -50,7 +50,94 @@ def parse():
     ap.add_argument("--tail-overlap", action="store_true", help="let the end of a step (last weight gradients, SGD, weight re-preparation) "
                     "overlap the next step's frozen layers instead of joining the weight-gradient stream first "
                     "(GeneralizedRCNN.overlap_optimizer_tail; measured 119.3 vs 121.4 images/s at N=1: off by default)")
+    ap.add_argument("--bucket-mb", type=float, default=None, help="gradient bucket size in MB (parallel.GradBuckets; default 64 / UNIT_BUCKET_MB)")
+    ap.add_argument("--reduce-mode", default=None, choices=["allreduce", "rs_ag", "direct"], help="how a gradient bucket crosses xGMI: one all-reduce "
+                    "(default), reduce-scatter + all-gather in place, or all-to-all + ordered owner-side sum + all-gather (all 7 links at once, "
+                    "bit-reproducible); parallel.py")
+    ap.add_argument("--bf16-buckets", action="store_true", help="exchange bf16 copies of the gradient buckets (half the bytes)")
+    ap.add_argument("--force-collectives", action="store_true", help="N=1 only: initialise RCCL with one rank and keep every collective of the "
+                    "data-parallel step in the timed region (what an N>1 run adds on the device side, minus the wire)")
+    ap.add_argument("--shapes", default="fixed", choices=["fixed", "voc"], help="fixed: the headline 600x1000 workload; voc: a SECONDARY labelled line "
+                    "over steps whose image sizes are drawn like ResizeShortestEdge((480..800), 1333) on VOC aspect ratios "
+                    "(configs/VOC/VOC-RCNN-101-C4-split1.yaml:27-29)")
+    ap.add_argument("--dry-launch", action="store_true", help="launcher self-test: the rank processes print their rendezvous environment and exit "
+                    "(no GPU call anywhere)")
+    ap.add_argument("--launch-timeout", type=float, default=3600.0, help="seconds the launcher waits for its rank processes")
     return ap.parse_args()
+
+
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def launch_ranks(args):
+    """`python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment: this process -- which has made NO GPU call and makes
+    none -- starts N fresh copies of itself, one rank per GPU (the reference: scripts/train_VOC.py:67-77 -> detectron2 launch ->
+    mp.spawn + init_process_group("NCCL", tcp://127.0.0.1:port)), waits for them, prints rank 0's JSON line if and only if every
+    rank ended with status 0, and returns the first non-zero status otherwise. Children are ended by PID, never by pattern."""
+    import subprocess
+    import tempfile
+    n = args.gpus
+    backend = os.environ.get("UNIT_DIST_BACKEND", "nccl")
+    if not args.dry_launch and backend == "nccl":
+        ndev = torch.cuda.device_count()          # counts devices without initialising the GPU runtime in this process
+        if ndev < n:
+            print(f"bench.py: --gpus {n} needs {n} visible GPUs (one rank per GPU over RCCL), this box shows {ndev}. Nothing was run. "
+                  f"(A single-GPU rehearsal of the multi-process path exists: UNIT_DIST_BACKEND=gloo python bench.py --gpus {n}.)", file=sys.stderr)
+            return 2
+    port = _free_port()
+    outs = [tempfile.NamedTemporaryFile(prefix=f"unit_bench_rank{r}_", suffix=".out", delete=False) for r in range(n)]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), UNIT_BENCH_LAUNCHED="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # dmabuf IPC: RCCL across processes needs it on this driver
+        env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or n) // n)))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=outs[r]))
+    deadline = time.time() + args.launch_timeout
+    rc = 0
+    live = list(procs)
+    while live:
+        for p in list(live):
+            c = p.poll()
+            if c is not None:
+                live.remove(p)
+                if c != 0 and rc == 0:
+                    rc = c if c > 0 else 1
+        if (rc != 0 or time.time() > deadline) and live:
+            if rc == 0:
+                rc = 124
+                print(f"bench.py: rank processes still running after {args.launch_timeout:.0f} s", file=sys.stderr)
+            for p in live:          # one rank failed: the others would wait in a collective for ever
+                p.terminate()
+            t_end = time.time() + 20
+            for p in live:
+                try:
+                    p.wait(timeout=max(0.1, t_end - time.time()))
+                except subprocess.TimeoutExpired:
+                    p.kill()
+            live = []
+        else:
+            time.sleep(0.05)
+    texts = []
+    for f in outs:
+        f.close()
+        texts.append(open(f.name).read())
+        os.unlink(f.name)
+    text = "".join(texts) if args.dry_launch else texts[0]          # only rank 0 prints the result line
+    if rc != 0:
+        print(f"bench.py: a rank process ended with status {rc}; no result line", file=sys.stderr)
+        sys.stderr.write(text[-2000:])
+        return rc
+    sys.stdout.write(text)
+    sys.stdout.flush()
+    return 0
 
 
 def cpu_baseline(depth, variant):
@@ -106,17 +193,36 @@ def cpu_baseline(depth, variant):
 
 def main():
     args = parse()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        return launch_ranks(args)          # this process never touches the GPU
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        print(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks; refusing to print a line whose n_gpus is not "
+              "what was asked for", file=sys.stderr)
+        return 2
+    if args.dry_launch:
+        keys = ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "HSA_ENABLE_IPC_MODE_LEGACY")
+        print("DRY_LAUNCH " + json.dumps({k: os.environ.get(k) for k in keys}), flush=True)
+        if os.environ.get("UNIT_DRY_FAIL_RANK") == str(rank):          # launcher self-test: one rank dies, the others hang in a "collective"
+            return 3
+        if os.environ.get("UNIT_DRY_FAIL_RANK") is not None:
+            time.sleep(600)
+        return 0
     import torch.distributed as dist
     # UNIT_DIST_BACKEND=gloo + more ranks than GPUs is a single-GPU-box rehearsal of the multi-process path (the ranks then
     # share device 0 and the collectives go through the host); the real run is RCCL ("nccl"), one rank per GPU
     backend = os.environ.get("UNIT_DIST_BACKEND", "nccl")
     if backend != "nccl":
         local_rank = local_rank % max(1, torch.cuda.device_count())
-    if world > 1:
+    if world > 1 and backend == "nccl" and torch.cuda.device_count() < world:
+        print(f"bench.py: {world} ranks but {torch.cuda.device_count()} visible GPUs: one rank per GPU over RCCL", file=sys.stderr)
+        return 2
+    if world > 1 or args.force_collectives:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world == 1:
+            os.environ.setdefault("MASTER_PORT", str(_free_port()))
         torch.cuda.set_device(local_rank)
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
@@ -125,7 +231,7 @@ def main():
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
 
-    from unit_amd import config, ops
+    from unit_amd import _lib, config, ops
     from unit_amd.modeling import build_model
     from unit_amd.parallel import GradBuckets
     from unit_amd.solver import FlatSGD
@@ -143,7 +249,8 @@ def main():
     n_weak = 2 if args.variant == "s1" else 0
     sup, weak = synthetic_batch(2, n_weak, seed=100 + rank)   # rank r's shard of the global batch
     batch = model.pack_batch(sup, weak)                      # inputs resident in HBM before the timed region
-    buckets = GradBuckets(model)
+    buckets = GradBuckets(model, bucket_bytes=None if args.bucket_mb is None else int(args.bucket_mb * (1 << 20)), bf16=args.bf16_buckets,
+                          mode=args.reduce_mode, force=True if args.force_collectives else None)
     buckets.broadcast_parameters()
     opt = FlatSGD(model, cfg, grad_scale=buckets.grad_scale)
     from unit_amd.engine import EarlyUpdate
@@ -170,7 +277,7 @@ def main():
         timed_step = lambda: gs.run(packed=batch)
     for _ in range(max(args.warmup, 3 if args.graph else 0)):
         timed_step()
-    buckets.exposed_events = [] if world > 1 else None          # two event records per step around the bucket waits
+    buckets.exposed_events = [] if buckets.active else None          # two event records per step around the bucket waits
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -249,6 +356,7 @@ def main():
             "value": round(value, 3), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.dtype, "data": "synthetic", "launch": ("hipGraph replay" if world == 1 else "hipGraph replay (one graph per gradient-bucket stage, the bucket all-reduces launched between the replays | optimizer graph)") if (args.graph and early is None) else "eager",
+            "dist": buckets.describe(), "build_hash": _lib.build_hash(),
             "host_enqueue_ms_per_step": round(host_ms, 3),      # max over ranks
             "allreduce_exposed_ms": round(exposed_ms, 3),       # max over ranks: compute-stream time inside GradBuckets.finish() per step
             "config": {"workload": f"UniT base-training step {args.variant.upper()} (TrainerNoMeta.run_step): ResNet-{args.depth}-C4, "
@@ -334,9 +442,10 @@ def main():
             except subprocess.TimeoutExpired:
                 out["cpu_baseline"] = {"error": "oracle sample exceeded the 240 s bound on this host"}
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
+    return 0
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

@@ -21,6 +21,9 @@ extern "C" {
 #endif
 
 int unit_version(void);
+/* sha256 of the sources this library was built from (unit_amd/build.py:source_hash; csrc/build_stamp.hip): the loader compares it with
+ * the sources lying next to the library, bench.py prints it, profiles/pmc_traffic.json records it */
+const char* unit_build_hash(void);
 const char* unit_last_error(void);
 
 /* ---- a1 preprocess_image: modeling/meta_arch/rcnn.py:257-266 (+ ImageList.from_tensors zero padding) ---- */
@@ -140,6 +143,10 @@ int unit_stream_wait_stream(void* waiter, void* signaller);
 size_t unit_tensor_desc_bytes(void);
 int unit_multi_wgrad_reduce(const void* descs_dev, int n, int total_blocks, float* grads_flat, void* stream);
 int unit_multi_weight_prep(const void* descs_dev, int n, int total_blocks, const float* params_flat, int dtype, void* stream);
+/* local half of the "direct" data-parallel gradient exchange (unit_amd/parallel.py; replaces the sum DDP's bucket all-reduce does inside
+ * NCCL, reached from engine/defaults.py:256): out[i] = parts[0][i] + ... + parts[nparts-1][i], fp32, in that order; parts = [nparts][n]
+ * fp32 or bf16 (received by an all-to-all over all xGMI links at once), out fp32 [n] = this rank's shard of the gradient bucket */
+int unit_shard_sum(const void* parts, int dtype, int nparts, long n, float* out, void* stream);
 /* FrozenBatchNorm2d fold (detectron2 layers/batch_norm.py, eps 1e-5) and weight re-layout / cast */
 int unit_frozen_bn_fold(const float* w, const float* b, const float* rm, const float* rv, float eps, float* scale, float* shift,
                         int C, void* stream);

@@ -1,7 +1,9 @@
 """One rank of the 2-rank data-parallel rehearsal (tests/test_dp_gpu.py starts two of these as fresh child processes; both
 share cuda:0 and talk gloo through 127.0.0.1 -- the RCCL run differs only in the backend name).
-usage: python tests/dp_rehearsal_worker.py <rank> <world> <port> <out.pt> [fp32|bf16_buckets|graph|graph_whole|eager] [steps]
-(graph = one graph per gradient-bucket stage with the bucket all-reduces between the replays; graph_whole = one graph + one all-reduce)"""
+usage: python tests/dp_rehearsal_worker.py <rank> <world> <port> <out.pt> [fp32|bf16_buckets|graph|graph_whole|eager][_ragged] [steps]
+(graph = one graph per gradient-bucket stage with the bucket all-reduces between the replays; graph_whole = one graph + one all-reduce;
+_ragged: rank 1 meets a NEW batch key (another image size) at step 3 and again at step 5 while rank 0 keeps replaying its first key -- the ranks
+then disagree about eager vs replay in those steps and must still issue the same collectives)"""
 import os
 import sys
 
@@ -22,9 +24,9 @@ def rehearsal_cfg():
     return cfg
 
 
-def global_batch():
+def global_batch(hw=(128, 192)):
     from unit_amd.synthetic import synthetic_batch
-    return synthetic_batch(4, 4, hw=(128, 192), seed=5, max_gt=4)
+    return synthetic_batch(4, 4, hw=hw, seed=5, max_gt=4)
 
 
 def main():
@@ -41,13 +43,18 @@ def main():
     model.train()
     model.compute_dtype = torch.float32
     mode = sys.argv[5] if len(sys.argv) > 5 else "fp32"
+    ragged = mode.endswith("_ragged")
+    mode = mode[:-len("_ragged")] if ragged else mode
     steps = int(sys.argv[6]) if len(sys.argv) > 6 else 1
     tr = engine.TrainerNoMeta(cfg, model, bf16_buckets=(mode == "bf16_buckets"), use_graph=mode in ("graph", "graph_whole"),
                               graph_per_bucket=(mode == "graph"))
     if mode == "eager":          # the graphed trainer's packing capacity and device-resident learning rate, launched eagerly
         tr.optimizer._bind()
     sup, weak = global_batch()
-    for _ in range(steps):
+    sup2, weak2 = global_batch(hw=(128, 160))
+    for it in range(steps):
+        if ragged:
+            sup, weak = (sup2, weak2) if (rank == 1 and it in (3, 5)) else global_batch()
         if mode == "eager":
             tr.optimizer.use_device_lr(model.device)
             batch = model.pack_batch(engine.shard_batch(sup, rank, world), engine.shard_batch(weak, rank, world),

@@ -95,3 +95,17 @@ def test_two_ranks_graphed_step(dev, tmp_path, mode):
     assert torch.equal(e0["params"], e1["params"])
     assert torch.allclose(g0["losses"], e0["losses"], rtol=1e-5, atol=1e-6), (g0["losses"], e0["losses"])
     assert torch.allclose(g0["params"], e0["params"], rtol=1e-5, atol=1e-7), (g0["params"] - e0["params"]).abs().max()
+
+
+@pytest.mark.parametrize("mode", ["graph_whole", "graph"])
+def test_two_ranks_graphed_step_ranks_disagree_about_eager_vs_replay(dev, tmp_path, mode):
+    """Whether a step runs eagerly (first sight of a batch key) or as a replay is decided PER RANK: keys depend on the rank's own image sizes.
+    Rank 1 meets a new image size at steps 3 and 5 (eager, then captured) while rank 0 replays its first key: the two forms must issue the same
+    collectives -- in the one-graph mode an eager step therefore exchanges the whole buffer once, as the replay does (before: ~10 per-bucket
+    all-reduces against one -> mismatched collectives). Seven steps end, ranks bit-identical, equal to the all-eager run on the same data."""
+    g0, g1 = _run_ranks(tmp_path, extra=(mode + "_ragged", "7"))
+    assert torch.equal(g0["params"], g1["params"]), "ranks diverged"
+    (tmp_path / "e").mkdir()
+    e0, e1 = _run_ranks(tmp_path / "e", extra=("eager_ragged", "7"))
+    assert torch.equal(e0["params"], e1["params"])
+    assert torch.allclose(g0["params"], e0["params"], rtol=1e-5, atol=1e-7), (g0["params"] - e0["params"]).abs().max()

@@ -1,0 +1,50 @@
+"""bench.py's own N-rank launcher (`python bench.py --gpus N` without a torchrun around it), on CPU: the parent never touches the GPU,
+starts N fresh rank processes with the rendezvous environment of scripts/train_VOC.py:67-77 (detectron2 launch: one process per GPU,
+tcp://127.0.0.1:port), relays rank 0's output only when every rank succeeded, ends the survivors by PID when one rank dies, and never
+prints a result line whose n_gpus is not what --gpus asked for."""
+import json
+import os
+import subprocess
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BENCH = os.path.join(ROOT, "bench.py")
+
+
+def _run(args, env=None, timeout=300):
+    e = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    e.update(env or {})
+    return subprocess.run([sys.executable, BENCH] + args, capture_output=True, text=True, timeout=timeout, env=e)
+
+
+def test_dry_launch_starts_n_ranks_with_one_rendezvous():
+    r = _run(["--gpus", "4", "--dry-launch"])
+    assert r.returncode == 0, r.stderr
+    envs = [json.loads(l[len("DRY_LAUNCH "):]) for l in r.stdout.splitlines() if l.startswith("DRY_LAUNCH ")]
+    assert sorted(int(e["RANK"]) for e in envs) == [0, 1, 2, 3]
+    assert all(e["RANK"] == e["LOCAL_RANK"] for e in envs)          # one node: rank r drives GPU r
+    assert {e["WORLD_SIZE"] for e in envs} == {"4"} and {e["MASTER_ADDR"] for e in envs} == {"127.0.0.1"}
+    assert len({e["MASTER_PORT"] for e in envs}) == 1
+    assert {e["HSA_ENABLE_IPC_MODE_LEGACY"] for e in envs} == {"0"}          # dmabuf IPC for RCCL across processes
+
+
+def test_a_dead_rank_ends_the_run_non_zero_without_a_result_line():
+    t0 = time.time()
+    r = _run(["--gpus", "3", "--dry-launch"], env={"UNIT_DRY_FAIL_RANK": "1"})
+    assert r.returncode == 3, (r.returncode, r.stderr)
+    assert time.time() - t0 < 120          # the surviving ranks (asleep, as in a collective) were terminated, not waited for
+    assert r.stdout == ""
+    assert "no result line" in r.stderr
+
+
+def test_more_ranks_than_gpus_fails_loudly():
+    r = _run(["--gpus", "2", "--steps", "1", "--warmup", "0"], env={"CUDA_VISIBLE_DEVICES": "", "HIP_VISIBLE_DEVICES": ""})
+    assert r.returncode == 2
+    assert r.stdout == "" and "needs 2 visible GPUs" in r.stderr
+
+
+def test_world_size_from_a_launcher_must_equal_gpus():
+    r = _run(["--gpus", "8"], env={"WORLD_SIZE": "2", "RANK": "0", "LOCAL_RANK": "0"})
+    assert r.returncode == 2 and r.stdout == ""
+    assert "WORLD_SIZE=2" in r.stderr

@@ -63,6 +63,24 @@ def _worker(rank, world, port, q):
             for a, b in chunks:
                 cover[a:b] += 1
         assert int(cover.min()) == 1 and int(cover.max()) == 1
+        # (3) the other exchange forms of a bucket (parallel.MODES): reduce-scatter + all-gather in place, and the "direct" form
+        # (all-to-all of shard contributions, owner-side sum in rank order, all-gather) -- same sums, odd bucket sizes included
+        # (a tag whose length is not a multiple of the world size leaves a tail that goes through a small all-reduce)
+        for mode, mb in (("rs_ag", 8), ("direct", 8), ("direct", 0.37), ("rs_ag", 1.3)):
+            b2 = GradBuckets(model, bucket_bytes=int(mb * (1 << 20)), mode=mode)
+            assert b2.bucket_elems % world == 0
+            st.grads.copy_(torch.arange(st.size, dtype=torch.float32) % 97 * (rank + 1))
+            for tag in tags:
+                model.on_grad_ready(tag)
+            b2.finish()
+            assert torch.equal(st.grads, expect), (mode, mb, (st.grads - expect).abs().max())
+            assert b2.launched > len(tags) and b2.describe()["reduce_mode"] == mode and b2.describe()["ranks_seen"] == 2
+        # reduce_all (one-graph mode of engine.GraphedStep): one exchange of the whole buffer, every mode
+        for mode in ("allreduce", "rs_ag", "direct"):
+            b3 = GradBuckets(model, mode=mode)
+            st.grads.copy_(torch.arange(st.size, dtype=torch.float32) % 97 * (rank + 1))
+            b3.reduce_all()
+            assert torch.equal(st.grads, expect), mode
         q.put((rank, "ok"))
     except Exception as e:  # noqa
         import traceback
@@ -83,6 +101,26 @@ def test_grad_buckets_gloo_world2():
         p.join(timeout=60)
     for rank, msg in res:
         assert msg == "ok", f"rank {rank}: {msg}"
+
+
+def test_grad_buckets_knobs_from_env(monkeypatch):
+    """bucket size / exchange form come from the environment when the caller does not choose (bench.py --bucket-mb / --reduce-mode set them
+    explicitly); forcing collectives without a process group is an error, not a silent no-op"""
+    import pytest
+    from unit_amd.parallel import GradBuckets
+
+    class M:
+        on_grad_ready = "untouched"
+
+    monkeypatch.setenv("UNIT_BUCKET_MB", "16")
+    monkeypatch.setenv("UNIT_REDUCE_MODE", "direct")
+    b = GradBuckets(M())
+    assert b.bucket_bytes == 16 << 20 and b.mode == "direct" and not b.active and b.model.on_grad_ready is None
+    assert b.describe()["backend"] is None and b.describe()["ranks_seen"] == 1
+    with pytest.raises(ValueError):
+        GradBuckets(M(), mode="ring")
+    with pytest.raises(RuntimeError):
+        GradBuckets(M(), force=True)
 
 
 def test_shard_batch():

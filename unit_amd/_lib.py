@@ -62,11 +62,23 @@ def lib():
             fn = getattr(l, name)  # AttributeError if the .so does not export a declared symbol
             fn.restype = restype
             fn.argtypes = argtypes
+        if not os.environ.get("UNIT_HIP_LIB"):          # (an explicit override is a diagnostic build: whoever set it knows what it is)
+            from .build import source_hash
+            have, want = l.unit_build_hash().decode(), source_hash()
+            if have != want:
+                raise UnitLibError(
+                    f"{LIB_PATH} was built from other sources than the ones next to it (library stamp {have[:16]}, sources {want[:16]}): "
+                    "rebuild with `python -m unit_amd.build` -- a stale binary is never run")
         _lib = l
     return _lib
 
 
 _DEBUG_SYNC = bool(int(os.environ.get("UNIT_DEBUG_SYNC", "0")))      # diagnostic: name every launch and wait for it (finds the kernel behind a GPU fault)
+
+
+def build_hash():
+    """content hash of the sources the loaded library was built from (16 hex digits: what the bench line and the PMC file carry)"""
+    return lib().unit_build_hash().decode()[:16]
 
 
 LAUNCHES = [0]          # number of successful C-ABI calls so far (engine.GraphedStep: did anything go into the running capture?)

@@ -136,3 +136,44 @@ extern "C" int unit_stream_wait_stream(void* waiter, void* signaller) {
   if (e != hipSuccess) { unit_set_error(hipGetErrorString(e)); return UNIT_ERR_LAUNCH; }
   return UNIT_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// unit_shard_sum: out[i] = parts[0][i] + parts[1][i] + ... + parts[nparts-1][i], added in that (rank) order in fp32.
+// The local half of the "direct" gradient exchange of unit_amd/parallel.py (all-to-all of the ranks' shard contributions over
+// the seven xGMI links at once -> this ordered sum on the shard's owner -> all-gather): every element is summed by ONE rank in a
+// fixed order, so all ranks end with bit-identical gradients and a re-run reproduces them. parts = [nparts][n] contiguous,
+// fp32 or bf16 (widened before the add); out fp32. HBM-bound: (nparts + 1) * n * 4 bytes, 16 bytes per lane.
+template <typename T>
+__global__ void __launch_bounds__(256) shard_sum_kernel(const T* __restrict__ parts, int nparts, long n, float* __restrict__ out) {
+  long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (i >= n) return;
+  if (i + 4 <= n) {
+    f32x4 s;
+    {
+      const T* p = parts + i;
+      s = f32x4{(float)p[0], (float)p[1], (float)p[2], (float)p[3]};
+    }
+    for (int r = 1; r < nparts; ++r) {
+      const T* p = parts + (size_t)r * n + i;
+      s += f32x4{(float)p[0], (float)p[1], (float)p[2], (float)p[3]};
+    }
+    out[i] = s[0]; out[i + 1] = s[1]; out[i + 2] = s[2]; out[i + 3] = s[3];
+  } else {
+    for (long j = i; j < n; ++j) {
+      float s = (float)parts[j];
+      for (int r = 1; r < nparts; ++r) s += (float)parts[(size_t)r * n + j];
+      out[j] = s;
+    }
+  }
+}
+
+extern "C" int unit_shard_sum(const void* parts, int dtype, int nparts, long n, float* out, void* stream) {
+  UNIT_CHECK_ARG(nparts >= 1 && n >= 0, "shard_sum: nparts >= 1");
+  if (n == 0) return UNIT_OK;
+  hipStream_t st = (hipStream_t)stream;
+  int g = cdiv(cdiv(n, 4), 256);
+  if (dtype == UNIT_BF16) shard_sum_kernel<bf16_t><<<g, 256, 0, st>>>((const bf16_t*)parts, nparts, n, out);
+  else shard_sum_kernel<float><<<g, 256, 0, st>>>((const float*)parts, nparts, n, out);
+  UNIT_LAUNCH_CHECK();
+  return UNIT_OK;
+}

@@ -78,7 +78,7 @@ class GraphedStep:
         of the backward as in eager mode; False: one graph, one all-reduce of the whole flat gradient buffer after it"""
         import torch
         self.model, self.optimizer, self.warmup_steps = model, optimizer, warmup_steps
-        self.buckets = buckets if (buckets is not None and buckets.world > 1) else None
+        self.buckets = buckets if (buckets is not None and buckets.active) else None
         self.per_bucket = per_bucket
         self.graphs = {}          # key -> (graph | (graph A, graph B), static PackedBatch, losses tensor)
         self.seen = set()         # keys that have run one eager step (constants uploaded, workspaces sized)
@@ -92,9 +92,20 @@ class GraphedStep:
         return step.losses
 
     def _body(self, batch):
-        losses = self._fwd_bwd(batch)
-        if self.buckets is not None:
-            self.buckets.finish()          # (eager warm-up steps only: the per-bucket all-reduces launched from inside the backward)
+        if self.buckets is not None and not self.per_bucket:
+            # eager step of the ONE-GRAPH mode: whether a step runs eagerly (first sight of a batch key) or as a replay is decided per
+            # rank -- keys depend on the rank's own image sizes and GT counts -- so both forms must issue the SAME collectives: no
+            # per-bucket launches from inside the backward here, one exchange of the whole buffer after it, exactly as the replay does
+            hook, self.model.on_grad_ready = self.model.on_grad_ready, None
+            try:
+                losses = self._fwd_bwd(batch)
+            finally:
+                self.model.on_grad_ready = hook
+            self.buckets.reduce_all()
+        else:
+            losses = self._fwd_bwd(batch)
+            if self.buckets is not None:
+                self.buckets.finish()      # per-bucket mode: the exchanges launched from inside the backward (same tags, same order as the replay)
         self.optimizer.step()
         self._join_side_streams()
         return losses
@@ -239,7 +250,7 @@ class GraphedStep:
 
 class TrainerNoMeta:
     def __init__(self, cfg, model, data_iter=None, weak_data_iter=None, group=None, early_update=False, bf16_buckets=False,
-                 use_graph=False, overlap_tail=False, graph_per_bucket=True, high_priority=False):
+                 use_graph=False, overlap_tail=False, graph_per_bucket=True, high_priority=False, reduce_mode=None, bucket_bytes=None):
         """overlap_tail: the end of a step (last weight gradients, all-reduce waits, SGD, weight re-preparation) stays on the model's
         weight-gradient stream and overlaps the next step's preprocessing / frozen layers (GeneralizedRCNN.overlap_optimizer_tail);
         read parameters between steps only after model.join_optimizer_tail() (state_dict() does it)."""
@@ -253,7 +264,8 @@ class TrainerNoMeta:
             torch.cuda.set_stream(model.high_priority_stream())
         model.overlap_optimizer_tail = bool(overlap_tail) and not early_update and not use_graph
         self.data_iter, self.weak_data_iter = data_iter, weak_data_iter
-        self.buckets = GradBuckets(model, group, bf16=bf16_buckets)
+        # reduce_mode / bucket_bytes: how and in what pieces the gradient buckets cross xGMI (parallel.GradBuckets; None = the env / defaults)
+        self.buckets = GradBuckets(model, group, bucket_bytes=bucket_bytes, bf16=bf16_buckets, mode=reduce_mode)
         self.buckets.broadcast_parameters()
         self.optimizer = FlatSGD(model, cfg, grad_scale=self.buckets.grad_scale)
         self.iter = 0

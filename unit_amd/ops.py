@@ -254,6 +254,14 @@ def cast(x, dtype):
     return y
 
 
+def shard_sum(parts, out):
+    """out[i] = parts[0][i] + parts[1][i] + ... in that order, fp32 (parts: [nparts, n] fp32 / bf16, contiguous; out: fp32 [n]);
+    the owner-side sum of the "direct" gradient exchange (parallel.GradBuckets(mode="direct"))"""
+    assert parts.dim() == 2 and parts.is_contiguous() and out.is_contiguous() and out.dtype == torch.float32 and out.numel() == parts.shape[1]
+    check(lib().unit_shard_sum(_p(parts), dt(parts.dtype), parts.shape[0], parts.shape[1], _p(out), _s()), "shard_sum")
+    return out
+
+
 def add_cast(a32, b, dtype, mask_ref=None, out=None):
     """y = cast((a32 [+ b]) [* (mask_ref > 0)])"""
     y = out if out is not None else torch.empty(a32.shape, dtype=dtype, device=a32.device)

@@ -1,15 +1,33 @@
 """Data parallelism over the GPUs of one node: one process per GPU, RCCL (torch.distributed backend "nccl") over xGMI.
 
 The reference wraps the model in torch DistributedDataParallel inside Detectron2's DefaultTrainer (reached from
-/root/reference/engine/defaults.py:256; per-GPU batch = IMS_PER_BATCH // world, data/build.py:354-355) and barriers every
-step (engine/defaults.py:285). Here the gradients already live in ONE flat fp32 buffer laid out in the order they become
-final during the explicit backward (unit_amd/flat.py), so a bucket is a contiguous slice: no gradient copies, no
-autograd hooks. `ready(tag)` is called by the backward plan as soon as a stage's wgrad kernels are enqueued; the
-all-reduce of that slice is launched asynchronously (RCCL's stream, ordered after the compute stream by torch's
-ProcessGroup) and overlaps the remaining backward. xGMI is point-to-point (7 links/GPU): buckets are large (default
-64 MB) so each collective is bandwidth- not latency-bound; the 1/world scaling is folded into the SGD kernel.
-No per-step barrier, no per-step metric gather."""
+/root/reference/engine/defaults.py:256; per-GPU batch = IMS_PER_BATCH // world, data/build.py:354-355; processes started by
+scripts/train_VOC.py:67-77) and barriers every step (engine/defaults.py:285). Here the gradients already live in ONE flat fp32
+buffer laid out in the order they become final during the explicit backward (unit_amd/flat.py), so a bucket is a contiguous
+slice: no gradient copies, no autograd hooks. `ready(tag)` is called by the backward plan as soon as a stage's wgrad kernels are
+enqueued; the exchange of that slice is launched asynchronously (RCCL's stream, ordered after the launching stream by torch's
+ProcessGroup) and overlaps the remaining backward. The 1/world scaling is folded into the SGD kernel. No per-step barrier, no
+per-step metric gather.
+
+How a bucket is exchanged is a knob (`mode`, env UNIT_REDUCE_MODE), because xGMI is point-to-point (7 links x ~153 GB/s per GPU)
+and which form fills the links is something only an 8-GPU curve can say (a ring is per-link bound, 2(n-1)/n S
+bytes through each link; a one-shot exchange uses all seven links at once and moves 2 S / n per link):
+  * "allreduce" (default) one `all_reduce` per bucket: RCCL picks ring / tree and its channel count;
+  * "rs_ag"     `reduce_scatter_tensor` + `all_gather_into_tensor`, both in place on the bucket (shard r of the bucket is rank r's):
+                the two halves of the ring as separate collectives;
+  * "direct"    `all_to_all_single` of the ranks' shard contributions (n-1 point-to-point transfers per rank, one per link) ->
+                the shard's owner adds the n contributions in rank order (`unit_shard_sum`, one HBM-bound launch) ->
+                `all_gather_into_tensor`. Every element is summed by one rank in a fixed order: bit-identical on all ranks and
+                reproducible from run to run whatever RCCL's algorithm choice.
+Bucket size (`bucket_bytes`, env UNIT_BUCKET_MB, default 64 MB: bandwidth- not latency-bound collectives) and bf16 buckets (half
+the bytes) combine with every mode. UNIT_FORCE_COLLECTIVES=1 (or force=True) keeps every collective in the step at world size 1
+too: a 1-GPU box then exercises RCCL initialisation, the launch from the weight-gradient stream, the waits and the bf16 / shard
+paths exactly as an 8-GPU run does (tests/test_rccl_gpu.py) -- the sums over one rank are the identity."""
+import os
+
 import torch.distributed as dist
+
+MODES = ("allreduce", "rs_ag", "direct")
 
 
 class _Widen:
@@ -26,19 +44,62 @@ class _Widen:
             self.work = None
 
 
+class _Chain:
+    """several work handles launched for one bucket: waiting for the bucket = waiting for all of them, in launch order"""
+
+    def __init__(self, works):
+        self.works = [w for w in works if w is not None]
+
+    def wait(self):
+        for w in self.works:
+            w.wait()
+        self.works = []
+
+
 class GradBuckets:
-    def __init__(self, model, group=None, bucket_bytes=64 << 20, bf16=False):
-        """bf16: all-reduce a bf16 copy of every bucket (half the bytes over xGMI: 134 instead of 268 MB per step for R101 S1) and
+    def __init__(self, model, group=None, bucket_bytes=None, bf16=False, mode=None, force=None):
+        """bf16: exchange a bf16 copy of every bucket (half the bytes over xGMI: 134 instead of 268 MB per step for R101 S1) and
         widen the sum back into the fp32 gradient buffer; the ranks stay bit-identical (same reduced values everywhere), each
-        summed gradient carries a relative 2^-8 rounding. Off by default: one node's links move the fp32 buckets behind the backward."""
+        summed gradient carries a relative 2^-8 rounding. Off by default: one node's links move the fp32 buckets behind the backward.
+        mode / bucket_bytes / force: see the module docstring (defaults from UNIT_REDUCE_MODE / UNIT_BUCKET_MB / UNIT_FORCE_COLLECTIVES)."""
         self.model, self.group, self.bf16 = model, group, bf16
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
-        self.bucket_elems = bucket_bytes // 4
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        if bucket_bytes is None:
+            bucket_bytes = int(float(os.environ.get("UNIT_BUCKET_MB", "64")) * (1 << 20))
+        self.mode = mode or os.environ.get("UNIT_REDUCE_MODE", "allreduce")
+        if self.mode not in MODES:
+            raise ValueError(f"GradBuckets mode {self.mode!r}: one of {MODES}")
+        if force is None:
+            force = bool(int(os.environ.get("UNIT_FORCE_COLLECTIVES", "0")))
+        if force and not dist.is_initialized():
+            raise RuntimeError("UNIT_FORCE_COLLECTIVES / force=True needs an initialised process group (world size 1 is fine)")
+        self.active = self.world > 1 or bool(force)          # False: single process, nothing to launch per bucket
+        self.bucket_bytes = int(bucket_bytes)
+        self.bucket_elems = max(self.world, self.bucket_bytes // 4 // self.world * self.world)     # a multiple of the world size: whole shards
         self._works = []
         self._tag_works = {}
         self._plan = None
+        self._recv = {}                 # "direct": receive buffers of the all-to-all, keyed by (elements, dtype)
+        self._comm_stream = None        # "direct": the stream the all-to-all -> shard sum -> all-gather chain of a bucket is ordered on
+        self.launched = 0               # collectives launched so far (tests / bench line)
         self.exposed_events = None      # bench.py: a list -> finish() brackets its waits with a HIP-event pair on the compute stream
-        model.on_grad_ready = self.ready if self.world > 1 else None    # single process: nothing to launch per bucket
+        model.on_grad_ready = self.ready if self.active else None
+
+    # ------------------------------------------------------------------------------------------------ description (bench line)
+    def describe(self):
+        """what an N-GPU bench line should say about the exchange it ran"""
+        backend = dist.get_backend(self.group) if dist.is_initialized() else None
+        ver = None
+        if backend == "nccl":
+            try:
+                import torch
+                ver = ".".join(str(v) for v in torch.cuda.nccl.version())
+            except Exception:          # noqa: the version string is informational
+                ver = None
+        return {"backend": ("rccl (torch.distributed 'nccl')" if backend == "nccl" else backend), "ranks_seen": self.world,
+                "rccl_version": ver, "reduce_mode": self.mode, "bucket_mb": round(self.bucket_bytes / (1 << 20), 2),
+                "bf16_buckets": bool(self.bf16), "collectives_forced_at_world_1": bool(self.active and self.world == 1)}
 
     def _build(self):
         st = self.model.store
@@ -56,7 +117,7 @@ class GradBuckets:
         """initial broadcast of the module state from rank 0 (DDP does this at construction, buffers included): the flat trainable
         buffer in one collective, every other floating-point tensor of the state dict (frozen stem / res2 weights, FrozenBN
         statistics, embeddings) packed into a second one."""
-        if self.world > 1:
+        if self.active:
             import torch
             from .layers import invalidate_prepared
             self.model._ensure_ready()
@@ -72,40 +133,95 @@ class GradBuckets:
                     for t in rest:
                         t.copy_(flat[o:o + t.numel()].view(t.shape))
                         o += t.numel()
+            self.launched += 2
             invalidate_prepared()          # frozen layers fold / cast their weights once: redo it from the broadcast values
             self.model.version += 1
 
+    # ------------------------------------------------------------------------------------------------ one bucket
+    def _exchange(self, t):
+        """launch the exchange of the 1-D tensor `t` (summed over the ranks, in place); -> work handle. Ordered after the CURRENT
+        stream; nothing here blocks the host or the current stream."""
+        n, w, r = t.numel(), self.world, self.rank
+        if self.mode == "allreduce" or n < w:
+            self.launched += 1
+            return dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        per = n // w
+        main = per * w
+        shard = t[r * per:(r + 1) * per]
+        tail = None
+        if main < n:          # < world elements (the plan cuts buckets at multiples of the world size: only a tag's last bucket can have one)
+            tail = dist.all_reduce(t[main:], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            self.launched += 1
+        if self.mode == "rs_ag":
+            # in place: the output of the reduce-scatter is this rank's shard of its input (recvbuff == sendbuff + rank * recvcount),
+            # the all-gather's input is its own shard of the output
+            w1 = dist.reduce_scatter_tensor(shard, t[:main], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            if not t.is_cuda:
+                w1.wait()          # host tensors (gloo): asynchronous collectives run on worker threads, not in stream order
+            w2 = dist.all_gather_into_tensor(t[:main], shard, group=self.group, async_op=True)
+            self.launched += 2
+            return _Chain([tail, w1, w2])
+        # "direct"
+        import torch
+        key = (main, t.dtype)
+        recv = self._recv.get(key)
+        if recv is None or recv.device != t.device:
+            recv = self._recv[key] = torch.empty(main, dtype=t.dtype, device=t.device)
+        if not t.is_cuda:          # host tensors (gloo tests of the chunk arithmetic): the same chain, synchronously
+            dist.all_to_all_single(recv, t[:main], group=self.group)
+            acc = recv[:per].float().clone()
+            for q in range(1, w):
+                acc += recv[q * per:(q + 1) * per].float()
+            shard.copy_(acc)
+            dist.all_gather_into_tensor(t[:main], shard.clone(), group=self.group)
+            self.launched += 2
+            return _Chain([tail])
+        from . import ops
+        if self._comm_stream is None:
+            self._comm_stream = torch.cuda.Stream(t.device)
+        cs = self._comm_stream
+        cs.wait_stream(torch.cuda.current_stream())          # the bucket's gradients are final where the caller stands
+        recv.record_stream(cs)
+        with torch.cuda.stream(cs):
+            w1 = dist.all_to_all_single(recv, t[:main], group=self.group, async_op=True)
+            w1.wait()                                        # `cs` (not the host) waits for the transfers
+            if t.dtype == torch.float32:
+                ops.shard_sum(recv.view(w, per), shard)
+            else:                                            # bf16 bucket: sum in fp32, round the shard once
+                acc = torch.empty(per, dtype=torch.float32, device=t.device)
+                ops.shard_sum(recv.view(w, per), acc)
+                shard.copy_(acc)
+            w2 = dist.all_gather_into_tensor(t[:main], shard, group=self.group, async_op=True)
+        self.launched += 2
+        return _Chain([tail, w2])
+
+    def _launch(self, g, a, b):
+        if self.bf16:
+            from . import ops
+            import torch
+            buf = ops.cast(g[a:b], torch.bfloat16)
+            return _Widen(self._exchange(buf), buf, g[a:b])
+        return self._exchange(g[a:b])
+
     def ready(self, tag):
-        if self.world == 1:
+        if not self.active:
             return
         if self._plan is None or self._store is not self.model.store:
             self._build()
         g = self.model.store.grads
         for a, b in self._plan.get(tag, []):
-            if self.bf16:
-                from . import ops
-                import torch
-                buf = ops.cast(g[a:b], torch.bfloat16)
-                w = _Widen(dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True), buf, g[a:b])
-            else:
-                w = dist.all_reduce(g[a:b], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            w = self._launch(g, a, b)
             self._works.append(w)
             self._tag_works.setdefault(tag, []).append(w)
 
     def reduce_all(self):
-        """ONE all-reduce of the whole flat gradient buffer on the current stream's timeline (engine.GraphedStep: the collectives
-        stay outside the captured graphs)"""
-        if self.world == 1:
+        """ONE exchange of the whole flat gradient buffer on the current stream's timeline (engine.GraphedStep with per_bucket=False:
+        the collectives stay outside the captured graphs; its eager steps use this too, so that a rank that replays and a rank that
+        runs the same step eagerly issue the same collectives)."""
+        if not self.active:
             return
         g = self.model.store.grads
-        if self.bf16:
-            from . import ops
-            import torch
-            buf = ops.cast(g, torch.bfloat16)
-            dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group)
-            g.copy_(buf)
-        else:
-            dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.group)
+        self._launch(g, 0, g.numel()).wait()
 
     def wait_tag(self, tag):
         """make the CURRENT stream wait for the all-reduces of one bucket (early per-bucket optimizer update)"""
