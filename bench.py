@@ -184,7 +184,15 @@ def cpu_baseline(depth, variant):
     full = STEP_TFLOP.get((variant, depth))
     heads = {"s1": 7, "s0": 3}[variant] * 1.499
     sample_tflop = round(full - heads * (1 - rois / 512.0), 2) if full else None
-    return {"value": round(2.0 / dt, 4), "unit": "images/sec", "cores": cores, "kind": "port",
+    cpu_model = None
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.lower().startswith("model name"):
+                cpu_model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    return {"value": round(2.0 / dt, 4), "unit": "images/sec", "cores": cores, "cpu_model": cpu_model, "host_cores_available": avail, "kind": "port",
             "sample": f"oracle (PyTorch-CPU fp32 + C) S1 fwd+bwd, R{depth}-C4, 2 supervised + 2 weak 3x600x1000 images, "
                       f"{rois} RoIs/image (1/{512 // rois} of 512), {dt:.1f} s",
             "sample_tflop": sample_tflop, "step_tflop": full, "cpu_tflops": round(sample_tflop / dt, 3) if sample_tflop else None,
@@ -388,12 +396,19 @@ def main():
                     traffic = tdoc.get(key + "_kernel", {}).get("hbm_bytes_per_launch")
                 except Exception:
                     traffic = None
+            # the PMC passes are a separate rocprofv3 run of this command (tools/pmc_bench.sh): their numbers describe THIS build only while the
+            # kernel sources have not changed since -- compared by content hash, never assumed
+            traffic_stale = traffic is not None and tdoc.get("_build_hash") != _lib.build_hash()
+            if traffic_stale:
+                traffic = None
             out["roofline"] = {"kernel": ("conv_igemm256_p8_kernel" if key == "conv_igemm256" else key + "_kernel") +
                                          " (implicit-GEMM conv fwd/dgrad, bf16 MFMA 16x16x32, 256x256x64 LDS-DMA tiles)",
                                "bound": "mfma", "achieved": r["tflops"], "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                                "frac": round(r["tflops"] / MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
-                               "traffic_source": (f"profiles/pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this command "
-                                                  f"at commit {tdoc.get('_commit', 'unknown')} (not collected inside this run)") if traffic else None,
+                               "traffic_source": (f"profiles/pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this command, kernel "
+                                                  f"sources {tdoc.get('_build_hash')} = this build (not collected inside this run)") if traffic else
+                                                 (f"withheld: profiles/pmc_traffic.json was measured on kernel sources {tdoc.get('_build_hash')}, this build is "
+                                                  f"{_lib.build_hash()} -- re-run tools/pmc_bench.sh") if traffic_stale else None,
                                "launches_per_step": r["launches_per_step"], "avg_launch_us": r["avg_launch_us"],
                                "algorithmic_gflop_per_launch": r["gflop_per_launch"],
                                "algorithmic_bytes_per_launch": r["algorithmic_bytes_per_launch"],
@@ -410,7 +425,7 @@ def main():
                 tot = sum(e[0].elapsed_time(e[1]) for e in ev)
                 byt = sum(e[3] for e in ev) / len(ev)
                 us = tot / len(ev) * 1e3
-                pm = next((v for kk, v in tdoc.items() if isinstance(v, dict) and pmc_key in kk), {})
+                pm = {} if traffic_stale else next((v for kk, v in tdoc.items() if isinstance(v, dict) and pmc_key in kk), {})
                 ref = sum((e[4] or 0) for e in ev) / len(ev)
                 return {"launches_per_step": len(ev) // args.steps, "avg_launch_us": round(us, 1), "algorithmic_bytes_per_launch": round(byt),
                         "achieved_gbs": round(byt / us / 1e3, 1), "frac_of_hbm_peak": round(byt / us / 1e3 / HBM_PEAK_GBS, 4),

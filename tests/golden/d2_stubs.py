@@ -460,6 +460,33 @@ class _MetadataCatalog:
         return cls.table[name]
 
 
+class WarmupMultiStepLR(torch.optim.lr_scheduler._LRScheduler):
+    """detectron2.solver.lr_scheduler.WarmupMultiStepLR (published v0.3 API; what d2's DefaultTrainer.build_lr_scheduler returns for the
+    reference's yaml `LR_SCHEDULER_NAME: WarmupMultiStepLR` default): lr = base_lr * warmup_factor(iter) * gamma ** #(milestones <= iter),
+    linear warm-up from `warmup_factor` to 1 over `warmup_iters` iterations."""
+
+    def __init__(self, optimizer, milestones, gamma=0.1, warmup_factor=0.001, warmup_iters=1000, warmup_method="linear", last_epoch=-1):
+        assert list(milestones) == sorted(milestones) and warmup_method == "linear"
+        self.milestones, self.gamma, self.warmup_factor, self.warmup_iters = list(milestones), gamma, warmup_factor, warmup_iters
+        super().__init__(optimizer, last_epoch)
+
+    def get_lr(self):
+        import bisect
+        it = self.last_epoch
+        f = 1.0
+        if it < self.warmup_iters:
+            alpha = it / self.warmup_iters
+            f = self.warmup_factor * (1 - alpha) + alpha
+        return [b * f * self.gamma ** bisect.bisect_right(self.milestones, it) for b in self.base_lrs]
+
+
+def maybe_add_gradient_clipping(cfg, optimizer):
+    """detectron2.solver.build.maybe_add_gradient_clipping: the optimizer unchanged unless SOLVER.CLIP_GRADIENTS.ENABLED (off in every UniT yaml)"""
+    clip = getattr(getattr(cfg.SOLVER, "CLIP_GRADIENTS", None), "ENABLED", False)
+    assert not clip, "gradient clipping is not part of the pinned path"
+    return optimizer
+
+
 VOC_THING_CLASSES = ["aeroplane", "bicycle", "bird", "boat", "bottle", "bus", "car", "cat", "chair", "cow", "diningtable", "dog",
                      "horse", "motorbike", "person", "pottedplant", "sheep", "sofa", "train", "tvmonitor"]
 
@@ -502,6 +529,20 @@ def install():
     _MetadataCatalog.table["voc_stub_train"] = _Metadata(VOC_THING_CLASSES)
     m = _mod("fvcore.nn")
     m.smooth_l1_loss = smooth_l1_loss
+    m = _mod("detectron2.solver.lr_scheduler")
+    m.WarmupMultiStepLR = WarmupMultiStepLR
+    _mod("detectron2.solver.build").maybe_add_gradient_clipping = maybe_add_gradient_clipping
+
+
+def load_reference_solver(ref_root="/root/reference"):
+    """the reference's solver/build.py (build_optimizer_C4: per-name LR / weight-decay groups over torch.optim.SGD) imported by file"""
+    install()
+    import os
+    spec = importlib.util.spec_from_file_location("ref_unit_solver_build", os.path.join(ref_root, "solver/build.py"))
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules[spec.name] = mod
+    spec.loader.exec_module(mod)
+    return mod
 
 
 def load_reference(ref_root="/root/reference"):

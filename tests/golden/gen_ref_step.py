@@ -121,10 +121,107 @@ def oracle_params(model):
     return {k: v.detach().cpu().clone().contiguous().requires_grad_(k in trainable) for k, v in model.state_dict().items()}
 
 
+TRAJ_STEPS = 5
+
+
+def traj_cfg(device="cpu"):
+    """the "s1" case with a solver schedule that shows all of its parts inside five iterations: two warm-up iterations (factor 0.25 -> 1),
+    two at the base rate, the step decay (gamma 0.1) at iteration 4; momentum 0.9 and weight decay 1e-4 are the yaml's
+    (configs/VOC/VOC-RCNN-101-C4-split1.yaml:42-49)."""
+    c = case_cfg("s1", device)
+    c.SOLVER.BASE_LR = 0.0005          # (0.02 of the yaml makes five steps from random-init weights a chaotic curve: loss_cls 9.6 -> 69 -> 25)
+    c.SOLVER.WARMUP_ITERS, c.SOLVER.WARMUP_FACTOR = 2, 0.25
+    c.SOLVER.STEPS, c.SOLVER.GAMMA = (4,), 0.1
+    # the per-name factors of solver/build.py:85-107 are all 1.0 in the shipped yamls; non-trivial here, so that a tensor filed under the
+    # wrong group (or a bias treated as a weight) changes the trajectory
+    c.SOLVER.REFINEMENT_LR_FACTOR, c.SOLVER.MIL_LR_FACTOR, c.SOLVER.DELTA_LR_FACTOR = 3.0, 0.5, 0.25
+    c.SOLVER.BIAS_LR_FACTOR, c.SOLVER.WEIGHT_DECAY_BIAS = 2.0, 0.0
+    return c
+
+
+def traj_inputs(device="cpu"):
+    """-> (cfg with the trajectory's solver schedule, model, sup, weak, perms): the "s1" case's model and data"""
+    _, model, sup, weak, perms, _ = step_inputs("s1", device)
+    return traj_cfg(device), model, sup, weak, perms
+
+
+def traj_sample(t, n=1024):
+    """the elements of a parameter tensor the trajectory fixture keeps: every stride-th, at most n"""
+    f = t.detach().reshape(-1)
+    return f[::max(1, f.numel() // n)][:n]
+
+
+def trajectory(G, out):
+    """TrainerNoMeta.run_step x TRAJ_STEPS as the reference defines it (engine/defaults.py:266-288: loss_dict -> sum -> zero_grad ->
+    backward -> optimizer.step; d2 SimpleTrainer hooks step the LR scheduler after it): the reference's meta-arch / RPN / ROI heads /
+    predictors (d2-ext blocks from the oracle, as everywhere in this file), the reference's OWN solver/build.py:build_optimizer_C4 on that
+    model's named modules -> torch.optim.SGD, d2's WarmupMultiStepLR. Same batch and same sampling permutations every iteration.
+    Written: losses per iteration, the LR / weight-decay group of every trainable tensor as build_optimizer_C4 assigned it, the base LR per
+    iteration, and per trainable tensor the norm of its total update plus a strided sample of its final values."""
+    from torch import nn
+    cfg = traj_cfg()
+    _, model, sup, weak, perms, _ = step_inputs("s1")
+    p = oracle_params(model)
+    ocfg = oracle_cfg(cfg)
+    ref, trace = G.build_reference_model(p, ocfg, perms, roi_cls=cfg.MODEL.ROI_HEADS.NAME, pred_cls=cfg.MODEL.ROI_HEADS.FAST_RCNN.NAME)
+    ref.roi_heads.visual_threshold = ocfg["visual_threshold"]
+    ref.roi_heads.box_predictor._freeze_layers(list(cfg.MODEL.FREEZE_LAYERS.FAST_RCNN))
+    # the d2-ext blocks read their weights from the dict `p`: hang every TRAINABLE one into the model's module tree under its Detectron2
+    # name (backbone.res4.5.conv1.weight -> module "backbone.res4.5.conv1", parameter "weight"), which is all build_optimizer_C4 looks at
+    pred_prefix = "roi_heads.box_predictor."
+    for k in sorted(p):
+        if not p[k].requires_grad or k.startswith(pred_prefix):
+            continue
+        parts, mod = k.split("."), ref
+        for a in parts[:-1]:
+            if a not in mod._modules:
+                mod.add_module(a, nn.Module())
+            mod = mod._modules[a]
+        par = nn.Parameter(p[k].detach().clone())
+        mod.register_parameter(parts[-1], par)
+        p[k] = par
+    named = {pred_prefix + n_: q for n_, q in ref.roi_heads.box_predictor.named_parameters() if q.requires_grad}
+    named.update({k: v for k, v in p.items() if isinstance(v, nn.Parameter)})
+    assert set(named) == {n_ for n_, q in model.named_parameters() if q.requires_grad}, \
+        sorted(set(named) ^ {n_ for n_, q in model.named_parameters() if q.requires_grad})[:8]
+    start = {k: v.detach().clone() for k, v in named.items()}
+    S = G.d2.load_reference_solver()
+    opt = S.build_optimizer_C4(cfg, ref)
+    assert sum(len(g["params"]) for g in opt.param_groups) == len(named)
+    by_id = {id(q): k for k, q in named.items()}
+    for g in opt.param_groups:
+        for q in g["params"]:
+            out[f"traj/group_lr/{by_id[id(q)]}"], out[f"traj/group_wd/{by_id[id(q)]}"] = np.array(g["lr"]), np.array(g["weight_decay"])
+    sched = G.d2.WarmupMultiStepLR(opt, cfg.SOLVER.STEPS, cfg.SOLVER.GAMMA, warmup_factor=cfg.SOLVER.WARMUP_FACTOR,
+                                   warmup_iters=cfg.SOLVER.WARMUP_ITERS)
+    ref.train()
+    losses_all, lrs = [], []
+    d2_sup, d2_weak = G.to_d2_inputs(sup), G.to_d2_inputs(weak)
+    for it in range(TRAJ_STEPS):
+        plain = named["proposal_generator.rpn_head.conv.weight"]          # a tensor no factor applies to: its group runs at the scheduled base rate
+        lrs.append(next(g["lr"] for g in opt.param_groups if any(q is plain for q in g["params"])))
+        losses = ref(d2_sup, d2_weak)
+        opt.zero_grad()
+        sum(losses.values()).backward()
+        opt.step()
+        sched.step()
+        losses_all.append([losses[k].item() for k in sorted(losses)])
+        print("traj", it, "lr", lrs[-1], {k: round(v.item(), 6) for k, v in sorted(losses.items())})
+    out["traj/loss_names"] = np.array(sorted(losses))
+    out["traj/losses"] = np.array(losses_all, dtype=np.float64)
+    out["traj/lrs"] = np.array(lrs, dtype=np.float64)
+    assert np.isfinite(out["traj/losses"]).all()
+    for k, q in named.items():
+        out[f"traj/delta_norm/{k}"] = np.array((q.detach() - start[k]).double().norm().item())
+        out[f"traj/final_sample/{k}"] = G.npy(traj_sample(q))
+    out["traj/names"] = np.array(sorted(named))
+
+
 def main(G):
     """G = the gen_unit_golden module (stubs installed, reference modules loaded)."""
     d2 = G.d2
     out = {}
+    trajectory(G, out)
     for name in CASES:
         cfg, model, sup, weak, perms, masks = step_inputs(name)
         p = oracle_params(model)

@@ -83,7 +83,7 @@ def test_conv_fwd(dev, case, dtype):
     res = torch.randn(ref.shape, generator=gen).to(dtype).float()
     ref_full = F.relu(ref + res)
     xd, wd = nhwc(x).to(dev).to(dtype), krsc(wt).to(dev).to(dtype)
-    tol = 2e-5 if dtype == torch.float32 else 2e-2
+    tol = 2e-5 if dtype == torch.float32 else 1e-4          # fp32 OUTPUT in both modes: bf16 products are exact in fp32, only the summation order differs
     for tile in (0, 1, 4):
         y = o.conv2d(xd, wd, k, r, r, stride, pad, bias=bias.to(dev), out_dtype=torch.float32, tile_cfg=tile)
         got = nchw(y.cpu()[..., :k])
@@ -93,8 +93,10 @@ def test_conv_fwd(dev, case, dtype):
     resd[..., :k] = nhwc(res)
     y2 = o.conv2d(xd, wd, k, r, r, stride, pad, bias=bias.to(dev), residual=resd.to(dev).to(dtype), relu=True)
     got2 = nchw(y2.float().cpu()[..., :k])
-    tol2 = tol if dtype == torch.float32 else 4e-2
-    assert torch.allclose(got2, ref_full, rtol=tol2, atol=tol2 * 4)
+    if dtype == torch.float32:
+        assert torch.allclose(got2, ref_full, rtol=tol, atol=tol * 4)
+    else:          # bf16 output: one rounding to nearest (2^-9 relative) with a 2x margin
+        assert torch.allclose(got2, ref_full, rtol=4e-3, atol=1e-3), (got2 - ref_full).abs().max()
 
 
 @pytest.mark.parametrize("case", [(2, 13, 17, 16, 24, 3, 1, 1), (1, 20, 31, 64, 128, 1, 1, 0), (2, 19, 23, 32, 64, 1, 2, 0),
@@ -152,7 +154,7 @@ def test_conv_big_tile_kernel(dev, case, big):
     xd, wd = nhwc(x).to(dev).bfloat16(), krsc(wt).to(dev).bfloat16()
     y = o.conv2d(xd, wd, k, r, r, stride, pad, bias=bias.to(dev), out_dtype=torch.float32, tile_cfg=big)
     got = nchw(y.cpu()[..., :k])
-    assert torch.allclose(got, ref, rtol=2e-2, atol=8e-2), (got - ref).abs().max()
+    assert torch.allclose(got, ref, rtol=1e-4, atol=1e-4), (got - ref).abs().max()
     ldy = (k + 3) // 4 * 4
     res = torch.randn(n, ref.shape[2], ref.shape[3], ldy, generator=gen).bfloat16()
     msk = torch.randn(n, ref.shape[2], ref.shape[3], ldy, generator=gen).bfloat16()
@@ -184,7 +186,7 @@ def test_conv_p8_kernel(dev, case, cfg):
     ldy = (k + 7) // 8 * 8
     y = o.conv2d(xd, wd, k, r, r, stride, pad, bias=bias.to(dev), ldy=ldy, tile_cfg=cfg)
     got = nchw(y.float().cpu()[..., :k])
-    assert torch.allclose(got, ref, rtol=2e-2, atol=8e-2), (got - ref).abs().max()
+    assert torch.allclose(got, ref, rtol=4e-3, atol=1e-3), (got - ref).abs().max()
     res = torch.randn(n, ref.shape[2], ref.shape[3], ldy, generator=gen).bfloat16()
     msk = torch.randn(n, ref.shape[2], ref.shape[3], ldy, generator=gen).bfloat16()
     y2 = o.conv2d(xd, wd, k, r, r, stride, pad, bias=bias.to(dev), residual=res.to(dev), mask_ref=msk.to(dev), relu=True, ldy=ldy, tile_cfg=cfg)
@@ -226,7 +228,7 @@ def test_conv_loader_consumer_kernel(dev, case, code):
     assert torch.equal(a[..., :k], b[..., :k])
     ref = F.conv2d(x.float().permute(0, 3, 1, 2).cpu(), wt.float().permute(0, 3, 1, 2).cpu(), bias.cpu(), stride=stride, padding=pad).permute(0, 2, 3, 1)
     got = o.conv2d(x, wt, k, r, r, stride, pad, bias=bias, ldy=ldy, tile_cfg=code).float().cpu()[..., :k]
-    assert torch.allclose(got, ref, rtol=2e-2, atol=8e-2)
+    assert torch.allclose(got, ref, rtol=4e-3, atol=1e-3)
 
 
 def test_conv_policy_picks_the_loader_consumer_kernel_for_res4(dev):
@@ -1133,7 +1135,7 @@ def test_conv_halo7_kernel(dev, case):
     ldy = (k + 7) // 8 * 8
     y = o.conv2d(xd, wd, k, 3, 3, 1, 1, bias=bias.to(dev), ldy=ldy, tile_cfg=14)
     got = nchw(y.float().cpu()[..., :k])
-    assert torch.allclose(got, ref, rtol=2e-2, atol=8e-2), (got - ref).abs().max()
+    assert torch.allclose(got, ref, rtol=4e-3, atol=1e-3), (got - ref).abs().max()
     res = torch.randn(n, 7, 7, ldy, generator=gen).bfloat16()
     msk = torch.randn(n, 7, 7, ldy, generator=gen).bfloat16()
     y2 = o.conv2d(xd, wd, k, 3, 3, 1, 1, bias=bias.to(dev), residual=res.to(dev), mask_ref=msk.to(dev), relu=True, ldy=ldy, tile_cfg=14)

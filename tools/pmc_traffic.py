@@ -2,7 +2,9 @@
 in separate passes, MI355X_MICROARCH.md 'HBM'):  python3 tools/pmc_traffic.py <fetch_dir> <write_dir> <out.json>
 gfx950 corrections of that guide: FETCH_SIZE (KB) reports half of the bytes of wide (16 B/lane) streaming reads -> x2;
 WRITE_SIZE (KB) is exact for 16 B/lane streaming stores. Infinity-Cache hits are counted (traffic past the L2)."""
-import collections, csv, glob, json, sys
+import collections, csv, glob, json, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from unit_amd.build import source_hash          # content hash of the kernel sources the profiled library was built from
 
 def collect(d, counter):
     fs = glob.glob(d + "/**/*counter_collection.csv", recursive=True)
@@ -17,7 +19,8 @@ fetch = collect(sys.argv[1], "FETCH_SIZE")
 write = collect(sys.argv[2], "WRITE_SIZE")
 out = {"_note": "bytes past the L2 (HBM + Infinity Cache) per launch, rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over "
                 "`bench.py --steps 2 --warmup 1 --no-overlap --no-roofline --no-cpu-baseline`; FETCH_SIZE doubled (gfx950 wide-read "
-                "correction, MI355X_MICROARCH.md); KB = 1024 B"}
+                "correction, MI355X_MICROARCH.md); KB = 1024 B",
+       "_build_hash": source_hash()[:16]}          # bench.py prints `roofline.traffic` only while this equals the loaded library's stamp
 groups = collections.defaultdict(lambda: [[], []])
 for k in sorted(set(fetch) | set(write)):
     if not any(t in k for t in ("conv_igemm", "conv_wgrad", "multi_", "roi_align", "sgd")):

@@ -83,6 +83,8 @@ class GraphedStep:
         self.graphs = {}          # key -> (graph | (graph A, graph B), static PackedBatch, losses tensor)
         self.seen = set()         # keys that have run one eager step (constants uploaded, workspaces sized)
         self.pool = None
+        from . import ops
+        ops.retain_retired_buffers()          # from here on an outgrown workspace / slab is kept: a captured graph replays into its address
         self.eager_left = max(1, warmup_steps)          # the very first step initialises the momentum buffers (another SGD launch flag)
         self._torch = torch
 
@@ -270,6 +272,10 @@ class TrainerNoMeta:
         self.optimizer = FlatSGD(model, cfg, grad_scale=self.buckets.grad_scale)
         self.iter = 0
         self.last_losses = None
+        # parity hook: {"rpn": int32 [B, anchors], "roi": int32 [B, capacity]} device permutations used for the anchor / RoI subsampling of
+        # EVERY step instead of the device RNG's draws (the sampling contract of DESIGN section 2: the reference's torch.randperm is the
+        # one part of a step that cannot be reproduced, so comparisons hand both sides the same permutation). None = production.
+        self.fixed_permutations = None
         self.early = EarlyUpdate(model, self.buckets, self.optimizer) if early_update else None
         self.graphed = GraphedStep(model, self.optimizer, buckets=self.buckets, per_bucket=graph_per_bucket) if (use_graph and not early_update) else None
 
@@ -284,7 +290,7 @@ class TrainerNoMeta:
             self.last_losses = self.graphed.run(base_data, classifier_data)
             return self.last_losses
         batch = self.model.pack_batch(base_data, classifier_data)
-        step = self.model.forward_train(batch, early_backward=True)
+        step = self.model.forward_train(batch, self.fixed_permutations, early_backward=True)
         self.model.backward_train(step)          # buckets' all-reduces are launched from inside (on_grad_ready)
         self.buckets.finish()
         if self.early is not None:

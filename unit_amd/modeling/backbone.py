@@ -58,11 +58,15 @@ class ResNet(nn.Module):
     def fwd(self, x, save=False, before_trainable=None):
         """before_trainable: called once, before the first stage whose weights train (GeneralizedRCNN.optimizer_tail: the frozen
         stem / res2 of a step may run beside the previous step's optimizer update)"""
+        joined = False
+        if before_trainable is not None and any(p.requires_grad for p in self.stem.parameters()):
+            before_trainable()          # FREEZE_AT 0: the stem trains too -- its weights are what the pending optimizer tail is writing
+            joined = True
         x = self.stem.fwd(x)
         ft = self.first_trainable_stage()
         ctx = []
         for i, st in enumerate((self.res2, self.res3, self.res4)):
-            if i == ft and before_trainable is not None:
+            if i == ft and before_trainable is not None and not joined:
                 before_trainable()
             x, c = st.fwd(x, save=save and i >= ft)
             ctx.append(c)

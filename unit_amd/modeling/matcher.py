@@ -8,14 +8,17 @@ from .. import ops
 
 class Matcher(object):
     def __init__(self, thresholds, labels, allow_low_quality_matches=False):
-        thresholds = thresholds[:]
-        assert thresholds[0] > 0
-        thresholds.insert(0, -float("inf"))
-        thresholds.append(float("inf"))
-        assert all([low <= high for (low, high) in zip(thresholds[:-1], thresholds[1:])])
-        assert all([l in [-1, 0, 1] for l in labels])
-        assert len(labels) == len(thresholds) - 1
-        self.thresholds = thresholds
+        """thresholds: ascending IoU cut points, the first one positive; labels: one of {-1, 0, 1} per interval they delimit (one more than
+        cut points). Kept as the reference keeps them -- `thresholds` with the two infinite sentinels around the cut points -- because callers
+        (and checkpoints of pickled configs) read these attributes."""
+        cuts = [float(t) for t in thresholds]
+        if not cuts or cuts[0] <= 0:
+            raise AssertionError("Matcher: the lowest threshold must be positive")
+        if any(b < a for a, b in zip(cuts, cuts[1:])):
+            raise AssertionError("Matcher: thresholds must ascend")
+        if len(labels) != len(cuts) + 1 or any(l not in (-1, 0, 1) for l in labels):
+            raise AssertionError("Matcher: one label in {-1, 0, 1} per interval (len(thresholds) + 1 of them)")
+        self.thresholds = [-float("inf")] + cuts + [float("inf")]
         self.labels = labels
         self.allow_low_quality_matches = allow_low_quality_matches
 

@@ -139,6 +139,9 @@ class ConvPlan:
             return
         entries = lst[1]
         self._pending[key] = [0, []]
+        cur = ops.raw_stream(self.model.device.index) if self.model.device.type == "cuda" else 0
+        if key != cur:          # the slabs were written on another stream (e.g. the RPN branch's per-layer weight gradient in fp32 mode): order
+            check(lib().unit_stream_wait_stream(ctypes.c_void_p(cur), ctypes.c_void_p(key)), "unit_stream_wait_stream")      # the reduce behind them
         sig = tuple((id(m), slab.data_ptr(), sp) for m, slab, sp in entries)
         tab = self._tables.get(sig)
         if tab is None:

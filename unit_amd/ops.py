@@ -123,8 +123,10 @@ def lc_tile_code(m, k, kgemm):
     return best[1]
 
 
-def _mid_tile_default(dtype, m, k, c, kgemm):
-    """-1: use the register-staged conv_igemm.hip kernel; 0..5: LDS-DMA 4-wave kernel with that tile (csrc/conv_igemm128.hip);
+def _mid_tile_default(dtype, m, k, c, kgemm, allow_lc=True):
+    """allow_lc=False: the caller's output cannot be written by the loader / consumer kernel (fp32 output, rows not a multiple of 16 bytes):
+    choose among the 4-wave tiles only.
+    -1: use the register-staged conv_igemm.hip kernel; 0..5: LDS-DMA 4-wave kernel with that tile (csrc/conv_igemm128.hip);
     >= 100: persistent loader / consumer workgroups (csrc/conv_igemm_lc.hip, `lc_tile_code`) -- the layers with a long contraction
     and few output tiles (res4 and the res3 -> res4 transition on four 600x1000 images: 1x1 1024 -> 256 15.0 -> 11.9 us, 3x3 256 -> 256
     26.8 -> 18.9 us, tools/lc_sweep.py); short contractions (K = 256 -> 1024: four k-steps per tile) and the large res2 / res3 maps stay
@@ -142,9 +144,10 @@ def _mid_tile_default(dtype, m, k, c, kgemm):
     # one-per-CU form stays ahead, with two k-steps per tile -- res3 128 -> 512 -- the 4-wave kernel, the 1024-wide transition layer is a
     # tie). In the step: 16.31 ms without vs 16.35 ms with it (three alternating runs each) -- not enabled.
     t80 = ((m + 79) // 80) * ((k + 127) // 128)
-    if not _NO_LC and _LC_TWO and k % 8 == 0 and kgemm >= 256 and 384 <= t80 <= 1024 and not (kgemm >= 512 and k >= 1024):
+    lc = allow_lc and not _NO_LC
+    if lc and _LC_TWO and k % 8 == 0 and kgemm >= 256 and 384 <= t80 <= 1024 and not (kgemm >= 512 and k >= 1024):
         return 2152
-    if not _NO_LC and kgemm >= 512 and tiles <= 640 and k % 8 == 0:
+    if lc and kgemm >= 512 and tiles <= 640 and k % 8 == 0:
         return lc_tile_code(m, k, kgemm)
     if _MID96:
         # 96-row tiles (tools/mid_sweep.py, profiles/r02_exp_mid_sweep_96_row_tiles.txt): the res4 1x1 -> 256 layers become 100 x 2 = 200
@@ -196,6 +199,31 @@ class _timed:
 
 
 _WS_RETIRED = []
+_GRAPHS_ALIVE = [False]          # set by engine.GraphedStep at its first capture: from then on an outgrown buffer's address may be baked into a graph
+
+
+def retain_retired_buffers():
+    """engine.GraphedStep, before its first capture: outgrown workspaces / weight-gradient slabs are kept alive from now on (a captured
+    hipGraph replays into the addresses it recorded). Without a graph they are returned to the allocator."""
+    _GRAPHS_ALIVE[0] = True
+
+
+def _retire(buf):
+    """an outgrown scratch buffer: kept for ever only while a captured graph may replay into it; otherwise handed back to the caching
+    allocator -- after the work already queued on the LAUNCH stream (which need not be torch's current stream: `on_stream`), hence the
+    record_stream. With multi-scale inputs (ResizeShortestEdge 480-800) the per-conv slabs regrow many times; keeping every old one pinned
+    tens of MB each for the life of the process."""
+    if _GRAPHS_ALIVE[0]:
+        _WS_RETIRED.append(buf)
+    elif buf.is_cuda:
+        buf.record_stream(torch.cuda.ExternalStream(raw_stream(buf.device.index), device=buf.device))
+
+
+def _grown(nbytes, old):
+    """new capacity for a buffer that must hold nbytes: geometric (x1.25 over the old size at least) so that a slowly rising maximum does
+    not reallocate at every step"""
+    have = old.numel() if old is not None else 0
+    return max(int(nbytes), have + have // 4)
 
 
 def workspace(nbytes, device, slot=0):
@@ -206,8 +234,8 @@ def workspace(nbytes, device, slot=0):
     w = _WS.get(key)
     if w is None or w.numel() < nbytes:
         if w is not None:
-            _WS_RETIRED.append(w)      # grow-only: a captured hipGraph (engine.GraphedStep) may have this address baked into its launches
-        w = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
+            _retire(w)      # a captured hipGraph (engine.GraphedStep) may have this address baked into its launches: see _retire
+        w = torch.empty(max(_grown(nbytes, w), 1 << 20), dtype=torch.uint8, device=device)
         _WS[key] = w
     return w
 
@@ -299,7 +327,7 @@ def conv2d(x, w, k, r, s, stride=1, pad=0, bias=None, residual=None, mask_ref=No
         e0 = torch.cuda.Event(enable_timing=True)
         e0.record()
     if tile_cfg == 0:          # the two policy functions cost ~5 us per call (the loader / consumer tile search): cached per shape
-        pkey = (x.dtype, n * oh * ow, k, c, r * s * c, out_dtype, ldy % 8, BIG_TILE_POLICY, MID_TILE_POLICY, _NO_LC)
+        pkey = (x.dtype, n * oh * ow, k, c, r * s * c, out_dtype, ldy % 8, BIG_TILE_POLICY, MID_TILE_POLICY, _NO_LC, _MID96, _LC_TWO, _NO_MID)
         pol = _POLICY_CACHE.get(pkey)
     else:
         pkey = pol = None
@@ -312,13 +340,14 @@ def conv2d(x, w, k, r, s, stride=1, pad=0, bias=None, residual=None, mask_ref=No
     elif tile_cfg in (7, 8, 9, 10, 19, 20):
         mid = {19: 4, 20: 5}.get(tile_cfg, tile_cfg - 7)
     elif tile_cfg == 0 and not big:
-        mid = MID_TILE_POLICY(x.dtype, n * oh * ow, k, c, r * s * c)
-        if mid >= 100 and (out_dtype != torch.bfloat16 or ldy % 8 != 0):        # the loader / consumer kernel writes bf16 rows of 16-byte vectors
-            was, globals()["_NO_LC"] = _NO_LC, True
-            try:
-                mid = MID_TILE_POLICY(x.dtype, n * oh * ow, k, c, r * s * c)
-            finally:
-                globals()["_NO_LC"] = was
+        lc_ok = out_dtype == torch.bfloat16 and ldy % 8 == 0        # the loader / consumer kernel writes bf16 rows of 16-byte vectors
+        try:
+            mid = MID_TILE_POLICY(x.dtype, n * oh * ow, k, c, r * s * c, allow_lc=lc_ok)
+        except TypeError:          # a user-supplied policy with the five-argument signature
+            mid = MID_TILE_POLICY(x.dtype, n * oh * ow, k, c, r * s * c)
+        if mid >= 100 and not lc_ok:          # ... that asked for the loader / consumer kernel anyway: the best 4-wave tile instead
+            tiles = ((n * oh * ow + 127) // 128) * ((k + 127) // 128)
+            mid = 2 if k <= 64 else (0 if tiles >= 256 else 1)
     if pkey is not None and pol is None:
         _POLICY_CACHE[pkey] = (big, mid)
     if mid >= 0:
@@ -467,9 +496,10 @@ def conv2d_wgrad_partial(x, dy, k, r, s, stride, pad, slab=None, variant=0):
     oh, ow = conv_out_size(h, wd, r, s, stride, pad)
     nbytes = lib().unit_conv2d_wgrad_workspace_bytes(dt(x.dtype), n, oh, ow, k, r, s, c)
     if slab is None or slab.numel() < nbytes:
+        old = slab
         if slab is not None:
-            _WS_RETIRED.append(slab)       # grow-only, as workspace(): a captured step may replay into the old slab
-        slab = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+            _retire(slab)       # as workspace(): a captured step may replay into the old slab
+        slab = torch.empty(_grown(nbytes, old), dtype=torch.uint8, device=x.device)
     splits = lib().unit_conv2d_wgrad_splits(dt(x.dtype), n, oh, ow, k, r, s, c)
     ldy = dy.shape[-1]
     prof = PROFILER
@@ -523,9 +553,10 @@ def conv2d_wgrad_group(items, slabs=None, splits_hint=0):
         need = pr[i].splits * k * r * s * x.shape[-1] * 4
         slab = slabs[i] if slabs is not None else None
         if slab is None or slab.numel() < need:
+            old = slab
             if slab is not None:
-                _WS_RETIRED.append(slab)       # grow-only (conv2d_wgrad_partial)
-            slab = torch.empty(need, dtype=torch.uint8, device=x.device)
+                _retire(slab)       # (conv2d_wgrad_partial)
+            slab = torch.empty(_grown(need, old), dtype=torch.uint8, device=x.device)
         pr[i].partial = slab.data_ptr()
         out.append((slab, pr[i].splits))
     with _timed("conv_wgrad", flops, nbytes):

@@ -232,9 +232,9 @@ class GradBuckets:
         """make the compute stream wait for every outstanding bucket (no host sync). With `exposed_events` set, the time the compute
         stream spends in these waits -- the part of the all-reduce that did NOT hide behind the backward -- is event-timed."""
         tail = getattr(self.model, "optimizer_tail", None)
-        if tail is not None and getattr(self.model, "_tail_pending", None) is not None:
-            with tail():      # the waits go to the stream the optimizer will run on (GeneralizedRCNN.overlap_optimizer_tail)
-                return self._finish()
+        if tail is not None:
+            with tail():      # the stream the optimizer will run on: the weight-gradient stream while a tail is pending
+                return self._finish()          # (GeneralizedRCNN.overlap_optimizer_tail), the current stream otherwise
         return self._finish()
 
     def _finish(self):

@@ -98,6 +98,20 @@ class FlatSGD:
                 self._apply(st, a, b)
                 self._early.add((a, b))
 
+    def join(self):
+        """make the current stream wait for an optimizer update that is still running on the model's weight-gradient stream
+        (TrainerNoMeta(overlap_tail=True) / GeneralizedRCNN.overlap_optimizer_tail). Call it before reading `model.store.params`,
+        `model.store.grads` or the momentum buffer on another stream between steps; `model.state_dict()`, `forward_train` and inference
+        do so themselves. A no-op without a pending tail."""
+        j = getattr(self.model, "join_optimizer_tail", None)
+        if j is not None:
+            j()
+
+    def momentum_buffer(self):
+        """the flat momentum buffer, safe to read on the current stream"""
+        self.join()
+        return self._buf
+
     def step(self):
         tail = getattr(self.model, "optimizer_tail", None)
         if tail is None:
