@@ -199,6 +199,81 @@ def cpu_baseline(depth, variant):
             "value_flop_normalised": round(2.0 / dt * sample_tflop / full, 4) if sample_tflop else None}
 
 
+def voc_shapes_run(args, cfg, model, buckets, opt, rank, world, dev):
+    """SECONDARY line (never the headline: BASELINE.json's metric is quoted on fixed 3x600x1000 images): the same S1 step over batches whose
+    image sizes change every step the way the reference's loader makes them (synthetic.voc_shaped_steps: VOC aspect ratios,
+    ResizeShortestEdge 480-800 / max 1333, one orientation per batch). The supervised and the weak batch of a step almost never pad to the
+    same size, so nearly every step takes the two-pass backbone path; tile policies, weight-gradient split plans and scratch sizes are met
+    for the first time inside the timed region, as they are in training."""
+    import torch.distributed as dist
+    from unit_amd import _lib, ops
+    from unit_amd.synthetic import synthetic_batch, voc_shaped_steps
+    steps, warm = max(args.steps, 40), max(args.warmup, 3)
+    plan = voc_shaped_steps(warm + steps, cfg, seed=100 + rank)
+    packed = []
+    for i, (sup_hw, weak_hw) in enumerate(plan):
+        sup = [synthetic_batch(1, 0, hw=hw, seed=1000 * rank + 10 * i + j)[0][0] for j, hw in enumerate(sup_hw)]
+        weak = [synthetic_batch(0, 1, hw=hw, seed=1000 * rank + 10 * i + 5 + j)[1][0] for j, hw in enumerate(weak_hw)]
+        packed.append(model.pack_batch(sup, weak, gt_buckets=(8, 16, 32)))          # resident in HBM before the timed region
+    gs = None
+    if args.graph:
+        from unit_amd.engine import GraphedStep
+        gs = GraphedStep(model, opt, warmup_steps=2, buckets=buckets)
+
+    def run(b):
+        if gs is not None:
+            return gs.run(packed=b)
+        st = model.forward_train(b, early_backward=True)
+        model.backward_train(st)
+        buckets.finish()
+        opt.step()
+        return st.losses
+
+    for b in packed[:warm]:
+        run(b)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    pol0, ws0, gstat0 = len(ops._POLICY_CACHE), ops.WS_GROWTHS[0], dict(gs.stats) if gs else None
+    mem0 = torch.cuda.memory_stats(dev)
+    t0 = time.perf_counter()
+    for b in packed[warm:]:
+        losses = run(b)
+    t_host = time.perf_counter() - t0
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    mem1 = torch.cuda.memory_stats(dev)
+    host_ms = t_host / steps * 1e3
+    if world > 1:
+        t = torch.tensor([dt, host_ms], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt, host_ms = (float(v) for v in t.tolist())
+    assert torch.isfinite(losses).all(), f"non-finite losses {losses}"
+    if rank == 0:
+        two_pass = sum(1 for s_hw, w_hw in plan[warm:] if (max(h for h, _ in s_hw), max(w for _, w in s_hw)) != (max(h for h, _ in w_hw), max(w for _, w in w_hw)))
+        px = sum(h * w for s_hw, w_hw in plan[warm:] for h, w in s_hw + w_hw) / steps
+        out = {"metric": "images/sec (fwd+bwd+SGD) R101-C4 VOC, multi-scale VOC-shaped batches (SECONDARY line, not BASELINE.json's metric)",
+               "headline": False, "value": round(2 * world * steps / dt, 3), "unit": "images/sec", "n_gpus": world, "steps": steps, "warmup": warm,
+               "ms_per_step": round(dt / steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype,
+               "data": "synthetic", "launch": "hipGraph replay per batch key" if gs else "eager", "host_enqueue_ms_per_step": round(host_ms, 3),
+               "dist": buckets.describe(), "build_hash": _lib.build_hash(),
+               "config": {"workload": f"UniT base-training step S1, ResNet-{args.depth}-C4, 2 supervised + 2 weak images per GPU whose sizes change every "
+                                      "step: VOC raw sizes through ResizeShortestEdge((480, ..., 800), max 1333) with one orientation per batch "
+                                      "(configs/VOC/VOC-RCNN-101-C4-split1.yaml:27-29, data/build.py:476-497), 512 RoIs/image, 12000->2000",
+                          "images_per_gpu": 2, "global_batch": 2 * world, "parallelism": f"dp{world}",
+                          "mean_pixels_per_step": round(px), "pixels_relative_to_the_600x1000_workload": round(px / (4 * 600 * 1000), 3),
+                          "steps_on_the_two_pass_backbone_path": two_pass},
+               "shape_churn": {"tile_policy_cache_misses": len(ops._POLICY_CACHE) - pol0, "scratch_buffer_growths": ops.WS_GROWTHS[0] - ws0,
+                               "device_mallocs": mem1.get("num_device_alloc", 0) - mem0.get("num_device_alloc", 0),
+                               "allocator_retries": mem1.get("num_alloc_retries", 0) - mem0.get("num_alloc_retries", 0),
+                               "reserved_gb": round(mem1.get("reserved_bytes.all.peak", 0) / 2 ** 30, 2),
+                               "graph": ({k: gs.stats[k] - gstat0[k] for k in gs.stats} if gs else None)}}
+        print(json.dumps(out), flush=True)
+    return 0
+
+
 def main():
     args = parse()
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -273,6 +348,12 @@ def main():
             early.join()
         opt.step()
         return step.losses
+
+    if args.shapes == "voc":
+        rc = voc_shapes_run(args, cfg, model, buckets, opt, rank, world, dev)
+        if dist.is_initialized():
+            dist.destroy_process_group()
+        return rc
 
     if args.high_priority and not (args.no_overlap or args.graph):
         torch.cuda.synchronize()

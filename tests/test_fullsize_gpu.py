@@ -511,3 +511,111 @@ def test_coco_k80_eval_fullsize_80class_nms(dev):
     assert len(b) == 100 and len(hb) == 100
     assert f_h >= 0.98 and f_o >= 0.98, (f_h, f_o)
     assert out.pred_masks.shape == (len(hb), out_hw[0], out_hw[1])
+
+
+# =================================================================================================== config 2 (R50 at its own size) and the
+# yaml's REAL training shapes: INPUT.MIN_SIZE_TRAIN (480, ..., 800), MAX_SIZE_TRAIN 1333 (configs/VOC/VOC-RCNN-101-C4-split1.yaml:27-29)
+def _feat_hw(h, w):
+    """res4 map of an h x w input: stem conv s2 (k7 p3), max pool s2 (k3 p1), res3 / res4 first blocks s2 (1x1)"""
+    for _ in range(2):
+        h, w = (h - 1) // 2 + 1, (w - 1) // 2 + 1
+    return ((h - 1) // 2 + 1 - 1) // 2 + 1, ((w - 1) // 2 + 1 - 1) // 2 + 1
+
+
+def _s1_case(dev, depth, sup_hw, weak_hw, seed):
+    """one oracle S1 step on supervised images of sizes `sup_hw` and weak images of sizes `weak_hw` (lists of (h, w)); everything the
+    HIP side is compared with"""
+    cfg = config.voc_rcnn_c4_split1(depth)
+    cfg.MODEL.DEVICE = "cuda"
+    cfg.SEED = seed
+    model = build_model(cfg)
+    init_synthetic_weights(model, seed=1)
+    model.train()
+    sup = [synthetic_batch(1, 0, hw=hw, seed=seed + 11 * i)[0][0] for i, hw in enumerate(sup_hw)]
+    weak = [synthetic_batch(0, 1, hw=hw, seed=seed + 100 + 11 * i)[1][0] for i, hw in enumerate(weak_hw)]
+    batch = model.pack_batch(sup, weak)
+    model.compute_dtype = torch.float32
+    model._ensure_ready()
+    fh, fw = _feat_hw(max(h for h, _ in sup_hw), max(w for _, w in sup_hw))          # anchors live on the supervised batch's padded grid
+    perms = model.sampling_permutations(len(sup), fh * fw * 15, cfg.MODEL.RPN.POST_NMS_TOPK_TRAIN + batch.gt_boxes.shape[1])
+    p = oracle_params(model)
+    operms = dict(rpn=[x.long().cpu() for x in perms["rpn"]], roi=[x.long().cpu() for x in perms["roi"]])
+    ref, aux = orc.step_losses(p, [x["image"] for x in sup], [x["instances"].gt_boxes.tensor for x in sup],
+                               [x["instances"].gt_classes for x in sup], [x["image"] for x in weak],
+                               [x["instances"].gt_classes for x in weak], operms, ocfg_of(cfg))
+    sum(ref.values()).backward()
+    grads = {k: v.grad.clone() for k, v in p.items() if v.grad is not None}
+    ref = {k: v.item() for k, v in ref.items()}
+    keep = dict(anchor_labels=torch.stack(aux["anchor_labels"]), proposals=aux["proposals"], weak_proposals=aux["weak_proposals"],
+                sampled=[{k: v.clone() for k, v in s.items()} for s in aux["sampled"]])
+    del p, aux
+    return dict(cfg=cfg, model=model, batch=batch, perms=perms, ref=ref, grads=grads, aux=keep)
+
+
+def _teacher_forced(dev, st, dtype, tag, cos_names=None):
+    """the HIP step on the oracle's proposals in `dtype` on the production schedule: integer stages exact; fp32: losses 1e-4, every
+    trainable tensor's gradient within 2e-3 of its max; bf16: losses rtol 6e-3 + atol 1e-4, gradient cosine >= 0.9975 on `cos_names`"""
+    model, cfg, aux = st["model"], st["cfg"], st["aux"]
+    model.compute_dtype = dtype
+    try:
+        props = pack_proposals(aux["proposals"] + aux["weak_proposals"], cfg.MODEL.RPN.POST_NMS_TOPK_TRAIN, dev)
+        step = model.forward_train(st["batch"], st["perms"], early_backward=True, proposals=props)
+        model.backward_train(step)
+        got = dict(zip(LOSS_NAMES, step.losses.cpu().tolist()))
+        assert torch.equal(step.anchor_labels.cpu(), aux["anchor_labels"])
+        _check_sampled_exact(step, aux, cfg.MODEL.ROI_HEADS.BATCH_SIZE_PER_IMAGE)
+        params = dict(model.named_parameters())
+        if dtype == torch.float32:
+            worst = 0.0
+            for name, prm in params.items():
+                if not prm.requires_grad:
+                    continue
+                g, gr = prm.grad.detach().cpu(), st["grads"][name]
+                err = max((g - gr).abs().max().item() - 1e-7, 0.0) / (gr.abs().max().item() + 1e-12)
+                worst = max(worst, err)
+                assert err <= 2e-3, (tag, name, err)
+            dev_l = {k: abs(got[k] - v) / max(1.0, abs(v)) for k, v in st["ref"].items()}
+            log_metrics(tag, dict(loss_rel_dev=dev_l, worst_grad_rel_to_max=worst))
+            for k, v in dev_l.items():
+                assert v <= 1e-4, (tag, k, got[k], st["ref"][k])
+        else:
+            cos = {n: cosine(params[n].grad.detach().cpu(), st["grads"][n]) for n in cos_names}
+            log_metrics(tag, dict(losses_bf16_vs_fp32_oracle={k: (got[k], v) for k, v in st["ref"].items()}, grad_cosine=cos))
+            for k, v in st["ref"].items():
+                assert abs(got[k] - v) <= 6e-3 * abs(v) + 1e-4, (tag, k, got[k], v)
+            for n, c in cos.items():
+                assert c >= 0.9975, (tag, n, c)
+    finally:
+        model.compute_dtype = torch.float32
+
+
+R50_COS = ["roi_heads.box_head.res5.2.conv3.weight", "roi_heads.box_head.res5.0.conv1.weight", "roi_heads.weak_box_head.res5.1.conv2.weight",
+           "backbone.res4.5.conv3.weight", "backbone.res4.2.conv2.weight", "backbone.res4.0.conv1.weight", "backbone.res3.0.conv1.weight",
+           "proposal_generator.rpn_head.conv.weight", "roi_heads.box_predictor.cls_score_delta.weight",
+           "roi_heads.box_predictor.weak_detector_head.oicr_predictors.1.weight"]
+R101_COS = [n.replace("res4.5.", "res4.22.").replace("res4.2.", "res4.10.") for n in R50_COS]
+
+
+def test_r50_s1_fullsize_bf16(dev):
+    """BASELINE config 2 at its own size: ResNet-50-C4 VOC split1 base training, 2 + 2 images of 3x600x1000, bf16 on the production
+    schedule, teacher-forced against the fp32 oracle (and the fp32 mode of the same step at 1e-4, so the bf16 numbers have their anchor)."""
+    st = _s1_case(dev, 50, [HW, HW], [HW, HW], seed=7)
+    _teacher_forced(dev, st, torch.float32, "r50_s1_fp32_teacher_forced")
+    _teacher_forced(dev, st, torch.bfloat16, "r50_s1_bf16", R50_COS)
+
+
+def test_r101_s1_800x1333_fp32_and_bf16(dev):
+    """the LARGEST shape the yaml trains on (ResizeShortestEdge 800, max 1333: 50 x 84 res4 map, 63 000 anchors per image, 2.2x the pixels of
+    600x1000): tile policies, split counts of the weight gradients, workspace sizes and 32-bit offsets of every kernel at the real maximum"""
+    st = _s1_case(dev, 101, [(800, 1333)] * 2, [(800, 1333)] * 2, seed=9)
+    _teacher_forced(dev, st, torch.float32, "r101_s1_800x1333_fp32_teacher_forced")
+    _teacher_forced(dev, st, torch.bfloat16, "r101_s1_800x1333_bf16", R101_COS)
+
+
+def test_r50_s1_mixed_orientations_two_pass(dev):
+    """a landscape and a portrait image in the supervised batch (800x1216 + 1216x800 -> zero-padded to 1216x1216: more padding than image
+    in each slot) beside a weak batch that pads differently (800x1333 + 608x800 -> the two-pass backbone path of DESIGN section 5: forward
+    twice, backward twice, second pass's weight gradients accumulated)"""
+    st = _s1_case(dev, 50, [(800, 1216), (1216, 800)], [(800, 1333), (608, 800)], seed=13)
+    _teacher_forced(dev, st, torch.float32, "r50_s1_mixed_fp32_teacher_forced")
+    _teacher_forced(dev, st, torch.bfloat16, "r50_s1_mixed_bf16", R50_COS)

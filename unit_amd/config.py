@@ -159,6 +159,7 @@ def voc_rcnn_c4_split1(depth=101):
     c.MODEL.ROI_HEADS.FAST_RCNN.WEAK_DETECTOR.DETECTOR_TEMP = 2.0
     c.MODEL.ROI_HEADS.FAST_RCNN.WEAK_DETECTOR.REGRESSION_BRANCH = False
     c.SOLVER.IMS_PER_BATCH = 8
+    c.INPUT.MIN_SIZE_TRAIN = (480, 512, 544, 576, 608, 640, 672, 704, 736, 768, 800)          # yaml:27-29 (ResizeShortestEdge "choice", max 1333)
     return c
 
 

@@ -82,6 +82,7 @@ class GraphedStep:
         self.per_bucket = per_bucket
         self.graphs = {}          # key -> (graph | (graph A, graph B), static PackedBatch, losses tensor)
         self.seen = set()         # keys that have run one eager step (constants uploaded, workspaces sized)
+        self.stats = {"eager": 0, "captured": 0, "replayed": 0}          # how the steps so far ran (bench.py --shapes voc: the graph-mode hit rate)
         self.pool = None
         from . import ops
         ops.retain_retired_buffers()          # from here on an outgrown workspace / slab is kept: a captured graph replays into its address
@@ -196,8 +197,10 @@ class GraphedStep:
         if self.eager_left > 0 or key not in self.seen:   # the first steps, and the first step of every new key, run eagerly
             self.eager_left = max(0, self.eager_left - 1)
             self.seen.add(key)
+            self.stats["eager"] += 1
             return self._body(fresh)
         ent = self.graphs.get(key)
+        self.stats["replayed" if ent is not None else "captured"] += 1
         if ent is None:
             static = fresh.clone()
             g = torch.cuda.CUDAGraph()

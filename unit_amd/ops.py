@@ -208,11 +208,15 @@ def retain_retired_buffers():
     _GRAPHS_ALIVE[0] = True
 
 
+WS_GROWTHS = [0]          # scratch / slab buffers replaced by bigger ones so far (bench.py --shapes voc reports the count per run)
+
+
 def _retire(buf):
     """an outgrown scratch buffer: kept for ever only while a captured graph may replay into it; otherwise handed back to the caching
     allocator -- after the work already queued on the LAUNCH stream (which need not be torch's current stream: `on_stream`), hence the
     record_stream. With multi-scale inputs (ResizeShortestEdge 480-800) the per-conv slabs regrow many times; keeping every old one pinned
     tens of MB each for the life of the process."""
+    WS_GROWTHS[0] += 1
     if _GRAPHS_ALIVE[0]:
         _WS_RETIRED.append(buf)
     elif buf.is_cuda:

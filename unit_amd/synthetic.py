@@ -70,3 +70,42 @@ def synthetic_batch(n_sup=2, n_weak=2, hw=(600, 1000), num_classes=20, base_ids=
         cls = torch.randint(0, num_classes, (m,), generator=g)
         weak.append({"image": img, "height": h, "width": w, "instances": Instances((h, w), gt_classes=cls)})
     return sup, weak
+
+
+# (height, width) of PASCAL VOC JPEGs and how often they occur, roughly: almost every image has a 500-pixel long side; 3:4 and 2:3
+# landscapes dominate, a fifth are portraits
+VOC_RAW_SIZES = (((375, 500), 0.50), ((333, 500), 0.17), ((500, 375), 0.13), ((500, 333), 0.06), ((400, 500), 0.05), ((500, 400), 0.02),
+                 ((281, 500), 0.03), ((500, 500), 0.02), ((442, 500), 0.02))
+
+
+def resize_shortest_edge_shape(h, w, short, max_size):
+    """output size of Detectron2's ResizeShortestEdge (data/dataset_mapper.py:13-31 -> T.ResizeShortestEdge): scale the short side to
+    `short`, cap the long side at `max_size`, round half up"""
+    scale = short / min(h, w)
+    nh, nw = (short, scale * w) if h < w else (scale * h, short)
+    if max(nh, nw) > max_size:
+        k = max_size / max(nh, nw)
+        nh, nw = nh * k, nw * k
+    return int(nh + 0.5), int(nw + 0.5)
+
+
+def voc_shaped_steps(n_steps, cfg, n_sup=2, n_weak=2, seed=0):
+    """image sizes of `n_steps` training steps drawn the way the reference's loader produces them: a VOC raw size, ResizeShortestEdge with a
+    short side chosen from INPUT.MIN_SIZE_TRAIN and the long side capped at MAX_SIZE_TRAIN (configs/VOC/VOC-RCNN-101-C4-split1.yaml:27-29),
+    and -- the aspect-ratio grouping of data/build.py:476-497 -- every batch holds images of ONE orientation (landscape or portrait), the
+    supervised and the weak batch of a step being grouped independently. -> [(sup sizes, weak sizes)] as lists of (h, w)"""
+    import random
+    rng = random.Random(seed)
+    sizes, weights = zip(*VOC_RAW_SIZES)
+    land = [(s, w) for s, w in VOC_RAW_SIZES if s[1] >= s[0]]
+    port = [(s, w) for s, w in VOC_RAW_SIZES if s[1] < s[0]]
+    p_port = sum(w for _, w in port) / sum(weights)
+
+    def batch(n):
+        grp = port if rng.random() < p_port else land
+        out = []
+        for _ in range(n):
+            (h, w), = rng.choices([s for s, _ in grp], [w_ for _, w_ in grp])
+            out.append(resize_shortest_edge_shape(h, w, rng.choice(list(cfg.INPUT.MIN_SIZE_TRAIN)), cfg.INPUT.MAX_SIZE_TRAIN))
+        return out
+    return [(batch(n_sup), batch(n_weak)) for _ in range(n_steps)]
