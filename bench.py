@@ -245,6 +245,16 @@ def voc_shapes_run(args, cfg, model, buckets, opt, rank, world, dev):
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     mem1 = torch.cuda.memory_stats(dev)
+    # the host's own share: the same batches again, each enqueued onto an IDLE device (synchronize before, none after the clock stops) --
+    # `host_enqueue_ms_per_step` above includes queue back-pressure whenever the device is the slower side
+    idle = []
+    for b in packed[warm:warm + 10]:
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        run(b)
+        idle.append(time.perf_counter() - t1)
+    torch.cuda.synchronize()
+    host_idle_ms = sorted(idle)[len(idle) // 2] * 1e3
     host_ms = t_host / steps * 1e3
     if world > 1:
         t = torch.tensor([dt, host_ms], device=dev, dtype=torch.float64)
@@ -258,6 +268,7 @@ def voc_shapes_run(args, cfg, model, buckets, opt, rank, world, dev):
                "headline": False, "value": round(2 * world * steps / dt, 3), "unit": "images/sec", "n_gpus": world, "steps": steps, "warmup": warm,
                "ms_per_step": round(dt / steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype,
                "data": "synthetic", "launch": "hipGraph replay per batch key" if gs else "eager", "host_enqueue_ms_per_step": round(host_ms, 3),
+               "host_enqueue_ms_from_idle_device": round(host_idle_ms, 3),
                "dist": buckets.describe(), "build_hash": _lib.build_hash(),
                "config": {"workload": f"UniT base-training step S1, ResNet-{args.depth}-C4, 2 supervised + 2 weak images per GPU whose sizes change every "
                                       "step: VOC raw sizes through ResizeShortestEdge((480, ..., 800), max 1333) with one orientation per batch "
