@@ -285,8 +285,15 @@ def voc_shapes_run(args, cfg, model, buckets, opt, rank, world, dev):
     return 0
 
 
+def _trace(msg):
+    """UNIT_BENCH_TRACE=1: milestones on stderr (diagnosing a run that ends without its line)"""
+    if os.environ.get("UNIT_BENCH_TRACE"):
+        print(f"[bench {os.getpid()} {time.time():.3f}] {msg}", file=sys.stderr, flush=True)
+
+
 def main():
     args = parse()
+    _trace(f"start argv={sys.argv[1:]} WORLD_SIZE={os.environ.get('WORLD_SIZE')} MASTER_PORT={os.environ.get('MASTER_PORT')}")
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         return launch_ranks(args)          # this process never touches the GPU
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -322,6 +329,7 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
+        _trace("process group initialised")
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
 
@@ -346,6 +354,7 @@ def main():
     buckets = GradBuckets(model, bucket_bytes=None if args.bucket_mb is None else int(args.bucket_mb * (1 << 20)), bf16=args.bf16_buckets,
                           mode=args.reduce_mode, force=True if args.force_collectives else None)
     buckets.broadcast_parameters()
+    _trace("model built, parameters broadcast")
     opt = FlatSGD(model, cfg, grad_scale=buckets.grad_scale)
     from unit_amd.engine import EarlyUpdate
     early = EarlyUpdate(model, buckets, opt) if args.early_update else None
@@ -385,6 +394,7 @@ def main():
     for _ in range(args.steps):
         losses = timed_step()
     t_host = time.perf_counter() - t0          # the host's share: all K steps enqueued (nothing in a step waits for the device)
+    _trace("timed steps enqueued")
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -548,9 +558,11 @@ def main():
                 out["cpu_baseline"] = json.loads(line[-1][len("CPU_BASELINE "):]) if line else {"error": r.stderr[-300:]}
             except subprocess.TimeoutExpired:
                 out["cpu_baseline"] = {"error": "oracle sample exceeded the 240 s bound on this host"}
+        _trace("printing the line")
         print(json.dumps(out), flush=True)
     if dist.is_initialized():
         dist.destroy_process_group()
+    _trace("done")
     return 0
 
 

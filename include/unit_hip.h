@@ -43,6 +43,9 @@ int unit_preprocess_u8(const unsigned char* img_hwc, int C, int H, int W, int hf
 int unit_nchw_to_nhwc(const float* x, void* y, int dtype, int N, int C, int H, int W, int Cp, void* stream);
 int unit_nhwc_to_nchw(const void* x, int dtype, float* y, int N, int C, int H, int W, int Cp, void* stream);
 int unit_cast(const void* x, int in_dtype, void* y, int out_dtype, long n, void* stream);
+/* zero nbytes at p (16-byte aligned): replaces the torch.zeros / Tensor.zero_ fills of the reference's step (loss accumulators of
+ * engine/defaults.py:276-279's loss_dict, the zero-initialised gradient of a strided slice in autograd's conv backward) */
+int unit_fill_zero(void* p, size_t nbytes, void* stream);
 int unit_add_cast(const float* a32, const void* b, const void* mask_ref, void* y, int dtype, long n, void* stream);
 
 /* ---- a2/a3/a9/a10 convolution as implicit GEMM on MFMA: backbone (configs/VOC/VOC-RCNN-101-C4-split1.yaml:6-10 ->

@@ -1,0 +1,73 @@
+"""Which PyTorch (ATen) operators does one steady-state training step still dispatch, and from where?  python tools/stock_ops.py [two_pass]
+Runs the S1 R101 step under a TorchDispatchMode and lists every ATen call that is not pure metadata (views, allocation), with the first
+unit_amd frame that made it. The hot path's claim is that none of them launches a kernel: what remains should be allocation and views only."""
+import collections
+import sys
+import traceback
+
+import torch
+from torch.utils._python_dispatch import TorchDispatchMode
+
+sys.path.insert(0, ".")
+from unit_amd import config
+from unit_amd.modeling import build_model
+from unit_amd.solver import FlatSGD
+from unit_amd.synthetic import init_synthetic_weights, synthetic_batch
+
+META = ("empty", "view", "slice", "select", "as_strided", "reshape", "detach", "alias", "transpose", "permute", "unsqueeze", "squeeze",
+        "expand", "record_stream", "_unsafe_view", "t.default", "unbind", "split", "narrow", "_local_scalar_dense", "is_pinned", "unfold",
+        "lift_fresh", "_reshape_alias", "resize_", "set_", "stride", "size", "numel", "is_same_size", "contiguous", "_to_copy")
+
+
+class Log(TorchDispatchMode):
+    def __init__(self):
+        super().__init__()
+        self.calls = collections.Counter()
+
+    def __torch_dispatch__(self, func, types, args=(), kwargs=None):
+        name = str(func)
+        if not any(m in name for m in META) or "_to_copy" in name:
+            site = "?"
+            for fr in reversed(traceback.extract_stack()):
+                if "unit_amd" in fr.filename or "bench" in fr.filename:
+                    site = f"{fr.filename.split('unit_amd/')[-1]}:{fr.lineno} {fr.line.strip()[:70]}"
+                    break
+            dev = next((a.device.type for a in args if isinstance(a, torch.Tensor)), "-")
+            self.calls[(name, dev, site)] += 1
+        return func(*args, **(kwargs or {}))
+
+
+cfg = config.voc_rcnn_c4_split1(101)
+cfg.MODEL.DEVICE = "cuda:0"
+cfg.SEED = 0
+model = build_model(cfg)
+init_synthetic_weights(model, seed=1)
+model.train()
+model.compute_dtype = torch.bfloat16
+if len(sys.argv) > 1 and sys.argv[1] == "two_pass":
+    s1, _ = synthetic_batch(2, 0, hw=(608, 811), seed=1)
+    _, w1 = synthetic_batch(0, 2, hw=(736, 1105), seed=2)
+    batch = model.pack_batch(s1, w1)
+else:
+    sup, weak = synthetic_batch(2, 2, seed=100)
+    batch = model.pack_batch(sup, weak)
+opt = FlatSGD(model, cfg)
+
+
+def step():
+    st = model.forward_train(batch, early_backward=True)
+    model.backward_train(st)
+    opt.step()
+
+
+for _ in range(3):
+    step()
+torch.cuda.synchronize()
+log = Log()
+with log:
+    step()
+torch.cuda.synchronize()
+print("ATen calls of one steady-state step that are not views / allocation:")
+for (name, dev, site), n in sorted(log.calls.items(), key=lambda kv: (-kv[1], kv[0])):
+    print(f"{n:4d}  {name:40s} {dev:5s} {site}")
+print("total", sum(log.calls.values()))

@@ -396,6 +396,21 @@ extern "C" int unit_add_cast(const float* a32, const void* b, const void* mask_r
   return UNIT_OK;
 }
 
+// unit_fill_zero: the step's own memset (loss slots, the full-resolution target of a strided dgrad scatter, bitmaps): 16 bytes per lane,
+// byte tail by the last lanes. hipMemsetAsync would launch the runtime's fillBuffer kernel -- a stock op the hot path does not use.
+__global__ void __launch_bounds__(256) fill_zero_kernel(unsigned char* __restrict__ p, size_t nbytes) {
+  size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 16;
+  if (i + 16 <= nbytes) *reinterpret_cast<u32x4*>(p + i) = u32x4{0u, 0u, 0u, 0u};
+  else for (; i < nbytes; ++i) p[i] = 0;
+}
+extern "C" int unit_fill_zero(void* p, size_t nbytes, void* stream) {
+  if (nbytes == 0) return UNIT_OK;
+  UNIT_CHECK_ARG(((uintptr_t)p & 15) == 0, "fill_zero: 16-byte aligned pointer");
+  fill_zero_kernel<<<cdiv(cdiv(nbytes, 16), 256), 256, 0, (hipStream_t)stream>>>((unsigned char*)p, nbytes);
+  UNIT_LAUNCH_CHECK();
+  return UNIT_OK;
+}
+
 // y[i] = cast(x[i])  between fp32 and bf16 (either direction)
 template <typename TI, typename TO>
 __global__ void cast_kernel(const TI* __restrict__ x, TO* __restrict__ y, long n) {

@@ -11,6 +11,10 @@ struct UnitTensorDesc {
   void* wd;
   long offset;
   int splits, K, R, S, C, block0;
+  // weight prep only: row pitches (elements) of the two copies, 0 = contiguous. A pitched copy is one operand of a concatenated GEMM weight:
+  // wf rows [k] of pitch ldwf (1x1 convs: [K][C_a + C_b], the dual-input conv3 + shortcut GEMM of a Res5 head's first block), wd rows
+  // [(c, r', s')] of pitch ldwd ([C][K_a + K_b], its dgrad counterpart). wf may be NULL (only the dgrad copy is wanted).
+  int ldwf, ldwd;
 };
 
 #define MT_ELEMS_PER_BLOCK 1024
@@ -69,7 +73,7 @@ __global__ void __launch_bounds__(256) multi_prep_kernel(const UnitTensorDesc* _
       float sc = d.scale ? d.scale[k] : 1.0f;
 #pragma unroll
       for (int j = 0; j < 4; ++j) p[j] *= sc;
-      store4(wf + i, p);
+      if (wf) store4(wf + (d.ldwf ? (size_t)k * d.ldwf + (size_t)rs * d.C + c : i), p);
     }
 #pragma unroll
     for (int j = 0; j < 4; ++j) tile[cx + j][ky] = p[j];
@@ -80,8 +84,8 @@ __global__ void __launch_bounds__(256) multi_prep_kernel(const UnitTensorDesc* _
     int cy = threadIdx.x >> 3, kx = (threadIdx.x & 7) * 4;
     int c = c0 + cy;
     if (c < d.C) {
-      size_t o = (((size_t)c * d.R + (d.R - 1 - r)) * d.S + (d.S - 1 - sx)) * d.K + k0 + kx;
-      if ((d.K & 3) == 0) {                                      // rows of the dgrad copy stay 4-element aligned
+      size_t o = (((size_t)c * d.R + (d.R - 1 - r)) * d.S + (d.S - 1 - sx)) * (d.ldwd ? d.ldwd : d.K) + k0 + kx;
+      if ((d.K & 3) == 0 && (d.ldwd & 3) == 0) {                                      // rows of the dgrad copy stay 4-element aligned
         if (k0 + kx < d.K) store4(wd + o, f32x4{tile[cy][kx], tile[cy][kx + 1], tile[cy][kx + 2], tile[cy][kx + 3]});
       } else {
 #pragma unroll

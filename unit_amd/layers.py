@@ -65,6 +65,24 @@ class Conv2d(_EpochOnLoad):
         self.norm = FrozenBatchNorm2d(cout) if norm else None
         self._prep_key = None
         self.wf = self.wd = self.scale = self.shift = None
+        self._links = []          # [(kind "wf" | "wd", dst)]: further, PITCHED copies of the prepared weights (link_copy)
+
+    def link_copy(self, kind, dst):
+        """keep `dst` -- a 2-D strided view [rows, cols] into a concatenated GEMM weight (BottleneckBlock.prepare_dual) -- equal to the
+        prepared forward ("wf": rows = filters) or dgrad ("wd": rows = input channels) copy of this conv: written here once, then by
+        every refresh of the prepared copies (prepare() below; the optimizer's multi-tensor launch, multi.ConvPlan.prep_all, writes it
+        through a pitched descriptor -- no per-use torch.cat of the two operands)"""
+        self._links = [l for l in self._links if l[0] != kind] + [(kind, dst)]
+        self._refresh_links()
+        plan = getattr(self, "_plan", None)
+        if plan is not None:
+            plan._prep_table = None          # the table of the multi-tensor prep launch gains this destination
+
+    def _refresh_links(self):
+        for kind, dst in self._links:
+            src = self.wf if kind == "wf" else self.wd
+            if src is not None and src.dtype == dst.dtype:
+                dst.copy_(src.reshape(dst.shape))          # outside the steady-state step: first preparation / frozen layers only
 
     # -- weight preparation (FrozenBN fold + cast + dgrad re-layout); re-run when the master weights changed
     def prepare(self, dtype, version, need_dgrad=True):
@@ -84,6 +102,7 @@ class Conv2d(_EpochOnLoad):
                                            want_dgrad=need_dgrad, w_fwd=self.wf if self.wf is not None and self.wf.dtype == dtype else None,
                                            w_dgrad=self.wd if self.wd is not None and self.wd.dtype == dtype else None)
         self._prep_key = key
+        self._refresh_links()
 
     def fwd(self, x, relu=False, residual=None, out_dtype=None, stride=None):
         st = self.stride if stride is None else stride
@@ -167,7 +186,7 @@ class BottleneckBlock(nn.Module):
     def convs(self):
         return [c for c in (self.conv1, self.conv2, self.conv3, self.shortcut) if c is not None]
 
-    def fwd(self, x, save=False, stride=None, pool_rows=0, x_bits=None, out_bits=False):
+    def fwd(self, x, save=False, stride=None, pool_rows=0, x_bits=None, out_bits=False, pooled_out=None):
         """pool_rows > 0 (last block of a Res5 head): the block's output map is only ever averaged over each RoI's `pool_rows` bins
         (box_head.py:80) and, in the backward, tested for > 0 -- conv3's epilogue then produces the pooled features and a bit mask
         and never writes the map: returns ((pooled, bits | None), ctx) instead of (map, ctx)"""
@@ -184,7 +203,7 @@ class BottleneckBlock(nn.Module):
         if pool_rows:
             c3 = self.conv3
             _, bits, pooled = ops.conv2d_ex(y2, c3.wf, c3.cout, 1, 1, 0, bias=c3.shift, residual=sc, relu=True, want_bits=save,
-                                            pool_rows=pool_rows, want_y=False)
+                                            pool_rows=pool_rows, want_y=False, pooled_out=pooled_out)
             return (pooled, bits), ((x, y1, y2, st, x_bits) if save else None)
         if out_bits:       # the next block's backward reads (out > 0) as bits (Conv2d.dgrad mask_bits)
             c3 = self.conv3
@@ -201,28 +220,43 @@ class BottleneckBlock(nn.Module):
                 and ops.conv_ex_supported(x.dtype, self.conv3.cin, self.conv3.cout) and self.shortcut.cin % self.conv3.cin == 0
                 and self.shortcut.cout % self.conv1.cout == 0 and self.conv1.cout % 64 == 0 and self.conv1.cin % 64 == 0)
 
+    def prepare_dual(self):
+        """the concatenated weights of the dual-input GEMMs ([W3 | Wsc] forward, [W1^T ; Wsc^T] in dgrad layout backward) as PERSISTENT
+        prepared copies: the two convs of each pair link a pitched view of one buffer (Conv2d.link_copy), so whatever refreshes their
+        prepared weights -- in the training step the optimizer's one multi-tensor launch -- writes the concatenation too. (Until round 4
+        a 6 - 10 MB torch.cat per use and per stream: five stock copy kernels per step.) Called by the head's prepare() on the step's
+        main stream, before any side stream reads the buffers."""
+        if not (ops.FUSE_EPILOGUE and ops.FUSE_DUAL and getattr(self, "allow_dual", False) and self.shortcut is not None):
+            return
+        c3, sc, c1 = self.conv3, self.shortcut, self.conv1
+        if c3.wf is None or sc.wf is None or c3.wf.dtype != torch.bfloat16 or c3.k != 1 or sc.k != 1 or c1.k != 1:
+            return
+        key = (c3.wf.data_ptr(), sc.wf.data_ptr(), 0 if c1.wd is None else c1.wd.data_ptr(), 0 if sc.wd is None else sc.wd.data_ptr(),
+               0 if c3.shift is None else c3.shift.data_ptr(), 0 if sc.shift is None else sc.shift.data_ptr())
+        if self.__dict__.get("_dual_key") == key:
+            return
+        dev, dt = c3.wf.device, c3.wf.dtype
+        buf = torch.empty((c3.cout, 1, 1, c3.cin + sc.cin), dtype=dt, device=dev)
+        v = buf.view(c3.cout, -1)
+        c3.link_copy("wf", v[:, :c3.cin])
+        sc.link_copy("wf", v[:, c3.cin:])
+        self.__dict__["_wcat_fwd"] = buf
+        self.__dict__["_wcat_bwd"] = None
+        if c1.wd is not None and sc.wd is not None:
+            bufb = torch.empty((c1.cin, 1, 1, c1.cout + sc.cout), dtype=dt, device=dev)
+            vb = bufb.view(c1.cin, -1)
+            c1.link_copy("wd", vb[:, :c1.cout])
+            sc.link_copy("wd", vb[:, c1.cout:])
+            self.__dict__["_wcat_bwd"] = bufb
+        self.__dict__["_bcat"] = c3.shift + sc.shift          # FrozenBN shifts never change during training: once
+        self.__dict__["_dual_key"] = key
+
     def _cat_weights(self, which):
-        """[W3 | Wsc] (forward) / [W1^T ; Wsc^T] in dgrad layout (backward) from the prepared per-conv weights: a 6 MB device copy per
-        use, the prepared copies are refreshed by the optimizer's multi-tensor prep. One buffer (and one summed bias) PER HIP STREAM:
-        the Res5 forward runs the same head on two streams at once (rcnn.py forward plan) -- a shared buffer would be rewritten by one
-        stream while the other stream's GEMM reads it, and a bias filled on one stream could be read on the other before it is there."""
-        a, b = (self.conv3, self.shortcut) if which == "fwd" else (self.conv1, self.shortcut)
-        wa, wb = (a.wf, b.wf) if which == "fwd" else (a.wd, b.wd)
-        k = wa.shape[0]
-        sid = ops.raw_stream(wa.device.index) if wa.device.type == "cuda" else 0
-        bufs = self.__dict__.setdefault("_wcat_" + which, {})
-        buf = bufs.get(sid)
-        if buf is None or buf.dtype != wa.dtype or buf.device != wa.device:
-            buf = bufs[sid] = torch.empty((k, 1, 1, wa.shape[-1] + wb.shape[-1]), dtype=wa.dtype, device=wa.device)
-        torch.cat([wa.reshape(k, -1), wb.reshape(k, -1)], dim=1, out=buf.view(k, -1))
-        bias = None
-        if which == "fwd":
-            cache = self.__dict__.setdefault("_bcat", {})
-            ent = cache.get(sid)
-            if ent is None or ent[1] is not a.shift or ent[2] is not b.shift:
-                ent = cache[sid] = (a.shift + b.shift, a.shift, b.shift)
-            bias = ent[0]
-        return buf, bias
+        """-> ([W3 | Wsc], summed FrozenBN shift) forward, ([W1^T ; Wsc^T], None) backward: the persistent buffers of prepare_dual"""
+        self.prepare_dual()
+        buf = self.__dict__.get("_wcat_" + which)
+        assert buf is not None, "dual-input GEMM before the block's weights were prepared"
+        return buf, (self.__dict__["_bcat"] if which == "fwd" else None)
 
     def bwd(self, ctx, g, need_dx=True, mask_input=True):
         x, y1, y2, st, x_bits = ctx
@@ -251,7 +285,7 @@ class ResStage(nn.Sequential):
         blocks = [BottleneckBlock(cin if i == 0 else cout, cout, bottleneck, first_stride if i == 0 else 1) for i in range(num_blocks)]
         super().__init__(*blocks)
 
-    def fwd(self, x, save=False, first_stride=None, pool_rows=0, out_bits=False):
+    def fwd(self, x, save=False, first_stride=None, pool_rows=0, out_bits=False, pooled_out=None):
         """pool_rows / out_bits (Res5 heads, bf16): see BottleneckBlock.fwd -- the last block returns (pooled, bits) instead of its map;
         the blocks before it also leave a ReLU bit mask of their output for the next block's backward"""
         ctxs = []
@@ -259,7 +293,8 @@ class ResStage(nn.Sequential):
         for i, b in enumerate(self):
             last = i == len(self) - 1
             ob = out_bits and not last and ops.conv_ex_supported(x.dtype, b.conv3.cin, b.conv3.cout) and (i > 0 or (first_stride or b.stride) == 1)
-            x, c = b.fwd(x, save, stride=first_stride if i == 0 else None, pool_rows=pool_rows if last else 0, x_bits=x_bits, out_bits=ob)
+            x, c = b.fwd(x, save, stride=first_stride if i == 0 else None, pool_rows=pool_rows if last else 0, x_bits=x_bits, out_bits=ob,
+                         pooled_out=pooled_out if last else None)
             x_bits = None
             if ob:
                 x, x_bits = x
@@ -374,6 +409,7 @@ class LinearGroup:
         self.wf, self.wd = ops.weight_prep(w, None, self.kp, 1, 1, self.cin, self.cin, dtype, w_fwd=self.wf if self.wf is not None and self.wf.dtype == dtype else None,
                                            w_dgrad=self.wd if self.wd is not None and self.wd.dtype == dtype else None)
         self._prep_key = key
+        self._refresh_links()
 
     def fwd(self, x2d):
         """x [R,cin] -> fp32 [R,kp]"""

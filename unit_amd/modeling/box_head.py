@@ -38,9 +38,11 @@ class Res5BoxHead(nn.Module):
         for b in self.res5:
             for c in b.convs():
                 c.prepare(dtype, version, need_dgrad=True)
+            b.prepare_dual()          # concatenated weights of the first block's dual-input GEMMs (layers.BottleneckBlock.prepare_dual)
 
-    def fwd(self, pooled, save=False, keep_map=False):
+    def fwd(self, pooled, save=False, keep_map=False, feat_out=None):
         """pooled [R,14,14,C] (full) or [R,7,7,C] (strided) -> (mean-pooled features [R,2048], ctx).
+        feat_out: rows of a larger [*, 2048] matrix to write the features into (fused-pooling form only; otherwise ignored).
         ctx = (block contexts, res5 output map [R,7,7,2048]); `keep_map` keeps the map even without `save` (mask head input:
         Res5BoxHeadWithMask hands the un-pooled map to the mask head, roi_heads.py:691-710, and its mean to the predictor,
         roi_heads.py:735-744)."""
@@ -51,7 +53,7 @@ class Res5BoxHead(nn.Module):
             # the res5 map is consumed only by the mean (forward) and as a ReLU mask (backward): conv3's epilogue of the last block
             # emits the pooled features and one bit per element instead of the map (ctx[1] is then an ops.ReluBits)
             bins = (pooled.shape[1] // first_stride) * (pooled.shape[2] // first_stride)
-            (feat, bits), ctxs = self.res5.fwd(pooled, save=save, first_stride=first_stride, pool_rows=bins, out_bits=save)
+            (feat, bits), ctxs = self.res5.fwd(pooled, save=save, first_stride=first_stride, pool_rows=bins, out_bits=save, pooled_out=feat_out)
             return feat, ((ctxs, bits) if save else None)
         y, ctxs = self.res5.fwd(pooled, save=save, first_stride=first_stride)
         return ops.global_avgpool(y), ((ctxs, y) if (save or keep_map) else None)

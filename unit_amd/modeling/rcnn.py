@@ -300,7 +300,7 @@ class WeaklySupervisedRCNNNoMeta(nn.Module):
         n_sup, n_weak = batch.n_sup, batch.n_weak
         n_img = n_sup + n_weak
         c.n_sup, c.n_weak = n_sup, n_weak
-        c.losses = torch.zeros(len(LOSS_NAMES), dtype=torch.float32, device=self.device)
+        c.losses = ops.zeros(len(LOSS_NAMES), torch.float32, self.device)
 
         # a1 preprocess + a2 backbone. The reference runs the backbone once per batch (rcnn.py:439 supervised, :452 weak), each
         # batch zero-padded to ITS OWN largest image (ImageList.from_tensors). When both batches pad to the same size (always
@@ -366,10 +366,10 @@ class WeaklySupervisedRCNNNoMeta(nn.Module):
             self._reattach_grads()
             main, s2 = torch.cuda.current_stream(), self._rpn_stream
             s2.wait_stream(main)
-            for t in (head, feat, anchors, perms["rpn"]) + tuple(c.rpn_ctx):
+            for t in (head, feat, anchors, perms["rpn"], c.losses) + tuple(c.rpn_ctx):
                 t.record_stream(s2)
             with torch.cuda.stream(s2):
-                c.rpn_losses = torch.zeros(2, dtype=torch.float32, device=self.device)   # folded into c.losses at the join
+                c.rpn_losses = c.losses[6:8]          # the branch writes its two slots of the loss vector itself; nobody else touches them
                 rpn_branch()
                 c.drpn = rpn.rpn_head.bwd(c.rpn_ctx, c.dhead, n_sup)
             c.rpn_bwd_early = True
@@ -391,17 +391,15 @@ class WeaklySupervisedRCNNNoMeta(nn.Module):
 
         # a7 RoI sampling (supervised) + first-512 weak proposals ; a8 RoIAlign on all RoIs at once
         s = rh.batch_size_per_image
-        rois, c.roi_cls, c.roi_gt = [], None, None
+        c.roi_cls, c.roi_gt = None, None
+        rs, rw = n_sup * s, n_weak * (s // rh.weak_divisor)
+        c.rois = torch.empty((rs + rw, 5), dtype=torch.float32, device=self.device)          # supervised RoIs, then weak: both samplers write their rows
         if n_sup > 0:
-            r5, c.roi_cls, c.roi_gt, c.roi_counts = rh.label_and_sample_proposals(props[:n_sup], pcount[:n_sup], batch.gt_boxes,
-                                                                                  batch.gt_classes, batch.gt_count, perms["roi"])
-            rois.append(r5)
+            _, c.roi_cls, c.roi_gt, c.roi_counts = rh.label_and_sample_proposals(props[:n_sup], pcount[:n_sup], batch.gt_boxes,
+                                                                                 batch.gt_classes, batch.gt_count, perms["roi"],
+                                                                                 rois_out=c.rois[:rs])
         if n_weak > 0:
-            rw5, c.weak_valid = rh.weak_rois(props[n_sup:], pcount[n_sup:], n_sup)
-            rois.append(rw5)
-        c.rois = torch.cat(rois, 0) if len(rois) > 1 else rois[0]
-        rs = n_sup * s
-        rw = c.rois.shape[0] - rs
+            _, c.weak_valid = rh.weak_rois(props[n_sup:], pcount[n_sup:], n_sup, rois_out=c.rois[rs:])
         c.rs, c.rw = rs, rw
         if not split:
             pooled = rh.pool(feat, c.rois)
@@ -434,12 +432,16 @@ class WeaklySupervisedRCNNNoMeta(nn.Module):
                     s3 = self._wgrad_stream              # idle during the forward plan
                     s3.wait_stream(main)
                     pooled.record_stream(s3)
+                    # both chains write their rows of ONE feature matrix (no concatenation afterwards)
+                    wfeat_all = torch.empty((rs + rw, rh.weak_box_head.out_channels), dtype=pooled.dtype, device=pooled.device)
+                    wfeat_all.record_stream(s3)
                     with torch.cuda.stream(s3):
-                        f_sup, _ = rh.weak_box_head.fwd(pooled[:rs], save=False)
-                    f_weak, c.weak_ctx = rh.weak_box_head.fwd(pooled[rs:], save=True)
+                        f_sup, _ = rh.weak_box_head.fwd(pooled[:rs], save=False, feat_out=wfeat_all[:rs])
+                    f_weak, c.weak_ctx = rh.weak_box_head.fwd(pooled[rs:], save=True, feat_out=wfeat_all[rs:])
                     main.wait_stream(s3)
-                    f_sup.record_stream(main)
-                    wfeat_all = torch.cat([f_sup, f_weak], 0)
+                    if f_sup.data_ptr() != wfeat_all.data_ptr() or f_weak.data_ptr() != wfeat_all[rs:].data_ptr():
+                        f_sup.record_stream(main)          # (a head form without the fused pooling epilogue returned its own buffers)
+                        wfeat_all = torch.cat([f_sup, f_weak], 0)
                     c.weak_ctx_rows = None               # the context covers exactly the weak RoIs
                 else:
                     wfeat_all, c.weak_ctx = rh.weak_box_head.fwd(pooled, save=(rw > 0))
@@ -639,7 +641,7 @@ class WeaklySupervisedRCNNNoMeta(nn.Module):
             drpn = c.drpn
             drpn.record_stream(torch.cuda.current_stream())
             c.rpn_losses.record_stream(torch.cuda.current_stream())
-            c.losses[6:8] += c.rpn_losses                                  # the branch's loss_rpn_cls / loss_rpn_loc
+            # (the branch wrote loss_rpn_cls / loss_rpn_loc into its slots of c.losses)
             done("rpn")
         elif c.dhead is not None and any(p.requires_grad for p in rpn.rpn_head.parameters()):
             drpn = rpn.rpn_head.bwd(c.rpn_ctx, c.dhead, n_sup)
@@ -652,7 +654,7 @@ class WeaklySupervisedRCNNNoMeta(nn.Module):
                 if dp is not None:
                     rh.pool_bwd_gather(dp, n_im, ft.shape[1], ft.shape[2], c.rois[r_lo:r_hi], out, image_offset=img0, addend=add, mask_ref=ft)
                 else:
-                    ops.add_cast(torch.zeros(ft.shape, dtype=torch.float32, device=ft.device), add, dt, mask_ref=ft, out=out)
+                    ops.add_cast(ops.zeros(ft.shape, torch.float32, ft.device), add, dt, mask_ref=ft, out=out)
                 return out
 
             if not getattr(c, "split", False):
@@ -665,7 +667,7 @@ class WeaklySupervisedRCNNNoMeta(nn.Module):
                         rh.pool_bwd_gather(dp, hi - lo, fh, fw, c.rois[r_lo:r_hi], g[lo:hi], image_offset=lo, addend=add,
                                            mask_ref=feat[lo:hi])
                     else:
-                        z = torch.zeros(feat[lo:hi].shape, dtype=torch.float32, device=feat.device)
+                        z = ops.zeros(feat[lo:hi].shape, torch.float32, feat.device)
                         ops.add_cast(z, add, dt, mask_ref=feat[lo:hi], out=g[lo:hi])
                 self.backbone.bwd(c.bb_ctx, g, on_stage_done=done)
             else:

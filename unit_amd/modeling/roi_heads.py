@@ -78,7 +78,7 @@ class WSROIHeadNoMeta(nn.Module):
         return (7, 2) if self.pool_mode == "strided" else (self.pooler_resolution, 1)
 
     # ---- a7: ROIHeads.label_and_sample_proposals (roi_heads.py:563), device-resident counts
-    def label_and_sample_proposals(self, props, pcount, gt_boxes, gt_classes, gt_count, perm):
+    def label_and_sample_proposals(self, props, pcount, gt_boxes, gt_classes, gt_count, perm, rois_out=None):
         """props [B,P,4], pcount [B]; gt_* padded [B,Mcap,..]; perm [B, >= P+Mcap] int32.
         -> rois5 [B*S,5], roi_cls int32 [B*S] (-1 = empty slot), roi_gt [B*S,4], counts [B,2]"""
         if self.proposal_append_gt:
@@ -89,13 +89,13 @@ class WSROIHeadNoMeta(nn.Module):
         cls = ops.roi_classes(idx, lab, cc, gt_classes, gt_count, self.num_classes)
         _, sidx, counts = ops.subsample_labels(cls, cc, perm, self.batch_size_per_image, self.positive_fraction, self.num_classes,
                                                want_labels=False)
-        rois5, roi_cls, roi_gt = ops.gather_rois(cat, sidx, cls, idx, gt_boxes, gt_count)
+        rois5, roi_cls, roi_gt = ops.gather_rois(cat, sidx, cls, idx, gt_boxes, gt_count, rois_out=rois_out)
         self._last_sampling = (sidx, idx)        # mask head: gt_masks[matched_idx[sampled]] (select + crop_and_resize)
         return rois5, roi_cls, roi_gt, counts
 
     # ---- roi_heads.py:566-572: the first 512//divisor RPN outputs of every weak image, no GT, no sampling
-    def weak_rois(self, props, pcount, batch_index_offset):
-        return ops.first_k_rois(props, pcount, self.batch_size_per_image // self.weak_divisor, batch_index_offset)
+    def weak_rois(self, props, pcount, batch_index_offset, rois_out=None):
+        return ops.first_k_rois(props, pcount, self.batch_size_per_image // self.weak_divisor, batch_index_offset, rois_out=rois_out)
 
     def pool(self, feat, rois5, out=None):
         osz, step = self.pool_out

@@ -18,7 +18,7 @@ _NO_BIAS_CONVS = bool(int(os.environ.get("UNIT_PLAN_NO_BIAS_CONVS", "0")))      
 class TensorDesc(ctypes.Structure):
     _fields_ = [("partial", ctypes.c_void_p), ("scale", ctypes.c_void_p), ("wf", ctypes.c_void_p), ("wd", ctypes.c_void_p),
                 ("offset", ctypes.c_long), ("splits", ctypes.c_int), ("K", ctypes.c_int), ("R", ctypes.c_int), ("S", ctypes.c_int),
-                ("C", ctypes.c_int), ("block0", ctypes.c_int)]
+                ("C", ctypes.c_int), ("block0", ctypes.c_int), ("ldwf", ctypes.c_int), ("ldwd", ctypes.c_int)]
 
 
 class ConvPlan:
@@ -61,17 +61,26 @@ class ConvPlan:
         self._deferred = []                 # (conv, x, dy, stride, accumulate, raw stream that produced x / dy)
 
     def _build(self, convs, with_partial, entries=None):
-        """entries (reduce tables): [(conv, slab tensor, signed splits)]; splits < 0 = accumulate onto the gradient"""
-        descs = (TensorDesc * len(convs))()
-        b0 = 0
+        """entries (reduce tables): [(conv, slab tensor, signed splits)]; splits < 0 = accumulate onto the gradient.
+        Weight-prep tables (with_partial False) carry one more descriptor per linked copy of a conv (Conv2d.link_copy: a pitched view
+        into a concatenated GEMM weight): same source parameters, that destination, its row pitch."""
+        rows = []          # (conv, slab, splits, wf ptr, wd ptr, ldwf, ldwd)
         for i, m in enumerate(convs):
+            slab, splits = (entries[i][1], entries[i][2]) if entries is not None else (m._slab, m._splits)
+            rows.append((m, slab, splits, m.wf.data_ptr() if m.wf is not None else None, m.wd.data_ptr() if m.wd is not None else None, 0, 0))
+            if not with_partial:
+                for kind, dst in m._links:
+                    assert dst.stride(1) == 1 and dst.dtype == (m.wf if kind == "wf" else m.wd).dtype
+                    rows.append((m, None, 0, dst.data_ptr() if kind == "wf" else None, dst.data_ptr() if kind == "wd" else None,
+                                 dst.stride(0) if kind == "wf" else 0, dst.stride(0) if kind == "wd" else 0))
+        descs = (TensorDesc * len(rows))()
+        b0 = 0
+        for i, (m, slab, splits, wf, wd, ldwf, ldwd) in enumerate(rows):
             kk = m.cout * m.k * m.k * m.cin
             d = descs[i]
-            slab, splits = (entries[i][1], entries[i][2]) if entries is not None else (m._slab, m._splits)
             d.partial = slab.data_ptr() if (with_partial and slab is not None) else None
             d.scale = m.scale.data_ptr() if m.scale is not None else None
-            d.wf = m.wf.data_ptr() if m.wf is not None else None
-            d.wd = m.wd.data_ptr() if m.wd is not None else None
+            d.wf, d.wd, d.ldwf, d.ldwd = wf, wd, ldwf, ldwd
             d.offset = m._flat_offset
             d.splits, d.K, d.R, d.S, d.C, d.block0 = splits, m.cout, m.k, m.k, m.cin, b0
             if with_partial:
@@ -79,7 +88,7 @@ class ConvPlan:
             else:   # weight prep: one workgroup per 32 (k) x 32 (c) tile of each (r, s) tap (csrc/multi.hip)
                 b0 += ((m.cout + 31) // 32) * ((m.cin + 31) // 32) * m.k * m.k
         host = torch.frombuffer(bytearray(bytes(descs)), dtype=torch.uint8)
-        return host.to(self.model.device), len(convs), b0
+        return host.to(self.model.device), len(rows), b0
 
     def note_wgrad(self, conv, slab=None, splits=None, accumulate=False):
         """called right after a conv's split-M slabs were enqueued on the current stream. accumulate: the slabs hold a SECOND
@@ -163,7 +172,7 @@ class ConvPlan:
         convs = [m for m in self.convs if m.wf is not None and m.wf.dtype == dtype and m.wd is not None]
         if len(convs) != len(self.convs):
             return False           # first step: the per-layer prepare() path allocates the copies
-        sig = tuple((m.wf.data_ptr(), m.wd.data_ptr()) for m in convs)
+        sig = tuple((m.wf.data_ptr(), m.wd.data_ptr()) + tuple(d.data_ptr() for _, d in m._links) for m in convs)
         if self._prep_table is None or self._prep_table[3] != sig:
             dev, n, blocks = self._build(convs, False)
             self._prep_table = (dev, n, blocks, sig)

@@ -280,6 +280,13 @@ def nhwc_to_nchw(x, c=None):
     return y
 
 
+def zeros(shape, dtype, device):
+    """torch.zeros by the library's own fill kernel (unit_fill_zero): the step launches no stock fill"""
+    t = torch.empty(shape, dtype=dtype, device=device)
+    check(lib().unit_fill_zero(_p(t), t.numel() * t.element_size(), _s()), "fill_zero")
+    return t
+
+
 def cast(x, dtype):
     y = torch.empty(x.shape, dtype=dtype, device=x.device)
     check(lib().unit_cast(_p(x.contiguous()), dt(x.dtype), _p(y), dt(dtype), x.numel(), _s()), "cast")
@@ -323,7 +330,7 @@ def conv2d(x, w, k, r, s, stride=1, pad=0, bias=None, residual=None, mask_ref=No
         oy_mul, ohf, owf = scatter
     if out is None:
         if scatter is not None:
-            out = torch.zeros((n, ohf, owf, ldy), dtype=out_dtype, device=x.device)
+            out = zeros((n, ohf, owf, ldy), out_dtype, x.device)
         else:
             out = torch.empty((n, ohf, owf, ldy), dtype=out_dtype, device=x.device)
     prof = PROFILER
@@ -417,7 +424,8 @@ class ReluBits:
         return ((byte.int() >> (n & 7)) & 1).bool().view(self.r, self.bins, self.c)
 
 
-def conv2d_ex(x, w, k, r, s, pad=0, bias=None, residual=None, relu=False, mask_bits=None, want_bits=False, pool_rows=0, want_y=True, x2=None, variant=0):
+def conv2d_ex(x, w, k, r, s, pad=0, bias=None, residual=None, relu=False, mask_bits=None, want_bits=False, pool_rows=0, want_y=True, x2=None, variant=0,
+              pooled_out=None):
     """stride-1 bf16 conv on the 256x256 kernel with the extended epilogue (unit_conv2d_fwd_big_ex): returns (y | None, ReluBits |
     None, pooled [N, k] | None). pool_rows: must be OH*OW -- global average pool of each image (= RoI) fused; want_y=False then
     skips writing the map. mask_bits: ReluBits of an [N, OH*OW, k] map (RoI offset 0). x2 [N,H,W,C2]: second input of a 1x1 conv over
@@ -458,7 +466,8 @@ def conv2d_ex(x, w, k, r, s, pad=0, bias=None, residual=None, relu=False, mask_b
         prof.setdefault("conv_igemm256", []).append((e0, e1, 2.0 * m * k * r * s * (c + c2), nbytes))
     pooled = None
     if pool_rows:
-        pooled = torch.empty((n, k), dtype=x.dtype, device=x.device)
+        pooled = pooled_out if pooled_out is not None else torch.empty((n, k), dtype=x.dtype, device=x.device)
+        assert pooled.shape == (n, k) and pooled.is_contiguous() and pooled.dtype == x.dtype
         check(lib().unit_pool_finish(_p(part), n, pool_rows, ldy, k, _p(pooled), k, dt(x.dtype), _s()), "unit_pool_finish")
     return y, bits, pooled
 
@@ -795,11 +804,13 @@ def roi_classes(match_idx, match_label, count, gt_classes, gcount, k):
     return cls
 
 
-def gather_rois(cat, sampled_idx, cls, match_idx, gt, gcount):
+def gather_rois(cat, sampled_idx, cls, match_idx, gt, gcount, rois_out=None):
+    """rois_out: [b * s, 5] fp32 rows of a larger buffer to write the RoIs into (the step keeps supervised and weak RoIs in one tensor)"""
     b, ncap = cat.shape[0], cat.shape[1]
     s = sampled_idx.shape[1]
     dev = cat.device
-    rois = torch.empty((b * s, 5), dtype=torch.float32, device=dev)
+    rois = rois_out if rois_out is not None else torch.empty((b * s, 5), dtype=torch.float32, device=dev)
+    assert rois.shape == (b * s, 5) and rois.is_contiguous()
     rcls = torch.empty((b * s,), dtype=torch.int32, device=dev)
     rgt = torch.empty((b * s, 4), dtype=torch.float32, device=dev)
     check(lib().unit_gather_rois(_p(cat), ncap, _p(sampled_idx), s, _p(cls), _p(match_idx), _p(gt), _p(gcount), gt.shape[1], b,
@@ -807,9 +818,10 @@ def gather_rois(cat, sampled_idx, cls, match_idx, gt, gcount):
     return rois, rcls, rgt
 
 
-def first_k_rois(props, pcount, s, batch_index_offset=0):
+def first_k_rois(props, pcount, s, batch_index_offset=0, rois_out=None):
     b, pcap = props.shape[0], props.shape[1]
-    rois = torch.empty((b * s, 5), dtype=torch.float32, device=props.device)
+    rois = rois_out if rois_out is not None else torch.empty((b * s, 5), dtype=torch.float32, device=props.device)
+    assert rois.shape == (b * s, 5) and rois.is_contiguous()
     valid = torch.empty((b * s,), dtype=torch.int32, device=props.device)
     check(lib().unit_first_k_rois(_p(props), _p(pcount), pcap, s, b, batch_index_offset, _p(rois), _p(valid), _s()), "first_k_rois")
     return rois, valid
