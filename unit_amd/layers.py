@@ -409,7 +409,6 @@ class LinearGroup:
         self.wf, self.wd = ops.weight_prep(w, None, self.kp, 1, 1, self.cin, self.cin, dtype, w_fwd=self.wf if self.wf is not None and self.wf.dtype == dtype else None,
                                            w_dgrad=self.wd if self.wd is not None and self.wd.dtype == dtype else None)
         self._prep_key = key
-        self._refresh_links()
 
     def fwd(self, x2d):
         """x [R,cin] -> fp32 [R,kp]"""
