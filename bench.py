@@ -25,6 +25,8 @@ sys.path.insert(0, ROOT)
 STEP_TFLOP = {("s1", 101): 12.70, ("s1", 50): 11.61, ("s0", 101): 5.69}
 MFMA_PEAK_TFLOPS = 2500.0   # dense bf16, MI355X_MICROARCH.md (never the 2:1-sparse figure)
 HBM_PEAK_GBS = 8000.0       # HBM3E spec, same guide (6.3 TB/s is what a float4 copy reaches)
+FEED_B_PER_CLK = 27.0       # bytes per clock a CU takes in by LDS-DMA inside a conv loop (8 rows x 128 B pieces beside MFMAs and fragment reads:
+FEED_CLOCK_HZ = 2.1e9       # tools/feed_matrix.hip "conv-like" rows, profiles/r04_exp_feed_matrix.txt), at the clock the chip holds on those loops
 
 
 def parse():
@@ -281,8 +283,27 @@ def voc_shapes_run(args, cfg, model, buckets, opt, rank, world, dev):
                                "allocator_retries": mem1.get("num_alloc_retries", 0) - mem0.get("num_alloc_retries", 0),
                                "reserved_gb": round(mem1.get("reserved_bytes.all.peak", 0) / 2 ** 30, 2),
                                "graph": ({k: gs.stats[k] - gstat0[k] for k in gs.stats} if gs else None)}}
-        print(json.dumps(out), flush=True)
+        emit(json.dumps(out))
     return 0
+
+
+_RESULT = None          # the process's ORIGINAL stdout, kept for the one result line (claim_stdout)
+
+
+def claim_stdout():
+    """stdout carries exactly one JSON line. RCCL prints a version banner and its warnings to file descriptor 1 (at communicator creation and
+    again at teardown, i.e. after the result line), so the descriptor is duplicated for the result and fd 1 itself is pointed at stderr
+    before any library is initialised: whatever a library writes to "stdout" from then on lands in stderr."""
+    global _RESULT
+    if _RESULT is None:
+        sys.stdout.flush()
+        _RESULT = os.fdopen(os.dup(1), "w")
+        os.dup2(2, 1)
+
+
+def emit(line):
+    (_RESULT or sys.stdout).write(line + "\n")
+    (_RESULT or sys.stdout).flush()
 
 
 def _trace(msg):
@@ -303,9 +324,10 @@ def main():
         print(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks; refusing to print a line whose n_gpus is not "
               "what was asked for", file=sys.stderr)
         return 2
+    claim_stdout()
     if args.dry_launch:
         keys = ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "HSA_ENABLE_IPC_MODE_LEGACY")
-        print("DRY_LAUNCH " + json.dumps({k: os.environ.get(k) for k in keys}), flush=True)
+        emit("DRY_LAUNCH " + json.dumps({k: os.environ.get(k) for k in keys}))
         if os.environ.get("UNIT_DRY_FAIL_RANK") == str(rank):          # launcher self-test: one rank dies, the others hang in a "collective"
             return 3
         if os.environ.get("UNIT_DRY_FAIL_RANK") is not None:
@@ -325,10 +347,17 @@ def main():
         if world == 1:
             os.environ.setdefault("MASTER_PORT", str(_free_port()))
         torch.cuda.set_device(local_rank)
-        if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-        else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
+        for attempt in range(3):
+            try:
+                if backend == "nccl":
+                    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+                else:
+                    dist.init_process_group(backend, rank=rank, world_size=world)
+                break
+            except Exception as e:          # noqa: a port this process probed free a moment ago can be taken when the store binds it
+                if world > 1 or attempt == 2 or "EADDRINUSE" not in str(e):
+                    raise
+                os.environ["MASTER_PORT"] = str(_free_port())
         _trace("process group initialised")
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
@@ -537,6 +566,23 @@ def main():
                         "reference_equivalent_gbs": round(ref / us / 1e3, 1) if ref else None}
             out["roofline"]["hbm_kernels"] = {"peak_gbs": HBM_PEAK_GBS, "roi_align_fwd": hbm(prof, "roi_align_fwd", "roi_align_fwd"),
                                               "roi_align_bwd_gather": hbm(prof, "roi_align_bwd_gather", "roi_align_bwd_gather")}
+            # backbone convs (north_star: >= 60 % MFMA): achieved fraction of the dense bf16 peak over every forward / dgrad launch of the
+            # backbone + RPN-dgrad family (loader / consumer and 4-wave LDS-DMA kernels), and the CEILING the per-CU operand feed puts on it:
+            # a launch cannot end before its busiest CU has staged its tiles' operand bytes -- tiles per CU x k-steps x (BM + BN) x 128 B --
+            # at the rate a CU takes LDS-DMA bytes in inside a conv loop (FEED_B_PER_CLK, tools/feed_matrix.hip)
+            bb = prof.get("conv_igemm_dma") or []
+            if bb:
+                t_meas = sum(e[0].elapsed_time(e[1]) for e in bb) * 1e-3
+                fl = sum(e[2] for e in bb)
+                t_mfma = [e[2] / (MFMA_PEAK_TFLOPS * 1e12) for e in bb]
+                t_feed = [(e[4] or 0.0) / (FEED_B_PER_CLK * FEED_CLOCK_HZ) for e in bb]
+                out["roofline"]["backbone"] = {
+                    "launches_per_step": len(bb) // args.steps, "ms_per_step_single_stream": round(t_meas / args.steps * 1e3, 3),
+                    "backbone_frac": round(fl / t_meas / 1e12 / MFMA_PEAK_TFLOPS, 4),
+                    "backbone_ceiling": round(sum(t_mfma) / sum(max(a, b) for a, b in zip(t_mfma, t_feed)), 4),
+                    "ceiling_ms_per_step": round(sum(max(a, b) for a, b in zip(t_mfma, t_feed)) / args.steps * 1e3, 3),
+                    "feed_model": f"{FEED_B_PER_CLK} B/clk/CU at {FEED_CLOCK_HZ / 1e9:.1f} GHz through LDS-DMA inside a conv loop; ceiling = sum of MFMA-peak times / "
+                                  "sum of max(MFMA-peak time, busiest CU's staged bytes / feed rate) over the family's launches"}
             out["roofline"]["latency_kernels_us"] = {k2: round(sum(e[0].elapsed_time(e[1]) for e in prof[k2]) / len(prof[k2]) * 1e3, 1)
                                                      for k2 in ("sort_topk", "nms") if prof.get(k2)}
             if prof_insitu:
@@ -559,7 +605,7 @@ def main():
             except subprocess.TimeoutExpired:
                 out["cpu_baseline"] = {"error": "oracle sample exceeded the 240 s bound on this host"}
         _trace("printing the line")
-        print(json.dumps(out), flush=True)
+        emit(json.dumps(out))
     if dist.is_initialized():
         dist.destroy_process_group()
     _trace("done")

@@ -86,16 +86,28 @@ struct EpiExtra {
 #ifndef UNIT_EPI_NT
 #define UNIT_EPI_NT 2
 #endif
+// diagnostic builds only (tools/epi_issue.sh): bit 0 = the residual / mask loads come from registers instead of memory, bit 1 = the output
+// stores are issued only for a value that never occurs -- what is left is the epilogue's INSTRUCTION time (LDS round trip + VALU).
+#ifndef UNIT_EPI_DBG
+#define UNIT_EPI_DBG 0
+#endif
 typedef __attribute__((ext_vector_type(4))) int epi_i32x4;
 __device__ __forceinline__ bf16x8 epi_load8(const bf16_t* q) {
-#if UNIT_EPI_NT == 1 || UNIT_EPI_NT == 2
+#if UNIT_EPI_DBG & 1
+  bf16x8 v;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) v[j] = (bf16_t)(float)(((uintptr_t)q >> (4 + j)) & 3);
+  return v;
+#elif UNIT_EPI_NT == 1 || UNIT_EPI_NT == 2
   return __builtin_bit_cast(bf16x8, __builtin_nontemporal_load(reinterpret_cast<const epi_i32x4*>(q)));
 #else
   return *reinterpret_cast<const bf16x8*>(q);
 #endif
 }
 __device__ __forceinline__ void epi_store8(bf16_t* q, bf16x8 v) {
-#if UNIT_EPI_NT == 1 || UNIT_EPI_NT == 3
+#if UNIT_EPI_DBG & 2
+  if (__builtin_bit_cast(epi_i32x4, v)[0] == 0x7fc17fc3) *reinterpret_cast<bf16x8*>(q) = v;
+#elif UNIT_EPI_NT == 1 || UNIT_EPI_NT == 3
   __builtin_nontemporal_store(__builtin_bit_cast(epi_i32x4, v), reinterpret_cast<epi_i32x4*>(q));
 #else
   *reinterpret_cast<bf16x8*>(q) = v;

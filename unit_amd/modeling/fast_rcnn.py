@@ -72,7 +72,7 @@ class WeakDetectorOutputsBase(nn.Module):
         which are forward outputs: with `side_stream` they run beside the (single-workgroup-per-image, latency-bound) MIL
         kernel instead of behind it. Every launch writes its own columns of dy / its own loss slot."""
         k = self.num_classes
-        dy = torch.zeros((lin.shape[0], self.group.kp), dtype=grad_dtype, device=lin.device)
+        dy = ops.zeros((lin.shape[0], self.group.kp), grad_dtype, lin.device)
 
         def oicr(it, xr):
             if it == 0:
@@ -220,7 +220,7 @@ class SupervisedDetectorOutputsBase(nn.Module):
         k = self.num_classes
         wh = self.weak_detector_head
         scores = ops.sup_scores(lin_sup, self.col_cls, lin_sup_weak, wh.col_oicr[0], wh.oicr_iter, k + 1, self._novel_mask)
-        dy = torch.zeros((lin_sup.shape[0], self.group.kp), dtype=grad_dtype, device=lin_sup.device)
+        dy = ops.zeros((lin_sup.shape[0], self.group.kp), grad_dtype, lin_sup.device)
         ops.softmax_ce(scores, 0, k + 1, roi_cls, dy=dy, dcol0=self.col_cls, loss_out=loss_out[0:1])
         ops.box_reg_loss(lin_sup, self.col_bbox, k, roi_cls, rois5, roi_gt, self.bbox_reg_weights, dy=dy, dcol0=self.col_bbox,
                          loss_out=loss_out[1:2])
@@ -344,7 +344,7 @@ class SupervisedDetectorOutputsFineTune(SupervisedDetectorOutputsBase):
     def ft_losses(self, scores, bbox, roi_cls, rois5, roi_gt, loss_out, grad_dtype):
         """d(loss)/d(scores|bbox) == d(loss)/d([cls_score_ft | bbox_pred_ft] outputs): the ft heads enter additively."""
         k = self.num_classes
-        dy = torch.zeros((scores.shape[0], self.group_ft.kp), dtype=grad_dtype, device=scores.device)
+        dy = ops.zeros((scores.shape[0], self.group_ft.kp), grad_dtype, scores.device)
         ops.softmax_ce(scores, 0, k + 1, roi_cls, dy=dy, dcol0=self.col_cls, loss_out=loss_out[0:1])
         ops.box_reg_loss(bbox, 0, k, roi_cls, rois5, roi_gt, self.bbox_reg_weights, dy=dy, dcol0=self.col_bbox, loss_out=loss_out[1:2])
         return dy

@@ -407,9 +407,7 @@ class WeaklySupervisedRCNNNoMeta(nn.Module):
             osz = rh.pool_out[0]
             pooled = torch.empty((rs + rw, osz, osz, fc), dtype=feat.dtype, device=feat.device)
             rh.pool(feat, c.rois[:rs], out=pooled[:rs])
-            rois_w = c.rois[rs:].clone()
-            rois_w[:, 0] -= n_sup
-            rh.pool(feat_w, rois_w, out=pooled[rs:])
+            rh.pool(feat_w, c.rois[rs:], out=pooled[rs:], image_offset=n_sup)          # (the RoIs' batch indices count from the supervised images)
 
         # a9 Res5 heads: box_head on the supervised RoIs (grad); weak_box_head on ALL RoIs in one pass -- its supervised
         # half is the reference's no_grad evaluation (roi_heads.py:502-504), its weak half has grad (:512-513)

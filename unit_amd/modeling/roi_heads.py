@@ -97,9 +97,10 @@ class WSROIHeadNoMeta(nn.Module):
     def weak_rois(self, props, pcount, batch_index_offset, rois_out=None):
         return ops.first_k_rois(props, pcount, self.batch_size_per_image // self.weak_divisor, batch_index_offset, rois_out=rois_out)
 
-    def pool(self, feat, rois5, out=None):
+    def pool(self, feat, rois5, out=None, image_offset=0):
         osz, step = self.pool_out
-        return ops.roi_align(feat, rois5, self.pooler_resolution, osz, step, self.pooler_scale, self.sampling_ratio, True, out=out)
+        return ops.roi_align(feat, rois5, self.pooler_resolution, osz, step, self.pooler_scale, self.sampling_ratio, True, out=out,
+                             image_offset=image_offset)
 
     def pool_bwd(self, dpooled, feat_shape, rois5, dfeat32):
         _, step = self.pool_out

@@ -107,6 +107,15 @@ _NO_LC = bool(int(os.environ.get("UNIT_NO_LC", "0")))      # A/B switch: 1 = nev
 _MID96 = int(os.environ.get("UNIT_MID96", "0"))      # 0: off; 1: 96x128 tiles where tools/mid_sweep.py found them faster in isolation; 2: only the two-per-CU form
 
 
+def mid_tile_dims(mid):
+    """(BM pixels, BN channels) of a `mid` tile code: 0..5 = the 4-wave LDS-DMA tiles, 100 + 10 * (BM / 16) + BN / 64 = loader / consumer tiles
+    (+ 2000: their two-workgroups-per-CU form)"""
+    code = mid - 2000 if mid >= 2000 else mid
+    if code >= 100:
+        return (code - 100) // 10 * 16, (code % 10) * 64
+    return {0: (128, 128), 1: (64, 128), 2: (128, 64), 3: (64, 128), 4: (96, 128), 5: (96, 128)}[code]
+
+
 def lc_tile_code(m, k, kgemm):
     """tile of the persistent loader / consumer kernel (csrc/conv_igemm_lc.hip) for an [m pixels] x [k channels] x [kgemm] layer:
     100 + 10 * (BM / 16) + BN / 64. A workgroup's time is its tiles x k-steps x the (BM + BN) * 128 bytes a k-step stages (the CU's
@@ -379,8 +388,13 @@ def conv2d(x, w, k, r, s, stride=1, pad=0, bias=None, residual=None, mask_ref=No
         e1.record()
         es = out.element_size()
         nbytes = (x.numel() + w.numel()) * x.element_size() + n * oh * ow * ldy * es * (1 + (residual is not None) + (mask_ref is not None))
+        feed = None
+        if mid >= 0:          # operand bytes the busiest CU stages into LDS (feed-bound ceiling of the backbone layers, bench.py backbone_ceiling)
+            bm, bn = mid_tile_dims(mid)
+            tiles = ((n * oh * ow + bm - 1) // bm) * ((k + bn - 1) // bn)
+            feed = ((tiles + 255) // 256) * (r * s * c // 64) * (bm + bn) * 128.0
         prof.setdefault("conv_igemm256" if (big and mid < 0) else ("conv_igemm_dma" if mid >= 0 else "conv_igemm"), []).append(
-            (e0, e1, 2.0 * n * oh * ow * k * r * s * c, nbytes))
+            (e0, e1, 2.0 * n * oh * ow * k * r * s * c, nbytes, feed))
     return out
 
 
@@ -829,7 +843,9 @@ def first_k_rois(props, pcount, s, batch_index_offset=0, rois_out=None):
 
 # ------------------------------------------------------------------------------------------------ a8
 def roi_align(feat, rois, pooled_size=14, out_size=None, bin_step=1, spatial_scale=1.0 / 16, sampling_ratio=0, aligned=True,
-              roi_count=None, out=None):
+              roi_count=None, out=None, image_offset=0):
+    """image_offset: the RoIs' batch indices count from `image_offset` (feat[0] is image `image_offset` of the step's batch: the weak images
+    of a two-pass step). The kernel addresses image b at base + b * H * W * C, so the base handed over is moved back by that many images."""
     n, h, w, c = feat.shape
     r = rois.shape[0]
     out_size = out_size or pooled_size
@@ -840,7 +856,9 @@ def roi_align(feat, rois, pooled_size=14, out_size=None, bin_step=1, spatial_sca
     # ref_bytes: what the reference's ROIAlignV2 call moves for the same RoIs -- the full pooled_size x pooled_size grid (roi_heads.py:499:
     # 14 x 14), of which the strided mode materialises only the bins Res5's stride-2 1x1 convs read
     with _timed("roi_align_fwd", 0.0, (feat.numel() + r * out_size * out_size * c) * es, (feat.numel() + r * pooled_size * pooled_size * c) * es):
-        check(lib().unit_roi_align_fwd(_p(feat), dt(feat.dtype), n, h, w, c, _p(rois), _p(roi_count), r, pooled_size, out_size, bin_step,
+        _p(feat)
+        base = ctypes.c_void_p(feat.data_ptr() - image_offset * h * w * c * es)
+        check(lib().unit_roi_align_fwd(base, dt(feat.dtype), n + image_offset, h, w, c, _p(rois), _p(roi_count), r, pooled_size, out_size, bin_step,
                                        float(spatial_scale), sampling_ratio, int(aligned), _p(out), _s()), "roi_align_fwd")
     return out
 
