@@ -578,3 +578,48 @@ def test_s1_step_with_an_image_without_gt_fp32(dev):
     name = "backbone.res4.0.conv1.weight"
     g, gr = dict(model.named_parameters())[name].grad.cpu(), p[name].grad
     assert (g - gr).abs().max() <= 2e-3 * gr.abs().max() + 1e-7
+
+
+def test_dual_gemm_weight_concatenations_follow_the_optimizer(dev):
+    """The first Res5 block's dual-input GEMMs read [W3 | Wsc] and [W1^T ; Wsc^T] from PERSISTENT buffers that the two convs of each pair
+    link as pitched views (layers.BottleneckBlock.prepare_dual): the optimizer's multi-tensor weight-prep launch must refresh them together
+    with the per-conv copies (pitched descriptors of csrc/multi.hip), through a switch to the fp32 parity mode and back (the bf16 links
+    are skipped there and rebuilt afterwards -- bench.py does exactly this for its fp32_mode figure)."""
+    cfg = small_cfg()
+    model = build_model(cfg)
+    init_synthetic_weights(model, seed=1)
+    model.train()
+    opt = FlatSGD(model, cfg)
+    sup, weak = synthetic_batch(2, 2, hw=(128, 192), seed=21, max_gt=3)
+    batch = model.pack_batch(sup, weak)
+
+    def step(dtype):
+        model.compute_dtype = dtype
+        st = model.forward_train(batch, early_backward=True)
+        model.backward_train(st)
+        opt.step()
+        return st.losses
+
+    def check():
+        n = 0
+        for head in (model.roi_heads.box_head, model.roi_heads.weak_box_head):
+            b = head.res5[0]
+            c3, sc, c1 = b.conv3, b.shortcut, b.conv1
+            f, g = b.__dict__["_wcat_fwd"], b.__dict__["_wcat_bwd"]
+            assert torch.equal(f.view(c3.cout, -1), torch.cat([c3.wf.view(c3.cout, -1), sc.wf.view(sc.cout, -1)], 1))
+            assert torch.equal(g.view(c1.cin, -1), torch.cat([c1.wd.view(c1.cin, -1), sc.wd.view(sc.cin, -1)], 1))
+            n += 1
+        return n
+
+    l0 = step(torch.bfloat16)
+    w_before = model.roi_heads.box_head.res5[0].__dict__["_wcat_fwd"].clone()
+    step(torch.bfloat16)          # from here on the prepared copies (and the concatenations) come from the multi-tensor launch
+    torch.cuda.synchronize()
+    assert check() == 2
+    assert not torch.equal(w_before, model.roi_heads.box_head.res5[0].__dict__["_wcat_fwd"]), "the optimizer update did not reach the concatenation"
+    l32 = step(torch.float32)
+    l1 = step(torch.bfloat16)
+    step(torch.bfloat16)
+    torch.cuda.synchronize()
+    assert check() == 2
+    assert torch.isfinite(l0).all() and torch.isfinite(l32).all() and torch.isfinite(l1).all()

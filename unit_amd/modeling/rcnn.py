@@ -50,6 +50,20 @@ class PackedBatch:
                 None if self.gt_masks is None else tuple(self.gt_masks.shape))
 
 
+def _record_tree(obj, streams):
+    """record_stream on every tensor inside nested tuples / lists (ops.ReluBits included): memory allocated under one stream's context
+    that other streams go on using"""
+    if torch.is_tensor(obj):
+        if obj.is_cuda:
+            for s in streams:
+                obj.record_stream(s)
+    elif isinstance(obj, ops.ReluBits):
+        _record_tree(obj.data, streams)
+    elif isinstance(obj, (tuple, list)):
+        for o in obj:
+            _record_tree(o, streams)
+
+
 class _StepFn(torch.autograd.Function):
     """Exposes the explicit plan to torch.autograd as one node: forward has already run, backward runs the backward plan."""
 
@@ -102,6 +116,7 @@ class WeaklySupervisedRCNNNoMeta(nn.Module):
         # step's preprocessing / frozen stem / res2 run beside it; the main stream joins before its first trainable layer. Whoever reads
         # parameters or gradients on another stream in between calls join_optimizer_tail() first (state_dict() and inference do).
         self.overlap_optimizer_tail = False
+        self.two_pass_overlap = True          # ragged supervised / weak batches: the weak pass of the backbone beside the supervised one (forward_train)
         self._tail_pending = None
         self.overlap_streams = True
         self.split_weak_head = __import__("os").environ.get("UNIT_SPLIT_WEAK", "1") != "0"     # forward plan: weak_box_head as two 1024-RoI passes
@@ -319,8 +334,20 @@ class WeaklySupervisedRCNNNoMeta(nn.Module):
             xa, sa = ops.preprocess_images(batch.images[:n_sup], self._pixel_mean, self._pixel_std, dt, 8, self.normalize_images)
             xb, sb = ops.preprocess_images(batch.images[n_sup:], self._pixel_mean, self._pixel_std, dt, 8, self.normalize_images)
             sizes = sa + sb
+            # The two passes are independent until the RoIs are pooled: the weak batch's backbone + RPN head run on the (idle) head stream
+            # beside the supervised batch's. Both are small launches (two images: ~4 800 res4 pixels, 150 - 300 workgroups) that leave most
+            # of the chip empty on their own -- the case real multi-scale batches always hit (bench.py --shapes voc).
+            weak_side = self._head_stream if (self._streams_on() and self.two_pass_overlap) else None
+            if weak_side is not None:
+                self.join_optimizer_tail()          # the side pass reads the same weights the pending optimizer tail writes
+                weak_side.wait_stream(torch.cuda.current_stream())
+                xb.record_stream(weak_side)
+                with torch.cuda.stream(weak_side):
+                    feat_w, c.bb_ctx_w = self.backbone.fwd(xb, save=True)
+                    head_w, _ = rpn.rpn_head.fwd(feat_w, save=False)          # weak images: proposals only (no RPN loss)
             feat, c.bb_ctx = self.backbone.fwd(xa, save=True, before_trainable=self.join_optimizer_tail)          # `feat` = supervised images only
-            feat_w, c.bb_ctx_w = self.backbone.fwd(xb, save=True)
+            if weak_side is None:
+                feat_w, c.bb_ctx_w = self.backbone.fwd(xb, save=True)
             anchors_w = rpn.anchor_generator.grid(feat_w.shape[1], feat_w.shape[2])
         self.join_optimizer_tail()          # (a fully frozen backbone never called it)
         c.image_sizes = sizes
@@ -351,8 +378,13 @@ class WeaklySupervisedRCNNNoMeta(nn.Module):
             else:
                 perms = self.sampling_permutations(n_sup, anchors.shape[0], n_roi_cap)
         head, c.rpn_ctx = rpn.rpn_head.fwd(feat, save=True)
-        if split:
+        if split and head_w is None:
             head_w, _ = rpn.rpn_head.fwd(feat_w, save=False)          # weak images: proposals only (no RPN loss)
+        elif split:
+            # join the side pass; what it allocated is used (and later freed) by work on the main and weight-gradient streams
+            cur = torch.cuda.current_stream()
+            cur.wait_stream(self._head_stream)
+            _record_tree((feat_w, head_w, c.bb_ctx_w), (cur, self._wgrad_stream))
         c.dhead = None
         c.drpn = None
         c.rpn_bwd_early = False

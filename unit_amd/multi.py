@@ -70,7 +70,9 @@ class ConvPlan:
             rows.append((m, slab, splits, m.wf.data_ptr() if m.wf is not None else None, m.wd.data_ptr() if m.wd is not None else None, 0, 0))
             if not with_partial:
                 for kind, dst in m._links:
-                    assert dst.stride(1) == 1 and dst.dtype == (m.wf if kind == "wf" else m.wd).dtype
+                    if dst.dtype != (m.wf if kind == "wf" else m.wd).dtype:
+                        continue          # a bf16 concatenation while the model runs its fp32 parity mode: unused there, re-linked when bf16 returns
+                    assert dst.stride(1) == 1
                     rows.append((m, None, 0, dst.data_ptr() if kind == "wf" else None, dst.data_ptr() if kind == "wd" else None,
                                  dst.stride(0) if kind == "wf" else 0, dst.stride(0) if kind == "wd" else 0))
         descs = (TensorDesc * len(rows))()
@@ -172,7 +174,7 @@ class ConvPlan:
         convs = [m for m in self.convs if m.wf is not None and m.wf.dtype == dtype and m.wd is not None]
         if len(convs) != len(self.convs):
             return False           # first step: the per-layer prepare() path allocates the copies
-        sig = tuple((m.wf.data_ptr(), m.wd.data_ptr()) + tuple(d.data_ptr() for _, d in m._links) for m in convs)
+        sig = tuple((m.wf.data_ptr(), m.wd.data_ptr()) + tuple(d.data_ptr() for _, d in m._links if d.dtype == dtype) for m in convs)
         if self._prep_table is None or self._prep_table[3] != sig:
             dev, n, blocks = self._build(convs, False)
             self._prep_table = (dev, n, blocks, sig)
