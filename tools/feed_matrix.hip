@@ -14,6 +14,8 @@
 //   NM     MFMAs per phase and wave (0 or 16), NR / RK: LDS reads per phase and wave, RK 0 = ds_read_b128, 1 = ds_read_b64_tr_b16
 //   DEPTH  pieces per wave that may stay in flight across the wait (vmcnt immediate)
 //   STAG   waves 4-7 one barrier behind waves 0-3
+//   NV     VALU instructions (dependent v_fma chains, 8 independent chains) + one fp32 LDS round trip (4 ds_write_b128 + 2 ds_read_b128) that the
+//          STAGING section carries besides its two pieces: the epilogue sub-step an X-stationary kernel would put there
 // Output: bytes staged per CU and cycle (in-kernel s_memtime of wave 0, median over workgroups) and the chip-wide rate by wall clock.
 //   build:  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o unit_amd/_build/feed_matrix tools/feed_matrix.hip
 #include <hip/hip_runtime.h>
@@ -32,7 +34,7 @@ struct Args {
   const char* pool; unsigned pool_bytes; unsigned pitch; int iters; int depth; unsigned long long* cycles; int* sink;
 };
 
-template <int RPP, int TRAV, int NM, int NR, int RK, int STAG>
+template <int RPP, int TRAV, int NM, int NR, int RK, int STAG, int NV = 0>
 __global__ void __launch_bounds__(512, 2) feed_kernel(Args p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -52,6 +54,7 @@ __global__ void __launch_bounds__(512, 2) feed_kernel(Args p) {
 #pragma unroll
   for (int i = 0; i < 8; ++i) { fa[i] = (__bf16)(float)(lane + i); fb[i] = (__bf16)(float)(wid - i); }
   i32x4 rd[NR > 0 ? NR : 1];
+  float vsink = 0.f;
   auto stage = [&](int slot) {
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
@@ -62,6 +65,18 @@ __global__ void __launch_bounds__(512, 2) feed_kernel(Args p) {
     }
     if (TRAV == 0) { if (++col == cols) { col = 0; row0 = (row0 + 16 * RPP) % nrows; } }
     else row0 = (row0 + 16 * RPP) % nrows;
+    if (NV > 0) {          // epilogue sub-step stand-in: scratch round trip + NV VALU on eight independent chains
+      char* scr = smem + 8 * 16384 - 8 * 4096 + wid * 4096;          // top of slot 7 (this probe never validates data)
+      f32x4 v = acc[0];
+#pragma unroll
+      for (int a = 0; a < 4; ++a) *reinterpret_cast<f32x4*>(scr + (lane & 15) * 272 + (a * 16 + (lane >> 4) * 4) * 4) = v;
+      f32x4 r0 = *reinterpret_cast<const f32x4*>(scr + (lane >> 3) * 272 + (lane & 7) * 32);
+      f32x4 r1 = *reinterpret_cast<const f32x4*>(scr + (lane >> 3) * 272 + (lane & 7) * 32 + 16);
+      float e[8] = {r0[0], r0[1], r0[2], r0[3], r1[0], r1[1], r1[2], r1[3]};
+#pragma unroll
+      for (int i = 0; i < NV; ++i) e[i & 7] = __builtin_fmaf(e[i & 7], 1.0009765625f, 0.5f);
+      vsink += e[0] + e[1] + e[2] + e[3] + e[4] + e[5] + e[6] + e[7];
+    }
   };
   auto wait_depth = [&]() {
     switch (p.depth) {
@@ -114,16 +129,16 @@ __global__ void __launch_bounds__(512, 2) feed_kernel(Args p) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   unsigned long long t1 = __builtin_amdgcn_s_memtime();
   if (tid == 0) p.cycles[blockIdx.x] = t1 - t0;
-  float s = acc[0][0] + acc[1][1] + acc[2][2] + acc[3][3];
+  float s = acc[0][0] + acc[1][1] + acc[2][2] + acc[3][3] + vsink;
   if (s == 12345.678f) p.sink[0] = 1;
 }
 
 struct Pool { char* p; size_t bytes; };
 
-template <int RPP, int TRAV, int NM, int NR, int RK, int STAG>
+template <int RPP, int TRAV, int NM, int NR, int RK, int STAG, int NV = 0>
 static void run(const char* name, Pool pool, unsigned pitch, int depth, int ncu, unsigned long long* cyc_dev, int* sink) {
   const int iters = 400;
-  auto k = feed_kernel<RPP, TRAV, NM, NR, RK, STAG>;
+  auto k = feed_kernel<RPP, TRAV, NM, NR, RK, STAG, NV>;
   hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
   Args a{pool.p, (unsigned)pool.bytes, pitch, 50, depth, cyc_dev, sink};
   k<<<ncu, 512, 131072>>>(a);
@@ -139,8 +154,8 @@ static void run(const char* name, Pool pool, unsigned pitch, int depth, int ncu,
   hipMemcpy(cyc.data(), cyc_dev, ncu * sizeof(unsigned long long), hipMemcpyDeviceToHost);
   std::sort(cyc.begin(), cyc.end());
   double bytes = (double)iters * 4 * 16384.0;
-  printf("%-26s rows/piece %d %s pitch %5u pool %5zu MB depth %d | MFMA/phase %2d reads/phase %2d %-4s %s | %6.1f B/clk/CU  (cycles/phase %6.0f)  chip %6.2f TB/s\n",
-         name, RPP, TRAV ? "m-major" : "k-major", pitch, pool.bytes >> 20, depth, NM, NR, NR ? (RK ? "tr64" : "b128") : "-", STAG ? "stag" : "lock",
+  printf("%-26s rows/piece %d %s pitch %5u pool %5zu MB depth %d | MFMA/phase %2d reads/phase %2d %-4s %s VALU+LDS in staging %3d | %6.1f B/clk/CU  (cycles/phase %6.0f)  chip %6.2f TB/s\n",
+         name, RPP, TRAV ? "m-major" : "k-major", pitch, pool.bytes >> 20, depth, NM, NR, NR ? (RK ? "tr64" : "b128") : "-", STAG ? "stag" : "lock", NV,
          bytes / (double)cyc[ncu / 2], (double)cyc[ncu / 2] / (iters * 4.0), bytes * ncu / ms / 1e9);
   fflush(stdout);
 }
@@ -185,6 +200,11 @@ int main() {
     run<4, 1, 16, 12, 0, 1>("C wgrad, b128 reads", pool, 1024, 4, ncu, cyc, sink);
     run<4, 1, 16, 6, 1, 1>("C wgrad, half reads", pool, 1024, 4, ncu, cyc, sink);
     run<4, 0, 16, 12, 1, 1>("C wgrad, k-major", pool, 1024, 4, ncu, cyc, sink);
+    // (D) the X-stationary question: a conv-like staggered phase whose staging section also carries an epilogue sub-step
+    run<8, 0, 16, 8, 0, 1, 1>("D conv + epilogue step", pool, 1024, 4, ncu, cyc, sink);
+    run<8, 0, 16, 8, 0, 1, 25>("D conv + epilogue step", pool, 1024, 4, ncu, cyc, sink);
+    run<8, 0, 16, 8, 0, 1, 50>("D conv + epilogue step", pool, 1024, 4, ncu, cyc, sink);
+    run<8, 0, 16, 8, 0, 1, 100>("D conv + epilogue step", pool, 1024, 4, ncu, cyc, sink);
   }
   return 0;
 }

@@ -114,6 +114,55 @@ __device__ __forceinline__ void epi_store8(bf16_t* q, bf16x8 v) {
 #endif
 }
 
+// Instruction diet of a pass (round 4: the epilogue is bound by its ~150-200 instructions per 8-row pass, not by memory --
+// profiles/r04_exp_epilogue_issue.txt). UNIT_EPI_SLIM=0 restores the plain C forms (identical values; A/B and bit-identity tests).
+#ifndef UNIT_EPI_SLIM
+#define UNIT_EPI_SLIM 1
+#endif
+// max(x, 0) as ONE v_max_f32: fmaxf() compiles to a canonicalising v_max_f32 x, x in front of it (quiets a signalling NaN, nothing else)
+__device__ __forceinline__ float epi_relu(float x) {
+#if UNIT_EPI_SLIM
+  float r;
+  asm("v_max_f32 %0, 0, %1" : "=v"(r) : "v"(x));
+  return r;
+#else
+  return fmaxf(x, 0.f);
+#endif
+}
+// bit ? x : +0 as bit-field extract + and (v_bfe_i32 gives 0 / -1) instead of and + compare + (VCC wait) + select
+__device__ __forceinline__ float epi_keep_if_bit(float x, unsigned bits, int j) {
+#if UNIT_EPI_SLIM
+  return __builtin_bit_cast(float, __builtin_bit_cast(unsigned, x) & (unsigned)__builtin_amdgcn_sbfe((int)bits, j, 1));
+#else
+  return ((bits >> j) & 1u) ? x : 0.f;
+#endif
+}
+// one bit per element of eight packed bf16 values, (value > 0): on the PACKED words with 16-bit integer ops -- a bf16 is positive iff its
+// bits are a positive int16 (NaN apart: counts as positive here; the ReLU in front of it never lets one through) -- instead of eight
+// float compares and selects through VCC
+typedef __attribute__((ext_vector_type(2))) short epi_s16x2;
+typedef __attribute__((ext_vector_type(2))) unsigned short epi_u16x2;
+__device__ __forceinline__ unsigned epi_positive_bits(bf16x8 o) {
+#if UNIT_EPI_SLIM
+  u32x4 w = __builtin_bit_cast(u32x4, o);
+  unsigned acc = 0;
+#pragma unroll
+  for (int k = 3; k >= 0; --k) {
+    epi_s16x2 t = __builtin_elementwise_max(__builtin_bit_cast(epi_s16x2, w[k]), epi_s16x2{0, 0});
+    epi_u16x2 u = __builtin_elementwise_min(__builtin_bit_cast(epi_u16x2, t), epi_u16x2{1, 1});
+    unsigned r = __builtin_bit_cast(unsigned, u);
+    r |= r >> 15;                          // bit 0 = low half positive, bit 1 = high half (bit 16 stays set: cleared by the final mask)
+    acc = (acc << 2) | r;                  // words 3, 2, 1, 0 -> bit pairs 6-7, 4-5, 2-3, 0-1 (stray bits end above bit 15)
+  }
+  return acc & 0xffu;
+#else
+  unsigned bits = 0;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) bits |= ((float)o[j] > 0.f ? 1u : 0u) << j;
+  return bits;
+#endif
+}
+
 template <int FA, int FB, bool EX, int RB, bool PM = false, typename Put, typename Args>
 __device__ __forceinline__ void epilogue_rows_bf16_blocks(Put put_block, char* scr, float* pool, int m_w, int n_w, const Args& p, int lane, const PmRows* rows = nullptr,
                                                           unsigned long long* stamp = nullptr) {
@@ -204,7 +253,7 @@ __device__ __forceinline__ void epilogue_rows_bf16_blocks(Put put_block, char* s
       }
       if (p.relu) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], 0.f);
+        for (int j = 0; j < 8; ++j) v[j] = epi_relu(v[j]);
       }
       if (Mk) {
 #pragma unroll
@@ -214,7 +263,7 @@ __device__ __forceinline__ void epilogue_rows_bf16_blocks(Put put_block, char* s
         if (Mb) {
           unsigned mbits = mw[(b * E::NP + h) >> 2] >> (((b * E::NP + h) & 3) * 8);
 #pragma unroll
-          for (int j = 0; j < 8; ++j) v[j] = ((mbits >> j) & 1u) ? v[j] : 0.f;
+          for (int j = 0; j < 8; ++j) v[j] = epi_keep_if_bit(v[j], mbits, j);
         }
       }
       bf16x8 o;
@@ -222,9 +271,7 @@ __device__ __forceinline__ void epilogue_rows_bf16_blocks(Put put_block, char* s
       for (int j = 0; j < 8; ++j) o[j] = (bf16_t)v[j];
       if constexpr (EX) {
         if (Rb && cur.ok[h]) {
-          unsigned bits = 0;
-#pragma unroll
-          for (int j = 0; j < 8; ++j) bits |= ((float)o[j] > 0.f ? 1u : 0u) << j;      // the stored (rounded) value, as a mask_ref read would see it
+          unsigned bits = epi_positive_bits(o);      // of the stored (rounded) value, as a mask_ref read would see it
           rw[(b * E::NP + h) >> 2] |= bits << (((b * E::NP + h) & 3) * 8);
         }
         if (Pp && cur.ok[h]) {
