@@ -14,9 +14,17 @@ from unit_amd.modeling import build_model
 from unit_amd.solver import FlatSGD
 from unit_amd.synthetic import init_synthetic_weights, synthetic_batch
 
-META = ("empty", "view", "slice", "select", "as_strided", "reshape", "detach", "alias", "transpose", "permute", "unsqueeze", "squeeze",
-        "expand", "record_stream", "_unsafe_view", "t.default", "unbind", "split", "narrow", "_local_scalar_dense", "is_pinned", "unfold",
-        "lift_fresh", "_reshape_alias", "resize_", "set_", "stride", "size", "numel", "is_same_size", "contiguous", "_to_copy")
+# pure metadata / allocation: no kernel behind them (matched on the operator's base name, e.g. "aten.view" of "aten.view.default")
+META = {"empty", "empty_like", "empty_strided", "new_empty", "new_empty_strided", "view", "slice", "select", "as_strided", "reshape", "detach",
+        "alias", "transpose", "permute", "unsqueeze", "squeeze", "expand", "record_stream", "_unsafe_view", "t", "unbind", "split",
+        "split_with_sizes", "narrow", "_local_scalar_dense", "is_pinned", "unfold", "lift_fresh", "_reshape_alias", "resize_", "set_",
+        "stride", "size", "sym_size", "numel", "is_same_size", "view_as", "chunk", "diagonal"}
+
+
+def base_name(func):
+    n = str(func)                      # "aten.cat.default"
+    parts = n.split(".")
+    return parts[1] if len(parts) >= 2 else n
 
 
 class Log(TorchDispatchMode):
@@ -26,7 +34,7 @@ class Log(TorchDispatchMode):
 
     def __torch_dispatch__(self, func, types, args=(), kwargs=None):
         name = str(func)
-        if not any(m in name for m in META) or "_to_copy" in name:
+        if base_name(func) not in META:
             site = "?"
             for fr in reversed(traceback.extract_stack()):
                 if "unit_amd" in fr.filename or "bench" in fr.filename:

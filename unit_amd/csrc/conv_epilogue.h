@@ -137,30 +137,14 @@ __device__ __forceinline__ float epi_keep_if_bit(float x, unsigned bits, int j) 
   return ((bits >> j) & 1u) ? x : 0.f;
 #endif
 }
-// one bit per element of eight packed bf16 values, (value > 0): on the PACKED words with 16-bit integer ops -- a bf16 is positive iff its
-// bits are a positive int16 (NaN apart: counts as positive here; the ReLU in front of it never lets one through) -- instead of eight
-// float compares and selects through VCC
-typedef __attribute__((ext_vector_type(2))) short epi_s16x2;
-typedef __attribute__((ext_vector_type(2))) unsigned short epi_u16x2;
+// one bit per element of eight packed bf16 values, (value > 0). (A packed-integer form -- positive int16 per half word -- was tried in
+// round 4: hipcc folded its short-vector max / min into two compares for the first word only, wrong bits, caught by
+// test_conv_fused_pool_and_relu_bits; spelled out in 32-bit integer ops it needs more instructions than the eight compares + selects here.)
 __device__ __forceinline__ unsigned epi_positive_bits(bf16x8 o) {
-#if UNIT_EPI_SLIM
-  u32x4 w = __builtin_bit_cast(u32x4, o);
-  unsigned acc = 0;
-#pragma unroll
-  for (int k = 3; k >= 0; --k) {
-    epi_s16x2 t = __builtin_elementwise_max(__builtin_bit_cast(epi_s16x2, w[k]), epi_s16x2{0, 0});
-    epi_u16x2 u = __builtin_elementwise_min(__builtin_bit_cast(epi_u16x2, t), epi_u16x2{1, 1});
-    unsigned r = __builtin_bit_cast(unsigned, u);
-    r |= r >> 15;                          // bit 0 = low half positive, bit 1 = high half (bit 16 stays set: cleared by the final mask)
-    acc = (acc << 2) | r;                  // words 3, 2, 1, 0 -> bit pairs 6-7, 4-5, 2-3, 0-1 (stray bits end above bit 15)
-  }
-  return acc & 0xffu;
-#else
   unsigned bits = 0;
 #pragma unroll
   for (int j = 0; j < 8; ++j) bits |= ((float)o[j] > 0.f ? 1u : 0u) << j;
   return bits;
-#endif
 }
 
 template <int FA, int FB, bool EX, int RB, bool PM = false, typename Put, typename Args>

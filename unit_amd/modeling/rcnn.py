@@ -326,7 +326,7 @@ class WeaklySupervisedRCNNNoMeta(nn.Module):
         pad_of = lambda ss: (max(s[0] for s in ss), max(s[1] for s in ss))
         split = n_sup > 0 and n_weak > 0 and pad_of(raw[:n_sup]) != pad_of(raw[n_sup:])
         c.split = split
-        feat_w = head_w = anchors_w = None
+        feat_w = head_w = anchors_w = split_props = split_side = None
         if not split:
             x, sizes = ops.preprocess_images(batch.images, self._pixel_mean, self._pixel_std, dt, 8, self.normalize_images)
             feat, c.bb_ctx = self.backbone.fwd(x, save=True, before_trainable=self.join_optimizer_tail)
@@ -338,13 +338,25 @@ class WeaklySupervisedRCNNNoMeta(nn.Module):
             # beside the supervised batch's. Both are small launches (two images: ~4 800 res4 pixels, 150 - 300 workgroups) that leave most
             # of the chip empty on their own -- the case real multi-scale batches always hit (bench.py --shapes voc).
             weak_side = self._head_stream if (self._streams_on() and self.two_pass_overlap) else None
+            split_side = weak_side
             if weak_side is not None:
                 self.join_optimizer_tail()          # the side pass reads the same weights the pending optimizer tail writes
                 weak_side.wait_stream(torch.cuda.current_stream())
                 xb.record_stream(weak_side)
+                hw_all = self._sizes_on_device(sizes)
+                post = rpn.post_nms_topk[True]
+                if proposals is None:          # both passes write their proposals into one set of tensors
+                    split_props = (torch.empty((n_img, post, 4), dtype=torch.float32, device=self.device),
+                                   torch.empty((n_img, post), dtype=torch.float32, device=self.device),
+                                   torch.empty((n_img,), dtype=torch.int32, device=self.device))
+                    for t in split_props:
+                        t.record_stream(weak_side)
                 with torch.cuda.stream(weak_side):
                     feat_w, c.bb_ctx_w = self.backbone.fwd(xb, save=True)
                     head_w, _ = rpn.rpn_head.fwd(feat_w, save=False)          # weak images: proposals only (no RPN loss)
+                    if proposals is None:          # ... and the weak batch's proposal chain (latency-bound: free beside the supervised pass)
+                        rpn.predict_proposals(head_w, rpn.anchor_generator.grid(feat_w.shape[1], feat_w.shape[2]), hw_all[n_sup:], True,
+                                              out=tuple(t[n_sup:] for t in split_props))
             feat, c.bb_ctx = self.backbone.fwd(xa, save=True, before_trainable=self.join_optimizer_tail)          # `feat` = supervised images only
             if weak_side is None:
                 feat_w, c.bb_ctx_w = self.backbone.fwd(xb, save=True)
@@ -380,11 +392,6 @@ class WeaklySupervisedRCNNNoMeta(nn.Module):
         head, c.rpn_ctx = rpn.rpn_head.fwd(feat, save=True)
         if split and head_w is None:
             head_w, _ = rpn.rpn_head.fwd(feat_w, save=False)          # weak images: proposals only (no RPN loss)
-        elif split:
-            # join the side pass; what it allocated is used (and later freed) by work on the main and weight-gradient streams
-            cur = torch.cuda.current_stream()
-            cur.wait_stream(self._head_stream)
-            _record_tree((feat_w, head_w, c.bb_ctx_w), (cur, self._wgrad_stream))
         c.dhead = None
         c.drpn = None
         c.rpn_bwd_early = False
@@ -414,9 +421,20 @@ class WeaklySupervisedRCNNNoMeta(nn.Module):
         elif not split:
             props, pscores, pcount = rpn.predict_proposals(head, anchors, hw, True)
         else:
-            pa = rpn.predict_proposals(head, anchors, hw[:n_sup].contiguous(), True)
-            pb = rpn.predict_proposals(head_w, anchors_w, hw[n_sup:].contiguous(), True)
-            props, pscores, pcount = (torch.cat([a, b], 0) for a, b in zip(pa, pb))
+            if split_props is None:          # sequential passes (one stream): the same two calls, one set of tensors
+                post = rpn.post_nms_topk[True]
+                split_props = (torch.empty((n_img, post, 4), dtype=torch.float32, device=self.device),
+                               torch.empty((n_img, post), dtype=torch.float32, device=self.device),
+                               torch.empty((n_img,), dtype=torch.int32, device=self.device))
+                rpn.predict_proposals(head_w, anchors_w, hw[n_sup:], True, out=tuple(t[n_sup:] for t in split_props))
+            rpn.predict_proposals(head, anchors, hw[:n_sup], True, out=tuple(t[:n_sup] for t in split_props))
+            props, pscores, pcount = split_props
+        if split and c.bb_ctx_w is not None and split_side is not None:
+            # join the weak batch's side pass (backbone, RPN head, its proposal chain); what it allocated is used -- and later freed -- by work
+            # on the main and weight-gradient streams
+            cur = torch.cuda.current_stream()
+            cur.wait_stream(split_side)
+            _record_tree((feat_w, head_w, c.bb_ctx_w), (cur, self._wgrad_stream))
         c.proposals = (props, pscores, pcount)
         if perm_ready is not None:
             torch.cuda.current_stream().wait_event(perm_ready)

@@ -78,6 +78,8 @@ class DefaultAnchorGenerator(nn.Module):
         cell = self.cell_anchors[0]
         key = (h, w, cell.device, cell.data_ptr())
         if key not in self._cache:
+            if len(self._cache) >= 128:          # multi-scale training meets hundreds of map sizes: keep the most recent (a grid is ~1 MB)
+                self._cache.pop(next(iter(self._cache)))
             self._cache[key] = ops.anchor_grid(h, w, cell, self.stride, self.offset)
         return self._cache[key]
 
@@ -117,14 +119,14 @@ class WSRPN(nn.Module):
         return ops.rpn_loss(head, a, a, labels, match_idx, gt_boxes, anchors, self.batch_size_per_image * n, grad_dtype)
 
     # ---- a6: predict_proposals / find_top_rpn_proposals, sync-free (counts stay on the device)
-    def predict_proposals(self, head, anchors, image_hw_dev, training):
+    def predict_proposals(self, head, anchors, image_hw_dev, training, out=None):
         a = self.num_anchors
         n, hw, ld = head.shape
         ntot = hw * a
         topk = min(self.pre_nms_topk[training], ntot)
         skeys, sidx = ops.sort_desc(head, n, ntot, ld=ld, a=a, col0=0, topk=topk)
         cb, cs, cc = ops.rpn_decode_select(head, a, a, anchors, sidx, skeys, topk, image_hw_dev, self.min_box_size)
-        _, kc, boxes, scores = ops.nms(cb, cs, cc, self.nms_thresh, self.post_nms_topk[training])
+        _, kc, boxes, scores = ops.nms(cb, cs, cc, self.nms_thresh, self.post_nms_topk[training], out=out)
         return boxes, scores, kc
 
     # ---- plugin surface (rpn.py:20): inference / proposal generation on NCHW fp32 features

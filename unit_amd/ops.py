@@ -784,14 +784,20 @@ def rpn_decode_select(head, a, delta_col0, anchors, sorted_idx, sorted_logit, to
     return cb, cs, cc
 
 
-def nms(boxes_sorted, scores_sorted, count, thresh, max_keep):
-    """boxes [B,cap,4] in descending score order -> (keep_idx [B,max_keep], keep_count [B], out_boxes, out_scores)"""
+def nms(boxes_sorted, scores_sorted, count, thresh, max_keep, out=None):
+    """boxes [B,cap,4] in descending score order -> (keep_idx [B,max_keep], keep_count [B], out_boxes, out_scores).
+    out = (boxes [B,max_keep,4], scores [B,max_keep], keep_count int32 [B]): rows of larger buffers to write into (a two-pass step keeps the
+    proposals of both passes in one tensor)"""
     b, cap = boxes_sorted.shape[0], boxes_sorted.shape[1]
     dev = boxes_sorted.device
     keep = torch.empty((b, max_keep), dtype=torch.int32, device=dev)      # unit_nms writes the tails (-1 / 0) itself
-    kc = torch.empty((b,), dtype=torch.int32, device=dev)
-    ob = torch.empty((b, max_keep, 4), dtype=torch.float32, device=dev)
-    osc = torch.empty((b, max_keep), dtype=torch.float32, device=dev)
+    if out is not None:
+        ob, osc, kc = out
+        assert ob.shape == (b, max_keep, 4) and osc.shape == (b, max_keep) and kc.shape == (b,) and ob.is_contiguous() and osc.is_contiguous()
+    else:
+        kc = torch.empty((b,), dtype=torch.int32, device=dev)
+        ob = torch.empty((b, max_keep, 4), dtype=torch.float32, device=dev)
+        osc = torch.empty((b, max_keep), dtype=torch.float32, device=dev)
     nb = lib().unit_nms_workspace_bytes(b, cap)
     ws = workspace(nb, dev)
     with _timed("nms", 0.0, b * cap * 20.0):
