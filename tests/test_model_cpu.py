@@ -205,3 +205,25 @@ def test_wgrad_group_plan_is_host_arithmetic():
     assert plan([(2, 8, 8, 64, 128, 1, 1, 0)])[0] != 0                                # C % 128 != 0: not eligible
     assert ops.lib().unit_conv2d_wgrad_group_supported(ops.dt(torch.bfloat16), 4, 38, 63, 256, 1, 1, 1024) == 2
     assert ops.lib().unit_conv2d_wgrad_group_supported(ops.dt(torch.float32), 4, 38, 63, 256, 1, 1, 1024) == 0
+
+
+def test_voc_shaped_steps_follow_the_yaml_and_group_by_orientation():
+    """synthetic.voc_shaped_steps (bench.py --shapes voc): sizes as the reference's loader makes them -- short side from INPUT.MIN_SIZE_TRAIN,
+    long side <= MAX_SIZE_TRAIN (configs/VOC/VOC-RCNN-101-C4-split1.yaml:27-29), every batch one orientation (data/build.py:476-497)"""
+    from unit_amd import config
+    from unit_amd.synthetic import voc_shaped_steps
+    cfg = config.voc_rcnn_c4_split1(101)
+    assert tuple(cfg.INPUT.MIN_SIZE_TRAIN) == (480, 512, 544, 576, 608, 640, 672, 704, 736, 768, 800) and cfg.INPUT.MAX_SIZE_TRAIN == 1333
+    steps = voc_shaped_steps(200, cfg, seed=3)
+    assert steps == voc_shaped_steps(200, cfg, seed=3) and steps != voc_shaped_steps(200, cfg, seed=4)
+    shorts, portrait_batches = set(), 0
+    for sup, weak in steps:
+        for batch in (sup, weak):
+            assert len(batch) == 2
+            assert len({h > w for h, w in batch}) == 1, batch          # one orientation per batch
+            portrait_batches += batch[0][0] > batch[0][1]
+            for h, w in batch:
+                assert max(h, w) <= 1333
+                shorts.add(min(h, w))
+    assert shorts <= set(cfg.INPUT.MIN_SIZE_TRAIN) | set(range(470, 801)) and {480, 800} <= shorts
+    assert 20 < portrait_batches < 160          # about a fifth of VOC is portrait

@@ -12,6 +12,7 @@ Batching: the supervised and the weak images of a step go through the backbone a
 and `weak_box_head` as ONE batch (roi_heads.py:499-513).
 """
 import contextlib
+import os
 
 import torch
 from torch import nn
@@ -116,7 +117,9 @@ class WeaklySupervisedRCNNNoMeta(nn.Module):
         # step's preprocessing / frozen stem / res2 run beside it; the main stream joins before its first trainable layer. Whoever reads
         # parameters or gradients on another stream in between calls join_optimizer_tail() first (state_dict() and inference do).
         self.overlap_optimizer_tail = False
-        self.two_pass_overlap = True          # ragged supervised / weak batches: the weak pass of the backbone beside the supervised one (forward_train)
+        # ragged supervised / weak batches (forward_train): 0 = the two backbone passes one after the other; 1 = the weak batch's backbone + RPN head
+        # on the head stream beside the supervised batch's; 2 = its proposal chain there too
+        self.two_pass_overlap = int(os.environ.get("UNIT_TWO_PASS_OVERLAP", "2"))
         self._tail_pending = None
         self.overlap_streams = True
         self.split_weak_head = __import__("os").environ.get("UNIT_SPLIT_WEAK", "1") != "0"     # forward plan: weak_box_head as two 1024-RoI passes
@@ -345,7 +348,7 @@ class WeaklySupervisedRCNNNoMeta(nn.Module):
                 xb.record_stream(weak_side)
                 hw_all = self._sizes_on_device(sizes)
                 post = rpn.post_nms_topk[True]
-                if proposals is None:          # both passes write their proposals into one set of tensors
+                if proposals is None and self.two_pass_overlap >= 2:          # both passes write their proposals into one set of tensors
                     split_props = (torch.empty((n_img, post, 4), dtype=torch.float32, device=self.device),
                                    torch.empty((n_img, post), dtype=torch.float32, device=self.device),
                                    torch.empty((n_img,), dtype=torch.int32, device=self.device))
@@ -354,7 +357,7 @@ class WeaklySupervisedRCNNNoMeta(nn.Module):
                 with torch.cuda.stream(weak_side):
                     feat_w, c.bb_ctx_w = self.backbone.fwd(xb, save=True)
                     head_w, _ = rpn.rpn_head.fwd(feat_w, save=False)          # weak images: proposals only (no RPN loss)
-                    if proposals is None:          # ... and the weak batch's proposal chain (latency-bound: free beside the supervised pass)
+                    if split_props is not None:          # ... and the weak batch's proposal chain (latency-bound: free beside the supervised pass)
                         rpn.predict_proposals(head_w, rpn.anchor_generator.grid(feat_w.shape[1], feat_w.shape[2]), hw_all[n_sup:], True,
                                               out=tuple(t[n_sup:] for t in split_props))
             feat, c.bb_ctx = self.backbone.fwd(xa, save=True, before_trainable=self.join_optimizer_tail)          # `feat` = supervised images only

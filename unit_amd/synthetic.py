@@ -78,23 +78,13 @@ VOC_RAW_SIZES = (((375, 500), 0.50), ((333, 500), 0.17), ((500, 375), 0.13), ((5
                  ((281, 500), 0.03), ((500, 500), 0.02), ((442, 500), 0.02))
 
 
-def resize_shortest_edge_shape(h, w, short, max_size):
-    """output size of Detectron2's ResizeShortestEdge (data/dataset_mapper.py:13-31 -> T.ResizeShortestEdge): scale the short side to
-    `short`, cap the long side at `max_size`, round half up"""
-    scale = short / min(h, w)
-    nh, nw = (short, scale * w) if h < w else (scale * h, short)
-    if max(nh, nw) > max_size:
-        k = max_size / max(nh, nw)
-        nh, nw = nh * k, nw * k
-    return int(nh + 0.5), int(nw + 0.5)
-
-
 def voc_shaped_steps(n_steps, cfg, n_sup=2, n_weak=2, seed=0):
     """image sizes of `n_steps` training steps drawn the way the reference's loader produces them: a VOC raw size, ResizeShortestEdge with a
     short side chosen from INPUT.MIN_SIZE_TRAIN and the long side capped at MAX_SIZE_TRAIN (configs/VOC/VOC-RCNN-101-C4-split1.yaml:27-29),
     and -- the aspect-ratio grouping of data/build.py:476-497 -- every batch holds images of ONE orientation (landscape or portrait), the
     supervised and the weak batch of a step being grouped independently. -> [(sup sizes, weak sizes)] as lists of (h, w)"""
     import random
+    from .data_pipeline import resize_shortest_edge_size          # d2 ResizeShortestEdge.get_transform's arithmetic
     rng = random.Random(seed)
     sizes, weights = zip(*VOC_RAW_SIZES)
     land = [(s, w) for s, w in VOC_RAW_SIZES if s[1] >= s[0]]
@@ -106,6 +96,6 @@ def voc_shaped_steps(n_steps, cfg, n_sup=2, n_weak=2, seed=0):
         out = []
         for _ in range(n):
             (h, w), = rng.choices([s for s, _ in grp], [w_ for _, w_ in grp])
-            out.append(resize_shortest_edge_shape(h, w, rng.choice(list(cfg.INPUT.MIN_SIZE_TRAIN)), cfg.INPUT.MAX_SIZE_TRAIN))
+            out.append(resize_shortest_edge_size(h, w, rng.choice(list(cfg.INPUT.MIN_SIZE_TRAIN)), cfg.INPUT.MAX_SIZE_TRAIN))
         return out
     return [(batch(n_sup), batch(n_weak)) for _ in range(n_steps)]
