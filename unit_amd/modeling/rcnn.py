@@ -117,9 +117,11 @@ class WeaklySupervisedRCNNNoMeta(nn.Module):
         # step's preprocessing / frozen stem / res2 run beside it; the main stream joins before its first trainable layer. Whoever reads
         # parameters or gradients on another stream in between calls join_optimizer_tail() first (state_dict() and inference do).
         self.overlap_optimizer_tail = False
-        # ragged supervised / weak batches (forward_train): 0 = the two backbone passes one after the other; 1 = the weak batch's backbone + RPN head
-        # on the head stream beside the supervised batch's; 2 = its proposal chain there too
-        self.two_pass_overlap = int(os.environ.get("UNIT_TWO_PASS_OVERLAP", "2"))
+        # ragged supervised / weak batches (forward_train): 0 = the two backbone passes one after the other (default); 1 = the weak batch's backbone
+        # + RPN head on the head stream beside the supervised batch's; 2 = its proposal chain there too. Measured on VOC-shaped batches (bench.py
+        # --shapes voc, 100 steps, two alternating series on one box): 19.57 / 19.77 (0), 19.85 / 19.93 (1), 19.75 / 19.85 ms (2) -- small launches
+        # from two streams interleave, they do not overlap: the concurrent forms stay a switch, sequential is the default.
+        self.two_pass_overlap = int(os.environ.get("UNIT_TWO_PASS_OVERLAP", "0"))
         self._tail_pending = None
         self.overlap_streams = True
         self.split_weak_head = __import__("os").environ.get("UNIT_SPLIT_WEAK", "1") != "0"     # forward plan: weak_box_head as two 1024-RoI passes
