@@ -48,3 +48,14 @@ def test_world_size_from_a_launcher_must_equal_gpus():
     r = _run(["--gpus", "8"], env={"WORLD_SIZE": "2", "RANK": "0", "LOCAL_RANK": "0"})
     assert r.returncode == 2 and r.stdout == ""
     assert "WORLD_SIZE=2" in r.stderr
+
+
+def test_under_torch_distributed_run_the_ranks_run_main_directly():
+    """the driver's N > 1 command: `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N` -- WORLD_SIZE comes from the launcher,
+    bench.py must not start ranks of its own, and every rank sees the launcher's rendezvous"""
+    e = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29517", BENCH, "--gpus", "2", "--dry-launch"], capture_output=True, text=True, timeout=300, env=e)
+    assert r.returncode == 0, r.stderr[-2000:]
+    envs = [json.loads(l[len("DRY_LAUNCH "):]) for l in r.stdout.splitlines() if l.startswith("DRY_LAUNCH ")]
+    assert sorted(int(x["RANK"]) for x in envs) == [0, 1] and {x["MASTER_PORT"] for x in envs} == {"29517"}

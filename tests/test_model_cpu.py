@@ -220,8 +220,8 @@ def test_voc_shaped_steps_follow_the_yaml_and_group_by_orientation():
     for sup, weak in steps:
         for batch in (sup, weak):
             assert len(batch) == 2
-            assert len({h > w for h, w in batch}) == 1, batch          # one orientation per batch
-            portrait_batches += batch[0][0] > batch[0][1]
+            assert len({w > h for h, w in batch}) == 1, batch          # one aspect-ratio bucket per batch (width > height or not)
+            portrait_batches += not (batch[0][1] > batch[0][0])
             for h, w in batch:
                 assert max(h, w) <= 1333
                 shorts.add(min(h, w))

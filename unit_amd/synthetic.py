@@ -87,8 +87,8 @@ def voc_shaped_steps(n_steps, cfg, n_sup=2, n_weak=2, seed=0):
     from .data_pipeline import resize_shortest_edge_size          # d2 ResizeShortestEdge.get_transform's arithmetic
     rng = random.Random(seed)
     sizes, weights = zip(*VOC_RAW_SIZES)
-    land = [(s, w) for s, w in VOC_RAW_SIZES if s[1] >= s[0]]
-    port = [(s, w) for s, w in VOC_RAW_SIZES if s[1] < s[0]]
+    land = [(s, w) for s, w in VOC_RAW_SIZES if s[1] > s[0]]          # d2 AspectRatioGroupedDataset: bucket 0 = width > height, everything else
+    port = [(s, w) for s, w in VOC_RAW_SIZES if s[1] <= s[0]]         # (squares included) bucket 1
     p_port = sum(w for _, w in port) / sum(weights)
 
     def batch(n):
