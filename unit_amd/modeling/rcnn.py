@@ -818,9 +818,14 @@ class WeaklySupervisedRCNNNoMeta(nn.Module):
         if not self.overlap_streams or self.device.type != "cuda" or self.plan is None:
             return False   # (without the plan the wgrad kernels share one workspace and must stay on one stream)
         if getattr(self, "_head_stream", None) is None:
+            # UNIT_STREAM_MERGE (experiment switch): which of the three side roles share ONE stream object -- "hw" head + weight gradients,
+            # "hr" head + RPN branch, "wr" weight gradients + RPN branch, "all" one side stream; "" = three streams (which of them share a
+            # HARDWARE queue is then the runtime's choice: GPU_MAX_HW_QUEUES = 4 queues for five streams)
+            merge = os.environ.get("UNIT_STREAM_MERGE", "")
             self._head_stream = torch.cuda.Stream(self.device)
-            self._wgrad_stream = torch.cuda.Stream(self.device)
-            self._rpn_stream = torch.cuda.Stream(self.device)
+            self._wgrad_stream = self._head_stream if merge in ("hw", "all") else torch.cuda.Stream(self.device)
+            self._rpn_stream = (self._head_stream if merge in ("hr", "all") else self._wgrad_stream if merge == "wr"
+                                else torch.cuda.Stream(self.device))
         return True
 
     def _reattach_grads(self):
