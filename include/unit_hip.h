@@ -42,6 +42,9 @@ int unit_preprocess_u8(const unsigned char* img_hwc, int C, int H, int W, int hf
 /* NCHW fp32 <-> NHWC converters for the plugin boundary (reference tensors are NCHW fp32) */
 int unit_nchw_to_nhwc(const float* x, void* y, int dtype, int N, int C, int H, int W, int Cp, void* stream);
 int unit_nhwc_to_nchw(const void* x, int dtype, float* y, int N, int C, int H, int W, int Cp, void* stream);
+/* diagnostic: one wave spinning for `cycles` shader clocks on `stream` (sink: any 4 writable device bytes, never written). Two of them on two
+ * streams overlap iff the streams sit on different hardware queues (tools/queue_probe.py, unit_amd/modeling/rcnn.py stream set-up). */
+int unit_debug_spin(long long cycles, void* sink, void* stream);
 int unit_cast(const void* x, int in_dtype, void* y, int out_dtype, long n, void* stream);
 /* zero nbytes at p (16-byte aligned): replaces the torch.zeros / Tensor.zero_ fills of the reference's step (loss accumulators of
  * engine/defaults.py:276-279's loss_dict, the zero-initialised gradient of a strided slice in autograd's conv backward) */

@@ -411,6 +411,21 @@ extern "C" int unit_fill_zero(void* p, size_t nbytes, void* stream) {
   return UNIT_OK;
 }
 
+// unit_debug_spin: ONE workgroup of one wave that spins for `cycles` shader clocks (s_memtime). Diagnostic: two of these on two HIP streams take
+// one spin time when the streams sit on different hardware queues and two when they share one (tools/queue_probe.py; the runtime maps the
+// process's streams onto GPU_MAX_HW_QUEUES = 4 queues, and which of the step's streams share a queue decides 10 % of its time).
+__global__ void debug_spin_kernel(long long cycles, int* sink) {
+  long long t0 = (long long)__builtin_amdgcn_s_memtime();
+  int n = 0;
+  while ((long long)__builtin_amdgcn_s_memtime() - t0 < cycles) ++n;
+  if (n == -1) *sink = n;
+}
+extern "C" int unit_debug_spin(long long cycles, void* sink, void* stream) {
+  debug_spin_kernel<<<1, 64, 0, (hipStream_t)stream>>>(cycles, (int*)sink);
+  UNIT_LAUNCH_CHECK();
+  return UNIT_OK;
+}
+
 // y[i] = cast(x[i])  between fp32 and bf16 (either direction)
 template <typename TI, typename TO>
 __global__ void cast_kernel(const TI* __restrict__ x, TO* __restrict__ y, long n) {
