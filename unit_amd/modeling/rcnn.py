@@ -822,6 +822,10 @@ class WeaklySupervisedRCNNNoMeta(nn.Module):
             # "hr" head + RPN branch, "wr" weight gradients + RPN branch, "all" one side stream; "" = three streams (which of them share a
             # HARDWARE queue is then the runtime's choice: GPU_MAX_HW_QUEUES = 4 queues for five streams)
             merge = os.environ.get("UNIT_STREAM_MERGE", "")
+            if merge == "" and os.environ.get("UNIT_STREAM_PROBE", "1") != "0" and not torch.cuda.is_current_stream_capturing():
+                # three side streams on three hardware queues of their own (measured, not assumed: ops.streams_on_distinct_queues)
+                self._head_stream, self._wgrad_stream, self._rpn_stream = ops.streams_on_distinct_queues(self.device, 3)
+                return True
             self._head_stream = torch.cuda.Stream(self.device)
             self._wgrad_stream = self._head_stream if merge in ("hw", "all") else torch.cuda.Stream(self.device)
             self._rpn_stream = (self._head_stream if merge in ("hr", "all") else self._wgrad_stream if merge == "wr"

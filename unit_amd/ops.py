@@ -79,6 +79,49 @@ class on_stream:
         return False
 
 
+def streams_on_distinct_queues(device, n, candidates=12, spin_cycles=200000):
+    """-> n torch.cuda.Stream objects that sit on n DIFFERENT hardware queues, none of them the queue of the calling thread's current stream.
+    The ROCm runtime maps all HIP streams of a process onto GPU_MAX_HW_QUEUES (4) hardware queues in an order that depends on every stream
+    created before -- PyTorch's pool, RCCL's process group ... -- and two streams on one queue run strictly one after the other. Which of the
+    step's streams share a queue decides ~10 % of its time (head stream on the main stream's queue, as happens once a process group exists:
+    18.2 instead of 16.3 ms), so the choice is made by measurement: two single-wave spin kernels (unit_debug_spin) on two
+    streams take one spin time on different queues and two on the same. Costs ~10 ms once. Falls back to fewer distinct streams (roles then
+    share a stream OBJECT) when the runtime offers fewer queues."""
+    import time
+    cur = torch.cuda.current_stream(device)
+    sink = torch.zeros(4, dtype=torch.int32, device=device)
+    cyc = ctypes.c_longlong(int(spin_cycles))
+
+    def spin(st):
+        check(lib().unit_debug_spin(cyc, _p(sink), ctypes.c_void_p(st.cuda_stream)), "debug_spin")
+
+    def pair(a, b):
+        best = 1e9
+        for _ in range(2):
+            torch.cuda.synchronize(device)
+            t0 = time.perf_counter()
+            spin(a)
+            spin(b)
+            torch.cuda.synchronize(device)
+            best = min(best, time.perf_counter() - t0)
+        return best
+
+    cands = [torch.cuda.Stream(device) for _ in range(candidates)]
+    spin(cur)
+    one = pair(cands[0], cands[0]) / 2.0          # two spins on ONE stream: strictly serial
+    share = lambda a, b: pair(a, b) > 1.5 * one
+    reps = []
+    for c in cands:
+        if len(reps) == n:
+            break
+        if share(c, cur) or any(share(c, r) for r in reps):
+            continue
+        reps.append(c)
+    while len(reps) < n:          # fewer queues than roles: roles share a stream object (explicitly serial)
+        reps.append(reps[len(reps) % max(1, len(reps))] if reps else torch.cuda.Stream(device))
+    return reps
+
+
 def stream_wait_stream(waiter, signaller_raw=None):
     """everything enqueued on torch.cuda.Stream `waiter` from now on waits for what is on the stream with raw handle `signaller_raw`
     (default: the current launch stream) so far: one C call (unit_stream_wait_stream) instead of Event() + record + wait_event"""
