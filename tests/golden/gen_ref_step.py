@@ -124,12 +124,12 @@ def oracle_params(model):
 TRAJ_STEPS = 5
 
 
-def traj_cfg(device="cpu"):
-    """the "s1" case with a solver schedule that shows all of its parts inside five iterations: two warm-up iterations (factor 0.25 -> 1),
+def traj_cfg(device="cpu", case="s1"):
+    """the "s1" (or, case="s2", the fine-tune) case with a solver schedule that shows all of its parts inside five iterations: two warm-up iterations (factor 0.25 -> 1),
     two at the base rate, the step decay (gamma 0.1) at iteration 4; momentum 0.9 and weight decay 1e-4 are the yaml's
     (configs/VOC/VOC-RCNN-101-C4-split1.yaml:42-49)."""
-    c = case_cfg("s1", device)
-    c.SOLVER.BASE_LR = 0.0005          # (0.02 of the yaml makes five steps from random-init weights a chaotic curve: loss_cls 9.6 -> 69 -> 25)
+    c = case_cfg(case, device)
+    c.SOLVER.BASE_LR = 0.0005 if case == "s1" else 0.002          # (0.02 of the yaml makes five steps from random-init weights a chaotic curve: loss_cls 9.6 -> 69 -> 25)
     c.SOLVER.WARMUP_ITERS, c.SOLVER.WARMUP_FACTOR = 2, 0.25
     c.SOLVER.STEPS, c.SOLVER.GAMMA = (4,), 0.1
     # the per-name factors of solver/build.py:85-107 are all 1.0 in the shipped yamls; non-trivial here, so that a tensor filed under the
@@ -139,10 +139,10 @@ def traj_cfg(device="cpu"):
     return c
 
 
-def traj_inputs(device="cpu"):
-    """-> (cfg with the trajectory's solver schedule, model, sup, weak, perms): the "s1" case's model and data"""
-    _, model, sup, weak, perms, _ = step_inputs("s1", device)
-    return traj_cfg(device), model, sup, weak, perms
+def traj_inputs(device="cpu", case="s1"):
+    """-> (cfg with the trajectory's solver schedule, model, sup, weak, perms): the model and data of the "s1" / "s2" case"""
+    _, model, sup, weak, perms, _ = step_inputs(case, device)
+    return traj_cfg(device, case), model, sup, weak, perms
 
 
 def traj_sample(t, n=1024):
@@ -151,16 +151,18 @@ def traj_sample(t, n=1024):
     return f[::max(1, f.numel() // n)][:n]
 
 
-def trajectory(G, out):
-    """TrainerNoMeta.run_step x TRAJ_STEPS as the reference defines it (engine/defaults.py:266-288: loss_dict -> sum -> zero_grad ->
+def trajectory(G, out, tag="traj", case="s1"):
+    """case "s2", tag "traj_ft": TrainerFineTune.run_step (engine/defaults.py:442-463: supervised data only) on the 1-shot fine-tune yaml's freeze
+    lists -- only cls_score_ft / bbox_pred_ft train. Otherwise:
+    TrainerNoMeta.run_step x TRAJ_STEPS as the reference defines it (engine/defaults.py:266-288: loss_dict -> sum -> zero_grad ->
     backward -> optimizer.step; d2 SimpleTrainer hooks step the LR scheduler after it): the reference's meta-arch / RPN / ROI heads /
     predictors (d2-ext blocks from the oracle, as everywhere in this file), the reference's OWN solver/build.py:build_optimizer_C4 on that
     model's named modules -> torch.optim.SGD, d2's WarmupMultiStepLR. Same batch and same sampling permutations every iteration.
     Written: losses per iteration, the LR / weight-decay group of every trainable tensor as build_optimizer_C4 assigned it, the base LR per
     iteration, and per trainable tensor the norm of its total update plus a strided sample of its final values."""
     from torch import nn
-    cfg = traj_cfg()
-    _, model, sup, weak, perms, _ = step_inputs("s1")
+    cfg = traj_cfg(case=case)
+    _, model, sup, weak, perms, _ = step_inputs(case)
     p = oracle_params(model)
     ocfg = oracle_cfg(cfg)
     ref, trace = G.build_reference_model(p, ocfg, perms, roi_cls=cfg.MODEL.ROI_HEADS.NAME, pred_cls=cfg.MODEL.ROI_HEADS.FAST_RCNN.NAME)
@@ -191,14 +193,15 @@ def trajectory(G, out):
     by_id = {id(q): k for k, q in named.items()}
     for g in opt.param_groups:
         for q in g["params"]:
-            out[f"traj/group_lr/{by_id[id(q)]}"], out[f"traj/group_wd/{by_id[id(q)]}"] = np.array(g["lr"]), np.array(g["weight_decay"])
+            out[f"{tag}/group_lr/{by_id[id(q)]}"], out[f"{tag}/group_wd/{by_id[id(q)]}"] = np.array(g["lr"]), np.array(g["weight_decay"])
     sched = G.d2.WarmupMultiStepLR(opt, cfg.SOLVER.STEPS, cfg.SOLVER.GAMMA, warmup_factor=cfg.SOLVER.WARMUP_FACTOR,
                                    warmup_iters=cfg.SOLVER.WARMUP_ITERS)
     ref.train()
     losses_all, lrs = [], []
-    d2_sup, d2_weak = G.to_d2_inputs(sup), G.to_d2_inputs(weak)
+    d2_sup, d2_weak = G.to_d2_inputs(sup), (G.to_d2_inputs(weak) if weak else None)
+    # a weight no factor applies to: its group runs at the scheduled base rate
+    plain = named["proposal_generator.rpn_head.conv.weight" if case == "s1" else "roi_heads.box_predictor.cls_score_ft.weight"]
     for it in range(TRAJ_STEPS):
-        plain = named["proposal_generator.rpn_head.conv.weight"]          # a tensor no factor applies to: its group runs at the scheduled base rate
         lrs.append(next(g["lr"] for g in opt.param_groups if any(q is plain for q in g["params"])))
         losses = ref(d2_sup, d2_weak)
         opt.zero_grad()
@@ -206,15 +209,15 @@ def trajectory(G, out):
         opt.step()
         sched.step()
         losses_all.append([losses[k].item() for k in sorted(losses)])
-        print("traj", it, "lr", lrs[-1], {k: round(v.item(), 6) for k, v in sorted(losses.items())})
-    out["traj/loss_names"] = np.array(sorted(losses))
-    out["traj/losses"] = np.array(losses_all, dtype=np.float64)
-    out["traj/lrs"] = np.array(lrs, dtype=np.float64)
-    assert np.isfinite(out["traj/losses"]).all()
+        print(tag, it, "lr", lrs[-1], {k: round(v.item(), 6) for k, v in sorted(losses.items())})
+    out[f"{tag}/loss_names"] = np.array(sorted(losses))
+    out[f"{tag}/losses"] = np.array(losses_all, dtype=np.float64)
+    out[f"{tag}/lrs"] = np.array(lrs, dtype=np.float64)
+    assert np.isfinite(out[f"{tag}/losses"]).all()
     for k, q in named.items():
-        out[f"traj/delta_norm/{k}"] = np.array((q.detach() - start[k]).double().norm().item())
-        out[f"traj/final_sample/{k}"] = G.npy(traj_sample(q))
-    out["traj/names"] = np.array(sorted(named))
+        out[f"{tag}/delta_norm/{k}"] = np.array((q.detach() - start[k]).double().norm().item())
+        out[f"{tag}/final_sample/{k}"] = G.npy(traj_sample(q))
+    out[f"{tag}/names"] = np.array(sorted(named))
 
 
 def main(G):
@@ -222,6 +225,7 @@ def main(G):
     d2 = G.d2
     out = {}
     trajectory(G, out)
+    trajectory(G, out, tag="traj_ft", case="s2")
     for name in CASES:
         cfg, model, sup, weak, perms, masks = step_inputs(name)
         p = oracle_params(model)

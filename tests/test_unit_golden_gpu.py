@@ -364,22 +364,25 @@ def test_hip_inference_vs_reference_orchestration(dev, name):
 
 
 # ---------------------------------------------------------------------------------------------------- the trajectory (a17)
-def _traj_trainer(dev, dtype):
+def _traj_trainer(dev, dtype, case="s1"):
     import gen_ref_step as G
     from unit_amd import engine
-    cfg, model, sup, weak, perms = G.traj_inputs(device="cuda")
+    cfg, model, sup, weak, perms = G.traj_inputs(device="cuda", case=case)
     model.train()
     model.compute_dtype = dtype
-    tr = engine.TrainerNoMeta(cfg, model)
-    batch = model.pack_batch(sup, weak)
+    tr = (engine.TrainerNoMeta if case == "s1" else engine.TrainerFineTune)(cfg, model)
+    batch = model.pack_batch(sup, weak if weak else None)
     cap = cfg.MODEL.RPN.POST_NMS_TOPK_TRAIN + batch.gt_boxes.shape[1]
     roi = torch.stack([torch.cat([p, torch.arange(len(p), cap)]) for p in perms["roi"]])
     tr.fixed_permutations = {"rpn": torch.stack(perms["rpn"]).int().to(dev), "roi": roi.int().to(dev)}
-    return G, cfg, model, tr, sup, weak
+    return G, cfg, model, tr, sup, (weak if weak else None)
 
 
-def test_hip_five_step_trajectory_vs_reference_trainer(dev):
-    """TrainerNoMeta.run_step x 5 in fp32 (forward plan, backward plan, FlatSGD with the per-name LR / weight-decay segments, the scheduled
+@pytest.mark.parametrize("tag,case", [("traj", "s1"), ("traj_ft", "s2")])
+def test_hip_five_step_trajectory_vs_reference_trainer(dev, tag, case):
+    """(traj_ft / s2: TrainerFineTune.run_step x 5 -- engine/defaults.py:442-463 -- on the 1-shot fine-tune yaml: only the two _ft predictors train,
+    the proposals never change, so the later iterations stay as tight as the first.)
+    TrainerNoMeta.run_step x 5 in fp32 (forward plan, backward plan, FlatSGD with the per-name LR / weight-decay segments, the scheduled
     LR, re-prepared weight copies for the next step) against the trajectory the REFERENCE's trainer semantics produced on the same inputs:
     engine/defaults.py:266-288 over solver/build.py:build_optimizer_C4 -> torch.optim.SGD + d2 WarmupMultiStepLR (tests/golden/
     gen_ref_step.py:trajectory). Losses of every iteration to 1e-4 -- iteration k sees every earlier update, so a stale prepared-weight
@@ -388,17 +391,17 @@ def test_hip_five_step_trajectory_vs_reference_trainer(dev):
     3.6e-3 at worst: the last of the five gradients comes from weights that already differ in the sixth digit; a tensor in the wrong LR
     group -- factors 0.25 ... 3 in this fixture -- or a skipped momentum term is off by >= 0.5 of the update)."""
     from unit_amd.modeling.rcnn import LOSS_NAMES
-    G, cfg, model, tr, sup, weak = _traj_trainer(dev, torch.float32)
+    G, cfg, model, tr, sup, weak = _traj_trainer(dev, torch.float32, case)
     model._ensure_ready()
-    names = [str(n) for n in STEP["traj/names"]]
+    names = [str(n) for n in STEP[f"{tag}/names"]]
     params = dict(model.named_parameters())
     start = {n: G.traj_sample(params[n]).cpu().clone() for n in names}
-    loss_names = [str(k) for k in STEP["traj/loss_names"]]
+    loss_names = [str(k) for k in STEP[f"{tag}/loss_names"]]
     dev_it = []
     for it in range(G.TRAJ_STEPS):
         tr.run_step(sup, weak)
         got = tr.loss_dict()
-        dev_it.append(max(abs(got[k] - v) / max(1.0, abs(v)) for k, v in zip(loss_names, STEP["traj/losses"][it])))
+        dev_it.append(max(abs(got[k] - v) / max(1.0, abs(v)) for k, v in zip(loss_names, STEP[f"{tag}/losses"][it])))
     print("trajectory: worst loss deviation per iteration", dev_it)
     # 1e-4 (north_star) while the two runs see the same weights to rounding: iterations 0-2. From then on each side's own fp32 summation
     # order has been through three updates of 48 M parameters and the 16-RoI means of this tiny case amplify it (measured 1.4e-4 at
@@ -408,7 +411,7 @@ def test_hip_five_step_trajectory_vs_reference_trainer(dev):
     params = dict(model.named_parameters())
     bad, worst_rel, worst_upd = [], 0.0, 0.0
     for n in names:
-        ref = torch.from_numpy(STEP[f"traj/final_sample/{n}"])
+        ref = torch.from_numpy(STEP[f"{tag}/final_sample/{n}"])
         got = G.traj_sample(params[n]).cpu()
         upd = (ref - start[n]).norm().item()
         err = (got - ref).norm().item()

@@ -764,6 +764,26 @@ __global__ void pool_finish_kernel(const float* __restrict__ part, int R, int ro
   int r = blockIdx.x;
   int w0 = (r * rows) / 128, w1 = (r * rows + rows - 1) / 128;
   float inv = (float)rows;                     // divided, not multiplied by a reciprocal: unit_global_avgpool_fwd's arithmetic
+  int seg0 = r - (w0 * 128) / rows, seg1 = r - (w1 * 128) / rows;
+  const float* p0 = part + ((size_t)w0 * 4 + seg0) * ldy;
+  const float* p1 = part + ((size_t)w1 * 4 + seg1) * ldy;
+  // eight consecutive channels per thread: the two 32-byte loads of each of the (at most two) pieces are issued before anything is used
+  // (one channel per thread and loop iteration was eight dependent round trips: 27 us for 1024 RoIs x 2048 channels)
+  if ((K & 7) == 0 && (ldy & 3) == 0) {
+    for (int n = threadIdx.x * 8; n < K; n += blockDim.x * 8) {
+      f32x4 a0 = *reinterpret_cast<const f32x4*>(p0 + n), a1 = *reinterpret_cast<const f32x4*>(p0 + n + 4);
+      f32x4 b0 = {0.f, 0.f, 0.f, 0.f}, b1 = {0.f, 0.f, 0.f, 0.f};
+      if (w1 != w0) { b0 = *reinterpret_cast<const f32x4*>(p1 + n); b1 = *reinterpret_cast<const f32x4*>(p1 + n + 4); }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        float t = 0.f;
+        t += j < 4 ? a0[j] : a1[j - 4];
+        if (w1 != w0) t += j < 4 ? b0[j] : b1[j - 4];
+        out[(size_t)r * ldo + n + j] = (T)(t / inv);
+      }
+    }
+    return;
+  }
   for (int n = threadIdx.x; n < K; n += blockDim.x) {
     float t = 0.f;
     for (int wt = w0; wt <= w1; ++wt) {
