@@ -222,14 +222,26 @@ class WeaklySupervisedRCNNNoMeta(nn.Module):
         """called by the optimizer once the flat parameters changed: bump the version and refresh every trainable conv's
         prepared (FrozenBN-folded, cast, dgrad-transposed) copies in one multi-tensor launch."""
         self.version += 1
-        if getattr(self, "plan", None) is not None:
-            self.plan.prep_all(self.compute_dtype, self.version)
+        self._plan_ok_version = None
+        if getattr(self, "plan", None) is not None and self.plan.prep_all(self.compute_dtype, self.version):
+            self._plan_ok_version = self.version          # every planned conv's copies were refreshed by the multi-tensor launch
 
     def _ensure_ready(self):
         if self.training and (self.store is None or not self.store.is_current()):
             self.flatten_parameters()
         dt, v = self.compute_dtype, self.version
+        pending = self._tail_pending is not None
+        if pending and getattr(self, "_plan_ok_version", None) != v:
+            # (first steps) per-layer weight preparation would read parameters the optimizer tail is still writing on its stream
+            self.join_optimizer_tail()
+            pending = False
         self.backbone.prepare(dt, v)
+        if pending:
+            # the Linear groups of the RPN / ROI heads re-prepare their weights from the parameters EVERY step (they are not in the conv
+            # plan): with the previous step's update still running on the weight-gradient stream that happens in join_optimizer_tail(),
+            # not here on the current stream beside it (a race the round-4 stream placement exposed: test_rccl_gpu tail_overlap)
+            self._heads_unprepared = True
+            return
         self.proposal_generator.rpn_head.prepare(dt, v)
         self.roi_heads.prepare(dt, v)
 
@@ -778,6 +790,10 @@ class WeaklySupervisedRCNNNoMeta(nn.Module):
         if s is not None:
             torch.cuda.current_stream().wait_stream(s)
             self._tail_pending = None
+        if self.__dict__.get("_heads_unprepared"):
+            self._heads_unprepared = False
+            self.proposal_generator.rpn_head.prepare(self.compute_dtype, self.version)
+            self.roi_heads.prepare(self.compute_dtype, self.version)
 
     def state_dict(self, *args, **kwargs):
         self.join_optimizer_tail()
