@@ -163,6 +163,14 @@ int unit_weight_prep(const float* w_krsc, const float* scale_k, int K, int R, in
 size_t unit_bias_grad_scratch_bytes(int M, int K);
 int unit_bias_grad(const void* dy, int dtype, int M, int K, int ld, float* db, int accumulate, float* scratch, size_t scratch_bytes,
                    void* stream);
+/* weight + bias gradient of a group of Linear layers that share their input, bf16 operands, ONE launch (replaces autograd's
+ * addmm backward of the box predictors: modeling/roi_heads/fast_rcnn.py:315-316 cls_score_delta / bbox_pred_delta, :477-478 the _ft
+ * pair; weak_detector_fast_rcnn.py:75-95 classifier / detection streams, OICR predictors, regression branch):
+ * dw[k][c] = sum_r dy[r][k] x[r][c] (fp32 [K][C], overwritten), db[k] = sum_r dy[r][k]; x [R][C], dy [R][ldy] (columns >= K zero),
+ * K <= 128, C % 128 == 0, ldy % 8 == 0. Partial sums of row splits are added in split order: deterministic. */
+size_t unit_linear_wgrad_workspace_bytes(int R, int C, int K);
+int unit_linear_wgrad(const void* x, const void* dy, int dtype, int R, int C, int K, int ldy, float* dw, float* db,
+                      void* workspace, size_t workspace_bytes, void* stream);
 int unit_maxpool3x3s2_fwd(const void* x, void* y, int dtype, int N, int H, int W, int C, void* stream);
 /* Res5BoxHead.forward x.mean(dim=[2,3]): modeling/roi_heads/box_head.py:80 */
 int unit_global_avgpool_fwd(const void* x, void* y, int dtype, int R, int P, int C, void* stream);

@@ -610,6 +610,40 @@ def test_bias_grad_tall_is_deterministic_and_exact(dev):
     assert torch.allclose(part.cpu().double(), ref[:75], rtol=1e-5, atol=1e-4)
 
 
+@pytest.mark.parametrize("case", [(1024, 2048, 101, 104), (4000, 2048, 107, 112), (4712, 1024, 75, 80), (37, 2048, 101, 104),
+                                  (130, 256, 21, 24), (2048, 2048, 128, 128), (700, 1024, 5, 8)])
+def test_linear_wgrad_one_launch(dev, case):
+    """unit_linear_wgrad (the box / RPN predictors' weight + bias gradient from one launch): == the fp64 products of the bf16
+    operands within fp32 accumulation error (rtol 2e-5 of the row norm), bit-identical from run to run and across repeated launches on
+    the same tickets, rows >= K of the destination untouched, and equal to the 1x1-convolution path it replaces within 1e-5."""
+    o = ops()
+    r, c, k, ldy = case
+    x = (torch.randn(r, c, generator=g(5)) * 0.5).bfloat16()
+    dy = torch.zeros(r, ldy)
+    dy[:, :k] = torch.randn(r, k, generator=g(6)) * 0.05
+    dy = dy.bfloat16()
+    ref_w = dy[:, :k].double().t() @ x.double()
+    ref_b = dy[:, :k].double().sum(0)
+    xd, dyd = x.to(dev), dy.to(dev)
+    dw = torch.full((ldy, c), 7.0, device=dev)
+    db = torch.full((ldy,), 7.0, device=dev)
+    o.linear_wgrad(xd, dyd, k, dw, db)
+    first_w, first_b = dw.clone(), db.clone()
+    for _ in range(3):
+        dw2 = torch.full((ldy, c), -1.0, device=dev)
+        db2 = torch.full((ldy,), -1.0, device=dev)
+        o.linear_wgrad(xd, dyd, k, dw2, db2)
+        assert torch.equal(dw2[:k], first_w[:k]) and torch.equal(db2[:k], first_b[:k])
+    assert bool((dw[k:] == 7.0).all()) and bool((db[k:] == 7.0).all())
+    scale = float(ref_w.abs().max())
+    assert float((dw[:k].cpu().double() - ref_w).abs().max()) <= 2e-5 * scale + 1e-6
+    assert torch.allclose(db[:k].cpu().double(), ref_b, rtol=2e-5, atol=2e-5 * float(ref_b.abs().max()) + 1e-6)
+    old_w = o.conv2d_wgrad(xd.view(r, 1, 1, c), dyd.view(r, 1, 1, ldy), ldy, 1, 1).view(ldy, c)
+    old_b = o.bias_grad(dyd, k)
+    assert float((dw[:k] - old_w[:k]).abs().max()) <= 1e-5 * scale + 1e-6
+    assert torch.allclose(db[:k], old_b, rtol=1e-5, atol=1e-5 * float(ref_b.abs().max()) + 1e-6)
+
+
 def test_random_permutations_kernel(dev):
     """unit_perm_keys + stable sort: every row is a permutation of range(n); rows, streams and counter values give different
     permutations; the same (seed, counter) reproduces; position of an element is roughly uniform"""

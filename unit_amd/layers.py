@@ -10,6 +10,8 @@ Conventions
     a block's bwd returns d(loss)/d(block input) multiplied by (input > 0) when `mask_input` (the input is the
     previous block's post-ReLU output), so masks are fused into the dgrad epilogues and never run as kernels.
 """
+import os
+
 import torch
 from torch import nn
 
@@ -349,6 +351,9 @@ class Linear(_EpochOnLoad):
         self.bias = nn.Parameter(torch.zeros(cout))
 
 
+_LINEAR_WGRAD = os.environ.get("UNIT_LINEAR_WGRAD", "1") != "0"     # 0: the predictors' gradients as a 1x1 convolution + column sum (A/B)
+
+
 class LinearGroup:
     """Several Linear layers on the same input evaluated as ONE GEMM with concatenated output columns
     (padded to a multiple of 8). If the members' parameters are adjacent rows of a FlatStore the fused master weight /
@@ -422,7 +427,9 @@ class LinearGroup:
         gw, gb = self._fused_views("grad")
         trainable = any(m.weight.requires_grad for m in self.members)
         if trainable:
-            if gw is not None:
+            if gw is not None and _LINEAR_WGRAD and x2d.dtype == torch.bfloat16 and self.kp <= 128 and self.cin % 128 == 0:
+                ops.linear_wgrad(x2d, dy2d, self.k, gw, gb)       # rows [k, kp) of the view belong to other parameters: not written
+            elif gw is not None:
                 ops.conv2d_wgrad(x2d.view(r, 1, 1, self.cin), dy2d.view(r, 1, 1, self.kp), self.kp, 1, 1, out=gw.view(self.kp, 1, 1, self.cin))
                 ops.bias_grad(dy2d, self.k, out=gb)
             else:

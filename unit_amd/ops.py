@@ -665,6 +665,18 @@ def bias_grad(dy2d, k, out=None, accumulate=False):
     return out
 
 
+def linear_wgrad(x2d, dy2d, k, dw, db):
+    """bf16 x [R,C], dy [R,ldy] (pad columns zero) -> dw fp32 [k,C], db fp32 [k] from one launch (csrc/linear_wgrad.hip)."""
+    r, c = x2d.shape
+    ldy = dy2d.shape[1]
+    dev = x2d.device
+    nb = lib().unit_linear_wgrad_workspace_bytes(r, c, k)
+    ws = workspace(nb, dev, slot=4)
+    with _timed("conv_wgrad", 2.0 * r * k * c, (x2d.numel() + r * ldy) * 2 + 4 * k * c):
+        check(lib().unit_linear_wgrad(_p(x2d), _p(dy2d), dt(x2d.dtype), r, c, k, ldy, _p(dw), _p(db), _p(ws), ws.numel(), _s()),
+              "unit_linear_wgrad")
+
+
 def maxpool3x3s2(x):
     n, h, w, c = x.shape
     oh, ow = (h + 2 - 3) // 2 + 1, (w + 2 - 3) // 2 + 1
