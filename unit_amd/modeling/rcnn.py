@@ -122,6 +122,11 @@ class WeaklySupervisedRCNNNoMeta(nn.Module):
         # --shapes voc, 100 steps, two alternating series on one box): 19.57 / 19.77 (0), 19.85 / 19.93 (1), 19.75 / 19.85 ms (2) -- small launches
         # from two streams interleave, they do not overlap: the concurrent forms stay a switch, sequential is the default.
         self.two_pass_overlap = int(os.environ.get("UNIT_TWO_PASS_OVERLAP", "0"))
+        # backward-plan start (profiles/r04_exp_head_backward_start.txt): the RPN 3x3 conv's weight gradient goes out at the end of the
+        # early RPN backward instead of with the heads' bucket; the supervised head's backward follows its losses on the head stream
+        self.early_rpn_wgrad = os.environ.get("UNIT_EARLY_RPN_WGRAD", "1") != "0"
+        self.early_sup_backward = os.environ.get("UNIT_EARLY_SUP_BWD", "1") != "0"
+        self.sup_predictor_on_head_stream = os.environ.get("UNIT_SUP_PRED_ON_HEAD", "1") != "0"
         self._tail_pending = None
         self.overlap_streams = True
         self.split_weak_head = __import__("os").environ.get("UNIT_SPLIT_WEAK", "1") != "0"     # forward plan: weak_box_head as two 1024-RoI passes
@@ -428,6 +433,11 @@ class WeaklySupervisedRCNNNoMeta(nn.Module):
                 c.rpn_losses = c.losses[6:8]          # the branch writes its two slots of the loss vector itself; nobody else touches them
                 rpn_branch()
                 c.drpn = rpn.rpn_head.bwd(c.rpn_ctx, c.dhead, n_sup)
+                if self.early_rpn_wgrad and self.plan is not None:
+                    # the 3x3 conv's weight gradient was queued for the heads' grouped launch, which goes out at the first bucket boundary
+                    # of the backward plan -- behind everything this stream is given later (the OICR chains) and next to the predictors'
+                    # backward. Launched here it runs under RoIAlign (HBM-bound, a few waves per CU) while the chip is half empty.
+                    self.plan.launch_deferred()
             c.rpn_bwd_early = True
         elif n_sup > 0:
             c.rpn_losses = c.losses[6:8]
@@ -553,11 +563,18 @@ class WeaklySupervisedRCNNNoMeta(nn.Module):
             run_mask()
 
         # a10-a12 predictors + losses (+ gradients w.r.t. the Linear outputs)
+        lin_sup = None
+        if rs > 0 and rw > 0 and c.head_overlap and self.sup_predictor_on_head_stream and not getattr(bp, "finetune", False):
+            # box_head's features were produced on the head stream and its losses will run there: the supervised predictors' GEMM goes there
+            # too, at once, instead of queueing behind the weak predictors' on this stream (two 16- / 32-workgroup launches of ~25 us each)
+            with torch.cuda.stream(self._head_stream):
+                lin_sup = bp.group.fwd(c.box_feat)
         lin_weak_all = bp.weak_detector_head.group.fwd(wfeat_all)            # [rs+rw, 104] (oicr cols feed the sup scores)
         c.dy_sup = c.dy_weak = None
         sup_side = None
         if rs > 0:
-            lin_sup = bp.group.fwd(c.box_feat)
+            if lin_sup is None:
+                lin_sup = bp.group.fwd(c.box_feat)
             if getattr(bp, "finetune", False):
                 # a14 (roi_heads.py:595-644 / :826-870 + fast_rcnn.py:484-533): similarity transfer is active in TRAINING too
                 from .inference import class_roles, similarity_dict
@@ -582,6 +599,7 @@ class WeaklySupervisedRCNNNoMeta(nn.Module):
                     sup_side.wait_stream(torch.cuda.current_stream())
                 with torch.cuda.stream(sup_side) if sup_side is not None else contextlib.nullcontext():
                     c.dy_sup, c.scores = bp.sup_losses(lin_sup, lin_weak_all[:rs], c.roi_cls, c.rois[:rs], c.roi_gt, c.losses[0:2], dt)
+                c.sup_losses_on_head_stream = sup_side is not None
         if rw > 0:
             c.dy_weak = bp.weak_detector_head.fused_losses(lin_weak_all[rs:], c.rois[rs:], c.weak_valid, s // rh.weak_divisor, n_weak,
                                                      batch.multihot, c.losses[2:6], dt,
@@ -633,6 +651,7 @@ class WeaklySupervisedRCNNNoMeta(nn.Module):
             self._clear_unproduced(c)
 
         dbox = dweak = None
+        early_sup = False
         if c.dy_sup is not None and getattr(bp, "finetune", False):
             # VOC fine-tune yaml: everything below the ft heads is frozen -> their weight gradients are all there is.
             # COCO segm fine-tune yaml: the box head (and RPN) train -> the gradient continues through the ft heads, the frozen
@@ -652,9 +671,24 @@ class WeaklySupervisedRCNNNoMeta(nn.Module):
                                             t["novel"].numel(), rh.visual_threshold, ul, uv, dsim, dt)
                 dbox = dbox + bp.group.bwd(c.box_feat, dlin, need_dx=True) + wh.group.bwd(c.box_feat, dlin_w, need_dx=True)
         elif c.dy_sup is not None:
-            dbox = bp.group.bwd(c.box_feat, c.dy_sup, need_dx=box_trainable or bb_trainable)
+            # The supervised losses ran on the head stream, beside the (three times longer) weak loss chain on this one. With
+            # early_sup_backward the supervised predictor's backward and box_head's backward follow them THERE without waiting for this
+            # stream: box_head's backward starts ~0.3 ms before weak_box_head's, in the window where only one- and two-workgroup loss
+            # kernels run (profiles/r04_exp_head_backward_start.txt).
+            early_sup = (self.early_sup_backward and multi and c.head_overlap and box_trainable and c.dy_weak is not None
+                         and getattr(c, "sup_losses_on_head_stream", False) and getattr(c, "mask_ctx", None) is None
+                         and not torch.cuda.is_current_stream_capturing())      # (a captured segment must fork the head stream itself)
+            if early_sup:
+                with torch.cuda.stream(self._head_stream):
+                    dbox = bp.group.bwd(c.box_feat, c.dy_sup, need_dx=True)
+                    sup_pred_done = torch.cuda.Event()
+                    sup_pred_done.record()
+            else:
+                dbox = bp.group.bwd(c.box_feat, c.dy_sup, need_dx=box_trainable or bb_trainable)
         if c.dy_weak is not None:
             dweak = bp.weak_detector_head.group.bwd(c.weak_feat, c.dy_weak, need_dx=True)
+        if early_sup:
+            torch.cuda.current_stream().wait_event(sup_pred_done)      # the bucket's gradients are complete on this stream's timeline
         done("heads")
         dpool_sup = dpool_weak = None      # d(loss)/d(pooled) of the supervised / weak RoIs
         mask_hook = None
@@ -674,8 +708,9 @@ class WeaklySupervisedRCNNNoMeta(nn.Module):
             overlap = c.head_overlap and dbox is not None and box_trainable and dweak is not None
             if overlap:
                 main, s1 = torch.cuda.current_stream(), self._head_stream
-                s1.wait_stream(main)
-                dbox.record_stream(s1)
+                if not early_sup:
+                    s1.wait_stream(main)
+                    dbox.record_stream(s1)
                 with torch.cuda.stream(s1):
                     dpool_sup = rh.box_head.bwd(c.box_ctx, dbox)
                 dpool_weak = rh.weak_box_head.bwd(c.weak_ctx, dweak, row_slice=c.weak_ctx_rows)
