@@ -171,6 +171,10 @@ int unit_bias_grad(const void* dy, int dtype, int M, int K, int ld, float* db, i
 size_t unit_linear_wgrad_workspace_bytes(int R, int C, int K);
 int unit_linear_wgrad(const void* x, const void* dy, int dtype, int R, int C, int K, int ldy, float* dw, float* db,
                       void* workspace, size_t workspace_bytes, void* stream);
+/* a2 the frozen stem in one launch, bf16: conv 7x7 s2 p3 (3 -> 64, input channels padded to 8) + FrozenBN + ReLU + max_pool2d(3, 2, 1)
+ * (detectron2 BasicStem.forward behind configs/VOC/VOC-RCNN-101-C4-split1.yaml:6-10). x [N][H][W][8], w [64][7][7][8] with the
+ * FrozenBN scale folded in (unit_weight_prep), shift [64] fp32, y [N][PH][PW][64], PH = ((H-1)/2+1 - 1)/2 + 1 */
+int unit_stem_conv_pool(const void* x, const void* w, const float* shift, void* y, int dtype, int N, int H, int W, void* stream);
 int unit_maxpool3x3s2_fwd(const void* x, void* y, int dtype, int N, int H, int W, int C, void* stream);
 /* Res5BoxHead.forward x.mean(dim=[2,3]): modeling/roi_heads/box_head.py:80 */
 int unit_global_avgpool_fwd(const void* x, void* y, int dtype, int R, int P, int C, void* stream);

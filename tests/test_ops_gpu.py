@@ -644,6 +644,33 @@ def test_linear_wgrad_one_launch(dev, case):
     assert torch.allclose(db[:k], old_b, rtol=1e-5, atol=1e-5 * float(ref_b.abs().max()) + 1e-6)
 
 
+@pytest.mark.parametrize("shape", [(2, 75, 131), (1, 64, 64), (3, 37, 200), (2, 600, 1000), (1, 9, 7)])
+def test_stem_conv_pool_one_launch(dev, shape):
+    """unit_stem_conv_pool (7x7 s2 conv + folded FrozenBN + ReLU + 3x3 s2 max pool, one persistent launch) against the two-launch path it
+    replaces (same bf16 operands, fp32 accumulation in another order: equal up to one bf16 rounding step of a few elements) and against
+    torch fp32 on the bf16-rounded operands (rtol 2^-7 = one bf16 ulp, atol 2e-2 for sums that cancel). Odd sizes: partial tiles on
+    every side, maps smaller than one tile."""
+    o = ops()
+    n, h, w = shape
+    x = torch.zeros(n, h, w, 8)
+    x[..., :3] = torch.randn(n, h, w, 3, generator=g(31)) * 1.5
+    wt = torch.randn(64, 3, 7, 7, generator=g(32)) * 0.08
+    scale = 0.5 + torch.rand(64, generator=g(33))
+    shift = torch.randn(64, generator=g(34)) * 0.3
+    xb = x.bfloat16().to(dev)
+    wf, _ = o.weight_prep(krsc(wt).to(dev), scale.to(dev), 64, 7, 7, 3, 8, torch.bfloat16, want_dgrad=False)
+    sh = shift.to(dev)
+    y = o.stem_conv_pool(xb, wf, sh)
+    old = o.maxpool3x3s2(o.conv2d(xb, wf, 64, 7, 7, 2, 3, bias=sh, relu=True))
+    assert y.shape == old.shape
+    d = (y.float() - old.float()).abs()
+    assert float(d.max()) <= 2.0 ** -7 * float(old.float().abs().max()) + 1e-6
+    assert float((d > 0).float().mean()) < 0.02          # the accumulation order moves a rounding boundary for a few elements only
+    ref = F.max_pool2d(F.relu(F.conv2d(nchw(xb.float().cpu()[..., :3]), wf.float().cpu()[..., :3].permute(0, 3, 1, 2), stride=2, padding=3)
+                              + shift.view(1, -1, 1, 1)), 3, 2, 1)
+    assert torch.allclose(nchw(y.float().cpu()), ref, rtol=2.0 ** -7, atol=2e-2)
+
+
 def test_random_permutations_kernel(dev):
     """unit_perm_keys + stable sort: every row is a permutation of range(n); rows, streams and counter values give different
     permutations; the same (seed, counter) reproduces; position of an element is roughly uniform"""

@@ -20,6 +20,21 @@ __global__ void preprocess_kernel(const float* __restrict__ img, int C, int H, i
   int y = idx / Wmax, x = idx - y * Wmax;
   T* o = out + (size_t)idx * Cpad;
   bool in = (y < H) && (x < W);
+  if (Cpad == 8) {          // the model's stem input: one 16-B (bf16) / two 16-B (fp32) stores per pixel instead of eight scalar ones
+    float v[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      float t = 0.f;
+      if (in && c < C) {
+        float p = img[((size_t)c * H + y) * W + x];
+        if (prescale != 1.0f) p = p / prescale;
+        t = (p - mean[c & 3]) / stdv[c & 3];
+      }
+      v[c] = t;
+    }
+    Vec8<T>::store(o, v);
+    return;
+  }
   for (int c = 0; c < Cpad; ++c) {
     float v = 0.f;
     if (in && c < C) {

@@ -29,12 +29,25 @@ class EarlyUpdate:
         import torch
         self.buckets, self.optimizer = buckets, optimizer
         self.stream = None
+        self.model = model
+        self._resolved = False
         if model.device.type == "cuda":
             self.stream = torch.cuda.Stream(model.device)
             model.on_bucket_final = self._bucket_final
 
+    def _resolve(self):
+        # A process's HIP streams share 4 hardware queues: a fifth stream lands on the queue of one of the step's four and runs
+        # strictly behind it (measured: the own stream above sat on the weight-gradient stream's queue). UNIT_EARLY_STREAM=rpn: the updates go
+        # onto the model's RPN stream, which is idle during the backward. Resolved at the first bucket: the model builds its streams lazily.
+        import os
+        self._resolved = True
+        if os.environ.get("UNIT_EARLY_STREAM", "own") == "rpn" and self.model._streams_on():
+            self.stream = self.model._rpn_stream
+
     def _bucket_final(self, tag, producer):
         import torch
+        if not self._resolved:
+            self._resolve()
         self.stream.wait_stream(producer)
         with torch.cuda.stream(self.stream):
             self.buckets.wait_tag(tag)

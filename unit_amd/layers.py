@@ -330,6 +330,9 @@ class ResStage(nn.Sequential):
         return max(0, n - (k + 1) * self.BUCKET_BLOCKS)
 
 
+_FUSED_STEM = os.environ.get("UNIT_FUSED_STEM", "1") != "0"
+
+
 class BasicStem(nn.Module):
     """detectron2 BasicStem: conv 7x7 s2 p3 + FrozenBN + ReLU + max_pool2d(3,2,1) (frozen: FREEZE_AT >= 1)."""
 
@@ -338,7 +341,11 @@ class BasicStem(nn.Module):
         self.conv1 = Conv2d(3, cout, 7, 2, 3, norm=True, cin_pad=8)
 
     def fwd(self, x):
-        return ops.maxpool3x3s2(self.conv1.fwd(x, relu=True))
+        c = self.conv1
+        if (_FUSED_STEM and x.dtype == torch.bfloat16 and x.is_cuda and c.cout == 64 and x.shape[-1] == 8 and c.wf is not None
+                and c.wf.dtype == torch.bfloat16 and not c.weight.requires_grad):
+            return ops.stem_conv_pool(x, c.wf, c.shift)          # one persistent launch; the conv output never reaches HBM
+        return ops.maxpool3x3s2(c.fwd(x, relu=True))
 
 
 class Linear(_EpochOnLoad):

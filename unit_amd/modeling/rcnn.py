@@ -438,6 +438,10 @@ class WeaklySupervisedRCNNNoMeta(nn.Module):
                     # of the backward plan -- behind everything this stream is given later (the OICR chains) and next to the predictors'
                     # backward. Launched here it runs under RoIAlign (HBM-bound, a few waves per CU) while the chip is half empty.
                     self.plan.launch_deferred()
+                # what the backward plan waits for: this point of the stream, not whatever the stream is given later (OICR chains,
+                # engine.EarlyUpdate's per-bucket optimizer launches)
+                c.rpn_branch_done = torch.cuda.Event()
+                c.rpn_branch_done.record()
             c.rpn_bwd_early = True
         elif n_sup > 0:
             c.rpn_losses = c.losses[6:8]
@@ -735,9 +739,9 @@ class WeaklySupervisedRCNNNoMeta(nn.Module):
 
         drpn = None
         if getattr(c, "rpn_bwd_early", False):
-            torch.cuda.current_stream().wait_stream(self._rpn_stream)      # launched during the forward plan
+            torch.cuda.current_stream().wait_event(c.rpn_branch_done)      # launched during the forward plan
             if side is not None:
-                side.wait_stream(self._rpn_stream)                         # its wgrad slabs are reduced on the side stream
+                side.wait_event(c.rpn_branch_done)                         # its wgrad slabs are reduced on the side stream
             drpn = c.drpn
             drpn.record_stream(torch.cuda.current_stream())
             c.rpn_losses.record_stream(torch.cuda.current_stream())

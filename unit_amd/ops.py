@@ -677,6 +677,18 @@ def linear_wgrad(x2d, dy2d, k, dw, db):
               "unit_linear_wgrad")
 
 
+def stem_conv_pool(x, w_fwd, shift):
+    """bf16 x [N,H,W,8] -> [N,PH,PW,64]: 7x7 s2 conv + folded FrozenBN + ReLU + 3x3 s2 max pool in one launch (csrc/stem_pool.hip)"""
+    n, h, w, c = x.shape
+    assert c == 8 and tuple(w_fwd.shape) == (64, 7, 7, 8) and x.dtype == torch.bfloat16 and w_fwd.dtype == torch.bfloat16
+    oh, ow = (h - 1) // 2 + 1, (w - 1) // 2 + 1
+    ph, pw = (oh - 1) // 2 + 1, (ow - 1) // 2 + 1
+    y = torch.empty((n, ph, pw, 64), dtype=x.dtype, device=x.device)
+    with _timed("stem", 2.0 * n * oh * ow * 64 * 147, x.numel() * 2 + y.numel() * 2):
+        check(lib().unit_stem_conv_pool(_p(x), _p(w_fwd), _p(shift), _p(y), dt(x.dtype), n, h, w, _s()), "unit_stem_conv_pool")
+    return y
+
+
 def maxpool3x3s2(x):
     n, h, w, c = x.shape
     oh, ow = (h + 2 - 3) // 2 + 1, (w + 2 - 3) // 2 + 1
