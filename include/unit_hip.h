@@ -262,11 +262,14 @@ int unit_rpn_loss(const float* head, int ld, int A, int dcol0, const int8_t* lab
 int unit_sup_scores(const float* delta, int ldd, int dcol0, const float* weak, int ldw, int wcol0, int n_oicr, int ncls,
                     const unsigned char* novel_mask_dev, const float* extra, int lde, int ecol0, float* out, int ldo, int R,
                     void* stream);
+/* acc (may be NULL): 8 device bytes, zero at the call and handed back zero, private to the stream -- with it the rows are spread over one-wave
+ * workgroups and their partial losses are added through it in fixed point (bit-reproducible whatever the arrival order); without it one
+ * workgroup walks all rows */
 int unit_softmax_ce(const float* logits, int ld, int col0, int ncls, const int* labels, const float* weights, int R, float gscale,
-                    float* loss, void* dy, int dy_dtype, int ldd, int dcol0, void* stream);
+                    float* loss, void* dy, int dy_dtype, int ldd, int dcol0, unsigned long long* acc, void* stream);
 int unit_box_reg_loss(const float* bbox, int ld, int col0, int K, const int* labels, const float* rois5, const float* gt_boxes,
                       const float* weights4, int R, float gscale, float* loss, void* dy, int dy_dtype, int ldd, int dcol0,
-                      void* stream);
+                      unsigned long long* acc, void* stream);
 int unit_wsddn_mil(const float* streams, int ld, int ccol0, int dcol0, int K, const int* valid, int S, int B,
                    const unsigned char* multihot, float cls_temp, float det_temp, float mil_multiplier, float gscale, float* loss,
                    float* xr_out, void* dy, int dy_dtype, int ldd, int dyc0, int dyd0, void* stream);

@@ -671,6 +671,41 @@ def test_stem_conv_pool_one_launch(dev, shape):
     assert torch.allclose(nchw(y.float().cpu()), ref, rtol=2.0 ** -7, atol=2e-2)
 
 
+@pytest.mark.parametrize("r", [300, 1024, 4000, 20000])
+def test_multi_workgroup_losses_match_the_single_workgroup_form(dev, r):
+    """unit_softmax_ce / unit_box_reg_loss with the rows spread over one-wave workgroups (fixed-point packed accumulator): gradients
+    bit-identical to the single-workgroup launch, loss equal within fp32 summation order (1e-5 relative: 20 000 addends), bit-identical from launch to launch,
+    accumulator handed back zero (three launches in a row on the same 8 bytes)"""
+    o = ops()
+    ncls, k = 21, 20
+    logits = (torch.randn(r, 104, generator=g(41)) * 2).to(dev)
+    labels = torch.randint(-1, ncls, (r,), generator=g(42), dtype=torch.int32).to(dev)
+    weights = torch.rand(r, generator=g(43)).to(dev)
+    rois = torch.cat([torch.zeros(r, 1), rand_boxes(g(44), r)], 1).to(dev)
+    gt = rand_boxes(g(45), r).to(dev)
+
+    def run():
+        dy = torch.zeros(r, 104, dtype=torch.bfloat16, device=dev)
+        l1 = o.softmax_ce(logits, 0, ncls, labels, weights=weights, dy=dy, dcol0=0)
+        l2 = o.box_reg_loss(logits, 24, k, labels, rois, gt, (10.0, 10.0, 5.0, 5.0), dy=dy, dcol0=24)
+        return float(l1), float(l2), dy
+
+    assert o._MULTI_WG_LOSSES
+    a = run()
+    b = run()
+    c = run()
+    o._MULTI_WG_LOSSES = False
+    try:
+        ref = run()
+    finally:
+        o._MULTI_WG_LOSSES = True
+    assert a[0] == b[0] == c[0] and a[1] == b[1] == c[1] and torch.equal(a[2], b[2])
+    assert torch.equal(a[2], ref[2])
+    assert abs(a[0] - ref[0]) <= 1e-5 * abs(ref[0]) + 1e-9 and abs(a[1] - ref[1]) <= 1e-5 * abs(ref[1]) + 1e-9
+    acc = o._loss_acc(torch.device(dev))
+    assert int(acc.abs().sum()) == 0
+
+
 def test_random_permutations_kernel(dev):
     """unit_perm_keys + stable sort: every row is a permutation of range(n); rows, streams and counter values give different
     permutations; the same (seed, counter) reproduces; position of an element is roughly uniform"""

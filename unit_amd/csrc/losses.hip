@@ -16,6 +16,20 @@ __device__ __forceinline__ float block_sum(float v, float* lds /* >= 17 floats *
   return lds[16];
 }
 
+// Sum of one non-negative partial per workgroup, bit-reproducible, in ONE atomic per workgroup and no fence: the partial goes into the low
+// 56 bits of a 64-bit accumulator as fixed point (2^-36 units: integer addition is associative, so the arrival order does not matter), the
+// arrival count into the top 8 bits. The workgroup whose atomicAdd returns count == nblk - 1 holds the complete sum in (returned value +
+// its own addend); it leaves the accumulator zero for the next launch (the caller zeroes it once). nblk <= 255, sum < 2^20.
+__device__ __forceinline__ bool packed_sum_finish(unsigned long long* acc, float partial, int nblk, float* total) {
+  unsigned long long q = (unsigned long long)((double)partial * 68719476736.0) + (1ull << 56);
+  unsigned long long old = atomicAdd(acc, q);
+  if ((int)(old >> 56) != nblk - 1) return false;
+  unsigned long long sum = (old + q) & ((1ull << 56) - 1);
+  *total = (float)((double)sum * (1.0 / 68719476736.0));
+  *acc = 0ull;
+  return true;
+}
+
 // ---------------------------------------------------------------------------------------------------
 // a5  WSRPN.losses  modeling/proposal_generator/rpn.py:55-101
 //   loss_rpn_cls = sum_{label>=0} BCEwithlogits(logit, label) / (256*N) ; loss_rpn_loc = sum_{label==1} |d - t| / (256*N)
@@ -260,14 +274,14 @@ extern "C" int unit_sup_scores(const float* delta, int ldd, int dcol0, const flo
 template <typename TD>
 __global__ void softmax_ce_kernel(const float* __restrict__ logits, int ld, int col0, int ncls, const int* __restrict__ labels,
                                   const float* __restrict__ weights, int R, float gscale, float* __restrict__ loss,
-                                  TD* __restrict__ dy, int ldd, int dcol0) {
+                                  TD* __restrict__ dy, int ldd, int dcol0, unsigned long long* __restrict__ pacc) {
   __shared__ float lds[17];
   float cnt = 0.f;
-  for (int r = threadIdx.x; r < R; r += blockDim.x) cnt += labels[r] >= 0 ? 1.f : 0.f;
+  for (int r = threadIdx.x; r < R; r += blockDim.x) cnt += labels[r] >= 0 ? 1.f : 0.f;          // every workgroup counts all rows: same total
   float total = block_sum(cnt, lds);
   float inv = total > 0.f ? 1.f / total : 0.f;
   float acc = 0.f;
-  for (int r = threadIdx.x; r < R; r += blockDim.x) {
+  for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < R; r += gridDim.x * blockDim.x) {
     int lab = labels[r];
     const float* x = logits + (size_t)r * ld + col0;
     if (lab < 0) {
@@ -315,15 +329,27 @@ __global__ void softmax_ce_kernel(const float* __restrict__ logits, int ld, int 
     }
   }
   float s = block_sum(acc, lds);
-  if (threadIdx.x == 0) *loss = s * inv;
+  if (threadIdx.x == 0) {
+    if (gridDim.x == 1) *loss = s * inv;
+    else { float t; if (packed_sum_finish(pacc, s, gridDim.x, &t)) *loss = t * inv; }
+  }
+}
+// rows spread over one-wave workgroups when the caller supplies an accumulator (8 zero bytes, handed back zero): the single 1024-thread
+// workgroup spent 25-50 us of VALU time on ONE CU (1-4 k rows x 21 classes, two expf per element) on the step's critical path
+static int loss_grid(int R, const void* pacc, int* threads) {
+  if (pacc == nullptr || R <= 256) { *threads = 1024; return 1; }
+  *threads = 64;
+  int g = (R + 63) / 64;
+  return g > 240 ? 240 : g;
 }
 extern "C" int unit_softmax_ce(const float* logits, int ld, int col0, int ncls, const int* labels, const float* weights, int R,
-                               float gscale, float* loss, void* dy, int dy_dtype, int ldd, int dcol0, void* stream) {
+                               float gscale, float* loss, void* dy, int dy_dtype, int ldd, int dcol0, unsigned long long* acc, void* stream) {
   hipStream_t s = (hipStream_t)stream;
+  int th, g = loss_grid(R, acc, &th);
   if (dy_dtype == UNIT_BF16)
-    softmax_ce_kernel<bf16_t><<<1, 1024, 0, s>>>(logits, ld, col0, ncls, labels, weights, R, gscale, loss, (bf16_t*)dy, ldd, dcol0);
+    softmax_ce_kernel<bf16_t><<<g, th, 0, s>>>(logits, ld, col0, ncls, labels, weights, R, gscale, loss, (bf16_t*)dy, ldd, dcol0, acc);
   else
-    softmax_ce_kernel<float><<<1, 1024, 0, s>>>(logits, ld, col0, ncls, labels, weights, R, gscale, loss, (float*)dy, ldd, dcol0);
+    softmax_ce_kernel<float><<<g, th, 0, s>>>(logits, ld, col0, ncls, labels, weights, R, gscale, loss, (float*)dy, ldd, dcol0, acc);
   UNIT_LAUNCH_CHECK();
   return UNIT_OK;
 }
@@ -335,14 +361,14 @@ extern "C" int unit_softmax_ce(const float* logits, int ld, int col0, int ncls, 
 template <typename TD>
 __global__ void box_reg_loss_kernel(const float* __restrict__ bbox, int ld, int col0, int K, const int* __restrict__ labels,
                                     const float* __restrict__ rois5, const float* __restrict__ gtb, f32x4 w, int R, float gscale,
-                                    float* __restrict__ loss, TD* __restrict__ dy, int ldd, int dcol0) {
+                                    float* __restrict__ loss, TD* __restrict__ dy, int ldd, int dcol0, unsigned long long* __restrict__ pacc) {
   __shared__ float lds[17];
   float cnt = 0.f;
   for (int r = threadIdx.x; r < R; r += blockDim.x) cnt += labels[r] >= 0 ? 1.f : 0.f;
   float total = block_sum(cnt, lds);
   float inv = total > 0.f ? 1.f / total : 0.f;
   float acc = 0.f;
-  for (int r = threadIdx.x; r < R; r += blockDim.x) {
+  for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < R; r += gridDim.x * blockDim.x) {
     int lab = labels[r];
     if (dy) for (int c = 0; c < 4 * K; ++c) st(dy + (size_t)r * ldd + dcol0 + c, 0.f);
     if (lab < 0 || lab >= K) continue;
@@ -357,17 +383,21 @@ __global__ void box_reg_loss_kernel(const float* __restrict__ bbox, int ld, int 
     }
   }
   float s = block_sum(acc, lds);
-  if (threadIdx.x == 0) *loss = s * inv;
+  if (threadIdx.x == 0) {
+    if (gridDim.x == 1) *loss = s * inv;
+    else { float t; if (packed_sum_finish(pacc, s, gridDim.x, &t)) *loss = t * inv; }
+  }
 }
 extern "C" int unit_box_reg_loss(const float* bbox, int ld, int col0, int K, const int* labels, const float* rois5, const float* gt_boxes,
                                  const float* weights4, int R, float gscale, float* loss, void* dy, int dy_dtype, int ldd, int dcol0,
-                                 void* stream) {
+                                 unsigned long long* acc, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   f32x4 w = {weights4[0], weights4[1], weights4[2], weights4[3]};
+  int th, g = loss_grid(R, acc, &th);
   if (dy_dtype == UNIT_BF16)
-    box_reg_loss_kernel<bf16_t><<<1, 1024, 0, s>>>(bbox, ld, col0, K, labels, rois5, gt_boxes, w, R, gscale, loss, (bf16_t*)dy, ldd, dcol0);
+    box_reg_loss_kernel<bf16_t><<<g, th, 0, s>>>(bbox, ld, col0, K, labels, rois5, gt_boxes, w, R, gscale, loss, (bf16_t*)dy, ldd, dcol0, acc);
   else
-    box_reg_loss_kernel<float><<<1, 1024, 0, s>>>(bbox, ld, col0, K, labels, rois5, gt_boxes, w, R, gscale, loss, (float*)dy, ldd, dcol0);
+    box_reg_loss_kernel<float><<<g, th, 0, s>>>(bbox, ld, col0, K, labels, rois5, gt_boxes, w, R, gscale, loss, (float*)dy, ldd, dcol0, acc);
   UNIT_LAUNCH_CHECK();
   return UNIT_OK;
 }

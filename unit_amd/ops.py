@@ -985,11 +985,28 @@ def sup_scores(delta, dcol0, weak, wcol0, n_oicr, ncls, novel_mask=None, extra=N
     return out
 
 
+_LOSS_ACC = {}
+_MULTI_WG_LOSSES = os.environ.get("UNIT_MULTI_WG_LOSSES", "1") != "0"
+
+
+def _loss_acc(device):
+    """the 8-byte accumulator of the multi-workgroup loss kernels (include/unit_hip.h: unit_softmax_ce): one per (device, HIP stream), zeroed
+    once -- the kernels hand it back zero, launches on a stream are ordered"""
+    if not _MULTI_WG_LOSSES or device.type != "cuda":
+        return None
+    key = (device, raw_stream(device.index))
+    a = _LOSS_ACC.get(key)
+    if a is None:
+        a = _LOSS_ACC[key] = zeros(2, torch.int32, device)
+    return a
+
+
 def softmax_ce(logits, col0, ncls, labels, weights=None, dy=None, dcol0=0, gscale=1.0, loss_out=None):
     r, ld = logits.shape
     loss = loss_out if loss_out is not None else torch.empty(1, dtype=torch.float32, device=logits.device)
     check(lib().unit_softmax_ce(_p(logits), ld, col0, ncls, _p(labels), _p(weights), r, float(gscale), _p(loss), _p(dy),
-                                dt(dy.dtype) if dy is not None else 0, dy.shape[1] if dy is not None else 0, dcol0, _s()), "softmax_ce")
+                                dt(dy.dtype) if dy is not None else 0, dy.shape[1] if dy is not None else 0, dcol0, _p(_loss_acc(logits.device)),
+                                _s()), "softmax_ce")
     return loss
 
 
@@ -998,7 +1015,8 @@ def box_reg_loss(bbox, col0, k, labels, rois5, gt_boxes, weights, dy=None, dcol0
     loss = loss_out if loss_out is not None else torch.empty(1, dtype=torch.float32, device=bbox.device)
     w = (ctypes.c_float * 4)(*weights)
     check(lib().unit_box_reg_loss(_p(bbox), ld, col0, k, _p(labels), _p(rois5), _p(gt_boxes), w, r, float(gscale), _p(loss), _p(dy),
-                                  dt(dy.dtype) if dy is not None else 0, dy.shape[1] if dy is not None else 0, dcol0, _s()), "box_reg_loss")
+                                  dt(dy.dtype) if dy is not None else 0, dy.shape[1] if dy is not None else 0, dcol0, _p(_loss_acc(bbox.device)),
+                                  _s()), "box_reg_loss")
     return loss
 
 
