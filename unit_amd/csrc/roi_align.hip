@@ -8,6 +8,7 @@
 // `pooled_size` grid -- bin_step=2,out_size=7,pooled_size=14 is the "strided" mode that only materialises the bins a
 // stride-2 1x1 conv (Res5 conv1 + shortcut, stride_in_1x1) ever reads; bin_step=1 is the reference-identical full mode.
 #include "common.h"
+#include <stdlib.h>
 
 // Workgroups are dealt round-robin over the 8 XCDs (each with its own 4 MB L2). With bin b on XCD b % 8 every XCD touched every
 // RoI: the 19.6 MB of res4 maps were fetched 13x past the L2s (264 MB per forward launch, rocprofv3 FETCH_SIZE). A contiguous run
@@ -55,7 +56,9 @@ __device__ __forceinline__ Taps bilinear_taps(float y, float x, int H, int W) {
 }
 
 // grid: (R * out*out) blocks ; block: C/8 lanes (rounded up to 64)
-template <typename T>
+// SR > 0: sampling_ratio == SR known at compile time -- the SR x SR sample loop is unrolled and all 4 SR^2 tap loads of the bin are issued
+// before the first is used (one memory round trip per workgroup instead of SR^2 dependent ones); same arithmetic in the same order.
+template <typename T, int SR>
 __global__ void roi_align_fwd_kernel(const T* __restrict__ feat, int H, int W, int C, const float* __restrict__ rois,
                                      const int* __restrict__ roi_count, int pooled, int out_size, int bin_step, float scale,
                                      int sampling_ratio, int aligned, T* __restrict__ out) {
@@ -71,6 +74,37 @@ __global__ void roi_align_fwd_kernel(const T* __restrict__ feat, int H, int W, i
   RoiGeom g = roi_geom(rois + 5 * (size_t)r, scale, pooled, sampling_ratio, aligned != 0);
   int ph = oph * bin_step, pw = opw * bin_step;
   const T* f = feat + (size_t)g.b * H * W * C + c0;
+  if constexpr (SR > 0) {
+    Taps t[SR * SR];
+    float v[SR * SR][4][8];
+#pragma unroll
+    for (int iy = 0; iy < SR; ++iy) {
+      float y = g.sh + (float)ph * g.bh + ((float)iy + 0.5f) * g.bh / (float)SR;
+#pragma unroll
+      for (int ix = 0; ix < SR; ++ix) {
+        float x = g.sw + (float)pw * g.bw + ((float)ix + 0.5f) * g.bw / (float)SR;
+        Taps& q = t[iy * SR + ix];
+        q = bilinear_taps(y, x, H, W);            // the taps of an invalid sample are clamped in-range addresses: loaded, not used
+        Vec8<T>::load(f + ((size_t)q.yl * W + q.xl) * C, v[iy * SR + ix][0]);
+        Vec8<T>::load(f + ((size_t)q.yl * W + q.xh) * C, v[iy * SR + ix][1]);
+        Vec8<T>::load(f + ((size_t)q.yh * W + q.xl) * C, v[iy * SR + ix][2]);
+        Vec8<T>::load(f + ((size_t)q.yh * W + q.xh) * C, v[iy * SR + ix][3]);
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < SR * SR; ++k) {
+      if (!t[k].valid) continue;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        float val = t[k].w1 * v[k][0][i] + t[k].w2 * v[k][1][i] + t[k].w3 * v[k][2][i] + t[k].w4 * v[k][3][i];
+        acc[i] += val;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[i] = acc[i] / g.count;
+    Vec8<T>::store(o, acc);
+    return;
+  }
   for (int iy = 0; iy < g.gh; ++iy) {
     float y = g.sh + (float)ph * g.bh + ((float)iy + 0.5f) * g.bh / (float)g.gh;
     for (int ix = 0; ix < g.gw; ++ix) {
@@ -94,6 +128,137 @@ __global__ void roi_align_fwd_kernel(const T* __restrict__ feat, int H, int W, i
   Vec8<T>::store(o, acc);
 }
 
+// sampling_ratio 2, one workgroup per (RoI, row of output bins): the row's bins are walked by the same 128 lanes -- 7x fewer workgroups to
+// dispatch (100 352 two-wave workgroups of ~1 us were launch-rate-bound: 226 us for 2048 RoIs with all 16 tap loads of a bin in flight, 249 us
+// before), the y taps of the row computed once, neighbouring bins' taps re-read from the same CU's L1. Same arithmetic in the same order per bin.
+template <typename T, bool MERGE>
+__global__ void __launch_bounds__(256) roi_align_fwd_row_kernel(const T* __restrict__ feat, int H, int W, int C, const float* __restrict__ rois,
+                                         const int* __restrict__ roi_count, int pooled, int out_size, int bin_step, float scale,
+                                         int aligned, T* __restrict__ out, int rows_per_wg, int groups) {
+  constexpr int SR = 2;
+  int grp = (int)xcd_contiguous(blockIdx.x, gridDim.x);
+  int r = grp / groups, oph0 = (grp - r * groups) * rows_per_wg;
+  int c0 = threadIdx.x * 8;
+  if (c0 >= C) return;
+  bool live = !(roi_count && r >= *roi_count);
+  RoiGeom g = roi_geom(rois + 5 * (size_t)r, scale, pooled, SR, aligned != 0);
+  const T* f = feat + (size_t)g.b * H * W * C + c0;
+  for (int oph = oph0; oph < min(out_size, oph0 + rows_per_wg); ++oph) {
+  T* o = out + (((size_t)r * out_size + oph) * out_size) * C + c0;
+  if (!live) {
+    float z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int opw = 0; opw < out_size; ++opw) Vec8<T>::store(o + (size_t)opw * C, z);
+    continue;
+  }
+  int ph = oph * bin_step;
+  float ys[SR];
+#pragma unroll
+  for (int iy = 0; iy < SR; ++iy) ys[iy] = g.sh + (float)ph * g.bh + ((float)iy + 0.5f) * g.bh / (float)SR;
+  // bf16 maps, `merge`: the four samples of a bin mostly fall into the same one or two pixel rows / columns (a bin is a fraction of a
+  // feature pixel for all but the largest RoIs). The bilinear weights are separable (w = wy * wx, valid = valid_y && valid_x), so the bin is
+  //   sum_k wr[k] * sum_m wc[m] * F[row_k][col_m]   over the up to 4 tap rows / 4 tap columns,
+  // and equal rows (columns) are merged by adding their weights: typically 4-9 loads of 16 B per lane instead of 16, zero-weight taps skipped.
+  // Mathematically the reference's sum in another association: used for bf16 outputs only (fp32 parity mode keeps the reference's order).
+  int rr[4]; float wr[4];
+  if constexpr (MERGE) {
+    {
+#pragma unroll
+      for (int iy = 0; iy < SR; ++iy) {
+        float y = ys[iy];
+        bool vy = !(y < -1.0f || y > (float)H);
+        if (y <= 0.f) y = 0.f;
+        int yl = (int)y, yh;
+        if (yl >= H - 1) { yh = yl = H - 1; y = (float)yl; } else { yh = yl + 1; }
+        float ly = y - (float)yl, hy = 1.0f - ly;
+        rr[2 * iy] = yl; rr[2 * iy + 1] = yh;
+        wr[2 * iy] = vy ? hy : 0.f; wr[2 * iy + 1] = vy ? ly : 0.f;
+      }
+#pragma unroll
+      for (int k = 1; k < 4; ++k)
+#pragma unroll
+        for (int j = 0; j < k; ++j)
+          if (wr[k] != 0.f && rr[k] == rr[j]) { wr[j] += wr[k]; wr[k] = 0.f; }
+    }
+  }
+  for (int opw = 0; opw < out_size; ++opw) {
+    int pw = opw * bin_step;
+    if constexpr (MERGE) {
+      {
+        int cc[4]; float wc[4];
+#pragma unroll
+        for (int ix = 0; ix < SR; ++ix) {
+          float x = g.sw + (float)pw * g.bw + ((float)ix + 0.5f) * g.bw / (float)SR;
+          bool vx = !(x < -1.0f || x > (float)W);
+          if (x <= 0.f) x = 0.f;
+          int xl = (int)x, xh;
+          if (xl >= W - 1) { xh = xl = W - 1; x = (float)xl; } else { xh = xl + 1; }
+          float lx = x - (float)xl, hx = 1.0f - lx;
+          cc[2 * ix] = xl; cc[2 * ix + 1] = xh;
+          wc[2 * ix] = vx ? hx : 0.f; wc[2 * ix + 1] = vx ? lx : 0.f;
+        }
+#pragma unroll
+        for (int k = 1; k < 4; ++k)
+#pragma unroll
+          for (int j = 0; j < k; ++j)
+            if (wc[k] != 0.f && cc[k] == cc[j]) { wc[j] += wc[k]; wc[k] = 0.f; }
+        bf16x8 raw[4][4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+          for (int m = 0; m < 4; ++m)
+            if (wr[k] != 0.f && wc[m] != 0.f) raw[k][m] = *reinterpret_cast<const bf16x8*>(f + ((size_t)rr[k] * W + cc[m]) * C);
+        float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          if (wr[k] == 0.f) continue;
+          float ra[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+          for (int m = 0; m < 4; ++m) {
+            if (wc[m] == 0.f) continue;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) ra[i] += wc[m] * (float)raw[k][m][i];
+          }
+#pragma unroll
+          for (int i = 0; i < 8; ++i) acc[i] += wr[k] * ra[i];
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[i] = acc[i] / g.count;
+        Vec8<T>::store(o + (size_t)opw * C, acc);
+        continue;
+      }
+    }
+    Taps t[SR * SR];
+    float v[SR * SR][4][8];
+#pragma unroll
+    for (int iy = 0; iy < SR; ++iy) {
+#pragma unroll
+      for (int ix = 0; ix < SR; ++ix) {
+        float x = g.sw + (float)pw * g.bw + ((float)ix + 0.5f) * g.bw / (float)SR;
+        Taps& q = t[iy * SR + ix];
+        q = bilinear_taps(ys[iy], x, H, W);
+        Vec8<T>::load(f + ((size_t)q.yl * W + q.xl) * C, v[iy * SR + ix][0]);
+        Vec8<T>::load(f + ((size_t)q.yl * W + q.xh) * C, v[iy * SR + ix][1]);
+        Vec8<T>::load(f + ((size_t)q.yh * W + q.xl) * C, v[iy * SR + ix][2]);
+        Vec8<T>::load(f + ((size_t)q.yh * W + q.xh) * C, v[iy * SR + ix][3]);
+      }
+    }
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int k = 0; k < SR * SR; ++k) {
+      if (!t[k].valid) continue;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        float val = t[k].w1 * v[k][0][i] + t[k].w2 * v[k][1][i] + t[k].w3 * v[k][2][i] + t[k].w4 * v[k][3][i];
+        acc[i] += val;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[i] = acc[i] / g.count;
+    Vec8<T>::store(o + (size_t)opw * C, acc);
+  }
+  }
+}
+
 extern "C" int unit_roi_align_fwd(const void* feat_nhwc, int dtype, int N, int H, int W, int C, const float* rois,
                                   const int* roi_count_dev, int R, int pooled_size, int out_size, int bin_step,
                                   float spatial_scale, int sampling_ratio, int aligned, void* out, void* stream) {
@@ -104,12 +269,33 @@ extern "C" int unit_roi_align_fwd(const void* feat_nhwc, int dtype, int N, int H
   int threads = ((C / 8 + 63) / 64) * 64;
   long blocks = (long)R * out_size * out_size;
   hipStream_t st = (hipStream_t)stream;
-  if (dtype == UNIT_BF16)
-    roi_align_fwd_kernel<bf16_t><<<blocks, threads, 0, st>>>((const bf16_t*)feat_nhwc, H, W, C, rois, roi_count_dev, pooled_size, out_size, bin_step,
-                                                           spatial_scale, sampling_ratio, aligned, (bf16_t*)out);
+  static int row_form = -1;
+  static int merge = 1;
+  if (row_form < 0) {
+    const char* e = getenv("UNIT_ROI_ROW_FORM"); row_form = e ? atoi(e) : 1;
+    e = getenv("UNIT_ROI_MERGE_TAPS"); merge = e ? atoi(e) : 1;
+  }
+  if (sampling_ratio == 2 && row_form && dtype == UNIT_BF16 && threads <= 256) {
+    int rpw = row_form, groups = (out_size + rpw - 1) / rpw;
+    long rows = (long)R * groups;
+    if (dtype == UNIT_BF16 && merge)
+      roi_align_fwd_row_kernel<bf16_t, true><<<rows, threads, 0, st>>>((const bf16_t*)feat_nhwc, H, W, C, rois, roi_count_dev, pooled_size, out_size,
+                                                                     bin_step, spatial_scale, aligned, (bf16_t*)out, rpw, groups);
+    else
+      roi_align_fwd_row_kernel<bf16_t, false><<<rows, threads, 0, st>>>((const bf16_t*)feat_nhwc, H, W, C, rois, roi_count_dev, pooled_size, out_size,
+                                                                      bin_step, spatial_scale, aligned, (bf16_t*)out, rpw, groups);
+    UNIT_LAUNCH_CHECK();
+    return UNIT_OK;
+  }
+  if (dtype == UNIT_BF16 && sampling_ratio == 2)
+    roi_align_fwd_kernel<bf16_t, 2><<<blocks, threads, 0, st>>>((const bf16_t*)feat_nhwc, H, W, C, rois, roi_count_dev, pooled_size, out_size, bin_step,
+                                                              spatial_scale, sampling_ratio, aligned, (bf16_t*)out);
+  else if (dtype == UNIT_BF16)
+    roi_align_fwd_kernel<bf16_t, 0><<<blocks, threads, 0, st>>>((const bf16_t*)feat_nhwc, H, W, C, rois, roi_count_dev, pooled_size, out_size, bin_step,
+                                                              spatial_scale, sampling_ratio, aligned, (bf16_t*)out);
   else
-    roi_align_fwd_kernel<float><<<blocks, threads, 0, st>>>((const float*)feat_nhwc, H, W, C, rois, roi_count_dev, pooled_size, out_size, bin_step,
-                                                          spatial_scale, sampling_ratio, aligned, (float*)out);
+    roi_align_fwd_kernel<float, 0><<<blocks, threads, 0, st>>>((const float*)feat_nhwc, H, W, C, rois, roi_count_dev, pooled_size, out_size, bin_step,
+                                                             spatial_scale, sampling_ratio, aligned, (float*)out);
   UNIT_LAUNCH_CHECK();
   return UNIT_OK;
 }
