@@ -16,6 +16,7 @@ for scale in (1.0, 0.5):
         out.append(torch.cat([torch.full((s, 1), float(i)), xy, xy + wh], 1))
     rois = torch.cat(out, 0).to(dev)
     y = torch.empty(n * s, 7, 7, c, device=dev, dtype=torch.bfloat16)
-    ms = timeit(lambda: o.roi_align(feat, rois, 14, 7, 2, 1.0 / 16, 2, True, out=y), iters=20)
-    nb = (feat.numel() + y.numel()) * 2
-    print(f"box scale {scale}: {ms * 1e3:.1f} us  ({nb / ms / 1e6:.0f} GB/s on maps + pooled output)")
+    for sr in (2, 0):          # 0 = adaptive grid ceil(roi / pooled), the configuration of the step (POOLER_SAMPLING_RATIO 0)
+        ms = timeit(lambda: o.roi_align(feat, rois, 14, 7, 2, 1.0 / 16, sr, True, out=y), iters=20)
+        nb = (feat.numel() + y.numel()) * 2
+        print(f"box scale {scale} sampling_ratio {sr}: {ms * 1e3:.1f} us  ({nb / ms / 1e6:.0f} GB/s on maps + pooled output)")

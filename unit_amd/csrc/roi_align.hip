@@ -128,134 +128,122 @@ __global__ void roi_align_fwd_kernel(const T* __restrict__ feat, int H, int W, i
   Vec8<T>::store(o, acc);
 }
 
-// sampling_ratio 2, one workgroup per (RoI, row of output bins): the row's bins are walked by the same 128 lanes -- 7x fewer workgroups to
-// dispatch (100 352 two-wave workgroups of ~1 us were launch-rate-bound: 226 us for 2048 RoIs with all 16 tap loads of a bin in flight, 249 us
-// before), the y taps of the row computed once, neighbouring bins' taps re-read from the same CU's L1. Same arithmetic in the same order per bin.
-template <typename T, bool MERGE>
+// bf16, one workgroup per (RoI, row of output bins): the row's bins are walked by the same lanes -- 7x fewer workgroups to dispatch (100 352
+// two-wave workgroups of ~1 us were launch-rate-bound: 226 us for 2048 RoIs even with all tap loads of a bin in flight, 249 us before), the y
+// taps of the row computed once, neighbouring bins' taps re-read through the same CU's L1.
+// Sampling grids up to 2 x 2 per bin (sampling_ratio 1 or 2, or the adaptive ceil(roi / pooled) of sampling_ratio 0 for RoIs up to 2 x pooled
+// feature pixels: nearly all of them): the samples of a bin mostly fall into the same one or two pixel rows / columns. The bilinear weights
+// are separable (w = wy * wx, valid = valid_y && valid_x), so the bin is
+//     (1 / count) * sum_k wr[k] * sum_m wc[m] * F[row_k][col_m]        over the up to 4 tap rows x 4 tap columns,
+// and equal rows (columns) are merged by adding their weights: typically 4-9 loads of 16 B per lane instead of 16, zero-weight taps skipped,
+// all of them in flight before the first is used. Mathematically the reference's sum in another association: bf16 outputs only (the fp32
+// parity mode runs roi_align_fwd_kernel, the reference's order). Larger grids: the reference's per-sample loop, row form.
+__device__ __forceinline__ void taps_1d(float v, int n, bool& ok, int& lo, int& hi, float& wlo, float& whi) {
+  ok = !(v < -1.0f || v > (float)n);
+  if (v <= 0.f) v = 0.f;
+  lo = (int)v;
+  if (lo >= n - 1) { hi = lo = n - 1; v = (float)lo; } else { hi = lo + 1; }
+  whi = v - (float)lo; wlo = 1.0f - whi;
+}
+
+template <typename T>
 __global__ void __launch_bounds__(256) roi_align_fwd_row_kernel(const T* __restrict__ feat, int H, int W, int C, const float* __restrict__ rois,
-                                         const int* __restrict__ roi_count, int pooled, int out_size, int bin_step, float scale,
-                                         int aligned, T* __restrict__ out, int rows_per_wg, int groups) {
-  constexpr int SR = 2;
-  int grp = (int)xcd_contiguous(blockIdx.x, gridDim.x);
-  int r = grp / groups, oph0 = (grp - r * groups) * rows_per_wg;
+                                                                const int* __restrict__ roi_count, int pooled, int out_size, int bin_step,
+                                                                float scale, int sampling_ratio, int aligned, T* __restrict__ out) {
+  int row = (int)xcd_contiguous(blockIdx.x, gridDim.x);
+  int r = row / out_size, oph = row - r * out_size;
   int c0 = threadIdx.x * 8;
   if (c0 >= C) return;
-  bool live = !(roi_count && r >= *roi_count);
-  RoiGeom g = roi_geom(rois + 5 * (size_t)r, scale, pooled, SR, aligned != 0);
-  const T* f = feat + (size_t)g.b * H * W * C + c0;
-  for (int oph = oph0; oph < min(out_size, oph0 + rows_per_wg); ++oph) {
-  T* o = out + (((size_t)r * out_size + oph) * out_size) * C + c0;
-  if (!live) {
+  T* o = out + ((size_t)row * out_size) * C + c0;
+  if (roi_count && r >= *roi_count) {
     float z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     for (int opw = 0; opw < out_size; ++opw) Vec8<T>::store(o + (size_t)opw * C, z);
-    continue;
+    return;
   }
+  RoiGeom g = roi_geom(rois + 5 * (size_t)r, scale, pooled, sampling_ratio, aligned != 0);
   int ph = oph * bin_step;
-  float ys[SR];
+  const T* f = feat + (size_t)g.b * H * W * C + c0;
+  if (g.gh <= 2 && g.gw <= 2) {
+    int rr[4]; float wr[4];
 #pragma unroll
-  for (int iy = 0; iy < SR; ++iy) ys[iy] = g.sh + (float)ph * g.bh + ((float)iy + 0.5f) * g.bh / (float)SR;
-  // bf16 maps, `merge`: the four samples of a bin mostly fall into the same one or two pixel rows / columns (a bin is a fraction of a
-  // feature pixel for all but the largest RoIs). The bilinear weights are separable (w = wy * wx, valid = valid_y && valid_x), so the bin is
-  //   sum_k wr[k] * sum_m wc[m] * F[row_k][col_m]   over the up to 4 tap rows / 4 tap columns,
-  // and equal rows (columns) are merged by adding their weights: typically 4-9 loads of 16 B per lane instead of 16, zero-weight taps skipped.
-  // Mathematically the reference's sum in another association: used for bf16 outputs only (fp32 parity mode keeps the reference's order).
-  int rr[4]; float wr[4];
-  if constexpr (MERGE) {
-    {
+    for (int iy = 0; iy < 2; ++iy) {
+      float y = g.sh + (float)ph * g.bh + ((float)iy + 0.5f) * g.bh / (float)g.gh;
+      bool ok; float wl, wh;
+      taps_1d(y, H, ok, rr[2 * iy], rr[2 * iy + 1], wl, wh);
+      ok = ok && iy < g.gh;
+      wr[2 * iy] = ok ? wl : 0.f; wr[2 * iy + 1] = ok ? wh : 0.f;
+    }
 #pragma unroll
-      for (int iy = 0; iy < SR; ++iy) {
-        float y = ys[iy];
-        bool vy = !(y < -1.0f || y > (float)H);
-        if (y <= 0.f) y = 0.f;
-        int yl = (int)y, yh;
-        if (yl >= H - 1) { yh = yl = H - 1; y = (float)yl; } else { yh = yl + 1; }
-        float ly = y - (float)yl, hy = 1.0f - ly;
-        rr[2 * iy] = yl; rr[2 * iy + 1] = yh;
-        wr[2 * iy] = vy ? hy : 0.f; wr[2 * iy + 1] = vy ? ly : 0.f;
+    for (int k = 1; k < 4; ++k)
+#pragma unroll
+      for (int j = 0; j < k; ++j)
+        if (wr[k] != 0.f && rr[k] == rr[j]) { wr[j] += wr[k]; wr[k] = 0.f; }
+    for (int opw = 0; opw < out_size; ++opw) {
+      int pw = opw * bin_step;
+      int cc[4]; float wc[4];
+#pragma unroll
+      for (int ix = 0; ix < 2; ++ix) {
+        float x = g.sw + (float)pw * g.bw + ((float)ix + 0.5f) * g.bw / (float)g.gw;
+        bool ok; float wl, wh;
+        taps_1d(x, W, ok, cc[2 * ix], cc[2 * ix + 1], wl, wh);
+        ok = ok && ix < g.gw;
+        wc[2 * ix] = ok ? wl : 0.f; wc[2 * ix + 1] = ok ? wh : 0.f;
       }
 #pragma unroll
       for (int k = 1; k < 4; ++k)
 #pragma unroll
         for (int j = 0; j < k; ++j)
-          if (wr[k] != 0.f && rr[k] == rr[j]) { wr[j] += wr[k]; wr[k] = 0.f; }
+          if (wc[k] != 0.f && cc[k] == cc[j]) { wc[j] += wc[k]; wc[k] = 0.f; }
+      bf16x8 raw[4][4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+          if (wr[k] != 0.f && wc[m] != 0.f) raw[k][m] = *reinterpret_cast<const bf16x8*>(f + ((size_t)rr[k] * W + cc[m]) * C);
+      float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        if (wr[k] == 0.f) continue;
+        float ra[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+          if (wc[m] == 0.f) continue;
+#pragma unroll
+          for (int i = 0; i < 8; ++i) ra[i] += wc[m] * (float)raw[k][m][i];
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[i] += wr[k] * ra[i];
+      }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) acc[i] = acc[i] / g.count;
+      Vec8<T>::store(o + (size_t)opw * C, acc);
     }
+    return;
   }
-  for (int opw = 0; opw < out_size; ++opw) {
+  for (int opw = 0; opw < out_size; ++opw) {          // large RoIs (more than 2 samples per bin and axis): the reference's loop
     int pw = opw * bin_step;
-    if constexpr (MERGE) {
-      {
-        int cc[4]; float wc[4];
-#pragma unroll
-        for (int ix = 0; ix < SR; ++ix) {
-          float x = g.sw + (float)pw * g.bw + ((float)ix + 0.5f) * g.bw / (float)SR;
-          bool vx = !(x < -1.0f || x > (float)W);
-          if (x <= 0.f) x = 0.f;
-          int xl = (int)x, xh;
-          if (xl >= W - 1) { xh = xl = W - 1; x = (float)xl; } else { xh = xl + 1; }
-          float lx = x - (float)xl, hx = 1.0f - lx;
-          cc[2 * ix] = xl; cc[2 * ix + 1] = xh;
-          wc[2 * ix] = vx ? hx : 0.f; wc[2 * ix + 1] = vx ? lx : 0.f;
-        }
-#pragma unroll
-        for (int k = 1; k < 4; ++k)
-#pragma unroll
-          for (int j = 0; j < k; ++j)
-            if (wc[k] != 0.f && cc[k] == cc[j]) { wc[j] += wc[k]; wc[k] = 0.f; }
-        bf16x8 raw[4][4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k)
-#pragma unroll
-          for (int m = 0; m < 4; ++m)
-            if (wr[k] != 0.f && wc[m] != 0.f) raw[k][m] = *reinterpret_cast<const bf16x8*>(f + ((size_t)rr[k] * W + cc[m]) * C);
-        float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          if (wr[k] == 0.f) continue;
-          float ra[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-#pragma unroll
-          for (int m = 0; m < 4; ++m) {
-            if (wc[m] == 0.f) continue;
-#pragma unroll
-            for (int i = 0; i < 8; ++i) ra[i] += wc[m] * (float)raw[k][m][i];
-          }
-#pragma unroll
-          for (int i = 0; i < 8; ++i) acc[i] += wr[k] * ra[i];
-        }
-#pragma unroll
-        for (int i = 0; i < 8; ++i) acc[i] = acc[i] / g.count;
-        Vec8<T>::store(o + (size_t)opw * C, acc);
-        continue;
-      }
-    }
-    Taps t[SR * SR];
-    float v[SR * SR][4][8];
-#pragma unroll
-    for (int iy = 0; iy < SR; ++iy) {
-#pragma unroll
-      for (int ix = 0; ix < SR; ++ix) {
-        float x = g.sw + (float)pw * g.bw + ((float)ix + 0.5f) * g.bw / (float)SR;
-        Taps& q = t[iy * SR + ix];
-        q = bilinear_taps(ys[iy], x, H, W);
-        Vec8<T>::load(f + ((size_t)q.yl * W + q.xl) * C, v[iy * SR + ix][0]);
-        Vec8<T>::load(f + ((size_t)q.yl * W + q.xh) * C, v[iy * SR + ix][1]);
-        Vec8<T>::load(f + ((size_t)q.yh * W + q.xl) * C, v[iy * SR + ix][2]);
-        Vec8<T>::load(f + ((size_t)q.yh * W + q.xh) * C, v[iy * SR + ix][3]);
-      }
-    }
     float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int iy = 0; iy < g.gh; ++iy) {
+      float y = g.sh + (float)ph * g.bh + ((float)iy + 0.5f) * g.bh / (float)g.gh;
+      for (int ix = 0; ix < g.gw; ++ix) {
+        float x = g.sw + (float)pw * g.bw + ((float)ix + 0.5f) * g.bw / (float)g.gw;
+        Taps t = bilinear_taps(y, x, H, W);
+        if (!t.valid) continue;
+        float v1[8], v2[8], v3[8], v4[8];
+        Vec8<T>::load(f + ((size_t)t.yl * W + t.xl) * C, v1);
+        Vec8<T>::load(f + ((size_t)t.yl * W + t.xh) * C, v2);
+        Vec8<T>::load(f + ((size_t)t.yh * W + t.xl) * C, v3);
+        Vec8<T>::load(f + ((size_t)t.yh * W + t.xh) * C, v4);
 #pragma unroll
-    for (int k = 0; k < SR * SR; ++k) {
-      if (!t[k].valid) continue;
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        float val = t[k].w1 * v[k][0][i] + t[k].w2 * v[k][1][i] + t[k].w3 * v[k][2][i] + t[k].w4 * v[k][3][i];
-        acc[i] += val;
+        for (int i = 0; i < 8; ++i) {
+          float val = t.w1 * v1[i] + t.w2 * v2[i] + t.w3 * v3[i] + t.w4 * v4[i];
+          acc[i] += val;
+        }
       }
     }
 #pragma unroll
     for (int i = 0; i < 8; ++i) acc[i] = acc[i] / g.count;
     Vec8<T>::store(o + (size_t)opw * C, acc);
-  }
   }
 }
 
@@ -270,20 +258,10 @@ extern "C" int unit_roi_align_fwd(const void* feat_nhwc, int dtype, int N, int H
   long blocks = (long)R * out_size * out_size;
   hipStream_t st = (hipStream_t)stream;
   static int row_form = -1;
-  static int merge = 1;
-  if (row_form < 0) {
-    const char* e = getenv("UNIT_ROI_ROW_FORM"); row_form = e ? atoi(e) : 1;
-    e = getenv("UNIT_ROI_MERGE_TAPS"); merge = e ? atoi(e) : 1;
-  }
-  if (sampling_ratio == 2 && row_form && dtype == UNIT_BF16 && threads <= 256) {
-    int rpw = row_form, groups = (out_size + rpw - 1) / rpw;
-    long rows = (long)R * groups;
-    if (dtype == UNIT_BF16 && merge)
-      roi_align_fwd_row_kernel<bf16_t, true><<<rows, threads, 0, st>>>((const bf16_t*)feat_nhwc, H, W, C, rois, roi_count_dev, pooled_size, out_size,
-                                                                     bin_step, spatial_scale, aligned, (bf16_t*)out, rpw, groups);
-    else
-      roi_align_fwd_row_kernel<bf16_t, false><<<rows, threads, 0, st>>>((const bf16_t*)feat_nhwc, H, W, C, rois, roi_count_dev, pooled_size, out_size,
-                                                                      bin_step, spatial_scale, aligned, (bf16_t*)out, rpw, groups);
+  if (row_form < 0) { const char* e = getenv("UNIT_ROI_ROW_FORM"); row_form = e ? atoi(e) : 1; }
+  if (row_form && dtype == UNIT_BF16 && threads <= 256) {
+    roi_align_fwd_row_kernel<bf16_t><<<(long)R * out_size, threads, 0, st>>>((const bf16_t*)feat_nhwc, H, W, C, rois, roi_count_dev, pooled_size, out_size,
+                                                                           bin_step, spatial_scale, sampling_ratio, aligned, (bf16_t*)out);
     UNIT_LAUNCH_CHECK();
     return UNIT_OK;
   }
