@@ -266,6 +266,8 @@ def voc_shapes_run(args, cfg, model, buckets, opt, rank, world, dev):
     if rank == 0:
         two_pass = sum(1 for s_hw, w_hw in plan[warm:] if (max(h for h, _ in s_hw), max(w for _, w in s_hw)) != (max(h for h, _ in w_hw), max(w for _, w in w_hw)))
         px = sum(h * w for s_hw, w_hw in plan[warm:] for h, w in s_hw + w_hw) / steps
+        # what the kernels see: every batch of two is padded to its own largest height x largest width (ImageList.from_tensors)
+        padded = sum(len(b) * max(h for h, _ in b) * max(w for _, w in b) for s_hw, w_hw in plan[warm:] for b in (s_hw, w_hw)) / steps
         out = {"metric": "images/sec (fwd+bwd+SGD) R101-C4 VOC, multi-scale VOC-shaped batches (SECONDARY line, not BASELINE.json's metric)",
                "headline": False, "value": round(2 * world * steps / dt, 3), "unit": "images/sec", "n_gpus": world, "steps": steps, "warmup": warm,
                "ms_per_step": round(dt / steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype,
@@ -277,6 +279,7 @@ def voc_shapes_run(args, cfg, model, buckets, opt, rank, world, dev):
                                       "(configs/VOC/VOC-RCNN-101-C4-split1.yaml:27-29, data/build.py:476-497), 512 RoIs/image, 12000->2000",
                           "images_per_gpu": 2, "global_batch": 2 * world, "parallelism": f"dp{world}",
                           "mean_pixels_per_step": round(px), "pixels_relative_to_the_600x1000_workload": round(px / (4 * 600 * 1000), 3),
+                          "mean_padded_pixels_per_step": round(padded), "padded_pixels_relative_to_the_600x1000_workload": round(padded / (4 * 600 * 1000), 3),
                           "steps_on_the_two_pass_backbone_path": two_pass},
                "shape_churn": {"tile_policy_cache_misses": len(ops._POLICY_CACHE) - pol0, "scratch_buffer_growths": ops.WS_GROWTHS[0] - ws0,
                                "device_mallocs": mem1.get("num_device_alloc", 0) - mem0.get("num_device_alloc", 0),
