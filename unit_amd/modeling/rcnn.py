@@ -127,6 +127,7 @@ class WeaklySupervisedRCNNNoMeta(nn.Module):
         self.early_rpn_wgrad = os.environ.get("UNIT_EARLY_RPN_WGRAD", "1") != "0"
         self.early_sup_backward = os.environ.get("UNIT_EARLY_SUP_BWD", "1") != "0"
         self.sup_predictor_on_head_stream = os.environ.get("UNIT_SUP_PRED_ON_HEAD", "1") != "0"
+        self.decoupled_sup_chain = os.environ.get("UNIT_DECOUPLED_SUP_CHAIN", "1") != "0"
         self._tail_pending = None
         self.overlap_streams = True
         self.split_weak_head = __import__("os").environ.get("UNIT_SPLIT_WEAK", "1") != "0"     # forward plan: weak_box_head as two 1024-RoI passes
@@ -495,6 +496,7 @@ class WeaklySupervisedRCNNNoMeta(nn.Module):
         multi = rh.weak_box_head is not None
         box_trainable = any(p.requires_grad for p in rh.box_head.parameters())
         c.head_overlap = False
+        sup_rows_done = None
         c.weak_ctx_rows = slice(rs, rs + rw)         # rows of the weak RoIs inside weak_box_head's saved context
         if multi:
             if rs > 0 and self._streams_on() and getattr(rh, "mask_head", None) is None:
@@ -516,11 +518,14 @@ class WeaklySupervisedRCNNNoMeta(nn.Module):
                     wfeat_all.record_stream(s3)
                     with torch.cuda.stream(s3):
                         f_sup, _ = rh.weak_box_head.fwd(pooled[:rs], save=False, feat_out=wfeat_all[:rs])
+                        sup_rows_done = torch.cuda.Event()          # weak_box_head's features of the supervised RoIs are complete here
+                        sup_rows_done.record()
                     f_weak, c.weak_ctx = rh.weak_box_head.fwd(pooled[rs:], save=True, feat_out=wfeat_all[rs:])
                     main.wait_stream(s3)
                     if f_sup.data_ptr() != wfeat_all.data_ptr() or f_weak.data_ptr() != wfeat_all[rs:].data_ptr():
                         f_sup.record_stream(main)          # (a head form without the fused pooling epilogue returned its own buffers)
                         wfeat_all = torch.cat([f_sup, f_weak], 0)
+                        sup_rows_done = None
                     c.weak_ctx_rows = None               # the context covers exactly the weak RoIs
                 else:
                     wfeat_all, c.weak_ctx = rh.weak_box_head.fwd(pooled, save=(rw > 0))
@@ -567,13 +572,25 @@ class WeaklySupervisedRCNNNoMeta(nn.Module):
             run_mask()
 
         # a10-a12 predictors + losses (+ gradients w.r.t. the Linear outputs)
-        lin_sup = None
+        lin_sup = lin_weak_sup = None
         if rs > 0 and rw > 0 and c.head_overlap and self.sup_predictor_on_head_stream and not getattr(bp, "finetune", False):
             # box_head's features were produced on the head stream and its losses will run there: the supervised predictors' GEMM goes there
             # too, at once, instead of queueing behind the weak predictors' on this stream (two 16- / 32-workgroup launches of ~25 us each)
             with torch.cuda.stream(self._head_stream):
                 lin_sup = bp.group.fwd(c.box_feat)
-        lin_weak_all = bp.weak_detector_head.group.fwd(wfeat_all)            # [rs+rw, 104] (oicr cols feed the sup scores)
+                if sup_rows_done is not None and self.decoupled_sup_chain and not torch.cuda.is_current_stream_capturing():
+                    # (eager launches only: hipStreamEndCapture of ROCm 7.2 segfaults on the capture of this cross-stream event wait)
+                    # three-chain form: the weak predictors' outputs on the SUPERVISED RoIs (the OICR columns that feed the supervised scores)
+                    # need the chain on the weight-gradient stream only -- with them computed here, the supervised losses and (early_sup_backward)
+                    # box_head's backward no longer wait for weak_box_head's pass over the weak RoIs on the main stream, the longest of the three
+                    self._head_stream.wait_event(sup_rows_done)
+                    lin_weak_sup = bp.weak_detector_head.group.fwd(wfeat_all[:rs])
+        decoupled = lin_weak_sup is not None
+        if decoupled:
+            lin_weak_w = bp.weak_detector_head.group.fwd(wfeat_all[rs:])
+        else:
+            lin_weak_all = bp.weak_detector_head.group.fwd(wfeat_all)            # [rs+rw, 104] (oicr cols feed the sup scores)
+            lin_weak_sup, lin_weak_w = lin_weak_all[:rs], lin_weak_all[rs:]
         c.dy_sup = c.dy_weak = None
         sup_side = None
         if rs > 0:
@@ -589,7 +606,7 @@ class WeaklySupervisedRCNNNoMeta(nn.Module):
                 c.lin_w_box = wh.group.fwd(c.box_feat)
                 sims, lingual, keys = similarity_dict(self, c.lin_w_box, want_ctx=True)
                 t = class_roles(self)
-                c.scores, bbox = ops.transfer_predictions(lin_sup, bp.col_cls, bp.col_bbox, rh.num_classes, lin_weak_all[:rs], wh.col_oicr[0],
+                c.scores, bbox = ops.transfer_predictions(lin_sup, bp.col_cls, bp.col_bbox, rh.num_classes, lin_weak_sup, wh.col_oicr[0],
                                                           wh.oicr_iter, sims["cls"], sims["bbox"], t["base"], t["novel"], t["role"], t["slot"],
                                                           ft=lin_ft, fccol0=bp.col_cls, fbcol0=bp.col_bbox)
                 c.dy_sup = bp.ft_losses(c.scores, bbox, c.roi_cls, c.rois[:rs], c.roi_gt, c.losses[0:2], dt)
@@ -599,13 +616,13 @@ class WeaklySupervisedRCNNNoMeta(nn.Module):
             else:
                 # the supervised losses (5 small launches) do not depend on the weak chain: they run on the head stream beside it
                 sup_side = self._head_stream if (rw > 0 and self._streams_on()) else None
-                if sup_side is not None:
+                if sup_side is not None and not decoupled:
                     sup_side.wait_stream(torch.cuda.current_stream())
                 with torch.cuda.stream(sup_side) if sup_side is not None else contextlib.nullcontext():
-                    c.dy_sup, c.scores = bp.sup_losses(lin_sup, lin_weak_all[:rs], c.roi_cls, c.rois[:rs], c.roi_gt, c.losses[0:2], dt)
+                    c.dy_sup, c.scores = bp.sup_losses(lin_sup, lin_weak_sup, c.roi_cls, c.rois[:rs], c.roi_gt, c.losses[0:2], dt)
                 c.sup_losses_on_head_stream = sup_side is not None
         if rw > 0:
-            c.dy_weak = bp.weak_detector_head.fused_losses(lin_weak_all[rs:], c.rois[rs:], c.weak_valid, s // rh.weak_divisor, n_weak,
+            c.dy_weak = bp.weak_detector_head.fused_losses(lin_weak_w, c.rois[rs:], c.weak_valid, s // rh.weak_divisor, n_weak,
                                                      batch.multihot, c.losses[2:6], dt,
                                                      side_stream=self._rpn_stream if self._streams_on() else None)
         if sup_side is not None:
