@@ -1019,6 +1019,31 @@ def test_roi_align_fwd_bwd(dev, c):
     assert np.allclose(nchw(gots).numpy(), refs, rtol=1e-4, atol=1e-4)
 
 
+@pytest.mark.parametrize("sr", [0, 1, 2, 3])
+def test_roi_align_bf16_row_kernel_against_the_oracle(dev, sr):
+    """bf16 RoIAlign forward (one workgroup per row of bins; sampling grids up to 2 x 2 through merged separable taps, larger grids through the
+    reference's per-sample loop) against the oracle on the bf16-rounded map: the merged form is the reference's sum in another association,
+    so an output may sit one bf16 rounding step away -- rtol 2^-7, atol 2e-3 for sums that cancel. RoIs from a tenth of a bin to several
+    pixels per bin, partly outside the map, a zero-area one; adaptive (0) and fixed sampling ratios; full and strided (7 of 14) bins."""
+    o = ops()
+    gen = g(12)
+    n, h, w, c, r = 2, 38, 63, 256, 96
+    feat = torch.randn(n, c, h, w, generator=gen)
+    rois = make_rois(gen, r, n)
+    small = torch.rand(24, 4, generator=gen)
+    rois[3:27, 1:3] = small[:, :2] * 500 + 20
+    rois[3:27, 3:5] = rois[3:27, 1:3] + small[:, 2:] * 40 + 2          # boxes of 2 .. 42 px: a fraction of a feature pixel per bin
+    fb = feat.bfloat16()
+    ref = orc.roi_align_forward(fb.float().numpy(), rois.numpy(), sampling_ratio=sr)
+    got = o.roi_align(nhwc(fb.float()).to(dev).bfloat16(), rois.to(dev), sampling_ratio=sr).float().cpu()
+    assert np.allclose(nchw(got).numpy(), ref, rtol=2.0 ** -7, atol=2e-3)
+    got_s = o.roi_align(nhwc(fb.float()).to(dev).bfloat16(), rois.to(dev), pooled_size=14, out_size=7, bin_step=2, sampling_ratio=sr).float().cpu()
+    assert torch.equal(got_s, got[:, ::2, ::2, :])
+    cnt = torch.tensor([r - 10], dtype=torch.int32, device=dev)          # RoI slots past the count come back zero
+    got_c = o.roi_align(nhwc(fb.float()).to(dev).bfloat16(), rois.to(dev), sampling_ratio=sr, roi_count=cnt).float().cpu()
+    assert torch.equal(got_c[: r - 10], got[: r - 10]) and float(got_c[r - 10:].abs().max()) == 0.0
+
+
 @pytest.mark.parametrize("mode", [(14, 1), (7, 2)])
 def test_roi_align_bwd_gather(dev, mode):
     """deterministic gather-form backward == the fp64-accumulated oracle; fixed-slot hint, image offset, fused
