@@ -1321,6 +1321,39 @@ def test_conv_fused_pool_is_reproducible(dev):
         assert torch.isfinite(p0.float()).all()
 
 
+@pytest.mark.parametrize("shape", [(2, 75, 125), (1, 150, 250), (1, 37, 41)])
+def test_res2_first_block_dual_gemm_forward(dev, shape):
+    """frozen res2.0 in bf16: relu(conv3(y2) + shortcut(x)) as ONE dual-input GEMM over [y2 | x] (K = 64 + 64: two k-steps of the 256 x 256
+    kernel) against the two-kernel form and the fp32 block. The dual form adds both products in fp32 where the separate kernels round the
+    shortcut's output to bf16 first: it must be at least as close to fp32 as they are, and within two bf16 steps of them."""
+    from unit_amd import ops as o
+    from unit_amd.layers import BottleneckBlock
+    torch.manual_seed(3)
+    n, h, w = shape
+    blk = BottleneckBlock(64, 256, 64, 1).to(dev)
+    for c in blk.convs():
+        torch.nn.init.normal_(c.weight, std=(2.0 / (c.cout * c.k * c.k)) ** 0.5)
+        c.norm.weight.uniform_(0.5, 1.5)
+        c.norm.bias.uniform_(-0.2, 0.2)
+        c.weight.requires_grad = False
+    x = torch.relu(torch.randn(n, h, w, 64, device=dev)).bfloat16()
+    for c in blk.convs():
+        c.prepare(torch.bfloat16, 0, need_dgrad=False)
+    blk.allow_dual = True
+    assert blk._dual_ok(x, x, 1)
+    y_dual, _ = blk.fwd(x)
+    blk.allow_dual = False
+    y_sep, _ = blk.fwd(x)
+    for c in blk.convs():
+        c.prepare(torch.float32, 1, need_dgrad=False)
+    y32, _ = blk.fwd(x.float())
+    assert y_dual.shape == y_sep.shape == y32.shape
+    e_dual = float((y_dual.float() - y32).abs().mean()); e_sep = float((y_sep.float() - y32).abs().mean())
+    assert e_dual <= e_sep * 1.02 + 1e-6, (e_dual, e_sep)
+    assert torch.allclose(y_dual.float(), y_sep.float(), rtol=2.0 ** -6, atol=2e-2)
+    assert torch.allclose(y_dual.float(), y32, rtol=2.0 ** -6, atol=3e-2)
+
+
 @pytest.mark.parametrize("rois,lo,dual", [(128, 0, False), (256, 128, False), (40, 13, False), (256, 128, True)])
 def test_res5_head_fused_epilogues_equal_separate_kernels(dev, rois, lo, dual):
     """Res5BoxHead in bf16 with the fused epilogues (average pool + ReLU bit masks inside the convs) against the same head with the
