@@ -56,6 +56,20 @@ class _Chain:
         self.works = []
 
 
+class _EventWork:
+    """work handle of collectives that were enqueued ON a stream of ours (`GradBuckets._collective_stream`): waiting = the current stream
+    waits for the event recorded behind them; waiting twice is harmless"""
+
+    def __init__(self, event):
+        self.event = event
+
+    def wait(self):
+        if self.event is not None:
+            import torch
+            torch.cuda.current_stream().wait_event(self.event)
+            self.event = None
+
+
 class GradBuckets:
     def __init__(self, model, group=None, bucket_bytes=None, bf16=False, mode=None, force=None):
         """bf16: exchange a bf16 copy of every bucket (half the bytes over xGMI: 134 instead of 268 MB per step for R101 S1) and
@@ -81,7 +95,18 @@ class GradBuckets:
         self._tag_works = {}
         self._plan = None
         self._recv = {}                 # "direct": receive buffers of the all-to-all, keyed by (elements, dtype)
-        self._comm_stream = None        # "direct": the stream the all-to-all -> shard sum -> all-gather chain of a bucket is ordered on
+        self._comm_stream = None        # the stream a bucket's collectives are enqueued on (see _collective_stream)
+        # WHERE the RCCL kernels run. torch.distributed's nccl backend enqueues a collective with async_op=False on the caller's CURRENT stream
+        # and one with async_op=True on a stream of its own (tools/nccl_stream_probe.py under rocprofv3, torch 2.10). A process's HIP streams
+        # share 4 hardware queues, and that internal stream lands on whichever queue the runtime deals it: in the traced
+        # forced-collective run, the weight-gradient stream's -- where an 8-GPU all-reduce of a 64 MB bucket (milliseconds, not the
+        # microseconds of world size 1) would have run strictly in turn with the weight-gradient kernels it is meant to overlap; on the
+        # main stream's queue it would stall the dgrad chain. So the collectives of a bucket are enqueued synchronously on a stream WE place:
+        # "rpn" (default) = the model's RPN-branch stream, idle during the backward and on a hardware queue of its own by measurement
+        # (ops.streams_on_distinct_queues); "own" = a fresh stream; "internal" = torch's (the behaviour until round 4).
+        self.collective_stream = os.environ.get("UNIT_COLLECTIVE_STREAM", "rpn")
+        if self.collective_stream not in ("rpn", "own", "internal"):
+            raise ValueError("UNIT_COLLECTIVE_STREAM: rpn | own | internal")
         self.launched = 0               # collectives launched so far (tests / bench line)
         self.exposed_events = None      # bench.py: a list -> finish() brackets its waits with a HIP-event pair on the compute stream
         model.on_grad_ready = self.ready if self.active else None
@@ -99,7 +124,8 @@ class GradBuckets:
                 ver = None
         return {"backend": ("rccl (torch.distributed 'nccl')" if backend == "nccl" else backend), "ranks_seen": self.world,
                 "rccl_version": ver, "reduce_mode": self.mode, "bucket_mb": round(self.bucket_bytes / (1 << 20), 2),
-                "bf16_buckets": bool(self.bf16), "collectives_forced_at_world_1": bool(self.active and self.world == 1)}
+                "bf16_buckets": bool(self.bf16), "collectives_forced_at_world_1": bool(self.active and self.world == 1),
+                "collective_stream": self.collective_stream}
 
     def _build(self):
         st = self.model.store
@@ -138,9 +164,66 @@ class GradBuckets:
             self.model.version += 1
 
     # ------------------------------------------------------------------------------------------------ one bucket
+    def _collective_stream(self, device):
+        """the HIP stream the collectives of device buckets are enqueued on; None = torch's internal stream (async_op=True)"""
+        if self.collective_stream == "internal" or device.type != "cuda":
+            return None
+        import torch
+        if self.collective_stream == "rpn":
+            on = getattr(self.model, "_streams_on", None)
+            if on is not None and on():
+                return self.model._rpn_stream
+        if self._comm_stream is None:
+            self._comm_stream = torch.cuda.Stream(device)
+        return self._comm_stream
+
+    def _exchange_placed(self, t, cs):
+        """the exchange of _exchange with every collective enqueued synchronously on `cs` (behind the current stream's work so far), one event
+        behind the last of them as the work handle. Nothing blocks the host: a synchronous nccl collective is an enqueue."""
+        import torch
+        n, w, r = t.numel(), self.world, self.rank
+        cs.wait_stream(torch.cuda.current_stream())          # the bucket's gradients are final where the caller stands
+        t.record_stream(cs)
+        with torch.cuda.stream(cs):
+            if self.mode == "allreduce" or n < w:
+                dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+                self.launched += 1
+            else:
+                per = n // w
+                main = per * w
+                shard = t[r * per:(r + 1) * per]
+                if main < n:
+                    dist.all_reduce(t[main:], op=dist.ReduceOp.SUM, group=self.group)
+                    self.launched += 1
+                if self.mode == "rs_ag":
+                    dist.reduce_scatter_tensor(shard, t[:main], op=dist.ReduceOp.SUM, group=self.group)
+                    dist.all_gather_into_tensor(t[:main], shard, group=self.group)
+                else:      # "direct"
+                    from . import ops
+                    key = (main, t.dtype)
+                    recv = self._recv.get(key)
+                    if recv is None or recv.device != t.device:
+                        recv = self._recv[key] = torch.empty(main, dtype=t.dtype, device=t.device)
+                    recv.record_stream(cs)
+                    dist.all_to_all_single(recv, t[:main], group=self.group)
+                    if t.dtype == torch.float32:
+                        ops.shard_sum(recv.view(w, per), shard)
+                    else:                                            # bf16 bucket: sum in fp32, round the shard once
+                        acc = torch.empty(per, dtype=torch.float32, device=t.device)
+                        ops.shard_sum(recv.view(w, per), acc)
+                        shard.copy_(acc)
+                    dist.all_gather_into_tensor(t[:main], shard, group=self.group)
+                self.launched += 2
+            ev = torch.cuda.Event()
+            ev.record()
+        return _EventWork(ev)
+
     def _exchange(self, t):
         """launch the exchange of the 1-D tensor `t` (summed over the ranks, in place); -> work handle. Ordered after the CURRENT
         stream; nothing here blocks the host or the current stream."""
+        cs = self._collective_stream(t.device)
+        if cs is not None:
+            return self._exchange_placed(t, cs)
         n, w, r = t.numel(), self.world, self.rank
         if self.mode == "allreduce" or n < w:
             self.launched += 1
