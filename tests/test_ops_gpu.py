@@ -704,6 +704,15 @@ def test_multi_workgroup_losses_match_the_single_workgroup_form(dev, r):
     assert abs(a[0] - ref[0]) <= 1e-5 * abs(ref[0]) + 1e-9 and abs(a[1] - ref[1]) <= 1e-5 * abs(ref[1]) + 1e-9
     acc = o._loss_acc(torch.device(dev))
     assert int(acc.abs().sum()) == 0
+    # a diverged model: NaN logits in some rows -> the loss is NaN (as from the single-workgroup form), the ticket still completes and the
+    # accumulator comes back zero, so the next launch is right again
+    bad = logits.clone()
+    bad[5::97] = float("nan")
+    dyb = torch.zeros(r, 104, dtype=torch.bfloat16, device=dev)
+    lb = o.softmax_ce(bad, 0, ncls, labels, weights=weights, dy=dyb, dcol0=0)
+    assert not bool(torch.isfinite(lb).all()) and int(acc.abs().sum()) == 0
+    again = run()
+    assert again[0] == a[0] and again[1] == a[1]
 
 
 def test_random_permutations_kernel(dev):

@@ -17,16 +17,21 @@ __device__ __forceinline__ float block_sum(float v, float* lds /* >= 17 floats *
 }
 
 // Sum of one non-negative partial per workgroup, bit-reproducible, in ONE atomic per workgroup and no fence: the partial goes into the low
-// 56 bits of a 64-bit accumulator as fixed point (2^-28 units -- finer than the fp32 ulp of any partial >= 0.06; integer addition is
-// associative, so the arrival order does not matter), the arrival count into the top 8 bits. The workgroup whose atomicAdd returns
-// count == nblk - 1 holds the complete sum in (returned value + its own addend); it leaves the accumulator zero for the next launch (the
-// caller zeroes it once). nblk <= 255, sum < 2^28 (a first version with 2^-36 units overflowed into the count at 20 000 rows x loss 60).
+// 56 bits of a 64-bit accumulator as fixed point (2^-24 units: integer addition is associative, so the arrival order does not matter), the
+// arrival count into the top 8 bits. The workgroup whose atomicAdd returns count == nblk - 1 holds the complete sum in (returned value +
+// its own addend); it leaves the accumulator zero for the next launch (the caller zeroes it once). nblk <= 255.
+// A partial that is NaN, infinite or >= 2^23 (a diverged model) is entered as 2^47 units: 255 of them still do not carry into the count, the
+// ticket keeps working, the accumulator is handed back zero, and a total >= 2^47 units is reported as NaN -- the loss the single-workgroup form
+// would have produced and TrainerNoMeta.loss_dict()'s anomaly check looks for. (History: 2^-36 units overflowed into the count at 20 000 rows
+// x loss 60; a NaN partial converted to garbage, broke the ticket and left the accumulator dirty for every later launch.)
 __device__ __forceinline__ bool packed_sum_finish(unsigned long long* acc, float partial, int nblk, float* total) {
-  unsigned long long q = (unsigned long long)((double)partial * 268435456.0) + (1ull << 56);
+  const unsigned long long POISON = 1ull << 47;
+  bool ok = partial >= 0.f && partial < 8388608.f;          // false for NaN
+  unsigned long long q = (ok ? (unsigned long long)((double)partial * 16777216.0) : POISON) + (1ull << 56);
   unsigned long long old = atomicAdd(acc, q);
   if ((int)(old >> 56) != nblk - 1) return false;
   unsigned long long sum = (old + q) & ((1ull << 56) - 1);
-  *total = (float)((double)sum * (1.0 / 268435456.0));
+  *total = sum >= POISON ? __builtin_nanf("") : (float)((double)sum * (1.0 / 16777216.0));
   *acc = 0ull;
   return true;
 }
