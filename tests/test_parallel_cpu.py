@@ -121,6 +121,16 @@ def test_grad_buckets_knobs_from_env(monkeypatch):
         GradBuckets(M(), mode="ring")
     with pytest.raises(RuntimeError):
         GradBuckets(M(), force=True)
+    # where the collectives are enqueued: the library's stream by default, torch's internal one on request, anything else is an error; host
+    # tensors (these gloo tests) never get a HIP stream
+    import torch
+    assert b.collective_stream == "rpn" and b.describe()["collective_stream"] == "rpn"
+    assert b._collective_stream(torch.device("cpu")) is None
+    monkeypatch.setenv("UNIT_COLLECTIVE_STREAM", "internal")
+    assert GradBuckets(M()).collective_stream == "internal"
+    monkeypatch.setenv("UNIT_COLLECTIVE_STREAM", "somewhere")
+    with pytest.raises(ValueError):
+        GradBuckets(M())
 
 
 def test_shard_batch():
