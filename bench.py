@@ -36,7 +36,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--depth", type=int, default=101)
     ap.add_argument("--variant", default="s1", choices=["s1", "s0"])
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32", "bf16x3"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-overlap", action="store_true", help="single HIP stream for the whole run (profiling aid: every "
@@ -378,7 +378,7 @@ def main():
     model = build_model(cfg)
     init_synthetic_weights(model, seed=1)
     model.train()
-    model.compute_dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    model.compute_mode = args.dtype
     model.overlap_streams = not args.no_overlap
     n_weak = 2 if args.variant == "s1" else 0
     sup, weak = synthetic_batch(2, n_weak, seed=100 + rank)   # rank r's shard of the global batch

@@ -107,6 +107,37 @@ int unit_avgpool_bwd_bits(const void* dfeat, const unsigned char* bits, int R, i
 int unit_conv2d_fwd_mid(const void* x, const void* w, void* y, const float* bias, const void* residual, const void* mask_ref,
                         int out_dtype, int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int OH, int OW, int ldy,
                         int oy_mul, int OHf, int OWf, int relu, int tile, void* stream);
+/* ---- bf16x3 ("split") operands: the parity-grade fast mode (csrc/split.hip) ------------------------------------------------------------
+ * The reference computes its convolutions in fp32 (/root/reference/modeling/roi_heads/fast_rcnn.py:37-101, modeling/proposal_generator/
+ * rpn.py:55-101 over fp32 cuDNN convs); gfx950's fp32 MFMA runs at 1/16 of the bf16 rate. A fp32 value travels here as TWO bf16 numbers,
+ * hi = bf16(x), lo = bf16(x - hi) (16 significant bits), a "split tensor" [rows][2][C] bf16 (plane 0 = hi, plane 1 = lo; 4 bytes per
+ * element), and a product is three bf16 MFMA products with fp32 accumulation, x . w ~ hi.Wh + hi.Wl + lo.Wh: ~2^-17 relative per product.
+ *   unit_x3_split / unit_x3_merge   fp32 [rows][C] <-> split [rows][2][C] (C % 8 == 0; merge is exact)
+ *   unit_weight_prep_x3             fp32 [K][R][S][C] (x scale[k], the FrozenBN fold) -> w_fwd [K][R][S][C/64][3][64] = per 64-channel block
+ *                                   the k-segments [Wh | Wl | Wh] that meet the planes [hi | hi | lo] of x; w_dgrad [C][R][S][K/64][3][64] with the
+ *                                   taps flipped (either may be NULL)
+ *   unit_conv2d_fwd_x3              y = split(relu?(conv(x, w) + bias + residual) masked by (mask_ref > 0)); x, y, residual split tensors (y /
+ *                                   residual rows of ldy channels per plane, ldy % 8 == 0), mask_ref a split tensor of mask_c channels per plane
+ *                                   (its hi plane is tested); strided scatter (oy_mul, OHf, OWf) as unit_conv2d_fwd. tile: -1 = 256x256
+ *                                   phase-interleaved kernel (csrc/conv_igemm256p8.hip, position-class tiles on small 3x3 maps), 0 / 1 / 2 =
+ *                                   128x128 / 64x128 / 128x64 4-wave tiles (csrc/conv_igemm128.hip), 142 .. 182, 144 .. 164 = loader / consumer
+ *                                   tile codes (csrc/conv_igemm_lc.hip). C % 64 == 0.
+ *   unit_conv2d_wgrad_x3            dW ~ hi^T.hi + hi^T.lo + lo^T.hi: three passes of unit_conv2d_wgrad's bf16 kernels over the planes of split
+ *                                   x [N,H,W][2][C] and split dy [M][2][ldy]; 3 * unit_conv2d_wgrad_splits(UNIT_BF16, ...) slabs, workspace
+ *                                   3 * unit_conv2d_wgrad_workspace_bytes(UNIT_BF16, ...); dw == NULL leaves the slabs
+ *   unit_global_avgpool_x3_fwd      mean over `rows` consecutive rows of a split map [R][rows][2][C] -> fp32 [R][C] (box_head.py:80)
+ *   unit_global_avgpool_x3_bwd_relu g = split((y > 0) ? dfeat / rows : 0), y the split forward map */
+int unit_x3_split(const float* x, void* out, long rows, int C, void* stream);
+int unit_x3_merge(const void* in, float* out, long rows, int C, void* stream);
+int unit_weight_prep_x3(const float* w_krsc, const float* scale_k, int K, int R, int S, int C, void* w_fwd, void* w_dgrad, void* stream);
+int unit_conv2d_fwd_x3(const void* x, const void* w, void* y, const float* bias, const void* residual, const void* mask_ref, int mask_c,
+                       int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int OH, int OW, int ldy, int oy_mul, int OHf,
+                       int OWf, int relu, int tile, void* stream);
+int unit_conv2d_wgrad_x3(const void* x, const void* dy, float* dw, const float* scale_k, int N, int H, int W, int C, int K, int R, int S,
+                         int stride, int pad, int OH, int OW, int ldy, int accumulate, int variant, void* workspace, size_t workspace_bytes,
+                         void* stream);
+int unit_global_avgpool_x3_fwd(const void* y, float* out, int R, int rows, int C, void* stream);
+int unit_global_avgpool_x3_bwd_relu(const float* dfeat, const void* y, void* g, int R, int rows, int C, void* stream);
 size_t unit_conv2d_wgrad_workspace_bytes(int in_dtype, int N, int OH, int OW, int K, int R, int S, int C);
 /* variant: 0 = production policy. Big-M bf16 layers (C % 256 == 0, K % 256 == 0, M >= 16384) use a 256x256 tile: policy = the
  * phase-interleaved schedule (csrc/conv_wgrad256p8.hip) for pointwise layers and maps of <= 1024 pixels -- on 3x3 s1 p1 convs over maps
@@ -137,6 +168,10 @@ typedef struct UnitWgradProblem {
   const void* x; const void* dy; void* partial;
   int N, H, W, C, K, R, S, stride, pad, OH, OW, ldy;
   int splits, kind;      /* filled by unit_conv2d_wgrad_group_plan: split-M slabs of the layer; tile kind 1 = 128x128, 2 = 256x256 */
+  int x_pitch;           /* 0 = C. One PASS of a bf16x3 weight gradient (below) is a problem of its own: x / dy point at the pass's plane of the
+                          * split tensors, x_pitch = 2 * C, ldy = 2 * K, x_back / dy_back = elements between the tensor's start and the pointer
+                          * (0 or one plane), partial = the pass's own slabs */
+  int x_back, dy_back;
 } UnitWgradProblem;
 size_t unit_wgrad_problem_bytes(void);
 int unit_conv2d_wgrad_group_supported(int in_dtype, int N, int OH, int OW, int K, int R, int S, int C);

@@ -92,6 +92,48 @@ def test_s1_step_parity_fp32(dev, pool_mode, early):
     assert checked == 72   # R50: res3 13 + res4 19 + 2 x res5 10 + rpn 6 + heads 14 trainable tensors
 
 
+@pytest.mark.parametrize("early", [False, True])
+def test_s1_step_parity_bf16x3(dev, early):
+    """the parity-grade fast mode (compute_mode "bf16x3": every 64-multiple conv on the bf16 MFMA kernels over split operands, csrc/split.hip)
+    at the fp32 mode's bar: index decisions exact, losses within 1e-4. Gradients: the arithmetic itself is ~2^-17 per product (losses land
+    at 1e-6), what moves a weight gradient is a ReLU mask flipping where a pre-activation is within that of zero -- a discrete event that
+    changes one pixel's contribution; asserted at 1e-2 of the tensor's largest entry (fp32 mode: 2e-3; bf16: cosine only)."""
+    cfg = small_cfg()
+    model = build_model(cfg)
+    init_synthetic_weights(model, seed=1)
+    model.train()
+    model.compute_mode = "bf16x3"
+    sup, weak = synthetic_batch(2, 2, hw=(128, 192), seed=5, max_gt=4)
+    batch = model.pack_batch(sup, weak)
+    model._ensure_ready()
+    from unit_amd.layers import Conv2d
+    assert sum(1 for m in model.modules() if isinstance(m, Conv2d) and m.x3) >= 60          # R50: all but the stem and the predictors
+    perms = model.sampling_permutations(2, 8 * 12 * 15, cfg.MODEL.RPN.POST_NMS_TOPK_TRAIN + batch.gt_boxes.shape[1])
+    step = model.forward_train(batch, perms, early_backward=early)
+    model.backward_train(step)
+    got = dict(zip(LOSS_NAMES, step.losses.cpu().tolist()))
+    ref, p, aux = oracle_step(model, cfg, sup, weak, perms)
+    assert torch.equal(step.anchor_labels.cpu(), torch.stack(aux["anchor_labels"]))
+    for i in range(2):
+        rb = aux["sampled"][i]["boxes"]
+        sl = slice(i * 32, i * 32 + len(rb))
+        assert torch.allclose(step.rois[sl, 1:].cpu(), rb, rtol=1e-4, atol=1e-4 * 192), (step.rois[sl, 1:].cpu() - rb).abs().max()
+        assert torch.equal(step.roi_cls[sl].cpu().long(), aux["sampled"][i]["gt_classes"])
+    for k in LOSS_NAMES:
+        assert abs(got[k] - ref[k].item()) <= 1e-4 * max(1.0, abs(ref[k].item())), (k, got[k], ref[k].item())
+    worst = 0.0
+    for name, prm in model.named_parameters():
+        if not prm.requires_grad:
+            continue
+        g_ref = p[name].grad
+        g = prm.grad.detach().cpu()
+        scale = g_ref.abs().max().item() + 1e-12
+        err = (g - g_ref).abs().max().item()
+        worst = max(worst, err / scale)
+        assert err <= 1e-2 * scale + 1e-7, (name, err, scale)
+    print("bf16x3 small step: worst gradient error / max", worst, {k: abs(got[k] - ref[k].item()) for k in LOSS_NAMES})
+
+
 def test_s1_step_bf16_runs_and_tracks_fp32(dev):
     """bf16 compute mode: stated looser tolerance (bf16 has 8 significant bits; 50+ layers deep)."""
     cfg = small_cfg()

@@ -20,6 +20,20 @@
 __host__ __device__ __forceinline__ unsigned div_magic(unsigned d) { return d > 1 ? (unsigned)((0x100000000ull + d - 1) / d) : 0u; }
 __device__ __forceinline__ unsigned fast_div(unsigned x, unsigned d, unsigned magic) { return magic ? __umulhi(x, magic) : (d > 1 ? x / d : x); }
 
+// bf16x3 ("split") operands of the LDS-DMA conv kernels (their X3 instantiations; csrc/split.hip has the format and the converters).
+// An fp32 activation x travels as two bf16 planes per pixel row, [row][2][Cr]: hi = bf16(x), lo = bf16(x - hi) -- 16 significant bits
+// in 4 bytes -- and a weight likewise as Wh, Wl. x . W ~ hi.Wh + hi.Wl + lo.Wh with fp32 accumulation (the dropped lo.Wl term and the
+// representation error are ~2^-17 relative per product) is ONE GEMM over a three times longer contraction: each 64-channel block of
+// the k extent becomes `nseg` = 3 k-tiles, [hi | hi | lo] of x against [Wh | Wl | Wh] of a weight tensor laid out as
+// [K][R][S][Cr / 64][nseg][64]. To the kernels this is a conv with C = nseg * Cr virtual channels whose x k-tiles come from row
+// pitch `x_pitch`, plane (seg_lo >> segment) & 1, channel block cb. Only the staging addresses change: scalar arithmetic.
+struct SplitK {
+  int nseg;        // k segments per 64-channel block (3); 0 / 1 = plain bf16 operands
+  int seg_lo;      // bit s: segment s reads the lo plane of x (offset cr elements inside the row)
+  int cr;          // real channels per plane
+  int x_pitch;     // elements per pixel row of x (2 * cr)
+};
+
 struct PmClass { int tile0, np, oh0, nh, ow0, cw; unsigned magic_np, magic_cw; };      // tiles [tile0, next class's tile0) ; np = nh * cw positions
 struct PmRows {                                           // rows of one tile: class row i0 + (row of the tile)
   int i0, np, oh0, ow0, cw, OW, OHW, N;
@@ -147,15 +161,21 @@ __device__ __forceinline__ unsigned epi_positive_bits(bf16x8 o) {
   return bits;
 }
 
-template <int FA, int FB, bool EX, int RB, bool PM = false, typename Put, typename Args>
+// SPL (bf16x3 "split" tensors, split.hip): y and the residual are [row][2][ldy] bf16 -- plane 0 = bf16(v), plane 1 = bf16(v - plane 0),
+// 4 bytes per element like fp32 -- and mask_ref is a split tensor of p.mask_pitch elements per row whose plane 0 carries the sign.
+template <int FA, int FB, bool EX, int RB, bool PM = false, bool SPL = false, typename Put, typename Args>
 __device__ __forceinline__ void epilogue_rows_bf16_blocks(Put put_block, char* scr, float* pool, int m_w, int n_w, const Args& p, int lane, const PmRows* rows = nullptr,
                                                           unsigned long long* stamp = nullptr) {
   typedef EpiCfg<FA, RB> E;
+  static_assert(!(EX && SPL), "the fused pool / bit-mask epilogue has no split form");
   constexpr int NBLK = FB * 16 / RB;
   bf16_t* __restrict__ Y = (bf16_t*)p.y;
   const bf16_t* __restrict__ Rz = (const bf16_t*)p.residual;
   const bf16_t* __restrict__ Mk = EX ? nullptr : (const bf16_t*)p.mask_ref;
   const bool plain = EX || (p.oy_mul == 1 && p.OHf == p.OH && p.OWf == p.OW);
+  const long pitch = SPL ? 2L * p.ldy : (long)p.ldy;           // elements per output (and residual) row
+  long mpitch = pitch;                                         // ... per mask_ref row
+  if constexpr (SPL) mpitch = p.mask_pitch;
   const int rr = lane / E::LPR, c0 = (lane % E::LPR) * 8;
   const int n = n_w + c0;
   const bool n_ok = n < p.ldy;
@@ -194,7 +214,7 @@ __device__ __forceinline__ void epilogue_rows_bf16_blocks(Put put_block, char* s
     *reinterpret_cast<f32x4*>(d + 4) = f32x4{run[4], run[5], run[6], run[7]};
   };
 
-  struct Pre { long off[E::NP]; bool ok[E::NP]; bf16x8 res[E::NP], msk[E::NP]; };
+  struct Pre { long off[E::NP]; long moff[SPL ? E::NP : 1]; bool ok[E::NP]; bf16x8 res[E::NP], msk[E::NP]; bf16x8 res2[SPL ? E::NP : 1]; };
   auto prefetch = [&](int b, Pre& q) {
 #pragma unroll
     for (int h = 0; h < E::NP; ++h) {
@@ -204,15 +224,26 @@ __device__ __forceinline__ void epilogue_rows_bf16_blocks(Put put_block, char* s
       if constexpr (PM) {
         int img, oh, ow;
         q.ok[h] = rows->map(m, img, oh, ow) && n_ok;
-        q.off[h] = ((long)(q.ok[h] ? img : 0) * rows->OHW + oh * rows->OW + ow) * p.ldy + n;
+        long orow = (long)(q.ok[h] ? img : 0) * rows->OHW + oh * rows->OW + ow;
+        q.off[h] = orow * pitch + n;
+        if constexpr (SPL) q.moff[h] = orow * mpitch + n;
       } else
-      if (plain) q.off[h] = (long)mm * p.ldy + n;
-      else {
+      if (plain) {
+        q.off[h] = (long)mm * pitch + n;
+        if constexpr (SPL) q.moff[h] = (long)mm * mpitch + n;
+      } else {
         int ow = mm % p.OW; int t = mm / p.OW; int oh = t % p.OH; int nimg = t / p.OH;
-        q.off[h] = (((long)nimg * p.OHf + (long)oh * p.oy_mul) * p.OWf + (long)ow * p.oy_mul) * p.ldy + n;
+        long orow = ((long)nimg * p.OHf + (long)oh * p.oy_mul) * p.OWf + (long)ow * p.oy_mul;
+        q.off[h] = orow * pitch + n;
+        if constexpr (SPL) q.moff[h] = orow * mpitch + n;
       }
       if (Rz && q.ok[h]) q.res[h] = epi_load8(Rz + q.off[h]);
-      if (Mk && q.ok[h]) q.msk[h] = epi_load8(Mk + q.off[h]);
+      if constexpr (SPL) {
+        if (Rz && q.ok[h]) q.res2[h] = epi_load8(Rz + q.off[h] + p.ldy);
+        if (Mk && q.ok[h]) q.msk[h] = epi_load8(Mk + q.moff[h]);
+      } else {
+        if (Mk && q.ok[h]) q.msk[h] = epi_load8(Mk + q.off[h]);
+      }
     }
   };
 
@@ -232,8 +263,13 @@ __device__ __forceinline__ void epilogue_rows_bf16_blocks(Put put_block, char* s
       float v[8] = {v0[0] + bias8[0], v0[1] + bias8[1], v0[2] + bias8[2], v0[3] + bias8[3],
                     v1[0] + bias8[4], v1[1] + bias8[5], v1[2] + bias8[6], v1[3] + bias8[7]};
       if (Rz) {
+        if constexpr (SPL) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] += (float)cur.res[h][j];
+          for (int j = 0; j < 8; ++j) v[j] += (float)cur.res[h][j] + (float)cur.res2[h][j];      // (hi + lo is exact in fp32)
+        } else {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[j] += (float)cur.res[h][j];
+        }
       }
       if (p.relu) {
 #pragma unroll
@@ -270,6 +306,11 @@ __device__ __forceinline__ void epilogue_rows_bf16_blocks(Put put_block, char* s
           for (int j = 0; j < 8; ++j) run[j] += (float)o[j];
         }
         if (Y && cur.ok[h]) epi_store8(Y + cur.off[h], o);
+      } else if constexpr (SPL) {
+        bf16x8 o2;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o2[j] = (bf16_t)(v[j] - (float)o[j]);
+        if (cur.ok[h]) { epi_store8(Y + cur.off[h], o); epi_store8(Y + cur.off[h] + p.ldy, o2); }
       } else {
         if (cur.ok[h]) epi_store8(Y + cur.off[h], o);
       }
@@ -298,7 +339,7 @@ __device__ __forceinline__ void epilogue_rows_bf16_blocks(Put put_block, char* s
 }
 
 // 16x16 MFMA accumulators: acc[a][b] = 16x16 tile (channels a*16.., pixel rows b*16..); lane holds 4 consecutive channels of row lane & 15
-template <int FA, int FB, bool EX, bool PM = false, typename Args>
+template <int FA, int FB, bool EX, bool PM = false, bool SPL = false, typename Args>
 __device__ __forceinline__ void epilogue_rows_bf16_impl(const f32x4 (&acc)[FA][FB], char* scr, float* pool, int m_w, int n_w, const Args& p, int lane,
                                                         const PmRows* rows = nullptr, unsigned long long* stamp = nullptr) {
   typedef EpiCfg<FA, 16> E;
@@ -308,12 +349,12 @@ __device__ __forceinline__ void epilogue_rows_bf16_impl(const f32x4 (&acc)[FA][F
     for (int a = 0; a < FA; ++a)
       *reinterpret_cast<f32x4*>(sc + frow * E::PITCH + (a * 16 + fq * 4) * 4) = acc[a][b];
   };
-  epilogue_rows_bf16_blocks<FA, FB, EX, 16, PM>(put, scr, pool, m_w, n_w, p, lane, rows, stamp);
+  epilogue_rows_bf16_blocks<FA, FB, EX, 16, PM, SPL>(put, scr, pool, m_w, n_w, p, lane, rows, stamp);
 }
 
-template <int FA, int FB, typename Args>
+template <int FA, int FB, bool SPL = false, typename Args>
 __device__ __forceinline__ void epilogue_rows_bf16(const f32x4 (&acc)[FA][FB], char* scr, int m_w, int n_w, const Args& p, int lane) {
-  epilogue_rows_bf16_impl<FA, FB, false>(acc, scr, nullptr, m_w, n_w, p, lane);
+  epilogue_rows_bf16_impl<FA, FB, false, false, SPL>(acc, scr, nullptr, m_w, n_w, p, lane);
 }
 
 // 32x32 MFMA accumulators (v_mfma_f32_32x32x16_bf16, A = channels, B = pixels): acc[a][b] = 32 channels a*32.. x 32 pixel rows

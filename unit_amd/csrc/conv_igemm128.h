@@ -2,6 +2,7 @@
 // CU; conv_igemm_lc.hip: persistent loader / consumer workgroups)
 #pragma once
 #include "common.h"
+#include "conv_epilogue.h"
 
 struct ConvDmaArgs {
   const void* x; const void* w; void* y;
@@ -14,7 +15,11 @@ struct ConvDmaArgs {
   int Kgemm, M;
   int tiles_m, tiles_n;
   unsigned x_bytes, w_bytes;
+  SplitK sk;         // conv_epilogue.h: bf16x3 operands (X3 kernel instantiations only; nseg == 0 otherwise)
+  int mask_pitch;    // split epilogue: elements per row of mask_ref
 };
 
 // conv_igemm_lc.hip: tile code = 100 + 10 * (BM / 16) + (BN / 64)   (BM 64..128 pixels, BN 128 or 256 channels)
 int unit_conv_lc_launch(ConvDmaArgs& a, int out_dtype, int code, hipStream_t st);
+// conv_igemm128.hip: the bf16x3 instantiations of the 4-wave kernel / the loader-consumer kernel (a.sk filled by the caller)
+int unit_conv_mid_x3_launch(ConvDmaArgs& a, int tile, hipStream_t st);

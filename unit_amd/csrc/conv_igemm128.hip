@@ -41,8 +41,10 @@ template <> struct Out4<bf16_t> {
 
 typedef __attribute__((address_space(3))) void lds_void_t;
 
-template <typename TO, int BM, int BN, int NS>
+// X3: bf16x3 operands (conv_epilogue.h SplitK) -- split x, three k segments per 64-channel block, split output planes.
+template <typename TO, int BM, int BN, int NS, bool X3 = false>
 __global__ void __launch_bounds__(256, 2) conv_igemm_dma_kernel(ConvDmaArgs p) {
+  static_assert(!X3 || sizeof(TO) == 2, "bf16x3 operands: split bf16 output");
   constexpr int BK = 64;
   constexpr int BUF = (BM + BN) * 128;           // bytes per stage
   constexpr int WMT = BM / 2, WNT = BN / 2;      // wave tile: pixels x channels
@@ -85,7 +87,7 @@ __global__ void __launch_bounds__(256, 2) conv_igemm_dma_kernel(ConvDmaArgs p) {
     int mm = x_ok[i] ? m : 0;
     int ow = mm % p.OW; int t = mm / p.OW; int oh = t % p.OH; int n = t / p.OH;
     x_ih0[i] = oh * p.stride - p.pad; x_iw0[i] = ow * p.stride - p.pad;
-    x_base[i] = (unsigned)n * (unsigned)(p.H * p.W * p.C);
+    x_base[i] = (unsigned)n * (unsigned)(p.H * p.W * (X3 ? p.sk.x_pitch : p.C));
   }
 #pragma unroll
   for (int i = 0; i < WI; ++i) {
@@ -101,13 +103,18 @@ __global__ void __launch_bounds__(256, 2) conv_igemm_dma_kernel(ConvDmaArgs p) {
     int RS = p.R * p.S;
     int cb = kt / RS; int rs = kt - cb * RS;  // wave-uniform: C % 64 == 0 -> the whole k-tile sits inside one (r,s)
     int ch0 = cb * BK; int k0 = rs * p.C + ch0; int r = rs / p.S; int s = rs - r * p.S;
+    int xpitch = p.C, xch0 = ch0;
+    if constexpr (X3) {               // virtual channel block cb = (real block) * nseg + segment; the segment selects the plane of x
+      int cbr = cb / p.sk.nseg, sg = cb - cbr * p.sk.nseg;
+      xpitch = p.sk.x_pitch; xch0 = ((p.sk.seg_lo >> sg) & 1) * p.sk.cr + cbr * BK;
+    }
     char* base = smem + buf * BUF;
 #pragma unroll
     for (int i = 0; i < XI; ++i) {
       int R0 = (i * 4 + wid) * 8;
       int ih = x_ih0[i] + r, iw = x_iw0[i] + s;
       bool ok = x_ok[i] && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
-      unsigned off = (x_base[i] + (unsigned)((ih * p.W + iw) * p.C + ch0 + x_q[i] * 8)) * 2u;
+      unsigned off = (x_base[i] + (unsigned)((ih * p.W + iw) * xpitch + xch0 + x_q[i] * 8)) * 2u;
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, (lds_void_t*)(base + R0 * 128), 16, ok ? off : OOB, 0, 0, 0);
     }
 #pragma unroll
@@ -183,7 +190,7 @@ __global__ void __launch_bounds__(256, 2) conv_igemm_dma_kernel(ConvDmaArgs p) {
   if constexpr (sizeof(TO) == 2) {
     if ((p.ldy & 7) == 0) {          // row-major epilogue through a wave-private LDS scratch (conv_epilogue.h)
       __syncthreads();               // every wave is done with the operand stages
-      epilogue_rows_bf16<FA, FB>(acc, smem + wid * EpiCfg<FA>::BYTES, m0 + wm * WMT, n0 + wn * WNT, p, lane);
+      epilogue_rows_bf16<FA, FB, X3>(acc, smem + wid * EpiCfg<FA>::BYTES, m0 + wm * WMT, n0 + wn * WNT, p, lane);
       return;
     }
   }
@@ -441,18 +448,30 @@ static int launch_ksplit(ConvDmaArgs& a, hipStream_t st) {
   return UNIT_OK;
 }
 
-template <typename TO, int BM, int BN, int NS>
+template <typename TO, int BM, int BN, int NS, bool X3 = false>
 static int launch_dma(ConvDmaArgs& a, hipStream_t st) {
   a.tiles_m = cdiv(a.M, BM); a.tiles_n = cdiv(a.K, BN);
   size_t lds = (size_t)NS * (BM + BN) * 128;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)conv_igemm_dma_kernel<TO, BM, BN, NS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)conv_igemm_dma_kernel<TO, BM, BN, NS, X3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
-  conv_igemm_dma_kernel<TO, BM, BN, NS><<<a.tiles_m * a.tiles_n, 256, lds, st>>>(a);
+  conv_igemm_dma_kernel<TO, BM, BN, NS, X3><<<a.tiles_m * a.tiles_n, 256, lds, st>>>(a);
   UNIT_LAUNCH_CHECK();
   return UNIT_OK;
+}
+
+// bf16x3 operands (unit_conv2d_fwd_x3, conv_igemm256.hip fills the argument block): tile 0 = 128x128, 1 = 64x128, 2 = 128x64 of the
+// 4-wave kernel, >= 100 = loader / consumer tile code
+int unit_conv_mid_x3_launch(ConvDmaArgs& a, int tile, hipStream_t st) {
+  if (a.sk.nseg < 2 || (a.ldy & 7) != 0) { unit_set_error("conv_mid_x3: split operands with output rows of 16-byte vectors only"); return UNIT_ERR_UNSUPPORTED; }
+  if (tile >= 100) return unit_conv_lc_launch(a, UNIT_BF16, tile, st);
+  if (tile == 0) return launch_dma<bf16_t, 128, 128, 2, true>(a, st);
+  if (tile == 1) return launch_dma<bf16_t, 64, 128, 3, true>(a, st);
+  if (tile == 2) return launch_dma<bf16_t, 128, 64, 3, true>(a, st);
+  unit_set_error("conv_mid_x3: tile must be 0, 1, 2 or a loader / consumer tile code");
+  return UNIT_ERR_UNSUPPORTED;
 }
 
 // Same contract as unit_conv2d_fwd (include/unit_hip.h) restricted to bf16 inputs and C % 64 == 0.
@@ -467,6 +486,7 @@ extern "C" int unit_conv2d_fwd_mid(const void* x, const void* w, void* y, const 
   UNIT_CHECK_ARG(((uintptr_t)x % 16 == 0) && ((uintptr_t)w % 16 == 0) && ((uintptr_t)y % 16 == 0), "conv_mid: 16B alignment");
   UNIT_CHECK_ARG((tile >= 0 && tile <= 5) || tile >= 100, "conv_mid: tile must be 0..5 or a loader / consumer tile code (>= 100)");
   ConvDmaArgs a;
+  a.sk = SplitK{0, 0, 0, 0}; a.mask_pitch = 0;
   a.x = x; a.w = w; a.y = y; a.bias = bias; a.residual = residual; a.mask_ref = mask_ref;
   a.N = N; a.H = H; a.W = W; a.C = C; a.K = K; a.R = R; a.S = S; a.stride = stride; a.pad = pad;
   a.OH = OH; a.OW = OW; a.ldy = ldy; a.oy_mul = oy_mul; a.OHf = OHf; a.OWf = OWf; a.relu = relu;

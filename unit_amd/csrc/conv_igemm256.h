@@ -30,6 +30,8 @@ struct Conv256Args {
   PmClass pm_cls[9];
   // ceil(2^32 / OW), ceil(2^32 / OH) when every pixel index m satisfies m * max(OW, OH) < 2^32 (fast_div, conv_epilogue.h), else 0
   unsigned magic_ow, magic_oh;
+  SplitK sk;         // conv_epilogue.h: bf16x3 operands (X3 kernel instantiations only; nseg == 0 otherwise)
+  int mask_pitch;    // split epilogue: elements per row of mask_ref
 };
 
 // LDS image of an operand stage: [row][128 B = 64 k]; 16-B chunks XOR-swizzled with (row>>1)&7 (applied to the SOURCE

@@ -8,6 +8,7 @@
 // chunk (chunk ^= (row>>1)&7) and undone in the fragment reads. Two 64 KB LDS buffers: the DMA of k-tile t+1 is in flight
 // while k-tile t is multiplied; one vmcnt(0)+barrier per k-tile.  Requires C % 64 == 0 (every layer except the stem).
 #include "conv_igemm256.h"
+#include "conv_igemm128.h"
 #ifndef UNIT_P8M_DEFAULT
 #define UNIT_P8M_DEFAULT 0
 #endif
@@ -639,6 +640,7 @@ extern "C" int unit_conv2d_fwd_big(const void* x, const void* w, void* y, const 
   UNIT_CHECK_ARG((OH - 1) * oy_mul < OHf && (OW - 1) * oy_mul < OWf, "conv_big: output scatter out of range");
   UNIT_CHECK_ARG(((uintptr_t)x % 16 == 0) && ((uintptr_t)w % 16 == 0) && ((uintptr_t)y % 16 == 0), "conv_big: 16B alignment");
   Conv256Args a;
+  a.sk = SplitK{0, 0, 0, 0}; a.mask_pitch = 0;
   a.x = x; a.w = w; a.y = y; a.bias = bias; a.residual = residual; a.mask_ref = mask_ref;
   a.N = N; a.H = H; a.W = W; a.C = C; a.K = K; a.R = R; a.S = S; a.stride = stride; a.pad = pad;
   a.OH = OH; a.OW = OW; a.ldy = ldy; a.oy_mul = oy_mul; a.OHf = OHf; a.OWf = OWf; a.relu = relu;
@@ -716,6 +718,57 @@ extern "C" int unit_conv2d_fwd_big(const void* x, const void* w, void* y, const 
   return UNIT_ERR_UNSUPPORTED;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// bf16x3 ("split") convolution: fp32-grade forward / dgrad on the bf16 MFMA kernels (conv_epilogue.h SplitK, csrc/split.hip).
+//   x        split tensor [N,H,W][2][C] bf16 (hi plane, lo plane)
+//   w        [K][R][S][C / 64][3][64] bf16 = per 64-channel block [Wh | Wl | Wh] (unit_weight_prep_x3)
+//   y        split tensor [.][2][ldy]; residual: like y; mask_ref: split tensor with mask_c channels per plane (plane 0 carries the sign)
+// y = split(relu?(sum_k (hi.Wh + hi.Wl + lo.Wh) + bias + residual) * (mask_ref > 0)), fp32 accumulation: ~2^-17 relative per product, the
+// reference's fp32 arithmetic (fast_rcnn.py:37-101, rpn.py:55-101 run on fp32 convs) at three bf16 MFMA passes instead of the 16x
+// slower fp32 MFMA. tile: -1 = 256x256 phase-interleaved kernel (conv_igemm256p8.hip), 0 / 1 / 2 = 128x128 / 64x128 / 128x64 4-wave
+// tiles (conv_igemm128.hip), >= 100 = loader / consumer tile code (conv_igemm_lc.hip).
+extern "C" int unit_conv2d_fwd_x3(const void* x, const void* w, void* y, const float* bias, const void* residual, const void* mask_ref,
+                                  int mask_c, int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int OH, int OW, int ldy,
+                                  int oy_mul, int OHf, int OWf, int relu, int tile, void* stream) {
+  UNIT_CHECK_ARG(C % 64 == 0, "conv_x3: C must be a multiple of 64");
+  UNIT_CHECK_ARG(ldy % 8 == 0 && ldy >= K, "conv_x3: ldy must be a multiple of 8 and >= K");
+  UNIT_CHECK_ARG(OH == (H + 2 * pad - R) / stride + 1 && OW == (W + 2 * pad - S) / stride + 1, "conv_x3: OH/OW mismatch");
+  UNIT_CHECK_ARG((OH - 1) * oy_mul < OHf && (OW - 1) * oy_mul < OWf, "conv_x3: output scatter out of range");
+  UNIT_CHECK_ARG(((uintptr_t)x % 16 == 0) && ((uintptr_t)w % 16 == 0) && ((uintptr_t)y % 16 == 0), "conv_x3: 16B alignment");
+  UNIT_CHECK_ARG(mask_ref == nullptr || (mask_c >= ldy && mask_c % 8 == 0), "conv_x3: mask_c must be the mask tensor's channels per plane");
+  const int NSEG = 3;
+  size_t xb = (size_t)N * H * W * C * 4, wb = (size_t)K * R * S * C * NSEG * 2;
+  UNIT_CHECK_ARG(xb < 0xFFFFFFF0ull && wb < 0xFFFFFFF0ull, "conv_x3: operand larger than 4 GiB");
+  SplitK sk{NSEG, 0x4, C, 2 * C};          // segments [hi.Wh, hi.Wl, lo.Wh]
+  hipStream_t st = (hipStream_t)stream;
+  if ((long)N * OH * OW == 0 || K == 0) return UNIT_OK;
+  if (tile >= 0) {
+    ConvDmaArgs a;
+    a.sk = sk; a.mask_pitch = 2 * mask_c;
+    a.x = x; a.w = w; a.y = y; a.bias = bias; a.residual = residual; a.mask_ref = mask_ref;
+    a.N = N; a.H = H; a.W = W; a.C = NSEG * C; a.K = K; a.R = R; a.S = S; a.stride = stride; a.pad = pad;
+    a.OH = OH; a.OW = OW; a.ldy = ldy; a.oy_mul = oy_mul; a.OHf = OHf; a.OWf = OWf; a.relu = relu;
+    a.Kgemm = R * S * NSEG * C; a.M = N * OH * OW;
+    a.x_bytes = (unsigned)xb; a.w_bytes = (unsigned)wb;
+    return unit_conv_mid_x3_launch(a, tile, st);
+  }
+  Conv256Args a;
+  a.sk = sk; a.mask_pitch = 2 * mask_c;
+  a.x = x; a.w = w; a.y = y; a.bias = bias; a.residual = residual; a.mask_ref = mask_ref;
+  a.N = N; a.H = H; a.W = W; a.C = NSEG * C; a.K = K; a.R = R; a.S = S; a.stride = stride; a.pad = pad;
+  a.OH = OH; a.OW = OW; a.ldy = ldy; a.oy_mul = oy_mul; a.OHf = OHf; a.OWf = OWf; a.relu = relu;
+  a.Kgemm = R * S * NSEG * C; a.M = N * OH * OW;
+  a.x_bytes = (unsigned)xb; a.w_bytes = (unsigned)wb;
+  a.ex = EpiExtra{nullptr, nullptr, nullptr, 0}; a.ex_on = 0;
+  a.x2 = nullptr; a.x2_bytes = 0; a.cb_split = 0; a.ratio2 = 1; a.pm_ncls = 0;
+  set_div_magics(a);
+  // position-class tiles (3x3 s1 p1 on a small map: the k-tiles of all-padding taps are skipped) as in unit_conv2d_fwd_big
+  if (R == 3 && S == 3 && stride == 1 && pad == 1 && OH == H && OW == W && oy_mul == 1 && OHf == OH && OWf == OW && H * W <= 4096 &&
+      (size_t)N * H * W * ldy * 4 < 0xFFFFFFF0ull)
+    build_position_classes(a);
+  return unit_conv256_p8_launch(a, UNIT_BF16, true, false, st);
+}
+
 
 // ---------------------------------------------------------------------------------------------------------------------
 // Conv with the extended epilogue (conv_epilogue.h EpiExtra): 1x1 / 3x3 stride-1 bf16 conv on the phase-interleaved 256x256
@@ -742,6 +795,7 @@ extern "C" int unit_conv2d_fwd_big_ex(const void* x, const void* w, void* y, con
   int OH = H + 2 * pad - R + 1, OW = W + 2 * pad - S + 1;
   UNIT_CHECK_ARG(OH > 0 && OW > 0, "conv_big_ex: empty output");
   Conv256Args a;
+  a.sk = SplitK{0, 0, 0, 0}; a.mask_pitch = 0;
   a.x = x; a.w = w; a.y = y; a.bias = bias; a.residual = residual; a.mask_ref = nullptr;
   const int Ct = C + (x2 ? C2 : 0);
   a.N = N; a.H = H; a.W = W; a.C = Ct; a.K = K; a.R = R; a.S = S; a.stride = 1; a.pad = pad;

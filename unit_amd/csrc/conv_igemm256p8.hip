@@ -66,9 +66,12 @@ extern "C" int unit_debug_read_stamps(unsigned long long* host_out) {
 // tiles (RM schedule only). 224 rows divide the Res5 problem sizes (50 176 = 224 * 224 pixels per 1024 RoIs) into whole
 // rounds of 256 workgroups where 256-row tiles leave the last round 1/2 - 3/4 empty. The LDS image keeps its 64-row groups
 // (the 16 unused rows of the X1 half are staged as zeros and never read).
-template <typename TO, bool RM, int B1>
+// X3: bf16x3 operands (conv_epilogue.h SplitK): x is a split tensor, the k extent holds three segments per 64-channel block, the output
+// (and residual / mask_ref) are split tensors. Same schedule; only the staging offsets (scalars) and the epilogue's stores differ.
+template <typename TO, bool RM, int B1, bool X3 = false>
 __global__ void __launch_bounds__(512, 2) conv_igemm256_p8_kernel(Conv256Args p) {
   static_assert(RM || B1 == 4, "224-row tiles: RM schedule only");
+  static_assert(!X3 || (RM && sizeof(TO) == 2), "bf16x3 operands: RM schedule, split bf16 output");
   constexpr int FBT = 4 + B1;
   constexpr int BM = 32 * FBT, BN = 256, BK = 64;
   constexpr int HALF = 128 * 128;               // 16 KB half-tile
@@ -112,8 +115,8 @@ __global__ void __launch_bounds__(512, 2) conv_igemm256_p8_kernel(Conv256Args p)
   __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(X), 0, (int)p.x_bytes, 0x00020000);
   __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(Wt), 0, (int)p.w_bytes, 0x00020000);
   // dual-source 1x1 conv (Conv256Args::x2): the first cb_split 64-channel blocks of the k extent come from x (row pitch Cx), the rest from x2
-  const bool dual = p.x2 != nullptr;
-  const int Cx = dual ? p.cb_split * 64 : p.C;
+  const bool dual = !X3 && p.x2 != nullptr;
+  const int Cx = X3 ? p.sk.x_pitch : (dual ? p.cb_split * 64 : p.C);
   __amdgpu_buffer_rsrc_t rsX2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>((const bf16_t*)(dual ? p.x2 : p.x)), 0, (int)(dual ? p.x2_bytes : p.x_bytes), 0x00020000);
   constexpr unsigned OOB = 0xFFFFFFF0u;
 
@@ -175,10 +178,19 @@ __global__ void __launch_bounds__(512, 2) conv_igemm256_p8_kernel(Conv256Args p)
     s_lo = max(0, p.pad - pmr.ow0); s_hi = min(p.S - 1, p.W - 1 + p.pad - (pmr.ow0 + pmr.cw - 1));
   }
   int st_cb = 0, st_r = r_lo, st_s = s_lo;
+  int st_sg = 0, st_cbr = 0;            // X3: segment of the virtual channel block st_cb, and the real 64-channel block it reads (st_cb = st_cbr * nseg + st_sg)
   unsigned st_kx = (unsigned)((st_r * p.W + st_s) * Cx) * 2u, st_kw = (unsigned)((st_r * p.S + st_s) * p.C) * 2u;
+  if constexpr (X3) st_kx += (unsigned)((p.sk.seg_lo & 1) * p.sk.cr) * 2u;
   auto st_advance = [&]() {
-    if (++st_s > s_hi) { st_s = s_lo; if (++st_r > r_hi) { st_r = r_lo; ++st_cb; } }
-    st_kx = (unsigned)((st_r * p.W + st_s) * Cx + st_cb * BK) * 2u;
+    if (++st_s > s_hi) {
+      st_s = s_lo;
+      if (++st_r > r_hi) {
+        st_r = r_lo; ++st_cb;
+        if constexpr (X3) { if (++st_sg == p.sk.nseg) { st_sg = 0; ++st_cbr; } }
+      }
+    }
+    if constexpr (X3) st_kx = (unsigned)((st_r * p.W + st_s) * Cx + ((p.sk.seg_lo >> st_sg) & 1) * p.sk.cr + st_cbr * BK) * 2u;
+    else st_kx = (unsigned)((st_r * p.W + st_s) * Cx + st_cb * BK) * 2u;
     st_kw = (unsigned)((st_r * p.S + st_s) * p.C + st_cb * BK) * 2u;
   };
   auto stage_x = [&](int q, int d) {
@@ -422,7 +434,17 @@ __global__ void __launch_bounds__(512, 2) conv_igemm256_p8_kernel(Conv256Args p)
       P8_STAMP(2);
       __syncthreads();               // every wave is done with the operand stages
       P8_STAMP(3);
-      if constexpr (RM) {
+      if constexpr (X3) {              // split outputs: two bf16 planes per row (conv_epilogue.h SPL)
+        if constexpr (B1 == 4) {
+          if (pm) {
+            epilogue_rows_bf16_impl<4, FBT, false, true, true>(acc, smem + wid * EpiCfg<4>::BYTES, nullptr, wm * (FBT * 16), n0 + wn * 64, p, lane, &pmr);
+            return;
+          }
+        }
+        epilogue_rows_bf16_impl<4, FBT, false, false, true>(acc, smem + wid * EpiCfg<4>::BYTES, nullptr, m0 + wm * (FBT * 16), n0 + wn * 64, p, lane);
+        return;
+      }
+      if constexpr (RM && !X3) {
         if (p.ex_on) {               // fused average pool / ReLU bit mask / bit-mask input (unit_conv2d_fwd_big_ex)
           epilogue_rows_bf16_impl<4, FBT, true>(acc, smem + wid * EpiCfg<4>::BYTES, (float*)(smem + 36864 + wid * 8192), m0 + wm * (FBT * 16),
                                                 n0 + wn * 64, p, lane);
@@ -482,7 +504,7 @@ __global__ void __launch_bounds__(512, 2) conv_igemm256_p8_kernel(Conv256Args p)
   }
 }
 
-template <typename TO, bool RM, int B1>
+template <typename TO, bool RM, int B1, bool X3 = false>
 static int launch256_p8(Conv256Args& a, hipStream_t st) {
   if (a.pm_ncls == 0) a.tiles_m = cdiv(a.M, 32 * (4 + B1));
   a.tiles_n = cdiv(a.K, 256);
@@ -504,15 +526,19 @@ static int launch256_p8(Conv256Args& a, hipStream_t st) {
   size_t lds = 8 * 128 * 128;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)conv_igemm256_p8_kernel<TO, RM, B1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)conv_igemm256_p8_kernel<TO, RM, B1, X3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
-  conv_igemm256_p8_kernel<TO, RM, B1><<<grid, 512, lds, st>>>(a);
+  conv_igemm256_p8_kernel<TO, RM, B1, X3><<<grid, 512, lds, st>>>(a);
   UNIT_LAUNCH_CHECK();
   return UNIT_OK;
 }
 
 int unit_conv256_p8_launch(Conv256Args& a, int out_dtype, bool reads_in_mfma, bool rows224, hipStream_t st) {
+  if (a.sk.nseg > 1) {             // bf16x3 operands (unit_conv2d_fwd_x3)
+    if (out_dtype != UNIT_BF16 || (a.ldy & 7) != 0 || rows224 || !reads_in_mfma) { unit_set_error("conv_big: bf16x3 operands need the 256-row RM schedule and split output rows of 16-byte vectors"); return UNIT_ERR_UNSUPPORTED; }
+    return launch256_p8<bf16_t, true, 4, true>(a, st);
+  }
   if (rows224 && !reads_in_mfma) { unit_set_error("conv_big: 224-row tiles need the reads-in-MFMA schedule"); return UNIT_ERR_UNSUPPORTED; }
   if (out_dtype == UNIT_BF16) return rows224 ? launch256_p8<bf16_t, true, 3>(a, st) : reads_in_mfma ? launch256_p8<bf16_t, true, 4>(a, st) : launch256_p8<bf16_t, false, 4>(a, st);
   if (out_dtype == UNIT_F32) return rows224 ? launch256_p8<float, true, 3>(a, st) : reads_in_mfma ? launch256_p8<float, true, 4>(a, st) : launch256_p8<float, false, 4>(a, st);

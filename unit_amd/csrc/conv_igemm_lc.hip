@@ -57,7 +57,9 @@ template <int FB, int FA, int NL, int NSMAX = 3> struct LcCfg {
   static_assert(NSMAX != 2 || LDS <= 80 * 1024, "two-per-CU form: 80 KB of LDS per workgroup");
 };
 
-template <int FB, int FA, int NL, int NSMAX = 3>
+// X3: bf16x3 operands (conv_epilogue.h SplitK) -- the loaders' cursor carries the segment of the virtual channel block, the consumers
+// write split output planes; everything else is the same kernel.
+template <int FB, int FA, int NL, int NSMAX = 3, bool X3 = false>
 __global__ void __launch_bounds__((4 + NL) * 64) conv_igemm_lc_kernel(ConvDmaArgs p) {
   typedef LcCfg<FB, FA, NL, NSMAX> Cf;
   constexpr int BM = Cf::BM, BN = Cf::BN, BK = 64;
@@ -101,6 +103,8 @@ __global__ void __launch_bounds__((4 + NL) * 64) conv_igemm_lc_kernel(ConvDmaArg
     int x_ih0[4], x_iw0[4]; unsigned x_base[4]; bool x_ok[4]; int x_q[4];
     unsigned w_off[8]; bool w_ok[8];
     int cur_t = 0, cur_kt = 0, cur_cb = 0, cur_rs = 0;
+    int cur_sg = 0, cur_cbr = 0;                    // X3: cur_cb = cur_cbr * nseg + cur_sg
+    const int xpitch = X3 ? p.sk.x_pitch : p.C;
     auto setup_tile = [&](int t) {
       int id = t_first + t;
       int tile_n = id % p.tiles_n, tile_m = id / p.tiles_n;
@@ -114,7 +118,7 @@ __global__ void __launch_bounds__((4 + NL) * 64) conv_igemm_lc_kernel(ConvDmaArg
         int mm = x_ok[i] ? m : 0;
         int ow = mm % p.OW; int tt = mm / p.OW; int oh = tt % p.OH; int n = tt / p.OH;
         x_ih0[i] = oh * p.stride - p.pad; x_iw0[i] = ow * p.stride - p.pad;
-        x_base[i] = (unsigned)n * (unsigned)(p.H * p.W * p.C);
+        x_base[i] = (unsigned)n * (unsigned)(p.H * p.W * xpitch);
       }
 #pragma unroll
       for (int i = 0; i < WPL; ++i) {
@@ -128,6 +132,7 @@ __global__ void __launch_bounds__((4 + NL) * 64) conv_igemm_lc_kernel(ConvDmaArg
     // issue the k-step at the cursor into `slot`, advance the cursor (k order: channel block outermost, the R*S taps innermost)
     auto issue = [&](int slot) {
       int ch0 = cur_cb * BK, k0 = cur_rs * p.C + ch0, r = cur_rs / p.S, s = cur_rs - r * p.S;
+      if constexpr (X3) ch0 = ((p.sk.seg_lo >> cur_sg) & 1) * p.sk.cr + cur_cbr * BK;      // (k0 keeps the virtual block: the weights' layout)
       char* base = smem + slot * SLOT;
 #pragma unroll
       for (int i = 0; i < XPL; ++i) {
@@ -135,7 +140,7 @@ __global__ void __launch_bounds__((4 + NL) * 64) conv_igemm_lc_kernel(ConvDmaArg
         int R0 = (i * NL + l) * 8;
         int ih = x_ih0[i] + r, iw = x_iw0[i] + s;
         bool ok = x_ok[i] && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
-        unsigned off = (x_base[i] + (unsigned)((ih * p.W + iw) * p.C + ch0 + x_q[i] * 8)) * 2u;
+        unsigned off = (x_base[i] + (unsigned)((ih * p.W + iw) * xpitch + ch0 + x_q[i] * 8)) * 2u;
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, (lds_void_lc*)(base + R0 * 128), 16, ok ? off : OOB, 0, 0, 0);
       }
 #pragma unroll
@@ -145,9 +150,12 @@ __global__ void __launch_bounds__((4 + NL) * 64) conv_igemm_lc_kernel(ConvDmaArg
         unsigned off = w_off[i] + (unsigned)k0 * 2u;
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (lds_void_lc*)(base + XR * 128 + R0 * 128), 16, w_ok[i] ? off : OOB, 0, 0, 0);
       }
-      if (++cur_rs == RS) { cur_rs = 0; ++cur_cb; }
+      if (++cur_rs == RS) {
+        cur_rs = 0; ++cur_cb;
+        if constexpr (X3) { if (++cur_sg == p.sk.nseg) { cur_sg = 0; ++cur_cbr; } }
+      }
       if (++cur_kt == nk) {
-        cur_kt = 0; cur_cb = 0; cur_rs = 0;
+        cur_kt = 0; cur_cb = 0; cur_rs = 0; cur_sg = 0; cur_cbr = 0;
         if (++cur_t < t_count) setup_tile(cur_t);
       }
     };
@@ -216,11 +224,11 @@ __global__ void __launch_bounds__((4 + NL) * 64) conv_igemm_lc_kernel(ConvDmaArg
     }
     // this wave's BM x FA*16 block through its private scratch, row-major (conv_epilogue.h); the loaders are already D k-steps
     // into the next tile
-    epilogue_rows_bf16<FA, FB>(acc, scr, tile_m * BM, tile_n * BN + c * FA * 16, p, lane);
+    epilogue_rows_bf16<FA, FB, X3>(acc, scr, tile_m * BM, tile_n * BN + c * FA * 16, p, lane);
   }
 }
 
-template <int FB, int FA, int NL, int NSMAX = 3>
+template <int FB, int FA, int NL, int NSMAX = 3, bool X3 = false>
 static int launch_lc(ConvDmaArgs& a, hipStream_t st) {
   typedef LcCfg<FB, FA, NL, NSMAX> Cf;
   a.tiles_m = cdiv(a.M, Cf::BM); a.tiles_n = cdiv(a.K, Cf::BN);
@@ -229,10 +237,10 @@ static int launch_lc(ConvDmaArgs& a, hipStream_t st) {
   int grid = total < slots ? total : slots;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)conv_igemm_lc_kernel<FB, FA, NL, NSMAX>, hipFuncAttributeMaxDynamicSharedMemorySize, Cf::LDS);
+    (void)hipFuncSetAttribute((const void*)conv_igemm_lc_kernel<FB, FA, NL, NSMAX, X3>, hipFuncAttributeMaxDynamicSharedMemorySize, Cf::LDS);
     attr_set = true;
   }
-  conv_igemm_lc_kernel<FB, FA, NL, NSMAX><<<grid, Cf::THREADS, Cf::LDS, st>>>(a);
+  conv_igemm_lc_kernel<FB, FA, NL, NSMAX, X3><<<grid, Cf::THREADS, Cf::LDS, st>>>(a);
   UNIT_LAUNCH_CHECK();
   return UNIT_OK;
 }
@@ -243,6 +251,20 @@ int unit_conv_lc_launch(ConvDmaArgs& a, int out_dtype, int code, hipStream_t st)
   // Measured on the res4 shapes (tools/lc_sweep.py, profiles/r03_exp_loader_consumer.txt): neither a deeper ring (3 / 4 / 5 / 6 slots)
   // nor eight loaders change the time -- a k-step costs what its (BM + BN) * 128 bytes cost at the CU's intake from L2 / Infinity Cache
   // (~27 B/clk) -- so the default is the smallest footprint: three slots, four loaders.
+  if (a.sk.nseg > 1) {             // bf16x3 operands: the default form (three slots, four loaders) of every tile shape
+    switch (code) {
+      case 142: return launch_lc<4, 2, 4, 3, true>(a, st);
+      case 152: return launch_lc<5, 2, 4, 3, true>(a, st);
+      case 162: return launch_lc<6, 2, 4, 3, true>(a, st);
+      case 172: return launch_lc<7, 2, 4, 3, true>(a, st);
+      case 182: return launch_lc<8, 2, 4, 3, true>(a, st);
+      case 144: return launch_lc<4, 4, 4, 3, true>(a, st);
+      case 154: return launch_lc<5, 4, 4, 3, true>(a, st);
+      case 164: return launch_lc<6, 4, 4, 3, true>(a, st);
+    }
+    unit_set_error("conv_lc: bf16x3 operands: tile code 142 .. 182, 144 .. 164");
+    return UNIT_ERR_UNSUPPORTED;
+  }
   switch (code) {
     case 142: return launch_lc<4, 2, 4>(a, st);
     case 152: return launch_lc<5, 2, 4>(a, st);

@@ -20,6 +20,7 @@ struct WgradArgs {
   int tiles_k, tiles_n, splits, m_per_split;
   unsigned x_bytes, dy_bytes;
   unsigned magic_ohw, magic_ow; int OHW; int use_magic;
+  int x_pitch;     // elements per pixel row of x (Wgrad256Args::x_pitch)
 };
 
 template <typename TI> struct WgCfg;
@@ -103,7 +104,7 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_kernel(WgradArgs p) {
       bool mok = m < m_end;
       unsigned xoff;
       bool ok = mok && k_ok;
-      if (pointwise) xoff = ((unsigned)m * (unsigned)p.C + (unsigned)ch) * (unsigned)sizeof(TI);
+      if (pointwise) xoff = ((unsigned)m * (unsigned)p.x_pitch + (unsigned)ch) * (unsigned)sizeof(TI);
       else {
         // m -> (n, oh, ow) with multiply-high "magic" division (the rows change every step here, unlike the forward
         // kernel): q = umulhi(m, ceil(2^32/d)) is exact while m*d < 2^32 (checked on the host), else one correction
@@ -118,7 +119,7 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad_kernel(WgradArgs p) {
         }
         int ih = (int)oh * p.stride - p.pad + kr, iw = (int)ow * p.stride - p.pad + ksx;
         ok = ok && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
-        xoff = ((unsigned)n * (unsigned)(p.H * p.W * p.C) + (unsigned)((ih * p.W + iw) * p.C + ch)) * (unsigned)sizeof(TI);
+        xoff = ((unsigned)n * (unsigned)(p.H * p.W * p.x_pitch) + (unsigned)((ih * p.W + iw) * p.x_pitch + ch)) * (unsigned)sizeof(TI);
       }
       rx[i] = __builtin_amdgcn_raw_buffer_load_b128(rsX, ok ? xoff : OOB, 0, 0);
       unsigned doff = ((unsigned)m * (unsigned)p.ldy + (unsigned)nn) * (unsigned)sizeof(TI);
@@ -203,8 +204,10 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ partial, int split
 // conv_wgrad256.hip: 256x256 LDS-DMA kernel for the big-M bf16 layers (same slab layout)
 extern "C" int unit_wgrad_use_big(int in_dtype, long M, int K, int C, int RS);
 extern "C" int unit_wgrad_big_splits(long M, int tiles, int R, int S, int OHW);
-extern "C" int unit_conv2d_wgrad_big_launch(const void* x, const void* dy, float* partial, int N, int H, int W, int C, int K, int R, int S,
-                                            int stride, int pad, int OH, int OW, int ldy, int variant, size_t workspace_bytes, void* stream);
+// (x_pitch: elements per pixel row of x, x_span / dy_span: bytes from x / dy to the end of their tensors -- Wgrad256Args::x_pitch)
+int unit_conv2d_wgrad_big_launch_p(const void* x, const void* dy, float* partial, int N, int H, int W, int C, int K, int R, int S,
+                                   int stride, int pad, int OH, int OW, int ldy, int variant, size_t workspace_bytes, int x_pitch, size_t x_span,
+                                   size_t dy_span, void* stream);
 
 // 128x128 tile: the LDS-DMA ring kernel (conv_wgrad128r.hip) where it applies (bf16, C % 128 == 0, K % 128 == 0), variant 4 = the
 // register-staged kernel below everywhere. Isolated the two are equal on the backbone shapes (tools/wgrad128_bench.py: 18.2 vs 18.5 us,
@@ -242,21 +245,21 @@ extern "C" size_t unit_conv2d_wgrad_workspace_bytes(int in_dtype, int N, int OH,
   return (size_t)splits * K * Kgemm * sizeof(float);
 }
 
-// x [N,H,W,C], dy [M][ldy] (pixels of the conv's OUTPUT grid, row-major), dw fp32 [K][R][S][C].
-extern "C" int unit_conv2d_wgrad(const void* x, const void* dy, float* dw, const float* scale_k, int in_dtype, int N,
-                                 int H, int W, int C, int K, int R, int S, int stride, int pad, int OH, int OW, int ldy,
-                                 int accumulate, int variant, void* workspace, size_t workspace_bytes, void* stream) {
+// one pass of split-M slabs into `workspace` (no reduction); returns the number of slabs written or a negative status.
+// x_pitch: elements per pixel row of x; x_span / dy_span: bytes from x / dy to the end of their tensors (the buffer range of the loads).
+static int wgrad_pass(const void* x, const void* dy, int in_dtype, int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int OH,
+                      int OW, int ldy, int variant, void* workspace, size_t workspace_bytes, int x_pitch, size_t x_span, size_t dy_span,
+                      void* stream) {
   UNIT_CHECK_ARG(variant >= 0 && variant <= 4, "wgrad: variant 0..4");
   int epc = in_dtype == UNIT_BF16 ? 8 : 4;
   UNIT_CHECK_ARG(C % epc == 0 && K % epc == 0 && ldy % epc == 0, "wgrad: C, K, ldy must be multiples of 8 (bf16) / 4 (fp32)");
-  UNIT_CHECK_ARG(((uintptr_t)x % 16 == 0) && ((uintptr_t)dy % 16 == 0) && ((uintptr_t)dw % 16 == 0), "wgrad: 16B alignment");
+  UNIT_CHECK_ARG(((uintptr_t)x % 16 == 0) && ((uintptr_t)dy % 16 == 0), "wgrad: 16B alignment");
   WgradArgs a;
-  a.x = x; a.dy = dy; a.partial = (float*)workspace;
+  a.x = x; a.dy = dy; a.partial = (float*)workspace; a.x_pitch = x_pitch;
   a.N = N; a.H = H; a.W = W; a.C = C; a.K = K; a.R = R; a.S = S; a.stride = stride; a.pad = pad; a.OH = OH; a.OW = OW;
   a.ldy = ldy; a.Kgemm = R * S * C; a.M = N * OH * OW;
   UNIT_CHECK_ARG(a.Kgemm % 4 == 0, "wgrad: R*S*C % 4 != 0");
-  size_t esz = in_dtype == UNIT_BF16 ? 2 : 4;
-  size_t xb = (size_t)N * H * W * C * esz, db = (size_t)a.M * ldy * esz;
+  size_t xb = x_span, db = dy_span;
   UNIT_CHECK_ARG(xb < 0xFFFFFFF0ull && db < 0xFFFFFFF0ull, "wgrad: operand larger than 4 GiB");
   a.x_bytes = (unsigned)xb; a.dy_bytes = (unsigned)db;
   a.OHW = OH * OW;
@@ -265,16 +268,9 @@ extern "C" int unit_conv2d_wgrad(const void* x, const void* dy, float* dw, const
   a.magic_ohw = a.OHW > 1 ? (unsigned)((0x100000000ull + a.OHW - 1) / (unsigned long long)a.OHW) : 0xFFFFFFFFu;
   a.magic_ow = OW > 1 ? (unsigned)((0x100000000ull + OW - 1) / (unsigned long long)OW) : 0xFFFFFFFFu;
   hipStream_t st = (hipStream_t)stream;
-  if (unit_wgrad_use_big(in_dtype, a.M, K, C, R * S)) {
-    int sp = unit_conv2d_wgrad_big_launch(x, dy, (float*)workspace, N, H, W, C, K, R, S, stride, pad, OH, OW, ldy, variant <= 3 ? variant : 0,
-                                          workspace_bytes, stream);
-    if (sp < 0) return sp;
-    if (dw == nullptr) return UNIT_OK;
-    long KKb = (long)K * a.Kgemm;
-    wgrad_reduce_kernel<<<cdiv(KKb / 4, 256), 256, 0, st>>>((const float*)workspace, sp, KKb, a.Kgemm, scale_k, dw, accumulate);
-    UNIT_LAUNCH_CHECK();
-    return UNIT_OK;
-  }
+  if (unit_wgrad_use_big(in_dtype, a.M, K, C, R * S))
+    return unit_conv2d_wgrad_big_launch_p(x, dy, (float*)workspace, N, H, W, C, K, R, S, stride, pad, OH, OW, ldy, variant <= 3 ? variant : 0,
+                                          workspace_bytes, x_pitch, x_span, dy_span, stream);
   a.tiles_k = cdiv(a.Kgemm, 128); a.tiles_n = cdiv(K, 128);
   int ms = in_dtype == UNIT_BF16 ? 64 : 32;
   a.splits = choose_splits(a.M, a.tiles_k * a.tiles_n, ms);
@@ -290,6 +286,7 @@ extern "C" int unit_conv2d_wgrad(const void* x, const void* dy, float* dw, const
     b.stride = a.stride; b.pad = a.pad; b.OH = a.OH; b.OW = a.OW; b.ldy = a.ldy; b.Kgemm = a.Kgemm; b.M = a.M;
     b.tiles_k = a.tiles_k; b.tiles_n = a.tiles_n; b.splits = a.splits; b.m_per_split = a.m_per_split;
     b.x_bytes = a.x_bytes; b.dy_bytes = a.dy_bytes; b.magic_ohw = a.magic_ohw; b.magic_ow = a.magic_ow; b.OHW = a.OHW; b.use_magic = a.use_magic; b.valid_only = 0;
+    b.x_pitch = a.x_pitch;
     int rc = unit_wgrad128_ring_launch(b, st);
     if (rc != UNIT_OK) return rc;
   } else if (in_dtype == UNIT_BF16) {
@@ -304,9 +301,50 @@ extern "C" int unit_conv2d_wgrad(const void* x, const void* dy, float* dw, const
     conv_wgrad_kernel<float><<<grid, 256, lds, st>>>(a);
   }
   UNIT_LAUNCH_CHECK();
+  return a.splits;
+}
+
+// x [N,H,W,C], dy [M][ldy] (pixels of the conv's OUTPUT grid, row-major), dw fp32 [K][R][S][C].
+extern "C" int unit_conv2d_wgrad(const void* x, const void* dy, float* dw, const float* scale_k, int in_dtype, int N,
+                                 int H, int W, int C, int K, int R, int S, int stride, int pad, int OH, int OW, int ldy,
+                                 int accumulate, int variant, void* workspace, size_t workspace_bytes, void* stream) {
+  UNIT_CHECK_ARG((uintptr_t)dw % 16 == 0, "wgrad: 16B alignment");
+  size_t esz = in_dtype == UNIT_BF16 ? 2 : 4;
+  int sp = wgrad_pass(x, dy, in_dtype, N, H, W, C, K, R, S, stride, pad, OH, OW, ldy, variant, workspace, workspace_bytes, C,
+                      (size_t)N * H * W * C * esz, (size_t)N * OH * OW * ldy * esz, stream);
+  if (sp < 0) return sp;
   if (dw == nullptr) return UNIT_OK;   // partial slabs only: the caller reduces later (unit_multi_wgrad_reduce)
-  long KK = (long)K * a.Kgemm;
-  wgrad_reduce_kernel<<<cdiv(KK / 4, 256), 256, 0, st>>>(a.partial, a.splits, KK, a.Kgemm, scale_k, dw, accumulate);
+  long KK = (long)K * R * S * C;
+  wgrad_reduce_kernel<<<cdiv(KK / 4, 256), 256, 0, (hipStream_t)stream>>>((const float*)workspace, sp, KK, R * S * C, scale_k, dw, accumulate);
+  UNIT_LAUNCH_CHECK();
+  return UNIT_OK;
+}
+
+// bf16x3 weight gradient (csrc/split.hip): x split [N,H,W][2][C], dy split [M][2][ldy] -> dW ~ hi^T.hi + hi^T.lo + lo^T.hi as THREE passes of
+// the bf16 kernels above over the planes, each pass with its own split-M slabs (3 * unit_conv2d_wgrad_splits(UNIT_BF16, ...) in all, at
+// workspace + s*K*R*S*C floats like unit_conv2d_wgrad's); dw != NULL: reduced here, else the caller folds them (unit_multi_wgrad_reduce).
+extern "C" int unit_conv2d_wgrad_x3(const void* x, const void* dy, float* dw, const float* scale_k, int N, int H, int W, int C, int K, int R,
+                                    int S, int stride, int pad, int OH, int OW, int ldy, int accumulate, int variant, void* workspace,
+                                    size_t workspace_bytes, void* stream) {
+  UNIT_CHECK_ARG((uintptr_t)dw % 16 == 0, "wgrad_x3: 16B alignment");
+  UNIT_CHECK_ARG(C % 8 == 0 && ldy % 8 == 0, "wgrad_x3: C, ldy must be multiples of 8");
+  const size_t xt = (size_t)N * H * W * C * 4, dt = (size_t)N * OH * OW * ldy * 4;      // bytes of the split tensors
+  const size_t slab = (size_t)K * R * S * C * sizeof(float);
+  const int xpl[3] = {0, 0, 1}, dpl[3] = {0, 1, 0};                                    // plane of x / dy per pass: (hi, hi), (hi, lo), (lo, hi)
+  int total = 0;
+  for (int ps = 0; ps < 3; ++ps) {
+    size_t used = (size_t)total * slab;
+    if (workspace_bytes < used) { unit_set_error("wgrad_x3: workspace too small"); return UNIT_ERR_WORKSPACE; }
+    const char* xp = (const char*)x + (size_t)xpl[ps] * C * 2;
+    const char* dp = (const char*)dy + (size_t)dpl[ps] * ldy * 2;
+    int sp = wgrad_pass(xp, dp, UNIT_BF16, N, H, W, C, K, R, S, stride, pad, OH, OW, 2 * ldy, variant, (char*)workspace + used,
+                        workspace_bytes - used, 2 * C, xt - (size_t)xpl[ps] * C * 2, dt - (size_t)dpl[ps] * ldy * 2, stream);
+    if (sp < 0) return sp;
+    total += sp;
+  }
+  if (dw == nullptr) return UNIT_OK;
+  long KK = (long)K * R * S * C;
+  wgrad_reduce_kernel<<<cdiv(KK / 4, 256), 256, 0, (hipStream_t)stream>>>((const float*)workspace, total, KK, R * S * C, scale_k, dw, accumulate);
   UNIT_LAUNCH_CHECK();
   return UNIT_OK;
 }
@@ -325,6 +363,8 @@ struct UnitWgradProblem {
   const void* x; const void* dy; void* partial;
   int N, H, W, C, K, R, S, stride, pad, OH, OW, ldy;
   int splits, kind;
+  int x_pitch;            // 0 = C; one pass of a bf16x3 weight gradient: 2 * C (x, dy point at the pass's planes, ldy = 2 * K), x_back / dy_back =
+  int x_back, dy_back;    // elements between the tensor's start and the x / dy pointer (0 or one plane: keeps the loads' buffer range exact)
 };
 extern "C" size_t unit_wgrad_problem_bytes(void) { return sizeof(UnitWgradProblem); }
 
@@ -431,7 +471,9 @@ static int wgrad_group_fill(const UnitWgradProblem& q, Wgrad256Args& b) {
   b.N = q.N; b.H = q.H; b.W = q.W; b.C = q.C; b.K = q.K; b.R = q.R; b.S = q.S; b.stride = q.stride; b.pad = q.pad; b.OH = q.OH; b.OW = q.OW;
   b.ldy = q.ldy; b.Kgemm = q.R * q.S * q.C; b.M = q.N * q.OH * q.OW;
   UNIT_CHECK_ARG(b.M > 0, "wgrad_group: empty problem");
-  size_t xb = (size_t)q.N * q.H * q.W * q.C * 2, db = (size_t)b.M * q.ldy * 2;
+  b.x_pitch = q.x_pitch > 0 ? q.x_pitch : q.C;
+  UNIT_CHECK_ARG(b.x_pitch >= q.C && b.x_pitch % 8 == 0 && q.x_back >= 0 && q.dy_back >= 0, "wgrad_group: x_pitch / x_back / dy_back");
+  size_t xb = ((size_t)q.N * q.H * q.W * b.x_pitch - q.x_back) * 2, db = ((size_t)b.M * q.ldy - q.dy_back) * 2;
   UNIT_CHECK_ARG(xb < 0xFFFFFFF0ull && db < 0xFFFFFFF0ull, "wgrad_group: operand larger than 4 GiB");
   b.x_bytes = (unsigned)xb; b.dy_bytes = (unsigned)db;
   b.OHW = q.OH * q.OW;

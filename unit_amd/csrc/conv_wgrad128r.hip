@@ -76,7 +76,7 @@ __device__ __forceinline__ void wgrad128_ring_tile(const Wgrad256Args& p, int ti
       bool mok = m < m_end;
       unsigned xoff;
       bool ok = mok;
-      if (pointwise) xoff = ((unsigned)m * (unsigned)p.C + (unsigned)ch0 + s_col) * 2u;
+      if (pointwise) xoff = ((unsigned)m * (unsigned)p.x_pitch + (unsigned)ch0 + s_col) * 2u;
       else {
         int n, oh, ow;
         if (incremental) { n = in_[i]; oh = ioh[i]; ow = iow[i]; }
@@ -94,7 +94,7 @@ __device__ __forceinline__ void wgrad128_ring_tile(const Wgrad256Args& p, int ti
         }
         int ih = oh * p.stride - p.pad + kr, iw = ow * p.stride - p.pad + ksx;
         ok = ok && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
-        xoff = ((unsigned)n * (unsigned)(p.H * p.W * p.C) + (unsigned)((ih * p.W + iw) * p.C + ch0) + s_col) * 2u;
+        xoff = ((unsigned)n * (unsigned)(p.H * p.W * p.x_pitch) + (unsigned)((ih * p.W + iw) * p.x_pitch + ch0) + s_col) * 2u;
       }
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, (lds_void_w*)(bx + R0 * 256), 16, ok ? xoff : OOB, 0, 0, 0);
       unsigned doff = ((unsigned)m * (unsigned)p.ldy + (unsigned)n0 + s_col) * 2u;
@@ -202,7 +202,7 @@ __global__ void __launch_bounds__(256, 2) conv_wgrad128_group_kernel(WgradGroupA
   p.Kgemm = pin(src.Kgemm); p.M = pin(src.M); p.tiles_k = pin(src.tiles_k); p.tiles_n = pin(src.tiles_n); p.splits = pin(src.splits);
   p.m_per_split = pin(src.m_per_split); p.x_bytes = (unsigned)pin((int)src.x_bytes); p.dy_bytes = (unsigned)pin((int)src.dy_bytes);
   p.magic_ohw = (unsigned)pin((int)src.magic_ohw); p.magic_ow = (unsigned)pin((int)src.magic_ow); p.OHW = pin(src.OHW);
-  p.use_magic = pin(src.use_magic); p.valid_only = 0;
+  p.use_magic = pin(src.use_magic); p.valid_only = 0; p.x_pitch = pin(src.x_pitch);
   int t = slot - (int)g.unit_start[xcd][u] + (int)g.unit_tile0[xcd][u];
   wgrad128_ring_tile<NS>(p, t % p.tiles_k, t / p.tiles_k, (int)(code >> 9), smem);
 }

@@ -22,6 +22,10 @@ struct Wgrad256Args {
   // zeros, but the fp32 partial sums associate differently (the rows of a step and of a split change): equal to the full contraction
   // within fp32 rounding, deterministic, not bit-identical to it.
   int valid_only;
+  // elements per pixel row of x (== C for a plain tensor). A bf16x3 weight gradient (split x [.][2][C], split dy [.][2][K], csrc/split.hip)
+  // runs as three passes of these kernels -- planes (hi, hi), (hi, lo), (lo, hi): x / dy point at the plane, x_pitch = 2 * C, ldy = 2 * K,
+  // every pass writes its own slabs and the reduction adds them.
+  int x_pitch;
 };
 
 // grouped launches (conv_wgrad128r.hip: 128x128 ring tiles; conv_wgrad256p8.hip: 256x256 phase-interleaved tiles): up to 20 layers,

@@ -76,7 +76,7 @@ __global__ void __launch_bounds__(512, 2) conv_wgrad256_kernel(Wgrad256Args p) {
       bool mok = m < m_end;
       unsigned xoff;
       bool ok = mok;
-      if (pointwise) xoff = ((unsigned)m * (unsigned)p.C + (unsigned)ch0 + s_col[i]) * 2u;
+      if (pointwise) xoff = ((unsigned)m * (unsigned)p.x_pitch + (unsigned)ch0 + s_col[i]) * 2u;
       else {
         unsigned um = (unsigned)m, n, oh, ow;
         if (p.use_magic) {
@@ -89,7 +89,7 @@ __global__ void __launch_bounds__(512, 2) conv_wgrad256_kernel(Wgrad256Args p) {
         }
         int ih = (int)oh * p.stride - p.pad + kr, iw = (int)ow * p.stride - p.pad + ksx;
         ok = ok && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
-        xoff = ((unsigned)n * (unsigned)(p.H * p.W * p.C) + (unsigned)((ih * p.W + iw) * p.C + ch0) + s_col[i]) * 2u;
+        xoff = ((unsigned)n * (unsigned)(p.H * p.W * p.x_pitch) + (unsigned)((ih * p.W + iw) * p.x_pitch + ch0) + s_col[i]) * 2u;
       }
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, (lds_void_w*)(bx + R0 * 512), 16, ok ? xoff : OOB, 0, 0, 0);
       unsigned doff = ((unsigned)m * (unsigned)p.ldy + (unsigned)n0 + s_col[i]) * 2u;
@@ -187,14 +187,15 @@ extern "C" int unit_wgrad_big_splits_base(long M, int tiles) {
   return best;
 }
 
-extern "C" int unit_conv2d_wgrad_big_launch(const void* x, const void* dy, float* partial, int N, int H, int W, int C, int K, int R, int S,
-                                            int stride, int pad, int OH, int OW, int ldy, int variant, size_t workspace_bytes, void* stream) {
+int unit_conv2d_wgrad_big_launch_p(const void* x, const void* dy, float* partial, int N, int H, int W, int C, int K, int R, int S,
+                                   int stride, int pad, int OH, int OW, int ldy, int variant, size_t workspace_bytes, int x_pitch, size_t x_span,
+                                   size_t dy_span, void* stream) {
   Wgrad256Args a;
-  a.x = x; a.dy = dy; a.partial = partial;
+  a.x = x; a.dy = dy; a.partial = partial; a.x_pitch = x_pitch;
   a.N = N; a.H = H; a.W = W; a.C = C; a.K = K; a.R = R; a.S = S; a.stride = stride; a.pad = pad; a.OH = OH; a.OW = OW;
   a.ldy = ldy; a.Kgemm = R * S * C; a.M = N * OH * OW;
   UNIT_CHECK_ARG(ldy % 8 == 0, "wgrad_big: ldy must be a multiple of 8");
-  size_t xb = (size_t)N * H * W * C * 2, db = (size_t)a.M * ldy * 2;
+  size_t xb = x_span, db = dy_span;
   UNIT_CHECK_ARG(xb < 0xFFFFFFF0ull && db < 0xFFFFFFF0ull, "wgrad_big: operand larger than 4 GiB");
   a.x_bytes = (unsigned)xb; a.dy_bytes = (unsigned)db;
   a.OHW = OH * OW;
@@ -231,4 +232,10 @@ extern "C" int unit_conv2d_wgrad_big_launch(const void* x, const void* dy, float
   conv_wgrad256_kernel<<<a.tiles_k * a.tiles_n * a.splits, 512, lds, (hipStream_t)stream>>>(a);
   UNIT_LAUNCH_CHECK();
   return a.splits;
+}
+
+extern "C" int unit_conv2d_wgrad_big_launch(const void* x, const void* dy, float* partial, int N, int H, int W, int C, int K, int R, int S,
+                                            int stride, int pad, int OH, int OW, int ldy, int variant, size_t workspace_bytes, void* stream) {
+  return unit_conv2d_wgrad_big_launch_p(x, dy, partial, N, H, W, C, K, R, S, stride, pad, OH, OW, ldy, variant, workspace_bytes, C,
+                                        (size_t)N * H * W * C * 2, (size_t)N * OH * OW * ldy * 2, stream);
 }

@@ -85,7 +85,7 @@ __device__ __forceinline__ void wgrad256_p8_tile(const Wgrad256Args& p, int tile
       int oh = px / v_cw, ow = px - oh * v_cw;
       oh += v_oh0; ow += v_ow0;
       int ih = oh * p.stride - p.pad + kr, iw = ow * p.stride - p.pad + ksx;
-      tab[px] = ((unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W) ? (ih * p.W + iw) * p.C : -1;
+      tab[px] = ((unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W) ? (ih * p.W + iw) * p.x_pitch : -1;
       if (vo) tabd[px] = oh * p.OW + ow;
     }
 #pragma unroll
@@ -120,10 +120,10 @@ __device__ __forceinline__ void wgrad256_p8_tile(const Wgrad256Args& p, int tile
       int m = mstep + s_row[j];
       bool ok = m < m_end;
       unsigned xoff;
-      if (pointwise) xoff = ((unsigned)m * (unsigned)p.C + xcol[q]) * 2u;
+      if (pointwise) xoff = ((unsigned)m * (unsigned)p.x_pitch + xcol[q]) * 2u;
       else if (use_tab) {
         ok = ok && tv[j] >= 0;
-        xoff = ((unsigned)xn[j] * (unsigned)(p.H * p.W * p.C) + (unsigned)tv[j] + xcol[q]) * 2u;
+        xoff = ((unsigned)xn[j] * (unsigned)(p.H * p.W * p.x_pitch) + (unsigned)tv[j] + xcol[q]) * 2u;
       } else {
         unsigned um = (unsigned)m, n, oh, ow;
         if (p.use_magic) {
@@ -136,7 +136,7 @@ __device__ __forceinline__ void wgrad256_p8_tile(const Wgrad256Args& p, int tile
         }
         int ih = (int)oh * p.stride - p.pad + kr, iw = (int)ow * p.stride - p.pad + ksx;
         ok = ok && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
-        xoff = ((unsigned)n * (unsigned)(p.H * p.W * p.C) + (unsigned)((ih * p.W + iw) * p.C) + xcol[q]) * 2u;
+        xoff = ((unsigned)n * (unsigned)(p.H * p.W * p.x_pitch) + (unsigned)((ih * p.W + iw) * p.x_pitch) + xcol[q]) * 2u;
       }
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, (lds_void_w*)(base + (j * 8 + wid) * 1024), 16, ok ? xoff : OOB, 0, 0, UNIT_W8_AUX);
     }
@@ -463,7 +463,7 @@ __global__ void __launch_bounds__(512, 2) conv_wgrad256_group_kernel(WgradGroupA
   p.Kgemm = pinw(src.Kgemm); p.M = pinw(src.M); p.tiles_k = pinw(src.tiles_k); p.tiles_n = pinw(src.tiles_n); p.splits = pinw(src.splits);
   p.m_per_split = pinw(src.m_per_split); p.x_bytes = (unsigned)pinw((int)src.x_bytes); p.dy_bytes = (unsigned)pinw((int)src.dy_bytes);
   p.magic_ohw = (unsigned)pinw((int)src.magic_ohw); p.magic_ow = (unsigned)pinw((int)src.magic_ow); p.OHW = pinw(src.OHW);
-  p.use_magic = pinw(src.use_magic); p.valid_only = pinw(src.valid_only);
+  p.use_magic = pinw(src.use_magic); p.valid_only = pinw(src.valid_only); p.x_pitch = pinw(src.x_pitch);
   int t = slot - (int)g.unit_start[xcd][u] + (int)g.unit_tile0[xcd][u];
   int tap = (int)((code >> 5) & 15), split = (int)(code >> 9);
   if (p.valid_only) {

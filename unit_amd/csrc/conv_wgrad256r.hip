@@ -87,11 +87,11 @@ __global__ void __launch_bounds__(512, 2) conv_wgrad256_ring_kernel(Wgrad256Args
       bool mok = m < m_end;
       unsigned xoff;
       bool ok = mok;
-      if (pointwise) xoff = ((unsigned)m * (unsigned)p.C + (unsigned)ch0 + s_col[i]) * 2u;
+      if (pointwise) xoff = ((unsigned)m * (unsigned)p.x_pitch + (unsigned)ch0 + s_col[i]) * 2u;
       else if (incremental) {
         int ih = ioh[i] * p.stride - p.pad + kr, iw = iow[i] * p.stride - p.pad + ksx;
         ok = ok && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
-        xoff = ((unsigned)in_[i] * (unsigned)(p.H * p.W * p.C) + (unsigned)((ih * p.W + iw) * p.C + ch0) + s_col[i]) * 2u;
+        xoff = ((unsigned)in_[i] * (unsigned)(p.H * p.W * p.x_pitch) + (unsigned)((ih * p.W + iw) * p.x_pitch + ch0) + s_col[i]) * 2u;
         iow[i] += MS;
         if (iow[i] >= p.OW) { iow[i] -= p.OW; ioh[i] += 1; if (ioh[i] >= p.OH) { ioh[i] = 0; in_[i] += 1; } }
       } else {
@@ -106,7 +106,7 @@ __global__ void __launch_bounds__(512, 2) conv_wgrad256_ring_kernel(Wgrad256Args
         }
         int ih = (int)oh * p.stride - p.pad + kr, iw = (int)ow * p.stride - p.pad + ksx;
         ok = ok && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
-        xoff = ((unsigned)n * (unsigned)(p.H * p.W * p.C) + (unsigned)((ih * p.W + iw) * p.C + ch0) + s_col[i]) * 2u;
+        xoff = ((unsigned)n * (unsigned)(p.H * p.W * p.x_pitch) + (unsigned)((ih * p.W + iw) * p.x_pitch + ch0) + s_col[i]) * 2u;
       }
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, (lds_void_w*)(bx + R0 * 512), 16, ok ? xoff : OOB, 0, 0, 0);
       unsigned doff = ((unsigned)m * (unsigned)p.ldy + (unsigned)n0 + s_col[i]) * 2u;

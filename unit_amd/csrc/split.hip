@@ -1,0 +1,162 @@
+// split.hip -- the bf16x3 ("split") number format of the parity-grade fast mode, its converters and its weight preparation.
+//
+// Why: the reference computes every convolution in fp32 (/root/reference/modeling/roi_heads/fast_rcnn.py:37-101,
+// modeling/proposal_generator/rpn.py:55-101 sit on fp32 cuDNN convs) and the north_star asks for losses within 1e-4 of that. On gfx950
+// the fp32 MFMA (v_mfma_f32_16x16x4_f32) runs at 1/16 of the bf16 rate: the whole S1 step cannot be faster than 12.7 TFLOP / 157 TF/s =
+// 81 ms. bf16 alone (8 significant bits) lands at 6e-3. A fp32 value split into TWO bf16 numbers keeps 16 significant bits,
+//      x = hi + lo,   hi = bf16(x),   lo = bf16(x - hi)          (x - hi is exact in fp32)
+// and a product of two such numbers needs three bf16 MFMA products with fp32 accumulation,
+//      x . w ~ hi.Wh + hi.Wl + lo.Wh                              (the dropped lo.Wl term is < 2^-18 |x w|)
+// i.e. ~2^-17 relative per product at 3/16 of the fp32 MFMA's time. Measured through the whole R50 step on CPU (emulated with
+// F.conv2d on the split operands): losses within 2e-6 of fp32, index decisions identical.
+//
+// Storage ("split tensor"): an activation [rows][C] travels as [rows][2][C] bf16 -- plane 0 = hi, plane 1 = lo, 4 bytes per element
+// like fp32 -- so that the LDS-DMA staging of the conv kernels reads 128-byte k-tiles of either plane straight from memory. Weights
+// are prepared as [K][R][S][C / 64][3][64] = per 64-channel block the three k-segments [Wh | Wl | Wh] that pair with the planes
+// [hi | hi | lo] of x (conv_epilogue.h SplitK; unit_conv2d_fwd_x3). Weight gradients contract [hi | hi | lo] of x against
+// [hi | lo | hi] of dy as three slab passes (conv_wgrad.hip).
+#include "common.h"
+
+// fp32 [rows][C] -> split [rows][2][C]; one thread = 8 channels of one row (32 B in, 2 x 16 B out)
+__global__ void x3_split_kernel(const float* __restrict__ x, bf16_t* __restrict__ out, long rows, int C8) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows * C8) return;
+  long r = i / C8; int c = (int)(i - r * C8) * 8;
+  const int C = C8 * 8;
+  float v[8];
+  Vec8<float>::load(x + r * C + c, v);
+  bf16x8 h, l;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { h[j] = (bf16_t)v[j]; l[j] = (bf16_t)(v[j] - (float)h[j]); }
+  *reinterpret_cast<bf16x8*>(out + r * 2 * C + c) = h;
+  *reinterpret_cast<bf16x8*>(out + r * 2 * C + C + c) = l;
+}
+
+// split [rows][2][C] -> fp32 [rows][C] (hi + lo, exact)
+__global__ void x3_merge_kernel(const bf16_t* __restrict__ in, float* __restrict__ out, long rows, int C8) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows * C8) return;
+  long r = i / C8; int c = (int)(i - r * C8) * 8;
+  const int C = C8 * 8;
+  bf16x8 h = *reinterpret_cast<const bf16x8*>(in + r * 2 * C + c);
+  bf16x8 l = *reinterpret_cast<const bf16x8*>(in + r * 2 * C + C + c);
+  float v[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) v[j] = (float)h[j] + (float)l[j];
+  Vec8<float>::store(out + r * C + c, v);
+}
+
+extern "C" int unit_x3_split(const float* x, void* out, long rows, int C, void* stream) {
+  UNIT_CHECK_ARG(C % 8 == 0, "x3_split: C must be a multiple of 8");
+  UNIT_CHECK_ARG(((uintptr_t)x % 16 == 0) && ((uintptr_t)out % 16 == 0), "x3_split: 16B alignment");
+  long n = rows * (C / 8);
+  if (n == 0) return UNIT_OK;
+  x3_split_kernel<<<(unsigned)cdiv(n, 256L), 256, 0, (hipStream_t)stream>>>(x, (bf16_t*)out, rows, C / 8);
+  UNIT_LAUNCH_CHECK();
+  return UNIT_OK;
+}
+
+extern "C" int unit_x3_merge(const void* in, float* out, long rows, int C, void* stream) {
+  UNIT_CHECK_ARG(C % 8 == 0, "x3_merge: C must be a multiple of 8");
+  UNIT_CHECK_ARG(((uintptr_t)in % 16 == 0) && ((uintptr_t)out % 16 == 0), "x3_merge: 16B alignment");
+  long n = rows * (C / 8);
+  if (n == 0) return UNIT_OK;
+  x3_merge_kernel<<<(unsigned)cdiv(n, 256L), 256, 0, (hipStream_t)stream>>>((const bf16_t*)in, out, rows, C / 8);
+  UNIT_LAUNCH_CHECK();
+  return UNIT_OK;
+}
+
+// w fp32 [K][R][S][C] (x scale[k]: the FrozenBN fold) ->
+//   w_fwd   [K][R][S][C / 64][3][64]   segments [Wh | Wl | Wh]
+//   w_dgrad [C][R][S][K / 64][3][64]   taps flipped (dgrad = forward conv of dy with this tensor), same segments over the K axis
+__global__ void weight_prep_x3_kernel(const float* __restrict__ w, const float* __restrict__ scale, int K, int R, int S, int C,
+                                      bf16_t* __restrict__ wf, bf16_t* __restrict__ wd) {
+  long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  long total = (long)K * R * S * C;
+  if (idx >= total) return;
+  int c = idx % C; long t = idx / C;
+  int s = t % S; t /= S;
+  int r = t % R; int k = t / R;
+  float v = w[idx];
+  if (scale) v = v * scale[k];
+  bf16_t h = (bf16_t)v, l = (bf16_t)(v - (float)h);
+  if (wf) {
+    bf16_t* q = wf + (((size_t)k * R + r) * S + s) * (size_t)(3 * C) + (size_t)(c >> 6) * 192 + (c & 63);
+    q[0] = h; q[64] = l; q[128] = h;
+  }
+  if (wd) {
+    bf16_t* q = wd + (((size_t)c * R + (R - 1 - r)) * S + (S - 1 - s)) * (size_t)(3 * K) + (size_t)(k >> 6) * 192 + (k & 63);
+    q[0] = h; q[64] = l; q[128] = h;
+  }
+}
+
+extern "C" int unit_weight_prep_x3(const float* w_krsc, const float* scale_k, int K, int R, int S, int C, void* w_fwd, void* w_dgrad,
+                                   void* stream) {
+  UNIT_CHECK_ARG(w_fwd == nullptr || C % 64 == 0, "weight_prep_x3: C must be a multiple of 64 for the forward copy");
+  UNIT_CHECK_ARG(w_dgrad == nullptr || K % 64 == 0, "weight_prep_x3: K must be a multiple of 64 for the dgrad copy");
+  long total = (long)K * R * S * C;
+  if (total == 0) return UNIT_OK;
+  weight_prep_x3_kernel<<<(unsigned)cdiv(total, 256L), 256, 0, (hipStream_t)stream>>>(w_krsc, scale_k, K, R, S, C, (bf16_t*)w_fwd, (bf16_t*)w_dgrad);
+  UNIT_LAUNCH_CHECK();
+  return UNIT_OK;
+}
+
+// ---- the two pooling steps around a Res5 head on split tensors (box_head.py:80 x.mean(dim=[2,3]) and its backward) --------------------
+// y split [R][rows][2][C] -> mean over the rows, fp32 [R][C]
+__global__ void avgpool_x3_fwd_kernel(const bf16_t* __restrict__ y, float* __restrict__ out, int R, int rows, int C8) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long)R * C8) return;
+  int r = (int)(i / C8), c = (int)(i - (long)r * C8) * 8;
+  const int C = C8 * 8;
+  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  const bf16_t* p = y + ((size_t)r * rows) * 2 * C + c;
+  for (int m = 0; m < rows; ++m, p += 2 * C) {
+    bf16x8 h = *reinterpret_cast<const bf16x8*>(p);
+    bf16x8 l = *reinterpret_cast<const bf16x8*>(p + C);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] += (float)h[j] + (float)l[j];
+  }
+  float inv = 1.0f / (float)rows;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) acc[j] *= inv;
+  Vec8<float>::store(out + (size_t)r * C + c, acc);
+}
+
+extern "C" int unit_global_avgpool_x3_fwd(const void* y, float* out, int R, int rows, int C, void* stream) {
+  UNIT_CHECK_ARG(C % 8 == 0, "avgpool_x3: C must be a multiple of 8");
+  long n = (long)R * (C / 8);
+  if (n == 0) return UNIT_OK;
+  avgpool_x3_fwd_kernel<<<(unsigned)cdiv(n, 256L), 256, 0, (hipStream_t)stream>>>((const bf16_t*)y, out, R, rows, C / 8);
+  UNIT_LAUNCH_CHECK();
+  return UNIT_OK;
+}
+
+// g[r][m][c] = (y[r][m][c] > 0) ? dfeat[r][c] / rows : 0, written as a split tensor; y split (plane 0 carries the sign)
+__global__ void avgpool_x3_bwd_relu_kernel(const float* __restrict__ dfeat, const bf16_t* __restrict__ y, bf16_t* __restrict__ g, long M, int rows, int C8) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= M * C8) return;
+  long m = i / C8; int c = (int)(i - m * C8) * 8;
+  const int C = C8 * 8;
+  long r = m / rows;
+  float d[8];
+  Vec8<float>::load(dfeat + r * C + c, d);
+  bf16x8 yh = *reinterpret_cast<const bf16x8*>(y + m * 2 * C + c);
+  float inv = 1.0f / (float)rows;
+  bf16x8 h, l;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    float v = (float)yh[j] > 0.f ? d[j] * inv : 0.f;
+    h[j] = (bf16_t)v; l[j] = (bf16_t)(v - (float)h[j]);
+  }
+  *reinterpret_cast<bf16x8*>(g + m * 2 * C + c) = h;
+  *reinterpret_cast<bf16x8*>(g + m * 2 * C + C + c) = l;
+}
+
+extern "C" int unit_global_avgpool_x3_bwd_relu(const float* dfeat, const void* y, void* g, int R, int rows, int C, void* stream) {
+  UNIT_CHECK_ARG(C % 8 == 0, "avgpool_x3_bwd: C must be a multiple of 8");
+  long M = (long)R * rows, n = M * (C / 8);
+  if (n == 0) return UNIT_OK;
+  avgpool_x3_bwd_relu_kernel<<<(unsigned)cdiv(n, 256L), 256, 0, (hipStream_t)stream>>>(dfeat, (const bf16_t*)y, (bf16_t*)g, M, rows, C / 8);
+  UNIT_LAUNCH_CHECK();
+  return UNIT_OK;
+}

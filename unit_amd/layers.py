@@ -68,6 +68,9 @@ class Conv2d(_EpochOnLoad):
         self._prep_key = None
         self.wf = self.wd = self.scale = self.shift = None
         self._links = []          # [(kind "wf" | "wd", dst)]: further, PITCHED copies of the prepared weights (link_copy)
+        # bf16x3 parity-grade mode (ops.X3, csrc/split.hip): set by set_x3() on every conv whose channel counts allow it; the layer then
+        # takes / returns split tensors, its prepared copies are the three-segment bf16 weights of unit_conv2d_fwd_x3
+        self.x3 = False
 
     def link_copy(self, kind, dst):
         """keep `dst` -- a 2-D strided view [rows, cols] into a concatenated GEMM weight (BottleneckBlock.prepare_dual) -- equal to the
@@ -88,7 +91,7 @@ class Conv2d(_EpochOnLoad):
 
     # -- weight preparation (FrozenBN fold + cast + dgrad re-layout); re-run when the master weights changed
     def prepare(self, dtype, version, need_dgrad=True):
-        key = (dtype, version if self.weight.requires_grad else -1, _FROZEN_EPOCH[0], self.weight.data_ptr(), need_dgrad)
+        key = (dtype, version if self.weight.requires_grad else -1, _FROZEN_EPOCH[0], self.weight.data_ptr(), need_dgrad, self.x3)
         if key == self._prep_key:
             return
         if self.norm is not None:
@@ -100,6 +103,16 @@ class Conv2d(_EpochOnLoad):
         else:
             self.scale, self.shift = None, (self.bias.data if self.bias is not None else None)
         src = _krsc_storage(self.weight.data)
+        if self.x3:
+            assert dtype == torch.float32, "bf16x3 convs belong to the fp32-typed plan (compute_mode 'bf16x3')"
+            ok = lambda t, shape: t if (t is not None and t.dtype == torch.bfloat16 and tuple(t.shape) == shape) else None
+            self.wf, self.wd = ops.weight_prep_x3(src, self.scale, self.cout, self.k, self.k, self.cin, want_dgrad=need_dgrad,
+                                                  w_fwd=ok(self.wf, (self.cout, self.k, self.k, 3 * self.cin)),
+                                                  w_dgrad=ok(self.wd, (self.cin, self.k, self.k, 3 * self.cout)))
+            self._prep_key = key
+            return
+        if self.wf is not None and self.wf.dim() == 4 and self.wf.shape[-1] != self.cin_pad:
+            self.wf = self.wd = None          # left over from the bf16x3 mode
         self.wf, self.wd = ops.weight_prep(src, self.scale, self.cout, self.k, self.k, self.cin, self.cin_pad, dtype,
                                            want_dgrad=need_dgrad, w_fwd=self.wf if self.wf is not None and self.wf.dtype == dtype else None,
                                            w_dgrad=self.wd if self.wd is not None and self.wd.dtype == dtype else None)
@@ -108,6 +121,8 @@ class Conv2d(_EpochOnLoad):
 
     def fwd(self, x, relu=False, residual=None, out_dtype=None, stride=None):
         st = self.stride if stride is None else stride
+        if self.x3:
+            x, residual = ops.as_x3(x), ops.as_x3(residual)
         return ops.conv2d(x, self.wf, self.cout, self.k, self.k, st, self.pad, bias=self.shift, residual=residual, relu=relu,
                           out_dtype=out_dtype)
 
@@ -116,6 +131,8 @@ class Conv2d(_EpochOnLoad):
         mask_bits: ops.ReluBits of the input (what mask_ref > 0 would give) -- read instead of mask_ref where the 256x256 kernel's
         extended epilogue applies (1/16 of the mask bytes: 218 -> 180 us for the 512 -> 2048 dgrad + residual of a Res5 block)"""
         st = self.stride if stride is None else stride
+        if self.x3:
+            dy, residual, mask_ref, mask_bits = ops.as_x3(dy), ops.as_x3(residual), ops.as_x3(mask_ref), None
         if st == 1 and mask_bits is not None and ops.conv_ex_supported(dy.dtype, self.cout, self.cin):
             mb = mask_bits.aligned()
             if mb is not None:
@@ -130,6 +147,11 @@ class Conv2d(_EpochOnLoad):
             return
         st = self.stride if stride is None else stride
         acc = ops.WGRAD_ACCUMULATE      # second contribution to the same gradients (ragged batches: backbone backward runs twice)
+        dy_plain = dy
+        if self.x3:
+            if self.bias is not None and self.bias.requires_grad:
+                dy_plain = ops.as_f32(dy)          # the bias gradient's column sums read plain fp32
+            x, dy = ops.as_x3(x), ops.as_x3(dy)
         if getattr(self, "_plan", None) is not None:
             # multi-tensor plan (unit_amd/multi.py): leave the split-M slabs in this layer's resident buffer; one
             # unit_multi_wgrad_reduce launch per bucket folds them into the flat gradient buffer later
@@ -138,7 +160,7 @@ class Conv2d(_EpochOnLoad):
             if self.bias is not None and self.bias.requires_grad:       # (a conv without FrozenBN: the RPN's 3x3)
                 if self.bias.grad is None:
                     self.bias.grad = torch.zeros_like(self.bias.data)
-                ops.bias_grad(dy.reshape(-1, dy.shape[-1]), self.cout, out=self.bias.grad, accumulate=acc)
+                ops.bias_grad(dy_plain.reshape(-1, dy_plain.shape[-1]), self.cout, out=self.bias.grad, accumulate=acc)
             if self._plan.defer_wgrad(self, x, dy, st, acc):
                 return       # goes out with the rest of its gradient bucket in one grouped launch (multi.py)
 
@@ -171,7 +193,22 @@ class Conv2d(_EpochOnLoad):
         if self.bias is not None and self.bias.requires_grad:
             if self.bias.grad is None:
                 self.bias.grad = torch.zeros_like(self.bias.data)
-            ops.bias_grad(dy.reshape(-1, dy.shape[-1]), self.cout, out=self.bias.grad, accumulate=acc)
+            ops.bias_grad(dy_plain.reshape(-1, dy_plain.shape[-1]), self.cout, out=self.bias.grad, accumulate=acc)
+
+
+def set_x3(module, on):
+    """switch every Conv2d under `module` whose shapes the bf16x3 kernels take (input and output channels multiples of 64, not a member of a
+    LinearGroup) to / from the bf16x3 mode. The small-channel layers left out -- the 3-channel stem, the predictors' GEMMs -- keep the true
+    fp32 kernels of the fp32 plan (0.3 % of the step's FLOPs)."""
+    n = 0
+    for m in module.modules():
+        if isinstance(m, Conv2d):
+            ok = bool(on) and m.cin % 64 == 0 and m.cout % 64 == 0 and m.cin_pad == m.cin and not getattr(m, "_in_linear_group", False)
+            if ok != m.x3:
+                m.x3 = ok
+                m._prep_key = None
+            n += int(ok)
+    return n
 
 
 class BottleneckBlock(nn.Module):
@@ -193,6 +230,8 @@ class BottleneckBlock(nn.Module):
         (box_head.py:80) and, in the backward, tested for > 0 -- conv3's epilogue then produces the pooled features and a bit mask
         and never writes the map: returns ((pooled, bits | None), ctx) instead of (map, ctx)"""
         st = self.stride if stride is None else stride
+        if self.conv1.x3:
+            x = ops.as_x3(x)          # (once: conv1 and the shortcut read it, the backward's weight gradients again)
         y1 = self.conv1.fwd(x, relu=True, stride=st)
         y2 = self.conv2.fwd(y1, relu=True)
         if self._dual_ok(x, y2, st) and not pool_rows:
@@ -262,6 +301,8 @@ class BottleneckBlock(nn.Module):
 
     def bwd(self, ctx, g, need_dx=True, mask_input=True):
         x, y1, y2, st, x_bits = ctx
+        if self.conv3.x3:
+            g = ops.as_x3(g)
         self.conv3.wgrad(y2, g)
         dy2 = self.conv3.dgrad(g, y2.shape[1:3], mask_ref=y2)
         self.conv2.wgrad(y1, dy2)

@@ -104,6 +104,7 @@ class WeaklySupervisedRCNNNoMeta(nn.Module):
             if any(layer == name.split(".")[0] for layer in cfg.MODEL.FREEZE_LAYERS.META_ARCH):
                 p.requires_grad = False
         self.compute_dtype = torch.bfloat16
+        self._x3 = False
         self.version = 0          # bumped by the optimizer: layers re-fold / re-cast their weights when it changes
         self.store = None
         self._anchor = None
@@ -135,6 +136,22 @@ class WeaklySupervisedRCNNNoMeta(nn.Module):
     @property
     def device(self):
         return self.pixel_mean.device
+
+    # "bf16" (the benchmarked mode: bf16 activations, MFMA, fp32 accumulation), "fp32" (true fp32 MFMA: the parity mode, 1/16 of the MFMA
+    # rate) or "bf16x3" (the parity-GRADE fast mode, csrc/split.hip: every conv with 64-multiple channel counts runs on the bf16 MFMA kernels
+    # over split operands -- hi.Wh + hi.Wl + lo.Wh, ~2^-17 per product -- inside the fp32 plan: activations between convs are ops.X3 split
+    # tensors, everything that is not a conv stays the fp32 kernel it is in the parity mode)
+    @property
+    def compute_mode(self):
+        return "bf16x3" if self._x3 else ("bf16" if self.compute_dtype == torch.bfloat16 else "fp32")
+
+    @compute_mode.setter
+    def compute_mode(self, mode):
+        assert mode in ("bf16", "fp32", "bf16x3"), mode
+        from ..layers import set_x3
+        self.compute_dtype = torch.bfloat16 if mode == "bf16" else torch.float32
+        self._x3 = mode == "bf16x3"
+        set_x3(self, self._x3)
 
     # ------------------------------------------------------------------ parameters
     def trainable_order(self):
@@ -235,6 +252,8 @@ class WeaklySupervisedRCNNNoMeta(nn.Module):
     def _ensure_ready(self):
         if self.training and (self.store is None or not self.store.is_current()):
             self.flatten_parameters()
+        if self._x3 and self.compute_dtype != torch.float32:      # someone assigned compute_dtype directly: that leaves the bf16x3 mode
+            self.compute_mode = "bf16" if self.compute_dtype == torch.bfloat16 else "fp32"
         dt, v = self.compute_dtype, self.version
         pending = self._tail_pending is not None
         if pending and getattr(self, "_plan_ok_version", None) != v:
@@ -386,6 +405,10 @@ class WeaklySupervisedRCNNNoMeta(nn.Module):
             anchors_w = rpn.anchor_generator.grid(feat_w.shape[1], feat_w.shape[2])
         self.join_optimizer_tail()          # (a fully frozen backbone never called it)
         c.image_sizes = sizes
+        # bf16x3 mode: the backbone hands over split tensors (ops.X3). The RPN's conv reads them as they are; RoIAlign, its backward and the
+        # ReLU mask of the map gradient are fp32 kernels and read a merged copy (38 MB for four 600x1000 images) -- `feat` below
+        feat_c, feat_w_c = feat, feat_w
+        feat, feat_w = ops.as_f32(feat), (ops.as_f32(feat_w) if feat_w is not None else None)
         c.feat, c.feat_w = feat, feat_w
         n, fh, fw, fc = feat.shape
         anchors = rpn.anchor_generator.grid(fh, fw)
@@ -412,9 +435,9 @@ class WeaklySupervisedRCNNNoMeta(nn.Module):
                 perms["roi"].record_stream(torch.cuda.current_stream())
             else:
                 perms = self.sampling_permutations(n_sup, anchors.shape[0], n_roi_cap)
-        head, c.rpn_ctx = rpn.rpn_head.fwd(feat, save=True)
+        head, c.rpn_ctx = rpn.rpn_head.fwd(feat_c, save=True)
         if split and head_w is None:
-            head_w, _ = rpn.rpn_head.fwd(feat_w, save=False)          # weak images: proposals only (no RPN loss)
+            head_w, _ = rpn.rpn_head.fwd(feat_w_c, save=False)          # weak images: proposals only (no RPN loss)
         c.dhead = None
         c.drpn = None
         c.rpn_bwd_early = False
@@ -428,7 +451,7 @@ class WeaklySupervisedRCNNNoMeta(nn.Module):
             self._reattach_grads()
             main, s2 = torch.cuda.current_stream(), self._rpn_stream
             s2.wait_stream(main)
-            for t in (head, feat, anchors, perms["rpn"], c.losses) + tuple(c.rpn_ctx):
+            for t in (head, feat, feat_c, anchors, perms["rpn"], c.losses) + tuple(c.rpn_ctx):
                 t.record_stream(s2)
             with torch.cuda.stream(s2):
                 c.rpn_losses = c.losses[6:8]          # the branch writes its two slots of the loss vector itself; nobody else touches them
@@ -768,6 +791,8 @@ class WeaklySupervisedRCNNNoMeta(nn.Module):
             drpn = rpn.rpn_head.bwd(c.rpn_ctx, c.dhead, n_sup)
             done("rpn")
         if bb_trainable:
+            # (bf16x3 mode: the Res5 heads and the RPN conv return split tensors, the RoIAlign backward is an fp32 kernel)
+            dpool_sup, dpool_weak, drpn = ops.as_f32(dpool_sup), ops.as_f32(dpool_weak), ops.as_f32(drpn)
             # d(loss)/d(res4 output) = RoIAlign backward (gather form, deterministic) + RPN branch, times the ReLU mask --
             # one fused kernel per image group (supervised RoIs only touch supervised images, weak RoIs weak images)
             def grad_map(ft, dp, n_im, r_lo, r_hi, img0, add):

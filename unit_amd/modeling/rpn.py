@@ -33,7 +33,7 @@ class StandardRPNHead(nn.Module):
     def fwd(self, feat, save=False):
         """feat [N,H,W,C] -> head fp32 [N, H*W, kp] (cols [0,A) logits, [A,5A) deltas) ; ctx"""
         n, h, w, c = feat.shape
-        t = self.conv.fwd(feat, relu=True)
+        t = ops.as_f32(self.conv.fwd(feat, relu=True))          # (bf16x3 mode: the conv returns a split tensor, the predictors' GEMM is an fp32 kernel)
         head = self.pred.fwd(t.view(n * h * w, c)).view(n, h * w, self.pred.kp)
         return head, ((feat, t) if save else None)
 

@@ -29,7 +29,51 @@ def _p(t):
         return None
     if not t.is_cuda:
         raise RuntimeError("unit_amd ops need tensors on the ROCm device (no CPU fallback)")
+    if type(t) is X3:
+        raise TypeError("a bf16x3 split tensor (ops.X3) was handed to a kernel that reads plain fp32: convert with ops.as_f32 first")
     return ctypes.c_void_p(t.data_ptr())
+
+
+class X3(torch.Tensor):
+    """A bf16x3 "split" activation (csrc/split.hip): logically fp32 [..., C], physically two bf16 planes per row, [...][2][C] --
+    hi = bf16(x), lo = bf16(x - hi) -- in the 4 bytes per element of a float32 tensor of the SAME shape. The subclass is the marker:
+    it survives slicing / views / empty_like / cat (row-wise operations are all the plan does to activations), the conv wrappers take
+    it, every other wrapper refuses it (`_p`) until `as_f32` has merged the planes. Never do arithmetic on it with torch operators."""
+
+
+def _px(t):
+    """device pointer of a split tensor (or None)"""
+    if t is None:
+        return None
+    if type(t) is not X3:
+        raise TypeError("expected a bf16x3 split tensor (ops.X3): convert with ops.as_x3 first")
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def x3_split(x, out=None):
+    """fp32 [..., C] -> X3 of the same shape (unit_x3_split)"""
+    assert type(x) is not X3 and x.dtype == torch.float32 and x.is_contiguous(), "x3_split: contiguous fp32"
+    c = x.shape[-1]
+    y = out if out is not None else torch.empty(x.shape, dtype=torch.float32, device=x.device)
+    check(lib().unit_x3_split(_p(x), ctypes.c_void_p(y.data_ptr()), x.numel() // c, c, _s()), "x3_split")
+    return y.as_subclass(X3)
+
+
+def x3_merge(x, out=None):
+    """X3 -> plain fp32 of the same shape (hi + lo, exact)"""
+    assert type(x) is X3 and x.is_contiguous()
+    c = x.shape[-1]
+    y = out if out is not None else torch.empty(x.shape, dtype=torch.float32, device=x.device).as_subclass(torch.Tensor)
+    check(lib().unit_x3_merge(_px(x), _p(y), x.numel() // c, c, _s()), "x3_merge")
+    return y
+
+
+def as_x3(x):
+    return x if (x is None or type(x) is X3) else x3_split(x)
+
+
+def as_f32(x):
+    return x3_merge(x) if type(x) is X3 else x
 
 
 _raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
@@ -371,7 +415,12 @@ _POLICY_CACHE = {}
 def conv2d(x, w, k, r, s, stride=1, pad=0, bias=None, residual=None, mask_ref=None, relu=False, out_dtype=None,
            out=None, ldy=None, scatter=None, tile_cfg=0):
     """x [N,H,W,C] NHWC ; w [k][r][s][C] (same dtype). Returns y [N,OH,OW,ldy] (or writes the strided scatter target).
-    scatter = (oy_mul, OHf, OWf): output pixel (n,oh,ow) lands at (n, oh*oy_mul, ow*oy_mul) of `out` [N,OHf,OWf,ldy]."""
+    scatter = (oy_mul, OHf, OWf): output pixel (n,oh,ow) lands at (n, oh*oy_mul, ow*oy_mul) of `out` [N,OHf,OWf,ldy].
+    x an ops.X3 (bf16x3 split tensor, w prepared by weight_prep_x3): conv2d_x3."""
+    if type(x) is X3:
+        assert out_dtype is None and ldy is None
+        return conv2d_x3(x, w, k, r, s, stride, pad, bias=bias, residual=residual, mask_ref=mask_ref, relu=relu, out=out, scatter=scatter,
+                         tile=None if tile_cfg == 0 else tile_cfg)
     n, h, wd, c = x.shape
     oh, ow = conv_out_size(h, wd, r, s, stride, pad)
     out_dtype = out_dtype or x.dtype
@@ -539,6 +588,9 @@ def avgpool_bwd_bits(dfeat, bits, ph, pw):
 
 def conv2d_wgrad(x, dy, k, r, s, stride=1, pad=0, scale=None, out=None, accumulate=False, ldy=None, variant=0):
     """x [N,H,W,C], dy [N,OH,OW,ldy] -> dw fp32 [k,r,s,C] (scale[k] folded)."""
+    if type(x) is X3:
+        assert ldy is None
+        return conv2d_wgrad_x3(x, dy, k, r, s, stride, pad, scale=scale, out=out, accumulate=accumulate, variant=variant)
     n, h, wd, c = x.shape
     oh, ow = conv_out_size(h, wd, r, s, stride, pad)
     ldy = ldy or dy.shape[-1]
@@ -562,6 +614,8 @@ def conv2d_wgrad(x, dy, k, r, s, stride=1, pad=0, scale=None, out=None, accumula
 
 def conv2d_wgrad_partial(x, dy, k, r, s, stride, pad, slab=None, variant=0):
     """split-M partial slabs only (no reduction): returns (slab uint8 tensor, n_splits); slab i = floats [i*k*r*s*C, ...)."""
+    if type(x) is X3:
+        return _wgrad_partial_x3(x, dy, k, r, s, stride, pad, slab, variant)
     n, h, wd, c = x.shape
     oh, ow = conv_out_size(h, wd, r, s, stride, pad)
     nbytes = lib().unit_conv2d_wgrad_workspace_bytes(dt(x.dtype), n, oh, ow, k, r, s, c)
@@ -586,17 +640,129 @@ def conv2d_wgrad_partial(x, dy, k, r, s, stride, pad, slab=None, variant=0):
     return slab, splits
 
 
+
+# ------------------------------------------------------------------------------------------------ bf16x3 (split) convolutions
+def x3_tile_policy(m, k, c, kgemm_v):
+    """kernel / tile of a bf16x3 conv with m output pixels, k filters, c real input channels, kgemm_v = 3 * r * s * c virtual k extent:
+    -1 = the 256x256 phase-interleaved kernel, 0 / 1 / 2 = 4-wave tiles, >= 100 = loader / consumer tile code (the plain bf16 policies
+    applied to the three times longer contraction)"""
+    if k >= 256 and kgemm_v >= 512 and ((m + 255) // 256) * ((k + 255) // 256) >= 128:
+        return -1
+    if k <= 64:
+        return 2
+    tiles = ((m + 127) // 128) * ((k + 127) // 128)
+    if not _NO_LC and kgemm_v >= 512 and tiles <= 640 and k % 8 == 0:
+        return lc_tile_code(m, k, kgemm_v)
+    return 0 if tiles >= 256 else 1
+
+
+X3_TILE_POLICY = x3_tile_policy
+
+
+def conv2d_x3(x, w, k, r, s, stride=1, pad=0, bias=None, residual=None, mask_ref=None, relu=False, out=None, scatter=None, tile=None):
+    """bf16x3 convolution (unit_conv2d_fwd_x3): x X3 [N,H,W,C], w = weight_prep_x3's forward (or dgrad) copy, residual / mask_ref X3;
+    returns an X3 [N,OH,OW,k] (or writes the strided scatter target)."""
+    n, h, wd, c = x.shape
+    assert x.is_contiguous() and c % 64 == 0 and k % 8 == 0, "conv2d_x3: C % 64 == 0, K % 8 == 0"
+    oh, ow = conv_out_size(h, wd, r, s, stride, pad)
+    if scatter is None:
+        oy_mul, ohf, owf = 1, oh, ow
+    else:
+        oy_mul, ohf, owf = scatter
+    if out is None:
+        out = (zeros((n, ohf, owf, k), torch.float32, x.device) if scatter is not None
+               else torch.empty((n, ohf, owf, k), dtype=torch.float32, device=x.device)).as_subclass(X3)
+    assert type(out) is X3 and out.is_contiguous()
+    if residual is not None:
+        assert type(residual) is X3 and residual.is_contiguous() and residual.shape[-1] == k
+    mask_c = 0
+    if mask_ref is not None:
+        assert type(mask_ref) is X3 and mask_ref.is_contiguous()
+        mask_c = mask_ref.shape[-1]
+    m = n * oh * ow
+    if tile is None:
+        pkey = ("x3", m, k, c, r * s, X3_TILE_POLICY, _NO_LC)
+        tile = _POLICY_CACHE.get(pkey)
+        if tile is None:
+            tile = _POLICY_CACHE[pkey] = X3_TILE_POLICY(m, k, c, 3 * r * s * c)
+    prof = PROFILER
+    if prof is not None:
+        e0 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+    check(lib().unit_conv2d_fwd_x3(_px(x), _p(w), _px(out), _p(bias), _px(residual), _px(mask_ref), mask_c, n, h, wd, c, k, r, s, stride, pad,
+                                   oh, ow, k, oy_mul, ohf, owf, int(relu), int(tile), _s()), "unit_conv2d_fwd_x3")
+    if prof is not None:
+        e1 = torch.cuda.Event(enable_timing=True)
+        e1.record()
+        nbytes = (x.numel() + m * k * (1 + (residual is not None))) * 4 + (m * k * 2 if mask_ref is not None else 0) + w.numel() * 2
+        feed = None
+        if tile >= 0:
+            bm, bn = mid_tile_dims(tile)
+            tiles = ((m + bm - 1) // bm) * ((k + bn - 1) // bn)
+            feed = ((tiles + 255) // 256) * (3 * r * s * c // 64) * (bm + bn) * 128.0
+        # flops = the MFMA work issued: three bf16 products per fp32 product
+        prof.setdefault("conv_igemm256" if tile < 0 else "conv_igemm_dma", []).append((e0, e1, 3 * 2.0 * m * k * r * s * c, nbytes, feed))
+    return out
+
+
+def weight_prep_x3(w_krsc, scale, k, r, s, c, want_fwd=True, want_dgrad=True, w_fwd=None, w_dgrad=None):
+    """fp32 [k][r][s][c] storage -> (bf16 [k][r][s][c/64][3][64], bf16 [c][r][s][k/64][3][64]) = the k-segments [Wh | Wl | Wh] of the bf16x3
+    convs (forward: c % 64 == 0; dgrad: k % 64 == 0; either may be skipped)"""
+    dev = w_krsc.device
+    if want_fwd and w_fwd is None:
+        w_fwd = torch.empty((k, r, s, 3 * c), dtype=torch.bfloat16, device=dev)
+    if want_dgrad and w_dgrad is None:
+        w_dgrad = torch.empty((c, r, s, 3 * k), dtype=torch.bfloat16, device=dev)
+    check(lib().unit_weight_prep_x3(_p(w_krsc), _p(scale), k, r, s, c, _p(w_fwd) if want_fwd else None, _p(w_dgrad) if want_dgrad else None, _s()),
+          "weight_prep_x3")
+    return (w_fwd if want_fwd else None), (w_dgrad if want_dgrad else None)
+
+
+def conv2d_wgrad_x3(x, dy, k, r, s, stride=1, pad=0, scale=None, out=None, accumulate=False, variant=0, slab=None):
+    """bf16x3 weight gradient: x X3 [N,H,W,C], dy X3 [N,OH,OW,k] -> dw fp32 [k,r,s,C] (scale[k] folded); out=None and slab given (or
+    partial=True via conv2d_wgrad_partial): leaves the 3 * splits slabs"""
+    n, h, wd, c = x.shape
+    oh, ow = conv_out_size(h, wd, r, s, stride, pad)
+    assert type(x) is X3 and type(dy) is X3 and x.is_contiguous() and dy.is_contiguous() and dy.shape[-1] == k
+    if out is None:
+        out = torch.empty((k, r, s, c), dtype=torch.float32, device=x.device)
+    nbytes = 3 * lib().unit_conv2d_wgrad_workspace_bytes(BF16, n, oh, ow, k, r, s, c)
+    ws = workspace(nbytes, x.device, slot=2)
+    with _timed("conv_wgrad", 3 * 2.0 * n * oh * ow * k * r * s * c, (x.numel() + dy.numel()) * 4 + 4 * k * r * s * c):
+        check(lib().unit_conv2d_wgrad_x3(_px(x), _px(dy), _p(out), _p(scale), n, h, wd, c, k, r, s, stride, pad, oh, ow, k, int(accumulate),
+                                         int(variant), _p(ws), ws.numel(), _s()), "unit_conv2d_wgrad_x3")
+    return out
+
+
+def _wgrad_partial_x3(x, dy, k, r, s, stride, pad, slab, variant):
+    n, h, wd, c = x.shape
+    oh, ow = conv_out_size(h, wd, r, s, stride, pad)
+    assert type(dy) is X3 and x.is_contiguous() and dy.is_contiguous() and dy.shape[-1] == k
+    nbytes = 3 * lib().unit_conv2d_wgrad_workspace_bytes(BF16, n, oh, ow, k, r, s, c)
+    if slab is None or slab.numel() < nbytes:
+        old = slab
+        if slab is not None:
+            _retire(slab)
+        slab = torch.empty(_grown(nbytes, old), dtype=torch.uint8, device=x.device)
+    splits = 3 * lib().unit_conv2d_wgrad_splits(BF16, n, oh, ow, k, r, s, c)
+    with _timed("conv_wgrad", 3 * 2.0 * n * oh * ow * k * r * s * c, (x.numel() + dy.numel()) * 4 + 4 * k * r * s * c):
+        check(lib().unit_conv2d_wgrad_x3(_px(x), _px(dy), None, None, n, h, wd, c, k, r, s, stride, pad, oh, ow, k, 0, int(variant), _p(slab),
+                                         slab.numel(), _s()), "unit_conv2d_wgrad_x3(partial)")
+    return slab, splits
+
+
 class WgradProblem(ctypes.Structure):
     """include/unit_hip.h: UnitWgradProblem"""
     _fields_ = [("x", ctypes.c_void_p), ("dy", ctypes.c_void_p), ("partial", ctypes.c_void_p)] + \
-               [(f, ctypes.c_int) for f in ("N", "H", "W", "C", "K", "R", "S", "stride", "pad", "OH", "OW", "ldy", "splits", "kind")]
+               [(f, ctypes.c_int) for f in ("N", "H", "W", "C", "K", "R", "S", "stride", "pad", "OH", "OW", "ldy", "splits", "kind",
+                                            "x_pitch", "x_back", "dy_back")]
 
 
 def wgrad_group_supported(x, dy, k, r, s, stride, pad):
     """may this layer's weight gradient go into a grouped launch (csrc/conv_wgrad128r.hip)?"""
     n, h, wd, c = x.shape
     oh, ow = conv_out_size(h, wd, r, s, stride, pad)
-    return x.dtype == torch.bfloat16 and bool(lib().unit_conv2d_wgrad_group_supported(dt(x.dtype), n, oh, ow, k, r, s, c))
+    return type(x) is not X3 and x.dtype == torch.bfloat16 and bool(lib().unit_conv2d_wgrad_group_supported(dt(x.dtype), n, oh, ow, k, r, s, c))
 
 
 def conv2d_wgrad_group(items, slabs=None, splits_hint=0):
@@ -698,8 +864,12 @@ def maxpool3x3s2(x):
 
 
 def global_avgpool(x):
-    """[R,PH,PW,C] -> [R,C]"""
+    """[R,PH,PW,C] -> [R,C] (an X3 map: fp32 features, unit_global_avgpool_x3_fwd)"""
     r, ph, pw, c = x.shape
+    if type(x) is X3:
+        y = torch.empty((r, c), dtype=torch.float32, device=x.device)
+        check(lib().unit_global_avgpool_x3_fwd(_px(x), _p(y), r, ph * pw, c, _s()), "avgpool_x3_fwd")
+        return y
     y = torch.empty((r, c), dtype=x.dtype, device=x.device)
     check(lib().unit_global_avgpool_fwd(_p(x), _p(y), dt(x.dtype), r, ph * pw, c, _s()), "avgpool_fwd")
     return y
@@ -707,6 +877,10 @@ def global_avgpool(x):
 
 def global_avgpool_bwd_relu(dfeat, out):
     r, ph, pw, c = out.shape
+    if type(out) is X3:          # -> X3 gradient map
+        g = torch.empty(out.shape, dtype=torch.float32, device=out.device).as_subclass(X3)
+        check(lib().unit_global_avgpool_x3_bwd_relu(_p(dfeat), _px(out), _px(g), r, ph * pw, c, _s()), "avgpool_x3_bwd")
+        return g
     g = torch.empty_like(out)
     check(lib().unit_global_avgpool_bwd_relu(_p(dfeat), _p(out), _p(g), dt(out.dtype), r, ph * pw, c, _s()), "avgpool_bwd")
     return g
