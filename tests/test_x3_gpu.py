@@ -3,7 +3,8 @@ that stands in for the reference's fp32 convolutions (/root/reference/modeling/r
 modeling/proposal_generator/rpn.py:55-101) at bf16 MFMA rates.
 
 Two bars per operator: (1) the kernel's MECHANICS against an fp64 evaluation of exactly the three products it is defined as
-(hi.Wh + hi.Wl + lo.Wh on the split operands) -- what remains is fp32 accumulation order, asserted at 2e-6 of the output's scale;
+(hi.Wh + hi.Wl + lo.Wh on the split operands) -- what remains is the fp32 accumulation order (asserted at 2e-6 of the output's scale)
+and, for split OUTPUTS, their own 16 significant bits (2^-16 of each element);
 (2) the FORMAT's accuracy against the fp32 / fp64 convolution of the unsplit operands -- the ~2^-17 per product the design promises,
 asserted at 3e-5 of the output's scale (plain bf16 sits at 4e-3)."""
 import numpy as np
@@ -102,7 +103,8 @@ def test_conv_x3_kernels(dev, case, tile):
     y = o.conv2d_x3(xs, wf, k, r, r, stride, pad, bias=bias.to(dev), tile=tile)
     assert type(y) is o.X3
     got = o.as_f32(y).cpu().double()
-    assert (got - (ref3 + bias.double())).abs().max().item() <= 2e-6 * scale            # the kernel computes its three products
+    e3 = ref3 + bias.double()
+    assert ((got - e3).abs() <= 2.0 ** -16 * e3.abs() + 2e-6 * scale).all()            # the kernel computes its three products
     assert (got - (ref + bias.double())).abs().max().item() <= 3e-5 * scale             # ... which are fp32-grade
     # epilogue: bias + split residual, ReLU, mask by the sign of a split tensor's hi plane
     rs, ms = o.x3_split(res.to(dev)), o.x3_split(msk.to(dev))
@@ -110,14 +112,14 @@ def test_conv_x3_kernels(dev, case, tile):
     rh, rl = split_cpu(res)
     exp = torch.relu(ref3 + bias.double() + rh.double() + rl.double()) * (msk.to(torch.bfloat16).float() > 0)
     # (a value within rounding of zero may flip the ReLU: compare with a tolerance, not bitwise)
-    assert (y2 - exp).abs().max().item() <= 2e-6 * max(scale, exp.abs().max().item())
+    assert ((y2 - exp).abs() <= 2.0 ** -16 * exp.abs() + 2e-6 * max(scale, exp.abs().max().item())).all()
 
 
 def test_conv_x3_policy_and_position_classes(dev):
     """what the step launches (tile=None): the 256x256 kernel with position-class tiles on the Res5 3x3 shape equals the explicit 4-wave
     kernel within fp32 accumulation order, images not a multiple of the tile"""
     o = ops()
-    n, c, k = 300, 128, 512
+    n, c, k = 700, 128, 512
     gen = g(5)
     x = torch.randn(n, 7, 7, c, generator=gen)
     wt = torch.randn(k, 3, 3, c, generator=gen) / np.sqrt(9 * c)
@@ -126,9 +128,10 @@ def test_conv_x3_policy_and_position_classes(dev):
     assert o.X3_TILE_POLICY(n * 49, k, c, 27 * c) == -1
     a = o.as_f32(o.conv2d_x3(xs, wf, k, 3, 3, 1, 1, relu=True)).cpu()
     b = o.as_f32(o.conv2d_x3(xs, wf, k, 3, 3, 1, 1, relu=True, tile=0)).cpu()
-    assert torch.allclose(a, b, rtol=0, atol=2e-6 * b.abs().max().item())
+    assert torch.allclose(a, b, rtol=2.0 ** -15, atol=2e-6 * b.abs().max().item())
     ref3, _ = _x3_conv_ref(x[:8], wt, 1, 1)
-    assert (a[:8].double() - torch.relu(ref3)).abs().max().item() <= 2e-6 * ref3.abs().max().item()
+    e3 = torch.relu(ref3)
+    assert ((a[:8].double() - e3).abs() <= 2.0 ** -16 * e3 + 2e-6 * ref3.abs().max().item()).all()
     assert o.X3_TILE_POLICY(4 * 38 * 63, 256, 1024, 3 * 1024) >= 100          # res4: loader / consumer kernel
 
 

@@ -84,6 +84,8 @@ class Conv2d(_EpochOnLoad):
             plan._prep_table = None          # the table of the multi-tensor prep launch gains this destination
 
     def _refresh_links(self):
+        if self.x3:
+            return
         for kind, dst in self._links:
             src = self.wf if kind == "wf" else self.wd
             if src is not None and src.dtype == dst.dtype:
@@ -270,6 +272,8 @@ class BottleneckBlock(nn.Module):
         if not (ops.FUSE_EPILOGUE and ops.FUSE_DUAL and getattr(self, "allow_dual", False) and self.shortcut is not None):
             return
         c3, sc, c1 = self.conv3, self.shortcut, self.conv1
+        if c3.x3 or sc.x3 or c1.x3:
+            return          # bf16x3 mode: the prepared copies are three-segment weights, the dual-input GEMM is a plain-bf16 form
         if c3.wf is None or sc.wf is None or c3.wf.dtype != torch.bfloat16 or c3.k != 1 or sc.k != 1 or c1.k != 1:
             return
         key = (c3.wf.data_ptr(), sc.wf.data_ptr(), 0 if c1.wd is None else c1.wd.data_ptr(), 0 if sc.wd is None else sc.wd.data_ptr(),

@@ -103,8 +103,8 @@ class WeaklySupervisedRCNNNoMeta(nn.Module):
         for name, p in self.named_parameters():   # rcnn.py:250-255
             if any(layer == name.split(".")[0] for layer in cfg.MODEL.FREEZE_LAYERS.META_ARCH):
                 p.requires_grad = False
-        self.compute_dtype = torch.bfloat16
         self._x3 = False
+        self._compute_dtype = torch.bfloat16
         self.version = 0          # bumped by the optimizer: layers re-fold / re-cast their weights when it changes
         self.store = None
         self._anchor = None
@@ -143,15 +143,25 @@ class WeaklySupervisedRCNNNoMeta(nn.Module):
     # tensors, everything that is not a conv stays the fp32 kernel it is in the parity mode)
     @property
     def compute_mode(self):
-        return "bf16x3" if self._x3 else ("bf16" if self.compute_dtype == torch.bfloat16 else "fp32")
+        return "bf16x3" if self._x3 else ("bf16" if self._compute_dtype == torch.bfloat16 else "fp32")
 
     @compute_mode.setter
     def compute_mode(self, mode):
         assert mode in ("bf16", "fp32", "bf16x3"), mode
         from ..layers import set_x3
-        self.compute_dtype = torch.bfloat16 if mode == "bf16" else torch.float32
-        self._x3 = mode == "bf16x3"
-        set_x3(self, self._x3)
+        self._compute_dtype = torch.bfloat16 if mode == "bf16" else torch.float32
+        if self._x3 != (mode == "bf16x3"):
+            self._x3 = mode == "bf16x3"
+            set_x3(self, self._x3)
+
+    # the torch dtype of the plan's activations / gradients (bf16x3: float32-typed). Assigning it selects the plain mode of that dtype.
+    @property
+    def compute_dtype(self):
+        return self._compute_dtype
+
+    @compute_dtype.setter
+    def compute_dtype(self, dtype):
+        self.compute_mode = "bf16" if dtype == torch.bfloat16 else "fp32"
 
     # ------------------------------------------------------------------ parameters
     def trainable_order(self):
@@ -252,8 +262,6 @@ class WeaklySupervisedRCNNNoMeta(nn.Module):
     def _ensure_ready(self):
         if self.training and (self.store is None or not self.store.is_current()):
             self.flatten_parameters()
-        if self._x3 and self.compute_dtype != torch.float32:      # someone assigned compute_dtype directly: that leaves the bf16x3 mode
-            self.compute_mode = "bf16" if self.compute_dtype == torch.bfloat16 else "fp32"
         dt, v = self.compute_dtype, self.version
         pending = self._tail_pending is not None
         if pending and getattr(self, "_plan_ok_version", None) != v:
