@@ -210,3 +210,27 @@ def test_avgpool_x3(dev):
     assert type(gm) is o.X3
     exp = (d / 49).view(r, 1, 1, c) * (y > 0)
     assert torch.allclose(o.as_f32(gm).cpu(), exp, rtol=2.0 ** -15, atol=0)
+
+
+def test_wgrad_x3_grouped_launch(dev):
+    """the plan's grouped launches take X3 layers as three bf16 problems each (one per plane pass): same gradients as the per-layer call,
+    mixed tile kinds (256x256 and 128x128 grids), more problems than one grid's argument block holds"""
+    o = ops()
+    cases = [(4, 38, 63, 256, 256, 3, 1, 1), (4, 38, 63, 1024, 256, 1, 1, 0), (4, 38, 63, 256, 1024, 1, 1, 0), (2, 75, 125, 128, 128, 3, 1, 1),
+             (2, 75, 125, 512, 128, 1, 1, 0), (300, 7, 7, 512, 512, 3, 1, 1), (300, 7, 7, 512, 2048, 1, 1, 0), (300, 14, 14, 1024, 512, 1, 2, 0)]
+    items, refs = [], []
+    for i, (n, h, w, c, k, r, stride, pad) in enumerate(cases):
+        gen = g(20 + i)
+        x = torch.randn(n, h, w, c, generator=gen)
+        oh, ow = o.conv_out_size(h, w, r, r, stride, pad)
+        dy = torch.randn(n, oh, ow, k, generator=gen) / 8
+        xs, dys = o.x3_split(x.to(dev)), o.x3_split(dy.to(dev))
+        assert o.wgrad_group_supported(xs, dys, k, r, r, stride, pad)
+        items.append((xs, dys, k, r, r, stride, pad))
+        refs.append(o.conv2d_wgrad(xs, dys, k, r, r, stride, pad).cpu())
+    out = o.conv2d_wgrad_group(items)
+    for (slab, splits), (xs, dys, k, r, _, _, _), ref in zip(out, items, refs):
+        c = xs.shape[-1]
+        assert splits % 3 == 0
+        got = slab.view(torch.float32)[: splits * k * r * r * c].view(splits, k, r, r, c).sum(0).cpu()
+        assert torch.allclose(got, ref, rtol=0, atol=3e-6 * ref.abs().max().item()), (got - ref).abs().max()

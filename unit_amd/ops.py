@@ -759,44 +759,74 @@ class WgradProblem(ctypes.Structure):
 
 
 def wgrad_group_supported(x, dy, k, r, s, stride, pad):
-    """may this layer's weight gradient go into a grouped launch (csrc/conv_wgrad128r.hip)?"""
+    """may this layer's weight gradient go into a grouped launch (csrc/conv_wgrad128r.hip)? bf16 tensors, or X3 split tensors (each of
+    the three plane passes of a bf16x3 weight gradient is a bf16 problem of its own in the grid)"""
     n, h, wd, c = x.shape
     oh, ow = conv_out_size(h, wd, r, s, stride, pad)
-    return type(x) is not X3 and x.dtype == torch.bfloat16 and bool(lib().unit_conv2d_wgrad_group_supported(dt(x.dtype), n, oh, ow, k, r, s, c))
+    if type(x) is X3:
+        return type(dy) is X3 and bool(lib().unit_conv2d_wgrad_group_supported(BF16, n, oh, ow, k, r, s, c))
+    return x.dtype == torch.bfloat16 and bool(lib().unit_conv2d_wgrad_group_supported(dt(x.dtype), n, oh, ow, k, r, s, c))
+
+
+_X3_PASSES = ((0, 0), (0, 1), (1, 0))          # (plane of x, plane of dy) per pass: hi^T.hi + hi^T.lo + lo^T.hi
 
 
 def conv2d_wgrad_group(items, slabs=None, splits_hint=0):
     """split-M partial slabs of SEVERAL layers from one launch (unit_conv2d_wgrad_group). items: [(x, dy, k, r, s, stride, pad)];
     slabs: per item a uint8 tensor to reuse or None. Returns [(slab, n_splits)]; slab i of a layer = floats [i*k*r*s*C, ...) as
-    conv2d_wgrad_partial leaves them."""
+    conv2d_wgrad_partial leaves them. X3 items (bf16x3 split tensors) enter as three problems, one per plane pass, whose slabs follow
+    each other in the layer's buffer (n_splits = all of them)."""
     n_items = len(items)
     if n_items == 0:
         return []
     assert ctypes.sizeof(WgradProblem) == lib().unit_wgrad_problem_bytes()
-    pr = (WgradProblem * n_items)()
+    probs = []          # (item index, pass | None)
+    for i, it in enumerate(items):
+        if type(it[0]) is X3:
+            assert type(it[1]) is X3 and it[1].shape[-1] == it[2]
+            probs += [(i, ps) for ps in range(3)]
+        else:
+            probs.append((i, None))
+    pr = (WgradProblem * len(probs))()
     flops = nbytes = 0
-    for i, (x, dy, k, r, s, stride, pad) in enumerate(items):
+    for j, (i, ps) in enumerate(probs):
+        x, dy, k, r, s, stride, pad = items[i]
         n, h, wd, c = x.shape
         oh, ow = conv_out_size(h, wd, r, s, stride, pad)
-        q = pr[i]
-        q.x, q.dy = x.data_ptr(), dy.data_ptr()
-        q.N, q.H, q.W, q.C, q.K, q.R, q.S, q.stride, q.pad, q.OH, q.OW, q.ldy = n, h, wd, c, k, r, s, stride, pad, oh, ow, dy.shape[-1]
+        q = pr[j]
+        q.N, q.H, q.W, q.C, q.K, q.R, q.S, q.stride, q.pad, q.OH, q.OW = n, h, wd, c, k, r, s, stride, pad, oh, ow
+        if ps is None:
+            q.x, q.dy, q.ldy = x.data_ptr(), dy.data_ptr(), dy.shape[-1]
+            q.x_pitch = q.x_back = q.dy_back = 0
+            nbytes += (x.numel() + n * oh * ow * dy.shape[-1]) * 2 + 4 * k * r * s * c
+        else:
+            px, pd = _X3_PASSES[ps]
+            q.x, q.dy, q.ldy = x.data_ptr() + px * c * 2, dy.data_ptr() + pd * k * 2, 2 * k
+            q.x_pitch, q.x_back, q.dy_back = 2 * c, px * c, pd * k
+            nbytes += (x.numel() + n * oh * ow * k) * 2 + 4 * k * r * s * c
         flops += 2.0 * n * oh * ow * k * r * s * c
-        nbytes += (x.numel() + n * oh * ow * dy.shape[-1]) * 2 + 4 * k * r * s * c
-    check(lib().unit_conv2d_wgrad_group_plan(pr, n_items, int(splits_hint)), "unit_conv2d_wgrad_group_plan")
+    check(lib().unit_conv2d_wgrad_group_plan(pr, len(probs), int(splits_hint)), "unit_conv2d_wgrad_group_plan")
+    total = [0] * n_items
+    for j, (i, ps) in enumerate(probs):
+        total[i] += pr[j].splits
     out = []
     for i, (x, dy, k, r, s, stride, pad) in enumerate(items):
-        need = pr[i].splits * k * r * s * x.shape[-1] * 4
+        one = k * r * s * x.shape[-1] * 4
+        need = total[i] * one
         slab = slabs[i] if slabs is not None else None
         if slab is None or slab.numel() < need:
             old = slab
             if slab is not None:
                 _retire(slab)       # (conv2d_wgrad_partial)
             slab = torch.empty(_grown(need, old), dtype=torch.uint8, device=x.device)
-        pr[i].partial = slab.data_ptr()
-        out.append((slab, pr[i].splits))
+        out.append((slab, total[i]))
+    at = [0] * n_items
+    for j, (i, ps) in enumerate(probs):
+        x, dy, k, r, s, stride, pad = items[i]
+        pr[j].partial = out[i][0].data_ptr() + at[i] * k * r * s * x.shape[-1] * 4
+        at[i] += pr[j].splits
     with _timed("conv_wgrad", flops, nbytes):
-        check(lib().unit_conv2d_wgrad_group(pr, n_items, dt(torch.bfloat16), _s()), "unit_conv2d_wgrad_group")
+        check(lib().unit_conv2d_wgrad_group(pr, len(probs), dt(torch.bfloat16), _s()), "unit_conv2d_wgrad_group")
     return out
 
 
