@@ -99,6 +99,51 @@ def test_graphed_step_new_keys_after_warmup(dev):
     assert torch.allclose(m2.store.params, m1.store.params, rtol=1e-5, atol=1e-7)
 
 
+def test_graph_replays_survive_anchor_grid_eviction(dev):
+    """the anchor-grid cache is the grids' only owner and a captured step has a grid's address baked in. With more map
+    sizes than the cache holds (cap forced to 2 here; 128 in production, which multi-scale VOC exceeds) an evicted grid must outlive the
+    graphs: it is parked in ops._WS_RETIRED, eviction is least-recently-USED, and the replays of the evicted size still equal the eager run
+    after the freed-looking memory has been churned."""
+    from unit_amd import ops
+    sizes = [(96, 128), (160, 224), (128, 160), (112, 208)]
+    data = [[synthetic_batch(2, 2, hw=hw, seed=300 + 10 * i + j, max_gt=3) for j in range(2)] for i, hw in enumerate(sizes)]
+    seq = [data[0][0], data[0][1], data[1][0], data[1][1], data[2][0], data[2][1], data[3][0], data[3][1], data[0][0], data[1][1], data[0][1], data[2][0]]
+    cfg, m1 = _setup()
+    o1 = FlatSGD(m1, cfg)
+    ref = []
+    for d in seq:
+        b = m1.pack_batch(*d, gt_buckets=engine.GraphedStep.GT_BUCKETS)
+        o1._bind()
+        o1.use_device_lr(m1.device)
+        step = m1.forward_train(b, early_backward=True)
+        m1.backward_train(step)
+        o1.step()
+        ref.append(step.losses.clone())
+    torch.cuda.synchronize()
+    cfg, m2 = _setup()
+    gen = m2.proposal_generator.anchor_generator
+    gen.CACHE_CAP = 2
+    o2 = FlatSGD(m2, cfg)
+    gs = engine.GraphedStep(m2, o2, warmup_steps=2)
+    retired0 = len(ops._WS_RETIRED)
+    got = []
+    for d in seq:
+        got.append(gs.run(*d).clone())
+        junk = [torch.full((1 << 18,), float("nan"), device=dev) for _ in range(8)]          # churn what the allocator would hand out again
+        del junk
+    torch.cuda.synchronize()
+    assert len(gen._cache) <= 2 and len(ops._WS_RETIRED) > retired0          # grids were evicted, and kept alive for the graphs
+    for k, (a, b) in enumerate(zip(got, ref)):
+        assert torch.isfinite(a).all(), (k, a.tolist())
+        assert torch.allclose(a, b, rtol=1e-5, atol=1e-6), (k, a.tolist(), b.tolist())
+    # LRU, not FIFO: a hit moves the size to the back
+    g0 = gen.grid(6, 8)
+    gen.grid(10, 14)
+    assert gen.grid(6, 8) is g0
+    gen.grid(8, 10)                                                           # evicts (10, 14), the least recently used
+    assert gen.grid(6, 8) is g0
+
+
 def test_pack_batch_rejects_a_capacity_that_does_not_hold_the_batch(dev):
     cfg, m = _setup()
     sup, weak = synthetic_batch(1, 1, hw=(96, 128), seed=5, max_gt=40)

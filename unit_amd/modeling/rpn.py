@@ -74,14 +74,23 @@ class DefaultAnchorGenerator(nn.Module):
     def num_cell_anchors(self):
         return [self.cell_anchors[0].shape[0]]
 
+    CACHE_CAP = 128          # multi-scale training meets hundreds of map sizes; a grid is ~1 MB
+
     def grid(self, h, w):
+        """anchors of an h x w map, cached per size: least-recently-USED eviction beyond CACHE_CAP. A captured step (engine.GraphedStep) has
+        the grid's device address baked into its hipGraph and the cache is the tensor's only owner: once graphs may exist
+        (ops._GRAPHS_ALIVE) an evicted grid is parked in ops._WS_RETIRED instead of being freed, exactly like an outgrown workspace."""
         cell = self.cell_anchors[0]
         key = (h, w, cell.device, cell.data_ptr())
-        if key not in self._cache:
-            if len(self._cache) >= 128:          # multi-scale training meets hundreds of map sizes: keep the most recent (a grid is ~1 MB)
-                self._cache.pop(next(iter(self._cache)))
-            self._cache[key] = ops.anchor_grid(h, w, cell, self.stride, self.offset)
-        return self._cache[key]
+        g = self._cache.pop(key, None)
+        if g is None:
+            if len(self._cache) >= self.CACHE_CAP:
+                old = self._cache.pop(next(iter(self._cache)))          # the front of the dict = least recently used
+                if ops._GRAPHS_ALIVE[0]:
+                    ops._WS_RETIRED.append(old)
+            g = ops.anchor_grid(h, w, cell, self.stride, self.offset)
+        self._cache[key] = g          # (re-)inserted at the back: most recently used
+        return g
 
 
 @PROPOSAL_GENERATOR_REGISTRY.register()

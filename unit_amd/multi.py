@@ -182,5 +182,5 @@ class ConvPlan:
         check(lib().unit_multi_weight_prep(ops._p(t[0]), t[1], t[2], ops._p(self.model.store.params), ops.dt(dtype), ops._s()),
               "multi_weight_prep")
         for m in convs:
-            m._prep_key = (dtype, version, _FROZEN_EPOCH[0], m.weight.data_ptr(), True)
+            m._prep_key = (dtype, version, _FROZEN_EPOCH[0], m.weight.data_ptr(), True, m.x3)      # = Conv2d.prepare's key
         return True

@@ -646,7 +646,9 @@ def x3_tile_policy(m, k, c, kgemm_v):
     """kernel / tile of a bf16x3 conv with m output pixels, k filters, c real input channels, kgemm_v = 3 * r * s * c virtual k extent:
     -1 = the 256x256 phase-interleaved kernel, 0 / 1 / 2 = 4-wave tiles, >= 100 = loader / consumer tile code (the plain bf16 policies
     applied to the three times longer contraction)"""
-    if k >= 256 and kgemm_v >= 512 and ((m + 255) // 256) * ((k + 255) // 256) >= 128:
+    # (at least 200 tiles: the res4 256 -> 1024 layers -- 152 tiles on 256 CUs, 36.7 us -- run faster on the loader / consumer tiles: 36.2;
+    #  tools/x3_conv_sweep.py)
+    if k >= 256 and kgemm_v >= 512 and ((m + 255) // 256) * ((k + 255) // 256) >= 200:
         return -1
     if k <= 64:
         return 2
