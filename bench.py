@@ -62,6 +62,10 @@ def parse():
     ap.add_argument("--shapes", default="fixed", choices=["fixed", "voc"], help="fixed: the headline 600x1000 workload; voc: a SECONDARY labelled line "
                     "over steps whose image sizes are drawn like ResizeShortestEdge((480..800), 1333) on VOC aspect ratios "
                     "(configs/VOC/VOC-RCNN-101-C4-split1.yaml:27-29)")
+    ap.add_argument("--config", default=None, choices=["r50_s1", "s2", "coco_mask", "eval"],
+                    help="SECONDARY labelled lines for the other BASELINE.json configurations at their own size (N = 1): r50_s1 = config 2 (the headline "
+                         "path at --depth 50), s2 = config 4 (R101 1-shot fine-tune step), coco_mask = config 5 (COCO K = 80 + mask head step), "
+                         "eval = the inference path (VOC R101 1 / 4 images per call, COCO K = 80 with the 80-class NMS)")
     ap.add_argument("--dry-launch", action="store_true", help="launcher self-test: the rank processes print their rendezvous environment and exit "
                     "(no GPU call anywhere)")
     ap.add_argument("--launch-timeout", type=float, default=3600.0, help="seconds the launcher waits for its rank processes")
@@ -143,9 +147,10 @@ def launch_ranks(args):
 
 
 def cpu_baseline(depth, variant):
-    """The oracle (CPU restatement of the reference path, kind "port") timed on this box's host cores on a BOUNDED
-    sample: one S1 step (forward + backward) on 2 supervised + 2 weak 600x1000 images with 128 RoIs per image (the
-    bench workload with a quarter of the RoIs)."""
+    """The oracle (CPU restatement of the reference path, kind "port") timed on ALL of this box's host cores (the process's affinity
+    set; SURVEY 8d: torch.set_num_threads(os.cpu_count())) on a BOUNDED sample: one S1 step (forward + backward) on 2 supervised + 2 weak
+    600x1000 images -- first with 256 RoIs per image (half of the bench workload's; ~10 s), then, when that took under 40 s, with the full
+    512: `value` is the full workload's figure when it ran, the half sample's otherwise (both are reported)."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import unit_oracle as orc
     from unit_amd import config
@@ -155,37 +160,45 @@ def cpu_baseline(depth, variant):
         avail = len(os.sched_getaffinity(0))
     except AttributeError:
         avail = os.cpu_count() or 1
-    cores = max(1, min(avail, 16))     # threads actually used (more threads than the container's CPU quota only thrash)
+    cores = max(1, avail)              # every core the process may run on
     os.environ["OMP_NUM_THREADS"] = str(cores)
     torch.set_num_threads(cores)
     cfg = config.voc_rcnn_c4_split1(depth)
     cfg.MODEL.DEVICE = "cpu"
-    rois = 256          # half of the 512 RoIs per image: ~12 s of CPU work on 16 threads (the contract asks for a 10-30 s sample)
     m = build_model(cfg)
     init_synthetic_weights(m, seed=1)
     trainable = {n for n, p in m.named_parameters() if p.requires_grad}
-    p = {}
-    for k, v in m.state_dict().items():
-        t = v.detach().clone().contiguous()
-        if k in trainable:
-            t.requires_grad_(True)
-        p[k] = t
+    sd = m.state_dict()
     sup, weak = synthetic_batch(2, 2 if variant == "s1" else 0, seed=0)
     g = torch.Generator().manual_seed(2)
     perms = dict(rpn=[torch.randperm(38 * 63 * 15, generator=g) for _ in range(2)], roi=[torch.randperm(2000 + 8, generator=g) for _ in range(2)])
-    ocfg = dict(depth=depth, num_classes=20, novel_classes=list(cfg.DATASETS.FEWSHOT.NOVEL_CLASSES_ID), pixel_mean=cfg.MODEL.PIXEL_MEAN,
-                pixel_std=cfg.MODEL.PIXEL_STD, rois_per_image=rois, pre_nms_topk=12000, post_nms_topk=2000, multi_box_head=True)
-    t0 = time.time()
-    losses, _ = orc.step_losses(p, [x["image"] for x in sup], [x["instances"].gt_boxes.tensor for x in sup],
-                                [x["instances"].gt_classes for x in sup], [x["image"] for x in weak] if weak else None,
-                                [x["instances"].gt_classes for x in weak] if weak else None, perms, ocfg)
-    sum(losses.values()).backward()
-    dt = time.time() - t0
-    # FLOP normalisation: the sample runs every conv of the step except that the three Res5 passes see a quarter of the
-    # RoIs -- R101 S1: 4 x 166.1 + 4 x 45.6 (+ backward 4 x 2 x 147.3 + 2 x 2 x 45.6) GFLOP in full, 7 x 1499 / 4 for the heads
     full = STEP_TFLOP.get((variant, depth))
     heads = {"s1": 7, "s0": 3}[variant] * 1.499
-    sample_tflop = round(full - heads * (1 - rois / 512.0), 2) if full else None
+
+    def sample(rois):
+        p = {}
+        for k, v in sd.items():
+            t = v.detach().clone().contiguous()
+            if k in trainable:
+                t.requires_grad_(True)
+            p[k] = t
+        ocfg = dict(depth=depth, num_classes=20, novel_classes=list(cfg.DATASETS.FEWSHOT.NOVEL_CLASSES_ID), pixel_mean=cfg.MODEL.PIXEL_MEAN,
+                    pixel_std=cfg.MODEL.PIXEL_STD, rois_per_image=rois, pre_nms_topk=12000, post_nms_topk=2000, multi_box_head=True)
+        t0 = time.time()
+        losses, _ = orc.step_losses(p, [x["image"] for x in sup], [x["instances"].gt_boxes.tensor for x in sup],
+                                    [x["instances"].gt_classes for x in sup], [x["image"] for x in weak] if weak else None,
+                                    [x["instances"].gt_classes for x in weak] if weak else None, perms, ocfg)
+        sum(losses.values()).backward()
+        dt = time.time() - t0
+        # FLOP normalisation: the sample runs every conv of the step except that the three Res5 passes see rois / 512 of the
+        # RoIs -- R101 S1: 4 x 166.1 + 4 x 45.6 (+ backward 4 x 2 x 147.3 + 2 x 2 x 45.6) GFLOP in full, 7 x 1499 * rois / 512 for the heads
+        tf = round(full - heads * (1 - rois / 512.0), 2) if full else None
+        return {"rois_per_image": rois, "seconds": round(dt, 1), "images_per_sec": round(2.0 / dt, 4), "sample_tflop": tf,
+                "cpu_tflops": round(tf / dt, 3) if tf else None, "images_per_sec_flop_normalised": round(2.0 / dt * tf / full, 4) if tf else None}
+
+    half = sample(256)
+    whole = sample(512) if half["seconds"] < 40.0 else None
+    best = whole or half
     cpu_model = None
     try:
         for line in open("/proc/cpuinfo"):
@@ -194,11 +207,162 @@ def cpu_baseline(depth, variant):
                 break
     except OSError:
         pass
-    return {"value": round(2.0 / dt, 4), "unit": "images/sec", "cores": cores, "cpu_model": cpu_model, "host_cores_available": avail, "kind": "port",
+    return {"value": best["images_per_sec"], "unit": "images/sec", "cores": cores, "cpu_model": cpu_model, "host_cores_available": avail, "kind": "port",
             "sample": f"oracle (PyTorch-CPU fp32 + C) S1 fwd+bwd, R{depth}-C4, 2 supervised + 2 weak 3x600x1000 images, "
-                      f"{rois} RoIs/image (1/{512 // rois} of 512), {dt:.1f} s",
-            "sample_tflop": sample_tflop, "step_tflop": full, "cpu_tflops": round(sample_tflop / dt, 3) if sample_tflop else None,
-            "value_flop_normalised": round(2.0 / dt * sample_tflop / full, 4) if sample_tflop else None}
+                      f"{best['rois_per_image']} RoIs/image" + (" (the bench workload)" if whole else " (1/2 of 512)") + f", {best['seconds']} s on {cores} threads",
+            "sample_tflop": best["sample_tflop"], "step_tflop": full, "cpu_tflops": best["cpu_tflops"],
+            "value_flop_normalised": best["images_per_sec_flop_normalised"], "half_sample": half, "full_sample": whole}
+
+
+def _kernel_rates(prof, n_iter):
+    """per kernel family of an ops.PROFILER pass: launches per iteration, average launch time, TFLOP/s (MFMA) or GB/s (HBM) on the algorithmic work"""
+    out = {}
+    for k, ev in prof.items():
+        if not ev:
+            continue
+        tot = sum(e[0].elapsed_time(e[1]) for e in ev)      # ms
+        fl, by = sum(e[2] for e in ev), sum(e[3] for e in ev)
+        d = {"launches_per_iter": round(len(ev) / n_iter, 1), "avg_launch_us": round(tot / len(ev) * 1e3, 2), "ms_per_iter": round(tot / n_iter, 3)}
+        if fl:
+            d["tflops"] = round(fl / tot / 1e9, 1)
+        elif by:
+            d["gbs_on_algorithmic_bytes"] = round(by / tot / 1e6, 1)
+        out[k] = d
+    return out
+
+
+def other_config_run(args, dev):
+    """SECONDARY lines (never the headline): BASELINE.json configs 4 / 5 and the inference path at their own size on one GPU, each with the
+    dominant kernel's roofline entry from a single-stream HIP-event pass and the latency kernels (top-k sort, NMS) in us."""
+    from unit_amd import _lib, config, ops
+    from unit_amd.modeling import build_model
+    from unit_amd.parallel import GradBuckets
+    from unit_amd.solver import FlatSGD
+    from unit_amd.synthetic import init_synthetic_weights, synthetic_batch
+
+    def timed(fn, iters, warm):
+        for _ in range(warm):
+            fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / iters * 1e3
+
+    def profiled(fn, model, iters=3):
+        was = getattr(model, "overlap_streams", True)
+        model.overlap_streams = False
+        fn()
+        torch.cuda.synchronize()
+        prof = {}
+        ops.PROFILER = prof
+        for _ in range(iters):
+            fn()
+        torch.cuda.synchronize()
+        ops.PROFILER = None
+        model.overlap_streams = was
+        return _kernel_rates(prof, iters)
+
+    def roofline_of(rates):
+        conv = {k: v for k, v in rates.items() if k in ("conv_igemm256", "conv_igemm_dma", "conv_igemm", "conv_wgrad") and "tflops" in v}
+        if not conv:
+            return None
+        key = max(conv, key=lambda k: conv[k]["ms_per_iter"])
+        r = conv[key]
+        return {"kernel": {"conv_igemm256": "conv_igemm256_p8_kernel", "conv_igemm_dma": "conv_igemm_lc / conv_igemm_dma kernels", "conv_wgrad": "conv_wgrad group kernels"}.get(key, key),
+                "bound": "mfma", "achieved": r["tflops"], "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(r["tflops"] / MFMA_PEAK_TFLOPS, 4),
+                "traffic": None, "launches_per_iter": r["launches_per_iter"], "avg_launch_us": r["avg_launch_us"], "ms_per_iter": r["ms_per_iter"],
+                "measured_over": "3 iterations on ONE HIP stream with a HIP-event pair around every launch", "families": rates}
+
+    common = {"unit": "images/sec", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "higher_is_better": True, "scaling": "weak",
+              "vs_baseline": None, "dtype": args.dtype, "data": "synthetic", "secondary": True, "build_hash": _lib.build_hash()}
+    lines = []
+    if args.config == "s2":
+        cfg = config.voc_rcnn_c4_split1_ft(args.depth)
+        cfg.MODEL.DEVICE, cfg.SEED = str(dev), 0
+        m = build_model(cfg)
+        init_synthetic_weights(m, seed=1)
+        m.train()
+        m.compute_mode = args.dtype
+        sup, _ = synthetic_batch(2, 0, seed=100, base_ids=list(range(20)))
+        batch = m.pack_batch(sup, None)
+        b = GradBuckets(m)
+        opt = FlatSGD(m, cfg, grad_scale=b.grad_scale)
+
+        def step():
+            st = m.forward_train(batch, early_backward=True)
+            m.backward_train(st)
+            b.finish()
+            opt.step()
+        ms = timed(step, args.steps, args.warmup)
+        rates = profiled(step, m)
+        lines.append(dict(common, metric=f"SECONDARY images/sec (fwd+bwd+SGD) R{args.depth}-C4 VOC 1-shot fine-tune step S2, 600x1000 bs=2/GPU (BASELINE.json config 4)",
+                          value=round(2e3 / ms, 2), ms_per_step=round(ms, 3),
+                          config={"workload": f"UniT fine-tune step S2 (TrainerFineTune.run_step, engine/defaults.py:442-463; configs/VOC/FT/1_shot/VOC-RCNN-101-C4-split1-ft.yaml): "
+                                              f"ResNet-{args.depth}-C4, 2 images 3x600x1000, 512 RoIs/image, both Res5 heads forward, similarity transfer in training, only "
+                                              "cls_score_ft / bbox_pred_ft train", "step_tflop_per_gpu": 3.42, "step_tflops_achieved_per_gpu": round(3.42 / ms * 1e3, 1)},
+                          roofline=roofline_of(rates), latency_kernels_us={k: rates[k]["avg_launch_us"] for k in ("sort_topk", "nms") if k in rates}))
+    elif args.config == "coco_mask":
+        cfg = config.coco_rcnn_c4_split1_segm(args.depth)
+        cfg.MODEL.DEVICE, cfg.SEED = str(dev), 0
+        m = build_model(cfg)
+        init_synthetic_weights(m, seed=1)
+        m.train()
+        m.compute_mode = args.dtype
+        sup, weak = synthetic_batch(2, 2, num_classes=80, base_ids=list(cfg.DATASETS.FEWSHOT.BASE_CLASSES_ID), seed=100)
+        yy, xx = torch.meshgrid(torch.arange(600.0), torch.arange(1000.0), indexing="ij")
+        for x in sup:          # bitmask ground truth: the ellipse inscribed in every box
+            bx = x["instances"].gt_boxes.tensor
+            x["instances"].gt_masks = torch.stack([(((xx - (q[0] + q[2]) / 2) / ((q[2] - q[0]) / 2)) ** 2 + ((yy - (q[1] + q[3]) / 2) / ((q[3] - q[1]) / 2)) ** 2) <= 1.0 for q in bx])
+        batch = m.pack_batch(sup, weak)
+        b = GradBuckets(m)
+        opt = FlatSGD(m, cfg, grad_scale=b.grad_scale)
+
+        def step():
+            st = m.forward_train(batch, early_backward=True)
+            m.backward_train(st)
+            b.finish()
+            opt.step()
+            return st.losses
+        ms = timed(step, args.steps, args.warmup)
+        assert torch.isfinite(step()).all()
+        rates = profiled(step, m)
+        bb = {50: 75.4, 101: 166.1}[args.depth], {50: 56.6, 101: 147.3}[args.depth]
+        tf = (4 * bb[0] + 4 * 45.6 + 2 * 1499 + 4 * 2 * bb[1] + 2 * 2 * 45.6 + 2 * 2 * 1499) / 1e3
+        lines.append(dict(common, metric=f"SECONDARY images/sec (fwd+bwd+SGD) R{args.depth}-C4 COCO K=80 + mask head step, 600x1000 bs=2/GPU (BASELINE.json config 5)",
+                          value=round(2e3 / ms, 2), ms_per_step=round(ms, 3),
+                          config={"workload": f"UniT base-training step with the mask head (configs/COCO/COCO-RCNN-50-C4-split1-segm.yaml at RESNETS.DEPTH {args.depth}): K = 80, "
+                                              "2 supervised + 2 weak 3x600x1000 images, ONE Res5 head over 2048 RoIs (MULTI_BOX_HEAD False) keeping its map, mask head "
+                                              "(deconv 2x2 + 1x1) on <= 128 fg RoIs / image with bitmask targets, nine losses, SGD",
+                                  "step_tflop_per_gpu": round(tf, 2), "step_tflops_achieved_per_gpu": round(tf / ms * 1e3, 1)},
+                          roofline=roofline_of(rates), latency_kernels_us={k: rates[k]["avg_launch_us"] for k in ("sort_topk", "nms") if k in rates}))
+    else:          # eval
+        for name, mk, k, ns in (("VOC K=20", lambda: config.voc_rcnn_c4_split1(args.depth), 20, (1, 4)), ("COCO K=80 + masks", lambda: config.coco_rcnn_c4_split1_segm(args.depth), 80, (1,))):
+            cfg = mk()
+            cfg.MODEL.DEVICE = str(dev)
+            m = build_model(cfg)
+            init_synthetic_weights(m, seed=1)
+            m.eval()
+            m.compute_mode = args.dtype
+            for n in ns:
+                sup, _ = synthetic_batch(n, 0, num_classes=k, seed=7)
+                inp = [{"image": x["image"].to(dev), "height": 600, "width": 1000} for x in sup]
+                call = lambda: m(inp)
+                ms = timed(call, args.steps, args.warmup)
+                rates = profiled(call, m)
+                lines.append(dict(common, metric=f"SECONDARY images/sec inference R{args.depth}-C4 {name}, {n} image(s) 600x1000 per call",
+                                  value=round(n * 1e3 / ms, 2), ms_per_step=round(ms, 3),
+                                  config={"workload": f"WeaklySupervisedRCNNNoMeta.inference (meta_arch/rcnn.py:493-542): backbone, RPN 6000 -> 1000 proposals, both Res5 heads, "
+                                                      f"similarity transfer, per-class NMS over {k} classes, top-100, detector_postprocess"
+                                                      + (", mask head + paste" if k == 80 else "") + "; one host sync for the variable-length Instances",
+                                          "images_per_call": n},
+                                  roofline=roofline_of(rates), latency_kernels_us={kk: rates[kk]["avg_launch_us"] for kk in ("sort_topk", "nms") if kk in rates}))
+            del m
+    for ln in lines:
+        emit(json.dumps(ln))
+    return 0
+
 
 
 def voc_shapes_run(args, cfg, model, buckets, opt, rank, world, dev):
@@ -371,6 +535,13 @@ def main():
     from unit_amd.solver import FlatSGD
     from unit_amd.synthetic import init_synthetic_weights, synthetic_batch
 
+    if args.config == "r50_s1":
+        args.depth = 50          # BASELINE.json config 2: the headline path itself at RESNETS.DEPTH 50 (the line says so in metric / config)
+    elif args.config is not None:
+        if world != 1:
+            print("bench.py: --config lines are single-GPU figures", file=sys.stderr)
+            return 2
+        return other_config_run(args, dev)
     cfg = config.voc_rcnn_c4_split1(args.depth)
     cfg.MODEL.DEVICE = f"cuda:{local_rank}"
     cfg.SOLVER.IMS_PER_BATCH = 2 * world
@@ -529,7 +700,8 @@ def main():
         ms = dt / args.steps * 1e3
         value = 2 * world * args.steps / dt
         out = {
-            "metric": "images/sec (fwd+bwd+SGD) R101-C4 VOC 600x1000 bs=2/GPU" if args.depth == 101 else f"images/sec R{args.depth}-C4",
+            "metric": "images/sec (fwd+bwd+SGD) R101-C4 VOC 600x1000 bs=2/GPU" if args.depth == 101 else
+                      f"SECONDARY images/sec (fwd+bwd+SGD) R{args.depth}-C4 VOC 600x1000 bs=2/GPU" + (" (BASELINE.json config 2)" if args.depth == 50 else ""),
             "value": round(value, 3), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.dtype, "data": "synthetic", "launch": ("hipGraph replay" if world == 1 else "hipGraph replay (one graph per gradient-bucket stage, the bucket all-reduces launched between the replays | optimizer graph)") if (args.graph and early is None) else "eager",
@@ -638,7 +810,8 @@ def main():
             code = ("import sys, json; sys.argv=['bench.py']; sys.path.insert(0, %r); import bench; "
                     "print('CPU_BASELINE ' + json.dumps(bench.cpu_baseline(%d, %r)))" % (ROOT, args.depth, args.variant))
             try:
-                env = dict(os.environ, OMP_NUM_THREADS="16", CUDA_VISIBLE_DEVICES="", HIP_VISIBLE_DEVICES="")
+                env = dict(os.environ, CUDA_VISIBLE_DEVICES="", HIP_VISIBLE_DEVICES="")
+                env.pop("OMP_NUM_THREADS", None)          # the child takes every core of its affinity set
                 r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=240, env=env)
                 line = [l for l in r.stdout.splitlines() if l.startswith("CPU_BASELINE ")]
                 out["cpu_baseline"] = json.loads(line[-1][len("CPU_BASELINE "):]) if line else {"error": r.stderr[-300:]}

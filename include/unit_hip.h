@@ -349,6 +349,19 @@ int unit_detection_finalize(const float* cand_boxes, const float* cand_scores, c
                             int* out_class, int* out_roi, int* out_count, void* stream);
 int unit_detector_postprocess(float* boxes, const int* count, int B, int topk, const float* scale_xy_dev, const float* out_hw_dev,
                               unsigned char* nonempty, void* stream);
+/* output assembly without stock operators (the reference: boolean-mask indexing per image and field, detectron2 detector_postprocess via
+ * meta_arch/rcnn.py:411-429; torch.cat of per-image slices in roi_heads.py:691-710):
+ *   unit_compact_detections  stable compaction of the kept detections of every image (j < count[b] [&& nonempty[b][j]]) to the front of its
+ *                            block; classes come out as int64 (pred_classes); masks [B][topk][mask_elems] optional; out_count[b] = kept
+ *   unit_boxes_to_rois5      [B][T][4] boxes -> [B*T][5] RoIAlign rows (image index, box)
+ *   unit_gather_rows         out[b*T + j] = src[b*rcap + max(idx[b][j], 0)] (rows of row_bytes bytes, % 4 == 0)
+ *   unit_gather_blocks       the first `take` rows of each of nb blocks of block_rows rows -> dense [nb*take] rows */
+int unit_compact_detections(const float* boxes, const float* scores, const int* cls, const int* roi, const float* masks, int mask_elems,
+                            const int* count, const unsigned char* nonempty, int B, int topk, float* oboxes, float* oscores, long* ocls,
+                            int* oroi, float* omasks, int* out_count, void* stream);
+int unit_boxes_to_rois5(const float* boxes, int B, int T, float* rois5, void* stream);
+int unit_gather_rows(const void* src, const int* idx, int B, int T, int rcap, int row_bytes, void* out, void* stream);
+int unit_gather_blocks(const void* src, int nb, int block_rows, int take, int row_bytes, void* out, void* stream);
 
 /* ---- a16 mask head: modeling/roi_heads/mask_head.py:16-37, roi_heads.py:654-710 (+ detectron2 mask_rcnn_loss/inference,
  * BitMasks.crop_and_resize). The 2x2/s2 ConvTranspose2d is one 1x1 GEMM with 4*Cout columns run by unit_conv2d_fwd. ---- */

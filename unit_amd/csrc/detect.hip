@@ -497,3 +497,117 @@ extern "C" int unit_detector_postprocess(float* boxes, const int* count, int B, 
   UNIT_LAUNCH_CHECK();
   return UNIT_OK;
 }
+
+// ---- output assembly without stock operators (modeling/inference.py) ---------------------------------------------------------------
+// Stable compaction of the kept detections of every image (keep = j < count[b] [&& nonempty[b][j]]): rows of boxes / scores / classes
+// (as int64, the reference's pred_classes dtype) / RoI indices / mask probabilities move to the front of their image's block, out_count[b]
+// = rows kept. One workgroup per image; topk <= 1024. The reference does this with boolean-mask indexing per image and field
+// (detectron2 detector_postprocess via meta_arch/rcnn.py:411-429): ~6 launches and a host sync per image.
+__global__ void __launch_bounds__(256) compact_detections_kernel(const float* __restrict__ boxes, const float* __restrict__ scores, const int* __restrict__ cls,
+                                                                 const int* __restrict__ roi, const float* __restrict__ masks, int mask_elems,
+                                                                 const int* __restrict__ count, const unsigned char* __restrict__ nonempty, int topk,
+                                                                 float* __restrict__ oboxes, float* __restrict__ oscores, long* __restrict__ ocls,
+                                                                 int* __restrict__ oroi, float* __restrict__ omasks, int* __restrict__ out_count) {
+  __shared__ int pos[1024];
+  __shared__ int total;
+  const int b = blockIdx.x, c = min(count[b], topk);
+  if (threadIdx.x == 0) {          // serial prefix over <= 1024 flags: a few hundred cycles, once per image
+    int n = 0;
+    for (int j = 0; j < topk; ++j) {
+      bool keep = j < c && (nonempty == nullptr || nonempty[(size_t)b * topk + j]);
+      pos[j] = keep ? n++ : -1;
+    }
+    total = n;
+    out_count[b] = n;
+  }
+  __syncthreads();
+  for (int j = threadIdx.x; j < topk; j += blockDim.x) {
+    int d = pos[j];
+    if (d < 0) continue;
+    size_t s = (size_t)b * topk + j, o = (size_t)b * topk + d;
+    *reinterpret_cast<f32x4*>(oboxes + 4 * o) = *reinterpret_cast<const f32x4*>(boxes + 4 * s);
+    oscores[o] = scores[s]; ocls[o] = (long)cls[s]; oroi[o] = roi[s];
+  }
+  if (masks != nullptr) {
+    for (int j = 0; j < topk; ++j) {
+      int d = pos[j];
+      if (d < 0) continue;
+      const float* src = masks + ((size_t)b * topk + j) * mask_elems;
+      float* dst = omasks + ((size_t)b * topk + d) * mask_elems;
+      for (int e = threadIdx.x; e < mask_elems; e += blockDim.x) dst[e] = src[e];
+    }
+  }
+}
+extern "C" int unit_compact_detections(const float* boxes, const float* scores, const int* cls, const int* roi, const float* masks, int mask_elems,
+                                       const int* count, const unsigned char* nonempty, int B, int topk, float* oboxes, float* oscores,
+                                       long* ocls, int* oroi, float* omasks, int* out_count, void* stream) {
+  UNIT_CHECK_ARG(topk >= 0 && topk <= 1024, "compact_detections: topk <= 1024");
+  UNIT_CHECK_ARG(masks == nullptr || (omasks != nullptr && omasks != masks), "compact_detections: masks need a separate output");
+  if (B == 0) return UNIT_OK;
+  compact_detections_kernel<<<B, 256, 0, (hipStream_t)stream>>>(boxes, scores, cls, roi, masks, mask_elems, count, nonempty, topk, oboxes, oscores, ocls,
+                                                                oroi, omasks, out_count);
+  UNIT_LAUNCH_CHECK();
+  return UNIT_OK;
+}
+
+// boxes [B][T][4] -> RoIAlign rows [B*T][5] = (image index, x0, y0, x1, y1)
+__global__ void boxes_to_rois5_kernel(const float* __restrict__ boxes, int T, long n, float* __restrict__ rois5) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  f32x4 v = *reinterpret_cast<const f32x4*>(boxes + 4 * i);
+  float* o = rois5 + 5 * i;
+  o[0] = (float)(i / T); o[1] = v[0]; o[2] = v[1]; o[3] = v[2]; o[4] = v[3];
+}
+extern "C" int unit_boxes_to_rois5(const float* boxes, int B, int T, float* rois5, void* stream) {
+  long n = (long)B * T;
+  if (n == 0) return UNIT_OK;
+  boxes_to_rois5_kernel<<<(unsigned)cdiv(n, 256L), 256, 0, (hipStream_t)stream>>>(boxes, T, n, rois5);
+  UNIT_LAUNCH_CHECK();
+  return UNIT_OK;
+}
+
+// out[b * T + j][:] = src[b * rcap + max(idx[b][j], 0)][:]   (rows of `row_bytes` bytes, a multiple of 4): similarity['seg'][filter_inds]
+// of roi_heads.py:768-771, and any other per-image row gather
+__global__ void gather_rows_kernel(const unsigned* __restrict__ src, const int* __restrict__ idx, int T, int rcap, int row_words, long n_rows,
+                                   unsigned* __restrict__ out) {
+  long r = blockIdx.x;
+  if (r >= n_rows) return;
+  long b = r / T;
+  int k = idx[r];
+  const unsigned* s = src + ((size_t)b * rcap + (k > 0 ? k : 0)) * row_words;
+  unsigned* d = out + (size_t)r * row_words;
+  for (int e = threadIdx.x; e < row_words; e += blockDim.x) d[e] = s[e];
+}
+extern "C" int unit_gather_rows(const void* src, const int* idx, int B, int T, int rcap, int row_bytes, void* out, void* stream) {
+  UNIT_CHECK_ARG(row_bytes % 4 == 0, "gather_rows: rows of whole 32-bit words");
+  long n = (long)B * T;
+  if (n == 0 || row_bytes == 0) return UNIT_OK;
+  UNIT_CHECK_ARG(n < 0x7FFFFFFFl, "gather_rows: too many rows");
+  gather_rows_kernel<<<(unsigned)n, 128, 0, (hipStream_t)stream>>>((const unsigned*)src, idx, T, rcap, row_bytes / 4, n, (unsigned*)out);
+  UNIT_LAUNCH_CHECK();
+  return UNIT_OK;
+}
+
+// the first `take` rows of each of `nb` blocks of `block_rows` rows -> one dense [nb * take][row] tensor (rows of `row_bytes` bytes, a multiple
+// of 4): the foreground RoI slots of every image for the mask head (roi_heads.py:691-710 select_foreground_proposals; the sampler emits
+// [fg..., bg...] per image). Replaces one torch.cat of per-image slices per field.
+__global__ void gather_blocks_kernel(const unsigned* __restrict__ src, int block_rows, int take, int row_words, unsigned* __restrict__ out) {
+  long r = blockIdx.x;                      // output row
+  long b = r / take, j = r - b * take;
+  const unsigned* s = src + ((size_t)b * block_rows + j) * row_words;
+  unsigned* d = out + (size_t)r * row_words;
+  if ((row_words & 3) == 0) {
+    for (int e = threadIdx.x; e < row_words / 4; e += blockDim.x) reinterpret_cast<u32x4*>(d)[e] = reinterpret_cast<const u32x4*>(s)[e];
+  } else {
+    for (int e = threadIdx.x; e < row_words; e += blockDim.x) d[e] = s[e];
+  }
+}
+extern "C" int unit_gather_blocks(const void* src, int nb, int block_rows, int take, int row_bytes, void* out, void* stream) {
+  UNIT_CHECK_ARG(row_bytes % 4 == 0 && take <= block_rows, "gather_blocks: rows of whole 32-bit words, take <= block_rows");
+  UNIT_CHECK_ARG((row_bytes % 16 != 0) || (((uintptr_t)src % 16 == 0) && ((uintptr_t)out % 16 == 0)), "gather_blocks: 16B alignment");
+  long n = (long)nb * take;
+  if (n == 0 || row_bytes == 0) return UNIT_OK;
+  gather_blocks_kernel<<<(unsigned)n, row_bytes >= 4096 ? 256 : 64, 0, (hipStream_t)stream>>>((const unsigned*)src, block_rows, take, row_bytes / 4, (unsigned*)out);
+  UNIT_LAUNCH_CHECK();
+  return UNIT_OK;
+}

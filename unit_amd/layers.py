@@ -473,8 +473,9 @@ class LinearGroup:
         y = ops.conv2d(x2d.view(r, 1, 1, self.cin), self.wf, self.k, 1, 1, bias=self.bias, out_dtype=torch.float32, ldy=self.kp)
         return y.view(r, self.kp)
 
-    def bwd(self, x2d, dy2d, need_dx=True, mask_ref=None):
-        """dy [R,kp] (compute dtype, pad columns zero). Writes member .grad; returns dx [R,cin] (* (mask_ref > 0))."""
+    def bwd(self, x2d, dy2d, need_dx=True, mask_ref=None, out=None):
+        """dy [R,kp] (compute dtype, pad columns zero). Writes member .grad; returns dx [R,cin] (* (mask_ref > 0)); out: contiguous rows
+        of a larger [*, cin] matrix to write dx into."""
         r = x2d.shape[0]
         gw, gb = self._fused_views("grad")
         trainable = any(m.weight.requires_grad for m in self.members)
@@ -501,5 +502,6 @@ class LinearGroup:
         if not need_dx:
             return None
         dx = ops.conv2d(dy2d.view(r, 1, 1, self.kp), self.wd, self.cin, 1, 1,
-                        mask_ref=mask_ref.view(r, 1, 1, self.cin) if mask_ref is not None else None)
+                        mask_ref=mask_ref.view(r, 1, 1, self.cin) if mask_ref is not None else None,
+                        out=out.view(r, 1, 1, self.cin) if out is not None else None)
         return dx.view(r, self.cin)

@@ -42,7 +42,7 @@ class Res5BoxHead(nn.Module):
 
     def fwd(self, pooled, save=False, keep_map=False, feat_out=None):
         """pooled [R,14,14,C] (full) or [R,7,7,C] (strided) -> (mean-pooled features [R,2048], ctx).
-        feat_out: rows of a larger [*, 2048] matrix to write the features into (fused-pooling form only; otherwise ignored).
+        feat_out: rows of a larger [*, 2048] matrix to write the features into.
         ctx = (block contexts, res5 output map [R,7,7,2048]); `keep_map` keeps the map even without `save` (mask head input:
         Res5BoxHeadWithMask hands the un-pooled map to the mask head, roi_heads.py:691-710, and its mean to the predictor,
         roi_heads.py:735-744)."""
@@ -56,7 +56,7 @@ class Res5BoxHead(nn.Module):
             (feat, bits), ctxs = self.res5.fwd(pooled, save=save, first_stride=first_stride, pool_rows=bins, out_bits=save, pooled_out=feat_out)
             return feat, ((ctxs, bits) if save else None)
         y, ctxs = self.res5.fwd(pooled, save=save, first_stride=first_stride)
-        return ops.global_avgpool(y), ((ctxs, y) if (save or keep_map) else None)
+        return ops.global_avgpool(y, out=feat_out), ((ctxs, y) if (save or keep_map) else None)
 
     def bwd(self, ctx, dfeat, row_slice=None, map_grad_hook=None):
         """dfeat: d(loss)/d(mean features) [R,2048] -> d(loss)/d(pooled). row_slice: backprop only these RoI rows.

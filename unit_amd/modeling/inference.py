@@ -93,11 +93,10 @@ def roi_heads_inference(rh, feat, props, pcount, hw, dt, with_mask=True, want_si
     mh = getattr(rh, "mask_head", None)
     sim_seg = None
     if mh is not None and "seg" in rh.terms and (with_mask or want_similarity):
-        flat_idx = (torch.arange(n, device=dev)[:, None] * rcap + roi.clamp(min=0).long()).view(-1)
-        sim_seg = sims["seg"][flat_idx].contiguous()          # similarity['seg'][filter_inds] (roi_heads.py:768-771)
+        sim_seg = ops.gather_rows(sims["seg"], roi, rcap)          # similarity['seg'][filter_inds] (roi_heads.py:768-771)
     if mh is not None and with_mask:
         topk = boxes.shape[1]
-        det_rois = torch.cat([torch.arange(n, device=dev, dtype=torch.float32).repeat_interleave(topk)[:, None], boxes.view(-1, 4)], 1)
+        det_rois = ops.boxes_to_rois5(boxes)
         mask_probs = mask_probs_on_boxes(rh, feat, det_rois, cls.view(-1).contiguous(), sim_seg).view(n, topk, mh.mask_size, mh.mask_size)
     if want_similarity:
         return boxes, sc, cls, roi, cnt, mask_probs, sim_seg
@@ -123,14 +122,14 @@ def inference(model, batched_inputs, do_postprocess=True):
     n, fh, fw, _ = feat.shape
     anchors = rpn.anchor_generator.grid(fh, fw)
     head, _ = rpn.rpn_head.fwd(feat)
-    hw = torch.tensor(sizes, dtype=torch.float32).to(dev)
+    hw = model._sizes_on_device(sizes)          # (uploaded once per distinct value)
     if rpn is not None and "proposals" not in batched_inputs[0]:
         props, pscores, pcount = rpn.predict_proposals(head, anchors, hw, False)
     else:       # precomputed proposals (rcnn.py:533-536)
         props, pcount = pack_proposal_instances([x["proposals"] for x in batched_inputs], dev)
     boxes, sc, cls, roi, cnt, mask_probs = roi_heads_inference(rh, feat, props, pcount, hw, dt)
     out_hw = [(x.get("height", s[0]), x.get("width", s[1])) for x, s in zip(batched_inputs, sizes)]
-    return build_instances(boxes, sc, cls, roi, cnt, mask_probs, sizes, out_hw if do_postprocess else None)
+    return build_instances(boxes, sc, cls, roi, cnt, mask_probs, sizes, out_hw if do_postprocess else None, consts=model._const_on_device)
 
 
 def pack_proposal_instances(proposals, dev):
@@ -143,28 +142,34 @@ def pack_proposal_instances(proposals, dev):
     return props, torch.tensor([len(b) for b in bs], dtype=torch.int32).to(dev)
 
 
-def build_instances(boxes, sc, cls, roi, cnt, mask_probs, sizes, out_hw=None):
+def build_instances(boxes, sc, cls, roi, cnt, mask_probs, sizes, out_hw=None, consts=None):
     """device detections -> the reference's output format: list of {"instances": Instances} after `_postprocess` (rcnn.py:411-429)
     when out_hw is given, else list of Instances in network-input coordinates (what ROI heads return)."""
     dev = boxes.device
     do_postprocess = out_hw is not None
     if do_postprocess:
-        scale = torch.tensor([[o[1] / s[1], o[0] / s[0]] for o, s in zip(out_hw, sizes)], dtype=torch.float32).to(dev)
-        ohw = torch.tensor(out_hw, dtype=torch.float32).to(dev)
+        mk_scale = lambda: torch.tensor([[o[1] / s[1], o[0] / s[0]] for o, s in zip(out_hw, sizes)], dtype=torch.float32)
+        mk_ohw = lambda: torch.tensor(out_hw, dtype=torch.float32)
+        if consts is not None:          # GeneralizedRCNN._const_on_device: one upload per distinct value, none in the steady state
+            scale, ohw = consts(("pp_scale", tuple(out_hw), tuple(sizes)), mk_scale), consts(("pp_ohw", tuple(out_hw)), mk_ohw)
+        else:
+            scale, ohw = mk_scale().to(dev), mk_ohw().to(dev)
         nonempty = ops.detector_postprocess(boxes, cnt, scale, ohw)
+    # kept rows of every image to the front of its block in ONE launch (the reference indexes every field with a boolean mask per image);
+    # after that the per-image fields are views
+    boxes, sc, cls64, roi, mask_probs, kept = ops.compact_detections(boxes, sc, cls, roi, cnt, nonempty if do_postprocess else None, mask_probs)
     results = []
-    counts = cnt.tolist()          # API boundary: python lists of Instances need the counts on the host
+    counts = kept.tolist()          # API boundary: python lists of Instances need the counts on the host (the call's one sync)
     for i, c in enumerate(counts):
         size = out_hw[i] if do_postprocess else sizes[i]
-        keep = nonempty[i, :c].bool() if do_postprocess else slice(None)
-        inst = Instances(size, pred_boxes=Boxes(boxes[i, :c][keep]), scores=sc[i, :c][keep], pred_classes=cls[i, :c][keep].long())
-        inst._roi_index = roi[i, :c][keep]
+        inst = Instances(size, pred_boxes=Boxes(boxes[i, :c]), scores=sc[i, :c], pred_classes=cls64[i, :c])
+        inst._roi_index = roi[i, :c]
         if mask_probs is not None:
-            mp = mask_probs[i, :c][keep]
+            mp = mask_probs[i, :c]
             if do_postprocess:
                 # detector_postprocess (rcnn.py:423): paste the 14x14 masks into the output image, threshold 0.5 -> bool [R,H,W]
                 inst.pred_mask_probs = mp[:, None]
-                inst.pred_masks = ops.paste_masks(mp, inst.pred_boxes.tensor, size, 0.5).bool()
+                inst.pred_masks = ops.paste_masks(mp, inst.pred_boxes.tensor, size, 0.5).view(torch.bool)          # (0 / 1 bytes: a view)
             else:
                 inst.pred_masks = mp[:, None]                       # (R,1,14,14) like mask_rcnn_inference
         results.append({"instances": inst} if do_postprocess else inst)

@@ -38,7 +38,10 @@ class ConvTranspose2x2(_EpochOnLoad):
         w = self.weight.data if self.weight.data.is_contiguous() else self.weight.data.contiguous()
         check(lib().unit_deconv2x2_weight_prep(ops._p(w), self.cin, self.cout, ops._p(self.wf), ops._p(self.wd), ops.dt(dtype), ops._s()),
               "deconv2x2_weight_prep")
-        self.bias4 = self.bias.data.repeat(4)            # tiny (256 -> 1024) tiling of the bias over the four taps
+        # the bias tiled over the four taps (256 -> 1024), by the library's row gather (four copies of row 0)
+        if self.__dict__.get("_tap_rows") is None or self._tap_rows.device != dev:
+            self.__dict__["_tap_rows"] = ops.zeros((1, 4), torch.int32, dev)
+        self.bias4 = ops.gather_rows(self.bias.data.view(1, -1), self._tap_rows, 1).view(-1)
         self._key = key
 
     def fwd(self, x):

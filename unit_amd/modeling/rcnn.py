@@ -587,10 +587,11 @@ class WeaklySupervisedRCNNNoMeta(nn.Module):
             sidx, midx = rh._last_sampling
             gidx = gather_match_index(sidx, midx)
             sel = [slice(i * s, i * s + fgc) for i in range(n_sup)]
-            x_fg = torch.cat([ymap[sl] for sl in sel], 0)
-            cls_fg = torch.cat([c.roi_cls[sl] for sl in sel], 0)
-            rois_fg = torch.cat([c.rois[sl] for sl in sel], 0)
-            tgt = mask_targets(batch.gt_masks, rois_fg, torch.cat([gidx[sl] for sl in sel], 0), cls_fg, rh.num_classes, mh.mask_size)
+            # the first fgc slots of every image's block as dense tensors: one launch per field (four torch.cat of per-image slices before)
+            x_fg = ops.gather_blocks(ymap, n_sup, s, fgc)
+            cls_fg = ops.gather_blocks(c.roi_cls, n_sup, s, fgc)
+            rois_fg = ops.gather_blocks(c.rois, n_sup, s, fgc)
+            tgt = mask_targets(batch.gt_masks, rois_fg, ops.gather_blocks(gidx, n_sup, s, fgc), cls_fg, rh.num_classes, mh.mask_size)
             kw = {}
             if sim is not None:      # similarity['seg'][fg] (roi_heads.py:893-897): fg slot -> its RoI row
                 rows = self._const_on_device(("fg_rows", n_sup, s, fgc), lambda: torch.cat([torch.arange(sl.start, sl.stop, dtype=torch.int32) for sl in sel]))
@@ -702,7 +703,7 @@ class WeaklySupervisedRCNNNoMeta(nn.Module):
         if c.dy_weak is None or c.dy_sup is None:
             self._clear_unproduced(c)
 
-        dbox = dweak = None
+        dbox = dweak = dall_buf = None
         early_sup = False
         if c.dy_sup is not None and getattr(bp, "finetune", False):
             # VOC fine-tune yaml: everything below the ft heads is frozen -> their weight gradients are all there is.
@@ -736,9 +737,13 @@ class WeaklySupervisedRCNNNoMeta(nn.Module):
                     sup_pred_done = torch.cuda.Event()
                     sup_pred_done.record()
             else:
-                dbox = bp.group.bwd(c.box_feat, c.dy_sup, need_dx=box_trainable or bb_trainable)
+                if not multi and c.dy_weak is not None and box_trainable:
+                    # one Res5 head serves both RoI groups (MULTI_BOX_HEAD False): the two predictors' input gradients are the rows of ONE
+                    # matrix, written in place (a torch.cat before)
+                    dall_buf = torch.empty((rs + rw, c.box_feat.shape[1]), dtype=c.dy_sup.dtype, device=self.device)
+                dbox = bp.group.bwd(c.box_feat, c.dy_sup, need_dx=box_trainable or bb_trainable, out=dall_buf[:rs] if dall_buf is not None else None)
         if c.dy_weak is not None:
-            dweak = bp.weak_detector_head.group.bwd(c.weak_feat, c.dy_weak, need_dx=True)
+            dweak = bp.weak_detector_head.group.bwd(c.weak_feat, c.dy_weak, need_dx=True, out=dall_buf[rs:] if dall_buf is not None else None)
         if early_sup:
             torch.cuda.current_stream().wait_event(sup_pred_done)      # the bucket's gradients are complete on this stream's timeline
         done("heads")
@@ -780,7 +785,7 @@ class WeaklySupervisedRCNNNoMeta(nn.Module):
         else:
             parts = [t for t in (dbox, dweak) if t is not None]
             if parts and box_trainable:
-                dall = torch.cat(parts, 0) if len(parts) > 1 else parts[0]
+                dall = dall_buf if (dall_buf is not None and len(parts) == 2) else (torch.cat(parts, 0) if len(parts) > 1 else parts[0])
                 dpool = rh.box_head.bwd(c.box_ctx, dall, map_grad_hook=mask_hook)
                 done("box_head")
                 dpool_sup, dpool_weak = (dpool[:rs] if rs > 0 else None), (dpool[rs:] if rw > 0 else None)

@@ -895,14 +895,16 @@ def maxpool3x3s2(x):
     return y
 
 
-def global_avgpool(x):
-    """[R,PH,PW,C] -> [R,C] (an X3 map: fp32 features, unit_global_avgpool_x3_fwd)"""
+def global_avgpool(x, out=None):
+    """[R,PH,PW,C] -> [R,C] (an X3 map: fp32 features, unit_global_avgpool_x3_fwd); out: contiguous rows of a larger feature matrix"""
     r, ph, pw, c = x.shape
+    if out is not None:
+        assert out.shape == (r, c) and out.is_contiguous() and out.dtype == (torch.float32 if type(x) is X3 else x.dtype)
     if type(x) is X3:
-        y = torch.empty((r, c), dtype=torch.float32, device=x.device)
+        y = out if out is not None else torch.empty((r, c), dtype=torch.float32, device=x.device)
         check(lib().unit_global_avgpool_x3_fwd(_px(x), _p(y), r, ph * pw, c, _s()), "avgpool_x3_fwd")
         return y
-    y = torch.empty((r, c), dtype=x.dtype, device=x.device)
+    y = out if out is not None else torch.empty((r, c), dtype=x.dtype, device=x.device)
     check(lib().unit_global_avgpool_fwd(_p(x), _p(y), dt(x.dtype), r, ph * pw, c, _s()), "avgpool_fwd")
     return y
 
@@ -1312,7 +1314,7 @@ def detections(probs, deltas, props, pcount, image_hw, weights, score_thresh, nm
     dev = probs.device
     cap = cand_cap or min(rcap * k, 65536)
     cb = torch.empty((b, cap, 4), dtype=torch.float32, device=dev)
-    cs = torch.zeros((b, cap), dtype=torch.float32, device=dev)
+    cs = zeros((b, cap), torch.float32, dev)
     cc = torch.empty((b, cap), dtype=torch.int32, device=dev)
     cr = torch.empty((b, cap), dtype=torch.int32, device=dev)
     cnt = torch.empty((b,), dtype=torch.int32, device=dev)
@@ -1342,6 +1344,53 @@ def detector_postprocess(boxes, count, scale_xy, out_hw):
     nonempty = torch.empty((b, topk), dtype=torch.uint8, device=boxes.device)
     check(lib().unit_detector_postprocess(_p(boxes), _p(count), b, topk, _p(scale_xy), _p(out_hw), _p(nonempty), _s()), "detector_postprocess")
     return nonempty
+
+
+def compact_detections(boxes, sc, cls, roi, cnt, nonempty=None, masks=None):
+    """stable compaction of each image's kept detections (j < cnt[b] and nonempty[b][j]) to the front of its block (unit_compact_detections)
+    -> (boxes, scores, classes int64, roi index, masks | None, kept count int32 [B])"""
+    b, topk = boxes.shape[0], boxes.shape[1]
+    dev = boxes.device
+    ob, osc = torch.empty_like(boxes), torch.empty_like(sc)
+    ocls = torch.empty((b, topk), dtype=torch.int64, device=dev)
+    oroi = torch.empty_like(roi)
+    om = torch.empty_like(masks) if masks is not None else None
+    kept = torch.empty((b,), dtype=torch.int32, device=dev)
+    me = masks[0, 0].numel() if masks is not None else 0
+    check(lib().unit_compact_detections(_p(boxes), _p(sc), _p(cls), _p(roi), _p(masks), me, _p(cnt), _p(nonempty), b, topk, _p(ob), _p(osc), _p(ocls),
+                                        _p(oroi), _p(om), _p(kept), _s()), "compact_detections")
+    return ob, osc, ocls, oroi, om, kept
+
+
+def boxes_to_rois5(boxes):
+    """[B,T,4] -> [B*T,5] RoIAlign rows (image index, box)"""
+    b, t = boxes.shape[0], boxes.shape[1]
+    out = torch.empty((b * t, 5), dtype=torch.float32, device=boxes.device)
+    check(lib().unit_boxes_to_rois5(_p(boxes), b, t, _p(out), _s()), "boxes_to_rois5")
+    return out
+
+
+def gather_rows(src, idx, rcap):
+    """src [B*rcap, ...] rows, idx int32 [B,T] (negative = row 0) -> [B*T, ...] = src[b*rcap + idx[b][j]]"""
+    b, t = idx.shape
+    row = src[0].numel() * src.element_size()
+    out = torch.empty((b * t,) + tuple(src.shape[1:]), dtype=src.dtype, device=src.device)
+    check(lib().unit_gather_rows(_p(src), _p(idx), b, t, rcap, row, _p(out), _s()), "gather_rows")
+    return out
+
+
+def gather_blocks(src, nb, block_rows, take):
+    """src [nb*block_rows, ...] (or more rows) -> dense [nb*take, ...]: the first `take` rows of every block (one launch instead of a
+    torch.cat of nb slices)"""
+    assert src.is_contiguous() and src.shape[0] >= nb * block_rows
+    x3 = type(src) is X3
+    row = src[0].numel() * src.element_size()
+    out = torch.empty((nb * take,) + tuple(src.shape[1:]), dtype=src.dtype, device=src.device)
+    if x3:
+        out = out.as_subclass(X3)
+    ptr = (lambda t: ctypes.c_void_p(t.data_ptr())) if x3 else _p
+    check(lib().unit_gather_blocks(ptr(src), nb, block_rows, take, row, ptr(out), _s()), "gather_blocks")
+    return out
 
 
 def paste_masks(probs, boxes, out_hw, threshold=0.5, valid=None):
