@@ -59,6 +59,10 @@ def parse():
     ap.add_argument("--bf16-buckets", action="store_true", help="exchange bf16 copies of the gradient buckets (half the bytes)")
     ap.add_argument("--force-collectives", action="store_true", help="N=1 only: initialise RCCL with one rank and keep every collective of the "
                     "data-parallel step in the timed region (what an N>1 run adds on the device side, minus the wire)")
+    ap.add_argument("--no-tune", action="store_true", help="N > 1: skip the ~30 s exchange probe (reduce mode x bucket size x collective stream) "
+                    "and run the timed region on the flags / environment as given")
+    ap.add_argument("--collective-stream", default=None, choices=["rpn", "own", "internal"], help="where a bucket's collectives are enqueued "
+                    "(parallel.GradBuckets; default rpn / UNIT_COLLECTIVE_STREAM)")
     ap.add_argument("--shapes", default="fixed", choices=["fixed", "voc"], help="fixed: the headline 600x1000 workload; voc: a SECONDARY labelled line "
                     "over steps whose image sizes are drawn like ResizeShortestEdge((480..800), 1333) on VOC aspect ratios "
                     "(configs/VOC/VOC-RCNN-101-C4-split1.yaml:27-29)")
@@ -81,6 +85,41 @@ def _free_port():
     return p
 
 
+def visible_gpu_count():
+    """GPUs this process may use, counted WITHOUT touching the HIP runtime (the launcher parent must stay GPU-free: a process that has
+    initialised the GPU may not start others on this pool): KFD topology nodes with SIMDs, else /dev/dri render nodes, capped by the
+    *_VISIBLE_DEVICES lists. None when neither source is readable (the ranks then find out themselves)."""
+    import glob
+    import re
+    n = None
+    try:
+        base = "/sys/class/kfd/kfd/topology/nodes"
+        cnt = 0
+        for d in os.listdir(base):
+            m = re.search(r"simd_count\s+(\d+)", open(os.path.join(base, d, "properties")).read())
+            cnt += 1 if (m and int(m.group(1)) > 0) else 0
+        n = cnt
+    except OSError:
+        r = glob.glob("/dev/dri/renderD*")
+        n = len(r) if r else None
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:          # (a visibility list caps the count even where sysfs is not readable)
+            k = len([x for x in v.split(",") if x.strip() != ""])
+            n = k if n is None else min(n, k)
+    return n
+
+
+def pick_exchange(table):
+    """table: [{"mode", "bucket_mb", "stream", "ms" (max over ranks) | None, "error" | None}] -> the entry the timed region runs on: the
+    fastest measured one (ties: fewer bytes in flight per collective first, then the table's order); None when nothing ran"""
+    ok = [(e["ms"], i) for i, e in enumerate(table) if e.get("ms") is not None and not e.get("error")]
+    if not ok:
+        return None
+    best = min(ok)
+    return table[best[1]]
+
+
 def launch_ranks(args):
     """`python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment: this process -- which has made NO GPU call and makes
     none -- starts N fresh copies of itself, one rank per GPU (the reference: scripts/train_VOC.py:67-77 -> detectron2 launch ->
@@ -91,8 +130,8 @@ def launch_ranks(args):
     n = args.gpus
     backend = os.environ.get("UNIT_DIST_BACKEND", "nccl")
     if not args.dry_launch and backend == "nccl":
-        ndev = torch.cuda.device_count()          # counts devices without initialising the GPU runtime in this process
-        if ndev < n:
+        ndev = visible_gpu_count()          # sysfs only: this process never initialises the GPU runtime
+        if ndev is not None and ndev < n:
             print(f"bench.py: --gpus {n} needs {n} visible GPUs (one rank per GPU over RCCL), this box shows {ndev}. Nothing was run. "
                   f"(A single-GPU rehearsal of the multi-process path exists: UNIT_DIST_BACKEND=gloo python bench.py --gpus {n}.)", file=sys.stderr)
             return 2
@@ -437,7 +476,7 @@ def voc_shapes_run(args, cfg, model, buckets, opt, rank, world, dev):
                "ms_per_step": round(dt / steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype,
                "data": "synthetic", "launch": "hipGraph replay per batch key" if gs else "eager", "host_enqueue_ms_per_step": round(host_ms, 3),
                "host_enqueue_ms_from_idle_device": round(host_idle_ms, 3),
-               "dist": buckets.describe(), "build_hash": _lib.build_hash(),
+               "dist": dict(buckets.describe(), tuning=tuning, exposed_ms_per_bucket_tag=per_bucket), "build_hash": _lib.build_hash(),
                "config": {"workload": f"UniT base-training step S1, ResNet-{args.depth}-C4, 2 supervised + 2 weak images per GPU whose sizes change every "
                                       "step: VOC raw sizes through ResizeShortestEdge((480, ..., 800), max 1333) with one orientation per batch "
                                       "(configs/VOC/VOC-RCNN-101-C4-split1.yaml:27-29, data/build.py:476-497), 512 RoIs/image, 12000->2000",
@@ -554,8 +593,12 @@ def main():
     n_weak = 2 if args.variant == "s1" else 0
     sup, weak = synthetic_batch(2, n_weak, seed=100 + rank)   # rank r's shard of the global batch
     batch = model.pack_batch(sup, weak)                      # inputs resident in HBM before the timed region
-    buckets = GradBuckets(model, bucket_bytes=None if args.bucket_mb is None else int(args.bucket_mb * (1 << 20)), bf16=args.bf16_buckets,
-                          mode=args.reduce_mode, force=True if args.force_collectives else None)
+    def make_buckets(mode=None, bucket_mb=None, stream=None):
+        mb = bucket_mb if bucket_mb is not None else args.bucket_mb
+        return GradBuckets(model, bucket_bytes=None if mb is None else int(mb * (1 << 20)), bf16=args.bf16_buckets, mode=mode or args.reduce_mode,
+                           force=True if args.force_collectives else None, collective_stream=stream or args.collective_stream)
+
+    buckets = make_buckets()
     buckets.broadcast_parameters()
     _trace("model built, parameters broadcast")
     opt = FlatSGD(model, cfg, grad_scale=buckets.grad_scale)
@@ -571,6 +614,50 @@ def main():
             early.join()
         opt.step()
         return step.losses
+
+    # N > 1: the driver's scaling run is ONE run per N -- it tunes itself. ~30 s of 8-step probes over how a gradient bucket crosses xGMI
+    # (reduce mode x bucket size x the stream the collectives are enqueued on), every rank timing the same configuration between barriers,
+    # the slowest rank's time agreed by one all-reduce; the timed region then runs on the fastest, and the whole table is printed in `dist`.
+    tuning = None
+    if world > 1 and not (args.no_tune or args.graph or args.early_update or args.shapes != "fixed"):
+        modes = [args.reduce_mode] if args.reduce_mode else ["allreduce", "rs_ag", "direct"]
+        sizes_mb = [args.bucket_mb] if args.bucket_mb is not None else [25.0, 64.0]
+        streams = [args.collective_stream] if args.collective_stream else ["rpn", "own"]
+        table = []
+        for _ in range(3):
+            one_step()          # first steps: allocations, weight copies
+        for md in modes:
+            for mb in sizes_mb:
+                for cs in streams:
+                    entry = {"mode": md, "bucket_mb": mb, "stream": cs, "ms": None, "error": None}
+                    try:
+                        buckets = make_buckets(md, mb, cs)
+                        for _ in range(2):
+                            one_step()
+                        dist.barrier()
+                        torch.cuda.synchronize()
+                        tp = time.perf_counter()
+                        for _ in range(8):
+                            one_step()
+                        torch.cuda.synchronize()
+                        ms_p = (time.perf_counter() - tp) / 8 * 1e3
+                    except Exception as e:          # noqa: a backend without this collective (gloo rehearsal): every rank raises alike, before any transfer
+                        ms_p, entry["error"] = float("inf"), f"{type(e).__name__}: {str(e)[:120]}"
+                    tt = torch.tensor([ms_p if ms_p != float("inf") else 1e30], device=dev, dtype=torch.float64)
+                    dist.all_reduce(tt, op=dist.ReduceOp.MAX)          # the slowest rank's time; 1e30 = some rank could not run it
+                    if float(tt) < 1e29:
+                        entry["ms"], entry["error"] = round(float(tt), 3), None
+                    elif entry["error"] is None:
+                        entry["error"] = "failed on another rank"
+                    table.append(entry)
+        chosen = pick_exchange(table)
+        if chosen is None:
+            print("bench.py: no exchange configuration ran on every rank", file=sys.stderr)
+            return 4
+        buckets = make_buckets(chosen["mode"], chosen["bucket_mb"], chosen["stream"])
+        tuning = {"probe": "8 steps per configuration after 2 warm-up steps, max over ranks", "table": table,
+                  "chosen": {k: chosen[k] for k in ("mode", "bucket_mb", "stream", "ms")}}
+        _trace(f"exchange tuned: {tuning['chosen']}")
 
     if args.shapes == "voc":
         rc = voc_shapes_run(args, cfg, model, buckets, opt, rank, world, dev)
@@ -590,6 +677,7 @@ def main():
     for _ in range(max(args.warmup, 3 if args.graph else 0)):
         timed_step()
     buckets.exposed_events = [] if buckets.active else None          # two event records per step around the bucket waits
+    buckets.exposed_per_bucket = [] if (buckets.active and world > 1) else None
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -605,7 +693,18 @@ def main():
     exposed_ms = 0.0
     if buckets.exposed_events:
         exposed_ms = sum(a.elapsed_time(b) for a, b in buckets.exposed_events) / args.steps
-    buckets.exposed_events = None
+    per_bucket = None
+    if buckets.exposed_per_bucket:
+        acc = {}
+        for tags, e0, marks in buckets.exposed_per_bucket:
+            prev = e0
+            for tg, mk in zip(tags, marks):
+                a = acc.setdefault(tg, [0.0, 0])
+                a[0] += prev.elapsed_time(mk)
+                a[1] += 1
+                prev = mk
+        per_bucket = {tg: round(v[0] / args.steps, 4) for tg, v in acc.items()}          # ms per step the compute stream waited for this tag's buckets (rank 0)
+    buckets.exposed_events = buckets.exposed_per_bucket = None
     # roofline passes (outside the `value` timing: ~650 extra HIP-event records per step perturb it by a few per cent):
     # the same K steps again with a HIP-event pair around every conv launch, recorded on the launch stream --
     #  (1) on ONE stream (overlap off): an event interval is then that kernel alone -> `achieved`
@@ -705,7 +804,7 @@ def main():
             "value": round(value, 3), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.dtype, "data": "synthetic", "launch": ("hipGraph replay" if world == 1 else "hipGraph replay (one graph per gradient-bucket stage, the bucket all-reduces launched between the replays | optimizer graph)") if (args.graph and early is None) else "eager",
-            "dist": buckets.describe(), "build_hash": _lib.build_hash(),
+            "dist": dict(buckets.describe(), tuning=tuning, exposed_ms_per_bucket_tag=per_bucket), "build_hash": _lib.build_hash(),
             "host_enqueue_ms_per_step": round(host_ms, 3),      # max over ranks
             "allreduce_exposed_ms": round(exposed_ms, 3),       # max over ranks: compute-stream time inside GradBuckets.finish() per step
             "config": {"workload": f"UniT base-training step {args.variant.upper()} (TrainerNoMeta.run_step): ResNet-{args.depth}-C4, "

@@ -59,3 +59,35 @@ def test_under_torch_distributed_run_the_ranks_run_main_directly():
     assert r.returncode == 0, r.stderr[-2000:]
     envs = [json.loads(l[len("DRY_LAUNCH "):]) for l in r.stdout.splitlines() if l.startswith("DRY_LAUNCH ")]
     assert sorted(int(x["RANK"]) for x in envs) == [0, 1] and {x["MASTER_PORT"] for x in envs} == {"29517"}
+
+
+def test_exchange_selection_and_gpu_count_without_hip():
+    """the N > 1 self-tuning run (bench.py: 8-step probes of reduce mode x bucket size x collective stream): the selection rule, and the
+    launcher's device count, which must not initialise the HIP runtime in the parent (sysfs / the *_VISIBLE_DEVICES lists only)"""
+    sys.path.insert(0, ROOT)
+    import bench
+    table = [{"mode": "allreduce", "bucket_mb": 64.0, "stream": "rpn", "ms": 21.5, "error": None},
+             {"mode": "rs_ag", "bucket_mb": 25.0, "stream": "own", "ms": None, "error": "RuntimeError: no reduce_scatter in this backend"},
+             {"mode": "direct", "bucket_mb": 25.0, "stream": "own", "ms": 19.25, "error": None},
+             {"mode": "direct", "bucket_mb": 64.0, "stream": "rpn", "ms": 19.25, "error": None},
+             {"mode": "allreduce", "bucket_mb": 25.0, "stream": "own", "ms": 30.0, "error": None}]
+    best = bench.pick_exchange(table)
+    assert (best["mode"], best["bucket_mb"], best["stream"]) == ("direct", 25.0, "own")          # fastest; a tie goes to the table's order
+    assert bench.pick_exchange([table[1]]) is None and bench.pick_exchange([]) is None
+    src = open(BENCH).read()
+    body = src[src.index("def launch_ranks"):src.index("def cpu_baseline")]
+    assert "torch.cuda" not in body          # the parent makes no torch.cuda call at all
+    old = {k: os.environ.get(k) for k in ("HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES")}
+    try:
+        os.environ["HIP_VISIBLE_DEVICES"] = ""
+        n = bench.visible_gpu_count()
+        assert n is None or n == 0
+        os.environ["HIP_VISIBLE_DEVICES"] = "0,1,2"
+        n = bench.visible_gpu_count()
+        assert n is None or 0 <= n <= 3
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v

@@ -58,20 +58,20 @@ class _Chain:
 
 class _EventWork:
     """work handle of collectives that were enqueued ON a stream of ours (`GradBuckets._collective_stream`): waiting = the current stream
-    waits for the event recorded behind them; waiting twice is harmless"""
+    waits for the event recorded behind them. The event is KEPT (a stream-side wait is idempotent and costs one packet): a bucket may be
+    waited for on two streams -- engine.EarlyUpdate's update stream through wait_tag(), then the compute stream in finish() -- and each of
+    them must be ordered behind the collective; `_finish` drops the handles."""
 
     def __init__(self, event):
         self.event = event
 
     def wait(self):
-        if self.event is not None:
-            import torch
-            torch.cuda.current_stream().wait_event(self.event)
-            self.event = None
+        import torch
+        torch.cuda.current_stream().wait_event(self.event)
 
 
 class GradBuckets:
-    def __init__(self, model, group=None, bucket_bytes=None, bf16=False, mode=None, force=None):
+    def __init__(self, model, group=None, bucket_bytes=None, bf16=False, mode=None, force=None, collective_stream=None):
         """bf16: exchange a bf16 copy of every bucket (half the bytes over xGMI: 134 instead of 268 MB per step for R101 S1) and
         widen the sum back into the fp32 gradient buffer; the ranks stay bit-identical (same reduced values everywhere), each
         summed gradient carries a relative 2^-8 rounding. Off by default: one node's links move the fp32 buckets behind the backward.
@@ -92,6 +92,7 @@ class GradBuckets:
         self.bucket_bytes = int(bucket_bytes)
         self.bucket_elems = max(self.world, self.bucket_bytes // 4 // self.world * self.world)     # a multiple of the world size: whole shards
         self._works = []
+        self._work_tags = []
         self._tag_works = {}
         self._plan = None
         self._recv = {}                 # "direct": receive buffers of the all-to-all, keyed by (elements, dtype)
@@ -104,11 +105,12 @@ class GradBuckets:
         # main stream's queue it would stall the dgrad chain. So the collectives of a bucket are enqueued synchronously on a stream WE place:
         # "rpn" (default) = the model's RPN-branch stream, idle during the backward and on a hardware queue of its own by measurement
         # (ops.streams_on_distinct_queues); "own" = a fresh stream; "internal" = torch's (the behaviour until round 4).
-        self.collective_stream = os.environ.get("UNIT_COLLECTIVE_STREAM", "rpn")
+        self.collective_stream = collective_stream or os.environ.get("UNIT_COLLECTIVE_STREAM", "rpn")
         if self.collective_stream not in ("rpn", "own", "internal"):
             raise ValueError("UNIT_COLLECTIVE_STREAM: rpn | own | internal")
         self.launched = 0               # collectives launched so far (tests / bench line)
         self.exposed_events = None      # bench.py: a list -> finish() brackets its waits with a HIP-event pair on the compute stream
+        self.exposed_per_bucket = None  # bench.py: a list -> finish() also records one event behind EVERY bucket's wait: (tags, [events])
         model.on_grad_ready = self.ready if self.active else None
 
     # ------------------------------------------------------------------------------------------------ description (bench line)
@@ -295,6 +297,7 @@ class GradBuckets:
         for a, b in self._plan.get(tag, []):
             w = self._launch(g, a, b)
             self._works.append(w)
+            self._work_tags.append(tag)
             self._tag_works.setdefault(tag, []).append(w)
 
     def reduce_all(self):
@@ -326,12 +329,21 @@ class GradBuckets:
             import torch
             ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
             ev[0].record()
+        marks = [] if (self.exposed_per_bucket is not None and ev is not None) else None
         for w in self._works:
             w.wait()
+            if marks is not None:          # the compute stream's time between two marks = what THIS bucket's exchange left exposed
+                import torch
+                m = torch.cuda.Event(enable_timing=True)
+                m.record()
+                marks.append(m)
         if ev is not None:
             ev[1].record()
             self.exposed_events.append(ev)
+            if marks is not None:
+                self.exposed_per_bucket.append((list(self._work_tags), ev[0], marks))
         self._works = []
+        self._work_tags = []
         self._tag_works = {}
 
     @property
