@@ -138,6 +138,21 @@ int unit_conv2d_wgrad_x3(const void* x, const void* dy, float* dw, const float* 
                          void* stream);
 int unit_global_avgpool_x3_fwd(const void* y, float* out, int R, int rows, int C, void* stream);
 int unit_global_avgpool_x3_bwd_relu(const float* dfeat, const void* y, void* g, int R, int rows, int C, void* stream);
+/* Pair launches: ONE grid over two independent problems of the SAME layer (same weights, channels, taps, stride, epilogue) that differ in their
+ * tensors and map sizes -- the supervised and the weak batch of a training step, each zero-padded to its OWN largest image
+ * (/root/reference/modeling/meta_arch/rcnn.py:438-452 runs the backbone once per batch; data/build.py:476-486 groups each loader's images by
+ * aspect ratio, so the two padded sizes almost never agree). Pointwise stride-1 layers need nothing (concatenate the rows); every other layer
+ * takes the second problem here instead of a second, half-empty launch. kernel: 0 = unit_conv2d_fwd (tile = tile_cfg), 1 = unit_conv2d_fwd_mid
+ * (tile 0 / 1 / 2 / 4 / 5 or a loader-consumer code 142 .. 182, 144 .. 164), 2 = unit_conv2d_fwd_big (tile = variant 0 / 8 / 12: row-major 256-row
+ * tiles), 3 = unit_conv2d_fwd_x3 (mask_c as there). The second problem's OH / OW follow from its H / W; OHf / OWf = its scatter target's map
+ * size (= OH / OW without scatter). Each problem's result is what the single launch writes, bit for bit. */
+typedef struct UnitConvSecond {
+  const void* x; void* y; const void* residual; const void* mask_ref;
+  int N, H, W, OHf, OWf;
+} UnitConvSecond;
+int unit_conv2d_fwd_pair(int kernel, const void* x, const void* w, void* y, const float* bias, const void* residual, const void* mask_ref, int mask_c,
+                         int in_dtype, int out_dtype, int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int OH, int OW, int ldy,
+                         int oy_mul, int OHf, int OWf, int relu, int tile, const UnitConvSecond* second, void* stream);
 size_t unit_conv2d_wgrad_workspace_bytes(int in_dtype, int N, int OH, int OW, int K, int R, int S, int C);
 /* variant: 0 = production policy. Big-M bf16 layers (C % 256 == 0, K % 256 == 0, M >= 16384) use a 256x256 tile: policy = the
  * phase-interleaved schedule (csrc/conv_wgrad256p8.hip) for pointwise layers and maps of <= 1024 pixels -- on 3x3 s1 p1 convs over maps

@@ -620,20 +620,24 @@ def _s1_case(dev, depth, sup_hw, weak_hw, seed):
     return dict(cfg=cfg, model=model, batch=batch, perms=perms, ref=ref, grads=grads, aux=keep)
 
 
-def _teacher_forced(dev, st, dtype, tag, cos_names=None):
-    """the HIP step on the oracle's proposals in `dtype` on the production schedule: integer stages exact; fp32: losses 1e-4, every
-    trainable tensor's gradient within 2e-3 of its max; bf16: losses rtol 6e-3 + atol 1e-4, gradient cosine >= 0.9975 on `cos_names`"""
+def _teacher_forced(dev, st, dtype, tag, cos_names=None, single_pass=None):
+    """the HIP step on the oracle's proposals in `dtype` (torch.float32 / torch.bfloat16 / "bf16x3") on the production schedule: integer stages
+    exact; fp32 and bf16x3: losses 1e-4, every trainable tensor's gradient within 2e-3 of its max; bf16: losses rtol 6e-3 + atol 1e-4, gradient
+    cosine >= 0.9975 on `cos_names`. single_pass: assert that a batch whose two groups pad differently took (True) / did not take (False) the
+    ragged single-pass backbone (ops.Ragged)"""
     model, cfg, aux = st["model"], st["cfg"], st["aux"]
-    model.compute_dtype = dtype
+    model.compute_mode = dtype if isinstance(dtype, str) else ("bf16" if dtype == torch.bfloat16 else "fp32")
     try:
         props = pack_proposals(aux["proposals"] + aux["weak_proposals"], cfg.MODEL.RPN.POST_NMS_TOPK_TRAIN, dev)
         step = model.forward_train(st["batch"], st["perms"], early_backward=True, proposals=props)
         model.backward_train(step)
         got = dict(zip(LOSS_NAMES, step.losses.cpu().tolist()))
+        if single_pass is not None:
+            assert step.split and bool(step.ragged) == single_pass, (tag, step.split, step.ragged)
         assert torch.equal(step.anchor_labels.cpu(), aux["anchor_labels"])
         _check_sampled_exact(step, aux, cfg.MODEL.ROI_HEADS.BATCH_SIZE_PER_IMAGE)
         params = dict(model.named_parameters())
-        if dtype == torch.float32:
+        if dtype == torch.float32 or dtype == "bf16x3":
             worst = 0.0
             for name, prm in params.items():
                 if not prm.requires_grad:
@@ -654,7 +658,7 @@ def _teacher_forced(dev, st, dtype, tag, cos_names=None):
             for n, c in cos.items():
                 assert c >= 0.9975, (tag, n, c)
     finally:
-        model.compute_dtype = torch.float32
+        model.compute_mode = "fp32"
 
 
 R50_COS = ["roi_heads.box_head.res5.2.conv3.weight", "roi_heads.box_head.res5.0.conv1.weight", "roi_heads.weak_box_head.res5.1.conv2.weight",
@@ -678,12 +682,19 @@ def test_r101_s1_800x1333_fp32_and_bf16(dev):
     st = _s1_case(dev, 101, [(800, 1333)] * 2, [(800, 1333)] * 2, seed=9)
     _teacher_forced(dev, st, torch.float32, "r101_s1_800x1333_fp32_teacher_forced")
     _teacher_forced(dev, st, torch.bfloat16, "r101_s1_800x1333_bf16", R101_COS)
+    _teacher_forced(dev, st, "bf16x3", "r101_s1_800x1333_bf16x3_teacher_forced")
 
 
 def test_r50_s1_mixed_orientations_two_pass(dev):
     """a landscape and a portrait image in the supervised batch (800x1216 + 1216x800 -> zero-padded to 1216x1216: more padding than image
-    in each slot) beside a weak batch that pads differently (800x1333 + 608x800 -> the two-pass backbone path of DESIGN section 5: forward
-    twice, backward twice, second pass's weight gradients accumulated)"""
+    in each slot) beside a weak batch that pads differently (800x1333 + 608x800): the reference runs the backbone once per batch
+    (rcnn.py:439, :452). Default: ONE ragged pass (ops.Ragged -- pointwise layers over the concatenated rows, pair launches for the rest,
+    weight gradients with the groups as parts) in all three compute modes; the two-pass form of rounds 1-4 (forward twice, backward twice,
+    second pass's weight gradients accumulated) stays behind `ragged_single_pass = False` and is held to the same bar."""
     st = _s1_case(dev, 50, [(800, 1216), (1216, 800)], [(800, 1333), (608, 800)], seed=13)
-    _teacher_forced(dev, st, torch.float32, "r50_s1_mixed_fp32_teacher_forced")
-    _teacher_forced(dev, st, torch.bfloat16, "r50_s1_mixed_bf16", R50_COS)
+    _teacher_forced(dev, st, torch.float32, "r50_s1_mixed_fp32_teacher_forced", single_pass=True)
+    _teacher_forced(dev, st, torch.bfloat16, "r50_s1_mixed_bf16", R50_COS, single_pass=True)
+    _teacher_forced(dev, st, "bf16x3", "r50_s1_mixed_bf16x3_teacher_forced", single_pass=True)
+    st["model"].ragged_single_pass = False
+    _teacher_forced(dev, st, torch.float32, "r50_s1_mixed_fp32_two_pass", single_pass=False)
+    _teacher_forced(dev, st, torch.bfloat16, "r50_s1_mixed_bf16_two_pass", R50_COS, single_pass=False)

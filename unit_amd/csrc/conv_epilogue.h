@@ -34,6 +34,29 @@ struct SplitK {
   int x_pitch;     // elements per pixel row of x (2 * cr)
 };
 
+// "Pair" launches (PAIR kernel instantiations): ONE grid over two independent problems of the SAME layer -- same weights, channels, taps, stride,
+// epilogue -- that differ in their tensors and map sizes: the supervised and the weak batch of a training step, each zero-padded to its OWN
+// largest image (meta_arch/rcnn.py:438-452, data/build.py:476-486 aspect-ratio grouping), so that a 3x3 / strided layer of both runs as one
+// launch instead of two half-empty ones (pointwise stride-1 layers need nothing: their rows are independent, the two batches are simply
+// concatenated). Workgroups [0, tiles0) run the first problem, the rest the second: the kernel swaps these fields into its argument block.
+struct ConvSecond {
+  int on, tiles0;
+  const void* x; void* y; const void* residual; const void* mask_ref;
+  int N, H, W, OH, OW, OHf, OWf, M, tiles_m;
+  unsigned x_bytes, magic_ow, magic_oh;
+};
+template <typename A>
+__device__ __forceinline__ void pair_swap_common(A& p) {
+  p.x = p.second.x; p.y = p.second.y; p.residual = p.second.residual; p.mask_ref = p.second.mask_ref;
+  p.N = p.second.N; p.H = p.second.H; p.W = p.second.W; p.OH = p.second.OH; p.OW = p.second.OW; p.OHf = p.second.OHf; p.OWf = p.second.OWf;
+  p.M = p.second.M; p.tiles_m = p.second.tiles_m; p.x_bytes = p.second.x_bytes;
+}
+// non-persistent kernels: called once at entry with the workgroup id
+template <typename A>
+__device__ __forceinline__ void pair_enter(A& p, int& bid) {
+  if (p.second.on && bid >= p.second.tiles0) { bid -= p.second.tiles0; pair_swap_common(p); }
+}
+
 struct PmClass { int tile0, np, oh0, nh, ow0, cw; unsigned magic_np, magic_cw; };      // tiles [tile0, next class's tile0) ; np = nh * cw positions
 struct PmRows {                                           // rows of one tile: class row i0 + (row of the tile)
   int i0, np, oh0, ow0, cw, OW, OHW, N;

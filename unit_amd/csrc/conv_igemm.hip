@@ -16,6 +16,8 @@
 // Fused epilogue: + bias[n] (FrozenBN shift / conv bias) + residual, ReLU or ReLU-mask (dgrad), strided scatter
 // (1x1 stride-2 dgrad writes every other pixel of a pre-zeroed tensor).
 #include "common.h"
+#include "conv_epilogue.h"
+#include "conv_pair.h"
 
 struct ConvArgs {
   const void* x; const void* w; void* y;
@@ -29,6 +31,7 @@ struct ConvArgs {
   int M;       // N*OH*OW
   int tiles_m, tiles_n;
   unsigned x_bytes, w_bytes;
+  ConvSecond second;  // conv_epilogue.h: pair launches
 };
 
 template <typename T> struct ElemsPerChunk { static constexpr int v = 16 / sizeof(T); };
@@ -74,7 +77,7 @@ template <> struct Out4<bf16_t> {
 
 __device__ __forceinline__ int swz(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
 
-template <typename TI, typename TO, int TM, int TN>
+template <typename TI, typename TO, int TM, int TN, bool PAIR = false>
 __global__ void __launch_bounds__(256, 2) conv_igemm_kernel(ConvArgs p) {
   constexpr int BM = 2 * TM * 16;   // pixels per block
   constexpr int BN = 2 * TN * 16;   // channels per block
@@ -86,8 +89,9 @@ __global__ void __launch_bounds__(256, 2) conv_igemm_kernel(ConvArgs p) {
   constexpr int BUF_BYTES = (BM + BN) * 128;
 
   // XCD-aware tile order: blocks b, b+8, ... share an XCD/L2 -> give each XCD a contiguous run of tiles, n fastest.
-  int nwg = p.tiles_m * p.tiles_n;
   int bid = blockIdx.x;
+  if constexpr (PAIR) pair_enter(p, bid);
+  int nwg = p.tiles_m * p.tiles_n;
   {
     int q = nwg / 8, r = nwg % 8, xcd = bid % 8, loc = bid / 8;
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
@@ -231,8 +235,14 @@ static int launch_conv(ConvArgs& a, hipStream_t st) {
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)conv_igemm_kernel<TI, TO, TM, TN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)conv_igemm_kernel<TI, TO, TM, TN, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
+  if (a.second.on) {          // pair launch: the second problem's tiles follow the first's
+    a.second.tiles_m = cdiv(a.second.M, BM);
+    a.second.tiles0 = a.tiles_m * a.tiles_n;
+    conv_igemm_kernel<TI, TO, TM, TN, true><<<(a.tiles_m + a.second.tiles_m) * a.tiles_n, 256, lds, st>>>(a);
+  } else
   conv_igemm_kernel<TI, TO, TM, TN><<<a.tiles_m * a.tiles_n, 256, lds, st>>>(a);
   UNIT_LAUNCH_CHECK();
   return UNIT_OK;
@@ -242,10 +252,11 @@ template <typename TI, typename TO>
 static int dispatch_tile(ConvArgs& a, int tile_cfg, hipStream_t st) {
   // tile_cfg: 0 auto, 1 = 128x128, 2 = 64(m)x128(n), 3 = 128(m)x64(n), 4 = 64x64
   if (tile_cfg == 0) {
-    long t128 = (long)cdiv(a.M, 128) * cdiv(a.K, 128);
-    if (a.K <= 64) tile_cfg = ((long)cdiv(a.M, 128) >= 384) ? 3 : 4;
+    long M = (long)a.M + (a.second.on ? a.second.M : 0);          // a pair launch fills the chip with both problems' tiles
+    long t128 = (long)cdiv(M, 128) * cdiv(a.K, 128);
+    if (a.K <= 64) tile_cfg = ((long)cdiv(M, 128) >= 384) ? 3 : 4;
     else if (t128 >= 384) tile_cfg = 1;
-    else if ((long)cdiv(a.M, 64) * cdiv(a.K, 128) >= 256) tile_cfg = 2;
+    else if ((long)cdiv(M, 64) * cdiv(a.K, 128) >= 256) tile_cfg = 2;
     else tile_cfg = 4;
   }
   switch (tile_cfg) {
@@ -263,6 +274,13 @@ extern "C" int unit_conv2d_fwd(const void* x, const void* w, void* y, const floa
                                const void* mask_ref, int in_dtype, int out_dtype, int N, int H, int W, int C, int K,
                                int R, int S, int stride, int pad, int OH, int OW, int ldy, int oy_mul, int OHf, int OWf,
                                int relu, int tile_cfg, void* stream) {
+  return unit_conv_generic_impl(x, w, y, bias, residual, mask_ref, in_dtype, out_dtype, N, H, W, C, K, R, S, stride, pad, OH, OW, ldy, oy_mul, OHf, OWf,
+                                relu, tile_cfg, nullptr, stream);
+}
+
+int unit_conv_generic_impl(const void* x, const void* w, void* y, const float* bias, const void* residual, const void* mask_ref, int in_dtype,
+                           int out_dtype, int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int OH, int OW, int ldy, int oy_mul,
+                           int OHf, int OWf, int relu, int tile_cfg, const UnitConvSecond* second, void* stream) {
   int epc = in_dtype == UNIT_BF16 ? 8 : 4;
   UNIT_CHECK_ARG(C % epc == 0, "conv: C must be a multiple of 8 (bf16) / 4 (fp32)");
   UNIT_CHECK_ARG(ldy % 4 == 0 && ldy >= K, "conv: ldy must be a multiple of 4 and >= K");
@@ -278,7 +296,8 @@ extern "C" int unit_conv2d_fwd(const void* x, const void* w, void* y, const floa
   size_t xb = (size_t)N * H * W * C * esz, wb = (size_t)K * R * S * C * esz;
   UNIT_CHECK_ARG(xb < 0xFFFFFFF0ull && wb < 0xFFFFFFF0ull, "conv: operand larger than 4 GiB (32-bit buffer offsets)");
   a.x_bytes = (unsigned)xb; a.w_bytes = (unsigned)wb;
-  if (a.M == 0 || K == 0) return UNIT_OK;
+  { int rc = unit_fill_second(a.second, second, R, S, stride, pad, oy_mul, (size_t)C * esz); if (rc != UNIT_OK) return rc; }
+  if (K == 0 || (a.M == 0 && !a.second.on)) return UNIT_OK;
   hipStream_t st = (hipStream_t)stream;
   if (in_dtype == UNIT_BF16 && out_dtype == UNIT_BF16) return dispatch_tile<bf16_t, bf16_t>(a, tile_cfg, st);
   if (in_dtype == UNIT_BF16 && out_dtype == UNIT_F32) return dispatch_tile<bf16_t, float>(a, tile_cfg, st);

@@ -15,6 +15,7 @@ struct ConvDmaArgs {
   int Kgemm, M;
   int tiles_m, tiles_n;
   unsigned x_bytes, w_bytes;
+  ConvSecond second; // conv_epilogue.h: pair launches (PAIR kernel instantiations; second.on == 0 otherwise)
   SplitK sk;         // conv_epilogue.h: bf16x3 operands (X3 kernel instantiations only; nseg == 0 otherwise)
   int mask_pitch;    // split epilogue: elements per row of mask_ref
 };

@@ -17,6 +17,7 @@
 #endif
 
 #include "conv_igemm128.h"
+#include "conv_pair.h"
 
 __device__ __forceinline__ int swz128(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
 
@@ -42,7 +43,7 @@ template <> struct Out4<bf16_t> {
 typedef __attribute__((address_space(3))) void lds_void_t;
 
 // X3: bf16x3 operands (conv_epilogue.h SplitK) -- split x, three k segments per 64-channel block, split output planes.
-template <typename TO, int BM, int BN, int NS, bool X3 = false>
+template <typename TO, int BM, int BN, int NS, bool X3 = false, bool PAIR = false>
 __global__ void __launch_bounds__(256, 2) conv_igemm_dma_kernel(ConvDmaArgs p) {
   static_assert(!X3 || sizeof(TO) == 2, "bf16x3 operands: split bf16 output");
   constexpr int BK = 64;
@@ -52,8 +53,9 @@ __global__ void __launch_bounds__(256, 2) conv_igemm_dma_kernel(ConvDmaArgs p) {
   constexpr int XI = BM / 32, WI = BN / 32;      // LDS-DMA instructions per wave and operand (8 rows each)
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
-  int nwg = p.tiles_m * p.tiles_n;
   int bid = blockIdx.x;
+  if constexpr (PAIR) pair_enter(p, bid);
+  int nwg = p.tiles_m * p.tiles_n;
   {
     int q = nwg / 8, r = nwg % 8, xcd = bid % 8, loc = bid / 8;
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
@@ -455,8 +457,14 @@ static int launch_dma(ConvDmaArgs& a, hipStream_t st) {
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)conv_igemm_dma_kernel<TO, BM, BN, NS, X3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)conv_igemm_dma_kernel<TO, BM, BN, NS, X3, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
+  if (a.second.on) {          // pair launch (conv_epilogue.h ConvSecond): the second problem's tiles follow the first's
+    a.second.tiles_m = cdiv(a.second.M, BM);
+    a.second.tiles0 = a.tiles_m * a.tiles_n;
+    conv_igemm_dma_kernel<TO, BM, BN, NS, X3, true><<<(a.tiles_m + a.second.tiles_m) * a.tiles_n, 256, lds, st>>>(a);
+  } else
   conv_igemm_dma_kernel<TO, BM, BN, NS, X3><<<a.tiles_m * a.tiles_n, 256, lds, st>>>(a);
   UNIT_LAUNCH_CHECK();
   return UNIT_OK;
@@ -479,6 +487,13 @@ int unit_conv_mid_x3_launch(ConvDmaArgs& a, int tile, hipStream_t st) {
 extern "C" int unit_conv2d_fwd_mid(const void* x, const void* w, void* y, const float* bias, const void* residual,
                                    const void* mask_ref, int out_dtype, int N, int H, int W, int C, int K, int R, int S, int stride,
                                    int pad, int OH, int OW, int ldy, int oy_mul, int OHf, int OWf, int relu, int tile, void* stream) {
+  return unit_conv_mid_impl(x, w, y, bias, residual, mask_ref, out_dtype, N, H, W, C, K, R, S, stride, pad, OH, OW, ldy, oy_mul, OHf, OWf, relu, tile,
+                            nullptr, stream);
+}
+
+int unit_conv_mid_impl(const void* x, const void* w, void* y, const float* bias, const void* residual, const void* mask_ref, int out_dtype, int N,
+                       int H, int W, int C, int K, int R, int S, int stride, int pad, int OH, int OW, int ldy, int oy_mul, int OHf, int OWf, int relu,
+                       int tile, const UnitConvSecond* second, void* stream) {
   UNIT_CHECK_ARG(C % 64 == 0, "conv_mid: C must be a multiple of 64");
   UNIT_CHECK_ARG(ldy % 4 == 0 && ldy >= K, "conv_mid: ldy must be a multiple of 4 and >= K");
   UNIT_CHECK_ARG(OH == (H + 2 * pad - R) / stride + 1 && OW == (W + 2 * pad - S) / stride + 1, "conv_mid: OH/OW mismatch");
@@ -486,7 +501,7 @@ extern "C" int unit_conv2d_fwd_mid(const void* x, const void* w, void* y, const 
   UNIT_CHECK_ARG(((uintptr_t)x % 16 == 0) && ((uintptr_t)w % 16 == 0) && ((uintptr_t)y % 16 == 0), "conv_mid: 16B alignment");
   UNIT_CHECK_ARG((tile >= 0 && tile <= 5) || tile >= 100, "conv_mid: tile must be 0..5 or a loader / consumer tile code (>= 100)");
   ConvDmaArgs a;
-  a.sk = SplitK{0, 0, 0, 0}; a.mask_pitch = 0;
+  a.sk = SplitK{0, 0, 0, 0}; a.mask_pitch = 0; a.second.on = 0;
   a.x = x; a.w = w; a.y = y; a.bias = bias; a.residual = residual; a.mask_ref = mask_ref;
   a.N = N; a.H = H; a.W = W; a.C = C; a.K = K; a.R = R; a.S = S; a.stride = stride; a.pad = pad;
   a.OH = OH; a.OW = OW; a.ldy = ldy; a.oy_mul = oy_mul; a.OHf = OHf; a.OWf = OWf; a.relu = relu;
@@ -494,7 +509,9 @@ extern "C" int unit_conv2d_fwd_mid(const void* x, const void* w, void* y, const 
   size_t xb = (size_t)N * H * W * C * 2, wb = (size_t)K * R * S * C * 2;
   UNIT_CHECK_ARG(xb < 0xFFFFFFF0ull && wb < 0xFFFFFFF0ull, "conv_mid: operand larger than 4 GiB");
   a.x_bytes = (unsigned)xb; a.w_bytes = (unsigned)wb;
-  if (a.M == 0 || K == 0) return UNIT_OK;
+  { int rc = unit_fill_second(a.second, second, R, S, stride, pad, oy_mul, (size_t)C * 2); if (rc != UNIT_OK) return rc; }
+  if (K == 0 || (a.M == 0 && !a.second.on)) return UNIT_OK;
+  UNIT_CHECK_ARG(!a.second.on || tile != 3, "conv_mid: the split-K tile has no pair form");
   hipStream_t st = (hipStream_t)stream;
   if (tile >= 100) return unit_conv_lc_launch(a, out_dtype, tile, st);       // persistent loader / consumer workgroups (conv_igemm_lc.hip)
   if (out_dtype == UNIT_BF16) {

@@ -30,6 +30,7 @@ struct Conv256Args {
   PmClass pm_cls[9];
   // ceil(2^32 / OW), ceil(2^32 / OH) when every pixel index m satisfies m * max(OW, OH) < 2^32 (fast_div, conv_epilogue.h), else 0
   unsigned magic_ow, magic_oh;
+  ConvSecond second; // conv_epilogue.h: pair launches (PAIR kernel instantiations; second.on == 0 otherwise)
   SplitK sk;         // conv_epilogue.h: bf16x3 operands (X3 kernel instantiations only; nseg == 0 otherwise)
   int mask_pitch;    // split epilogue: elements per row of mask_ref
 };

@@ -9,6 +9,7 @@
 // while k-tile t is multiplied; one vmcnt(0)+barrier per k-tile.  Requires C % 64 == 0 (every layer except the stem).
 #include "conv_igemm256.h"
 #include "conv_igemm128.h"
+#include "conv_pair.h"
 #ifndef UNIT_P8M_DEFAULT
 #define UNIT_P8M_DEFAULT 0
 #endif
@@ -634,13 +635,20 @@ int unit_conv256_use_m32() { return UNIT_P8M_DEFAULT; }
 extern "C" int unit_conv2d_fwd_big(const void* x, const void* w, void* y, const float* bias, const void* residual,
                                    const void* mask_ref, int out_dtype, int N, int H, int W, int C, int K, int R, int S, int stride,
                                    int pad, int OH, int OW, int ldy, int oy_mul, int OHf, int OWf, int relu, int variant, void* stream) {
+  return unit_conv_big_impl(x, w, y, bias, residual, mask_ref, out_dtype, N, H, W, C, K, R, S, stride, pad, OH, OW, ldy, oy_mul, OHf, OWf, relu,
+                            variant, nullptr, stream);
+}
+
+int unit_conv_big_impl(const void* x, const void* w, void* y, const float* bias, const void* residual, const void* mask_ref, int out_dtype, int N,
+                       int H, int W, int C, int K, int R, int S, int stride, int pad, int OH, int OW, int ldy, int oy_mul, int OHf, int OWf, int relu,
+                       int variant, const UnitConvSecond* second, void* stream) {
   UNIT_CHECK_ARG(C % 64 == 0, "conv_big: C must be a multiple of 64");
   UNIT_CHECK_ARG(ldy % 4 == 0 && ldy >= K, "conv_big: ldy must be a multiple of 4 and >= K");
   UNIT_CHECK_ARG(OH == (H + 2 * pad - R) / stride + 1 && OW == (W + 2 * pad - S) / stride + 1, "conv_big: OH/OW mismatch");
   UNIT_CHECK_ARG((OH - 1) * oy_mul < OHf && (OW - 1) * oy_mul < OWf, "conv_big: output scatter out of range");
   UNIT_CHECK_ARG(((uintptr_t)x % 16 == 0) && ((uintptr_t)w % 16 == 0) && ((uintptr_t)y % 16 == 0), "conv_big: 16B alignment");
   Conv256Args a;
-  a.sk = SplitK{0, 0, 0, 0}; a.mask_pitch = 0;
+  a.sk = SplitK{0, 0, 0, 0}; a.mask_pitch = 0; a.second.on = 0;
   a.x = x; a.w = w; a.y = y; a.bias = bias; a.residual = residual; a.mask_ref = mask_ref;
   a.N = N; a.H = H; a.W = W; a.C = C; a.K = K; a.R = R; a.S = S; a.stride = stride; a.pad = pad;
   a.OH = OH; a.OW = OW; a.ldy = ldy; a.oy_mul = oy_mul; a.OHf = OHf; a.OWf = OWf; a.relu = relu;
@@ -651,8 +659,13 @@ extern "C" int unit_conv2d_fwd_big(const void* x, const void* w, void* y, const 
   a.ex = EpiExtra{nullptr, nullptr, nullptr, 0}; a.ex_on = 0;
   a.x2 = nullptr; a.x2_bytes = 0; a.cb_split = 0; a.ratio2 = 1; a.pm_ncls = 0;
   set_div_magics(a);
-  if (a.M == 0 || K == 0) return UNIT_OK;
+  { int rc = unit_fill_second(a.second, second, R, S, stride, pad, oy_mul, (size_t)C * 2); if (rc != UNIT_OK) return rc; }
+  if (K == 0 || (a.M == 0 && !a.second.on)) return UNIT_OK;
   hipStream_t st = (hipStream_t)stream;
+  if (a.second.on) {          // pair launch: the phase-interleaved kernel on row-major 256-row tiles
+    UNIT_CHECK_ARG(out_dtype == UNIT_BF16 && (ldy & 7) == 0 && (variant == 0 || variant == 8 || variant == 12), "conv_big: pair launches: bf16 output, ldy % 8 == 0, variant 0 / 8 / 12");
+    return unit_conv256_p8_launch(a, out_dtype, true, false, st);
+  }
   // variant 0 / 4: one barrier per k-tile, 256-row tiles; 3: 224-row tiles; 5: 224 or 256 rows, whichever needs fewer
   // rounds x rows (isolated launches gain 6-7 % on the Res5 shapes: 50 176 = 224 * 224 pixels; inside the multi-stream step
   // the other streams already fill the partial last round and the 7 % extra operand feed of the smaller tile costs 0.8 %);
@@ -730,6 +743,13 @@ extern "C" int unit_conv2d_fwd_big(const void* x, const void* w, void* y, const 
 extern "C" int unit_conv2d_fwd_x3(const void* x, const void* w, void* y, const float* bias, const void* residual, const void* mask_ref,
                                   int mask_c, int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int OH, int OW, int ldy,
                                   int oy_mul, int OHf, int OWf, int relu, int tile, void* stream) {
+  return unit_conv_x3_impl(x, w, y, bias, residual, mask_ref, mask_c, N, H, W, C, K, R, S, stride, pad, OH, OW, ldy, oy_mul, OHf, OWf, relu, tile,
+                           nullptr, stream);
+}
+
+int unit_conv_x3_impl(const void* x, const void* w, void* y, const float* bias, const void* residual, const void* mask_ref, int mask_c, int N, int H,
+                      int W, int C, int K, int R, int S, int stride, int pad, int OH, int OW, int ldy, int oy_mul, int OHf, int OWf, int relu, int tile,
+                      const UnitConvSecond* second, void* stream) {
   UNIT_CHECK_ARG(C % 64 == 0, "conv_x3: C must be a multiple of 64");
   UNIT_CHECK_ARG(ldy % 8 == 0 && ldy >= K, "conv_x3: ldy must be a multiple of 8 and >= K");
   UNIT_CHECK_ARG(OH == (H + 2 * pad - R) / stride + 1 && OW == (W + 2 * pad - S) / stride + 1, "conv_x3: OH/OW mismatch");
@@ -741,9 +761,12 @@ extern "C" int unit_conv2d_fwd_x3(const void* x, const void* w, void* y, const f
   UNIT_CHECK_ARG(xb < 0xFFFFFFF0ull && wb < 0xFFFFFFF0ull, "conv_x3: operand larger than 4 GiB");
   SplitK sk{NSEG, 0x4, C, 2 * C};          // segments [hi.Wh, hi.Wl, lo.Wh]
   hipStream_t st = (hipStream_t)stream;
-  if ((long)N * OH * OW == 0 || K == 0) return UNIT_OK;
+  ConvSecond sec;
+  { int rc = unit_fill_second(sec, second, R, S, stride, pad, oy_mul, (size_t)C * 4); if (rc != UNIT_OK) return rc; }
+  if (K == 0 || ((long)N * OH * OW == 0 && !sec.on)) return UNIT_OK;
   if (tile >= 0) {
     ConvDmaArgs a;
+    a.second = sec;
     a.sk = sk; a.mask_pitch = 2 * mask_c;
     a.x = x; a.w = w; a.y = y; a.bias = bias; a.residual = residual; a.mask_ref = mask_ref;
     a.N = N; a.H = H; a.W = W; a.C = NSEG * C; a.K = K; a.R = R; a.S = S; a.stride = stride; a.pad = pad;
@@ -753,6 +776,7 @@ extern "C" int unit_conv2d_fwd_x3(const void* x, const void* w, void* y, const f
     return unit_conv_mid_x3_launch(a, tile, st);
   }
   Conv256Args a;
+  a.second = sec;
   a.sk = sk; a.mask_pitch = 2 * mask_c;
   a.x = x; a.w = w; a.y = y; a.bias = bias; a.residual = residual; a.mask_ref = mask_ref;
   a.N = N; a.H = H; a.W = W; a.C = NSEG * C; a.K = K; a.R = R; a.S = S; a.stride = stride; a.pad = pad;
@@ -763,10 +787,33 @@ extern "C" int unit_conv2d_fwd_x3(const void* x, const void* w, void* y, const f
   a.x2 = nullptr; a.x2_bytes = 0; a.cb_split = 0; a.ratio2 = 1; a.pm_ncls = 0;
   set_div_magics(a);
   // position-class tiles (3x3 s1 p1 on a small map: the k-tiles of all-padding taps are skipped) as in unit_conv2d_fwd_big
-  if (R == 3 && S == 3 && stride == 1 && pad == 1 && OH == H && OW == W && oy_mul == 1 && OHf == OH && OWf == OW && H * W <= 4096 &&
+  if (!sec.on && R == 3 && S == 3 && stride == 1 && pad == 1 && OH == H && OW == W && oy_mul == 1 && OHf == OH && OWf == OW && H * W <= 4096 &&
       (size_t)N * H * W * ldy * 4 < 0xFFFFFFF0ull)
     build_position_classes(a);
   return unit_conv256_p8_launch(a, UNIT_BF16, true, false, st);
+}
+
+// Two problems of ONE layer in one grid (conv_epilogue.h ConvSecond): the supervised and the weak batch of a training step, each zero-padded to
+// its own largest image (meta_arch/rcnn.py:438-452). kernel: 0 = unit_conv2d_fwd (tile = tile_cfg), 1 = unit_conv2d_fwd_mid (tile), 2 =
+// unit_conv2d_fwd_big (tile = variant 0 / 8 / 12; row-major tiles), 3 = unit_conv2d_fwd_x3 (tile). Results per problem: bit-identical to the
+// single launches (same tiles, same k order).
+extern "C" int unit_conv2d_fwd_pair(int kernel, const void* x, const void* w, void* y, const float* bias, const void* residual, const void* mask_ref,
+                                    int mask_c, int in_dtype, int out_dtype, int N, int H, int W, int C, int K, int R, int S, int stride, int pad,
+                                    int OH, int OW, int ldy, int oy_mul, int OHf, int OWf, int relu, int tile, const UnitConvSecond* second,
+                                    void* stream) {
+  UNIT_CHECK_ARG(second != nullptr, "conv_pair: no second problem");
+  switch (kernel) {
+    case 0: return unit_conv_generic_impl(x, w, y, bias, residual, mask_ref, in_dtype, out_dtype, N, H, W, C, K, R, S, stride, pad, OH, OW, ldy, oy_mul, OHf,
+                                          OWf, relu, tile, second, stream);
+    case 1: return unit_conv_mid_impl(x, w, y, bias, residual, mask_ref, out_dtype, N, H, W, C, K, R, S, stride, pad, OH, OW, ldy, oy_mul, OHf, OWf, relu, tile,
+                                      second, stream);
+    case 2: return unit_conv_big_impl(x, w, y, bias, residual, mask_ref, out_dtype, N, H, W, C, K, R, S, stride, pad, OH, OW, ldy, oy_mul, OHf, OWf, relu, tile,
+                                      second, stream);
+    case 3: return unit_conv_x3_impl(x, w, y, bias, residual, mask_ref, mask_c, N, H, W, C, K, R, S, stride, pad, OH, OW, ldy, oy_mul, OHf, OWf, relu, tile,
+                                     second, stream);
+  }
+  unit_set_error("conv_pair: kernel 0 (generic), 1 (mid), 2 (big), 3 (bf16x3)");
+  return UNIT_ERR_ARG;
 }
 
 
@@ -795,7 +842,7 @@ extern "C" int unit_conv2d_fwd_big_ex(const void* x, const void* w, void* y, con
   int OH = H + 2 * pad - R + 1, OW = W + 2 * pad - S + 1;
   UNIT_CHECK_ARG(OH > 0 && OW > 0, "conv_big_ex: empty output");
   Conv256Args a;
-  a.sk = SplitK{0, 0, 0, 0}; a.mask_pitch = 0;
+  a.sk = SplitK{0, 0, 0, 0}; a.mask_pitch = 0; a.second.on = 0;
   a.x = x; a.w = w; a.y = y; a.bias = bias; a.residual = residual; a.mask_ref = nullptr;
   const int Ct = C + (x2 ? C2 : 0);
   a.N = N; a.H = H; a.W = W; a.C = Ct; a.K = K; a.R = R; a.S = S; a.stride = 1; a.pad = pad;

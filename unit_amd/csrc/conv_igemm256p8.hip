@@ -68,9 +68,11 @@ extern "C" int unit_debug_read_stamps(unsigned long long* host_out) {
 // (the 16 unused rows of the X1 half are staged as zeros and never read).
 // X3: bf16x3 operands (conv_epilogue.h SplitK): x is a split tensor, the k extent holds three segments per 64-channel block, the output
 // (and residual / mask_ref) are split tensors. Same schedule; only the staging offsets (scalars) and the epilogue's stores differ.
-template <typename TO, bool RM, int B1, bool X3 = false>
+// PAIR: two problems of one layer in one grid (conv_epilogue.h ConvSecond; row-major tiles only).
+template <typename TO, bool RM, int B1, bool X3 = false, bool PAIR = false>
 __global__ void __launch_bounds__(512, 2) conv_igemm256_p8_kernel(Conv256Args p) {
   static_assert(RM || B1 == 4, "224-row tiles: RM schedule only");
+  static_assert(!PAIR || (RM && B1 == 4), "pair launches: 256-row RM schedule");
   static_assert(!X3 || (RM && sizeof(TO) == 2), "bf16x3 operands: RM schedule, split bf16 output");
   constexpr int FBT = 4 + B1;
   constexpr int BM = 32 * FBT, BN = 256, BK = 64;
@@ -78,9 +80,12 @@ __global__ void __launch_bounds__(512, 2) conv_igemm256_p8_kernel(Conv256Args p)
   constexpr int SX0 = 0, SW0 = HALF, SW1 = 2 * HALF, SX1 = 3 * HALF, BUF = 4 * HALF;
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
-  int nwg = p.tiles_m * p.tiles_n;
   int bid = blockIdx.x;
-  const bool pm = RM && B1 == 4 && p.pm_ncls > 0;
+  if constexpr (PAIR) {
+    if (p.second.on && bid >= p.second.tiles0) { bid -= p.second.tiles0; pair_swap_common(p); p.magic_ow = p.second.magic_ow; p.magic_oh = p.second.magic_oh; }
+  }
+  int nwg = p.tiles_m * p.tiles_n;
+  const bool pm = !PAIR && RM && B1 == 4 && p.pm_ncls > 0;
   int tile_n, tile_m;
   PmRows pmr = {0, 1, 0, 0, 1, p.OW, p.OH * p.OW, p.N, 0u, 0u};
   int pm_nh = 1;
@@ -506,6 +511,26 @@ __global__ void __launch_bounds__(512, 2) conv_igemm256_p8_kernel(Conv256Args p)
 
 template <typename TO, bool RM, int B1, bool X3 = false>
 static int launch256_p8(Conv256Args& a, hipStream_t st) {
+  if (a.second.on) {          // pair launch (conv_epilogue.h ConvSecond): row-major 256-row tiles of both problems in one grid
+    if constexpr (RM && B1 == 4 && sizeof(TO) == 2) {
+      a.pm_ncls = 0;
+      a.tiles_m = cdiv(a.M, 256); a.tiles_n = cdiv(a.K, 256);
+      a.second.tiles_m = cdiv(a.second.M, 256);
+      a.second.tiles0 = a.tiles_m * a.tiles_n;
+      size_t lds2 = 8 * 128 * 128;
+      static bool attr2 = false;
+      if (!attr2) {
+        (void)hipFuncSetAttribute((const void*)conv_igemm256_p8_kernel<TO, RM, B1, X3, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
+        attr2 = true;
+      }
+      conv_igemm256_p8_kernel<TO, RM, B1, X3, true><<<(a.tiles_m + a.second.tiles_m) * a.tiles_n, 512, lds2, st>>>(a);
+      UNIT_LAUNCH_CHECK();
+      return UNIT_OK;
+    } else {
+      unit_set_error("conv_big: pair launches need the 256-row RM schedule with bf16 output");
+      return UNIT_ERR_UNSUPPORTED;
+    }
+  }
   if (a.pm_ncls == 0) a.tiles_m = cdiv(a.M, 32 * (4 + B1));
   a.tiles_n = cdiv(a.K, 256);
   int grid = a.tiles_m * a.tiles_n;
@@ -537,7 +562,7 @@ static int launch256_p8(Conv256Args& a, hipStream_t st) {
 int unit_conv256_p8_launch(Conv256Args& a, int out_dtype, bool reads_in_mfma, bool rows224, hipStream_t st) {
   if (a.sk.nseg > 1) {             // bf16x3 operands (unit_conv2d_fwd_x3)
     if (out_dtype != UNIT_BF16 || (a.ldy & 7) != 0 || rows224 || !reads_in_mfma) { unit_set_error("conv_big: bf16x3 operands need the 256-row RM schedule and split output rows of 16-byte vectors"); return UNIT_ERR_UNSUPPORTED; }
-    return launch256_p8<bf16_t, true, 4, true>(a, st);
+    return launch256_p8<bf16_t, true, 4, true>(a, st);          // (a pair launch goes through the same launcher)
   }
   if (rows224 && !reads_in_mfma) { unit_set_error("conv_big: 224-row tiles need the reads-in-MFMA schedule"); return UNIT_ERR_UNSUPPORTED; }
   if (out_dtype == UNIT_BF16) return rows224 ? launch256_p8<bf16_t, true, 3>(a, st) : reads_in_mfma ? launch256_p8<bf16_t, true, 4>(a, st) : launch256_p8<bf16_t, false, 4>(a, st);

@@ -59,7 +59,9 @@ template <int FB, int FA, int NL, int NSMAX = 3> struct LcCfg {
 
 // X3: bf16x3 operands (conv_epilogue.h SplitK) -- the loaders' cursor carries the segment of the virtual channel block, the consumers
 // write split output planes; everything else is the same kernel.
-template <int FB, int FA, int NL, int NSMAX = 3, bool X3 = false>
+// PAIR: two problems of one layer in one grid (conv_epilogue.h ConvSecond): tile ids >= second.tiles0 belong to the second problem; the loaders'
+// cursor and the consumers swap the problem's fields in per tile (a workgroup's run of tiles may cross from one problem into the other).
+template <int FB, int FA, int NL, int NSMAX = 3, bool X3 = false, bool PAIR = false>
 __global__ void __launch_bounds__((4 + NL) * 64) conv_igemm_lc_kernel(ConvDmaArgs p) {
   typedef LcCfg<FB, FA, NL, NSMAX> Cf;
   constexpr int BM = Cf::BM, BN = Cf::BN, BK = 64;
@@ -69,7 +71,7 @@ __global__ void __launch_bounds__((4 + NL) * 64) conv_igemm_lc_kernel(ConvDmaArg
 
   // this workgroup's run of tiles: the XCD-aware id map of the other conv kernels (workgroup b runs on XCD b % 8; an XCD's
   // workgroups get neighbouring runs: the channel tiles of a pixel block share its rows through that XCD's L2), then an even split
-  const int total = p.tiles_m * p.tiles_n, nwg = gridDim.x;
+  const int total = (p.tiles_m + (PAIR ? p.second.tiles_m : 0)) * p.tiles_n, nwg = gridDim.x;
   int bid = blockIdx.x;
   {
     int q = nwg / 8, r = nwg % 8, xcd = bid % 8, loc = bid / 8;
@@ -88,11 +90,15 @@ __global__ void __launch_bounds__((4 + NL) * 64) conv_igemm_lc_kernel(ConvDmaArg
     const int l = wid - 4;
     const bf16_t* __restrict__ X = (const bf16_t*)p.x;
     const bf16_t* __restrict__ Wt = (const bf16_t*)p.w;
-    __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(X), 0, (int)p.x_bytes, 0x00020000);
+    __amdgpu_buffer_rsrc_t rsX0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(X), 0, (int)p.x_bytes, 0x00020000);
+    __amdgpu_buffer_rsrc_t rsX1 = rsX0;
+    if constexpr (PAIR) rsX1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>((const bf16_t*)p.second.x), 0, (int)p.second.x_bytes, 0x00020000);
     __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(Wt), 0, (int)p.w_bytes, 0x00020000);
     constexpr unsigned OOB = 0xFFFFFFF0u;
     const int lrow = lane >> 3, lc = lane & 7;
     const int RS = p.R * p.S;
+    int cH = p.H, cW = p.W;                         // map size of the problem the cursor's tile belongs to
+    bool cur_second = false;
     // The TP pieces of a k-step (X pieces 0 .. XP-1, then the W pieces) are dealt round-robin to the NL loaders: X piece i*NL + l, W piece
     // i*NL + lw with XP + lw = l (mod NL); piece = 8 rows: lane -> row + lrow, LDS chunk lc (lane-linear image), SOURCE chunk
     // lc ^ ((row >> 1) & 7)
@@ -107,6 +113,11 @@ __global__ void __launch_bounds__((4 + NL) * 64) conv_igemm_lc_kernel(ConvDmaArg
     const int xpitch = X3 ? p.sk.x_pitch : p.C;
     auto setup_tile = [&](int t) {
       int id = t_first + t;
+      int M = p.M, OW = p.OW, OH = p.OH;
+      cH = p.H; cW = p.W; cur_second = false;
+      if constexpr (PAIR) {
+        if (id >= p.second.tiles0) { id -= p.second.tiles0; M = p.second.M; OW = p.second.OW; OH = p.second.OH; cH = p.second.H; cW = p.second.W; cur_second = true; }
+      }
       int tile_n = id % p.tiles_n, tile_m = id / p.tiles_n;
       int m0 = tile_m * BM, n0 = tile_n * BN;
 #pragma unroll
@@ -114,11 +125,11 @@ __global__ void __launch_bounds__((4 + NL) * 64) conv_igemm_lc_kernel(ConvDmaArg
         int row = (i * NL + l) * 8 + lrow;
         x_q[i] = lc ^ ((row >> 1) & 7);
         int m = m0 + row;
-        x_ok[i] = row < BM && m < p.M;
+        x_ok[i] = row < BM && m < M;
         int mm = x_ok[i] ? m : 0;
-        int ow = mm % p.OW; int tt = mm / p.OW; int oh = tt % p.OH; int n = tt / p.OH;
+        int ow = mm % OW; int tt = mm / OW; int oh = tt % OH; int n = tt / OH;
         x_ih0[i] = oh * p.stride - p.pad; x_iw0[i] = ow * p.stride - p.pad;
-        x_base[i] = (unsigned)n * (unsigned)(p.H * p.W * xpitch);
+        x_base[i] = (unsigned)n * (unsigned)(cH * cW * xpitch);
       }
 #pragma unroll
       for (int i = 0; i < WPL; ++i) {
@@ -139,9 +150,10 @@ __global__ void __launch_bounds__((4 + NL) * 64) conv_igemm_lc_kernel(ConvDmaArg
         if (i * NL + l >= XP) continue;             // (wave-uniform)
         int R0 = (i * NL + l) * 8;
         int ih = x_ih0[i] + r, iw = x_iw0[i] + s;
-        bool ok = x_ok[i] && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
-        unsigned off = (x_base[i] + (unsigned)((ih * p.W + iw) * xpitch + ch0 + x_q[i] * 8)) * 2u;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, (lds_void_lc*)(base + R0 * 128), 16, ok ? off : OOB, 0, 0, 0);
+        bool ok = x_ok[i] && (unsigned)ih < (unsigned)cH && (unsigned)iw < (unsigned)cW;
+        unsigned off = (x_base[i] + (unsigned)((ih * cW + iw) * xpitch + ch0 + x_q[i] * 8)) * 2u;
+        if (PAIR && cur_second) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX1, (lds_void_lc*)(base + R0 * 128), 16, ok ? off : OOB, 0, 0, 0);      // (scalar branch)
+        else __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX0, (lds_void_lc*)(base + R0 * 128), 16, ok ? off : OOB, 0, 0, 0);
       }
 #pragma unroll
       for (int i = 0; i < WPL; ++i) {
@@ -193,6 +205,8 @@ __global__ void __launch_bounds__((4 + NL) * 64) conv_igemm_lc_kernel(ConvDmaArg
   int slot = 0;
   for (int t = 0; t < t_count; ++t) {
     int id = t_first + t;
+    bool second = false;
+    if constexpr (PAIR) { if (id >= p.second.tiles0) { id -= p.second.tiles0; second = true; } }
     int tile_n = id % p.tiles_n, tile_m = id / p.tiles_n;
     f32x4 acc[FA][FB];
 #pragma unroll
@@ -224,6 +238,11 @@ __global__ void __launch_bounds__((4 + NL) * 64) conv_igemm_lc_kernel(ConvDmaArg
     }
     // this wave's BM x FA*16 block through its private scratch, row-major (conv_epilogue.h); the loaders are already D k-steps
     // into the next tile
+    if (PAIR && second) {          // the second problem's output / residual / mask tensors and sizes
+      ConvDmaArgs q = p;
+      pair_swap_common(q);
+      epilogue_rows_bf16<FA, FB, X3>(acc, scr, tile_m * BM, tile_n * BN + c * FA * 16, q, lane);
+    } else
     epilogue_rows_bf16<FA, FB, X3>(acc, scr, tile_m * BM, tile_n * BN + c * FA * 16, p, lane);
   }
 }
@@ -233,6 +252,25 @@ static int launch_lc(ConvDmaArgs& a, hipStream_t st) {
   typedef LcCfg<FB, FA, NL, NSMAX> Cf;
   a.tiles_m = cdiv(a.M, Cf::BM); a.tiles_n = cdiv(a.K, Cf::BN);
   int total = a.tiles_m * a.tiles_n;
+  if (a.second.on) {          // pair launch (only the default three-slot / four-loader forms carry a PAIR instantiation)
+    if constexpr (NL == 4 && NSMAX == 3) {
+      a.second.tiles_m = cdiv(a.second.M, Cf::BM);
+      a.second.tiles0 = total;
+      total += a.second.tiles_m * a.tiles_n;
+      int grid = total < 256 ? total : 256;
+      static bool attr2 = false;
+      if (!attr2) {
+        (void)hipFuncSetAttribute((const void*)conv_igemm_lc_kernel<FB, FA, NL, NSMAX, X3, true>, hipFuncAttributeMaxDynamicSharedMemorySize, Cf::LDS);
+        attr2 = true;
+      }
+      conv_igemm_lc_kernel<FB, FA, NL, NSMAX, X3, true><<<grid, Cf::THREADS, Cf::LDS, st>>>(a);
+      UNIT_LAUNCH_CHECK();
+      return UNIT_OK;
+    } else {
+      unit_set_error("conv_lc: pair launches take the tile codes 142 .. 182, 144 .. 164");
+      return UNIT_ERR_UNSUPPORTED;
+    }
+  }
   const int slots = NSMAX == 2 ? 512 : 256;          // persistent workgroups: one per CU, two with the two-slot ring
   int grid = total < slots ? total : slots;
   static bool attr_set = false;

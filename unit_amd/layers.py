@@ -123,16 +123,60 @@ class Conv2d(_EpochOnLoad):
 
     def fwd(self, x, relu=False, residual=None, out_dtype=None, stride=None):
         st = self.stride if stride is None else stride
+        if isinstance(x, ops.Ragged):
+            return self._fwd_ragged(x, relu, residual, st)
         if self.x3:
             x, residual = ops.as_x3(x), ops.as_x3(residual)
         return ops.conv2d(x, self.wf, self.cout, self.k, self.k, st, self.pad, bias=self.shift, residual=residual, relu=relu,
                           out_dtype=out_dtype)
 
+    # ---- ragged batches (ops.Ragged: two image groups of different padded sizes in one tensor)
+    def _pointwise(self, st):
+        return self.k == 1 and st == 1 and self.pad == 0
+
+    def _fwd_ragged(self, x, relu, residual, st):
+        if self.x3 and type(x.flat) is not ops.X3:
+            x = x.like(ops.x3_split(x.flat))
+        if residual is not None and self.x3 and type(residual.flat) is not ops.X3:
+            residual = residual.like(ops.x3_split(residual.flat))
+        if self._pointwise(st):          # rows are independent: ONE GEMM over both groups
+            y = ops.conv2d(x.as_gemm(), self.wf, self.cout, 1, 1, 1, 0, bias=self.shift, residual=residual.as_gemm() if residual is not None else None,
+                           relu=relu)
+            return x.like(y.view(y.shape[2], y.shape[3]))
+        dims = [(n,) + ops.conv_out_size(h, w, self.k, self.k, st, self.pad) for n, h, w in x.dims]
+        out = ops.Ragged.empty(dims, self.cout, x.flat)
+        ops.conv2d_pair(x.groups(), self.wf, self.cout, self.k, self.k, st, self.pad, bias=self.shift,
+                        residuals=residual.groups() if residual is not None else None, relu=relu, outs=out.groups())
+        return out
+
+    def _dgrad_ragged(self, dy, in_dims, mask_ref, residual, st):
+        if self.x3:
+            cv = lambda t: t if (t is None or type(t.flat) is ops.X3) else t.like(ops.x3_split(t.flat))
+            dy, mask_ref, residual = cv(dy), cv(mask_ref), cv(residual)
+        gm = lambda t: t.as_gemm() if t is not None else None
+        gr = lambda t: t.groups() if t is not None else None
+        if self._pointwise(st):
+            y = ops.conv2d(dy.as_gemm(), self.wd, self.cin, 1, 1, 1, 0, residual=gm(residual), mask_ref=gm(mask_ref))
+            return dy.like(y.view(y.shape[2], y.shape[3]))
+        if st == 1:
+            out = ops.Ragged.empty(dy.dims, self.cin, dy.flat)
+            ops.conv2d_pair(dy.groups(), self.wd, self.cin, self.k, self.k, 1, self.k - 1 - self.pad, residuals=gr(residual), mask_refs=gr(mask_ref),
+                            outs=out.groups())
+            return out
+        assert self.k == 1, "strided dgrad is only needed for the 1x1 stride-2 convs of C4 ResNets"
+        out = ops.Ragged.zeros(in_dims, self.cin, dy.flat)
+        ops.conv2d_pair(dy.groups(), self.wd, self.cin, 1, 1, 1, 0, residuals=gr(residual), mask_refs=gr(mask_ref), outs=out.groups(),
+                        scatters=[(st, h, w) for _, h, w in in_dims])
+        return out
+
     def dgrad(self, dy, in_hw, mask_ref=None, residual=None, stride=None, mask_bits=None):
-        """d(loss)/d(input) [N,H,W,cin]; 1x1 stride-2: strided scatter into a zeroed full-resolution tensor.
+        """d(loss)/d(input) [N,H,W,cin]; 1x1 stride-2: strided scatter into a zeroed full-resolution tensor. (dy an ops.Ragged: in_hw = the input's
+        group dims [(n, h, w), (n, h, w)].)
         mask_bits: ops.ReluBits of the input (what mask_ref > 0 would give) -- read instead of mask_ref where the 256x256 kernel's
         extended epilogue applies (1/16 of the mask bytes: 218 -> 180 us for the 512 -> 2048 dgrad + residual of a Res5 block)"""
         st = self.stride if stride is None else stride
+        if isinstance(dy, ops.Ragged):
+            return self._dgrad_ragged(dy, in_hw, mask_ref, residual, st)
         if self.x3:
             dy, residual, mask_ref, mask_bits = ops.as_x3(dy), ops.as_x3(residual), ops.as_x3(mask_ref), None
         if st == 1 and mask_bits is not None and ops.conv_ex_supported(dy.dtype, self.cout, self.cin):
@@ -144,13 +188,32 @@ class Conv2d(_EpochOnLoad):
         assert self.k == 1, "strided dgrad is only needed for the 1x1 stride-2 convs of C4 ResNets"
         return ops.conv2d(dy, self.wd, self.cin, 1, 1, 1, 0, residual=residual, mask_ref=mask_ref, scatter=(st, in_hw[0], in_hw[1]))
 
+    def _grad_krsc(self):
+        g = self.weight.grad
+        if g is None:
+            g = torch.zeros_like(self.weight.data, memory_format=torch.channels_last)
+            self.weight.grad = g
+        gk = g.permute(0, 2, 3, 1)
+        if not gk.is_contiguous():
+            raise RuntimeError("conv weight .grad must be a channels_last ([K][R][S][C]) tensor")
+        return gk
+
     def wgrad(self, x, dy, stride=None):
         if not self.weight.requires_grad:
             return
         st = self.stride if stride is None else stride
         acc = ops.WGRAD_ACCUMULATE      # second contribution to the same gradients (ragged batches: backbone backward runs twice)
+        if isinstance(x, ops.Ragged):
+            if self.x3:
+                cv = lambda t: t if type(t.flat) is ops.X3 else t.like(ops.x3_split(t.flat))
+                x, dy = cv(x), cv(dy)
+            if self._pointwise(st):          # one contraction over the rows of both groups
+                x, dy = x.as_gemm(), dy.as_gemm()
+            else:                            # the groups are two PARTS of this layer's gradient: their slabs follow each other, one reduction
+                assert self.bias is None or not self.bias.requires_grad
+                x, dy = ops.Parts(x.groups()), ops.Parts(dy.groups())
         dy_plain = dy
-        if self.x3:
+        if self.x3 and not isinstance(x, ops.Parts):
             if self.bias is not None and self.bias.requires_grad:
                 dy_plain = ops.as_f32(dy)          # the bias gradient's column sums read plain fp32
             x, dy = ops.as_x3(x), ops.as_x3(dy)
@@ -184,13 +247,12 @@ class Conv2d(_EpochOnLoad):
             with ops.on_stream(side):             # (no torch stream switch: ~100 of these per step)
                 launch()
             return
-        g = self.weight.grad
-        if g is None:
-            g = torch.zeros_like(self.weight.data, memory_format=torch.channels_last)
-            self.weight.grad = g
-        gk = g.permute(0, 2, 3, 1)
-        if not gk.is_contiguous():
-            raise RuntimeError("conv weight .grad must be a channels_last ([K][R][S][C]) tensor")
+        if isinstance(x, ops.Parts):
+            g = self._grad_krsc()
+            for i, (xp, dp) in enumerate(zip(x, dy)):
+                ops.conv2d_wgrad(xp, dp, self.cout, self.k, self.k, st, self.pad, scale=self.scale, out=g, accumulate=acc or i > 0)
+            return
+        gk = self._grad_krsc()
         ops.conv2d_wgrad(x, dy, self.cout, self.k, self.k, st, self.pad, scale=self.scale, out=gk, accumulate=acc)
         if self.bias is not None and self.bias.requires_grad:
             if self.bias.grad is None:
@@ -232,7 +294,10 @@ class BottleneckBlock(nn.Module):
         (box_head.py:80) and, in the backward, tested for > 0 -- conv3's epilogue then produces the pooled features and a bit mask
         and never writes the map: returns ((pooled, bits | None), ctx) instead of (map, ctx)"""
         st = self.stride if stride is None else stride
-        if self.conv1.x3:
+        if isinstance(x, ops.Ragged):
+            if self.conv1.x3 and type(x.flat) is not ops.X3:
+                x = x.like(ops.x3_split(x.flat))
+        elif self.conv1.x3:
             x = ops.as_x3(x)          # (once: conv1 and the shortcut read it, the backward's weight gradients again)
         y1 = self.conv1.fwd(x, relu=True, stride=st)
         y2 = self.conv2.fwd(y1, relu=True)
@@ -258,6 +323,8 @@ class BottleneckBlock(nn.Module):
     def _dual_ok(self, x, y2, st):
         """conv3 + shortcut (forward) and conv1 dgrad + shortcut dgrad (backward) can run as dual-input GEMMs: the Res5 heads' first block
         in bf16 on the stride-2-subsampled RoIAlign output (every conv of the block is then stride 1)"""
+        if isinstance(x, ops.Ragged):
+            return False
         return (ops.FUSE_EPILOGUE and ops.FUSE_DUAL and getattr(self, "allow_dual", False) and self.shortcut is not None and st == 1
                 and x.dtype == torch.bfloat16 and x.shape[:3] == y2.shape[:3] and x.shape[0] > 0
                 and ops.conv_ex_supported(x.dtype, self.conv3.cin, self.conv3.cout) and self.shortcut.cin % self.conv3.cin == 0
@@ -305,18 +372,23 @@ class BottleneckBlock(nn.Module):
 
     def bwd(self, ctx, g, need_dx=True, mask_input=True):
         x, y1, y2, st, x_bits = ctx
-        if self.conv3.x3:
+        rag = isinstance(x, ops.Ragged)
+        if rag:
+            if self.conv3.x3 and type(g.flat) is not ops.X3:
+                g = g.like(ops.x3_split(g.flat))
+        elif self.conv3.x3:
             g = ops.as_x3(g)
+        hw_of = (lambda t: t.dims) if rag else (lambda t: t.shape[1:3])
         self.conv3.wgrad(y2, g)
-        dy2 = self.conv3.dgrad(g, y2.shape[1:3], mask_ref=y2)
+        dy2 = self.conv3.dgrad(g, hw_of(y2), mask_ref=y2)
         self.conv2.wgrad(y1, dy2)
-        dy1 = self.conv2.dgrad(dy2, y1.shape[1:3], mask_ref=y1)
+        dy1 = self.conv2.dgrad(dy2, hw_of(y1), mask_ref=y1)
         self.conv1.wgrad(x, dy1, stride=st)
         if self.shortcut is not None:
             self.shortcut.wgrad(x, g, stride=st)
         if not need_dx:
             return None
-        hw = x.shape[1:3]
+        hw = hw_of(x)
         if self._dual_ok(x, y2, st) and not mask_input and g.dtype == torch.bfloat16:
             wcat, _ = self._cat_weights("bwd")          # dx = [dy1 | g] . [W1^T ; Wsc^T]
             return ops.conv2d_ex(dy1, wcat, self.conv1.cin, 1, 1, 0, x2=g)[0]
@@ -339,7 +411,8 @@ class ResStage(nn.Sequential):
         x_bits = None
         for i, b in enumerate(self):
             last = i == len(self) - 1
-            ob = out_bits and not last and ops.conv_ex_supported(x.dtype, b.conv3.cin, b.conv3.cout) and (i > 0 or (first_stride or b.stride) == 1)
+            ob = (out_bits and not last and not isinstance(x, ops.Ragged) and ops.conv_ex_supported(x.dtype, b.conv3.cin, b.conv3.cout)
+                  and (i > 0 or (first_stride or b.stride) == 1))
             x, c = b.fwd(x, save, stride=first_stride if i == 0 else None, pool_rows=pool_rows if last else 0, x_bits=x_bits, out_bits=ob,
                          pooled_out=pooled_out if last else None)
             x_bits = None
@@ -387,10 +460,26 @@ class BasicStem(nn.Module):
 
     def fwd(self, x):
         c = self.conv1
+        if isinstance(x, (list, tuple)):
+            # two image groups of different padded sizes (ops.Ragged downstream): the frozen stem runs per group -- two launches of a kernel
+            # that is 3 % of the forward -- writing the groups' rows of ONE tensor
+            dims = []
+            for t in x:
+                n, h, w, _ = t.shape
+                oh, ow = (h - 1) // 2 + 1, (w - 1) // 2 + 1
+                dims.append((n, (oh - 1) // 2 + 1, (ow - 1) // 2 + 1))
+            out = ops.Ragged.empty(dims, c.cout, x[0])
+            for i, t in enumerate(x):
+                self._fwd_one(t, out.group(i))
+            return out
+        return self._fwd_one(x, None)
+
+    def _fwd_one(self, x, out):
+        c = self.conv1
         if (_FUSED_STEM and x.dtype == torch.bfloat16 and x.is_cuda and c.cout == 64 and x.shape[-1] == 8 and c.wf is not None
                 and c.wf.dtype == torch.bfloat16 and not c.weight.requires_grad):
-            return ops.stem_conv_pool(x, c.wf, c.shift)          # one persistent launch; the conv output never reaches HBM
-        return ops.maxpool3x3s2(c.fwd(x, relu=True))
+            return ops.stem_conv_pool(x, c.wf, c.shift, out=out)          # one persistent launch; the conv output never reaches HBM
+        return ops.maxpool3x3s2(c.fwd(x, relu=True), out=out)
 
 
 class Linear(_EpochOnLoad):

@@ -123,6 +123,9 @@ class WeaklySupervisedRCNNNoMeta(nn.Module):
         # --shapes voc, 100 steps, two alternating series on one box): 19.57 / 19.77 (0), 19.85 / 19.93 (1), 19.75 / 19.85 ms (2) -- small launches
         # from two streams interleave, they do not overlap: the concurrent forms stay a switch, sequential is the default.
         self.two_pass_overlap = int(os.environ.get("UNIT_TWO_PASS_OVERLAP", "0"))
+        # ragged supervised / weak batches as ONE backbone + RPN-head pass (ops.Ragged: pointwise layers over the concatenated rows, every
+        # other layer as a pair launch, weight gradients with the groups as parts): default; 0 = the two passes of rounds 1-4 (A/B, tests)
+        self.ragged_single_pass = os.environ.get("UNIT_RAGGED", "1") != "0"
         # backward-plan start (profiles/r04_exp_head_backward_start.txt): the RPN 3x3 conv's weight gradient goes out at the end of the
         # early RPN backward instead of with the heads' bucket; the supervised head's backward follows its losses on the head stream
         self.early_rpn_wgrad = os.environ.get("UNIT_EARLY_RPN_WGRAD", "1") != "0"
@@ -376,7 +379,7 @@ class WeaklySupervisedRCNNNoMeta(nn.Module):
         pad_of = lambda ss: (max(s[0] for s in ss), max(s[1] for s in ss))
         split = n_sup > 0 and n_weak > 0 and pad_of(raw[:n_sup]) != pad_of(raw[n_sup:])
         c.split = split
-        feat_w = head_w = anchors_w = split_props = split_side = None
+        feat_w = head_w = anchors_w = split_props = split_side = feat_r = None
         if not split:
             x, sizes = ops.preprocess_images(batch.images, self._pixel_mean, self._pixel_std, dt, 8, self.normalize_images)
             feat, c.bb_ctx = self.backbone.fwd(x, save=True, before_trainable=self.join_optimizer_tail)
@@ -407,9 +410,16 @@ class WeaklySupervisedRCNNNoMeta(nn.Module):
                     if split_props is not None:          # ... and the weak batch's proposal chain (latency-bound: free beside the supervised pass)
                         rpn.predict_proposals(head_w, rpn.anchor_generator.grid(feat_w.shape[1], feat_w.shape[2]), hw_all[n_sup:], True,
                                               out=tuple(t[n_sup:] for t in split_props))
-            feat, c.bb_ctx = self.backbone.fwd(xa, save=True, before_trainable=self.join_optimizer_tail)          # `feat` = supervised images only
-            if weak_side is None:
-                feat_w, c.bb_ctx_w = self.backbone.fwd(xb, save=True)
+            if weak_side is None and self.ragged_single_pass:
+                # ONE pass over both groups (ops.Ragged): the reference's two backbone calls (rcnn.py:439, :452) differ only in where each
+                # batch's zero padding starts, which every non-pointwise layer gets from its group's own map size
+                feat_r, c.bb_ctx = self.backbone.fwd([xa, xb], save=True, before_trainable=self.join_optimizer_tail)
+                c.bb_ctx_w = None
+                feat, feat_w = feat_r.groups()
+            else:
+                feat, c.bb_ctx = self.backbone.fwd(xa, save=True, before_trainable=self.join_optimizer_tail)          # `feat` = supervised images only
+                if weak_side is None:
+                    feat_w, c.bb_ctx_w = self.backbone.fwd(xb, save=True)
             anchors_w = rpn.anchor_generator.grid(feat_w.shape[1], feat_w.shape[2])
         self.join_optimizer_tail()          # (a fully frozen backbone never called it)
         c.image_sizes = sizes
@@ -443,9 +453,14 @@ class WeaklySupervisedRCNNNoMeta(nn.Module):
                 perms["roi"].record_stream(torch.cuda.current_stream())
             else:
                 perms = self.sampling_permutations(n_sup, anchors.shape[0], n_roi_cap)
-        head, c.rpn_ctx = rpn.rpn_head.fwd(feat_c, save=True)
-        if split and head_w is None:
-            head_w, _ = rpn.rpn_head.fwd(feat_w_c, save=False)          # weak images: proposals only (no RPN loss)
+        c.ragged = feat_r is not None
+        if c.ragged:
+            hr, c.rpn_ctx = rpn.rpn_head.fwd(feat_r, save=True)          # both groups: one conv launch, one predictor GEMM
+            head, head_w = (hr.group(i).view(d[0], d[1] * d[2], hr.channels) for i, d in enumerate(hr.dims))
+        else:
+            head, c.rpn_ctx = rpn.rpn_head.fwd(feat_c, save=True)
+            if split and head_w is None:
+                head_w, _ = rpn.rpn_head.fwd(feat_w_c, save=False)          # weak images: proposals only (no RPN loss)
         c.dhead = None
         c.drpn = None
         c.rpn_bwd_early = False
@@ -492,7 +507,7 @@ class WeaklySupervisedRCNNNoMeta(nn.Module):
                 rpn.predict_proposals(head_w, anchors_w, hw[n_sup:], True, out=tuple(t[n_sup:] for t in split_props))
             rpn.predict_proposals(head, anchors, hw[:n_sup], True, out=tuple(t[:n_sup] for t in split_props))
             props, pscores, pcount = split_props
-        if split and c.bb_ctx_w is not None and split_side is not None:
+        if split and getattr(c, "bb_ctx_w", None) is not None and split_side is not None:
             # join the weak batch's side pass (backbone, RPN head, its proposal chain); what it allocated is used -- and later freed -- by work
             # on the main and weight-gradient streams
             cur = torch.cuda.current_stream()
@@ -808,8 +823,8 @@ class WeaklySupervisedRCNNNoMeta(nn.Module):
             dpool_sup, dpool_weak, drpn = ops.as_f32(dpool_sup), ops.as_f32(dpool_weak), ops.as_f32(drpn)
             # d(loss)/d(res4 output) = RoIAlign backward (gather form, deterministic) + RPN branch, times the ReLU mask --
             # one fused kernel per image group (supervised RoIs only touch supervised images, weak RoIs weak images)
-            def grad_map(ft, dp, n_im, r_lo, r_hi, img0, add):
-                out = torch.empty_like(ft)
+            def grad_map(ft, dp, n_im, r_lo, r_hi, img0, add, out=None):
+                out = out if out is not None else torch.empty_like(ft)
                 if dp is not None:
                     rh.pool_bwd_gather(dp, n_im, ft.shape[1], ft.shape[2], c.rois[r_lo:r_hi], out, image_offset=img0, addend=add, mask_ref=ft)
                 else:
@@ -829,6 +844,12 @@ class WeaklySupervisedRCNNNoMeta(nn.Module):
                         z = ops.zeros(feat[lo:hi].shape, torch.float32, feat.device)
                         ops.add_cast(z, add, dt, mask_ref=feat[lo:hi], out=g[lo:hi])
                 self.backbone.bwd(c.bb_ctx, g, on_stage_done=done)
+            elif getattr(c, "ragged", False):
+                # ragged batches, single pass: the two groups' gradient maps are the rows of ONE ops.Ragged; one backward pass
+                gr = ops.Ragged.empty([tuple(feat.shape[:3]), tuple(c.feat_w.shape[:3])], feat.shape[3], feat)
+                grad_map(feat, dpool_sup, n_sup, 0, rs, 0, drpn, out=gr.group(0))
+                grad_map(c.feat_w, dpool_weak, c.n_weak, rs, rs + rw, n_sup, None, out=gr.group(1))
+                self.backbone.bwd(c.bb_ctx, gr, on_stage_done=done)
             else:
                 # ragged batches (forward ran the backbone twice): two backward passes; the weight gradients of the second
                 # accumulate onto the first (whose slabs are reduced before the second pass may touch the same gradients)

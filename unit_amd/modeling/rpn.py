@@ -32,6 +32,13 @@ class StandardRPNHead(nn.Module):
 
     def fwd(self, feat, save=False):
         """feat [N,H,W,C] -> head fp32 [N, H*W, kp] (cols [0,A) logits, [A,5A) deltas) ; ctx"""
+        if isinstance(feat, ops.Ragged):
+            # two image groups of different padded sizes: the 3x3 conv as one pair launch, the predictors' GEMM over the rows of both;
+            # -> ops.Ragged head [M0 + M1, kp] (group i viewed as [n_i, h_i * w_i, kp] by the caller); ctx = the first (supervised) group's
+            t = self.conv.fwd(feat, relu=True)
+            t = t.like(ops.as_f32(t.flat))
+            head = t.like(self.pred.fwd(t.flat))
+            return head, ((feat.group(0), t.group(0)) if save else None)
         n, h, w, c = feat.shape
         t = ops.as_f32(self.conv.fwd(feat, relu=True))          # (bf16x3 mode: the conv returns a split tensor, the predictors' GEMM is an fp32 kernel)
         head = self.pred.fwd(t.view(n * h * w, c)).view(n, h * w, self.pred.kp)

@@ -613,7 +613,39 @@ def conv2d_wgrad(x, dy, k, r, s, stride=1, pad=0, scale=None, out=None, accumula
 
 
 def conv2d_wgrad_partial(x, dy, k, r, s, stride, pad, slab=None, variant=0):
-    """split-M partial slabs only (no reduction): returns (slab uint8 tensor, n_splits); slab i = floats [i*k*r*s*C, ...)."""
+    """split-M partial slabs only (no reduction): returns (slab uint8 tensor, n_splits); slab i = floats [i*k*r*s*C, ...).
+    x / dy ops.Parts: the parts' slabs follow each other (n_splits = all of them)."""
+    if isinstance(x, Parts):
+        c = x[0].shape[-1]
+        x3 = type(x[0]) is X3
+        need, per = [], []
+        for xp, dp in zip(x, dy):
+            n, h, wd, _ = xp.shape
+            oh, ow = conv_out_size(h, wd, r, s, stride, pad)
+            mul = 3 if x3 else 1
+            need.append(mul * lib().unit_conv2d_wgrad_workspace_bytes(BF16 if x3 else dt(xp.dtype), n, oh, ow, k, r, s, c))
+            per.append(mul * lib().unit_conv2d_wgrad_splits(BF16 if x3 else dt(xp.dtype), n, oh, ow, k, r, s, c))
+        nbytes = sum(need)
+        if slab is None or slab.numel() < nbytes:
+            old = slab
+            if slab is not None:
+                _retire(slab)
+            slab = torch.empty(_grown(nbytes, old), dtype=torch.uint8, device=x[0].device)
+        one = k * r * s * c * 4
+        at = 0
+        for xp, dp, sp in zip(x, dy, per):
+            n, h, wd, _ = xp.shape
+            oh, ow = conv_out_size(h, wd, r, s, stride, pad)
+            view = slab[at * one:]
+            with _timed("conv_wgrad", (3 if x3 else 1) * 2.0 * n * oh * ow * k * r * s * c, (xp.numel() + dp.numel()) * xp.element_size() + 4 * k * r * s * c):
+                if x3:
+                    check(lib().unit_conv2d_wgrad_x3(_px(xp), _px(dp), None, None, n, h, wd, c, k, r, s, stride, pad, oh, ow, k, 0, int(variant), _p(view),
+                                                     view.numel(), _s()), "unit_conv2d_wgrad_x3(part)")
+                else:
+                    check(lib().unit_conv2d_wgrad(_p(xp), _p(dp), None, None, dt(xp.dtype), n, h, wd, c, k, r, s, stride, pad, oh, ow, dp.shape[-1], 0,
+                                                  int(variant), _p(view), view.numel(), _s()), "unit_conv2d_wgrad(part)")
+            at += sp
+        return slab, at
     if type(x) is X3:
         return _wgrad_partial_x3(x, dy, k, r, s, stride, pad, slab, variant)
     n, h, wd, c = x.shape
@@ -639,6 +671,142 @@ def conv2d_wgrad_partial(x, dy, k, r, s, stride, pad, slab=None, variant=0):
                                                   (x.numel() + n * oh * ow * ldy) * x.element_size() + 4 * k * r * s * c))
     return slab, splits
 
+
+
+# ------------------------------------------------------------------------------------------------ ragged batches (two image groups)
+class Ragged:
+    """Activations of TWO image groups -- the supervised and the weak batch of a training step, each zero-padded to its own largest image
+    (meta_arch/rcnn.py:438-452) -- as ONE tensor: the pixel rows of group 0 followed by those of group 1, `flat` [M0 + M1, C] (plain or X3).
+    Pointwise stride-1 layers run over `flat` as one GEMM (rows are independent); every other layer runs both groups in one PAIR launch
+    (unit_conv2d_fwd_pair) on the group views; weight gradients take the groups as parts of one layer. `group(i)` is a zero-copy
+    [n, h, w, C] view."""
+
+    def __init__(self, flat, dims):
+        assert flat.dim() == 2 and len(dims) == 2 and sum(n * h * w for n, h, w in dims) == flat.shape[0], (flat.shape, dims)
+        self.flat, self.dims = flat, [tuple(d) for d in dims]
+
+    @property
+    def dtype(self):
+        return self.flat.dtype
+
+    @property
+    def device(self):
+        return self.flat.device
+
+    @property
+    def channels(self):
+        return self.flat.shape[1]
+
+    def rows(self, i):
+        lo = 0 if i == 0 else self.dims[0][0] * self.dims[0][1] * self.dims[0][2]
+        n, h, w = self.dims[i]
+        return lo, lo + n * h * w
+
+    def group(self, i):
+        lo, hi = self.rows(i)
+        n, h, w = self.dims[i]
+        return self.flat[lo:hi].view(n, h, w, self.flat.shape[1])
+
+    def groups(self):
+        return self.group(0), self.group(1)
+
+    def as_gemm(self):
+        """[1, 1, M0 + M1, C]: what a pointwise stride-1 layer sees"""
+        return self.flat.view(1, 1, self.flat.shape[0], self.flat.shape[1])
+
+    def like(self, flat):
+        return Ragged(flat, self.dims)
+
+    def record_stream(self, stream):
+        self.flat.record_stream(stream)
+
+    @staticmethod
+    def empty(dims, c, like):
+        """uninitialised Ragged of `c` channels with the dtype / device / X3-ness of the tensor `like`"""
+        m = sum(n * h * w for n, h, w in dims)
+        t = torch.empty((m, c), dtype=like.dtype, device=like.device)
+        return Ragged(t.as_subclass(X3) if type(like) is X3 else t, dims)
+
+    @staticmethod
+    def zeros(dims, c, like):
+        m = sum(n * h * w for n, h, w in dims)
+        t = zeros((m, c), like.dtype, like.device)
+        return Ragged(t.as_subclass(X3) if type(like) is X3 else t, dims)
+
+
+class Parts(tuple):
+    """the operand of a layer's weight gradient as several PARTS (the image groups of an ops.Ragged through a non-pointwise layer): x = Parts of
+    [n, h, w, C] tensors, dy = Parts of the matching [n, oh, ow, K] tensors. The parts' split-M slabs follow each other in the layer's buffer and
+    one reduction adds them -- a part is to the weight gradient what one more split-M range is."""
+
+    def record_stream(self, stream):
+        for t in self:
+            t.record_stream(stream)
+
+
+class ConvSecond(ctypes.Structure):
+    """include/unit_hip.h: UnitConvSecond"""
+    _fields_ = [("x", ctypes.c_void_p), ("y", ctypes.c_void_p), ("residual", ctypes.c_void_p), ("mask_ref", ctypes.c_void_p)] + \
+               [(f, ctypes.c_int) for f in ("N", "H", "W", "OHf", "OWf")]
+
+
+def conv2d_pair(xs, w, k, r, s, stride=1, pad=0, bias=None, residuals=None, mask_refs=None, relu=False, outs=None, scatters=None, force=None):
+    """the same conv layer over TWO inputs of different map sizes in ONE launch (unit_conv2d_fwd_pair; csrc/conv_epilogue.h ConvSecond):
+    xs = (x0, x1) NHWC of one dtype / channel count (plain or X3), residuals / mask_refs / outs / scatters pairs (or None). The kernel and
+    tile are chosen for the SUM of the two problems' pixels (force = (kernel, tile) of unit_conv2d_fwd_pair overrides: tests). Returns (y0, y1);
+    each equals the single launch's result bit for bit."""
+    x0, x1 = xs
+    x3 = type(x0) is X3
+    assert (type(x1) is X3) == x3 and x0.dtype == x1.dtype and x0.shape[3] == x1.shape[3]
+    c = x0.shape[3]
+    residuals = residuals or (None, None)
+    mask_refs = mask_refs or (None, None)
+    scatters = scatters or (None, None)
+    geo = []
+    for x, sc in zip(xs, scatters):
+        n, h, wd, _ = x.shape
+        oh, ow = conv_out_size(h, wd, r, s, stride, pad)
+        oy_mul, ohf, owf = (1, oh, ow) if sc is None else sc
+        geo.append((n, h, wd, oh, ow, oy_mul, ohf, owf))
+    assert geo[0][5] == geo[1][5], "conv2d_pair: one scatter multiplier for both problems"
+    ldy = k if x3 else (k + 3) // 4 * 4
+    if outs is None:
+        mk = (lambda shape: zeros(shape, x0.dtype, x0.device)) if scatters[0] is not None else (lambda shape: torch.empty(shape, dtype=x0.dtype, device=x0.device))
+        outs = tuple(mk((g[0], g[6], g[7], ldy)) for g in geo)
+        if x3:
+            outs = tuple(o.as_subclass(X3) for o in outs)
+    ptr = (lambda t: None if t is None else ctypes.c_void_p(t.data_ptr())) if x3 else _p
+    if x3:
+        for t in tuple(xs) + tuple(outs) + tuple(q for q in residuals + mask_refs if q is not None):
+            assert type(t) is X3 and t.is_contiguous()
+    m_tot = sum(g[0] * g[3] * g[4] for g in geo)
+    mask_c = mask_refs[0].shape[-1] if (x3 and mask_refs[0] is not None) else 0
+    if force is not None:
+        kernel, tile = force
+    elif x3:
+        kernel, tile = 3, X3_TILE_POLICY(m_tot, k, c, 3 * r * s * c)
+    else:
+        big = BIG_TILE_POLICY(x0.dtype, m_tot, k, c, r * s * c) and ldy % 8 == 0
+        mid = -1
+        if not big:
+            lc_ok = x0.dtype == torch.bfloat16 and ldy % 8 == 0
+            mid = MID_TILE_POLICY(x0.dtype, m_tot, k, c, r * s * c, allow_lc=lc_ok)
+            if mid >= 2000 or mid == 3:          # forms without a pair instantiation: the plain 4-wave tile instead
+                tiles = ((m_tot + 127) // 128) * ((k + 127) // 128)
+                mid = 2 if k <= 64 else (0 if tiles >= 256 else 1)
+        kernel, tile = (2, 0) if big else ((1, mid) if mid >= 0 else (0, 0))
+    g0, g1 = geo
+    sec = ConvSecond()
+    sec.x, sec.y = xs[1].data_ptr(), outs[1].data_ptr()
+    sec.residual = residuals[1].data_ptr() if residuals[1] is not None else None
+    sec.mask_ref = mask_refs[1].data_ptr() if mask_refs[1] is not None else None
+    sec.N, sec.H, sec.W, sec.OHf, sec.OWf = g1[0], g1[1], g1[2], g1[6], g1[7]
+    with _timed("conv_igemm256" if kernel == 2 or (kernel == 3 and tile < 0) else ("conv_igemm_dma" if kernel in (1, 3) else "conv_igemm"),
+                (3 if x3 else 1) * 2.0 * m_tot * k * r * s * c, (sum(x.numel() for x in xs) + m_tot * ldy) * x0.element_size()):
+        check(lib().unit_conv2d_fwd_pair(kernel, ptr(xs[0]), _p(w), ptr(outs[0]), _p(bias), ptr(residuals[0]), ptr(mask_refs[0]), mask_c,
+                                         BF16 if x3 else dt(x0.dtype), BF16 if x3 else dt(x0.dtype), g0[0], g0[1], g0[2], c, k, r, s, stride, pad, g0[3], g0[4],
+                                         ldy, g0[5], g0[6], g0[7], int(relu), int(tile), ctypes.byref(sec), _s()), "unit_conv2d_fwd_pair")
+    return outs
 
 
 # ------------------------------------------------------------------------------------------------ bf16x3 (split) convolutions
@@ -762,7 +930,9 @@ class WgradProblem(ctypes.Structure):
 
 def wgrad_group_supported(x, dy, k, r, s, stride, pad):
     """may this layer's weight gradient go into a grouped launch (csrc/conv_wgrad128r.hip)? bf16 tensors, or X3 split tensors (each of
-    the three plane passes of a bf16x3 weight gradient is a bf16 problem of its own in the grid)"""
+    the three plane passes of a bf16x3 weight gradient is a bf16 problem of its own in the grid); ops.Parts: every part"""
+    if isinstance(x, Parts):
+        return all(wgrad_group_supported(xp, dp, k, r, s, stride, pad) for xp, dp in zip(x, dy))
     n, h, wd, c = x.shape
     oh, ow = conv_out_size(h, wd, r, s, stride, pad)
     if type(x) is X3:
@@ -776,23 +946,26 @@ _X3_PASSES = ((0, 0), (0, 1), (1, 0))          # (plane of x, plane of dy) per p
 def conv2d_wgrad_group(items, slabs=None, splits_hint=0):
     """split-M partial slabs of SEVERAL layers from one launch (unit_conv2d_wgrad_group). items: [(x, dy, k, r, s, stride, pad)];
     slabs: per item a uint8 tensor to reuse or None. Returns [(slab, n_splits)]; slab i of a layer = floats [i*k*r*s*C, ...) as
-    conv2d_wgrad_partial leaves them. X3 items (bf16x3 split tensors) enter as three problems, one per plane pass, whose slabs follow
-    each other in the layer's buffer (n_splits = all of them)."""
+    conv2d_wgrad_partial leaves them. An item is one or more PROBLEMS of the grid whose slabs follow each other in the layer's buffer
+    (n_splits = all of them): one per part of an ops.Parts operand (the image groups of a ragged batch), times one per plane pass for X3
+    (bf16x3 split) tensors."""
     n_items = len(items)
     if n_items == 0:
         return []
     assert ctypes.sizeof(WgradProblem) == lib().unit_wgrad_problem_bytes()
-    probs = []          # (item index, pass | None)
+    probs = []          # (item index, x part, dy part, pass | None)
     for i, it in enumerate(items):
-        if type(it[0]) is X3:
-            assert type(it[1]) is X3 and it[1].shape[-1] == it[2]
-            probs += [(i, ps) for ps in range(3)]
-        else:
-            probs.append((i, None))
+        parts = list(zip(it[0], it[1])) if isinstance(it[0], Parts) else [(it[0], it[1])]
+        for xp, dp in parts:
+            if type(xp) is X3:
+                assert type(dp) is X3 and dp.shape[-1] == it[2]
+                probs += [(i, xp, dp, ps) for ps in range(3)]
+            else:
+                probs.append((i, xp, dp, None))
     pr = (WgradProblem * len(probs))()
     flops = nbytes = 0
-    for j, (i, ps) in enumerate(probs):
-        x, dy, k, r, s, stride, pad = items[i]
+    for j, (i, x, dy, ps) in enumerate(probs):
+        _, _, k, r, s, stride, pad = items[i]
         n, h, wd, c = x.shape
         oh, ow = conv_out_size(h, wd, r, s, stride, pad)
         q = pr[j]
@@ -809,22 +982,24 @@ def conv2d_wgrad_group(items, slabs=None, splits_hint=0):
         flops += 2.0 * n * oh * ow * k * r * s * c
     check(lib().unit_conv2d_wgrad_group_plan(pr, len(probs), int(splits_hint)), "unit_conv2d_wgrad_group_plan")
     total = [0] * n_items
-    for j, (i, ps) in enumerate(probs):
+    for j, (i, _, _, _) in enumerate(probs):
         total[i] += pr[j].splits
     out = []
-    for i, (x, dy, k, r, s, stride, pad) in enumerate(items):
-        one = k * r * s * x.shape[-1] * 4
+    for i, it in enumerate(items):
+        k, r, s = it[2], it[3], it[4]
+        x0 = it[0][0] if isinstance(it[0], Parts) else it[0]
+        one = k * r * s * x0.shape[-1] * 4
         need = total[i] * one
         slab = slabs[i] if slabs is not None else None
         if slab is None or slab.numel() < need:
             old = slab
             if slab is not None:
                 _retire(slab)       # (conv2d_wgrad_partial)
-            slab = torch.empty(_grown(need, old), dtype=torch.uint8, device=x.device)
+            slab = torch.empty(_grown(need, old), dtype=torch.uint8, device=x0.device)
         out.append((slab, total[i]))
     at = [0] * n_items
-    for j, (i, ps) in enumerate(probs):
-        x, dy, k, r, s, stride, pad = items[i]
+    for j, (i, x, _, _) in enumerate(probs):
+        k, r, s = items[i][2], items[i][3], items[i][4]
         pr[j].partial = out[i][0].data_ptr() + at[i] * k * r * s * x.shape[-1] * 4
         at[i] += pr[j].splits
     with _timed("conv_wgrad", flops, nbytes):
@@ -875,22 +1050,24 @@ def linear_wgrad(x2d, dy2d, k, dw, db):
               "unit_linear_wgrad")
 
 
-def stem_conv_pool(x, w_fwd, shift):
+def stem_conv_pool(x, w_fwd, shift, out=None):
     """bf16 x [N,H,W,8] -> [N,PH,PW,64]: 7x7 s2 conv + folded FrozenBN + ReLU + 3x3 s2 max pool in one launch (csrc/stem_pool.hip)"""
     n, h, w, c = x.shape
     assert c == 8 and tuple(w_fwd.shape) == (64, 7, 7, 8) and x.dtype == torch.bfloat16 and w_fwd.dtype == torch.bfloat16
     oh, ow = (h - 1) // 2 + 1, (w - 1) // 2 + 1
     ph, pw = (oh - 1) // 2 + 1, (ow - 1) // 2 + 1
-    y = torch.empty((n, ph, pw, 64), dtype=x.dtype, device=x.device)
+    y = out if out is not None else torch.empty((n, ph, pw, 64), dtype=x.dtype, device=x.device)
+    assert tuple(y.shape) == (n, ph, pw, 64) and y.is_contiguous()
     with _timed("stem", 2.0 * n * oh * ow * 64 * 147, x.numel() * 2 + y.numel() * 2):
         check(lib().unit_stem_conv_pool(_p(x), _p(w_fwd), _p(shift), _p(y), dt(x.dtype), n, h, w, _s()), "unit_stem_conv_pool")
     return y
 
 
-def maxpool3x3s2(x):
+def maxpool3x3s2(x, out=None):
     n, h, w, c = x.shape
     oh, ow = (h + 2 - 3) // 2 + 1, (w + 2 - 3) // 2 + 1
-    y = torch.empty((n, oh, ow, c), dtype=x.dtype, device=x.device)
+    y = out if out is not None else torch.empty((n, oh, ow, c), dtype=x.dtype, device=x.device)
+    assert tuple(y.shape) == (n, oh, ow, c) and y.is_contiguous() and y.dtype == x.dtype
     check(lib().unit_maxpool3x3s2_fwd(_p(x), _p(y), dt(x.dtype), n, h, w, c, _s()), "maxpool")
     return y
 
