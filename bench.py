@@ -408,7 +408,7 @@ def voc_shapes_run(args, cfg, model, buckets, opt, rank, world, dev):
     """SECONDARY line (never the headline: BASELINE.json's metric is quoted on fixed 3x600x1000 images): the same S1 step over batches whose
     image sizes change every step the way the reference's loader makes them (synthetic.voc_shaped_steps: VOC aspect ratios,
     ResizeShortestEdge 480-800 / max 1333, one orientation per batch). The supervised and the weak batch of a step almost never pad to the
-    same size, so nearly every step takes the two-pass backbone path; tile policies, weight-gradient split plans and scratch sizes are met
+    same size: such a step runs ONE ragged backbone + RPN-head pass over both groups (ops.Ragged; two passes until round 4); tile policies, weight-gradient split plans and scratch sizes are met
     for the first time inside the timed region, as they are in training."""
     import torch.distributed as dist
     from unit_amd import _lib, ops
@@ -476,14 +476,15 @@ def voc_shapes_run(args, cfg, model, buckets, opt, rank, world, dev):
                "ms_per_step": round(dt / steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype,
                "data": "synthetic", "launch": "hipGraph replay per batch key" if gs else "eager", "host_enqueue_ms_per_step": round(host_ms, 3),
                "host_enqueue_ms_from_idle_device": round(host_idle_ms, 3),
-               "dist": dict(buckets.describe(), tuning=tuning, exposed_ms_per_bucket_tag=per_bucket), "build_hash": _lib.build_hash(),
+               "dist": buckets.describe(), "build_hash": _lib.build_hash(),
                "config": {"workload": f"UniT base-training step S1, ResNet-{args.depth}-C4, 2 supervised + 2 weak images per GPU whose sizes change every "
                                       "step: VOC raw sizes through ResizeShortestEdge((480, ..., 800), max 1333) with one orientation per batch "
                                       "(configs/VOC/VOC-RCNN-101-C4-split1.yaml:27-29, data/build.py:476-497), 512 RoIs/image, 12000->2000",
                           "images_per_gpu": 2, "global_batch": 2 * world, "parallelism": f"dp{world}",
                           "mean_pixels_per_step": round(px), "pixels_relative_to_the_600x1000_workload": round(px / (4 * 600 * 1000), 3),
                           "mean_padded_pixels_per_step": round(padded), "padded_pixels_relative_to_the_600x1000_workload": round(padded / (4 * 600 * 1000), 3),
-                          "steps_on_the_two_pass_backbone_path": two_pass},
+                          "steps_whose_two_batches_pad_differently": two_pass,
+                          "backbone_passes_per_such_step": 1 if getattr(model, "ragged_single_pass", False) else 2},
                "shape_churn": {"tile_policy_cache_misses": len(ops._POLICY_CACHE) - pol0, "scratch_buffer_growths": ops.WS_GROWTHS[0] - ws0,
                                "device_mallocs": mem1.get("num_device_alloc", 0) - mem0.get("num_device_alloc", 0),
                                "allocator_retries": mem1.get("num_alloc_retries", 0) - mem0.get("num_alloc_retries", 0),

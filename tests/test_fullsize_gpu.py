@@ -645,7 +645,9 @@ def _teacher_forced(dev, st, dtype, tag, cos_names=None, single_pass=None):
                 g, gr = prm.grad.detach().cpu(), st["grads"][name]
                 err = max((g - gr).abs().max().item() - 1e-7, 0.0) / (gr.abs().max().item() + 1e-12)
                 worst = max(worst, err)
-                assert err <= 2e-3, (tag, name, err)
+                # (bf16x3: ~2^-17 per product instead of 2^-24 -- a few more ReLU masks flip where a pre-activation is within rounding of zero;
+                #  measured worst 2.2e-3 on the mixed-orientation case, 1.6e-3 on the 600x1000 one)
+                assert err <= (4e-3 if dtype == "bf16x3" else 2e-3), (tag, name, err)
             dev_l = {k: abs(got[k] - v) / max(1.0, abs(v)) for k, v in st["ref"].items()}
             log_metrics(tag, dict(loss_rel_dev=dev_l, worst_grad_rel_to_max=worst))
             for k, v in dev_l.items():
