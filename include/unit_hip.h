@@ -111,10 +111,10 @@ int unit_conv2d_fwd_mid(const void* x, const void* w, void* y, const float* bias
  * The reference computes its convolutions in fp32 (/root/reference/modeling/roi_heads/fast_rcnn.py:37-101, modeling/proposal_generator/
  * rpn.py:55-101 over fp32 cuDNN convs); gfx950's fp32 MFMA runs at 1/16 of the bf16 rate. A fp32 value travels here as TWO bf16 numbers,
  * hi = bf16(x), lo = bf16(x - hi) (16 significant bits), a "split tensor" [rows][2][C] bf16 (plane 0 = hi, plane 1 = lo; 4 bytes per
- * element), and a product is three bf16 MFMA products with fp32 accumulation, x . w ~ hi.Wh + hi.Wl + lo.Wh: ~2^-17 relative per product.
+ * element), and a product is three bf16 MFMA products with fp32 accumulation, x . w ~ lo.Wh + hi.Wh + hi.Wl: ~2^-17 relative per product.
  *   unit_x3_split / unit_x3_merge   fp32 [rows][C] <-> split [rows][2][C] (C % 8 == 0; merge is exact)
  *   unit_weight_prep_x3             fp32 [K][R][S][C] (x scale[k], the FrozenBN fold) -> w_fwd [K][R][S][C/64][3][64] = per 64-channel block
- *                                   the k-segments [Wh | Wl | Wh] that meet the planes [hi | hi | lo] of x; w_dgrad [C][R][S][K/64][3][64] with the
+ *                                   the k-segments [Wh | Wh | Wl] that meet the planes [lo | hi | hi] of x; w_dgrad [C][R][S][K/64][3][64] with the
  *                                   taps flipped (either may be NULL)
  *   unit_conv2d_fwd_x3              y = split(relu?(conv(x, w) + bias + residual) masked by (mask_ref > 0)); x, y, residual split tensors (y /
  *                                   residual rows of ldy channels per plane, ldy % 8 == 0), mask_ref a split tensor of mask_c channels per plane

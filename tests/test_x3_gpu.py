@@ -58,11 +58,11 @@ def test_weight_prep_x3_layout(dev):
     wf, wd = o.weight_prep_x3(w.to(dev), scale.to(dev), k, r, r, c)
     ws = w * scale.view(-1, 1, 1, 1)
     h, l = split_cpu(ws)
-    exp = torch.stack([h.view(k, r, r, c // 64, 64), l.view(k, r, r, c // 64, 64), h.view(k, r, r, c // 64, 64)], 4).reshape(k, r, r, 3 * c)
+    exp = torch.stack([h.view(k, r, r, c // 64, 64), h.view(k, r, r, c // 64, 64), l.view(k, r, r, c // 64, 64)], 4).reshape(k, r, r, 3 * c)
     assert torch.equal(wf.cpu(), exp)
     hd = h.flip(1, 2).permute(3, 1, 2, 0).contiguous()                       # [c][r'][s'][k], taps flipped
     ld = l.flip(1, 2).permute(3, 1, 2, 0).contiguous()
-    expd = torch.stack([hd.view(c, r, r, k // 64, 64), ld.view(c, r, r, k // 64, 64), hd.view(c, r, r, k // 64, 64)], 4).reshape(c, r, r, 3 * k)
+    expd = torch.stack([hd.view(c, r, r, k // 64, 64), hd.view(c, r, r, k // 64, 64), ld.view(c, r, r, k // 64, 64)], 4).reshape(c, r, r, 3 * k)
     assert torch.equal(wd.cpu(), expd)
 
 

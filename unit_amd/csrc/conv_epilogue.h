@@ -22,13 +22,13 @@ __device__ __forceinline__ unsigned fast_div(unsigned x, unsigned d, unsigned ma
 
 // bf16x3 ("split") operands of the LDS-DMA conv kernels (their X3 instantiations; csrc/split.hip has the format and the converters).
 // An fp32 activation x travels as two bf16 planes per pixel row, [row][2][Cr]: hi = bf16(x), lo = bf16(x - hi) -- 16 significant bits
-// in 4 bytes -- and a weight likewise as Wh, Wl. x . W ~ hi.Wh + hi.Wl + lo.Wh with fp32 accumulation (the dropped lo.Wl term and the
+// in 4 bytes -- and a weight likewise as Wh, Wl. x . W ~ lo.Wh + hi.Wh + hi.Wl with fp32 accumulation (the dropped lo.Wl term and the
 // representation error are ~2^-17 relative per product) is ONE GEMM over a three times longer contraction: each 64-channel block of
-// the k extent becomes `nseg` = 3 k-tiles, [hi | hi | lo] of x against [Wh | Wl | Wh] of a weight tensor laid out as
+// the k extent becomes `nseg` = 3 k-tiles, [lo | hi | hi] of x against [Wh | Wh | Wl] of a weight tensor laid out as
 // [K][R][S][Cr / 64][nseg][64]. To the kernels this is a conv with C = nseg * Cr virtual channels whose x k-tiles come from row
 // pitch `x_pitch`, plane (seg_lo >> segment) & 1, channel block cb. Only the staging addresses change: scalar arithmetic.
 struct SplitK {
-  int nseg;        // k segments per 64-channel block (3); 0 / 1 = plain bf16 operands
+  int nseg;        // k segments per 64-channel block (3: [lo.Wh, hi.Wh, hi.Wl]); 0 / 1 = plain bf16 operands
   int seg_lo;      // bit s: segment s reads the lo plane of x (offset cr elements inside the row)
   int cr;          // real channels per plane
   int x_pitch;     // elements per pixel row of x (2 * cr)

@@ -734,9 +734,9 @@ int unit_conv_big_impl(const void* x, const void* w, void* y, const float* bias,
 // ---------------------------------------------------------------------------------------------------------------------
 // bf16x3 ("split") convolution: fp32-grade forward / dgrad on the bf16 MFMA kernels (conv_epilogue.h SplitK, csrc/split.hip).
 //   x        split tensor [N,H,W][2][C] bf16 (hi plane, lo plane)
-//   w        [K][R][S][C / 64][3][64] bf16 = per 64-channel block [Wh | Wl | Wh] (unit_weight_prep_x3)
+//   w        [K][R][S][C / 64][3][64] bf16 = per 64-channel block [Wh | Wh | Wl] (unit_weight_prep_x3) against the planes [lo | hi | hi] of x
 //   y        split tensor [.][2][ldy]; residual: like y; mask_ref: split tensor with mask_c channels per plane (plane 0 carries the sign)
-// y = split(relu?(sum_k (hi.Wh + hi.Wl + lo.Wh) + bias + residual) * (mask_ref > 0)), fp32 accumulation: ~2^-17 relative per product, the
+// y = split(relu?(sum_k (lo.Wh + hi.Wh + hi.Wl) + bias + residual) * (mask_ref > 0)), fp32 accumulation: ~2^-17 relative per product, the
 // reference's fp32 arithmetic (fast_rcnn.py:37-101, rpn.py:55-101 run on fp32 convs) at three bf16 MFMA passes instead of the 16x
 // slower fp32 MFMA. tile: -1 = 256x256 phase-interleaved kernel (conv_igemm256p8.hip), 0 / 1 / 2 = 128x128 / 64x128 / 128x64 4-wave
 // tiles (conv_igemm128.hip), >= 100 = loader / consumer tile code (conv_igemm_lc.hip).
@@ -759,7 +759,7 @@ int unit_conv_x3_impl(const void* x, const void* w, void* y, const float* bias, 
   const int NSEG = 3;
   size_t xb = (size_t)N * H * W * C * 4, wb = (size_t)K * R * S * C * NSEG * 2;
   UNIT_CHECK_ARG(xb < 0xFFFFFFF0ull && wb < 0xFFFFFFF0ull, "conv_x3: operand larger than 4 GiB");
-  SplitK sk{NSEG, 0x4, C, 2 * C};          // segments [hi.Wh, hi.Wl, lo.Wh]
+  SplitK sk{NSEG, 0x1, C, 2 * C};          // segments [lo.Wh, hi.Wh, hi.Wl]
   hipStream_t st = (hipStream_t)stream;
   ConvSecond sec;
   { int rc = unit_fill_second(sec, second, R, S, stride, pad, oy_mul, (size_t)C * 4); if (rc != UNIT_OK) return rc; }

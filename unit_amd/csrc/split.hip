@@ -6,14 +6,14 @@
 // 81 ms. bf16 alone (8 significant bits) lands at 6e-3. A fp32 value split into TWO bf16 numbers keeps 16 significant bits,
 //      x = hi + lo,   hi = bf16(x),   lo = bf16(x - hi)          (x - hi is exact in fp32)
 // and a product of two such numbers needs three bf16 MFMA products with fp32 accumulation,
-//      x . w ~ hi.Wh + hi.Wl + lo.Wh                              (the dropped lo.Wl term is < 2^-18 |x w|)
+//      x . w ~ lo.Wh + hi.Wh + hi.Wl                              (the dropped lo.Wl term is < 2^-18 |x w|)
 // i.e. ~2^-17 relative per product at 3/16 of the fp32 MFMA's time. Measured through the whole R50 step on CPU (emulated with
 // F.conv2d on the split operands): losses within 2e-6 of fp32, index decisions identical.
 //
 // Storage ("split tensor"): an activation [rows][C] travels as [rows][2][C] bf16 -- plane 0 = hi, plane 1 = lo, 4 bytes per element
 // like fp32 -- so that the LDS-DMA staging of the conv kernels reads 128-byte k-tiles of either plane straight from memory. Weights
-// are prepared as [K][R][S][C / 64][3][64] = per 64-channel block the three k-segments [Wh | Wl | Wh] that pair with the planes
-// [hi | hi | lo] of x (conv_epilogue.h SplitK; unit_conv2d_fwd_x3). Weight gradients contract [hi | hi | lo] of x against
+// are prepared as [K][R][S][C / 64][3][64] = per 64-channel block the three k-segments [Wh | Wh | Wl] that pair with the planes
+// [lo | hi | hi] of x (conv_epilogue.h SplitK; unit_conv2d_fwd_x3). Weight gradients contract [hi | hi | lo] of x against
 // [hi | lo | hi] of dy as three slab passes (conv_wgrad.hip).
 #include "common.h"
 
@@ -67,7 +67,8 @@ extern "C" int unit_x3_merge(const void* in, float* out, long rows, int C, void*
 }
 
 // w fp32 [K][R][S][C] (x scale[k]: the FrozenBN fold) ->
-//   w_fwd   [K][R][S][C / 64][3][64]   segments [Wh | Wl | Wh]
+//   w_fwd   [K][R][S][C / 64][3][64]   segments [Wh | Wh | Wl]  (against the planes [lo | hi | hi] of x: consecutive k-tiles share an
+//                                      operand -- Wh, then hi -- which the 256x256 kernel keeps in registers, conv_igemm256p8.hip)
 //   w_dgrad [C][R][S][K / 64][3][64]   taps flipped (dgrad = forward conv of dy with this tensor), same segments over the K axis
 __global__ void weight_prep_x3_kernel(const float* __restrict__ w, const float* __restrict__ scale, int K, int R, int S, int C,
                                       bf16_t* __restrict__ wf, bf16_t* __restrict__ wd) {
@@ -82,11 +83,11 @@ __global__ void weight_prep_x3_kernel(const float* __restrict__ w, const float* 
   bf16_t h = (bf16_t)v, l = (bf16_t)(v - (float)h);
   if (wf) {
     bf16_t* q = wf + (((size_t)k * R + r) * S + s) * (size_t)(3 * C) + (size_t)(c >> 6) * 192 + (c & 63);
-    q[0] = h; q[64] = l; q[128] = h;
+    q[0] = h; q[64] = h; q[128] = l;
   }
   if (wd) {
     bf16_t* q = wd + (((size_t)c * R + (R - 1 - r)) * S + (S - 1 - s)) * (size_t)(3 * K) + (size_t)(k >> 6) * 192 + (k & 63);
-    q[0] = h; q[64] = l; q[128] = h;
+    q[0] = h; q[64] = h; q[128] = l;
   }
 }
 
