@@ -186,8 +186,8 @@ def launch_ranks(args):
 
 
 def cpu_baseline(depth, variant):
-    """The oracle (CPU restatement of the reference path, kind "port") timed on ALL of this box's host cores (the process's affinity
-    set; SURVEY 8d: torch.set_num_threads(os.cpu_count())) on a BOUNDED sample: one S1 step (forward + backward) on 2 supervised + 2 weak
+    """The oracle (CPU restatement of the reference path, kind "port") timed on this box's host cores -- as many threads as a short probe
+    finds fastest, up to the whole affinity set (torch.set_num_threads(os.cpu_count())) -- on a BOUNDED sample: one S1 step (forward + backward) on 2 supervised + 2 weak
     600x1000 images -- first with 256 RoIs per image (half of the bench workload's; ~10 s), then, when that took under 40 s, with the full
     512: `value` is the full workload's figure when it ran, the half sample's otherwise (both are reported)."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
@@ -199,7 +199,32 @@ def cpu_baseline(depth, variant):
         avail = len(os.sched_getaffinity(0))
     except AttributeError:
         avail = os.cpu_count() or 1
-    cores = max(1, avail)              # every core the process may run on
+    # How many threads: every core of the affinity set is the plan -- but the GPU boxes show 256 logical CPUs to a container whose
+    # CPU share is a fraction of them, and PyTorch-CPU convolutions then THRASH (measured on a box, tools/cpu_threads_probe.py: the Res5 3x3 conv
+    # 2.1 / 2.7 / 1.8 / 1.0 / 0.33 TFLOP/s at 16 / 32 / 64 / 128 / 256 threads). So the count is measured, not assumed: a 2-second probe of one
+    # res4-sized convolution per candidate, the fastest wins, the table goes into the line.
+    import torch.nn.functional as F
+    quota = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        quota = None if q == "max" else round(float(q) / float(per), 2)
+    except (OSError, ValueError):
+        pass
+    cands = sorted({c for c in (8, 16, 32, 64, 128, avail) if c <= avail})
+    px, pw = torch.randn(4, 256, 38, 63), torch.randn(256, 256, 3, 3)
+    probe = {}
+    for cnd in cands:
+        torch.set_num_threads(cnd)
+        F.conv2d(px, pw, padding=1)
+        t0 = time.time()
+        reps = 0
+        while reps < 3 or (time.time() - t0 < 0.25 and reps < 50):
+            F.conv2d(px, pw, padding=1)
+            reps += 1
+        probe[cnd] = round((time.time() - t0) / reps * 1e3, 2)          # ms per convolution
+        if probe[cnd] > 4 * min(probe.values()):
+            break                                                        # (past the knee: more threads only get slower)
+    cores = min(probe, key=probe.get)
     os.environ["OMP_NUM_THREADS"] = str(cores)
     torch.set_num_threads(cores)
     cfg = config.voc_rcnn_c4_split1(depth)
@@ -246,7 +271,8 @@ def cpu_baseline(depth, variant):
                 break
     except OSError:
         pass
-    return {"value": best["images_per_sec"], "unit": "images/sec", "cores": cores, "cpu_model": cpu_model, "host_cores_available": avail, "kind": "port",
+    return {"value": best["images_per_sec"], "unit": "images/sec", "cores": cores, "cpu_model": cpu_model, "host_cores_available": avail,
+            "cgroup_cpu_quota": quota, "thread_probe_ms_per_res4_conv": probe, "kind": "port",
             "sample": f"oracle (PyTorch-CPU fp32 + C) S1 fwd+bwd, R{depth}-C4, 2 supervised + 2 weak 3x600x1000 images, "
                       f"{best['rois_per_image']} RoIs/image" + (" (the bench workload)" if whole else " (1/2 of 512)") + f", {best['seconds']} s on {cores} threads",
             "sample_tflop": best["sample_tflop"], "step_tflop": full, "cpu_tflops": best["cpu_tflops"],
