@@ -217,7 +217,7 @@ class Conv2d(_EpochOnLoad):
             if self.bias is not None and self.bias.requires_grad:
                 dy_plain = ops.as_f32(dy)          # the bias gradient's column sums read plain fp32
             x, dy = ops.as_x3(x), ops.as_x3(dy)
-        if getattr(self, "_plan", None) is not None:
+        if getattr(self, "_plan", None) is not None and not ops.WGRAD_DIRECT:
             # multi-tensor plan (unit_amd/multi.py): leave the split-M slabs in this layer's resident buffer; one
             # unit_multi_wgrad_reduce launch per bucket folds them into the flat gradient buffer later
             side = ops.WGRAD_STREAM

@@ -100,8 +100,13 @@ class ResNet(nn.Module):
             g = st.bwd(ctx[i], g, need_dx=(i > ft), mask_input=True, on_block_done=cb)
         return None
 
-    # ---- plugin surface: NCHW fp32 in, {"res4": NCHW fp32} out (inference / feature extraction only)
+    # ---- plugin surface: NCHW fp32 in, {"res4": NCHW fp32} out
     def forward(self, x):
+        if self.training and torch.is_grad_enabled():
+            # training under a meta-architecture other than the fused step (the reference's own rcnn.py:439): one autograd node over the
+            # explicit forward / backward of the backbone (modeling/train_modules.py)
+            from .train_modules import backbone_forward_train
+            return backbone_forward_train(self, x)
         dtype = getattr(self, "compute_dtype", torch.bfloat16)
         self.prepare(dtype, 0)
         xh = ops.nchw_to_nhwc(x, dtype=dtype, cpad=8)

@@ -116,7 +116,12 @@ class WSROIHeadNoMeta(nn.Module):
         Eval: -> (list[Instances(pred_boxes, scores, pred_classes[, pred_masks])], None)."""
         del images, weak_images
         if self.training:
-            raise RuntimeError("WSROIHead*.forward in training mode: " + _FUSED)
+            # roi_heads.py:553-591 in training under a meta-architecture other than the fused step: ONE autograd node over the heads'
+            # explicit forward / backward (modeling/train_modules.py) -> (sampled proposals, {loss_cls, loss_box_reg, loss_im_cls, loss_oicr_*})
+            if tta or return_similarity or return_proposals or train_only_weak:
+                raise NotImplementedError("tta / return_similarity / return_proposals / train_only_weak are outside the hot path (SURVEY.md section 2)")
+            from .train_modules import roi_heads_forward_train
+            return roi_heads_forward_train(self, features, proposals, targets, weak_features, weak_proposals, weak_targets)
         if tta or return_similarity or return_proposals:
             raise NotImplementedError("tta / return_similarity / return_proposals belong to the TTA and visualisation tools, "
                                       "outside the hot path (SURVEY.md section 2)")

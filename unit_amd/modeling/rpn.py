@@ -145,11 +145,13 @@ class WSRPN(nn.Module):
         _, kc, boxes, scores = ops.nms(cb, cs, cc, self.nms_thresh, self.post_nms_topk[training], out=out)
         return boxes, scores, kc
 
-    # ---- plugin surface (rpn.py:20): inference / proposal generation on NCHW fp32 features
+    # ---- plugin surface (rpn.py:20) on NCHW fp32 features: eval = proposal generation; training = losses + proposals as an autograd node
     def forward(self, images, features, gt_instances=None, loss_weights=None):
-        if self.training and gt_instances is not None:
-            raise RuntimeError("WSRPN training runs inside WeaklySupervisedRCNNNoMeta's fused step (explicit backward); "
-                               "call the meta-architecture, or use label_and_sample_anchors/losses/predict_proposals.")
+        if self.training:
+            # rpn.py:20-53 in training, as ONE autograd node over the RPN's explicit forward / backward (modeling/train_modules.py): losses
+            # when gt_instances are given (:41-46), proposals when images are (:48-52; PRE / POST_NMS_TOPK_TRAIN)
+            from .train_modules import rpn_forward_train
+            return rpn_forward_train(self, images, features, gt_instances)
         dtype = getattr(self, "compute_dtype", torch.bfloat16)
         self.rpn_head.prepare(dtype, 0)
         feat = features["res4"] if isinstance(features, dict) else features

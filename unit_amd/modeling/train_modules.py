@@ -1,0 +1,273 @@
+"""Training-mode forwards of the plug-in modules on their own -- for a meta-architecture OTHER than this package's fused step, e.g. the
+reference's own `WeaklySupervisedRCNNNoMeta.forward` (/root/reference/modeling/meta_arch/rcnn.py:433-491), which calls
+
+    features = self.backbone(images.tensor)                                              # :439 / :452
+    proposals, proposal_losses = self.proposal_generator(images, features, gt_instances) # :463  (weak images: under no_grad, gt None, :468)
+    _, detector_losses = self.roi_heads(images, features, proposals, gt_instances, weak_images=..., weak_features=..., weak_proposals=...,
+                                        weak_targets=...)                                # :480
+    sum(losses.values()).backward()                                                      # engine/defaults.py:280
+
+Each call is ONE torch.autograd.Function node over the same explicit forward / backward segments the fused step is made of (no tracing):
+the node's forward runs the HIP kernels and keeps the context, its backward runs the segment's explicit backward, ACCUMULATES the
+module's parameter gradients into `.grad` (torch semantics: zero_grad() between steps) and hands d(loss)/d(features) to autograd, which
+sums the RPN's and the ROI heads' contributions before the backbone's node runs. One HIP stream, no plan-level fusions (multi-tensor
+weight-gradient launches, stream overlap): the fused step stays the fast path, these are the drop-in surface. Supported: the VOC / COCO
+base-training heads without the mask branch (WSROIHeadNoMeta); fine-tune and mask heads train through the fused step only.
+
+Sampling follows the explicit-permutation contract of the fused step: a module draws its permutations from its own device counter unless
+`module.next_perm` (int32 [n_images, capacity]) is set, which is consumed once (tests)."""
+import torch
+
+from .. import ops
+from ..structures import Boxes, Instances
+
+
+def _pversion(module):
+    """changes whenever a parameter of the module was updated in place (any optimizer): the prepared weight copies follow it"""
+    return sum(int(p._version) for p in module.parameters())
+
+
+def _dtype(module):
+    return getattr(module, "compute_dtype", torch.bfloat16)
+
+
+class _direct_grads:
+    """weight gradients of the convs go straight into `.grad`, accumulating (not through the fused step's multi-tensor plan)"""
+
+    def __enter__(self):
+        self.prev = (ops.WGRAD_DIRECT, ops.WGRAD_ACCUMULATE, ops.WGRAD_STREAM)
+        ops.WGRAD_DIRECT, ops.WGRAD_ACCUMULATE, ops.WGRAD_STREAM = True, True, None
+        return self
+
+    def __exit__(self, *exc):
+        ops.WGRAD_DIRECT, ops.WGRAD_ACCUMULATE, ops.WGRAD_STREAM = self.prev
+        return False
+
+
+def _check_unit_weights(g, what):
+    if not bool(torch.all(g == 1.0)):
+        raise RuntimeError(f"{what}: backward() expects d(total)/d(loss_i) == 1 for every returned loss (sum(loss_dict.values()).backward(), "
+                           "engine/defaults.py:280); scaled / partial losses are not supported by the explicit backward")
+
+
+def _nhwc(f, dtype):
+    return ops.nchw_to_nhwc(f.detach().float().contiguous(), dtype=dtype)
+
+
+def _nchw32(t):
+    return ops.nhwc_to_nchw(ops.as_f32(t).contiguous())
+
+
+def _pack_gt(instances, dev, want_classes=True):
+    """list[Instances(gt_boxes[, gt_classes])] -> (boxes [n, cap, 4] fp32, classes int64 [n, cap], count int32 [n]) on the device"""
+    bs = [(i.gt_boxes.tensor if hasattr(i.gt_boxes, "tensor") else i.gt_boxes).float() for i in instances]
+    cap = (max([len(b) for b in bs] + [1]) + 7) // 8 * 8
+    boxes = torch.zeros((len(bs), cap, 4), dtype=torch.float32)
+    cls = torch.zeros((len(bs), cap), dtype=torch.int64)
+    for i, b in enumerate(bs):
+        boxes[i, :len(b)] = b.cpu()
+        if want_classes:
+            cls[i, :len(b)] = instances[i].gt_classes.cpu()
+    return boxes.to(dev), cls.to(dev), torch.tensor([len(b) for b in bs], dtype=torch.int32).to(dev)
+
+
+def _draw(module, n, cap, stream_id, dev):
+    perm = getattr(module, "next_perm", None)
+    if perm is not None:
+        module.next_perm = None
+        assert perm.shape[0] == n and perm.shape[1] >= cap, (perm.shape, n, cap)
+        return perm.to(dev).to(torch.int32).contiguous()
+    gen = module.__dict__.get("_perm_gen")
+    if gen is None or gen.device != dev:
+        gen = module.__dict__["_perm_gen"] = torch.zeros(1, dtype=torch.int64, device=dev)
+    out = ops.random_permutations(n, cap, int(getattr(module, "seed", 0)), gen, stream_id, dev)
+    ops.counter_bump(gen)
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ backbone
+class _BackboneFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, module):
+        dtype = _dtype(module)
+        module.prepare(dtype, _pversion(module))
+        y, bctx = module.fwd(ops.nchw_to_nhwc(x.detach().float().contiguous(), dtype=dtype, cpad=8), save=True)
+        ctx.module, ctx.bctx, ctx.y = module, bctx, y
+        return _nchw32(y)
+
+    @staticmethod
+    def backward(ctx, g):
+        m, y = ctx.module, ops.as_f32(ctx.y)
+        gh = ops.nchw_to_nhwc(g.contiguous().float(), dtype=torch.float32)
+        gm = ops.add_cast(gh, None, y.dtype, mask_ref=y)          # d / d(pre-ReLU output of res4) = g * (out > 0): what ResNet.bwd takes
+        with _direct_grads():
+            m.bwd(ctx.bctx, gm)
+        return None, None
+
+
+def backbone_forward_train(module, x):
+    return {"res4": _BackboneFn.apply(x, module)}
+
+
+# ------------------------------------------------------------------------------------------------ WSRPN (rpn.py:20-53)
+class _RpnFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, f, module, io):
+        dtype = _dtype(module)
+        module.rpn_head.prepare(dtype, _pversion(module.rpn_head))
+        feat = _nhwc(f, dtype)
+        n, h, w, _ = feat.shape
+        dev = feat.device
+        anchors = module.anchor_generator.grid(h, w)
+        gt = io["gt"]
+        head, rctx = module.rpn_head.fwd(feat, save=gt is not None)
+        losses = ops.zeros(2, torch.float32, dev)
+        ctx.module, ctx.n, ctx.rctx, ctx.dhead = module, n, rctx, None
+        if gt is not None:
+            gt_boxes, _, gt_count = _pack_gt(gt, dev, want_classes=False)
+            perm = _draw(module, n, anchors.shape[0], 0, dev)
+            labels, match, _ = module.label_and_sample_anchors(anchors, gt_boxes, gt_count, perm)
+            _, ctx.dhead = ops.rpn_loss(head, module.num_anchors, module.num_anchors, labels, match, gt_boxes, anchors,
+                                        module.batch_size_per_image * n, dtype, loss_out=losses)
+            io["anchor_labels"] = labels
+        if io["sizes"] is not None:
+            hw = torch.tensor(io["sizes"], dtype=torch.float32).to(dev)
+            io["proposals"] = module.predict_proposals(head, anchors, hw, True)
+        return losses
+
+    @staticmethod
+    def backward(ctx, gl):
+        if ctx.dhead is None:
+            return None, None, None
+        _check_unit_weights(gl, "WSRPN")
+        with _direct_grads():
+            drpn = ctx.module.rpn_head.bwd(ctx.rctx, ctx.dhead, ctx.n)
+        return _nchw32(drpn), None, None
+
+
+def rpn_forward_train(module, images, features, gt_instances):
+    f = features["res4"] if isinstance(features, dict) else features
+    io = {"gt": gt_instances, "sizes": list(images.image_sizes) if images is not None else None}
+    lv = _RpnFn.apply(f, module, io)
+    proposals = None
+    if images is not None:
+        boxes, scores, counts = io["proposals"]
+        proposals = [Instances(images.image_sizes[i], proposal_boxes=Boxes(boxes[i, :c]), objectness_logits=scores[i, :c])
+                     for i, c in enumerate(counts.tolist())]          # API boundary: python lists need the counts on the host
+    losses = {"loss_rpn_cls": lv[0], "loss_rpn_loc": lv[1]} if gt_instances is not None else {}
+    module._last_train_io = io          # (tests: anchor labels)
+    return proposals, losses
+
+
+# ------------------------------------------------------------------------------------------------ WSROIHeadNoMeta (roi_heads.py:496-591)
+HEAD_LOSSES = ["loss_cls", "loss_box_reg", "loss_im_cls", "loss_oicr_1", "loss_oicr_2", "loss_oicr_3"]
+
+
+class _HeadsFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, f, fw, rh, io):
+        from .inference import pack_proposal_instances
+        dtype = _dtype(rh)
+        rh.prepare(dtype, _pversion(rh))
+        bp = rh.box_predictor
+        wh = bp.weak_detector_head
+        feat = ops.as_f32(_nhwc(f, dtype))
+        dev = feat.device
+        n_sup = feat.shape[0]
+        has_weak = io["weak_proposals"] is not None
+        feat_w = ops.as_f32(_nhwc(fw, dtype)) if has_weak else None
+        n_weak = feat_w.shape[0] if has_weak else 0
+        s = rh.batch_size_per_image
+        sw = s // rh.weak_divisor
+        rs, rw = n_sup * s, n_weak * sw
+        props, pcount = pack_proposal_instances(io["proposals"], dev)
+        gt_boxes, gt_classes, gt_count = _pack_gt(io["targets"], dev)
+        given = getattr(rh, "next_perm", None)
+        if given is not None and given.shape[1] - gt_boxes.shape[1] > props.shape[1]:
+            # a caller-supplied permutation ranges over [proposal slots | GT slots] of the capacity it was drawn for (the fused step: POST_NMS_TOPK
+            # proposal slots): give the proposals that many slots so that the same indices mean the same candidates
+            pad = torch.zeros((props.shape[0], given.shape[1] - gt_boxes.shape[1], 4), dtype=torch.float32, device=dev)
+            pad[:, :props.shape[1]] = props
+            props = pad
+        perm = _draw(rh, n_sup, props.shape[1] + gt_boxes.shape[1], 1, dev)
+        rois = torch.empty((rs + rw, 5), dtype=torch.float32, device=dev)
+        _, roi_cls, roi_gt, _ = rh.label_and_sample_proposals(props, pcount, gt_boxes, gt_classes, gt_count, perm, rois_out=rois[:rs])
+        weak_valid = None
+        if has_weak:
+            wprops, wcount = pack_proposal_instances(io["weak_proposals"], dev)
+            _, weak_valid = rh.weak_rois(wprops, wcount, n_sup, rois_out=rois[rs:])
+        osz = rh.pool_out[0]
+        pooled = torch.empty((rs + rw, osz, osz, feat.shape[3]), dtype=feat.dtype, device=dev)
+        rh.pool(feat, rois[:rs], out=pooled[:rs])
+        if has_weak:
+            rh.pool(feat_w, rois[rs:], out=pooled[rs:], image_offset=n_sup)
+        multi = rh.weak_box_head is not None
+        box_trainable = any(p.requires_grad for p in rh.box_head.parameters())
+        if multi:
+            box_feat, box_ctx = rh.box_head.fwd(pooled[:rs], save=box_trainable)
+            wfeat_all, weak_ctx = rh.weak_box_head.fwd(pooled, save=has_weak)          # its supervised rows: the reference's no_grad evaluation
+            rows = slice(rs, rs + rw)
+        else:
+            wfeat_all, box_ctx = rh.box_head.fwd(pooled, save=box_trainable)
+            box_feat, weak_ctx, rows = wfeat_all[:rs], None, None
+        lin_sup = bp.group.fwd(box_feat)
+        lin_weak = wh.group.fwd(wfeat_all)
+        losses = ops.zeros(len(HEAD_LOSSES), torch.float32, dev)
+        dy_sup, _ = bp.sup_losses(lin_sup, lin_weak[:rs], roi_cls, rois[:rs], roi_gt, losses[0:2], dtype)
+        dy_weak = None
+        if has_weak:
+            multihot = torch.zeros((n_weak, rh.num_classes), dtype=torch.uint8)
+            for i, c in enumerate(io["weak_targets"]):
+                multihot[i, c.long().cpu()] = 1          # torch.unique(gt_classes) (weak_detector_fast_rcnn.py:203)
+            dy_weak = wh.fused_losses(lin_weak[rs:], rois[rs:], weak_valid, sw, n_weak, multihot.to(dev), losses[2:6], dtype)
+        io["rois"], io["roi_cls"] = rois, roi_cls
+        ctx.rh, ctx.geo = rh, (n_sup, n_weak, rs, rw, feat.shape, feat_w.shape if has_weak else None, multi, rows)
+        ctx.saved = (box_feat, wfeat_all, box_ctx, weak_ctx, dy_sup, dy_weak, rois)
+        return losses
+
+    @staticmethod
+    def backward(ctx, gl):
+        _check_unit_weights(gl, "WSROIHeadNoMeta")
+        rh = ctx.rh
+        bp, wh = rh.box_predictor, rh.box_predictor.weak_detector_head
+        n_sup, n_weak, rs, rw, fshape, fwshape, multi, rows = ctx.geo
+        box_feat, wfeat_all, box_ctx, weak_ctx, dy_sup, dy_weak, rois = ctx.saved
+        g = gw = None
+        with _direct_grads():
+            dbox = bp.group.bwd(box_feat, dy_sup, need_dx=True)
+            dweak = wh.group.bwd(wfeat_all[rs:], dy_weak, need_dx=True) if dy_weak is not None else None
+            if multi:
+                dpool_sup = rh.box_head.bwd(box_ctx, dbox) if box_ctx is not None else None
+                dpool_weak = rh.weak_box_head.bwd(weak_ctx, dweak, row_slice=rows) if dweak is not None else None
+            else:
+                dall = dbox if dweak is None else torch.cat([dbox, dweak], 0)
+                dpool = rh.box_head.bwd(box_ctx, dall)
+                dpool_sup, dpool_weak = dpool[:rs], (dpool[rs:] if rw > 0 else None)
+        dev = rois.device
+        if dpool_sup is not None:
+            g = torch.empty(fshape, dtype=torch.float32, device=dev)
+            rh.pool_bwd_gather(ops.as_f32(dpool_sup), n_sup, fshape[1], fshape[2], rois[:rs], g)
+        if dpool_weak is not None:
+            gw = torch.empty(fwshape, dtype=torch.float32, device=dev)
+            rh.pool_bwd_gather(ops.as_f32(dpool_weak), n_weak, fwshape[1], fwshape[2], rois[rs:], gw, image_offset=n_sup)
+        return (ops.nhwc_to_nchw(g) if g is not None else None), (ops.nhwc_to_nchw(gw) if gw is not None else None), None, None
+
+
+def roi_heads_forward_train(rh, features, proposals, targets, weak_features, weak_proposals, weak_targets):
+    if getattr(rh, "mask_head", None) is not None or getattr(rh, "finetune", False):
+        raise RuntimeError("module-level training forward: the mask / fine-tune ROI heads train through WeaklySupervisedRCNNNoMeta's fused step")
+    assert targets, "WSROIHeadNoMeta.forward in training needs targets (roi_heads.py:562)"
+    f = features["res4"] if isinstance(features, dict) else features
+    has_weak = weak_proposals is not None and weak_features is not None
+    fw = (weak_features["res4"] if isinstance(weak_features, dict) else weak_features) if has_weak else f.new_zeros(1)
+    io = {"proposals": proposals, "targets": targets, "weak_proposals": weak_proposals if has_weak else None, "weak_targets": weak_targets}
+    lv = _HeadsFn.apply(f, fw, rh, io)
+    names = HEAD_LOSSES if has_weak else HEAD_LOSSES[:2]
+    rh._last_train_io = io
+    s = rh.batch_size_per_image
+    sampled = []
+    for i, p in enumerate(proposals):          # the sampled proposals, as the reference returns them (roi_heads.py:588)
+        r = io["rois"][i * s:(i + 1) * s]
+        c = io["roi_cls"][i * s:(i + 1) * s]
+        sampled.append(Instances(p.image_size, proposal_boxes=Boxes(r[:, 1:]), gt_classes=c))
+    return sampled, {n: lv[HEAD_LOSSES.index(n)] for n in names}

@@ -267,6 +267,9 @@ BIG_TILE_VARIANT = int(__import__("os").environ.get("UNIT_BIG_VARIANT", "0"))
 WGRAD_STREAM = None
 # True while a SECOND backbone backward of the same step runs (ragged supervised / weak batches): weight gradients accumulate
 WGRAD_ACCUMULATE = False
+# True inside the module-level training backward (modeling/train_modules.py): conv weight gradients go straight into `.grad`, not through the
+# fused step's multi-tensor plan (slabs + bucket reductions)
+WGRAD_DIRECT = False
 
 # bench.py sets this to a dict to time every conv_igemm launch with HIP events on the launch stream (roofline evidence)
 PROFILER = None
