@@ -86,9 +86,18 @@ def _draw(module, n, cap, stream_id, dev):
 
 
 # ------------------------------------------------------------------------------------------------ backbone
+def _anchor(module, dev):
+    """a one-element leaf that requires grad: what makes a node whose only differentiable inputs are PARAMETERS (updated by the explicit
+    backward, not by autograd) part of the graph -- the backbone's images do not require grad (same device as WeaklySupervisedRCNNNoMeta._anchor)"""
+    a = module.__dict__.get("_train_anchor")
+    if a is None or a.device != dev:
+        a = module.__dict__["_train_anchor"] = torch.zeros(1, device=dev, requires_grad=True)
+    return a
+
+
 class _BackboneFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, module):
+    def forward(ctx, anchor, x, module):
         dtype = _dtype(module)
         module.prepare(dtype, _pversion(module))
         y, bctx = module.fwd(ops.nchw_to_nhwc(x.detach().float().contiguous(), dtype=dtype, cpad=8), save=True)
@@ -102,11 +111,11 @@ class _BackboneFn(torch.autograd.Function):
         gm = ops.add_cast(gh, None, y.dtype, mask_ref=y)          # d / d(pre-ReLU output of res4) = g * (out > 0): what ResNet.bwd takes
         with _direct_grads():
             m.bwd(ctx.bctx, gm)
-        return None, None
+        return torch.zeros(1, device=g.device), None, None
 
 
 def backbone_forward_train(module, x):
-    return {"res4": _BackboneFn.apply(x, module)}
+    return {"res4": _BackboneFn.apply(_anchor(module, x.device), x, module)}
 
 
 # ------------------------------------------------------------------------------------------------ WSRPN (rpn.py:20-53)
@@ -155,7 +164,8 @@ def rpn_forward_train(module, images, features, gt_instances):
         proposals = [Instances(images.image_sizes[i], proposal_boxes=Boxes(boxes[i, :c]), objectness_logits=scores[i, :c])
                      for i, c in enumerate(counts.tolist())]          # API boundary: python lists need the counts on the host
     losses = {"loss_rpn_cls": lv[0], "loss_rpn_loc": lv[1]} if gt_instances is not None else {}
-    module._last_train_io = io          # (tests: anchor labels)
+    if gt_instances is not None:
+        module._last_train_io = io          # (tests: anchor labels)
     return proposals, losses
 
 
