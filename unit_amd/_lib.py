@@ -64,7 +64,13 @@ def lib():
             fn.argtypes = argtypes
         if not os.environ.get("UNIT_HIP_LIB"):          # (an explicit override is a diagnostic build: whoever set it knows what it is)
             from .build import source_hash
-            have, want = l.unit_build_hash().decode(), source_hash()
+            have = l.unit_build_hash().decode()
+            try:
+                want = source_hash()
+            except OSError as e:          # the binary was shipped without its sources (an installed or trimmed copy): nothing to compare with
+                raise UnitLibError(
+                    f"cannot check {LIB_PATH} against its sources ({e}): ship unit_amd/csrc/ and include/unit_hip.h next to the library, or "
+                    "name the binary explicitly with UNIT_HIP_LIB (an explicit override is never checked)") from e
             if have != want:
                 raise UnitLibError(
                     f"{LIB_PATH} was built from other sources than the ones next to it (library stamp {have[:16]}, sources {want[:16]}): "

@@ -184,31 +184,85 @@ __device__ __forceinline__ unsigned epi_positive_bits(bf16x8 o) {
   return bits;
 }
 
+// Packed forms of a pass's tail (round 5; UNIT_EPI_SLIM): the eight outputs of a lane live as four dwords of two bf16 each.
+//   epi_cvt_pk   : two fp32 -> one dword, ONE v_cvt_pk_bf16_f32 (the C conversion of a single value costs one each plus a v_perm per pair)
+//   epi_relu_pk  : max(x, 0) of both halves as signed 16-bit integers (a bf16 is negative iff its int16 is; -0 -> +0). Rounding commutes
+//                  with max(., 0), so relu-after-rounding stores the same bits as rounding-after-relu. (A positive NaN stays a NaN where
+//                  v_max_f32 would have returned 0: a diverged model, and the loss is NaN either way.)
+//   epi_positive_bits_pk : (value > 0) of the eight halves = (int16 > 0): clamp to [0, 1] per half, then fold the four dwords into a byte.
+// Spelled in inline assembly: hipcc's short-vector min / max folding produced wrong bits in round 4 (see epi_positive_bits above).
+__device__ __forceinline__ unsigned epi_cvt_pk(float a, float b) {
+  unsigned r;
+  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ unsigned epi_relu_pk(unsigned w) {
+  unsigned r;
+  asm("v_pk_max_i16 %0, %1, 0" : "=v"(r) : "v"(w));
+  return r;
+}
+__device__ __forceinline__ unsigned epi_positive_bits_pk(u32x4 w, bool nonneg) {
+  unsigned t[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    unsigned x = w[i];
+    if (!nonneg) asm("v_pk_max_i16 %0, %1, 0" : "=v"(x) : "v"(x));
+    asm("v_pk_min_u16 %0, %1, %2" : "=v"(t[i]) : "v"(x), "v"(0x00010001u));      // 0 / 1 per half: bit 0 = element 2i, bit 16 = element 2i + 1
+  }
+  unsigned r = t[0] | (t[1] << 2) | (t[2] << 4) | (t[3] << 6);
+  return (r | (r >> 15)) & 0xffu;
+}
+typedef __attribute__((ext_vector_type(2))) float epi_f32x2;
+__device__ __forceinline__ float epi_lo(unsigned w) { return __builtin_bit_cast(float, w << 16); }
+__device__ __forceinline__ float epi_hi(unsigned w) { return __builtin_bit_cast(float, w & 0xffff0000u); }
+
+// Compile-time knowledge of a launch's epilogue switches: FL >= 0 names exactly which of them are on (the hot Res5 / RPN combinations get
+// straight-line passes the compiler can schedule across: the dynamic form branches six times per 8-row pass), FL = -1 reads them from
+// the arguments as before. Same values either way.
+// EPI_FULL: every row and channel of the wave tile exists (no bounds tests, no exec masks around the loads and stores).
+enum { EPI_RES = 1, EPI_RELU = 2, EPI_MK = 4, EPI_MB = 8, EPI_RB = 16, EPI_PP = 32, EPI_Y = 64, EPI_BIAS = 128, EPI_FULL = 256 };
+template <typename Args>
+__device__ __forceinline__ int epi_flags(const Args& p, bool ex) {
+  int f = (p.residual ? EPI_RES : 0) | (p.relu ? EPI_RELU : 0) | (p.y ? EPI_Y : 0) | (p.bias ? EPI_BIAS : 0);
+  if (ex) f |= (p.ex.mask_bits ? EPI_MB : 0) | (p.ex.relu_bits ? EPI_RB : 0) | (p.ex.pool_partial ? EPI_PP : 0);
+  else f |= p.mask_ref ? EPI_MK : 0;
+  return f;
+}
+
 // SPL (bf16x3 "split" tensors, split.hip): y and the residual are [row][2][ldy] bf16 -- plane 0 = bf16(v), plane 1 = bf16(v - plane 0),
 // 4 bytes per element like fp32 -- and mask_ref is a split tensor of p.mask_pitch elements per row whose plane 0 carries the sign.
-template <int FA, int FB, bool EX, int RB, bool PM = false, bool SPL = false, typename Put, typename Args>
+template <int FA, int FB, bool EX, int RB, bool PM = false, bool SPL = false, int FL = -1, typename Put, typename Args>
 __device__ __forceinline__ void epilogue_rows_bf16_blocks(Put put_block, char* scr, float* pool, int m_w, int n_w, const Args& p, int lane, const PmRows* rows = nullptr,
                                                           unsigned long long* stamp = nullptr) {
   typedef EpiCfg<FA, RB> E;
   static_assert(!(EX && SPL), "the fused pool / bit-mask epilogue has no split form");
+  static_assert(FL < 0 || !SPL, "split outputs: dynamic switches only");
   constexpr int NBLK = FB * 16 / RB;
   bf16_t* __restrict__ Y = (bf16_t*)p.y;
-  const bf16_t* __restrict__ Rz = (const bf16_t*)p.residual;
-  const bf16_t* __restrict__ Mk = EX ? nullptr : (const bf16_t*)p.mask_ref;
+  const bf16_t* __restrict__ Rz = (FL >= 0 && !(FL & EPI_RES)) ? nullptr : (const bf16_t*)p.residual;
+  const bf16_t* __restrict__ Mk = (EX || (FL >= 0 && !(FL & EPI_MK))) ? nullptr : (const bf16_t*)p.mask_ref;
+  const bool has_res = FL >= 0 ? (FL & EPI_RES) != 0 : Rz != nullptr;
+  const bool has_mk = FL >= 0 ? (!EX && (FL & EPI_MK) != 0) : Mk != nullptr;
+  const bool do_relu = FL >= 0 ? (FL & EPI_RELU) != 0 : p.relu != 0;
+  const bool has_y = FL >= 0 ? (FL & EPI_Y) != 0 : Y != nullptr;
+  constexpr bool FULLT = FL >= 0 && (FL & EPI_FULL) != 0;
+  static_assert(!(FULLT && PM), "position-class tiles carry their own row validity");
   const bool plain = EX || (p.oy_mul == 1 && p.OHf == p.OH && p.OWf == p.OW);
   const long pitch = SPL ? 2L * p.ldy : (long)p.ldy;           // elements per output (and residual) row
   long mpitch = pitch;                                         // ... per mask_ref row
   if constexpr (SPL) mpitch = p.mask_pitch;
   const int rr = lane / E::LPR, c0 = (lane % E::LPR) * 8;
   const int n = n_w + c0;
-  const bool n_ok = n < p.ldy;
+  const bool n_ok = FULLT || n < p.ldy;
   float bias8[8];
 #pragma unroll
-  for (int j = 0; j < 8; ++j) bias8[j] = (p.bias && n + j < p.K) ? p.bias[n + j] : 0.f;
+  for (int j = 0; j < 8; ++j) bias8[j] = ((FL < 0 || (FL & EPI_BIAS)) && p.bias && (FULLT || n + j < p.K)) ? p.bias[n + j] : 0.f;
+  const bool has_bias = FL >= 0 ? (FL & EPI_BIAS) != 0 : p.bias != nullptr;      // (the accumulators start at +0: no -0 that "+ 0.f" would have had to turn)
 
   const unsigned char* __restrict__ Mb = nullptr;
   unsigned char* __restrict__ Rb = nullptr;
   float* __restrict__ Pp = nullptr;
+  bool has_mb = false, has_rb = false, has_pp = false;
   int prow = 1, roi0 = 0, cur_roi = 0, nxt_edge = 0;
   long bword = 0;
   u32x4 mw = {0u, 0u, 0u, 0u}, rw = {0u, 0u, 0u, 0u};
@@ -216,10 +270,16 @@ __device__ __forceinline__ void epilogue_rows_bf16_blocks(Put put_block, char* s
   if constexpr (EX) {
     static_assert(FA == 4, "pooling epilogue: 64-channel wave tiles");
     static_assert(FB <= 8 && E::RPP == 8, "bit words: 16 row passes of 8 rows per wave tile");
-    Mb = p.ex.mask_bits; Rb = p.ex.relu_bits; Pp = p.ex.pool_partial; prow = p.ex.pool_rows > 0 ? p.ex.pool_rows : 1;
+    Mb = (FL >= 0 && !(FL & EPI_MB)) ? nullptr : p.ex.mask_bits;
+    Rb = (FL >= 0 && !(FL & EPI_RB)) ? nullptr : p.ex.relu_bits;
+    Pp = (FL >= 0 && !(FL & EPI_PP)) ? nullptr : p.ex.pool_partial;
+    prow = p.ex.pool_rows > 0 ? p.ex.pool_rows : 1;
+    has_mb = FL >= 0 ? (FL & EPI_MB) != 0 : Mb != nullptr;
+    has_rb = FL >= 0 ? (FL & EPI_RB) != 0 : Rb != nullptr;
+    has_pp = FL >= 0 ? (FL & EPI_PP) != 0 : Pp != nullptr;
     bword = (((long)(m_w >> 7)) * (p.ldy >> 6) + (n_w >> 6)) * 64 + lane;          // this lane's word of the wave tile (m_w % 128 == 0)
-    if (Mb && n_ok && m_w < p.M) mw = reinterpret_cast<const u32x4*>(Mb)[bword];
-    if (Pp) {
+    if (has_mb && n_ok && m_w < p.M) mw = reinterpret_cast<const u32x4*>(Mb)[bword];
+    if (has_pp) {
       f32x4 z = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int i = 0; i < 8; ++i) *reinterpret_cast<f32x4*>(pool + (i * 64 + lane) * 4) = z;      // 4 x 8 x 64 floats
@@ -242,7 +302,7 @@ __device__ __forceinline__ void epilogue_rows_bf16_blocks(Put put_block, char* s
 #pragma unroll
     for (int h = 0; h < E::NP; ++h) {
       int m = m_w + b * RB + h * E::RPP + rr;
-      q.ok[h] = n_ok && m < p.M;
+      q.ok[h] = FULLT || (n_ok && m < p.M);
       int mm = q.ok[h] ? m : 0;
       if constexpr (PM) {
         int img, oh, ow;
@@ -260,12 +320,12 @@ __device__ __forceinline__ void epilogue_rows_bf16_blocks(Put put_block, char* s
         q.off[h] = orow * pitch + n;
         if constexpr (SPL) q.moff[h] = orow * mpitch + n;
       }
-      if (Rz && q.ok[h]) q.res[h] = epi_load8(Rz + q.off[h]);
+      if (has_res && q.ok[h]) q.res[h] = epi_load8(Rz + q.off[h]);
       if constexpr (SPL) {
-        if (Rz && q.ok[h]) q.res2[h] = epi_load8(Rz + q.off[h] + p.ldy);
-        if (Mk && q.ok[h]) q.msk[h] = epi_load8(Mk + q.moff[h]);
+        if (has_res && q.ok[h]) q.res2[h] = epi_load8(Rz + q.off[h] + p.ldy);
+        if (has_mk && q.ok[h]) q.msk[h] = epi_load8(Mk + q.moff[h]);
       } else {
-        if (Mk && q.ok[h]) q.msk[h] = epi_load8(Mk + q.off[h]);
+        if (has_mk && q.ok[h]) q.msk[h] = epi_load8(Mk + q.off[h]);
       }
     }
   };
@@ -283,41 +343,64 @@ __device__ __forceinline__ void epilogue_rows_bf16_blocks(Put put_block, char* s
       int r = h * E::RPP + rr;
       f32x4 v0 = *reinterpret_cast<const f32x4*>(scr + r * E::PITCH + c0 * 4);
       f32x4 v1 = *reinterpret_cast<const f32x4*>(scr + r * E::PITCH + c0 * 4 + 16);
-      float v[8] = {v0[0] + bias8[0], v0[1] + bias8[1], v0[2] + bias8[2], v0[3] + bias8[3],
-                    v1[0] + bias8[4], v1[1] + bias8[5], v1[2] + bias8[6], v1[3] + bias8[7]};
-      if (Rz) {
-        if constexpr (SPL) {
+      // (acc + bias) + residual as packed fp32 pairs (v_pk_add_f32: two adds per instruction)
+      epi_f32x2 t2[4] = {{v0[0], v0[1]}, {v0[2], v0[3]}, {v1[0], v1[1]}, {v1[2], v1[3]}};
+      if (has_bias) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) t2[i] += epi_f32x2{bias8[2 * i], bias8[2 * i + 1]};
+      }
+      if (has_res && !SPL) {
+        const u32x4 rz = __builtin_bit_cast(u32x4, cur.res[h]);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) t2[i] += epi_f32x2{epi_lo(rz[i]), epi_hi(rz[i])};
+      }
+      float v[8] = {t2[0][0], t2[0][1], t2[1][0], t2[1][1], t2[2][0], t2[2][1], t2[3][0], t2[3][1]};
+      if constexpr (SPL) {
+        if (has_res) {
 #pragma unroll
           for (int j = 0; j < 8; ++j) v[j] += (float)cur.res[h][j] + (float)cur.res2[h][j];      // (hi + lo is exact in fp32)
-        } else {
-#pragma unroll
-          for (int j = 0; j < 8; ++j) v[j] += (float)cur.res[h][j];
         }
       }
-      if (p.relu) {
+      // max(., 0) commutes with the rounding: where nothing sits between them it runs on the packed result (4 instructions instead of 8)
+      const bool relu_packed = UNIT_EPI_SLIM && !SPL && do_relu && !has_mk && !has_mb;
+      if (do_relu && !relu_packed) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] = epi_relu(v[j]);
       }
-      if (Mk) {
+      if (has_mk) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] = (float)cur.msk[h][j] > 0.f ? v[j] : 0.f;
       }
       if constexpr (EX) {
-        if (Mb) {
+        if (has_mb) {
           unsigned mbits = mw[(b * E::NP + h) >> 2] >> (((b * E::NP + h) & 3) * 8);
 #pragma unroll
           for (int j = 0; j < 8; ++j) v[j] = epi_keep_if_bit(v[j], mbits, j);
         }
       }
+#if UNIT_EPI_SLIM
+      u32x4 ow;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        ow[i] = epi_cvt_pk(v[2 * i], v[2 * i + 1]);
+        if (relu_packed) ow[i] = epi_relu_pk(ow[i]);
+      }
+      const bf16x8 o = __builtin_bit_cast(bf16x8, ow);
+#else
       bf16x8 o;
 #pragma unroll
       for (int j = 0; j < 8; ++j) o[j] = (bf16_t)v[j];
+#endif
       if constexpr (EX) {
-        if (Rb && cur.ok[h]) {
-          unsigned bits = epi_positive_bits(o);      // of the stored (rounded) value, as a mask_ref read would see it
+        if (has_rb && cur.ok[h]) {
+#if UNIT_EPI_SLIM
+          unsigned bits = epi_positive_bits_pk(ow, do_relu);      // of the stored (rounded) value, as a mask_ref read would see it
+#else
+          unsigned bits = epi_positive_bits(o);
+#endif
           rw[(b * E::NP + h) >> 2] |= bits << (((b * E::NP + h) & 3) * 8);
         }
-        if (Pp && cur.ok[h]) {
+        if (has_pp && cur.ok[h]) {
           int m = m_w + b * RB + r;
           if (m >= nxt_edge) {                     // this lane's rows entered the next RoI (rows only grow: at most 3 times)
             flush();
@@ -325,10 +408,15 @@ __device__ __forceinline__ void epilogue_rows_bf16_blocks(Put put_block, char* s
 #pragma unroll
             for (int j = 0; j < 8; ++j) run[j] = 0.f;
           }
+#if UNIT_EPI_SLIM
+#pragma unroll
+          for (int i = 0; i < 4; ++i) { run[2 * i] += epi_lo(ow[i]); run[2 * i + 1] += epi_hi(ow[i]); }
+#else
 #pragma unroll
           for (int j = 0; j < 8; ++j) run[j] += (float)o[j];
+#endif
         }
-        if (Y && cur.ok[h]) epi_store8(Y + cur.off[h], o);
+        if (has_y && cur.ok[h]) epi_store8(Y + cur.off[h], o);
       } else if constexpr (SPL) {
         bf16x8 o2;
 #pragma unroll
@@ -342,8 +430,8 @@ __device__ __forceinline__ void epilogue_rows_bf16_blocks(Put put_block, char* s
     EPI_STAMP(1 + b);
   }
   if constexpr (EX) {
-    if (Rb && n_ok && m_w < p.M) reinterpret_cast<u32x4*>(Rb)[bword] = rw;      // (a wave tile past the last row owns no word)
-    if (Pp) {
+    if (has_rb && n_ok && m_w < p.M) reinterpret_cast<u32x4*>(Rb)[bword] = rw;      // (a wave tile past the last row owns no word)
+    if (has_pp) {
       if (n_ok && m_w + rr < p.M) flush();
       // row classes -> one sum per (segment, channel), fixed order; lane = channel of the wave tile
       int last_row = m_w + FB * 16 - 1; if (last_row >= p.M) last_row = p.M - 1;
@@ -362,7 +450,7 @@ __device__ __forceinline__ void epilogue_rows_bf16_blocks(Put put_block, char* s
 }
 
 // 16x16 MFMA accumulators: acc[a][b] = 16x16 tile (channels a*16.., pixel rows b*16..); lane holds 4 consecutive channels of row lane & 15
-template <int FA, int FB, bool EX, bool PM = false, bool SPL = false, typename Args>
+template <int FA, int FB, bool EX, bool PM = false, bool SPL = false, int FL = -1, typename Args>
 __device__ __forceinline__ void epilogue_rows_bf16_impl(const f32x4 (&acc)[FA][FB], char* scr, float* pool, int m_w, int n_w, const Args& p, int lane,
                                                         const PmRows* rows = nullptr, unsigned long long* stamp = nullptr) {
   typedef EpiCfg<FA, 16> E;
@@ -372,7 +460,21 @@ __device__ __forceinline__ void epilogue_rows_bf16_impl(const f32x4 (&acc)[FA][F
     for (int a = 0; a < FA; ++a)
       *reinterpret_cast<f32x4*>(sc + frow * E::PITCH + (a * 16 + fq * 4) * 4) = acc[a][b];
   };
-  epilogue_rows_bf16_blocks<FA, FB, EX, 16, PM, SPL>(put, scr, pool, m_w, n_w, p, lane, rows, stamp);
+  epilogue_rows_bf16_blocks<FA, FB, EX, 16, PM, SPL, FL>(put, scr, pool, m_w, n_w, p, lane, rows, stamp);
+}
+
+// the switch combinations named in FLS... run their straight-line instantiation, anything else the dynamic form
+template <int FA, int FB, bool EX, bool PM, int... FLS, typename Args>
+__device__ __forceinline__ void epilogue_rows_bf16_dispatch(const f32x4 (&acc)[FA][FB], char* scr, float* pool, int m_w, int n_w, const Args& p, int lane,
+                                                            const PmRows* rows = nullptr, unsigned long long* stamp = nullptr) {
+#if UNIT_EPI_SLIM
+  int fl = epi_flags(p, EX);
+  if (!PM && m_w + FB * 16 <= p.M && n_w + FA * 16 <= p.K && n_w + FA * 16 <= p.ldy) fl |= EPI_FULL;
+  bool done = false;
+  (void)((fl == FLS ? (epilogue_rows_bf16_impl<FA, FB, EX, PM, false, FLS>(acc, scr, pool, m_w, n_w, p, lane, rows, stamp), done = true) : false) || ...);
+  if (done) return;
+#endif
+  epilogue_rows_bf16_impl<FA, FB, EX, PM, false, -1>(acc, scr, pool, m_w, n_w, p, lane, rows, stamp);
 }
 
 template <int FA, int FB, bool SPL = false, typename Args>

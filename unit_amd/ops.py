@@ -10,7 +10,7 @@ import math
 
 import torch
 
-from ._lib import check, lib
+from ._lib import _DEBUG_SYNC, check, lib
 
 F32, BF16 = 0, 1
 SCALE_CLAMP = math.log(1000.0 / 16)  # Box2BoxTransform scale_clamp (detectron2 default)
@@ -415,6 +415,24 @@ def conv_out_size(h, w, r, s, stride, pad):
 _POLICY_CACHE = {}
 
 
+_POLICY_SIG = {}
+
+
+def _policy_takes_allow_lc(fn):
+    """does this tile policy accept the `allow_lc` keyword? Looked at once per policy object (a TypeError raised INSIDE a policy must
+    surface, not be mistaken for the old five-argument signature)."""
+    r = _POLICY_SIG.get(fn)
+    if r is None:
+        import inspect
+        try:
+            ps = inspect.signature(fn).parameters
+            r = "allow_lc" in ps or any(q.kind is inspect.Parameter.VAR_KEYWORD for q in ps.values())
+        except (TypeError, ValueError):
+            r = True
+        _POLICY_SIG[fn] = r
+    return r
+
+
 def conv2d(x, w, k, r, s, stride=1, pad=0, bias=None, residual=None, mask_ref=None, relu=False, out_dtype=None,
            out=None, ldy=None, scatter=None, tile_cfg=0):
     """x [N,H,W,C] NHWC ; w [k][r][s][C] (same dtype). Returns y [N,OH,OW,ldy] (or writes the strided scatter target).
@@ -456,9 +474,9 @@ def conv2d(x, w, k, r, s, stride=1, pad=0, bias=None, residual=None, mask_ref=No
         mid = {19: 4, 20: 5}.get(tile_cfg, tile_cfg - 7)
     elif tile_cfg == 0 and not big:
         lc_ok = out_dtype == torch.bfloat16 and ldy % 8 == 0        # the loader / consumer kernel writes bf16 rows of 16-byte vectors
-        try:
+        if _policy_takes_allow_lc(MID_TILE_POLICY):
             mid = MID_TILE_POLICY(x.dtype, n * oh * ow, k, c, r * s * c, allow_lc=lc_ok)
-        except TypeError:          # a user-supplied policy with the five-argument signature
+        else:                      # a user-supplied policy with the five-argument signature
             mid = MID_TILE_POLICY(x.dtype, n * oh * ow, k, c, r * s * c)
         if mid >= 100 and not lc_ok:          # ... that asked for the loader / consumer kernel anyway: the best 4-wave tile instead
             tiles = ((n * oh * ow + 127) // 128) * ((k + 127) // 128)
@@ -1386,11 +1404,18 @@ def _loss_acc(device):
     a = _LOSS_ACC.get(key)
     if a is None:
         a = _LOSS_ACC[key] = zeros(2, torch.int32, device)
+    elif _DEBUG_SYNC:          # diagnostic runs follow faults: a loss kernel that was aborted mid-ticket left its count behind
+        check(lib().unit_fill_zero(_p(a), a.numel() * a.element_size(), _s()), "fill_zero")
     return a
 
 
 def softmax_ce(logits, col0, ncls, labels, weights=None, dy=None, dcol0=0, gscale=1.0, loss_out=None):
+    """weights: per-row, NON-NEGATIVE (the reference's are OICR pseudo-label scores, weak_detector_fast_rcnn.py:198-226): with more than 256
+    rows the per-workgroup partial sums travel as unsigned fixed point (csrc/losses.hip packed_sum_finish), where a negative, NaN or
+    >= 2^23 partial is reported as a NaN loss -- checked here under UNIT_DEBUG_SYNC=1"""
     r, ld = logits.shape
+    if _DEBUG_SYNC and weights is not None and weights.numel():
+        assert float(weights.min()) >= 0.0, "softmax_ce: negative row weights"
     loss = loss_out if loss_out is not None else torch.empty(1, dtype=torch.float32, device=logits.device)
     check(lib().unit_softmax_ce(_p(logits), ld, col0, ncls, _p(labels), _p(weights), r, float(gscale), _p(loss), _p(dy),
                                 dt(dy.dtype) if dy is not None else 0, dy.shape[1] if dy is not None else 0, dcol0, _p(_loss_acc(logits.device)),
