@@ -33,6 +33,8 @@ x = torch.randn(1024, 7, 7, 512, device=dev).bfloat16(); w = (torch.randn(2048, 
 res = torch.randn(1024, 7, 7, 2048, device=dev).bfloat16()
 run("512->2048 +res +relu", lambda: o.conv2d(x, w, 2048, 1, 1, 1, 0, residual=res, relu=True, tile_cfg=16))
 run("512->2048 plain", lambda: o.conv2d(x, w, 2048, 1, 1, 1, 0, relu=True, tile_cfg=16))
+b = torch.randn(2048, device=dev)
+run("512->2048 +bias +relu (straight-line passes, round 5)", lambda: o.conv2d(x, w, 2048, 1, 1, 1, 0, bias=b, relu=True, tile_cfg=16))
 x3 = torch.randn(1024, 7, 7, 512, device=dev).bfloat16(); w3 = (torch.randn(512, 3, 3, 512, device=dev) * 0.05).bfloat16()
 run("3x3 512->512 row-major tiles", lambda: o.conv2d(x3, w3, 512, 3, 3, 1, 1, relu=True, tile_cfg=22))
 PY

@@ -221,10 +221,10 @@ __device__ __forceinline__ float epi_hi(unsigned w) { return __builtin_bit_cast(
 // the arguments as before. Same values either way.
 // EPI_FULL: every row and channel of the wave tile exists (no bounds tests, no exec masks around the loads and stores).
 enum { EPI_RES = 1, EPI_RELU = 2, EPI_MK = 4, EPI_MB = 8, EPI_RB = 16, EPI_PP = 32, EPI_Y = 64, EPI_BIAS = 128, EPI_FULL = 256 };
-template <typename Args>
-__device__ __forceinline__ int epi_flags(const Args& p, bool ex) {
+template <bool EX, typename Args>
+__device__ __forceinline__ int epi_flags(const Args& p) {
   int f = (p.residual ? EPI_RES : 0) | (p.relu ? EPI_RELU : 0) | (p.y ? EPI_Y : 0) | (p.bias ? EPI_BIAS : 0);
-  if (ex) f |= (p.ex.mask_bits ? EPI_MB : 0) | (p.ex.relu_bits ? EPI_RB : 0) | (p.ex.pool_partial ? EPI_PP : 0);
+  if constexpr (EX) f |= (p.ex.mask_bits ? EPI_MB : 0) | (p.ex.relu_bits ? EPI_RB : 0) | (p.ex.pool_partial ? EPI_PP : 0);
   else f |= p.mask_ref ? EPI_MK : 0;
   return f;
 }
@@ -468,7 +468,7 @@ template <int FA, int FB, bool EX, bool PM, int... FLS, typename Args>
 __device__ __forceinline__ void epilogue_rows_bf16_dispatch(const f32x4 (&acc)[FA][FB], char* scr, float* pool, int m_w, int n_w, const Args& p, int lane,
                                                             const PmRows* rows = nullptr, unsigned long long* stamp = nullptr) {
 #if UNIT_EPI_SLIM
-  int fl = epi_flags(p, EX);
+  int fl = epi_flags<EX>(p);
   if (!PM && m_w + FB * 16 <= p.M && n_w + FA * 16 <= p.K && n_w + FA * 16 <= p.ldy) fl |= EPI_FULL;
   bool done = false;
   (void)((fl == FLS ? (epilogue_rows_bf16_impl<FA, FB, EX, PM, false, FLS>(acc, scr, pool, m_w, n_w, p, lane, rows, stamp), done = true) : false) || ...);
@@ -480,6 +480,16 @@ __device__ __forceinline__ void epilogue_rows_bf16_dispatch(const f32x4 (&acc)[F
 template <int FA, int FB, bool SPL = false, typename Args>
 __device__ __forceinline__ void epilogue_rows_bf16(const f32x4 (&acc)[FA][FB], char* scr, int m_w, int n_w, const Args& p, int lane) {
   epilogue_rows_bf16_impl<FA, FB, false, false, SPL>(acc, scr, nullptr, m_w, n_w, p, lane);
+}
+
+// the same with straight-line passes for the backbone's combinations on whole tiles (conv_igemm128.hip, conv_igemm_lc.hip): conv + folded
+// FrozenBN (+ shortcut) + ReLU forward, dgrad with the ReLU mask of the layer input (+ the shortcut's gradient)
+template <int FA, int FB, bool SPL = false, typename Args>
+__device__ __forceinline__ void epilogue_rows_bf16_fast(const f32x4 (&acc)[FA][FB], char* scr, int m_w, int n_w, const Args& p, int lane) {
+  if constexpr (SPL) epilogue_rows_bf16_impl<FA, FB, false, false, true>(acc, scr, nullptr, m_w, n_w, p, lane);
+  else epilogue_rows_bf16_dispatch<FA, FB, false, false, EPI_FULL | EPI_BIAS | EPI_RELU | EPI_Y, EPI_FULL | EPI_BIAS | EPI_RES | EPI_RELU | EPI_Y,
+                                   EPI_FULL | EPI_BIAS | EPI_Y, EPI_FULL | EPI_MK | EPI_Y, EPI_FULL | EPI_RES | EPI_MK | EPI_Y, EPI_FULL | EPI_Y>(
+      acc, scr, nullptr, m_w, n_w, p, lane);
 }
 
 // 32x32 MFMA accumulators (v_mfma_f32_32x32x16_bf16, A = channels, B = pixels): acc[a][b] = 32 channels a*32.. x 32 pixel rows

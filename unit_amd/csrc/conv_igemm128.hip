@@ -192,7 +192,7 @@ __global__ void __launch_bounds__(256, 2) conv_igemm_dma_kernel(ConvDmaArgs p) {
   if constexpr (sizeof(TO) == 2) {
     if ((p.ldy & 7) == 0) {          // row-major epilogue through a wave-private LDS scratch (conv_epilogue.h)
       __syncthreads();               // every wave is done with the operand stages
-      epilogue_rows_bf16<FA, FB, X3>(acc, smem + wid * EpiCfg<FA>::BYTES, m0 + wm * WMT, n0 + wn * WNT, p, lane);
+      epilogue_rows_bf16_fast<FA, FB, X3>(acc, smem + wid * EpiCfg<FA>::BYTES, m0 + wm * WMT, n0 + wn * WNT, p, lane);
       return;
     }
   }

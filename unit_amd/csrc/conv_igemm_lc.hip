@@ -241,9 +241,9 @@ __global__ void __launch_bounds__((4 + NL) * 64) conv_igemm_lc_kernel(ConvDmaArg
     if (PAIR && second) {          // the second problem's output / residual / mask tensors and sizes
       ConvDmaArgs q = p;
       pair_swap_common(q);
-      epilogue_rows_bf16<FA, FB, X3>(acc, scr, tile_m * BM, tile_n * BN + c * FA * 16, q, lane);
+      epilogue_rows_bf16_fast<FA, FB, X3>(acc, scr, tile_m * BM, tile_n * BN + c * FA * 16, q, lane);
     } else
-    epilogue_rows_bf16<FA, FB, X3>(acc, scr, tile_m * BM, tile_n * BN + c * FA * 16, p, lane);
+    epilogue_rows_bf16_fast<FA, FB, X3>(acc, scr, tile_m * BM, tile_n * BN + c * FA * 16, p, lane);
   }
 }
 
