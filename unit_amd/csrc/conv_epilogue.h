@@ -236,7 +236,6 @@ __device__ __forceinline__ void epilogue_rows_bf16_blocks(Put put_block, char* s
                                                           unsigned long long* stamp = nullptr) {
   typedef EpiCfg<FA, RB> E;
   static_assert(!(EX && SPL), "the fused pool / bit-mask epilogue has no split form");
-  static_assert(FL < 0 || !SPL, "split outputs: dynamic switches only");
   constexpr int NBLK = FB * 16 / RB;
   bf16_t* __restrict__ Y = (bf16_t*)p.y;
   const bf16_t* __restrict__ Rz = (FL >= 0 && !(FL & EPI_RES)) ? nullptr : (const bf16_t*)p.residual;
@@ -354,13 +353,15 @@ __device__ __forceinline__ void epilogue_rows_bf16_blocks(Put put_block, char* s
 #pragma unroll
         for (int i = 0; i < 4; ++i) t2[i] += epi_f32x2{epi_lo(rz[i]), epi_hi(rz[i])};
       }
-      float v[8] = {t2[0][0], t2[0][1], t2[1][0], t2[1][1], t2[2][0], t2[2][1], t2[3][0], t2[3][1]};
       if constexpr (SPL) {
         if (has_res) {
+          const u32x4 rz = __builtin_bit_cast(u32x4, cur.res[h]), rz2 = __builtin_bit_cast(u32x4, cur.res2[h]);
 #pragma unroll
-          for (int j = 0; j < 8; ++j) v[j] += (float)cur.res[h][j] + (float)cur.res2[h][j];      // (hi + lo is exact in fp32)
+          for (int i = 0; i < 4; ++i)      // (hi + lo is exact in fp32)
+            t2[i] += epi_f32x2{epi_lo(rz[i]), epi_hi(rz[i])} + epi_f32x2{epi_lo(rz2[i]), epi_hi(rz2[i])};
         }
       }
+      float v[8] = {t2[0][0], t2[0][1], t2[1][0], t2[1][1], t2[2][0], t2[2][1], t2[3][0], t2[3][1]};
       // max(., 0) commutes with the rounding: where nothing sits between them it runs on the packed result (4 instructions instead of 8)
       const bool relu_packed = UNIT_EPI_SLIM && !SPL && do_relu && !has_mk && !has_mb;
       if (do_relu && !relu_packed) {
@@ -418,9 +419,16 @@ __device__ __forceinline__ void epilogue_rows_bf16_blocks(Put put_block, char* s
         }
         if (has_y && cur.ok[h]) epi_store8(Y + cur.off[h], o);
       } else if constexpr (SPL) {
+#if UNIT_EPI_SLIM
+        u32x4 ow2;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) ow2[i] = epi_cvt_pk(v[2 * i] - epi_lo(ow[i]), v[2 * i + 1] - epi_hi(ow[i]));
+        const bf16x8 o2 = __builtin_bit_cast(bf16x8, ow2);
+#else
         bf16x8 o2;
 #pragma unroll
         for (int j = 0; j < 8; ++j) o2[j] = (bf16_t)(v[j] - (float)o[j]);
+#endif
         if (cur.ok[h]) { epi_store8(Y + cur.off[h], o); epi_store8(Y + cur.off[h] + p.ldy, o2); }
       } else {
         if (cur.ok[h]) epi_store8(Y + cur.off[h], o);
@@ -464,17 +472,18 @@ __device__ __forceinline__ void epilogue_rows_bf16_impl(const f32x4 (&acc)[FA][F
 }
 
 // the switch combinations named in FLS... run their straight-line instantiation, anything else the dynamic form
-template <int FA, int FB, bool EX, bool PM, int... FLS, typename Args>
+template <int FA, int FB, bool EX, bool PM, bool SPL, int... FLS, typename Args>
 __device__ __forceinline__ void epilogue_rows_bf16_dispatch(const f32x4 (&acc)[FA][FB], char* scr, float* pool, int m_w, int n_w, const Args& p, int lane,
                                                             const PmRows* rows = nullptr, unsigned long long* stamp = nullptr) {
 #if UNIT_EPI_SLIM
-  int fl = epi_flags<EX>(p);
+  int fl = SPL ? -2 : epi_flags<EX>(p);          // (split outputs: the straight-line forms measured 2 % SLOWER over the bf16x3 step, 40.15 -> 40.85-41.26 ms: dynamic form)
   if (!PM && m_w + FB * 16 <= p.M && n_w + FA * 16 <= p.K && n_w + FA * 16 <= p.ldy) fl |= EPI_FULL;
   bool done = false;
-  (void)((fl == FLS ? (epilogue_rows_bf16_impl<FA, FB, EX, PM, false, FLS>(acc, scr, pool, m_w, n_w, p, lane, rows, stamp), done = true) : false) || ...);
+  if constexpr (!SPL)
+    (void)((fl == FLS ? (epilogue_rows_bf16_impl<FA, FB, EX, PM, SPL, FLS>(acc, scr, pool, m_w, n_w, p, lane, rows, stamp), done = true) : false) || ...);
   if (done) return;
 #endif
-  epilogue_rows_bf16_impl<FA, FB, EX, PM, false, -1>(acc, scr, pool, m_w, n_w, p, lane, rows, stamp);
+  epilogue_rows_bf16_impl<FA, FB, EX, PM, SPL, -1>(acc, scr, pool, m_w, n_w, p, lane, rows, stamp);
 }
 
 template <int FA, int FB, bool SPL = false, typename Args>
@@ -486,8 +495,7 @@ __device__ __forceinline__ void epilogue_rows_bf16(const f32x4 (&acc)[FA][FB], c
 // FrozenBN (+ shortcut) + ReLU forward, dgrad with the ReLU mask of the layer input (+ the shortcut's gradient)
 template <int FA, int FB, bool SPL = false, typename Args>
 __device__ __forceinline__ void epilogue_rows_bf16_fast(const f32x4 (&acc)[FA][FB], char* scr, int m_w, int n_w, const Args& p, int lane) {
-  if constexpr (SPL) epilogue_rows_bf16_impl<FA, FB, false, false, true>(acc, scr, nullptr, m_w, n_w, p, lane);
-  else epilogue_rows_bf16_dispatch<FA, FB, false, false, EPI_FULL | EPI_BIAS | EPI_RELU | EPI_Y, EPI_FULL | EPI_BIAS | EPI_RES | EPI_RELU | EPI_Y,
+  epilogue_rows_bf16_dispatch<FA, FB, false, false, SPL, EPI_FULL | EPI_BIAS | EPI_RELU | EPI_Y, EPI_FULL | EPI_BIAS | EPI_RES | EPI_RELU | EPI_Y,
                                    EPI_FULL | EPI_BIAS | EPI_Y, EPI_FULL | EPI_MK | EPI_Y, EPI_FULL | EPI_RES | EPI_MK | EPI_Y, EPI_FULL | EPI_Y>(
       acc, scr, nullptr, m_w, n_w, p, lane);
 }

@@ -442,11 +442,14 @@ __global__ void __launch_bounds__(512, 2) conv_igemm256_p8_kernel(Conv256Args p)
       if constexpr (X3) {              // split outputs: two bf16 planes per row (conv_epilogue.h SPL)
         if constexpr (B1 == 4) {
           if (pm) {
-            epilogue_rows_bf16_impl<4, FBT, false, true, true>(acc, smem + wid * EpiCfg<4>::BYTES, nullptr, wm * (FBT * 16), n0 + wn * 64, p, lane, &pmr);
+            epilogue_rows_bf16_dispatch<4, FBT, false, true, true, EPI_BIAS | EPI_RELU | EPI_Y, EPI_MK | EPI_Y, EPI_Y>(
+                acc, smem + wid * EpiCfg<4>::BYTES, nullptr, wm * (FBT * 16), n0 + wn * 64, p, lane, &pmr);
             return;
           }
         }
-        epilogue_rows_bf16_impl<4, FBT, false, false, true>(acc, smem + wid * EpiCfg<4>::BYTES, nullptr, m0 + wm * (FBT * 16), n0 + wn * 64, p, lane);
+        epilogue_rows_bf16_dispatch<4, FBT, false, false, true, EPI_FULL | EPI_BIAS | EPI_RELU | EPI_Y, EPI_FULL | EPI_BIAS | EPI_RES | EPI_RELU | EPI_Y,
+                                    EPI_FULL | EPI_BIAS | EPI_Y, EPI_FULL | EPI_MK | EPI_Y, EPI_FULL | EPI_RES | EPI_MK | EPI_Y, EPI_FULL | EPI_Y>(
+            acc, smem + wid * EpiCfg<4>::BYTES, nullptr, m0 + wm * (FBT * 16), n0 + wn * 64, p, lane);
         return;
       }
       if constexpr (RM && !X3) {
@@ -454,7 +457,7 @@ __global__ void __launch_bounds__(512, 2) conv_igemm256_p8_kernel(Conv256Args p)
           // (layers.py BottleneckBlock: conv3 with / without the shortcut in the k extent, the pooled last block, the mask-bit dgrads)
           // (the Res5 problem sizes are whole numbers of tiles: only the all-rows-exist form of each combination is instantiated)
           constexpr int F = EPI_FULL;
-          epilogue_rows_bf16_dispatch<4, FBT, true, false,
+          epilogue_rows_bf16_dispatch<4, FBT, true, false, false,
                                       F | EPI_BIAS | EPI_RES | EPI_RELU | EPI_RB | EPI_Y, F | EPI_BIAS | EPI_RELU | EPI_RB | EPI_Y, F | EPI_BIAS | EPI_RELU | EPI_Y,
                                       F | EPI_BIAS | EPI_RES | EPI_RELU | EPI_RB | EPI_PP, F | EPI_BIAS | EPI_RES | EPI_RELU | EPI_PP,
                                       F | EPI_RES | EPI_MB | EPI_Y, F | EPI_MB | EPI_Y, F | EPI_Y>(
@@ -464,12 +467,12 @@ __global__ void __launch_bounds__(512, 2) conv_igemm256_p8_kernel(Conv256Args p)
       }
       if constexpr (RM && B1 == 4) {
         if (pm) {
-          epilogue_rows_bf16_dispatch<4, FBT, false, true, EPI_BIAS | EPI_RELU | EPI_Y, EPI_MK | EPI_Y, EPI_Y>(
+          epilogue_rows_bf16_dispatch<4, FBT, false, true, false, EPI_BIAS | EPI_RELU | EPI_Y, EPI_MK | EPI_Y, EPI_Y>(
               acc, smem + wid * EpiCfg<4>::BYTES, nullptr, wm * (FBT * 16), n0 + wn * 64, p, lane, &pmr);
           return;
         }
       }
-      epilogue_rows_bf16_dispatch<4, FBT, false, false, EPI_FULL | EPI_BIAS | EPI_RELU | EPI_Y, EPI_FULL | EPI_BIAS | EPI_Y, EPI_FULL | EPI_Y,
+      epilogue_rows_bf16_dispatch<4, FBT, false, false, false, EPI_FULL | EPI_BIAS | EPI_RELU | EPI_Y, EPI_FULL | EPI_BIAS | EPI_Y, EPI_FULL | EPI_Y,
                                   EPI_FULL | EPI_MK | EPI_Y, EPI_FULL | EPI_RES | EPI_MK | EPI_Y, EPI_BIAS | EPI_RELU | EPI_Y, EPI_MK | EPI_Y>(
           acc, smem + wid * EpiCfg<4>::BYTES, nullptr, m0 + wm * (FBT * 16), n0 + wn * 64, p, lane, nullptr, stamp ? stamp + 4 : nullptr);
       P8_STAMP(13);
