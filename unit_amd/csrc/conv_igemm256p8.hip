@@ -69,15 +69,21 @@ extern "C" int unit_debug_read_stamps(unsigned long long* host_out) {
 // X3: bf16x3 operands (conv_epilogue.h SplitK): x is a split tensor, the k extent holds three segments per 64-channel block, the output
 // (and residual / mask_ref) are split tensors. Same schedule; only the staging offsets (scalars) and the epilogue's stores differ.
 // PAIR: two problems of one layer in one grid (conv_epilogue.h ConvSecond; row-major tiles only).
-template <typename TO, bool RM, int B1, bool X3 = false, bool PAIR = false>
+// PERS (round 5): one workgroup per CU walks the row-major tiles bid, bid + gridDim.x, ... and issues the first k-tiles of its NEXT tile before the
+// epilogue of the current one, whose scratch moves behind the operand slots that prologue fills (LDS 146 KB): the 4.7 k cycles between a workgroup's
+// start and its first MFMA -- 12 % of a K = 512 tile, profiles/r05_exp_epilogue_diet.txt -- run under the epilogue's 7.8 k instead of after it.
+template <typename TO, bool RM, int B1, bool X3 = false, bool PAIR = false, bool PERS = false>
 __global__ void __launch_bounds__(512, 2) conv_igemm256_p8_kernel(Conv256Args p) {
   static_assert(RM || B1 == 4, "224-row tiles: RM schedule only");
   static_assert(!PAIR || (RM && B1 == 4), "pair launches: 256-row RM schedule");
   static_assert(!X3 || (RM && sizeof(TO) == 2), "bf16x3 operands: RM schedule, split bf16 output");
+  static_assert(!PERS || (RM && !PAIR && sizeof(TO) == 2), "persistent tiles: RM schedule, bf16 rows through the LDS epilogue, one problem");
   constexpr int FBT = 4 + B1;
   constexpr int BM = 32 * FBT, BN = 256, BK = 64;
   constexpr int HALF = 128 * 128;               // 16 KB half-tile
   constexpr int SX0 = 0, SW0 = HALF, SW1 = 2 * HALF, SX1 = 3 * HALF, BUF = 4 * HALF;
+  // epilogue scratch: over the operand stages, or (PERS) from buffer 1's X1 slot on -- the only slot the prologue of a tile leaves empty
+  constexpr int EPI_OFF = PERS ? BUF + SX1 : 0;
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   int bid = blockIdx.x;
@@ -85,7 +91,7 @@ __global__ void __launch_bounds__(512, 2) conv_igemm256_p8_kernel(Conv256Args p)
     if (p.second.on && bid >= p.second.tiles0) { bid -= p.second.tiles0; pair_swap_common(p); p.magic_ow = p.second.magic_ow; p.magic_oh = p.second.magic_oh; }
   }
   int nwg = p.tiles_m * p.tiles_n;
-  const bool pm = !PAIR && RM && B1 == 4 && p.pm_ncls > 0;
+  const bool pm = !PAIR && !PERS && RM && B1 == 4 && p.pm_ncls > 0;
   int tile_n, tile_m;
   PmRows pmr = {0, 1, 0, 0, 1, p.OW, p.OH * p.OW, p.N, 0u, 0u};
   int pm_nh = 1;
@@ -108,11 +114,14 @@ __global__ void __launch_bounds__(512, 2) conv_igemm256_p8_kernel(Conv256Args p)
     pmr.i0 = (tile_m - k.tile0) * BM; pmr.np = k.np; pmr.oh0 = k.oh0; pmr.ow0 = k.ow0; pmr.cw = k.cw;
     pmr.magic_np = k.magic_np; pmr.magic_cw = k.magic_cw;
     pm_nh = k.nh;
-  } else {
-    int q = nwg / 8, r = nwg % 8, xcd = bid % 8, loc = bid / 8;
-    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
-    tile_n = bid % p.tiles_n; tile_m = bid / p.tiles_n;
   }
+  // row-major tiles: workgroup (or, PERS, virtual workgroup) v runs on XCD v % 8 and takes the v / 8-th tile of that XCD's contiguous share
+  auto map_tile = [&](int v) {
+    int q = nwg / 8, r = nwg % 8, xcd = v % 8, loc = v / 8;
+    int t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+    tile_n = t % p.tiles_n; tile_m = t / p.tiles_n;
+  };
+  if (!pm) map_tile(bid);
   int m0 = tile_m * BM, n0 = tile_n * BN;
 
   const bf16_t* __restrict__ X = (const bf16_t*)p.x;
@@ -139,11 +148,14 @@ __global__ void __launch_bounds__(512, 2) conv_igemm256_p8_kernel(Conv256Args p)
   P8_STAMP(0);
   int lrow = lane >> 3, lc = lane & 7;
 
-  const bool pointwise = p.R == 1 && p.S == 1 && p.stride == 1 && p.pad == 0;      // (the bounds test of the single tap then only sees x_ih0 = 0 or the "past M" marker)
+  // (PERS launches are pointwise by the launcher's choice: the per-row tap origins (x_ih0 / x_iw0, 8 registers) do not exist there -- a row past
+  //  M is marked in its offset instead -- which is what lets the tile loop compile without spills)
+  const bool pointwise = PERS || (p.R == 1 && p.S == 1 && p.stride == 1 && p.pad == 0);      // (the bounds test of the single tap then only sees x_ih0 = 0 or the "past M" marker)
   // staging descriptors: half q (0,1), piece j (0,1) of this wave = half-tile rows R0 = (j*8 + wid)*8 .. +8 ; lane -> row
   // R0 + lrow, LDS chunk lc (lane-linear), SOURCE chunk lc ^ ((row>>1)&7)
   int x_ih0[4], x_iw0[4]; unsigned x_off0[4], w_off[4];
   const unsigned sw16 = (unsigned)((lc ^ ((((wid * 8 + lrow) >> 1)) & 7)) * 16);      // = sw * 16 of every piece of this lane (j * 64 rows do not change (R >> 1) & 7)
+  auto setup_tile = [&](int lrow, int lc) {          // the staging descriptors of the tile at (m0, n0); (lrow, lc) = lane >> 3, lane & 7
 #pragma unroll
   for (int q = 0; q < 2; ++q)
 #pragma unroll
@@ -168,11 +180,17 @@ __global__ void __launch_bounds__(512, 2) conv_igemm256_p8_kernel(Conv256Args p)
       int ih0 = oh * p.stride - p.pad, iw0 = ow * p.stride - p.pad;
       x_off0[q * 2 + j] = pointwise ? ((unsigned)mm * (unsigned)Cx + (unsigned)(sw * 8)) * 2u
                                     : ((unsigned)n * (unsigned)(p.H * p.W * Cx) + (unsigned)((ih0 * p.W + iw0) * Cx + sw * 8)) * 2u;  // tap (0,0), wraps for negative ih0/iw0
-      x_ih0[q * 2 + j] = ok ? ih0 : -(1 << 20);                    // rows past M fail the bounds test of every tap
-      x_iw0[q * 2 + j] = iw0;
+      if constexpr (PERS) {
+        if (!ok) x_off0[q * 2 + j] = OOB;
+      } else {
+        x_ih0[q * 2 + j] = ok ? ih0 : -(1 << 20);                    // rows past M fail the bounds test of every tap
+        x_iw0[q * 2 + j] = iw0;
+      }
       int nn = n0 + (R >> 5) * 64 + q * 32 + (R & 31);
       w_off[q * 2 + j] = nn < p.K ? ((unsigned)nn * (unsigned)p.Kgemm + (unsigned)sw * 8u) * 2u : OOB;
     }
+  };
+  setup_tile(lrow, lc);
 
   // k-tile order: channel block outermost, the R*S taps innermost (conv_igemm256.hip). (cb, r, s) of the k-tile that the
   // staging is currently working on, and the two byte offsets derived from them, live in scalar registers.
@@ -186,6 +204,11 @@ __global__ void __launch_bounds__(512, 2) conv_igemm256_p8_kernel(Conv256Args p)
   int st_sg = 0, st_cbr = 0;            // X3: segment of the virtual channel block st_cb, and the real 64-channel block it reads (st_cb = st_cbr * nseg + st_sg)
   unsigned st_kx = (unsigned)((st_r * p.W + st_s) * Cx) * 2u, st_kw = (unsigned)((st_r * p.S + st_s) * p.C) * 2u;
   if constexpr (X3) st_kx += (unsigned)((p.sk.seg_lo & 1) * p.sk.cr) * 2u;
+  auto st_reset = [&]() {               // back to the first k-tile (PERS: the next tile of this workgroup)
+    st_cb = 0; st_r = r_lo; st_s = s_lo; st_sg = 0; st_cbr = 0;
+    st_kx = (unsigned)((st_r * p.W + st_s) * Cx) * 2u; st_kw = (unsigned)((st_r * p.S + st_s) * p.C) * 2u;
+    if constexpr (X3) st_kx += (unsigned)((p.sk.seg_lo & 1) * p.sk.cr) * 2u;
+  };
   auto st_advance = [&]() {
     if (++st_s > s_hi) {
       st_s = s_lo;
@@ -202,8 +225,12 @@ __global__ void __launch_bounds__(512, 2) conv_igemm256_p8_kernel(Conv256Args p)
     char* base = smem + d * BUF + (q ? SX1 : SX0);
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-      int ih = x_ih0[q * 2 + j] + st_r, iw = x_iw0[q * 2 + j] + st_s;
-      bool ok = (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
+      bool ok;
+      if constexpr (PERS) ok = x_off0[q * 2 + j] != OOB;
+      else {
+        int ih = x_ih0[q * 2 + j] + st_r, iw = x_iw0[q * 2 + j] + st_s;
+        ok = (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
+      }
       if (dual && st_cb >= p.cb_split) {      // (scalar branch) the row of x2: same pixel, ratio2 times the pitch; the 16-B chunk swizzle term stays
         unsigned o2 = (x_off0[q * 2 + j] - sw16) * (unsigned)p.ratio2 + sw16 + (unsigned)((st_cb - p.cb_split) * BK) * 2u;
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX2, (lds_void*)(base + (j * 8 + wid) * 1024), 16, ok ? o2 : OOB, 0, 0, UNIT_P8_X_AUX);
@@ -221,10 +248,13 @@ __global__ void __launch_bounds__(512, 2) conv_igemm256_p8_kernel(Conv256Args p)
   };
 
   f32x4 acc[4][FBT];
+  auto zero_acc = [&]() {
 #pragma unroll
-  for (int a = 0; a < 4; ++a)
+    for (int a = 0; a < 4; ++a)
 #pragma unroll
-    for (int b = 0; b < FBT; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int b = 0; b < FBT; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+  };
+  zero_acc();
 
   const int nk = pm ? (p.C / BK) * (r_hi - r_lo + 1) * (s_hi - s_lo + 1) : p.Kgemm / BK;
   const int frow = lane & 15, fq = lane >> 4;
@@ -267,6 +297,49 @@ __global__ void __launch_bounds__(512, 2) conv_igemm256_p8_kernel(Conv256Args p)
     __builtin_amdgcn_s_setprio(0);                                                     \
   } while (0)
 
+  // the LDS epilogue of the tile at (m0e, n0e) (bf16 rows of 16-byte vectors; conv_epilogue.h) -- the caller has passed the barrier behind the last
+  // fragment read. PERS: the scratch sits behind the slots the next tile's prologue is filling (EPI_OFF).
+  auto lds_epilogue = [&](int m0e, int n0e, int lane) {
+    if constexpr (sizeof(TO) == 2) {
+      if constexpr (X3) {              // split outputs: two bf16 planes per row (conv_epilogue.h SPL)
+        if constexpr (B1 == 4) {
+          if (pm) {
+            epilogue_rows_bf16_dispatch<4, FBT, false, true, true, EPI_BIAS | EPI_RELU | EPI_Y, EPI_MK | EPI_Y, EPI_Y>(
+                acc, smem + EPI_OFF + wid * EpiCfg<4>::BYTES, nullptr, wm * (FBT * 16), n0e + wn * 64, p, lane, &pmr);
+            return;
+          }
+        }
+        epilogue_rows_bf16_dispatch<4, FBT, false, false, true, EPI_FULL | EPI_BIAS | EPI_RELU | EPI_Y, EPI_FULL | EPI_BIAS | EPI_RES | EPI_RELU | EPI_Y,
+                                    EPI_FULL | EPI_BIAS | EPI_Y, EPI_FULL | EPI_MK | EPI_Y, EPI_FULL | EPI_RES | EPI_MK | EPI_Y, EPI_FULL | EPI_Y>(
+            acc, smem + EPI_OFF + wid * EpiCfg<4>::BYTES, nullptr, m0e + wm * (FBT * 16), n0e + wn * 64, p, lane);
+        return;
+      }
+      if constexpr (RM && !X3) {
+        if (p.ex_on) {               // fused average pool / ReLU bit mask / bit-mask input (unit_conv2d_fwd_big_ex)
+          // (layers.py BottleneckBlock: conv3 with / without the shortcut in the k extent, the pooled last block, the mask-bit dgrads)
+          // (the Res5 problem sizes are whole numbers of tiles: only the all-rows-exist form of each combination is instantiated)
+          constexpr int F = EPI_FULL;
+          epilogue_rows_bf16_dispatch<4, FBT, true, false, false,
+                                      F | EPI_BIAS | EPI_RES | EPI_RELU | EPI_RB | EPI_Y, F | EPI_BIAS | EPI_RELU | EPI_RB | EPI_Y, F | EPI_BIAS | EPI_RELU | EPI_Y,
+                                      F | EPI_BIAS | EPI_RES | EPI_RELU | EPI_RB | EPI_PP, F | EPI_BIAS | EPI_RES | EPI_RELU | EPI_PP,
+                                      F | EPI_RES | EPI_MB | EPI_Y, F | EPI_MB | EPI_Y, F | EPI_Y>(
+              acc, smem + EPI_OFF + wid * EpiCfg<4>::BYTES, (float*)(smem + 36864 + wid * 8192), m0e + wm * (FBT * 16), n0e + wn * 64, p, lane);
+          return;
+        }
+      }
+      if constexpr (RM && B1 == 4) {
+        if (pm) {
+          epilogue_rows_bf16_dispatch<4, FBT, false, true, false, EPI_BIAS | EPI_RELU | EPI_Y, EPI_MK | EPI_Y, EPI_Y>(
+              acc, smem + EPI_OFF + wid * EpiCfg<4>::BYTES, nullptr, wm * (FBT * 16), n0e + wn * 64, p, lane, &pmr);
+          return;
+        }
+      }
+      epilogue_rows_bf16_dispatch<4, FBT, false, false, false, EPI_FULL | EPI_BIAS | EPI_RELU | EPI_Y, EPI_FULL | EPI_BIAS | EPI_Y, EPI_FULL | EPI_Y,
+                                  EPI_FULL | EPI_MK | EPI_Y, EPI_FULL | EPI_RES | EPI_MK | EPI_Y, EPI_BIAS | EPI_RELU | EPI_Y, EPI_MK | EPI_Y>(
+          acc, smem + EPI_OFF + wid * EpiCfg<4>::BYTES, nullptr, m0e + wm * (FBT * 16), n0e + wn * 64, p, lane, nullptr, stamp ? stamp + 4 : nullptr);
+    }
+  };
+
   if constexpr (RM) {
     // ---- RM schedule: the fragment reads of phase p+1 are issued INSIDE the MFMA section of phase p (one per MFMA gap, a
     // second X register set), so a LOAD section is only {2 LDS-DMA pieces, the k-tile's vmcnt wait}: tools/exp_p8.sh showed
@@ -306,14 +379,16 @@ __global__ void __launch_bounds__(512, 2) conv_igemm256_p8_kernel(Conv256Args p)
       __builtin_amdgcn_s_setprio(0);                                                     \
       if ((NR) > 0) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                   \
     } while (0)
-    stage_x(0, 0); stage_w(0, 0); stage_w(1, 0); stage_x(1, 0);
-    st_advance();
-    if (nk > 1) {
-      stage_x(0, 1); stage_w(0, 1); stage_w(1, 1);
-      asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-    } else {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
+    auto prologue_stage = [&]() {          // k-tile 0 whole, k-tile 1 without its X1 half (staged in phase 0 of the loop)
+      stage_x(0, 0); stage_w(0, 0); stage_w(1, 0); stage_x(1, 0);
+      st_advance();
+      if (nk > 1) { stage_x(0, 1); stage_w(0, 1); stage_w(1, 1); }
+    };
+    prologue_stage();
+    if (nk > 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    int pers_v = blockIdx.x;             // PERS: the virtual workgroup (tile) this pass of the loop below works on
+    while (true) {
     P8_BAR();
     P8_STAMP(1);
     read_w(smem + SW0, fw0);
@@ -372,6 +447,36 @@ __global__ void __launch_bounds__(512, 2) conv_igemm256_p8_kernel(Conv256Args p)
       P8_BAR();
     }
     if (grp == 0) P8_BAR();
+    if constexpr (!PERS) break;
+    else {
+      // ---- next tile of this workgroup: its first k-tiles go out BEFORE the epilogue of the current one
+      P8_STAMP(2);
+      __syncthreads();                   // every wave is done with the operand stages
+      P8_STAMP(3);
+      const int m0e = m0, n0e = n0, nv = pers_v + (int)gridDim.x;
+      const bool more = nv < nwg;
+      // (the fused-pool epilogue keeps its per-wave sums in the operand area: no early prologue under it)
+      const bool early = more && !(p.ex_on && p.ex.pool_partial != nullptr);
+      // (the lane number is made opaque here: what the epilogue and the descriptor set-up derive from it is then recomputed per tile instead of
+      //  being hoisted out of the tile loop and kept in registers across the main loop, which has none to spare)
+      int lane_o = lane;
+      asm volatile("" : "+v"(lane_o));
+      auto next_tile = [&]() { map_tile(nv); m0 = tile_m * BM; n0 = tile_n * BN; setup_tile(lane_o >> 3, lane_o & 7); st_reset(); prologue_stage(); };
+      if (early) next_tile();
+      lds_epilogue(m0e, n0e, lane_o);
+      if (!more) return;
+      if (!early) { __syncthreads(); next_tile(); }
+      else {                             // recomputed rather than kept: 16 descriptor registers less across the epilogue (which otherwise spills)
+        asm volatile("" : "+s"(m0), "+s"(n0));          // (opaque to common-subexpression elimination)
+        setup_tile(lane_o >> 3, lane_o & 7);
+      }
+      // the tile's k-tile 0 (and the epilogue's own loads / stores, which share the counter) has landed; the three half-tiles of k-tile 1 are
+      // covered by the loop's own wait in phase 2
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      zero_acc();
+      pers_v = nv;
+    }
+    }
 #undef P8_MM
   } else {
   // ---- prologue: k-tile 0 (4 half-tiles) and X0, W0 of k-tile 1 in flight
@@ -439,42 +544,7 @@ __global__ void __launch_bounds__(512, 2) conv_igemm256_p8_kernel(Conv256Args p)
       P8_STAMP(2);
       __syncthreads();               // every wave is done with the operand stages
       P8_STAMP(3);
-      if constexpr (X3) {              // split outputs: two bf16 planes per row (conv_epilogue.h SPL)
-        if constexpr (B1 == 4) {
-          if (pm) {
-            epilogue_rows_bf16_dispatch<4, FBT, false, true, true, EPI_BIAS | EPI_RELU | EPI_Y, EPI_MK | EPI_Y, EPI_Y>(
-                acc, smem + wid * EpiCfg<4>::BYTES, nullptr, wm * (FBT * 16), n0 + wn * 64, p, lane, &pmr);
-            return;
-          }
-        }
-        epilogue_rows_bf16_dispatch<4, FBT, false, false, true, EPI_FULL | EPI_BIAS | EPI_RELU | EPI_Y, EPI_FULL | EPI_BIAS | EPI_RES | EPI_RELU | EPI_Y,
-                                    EPI_FULL | EPI_BIAS | EPI_Y, EPI_FULL | EPI_MK | EPI_Y, EPI_FULL | EPI_RES | EPI_MK | EPI_Y, EPI_FULL | EPI_Y>(
-            acc, smem + wid * EpiCfg<4>::BYTES, nullptr, m0 + wm * (FBT * 16), n0 + wn * 64, p, lane);
-        return;
-      }
-      if constexpr (RM && !X3) {
-        if (p.ex_on) {               // fused average pool / ReLU bit mask / bit-mask input (unit_conv2d_fwd_big_ex)
-          // (layers.py BottleneckBlock: conv3 with / without the shortcut in the k extent, the pooled last block, the mask-bit dgrads)
-          // (the Res5 problem sizes are whole numbers of tiles: only the all-rows-exist form of each combination is instantiated)
-          constexpr int F = EPI_FULL;
-          epilogue_rows_bf16_dispatch<4, FBT, true, false, false,
-                                      F | EPI_BIAS | EPI_RES | EPI_RELU | EPI_RB | EPI_Y, F | EPI_BIAS | EPI_RELU | EPI_RB | EPI_Y, F | EPI_BIAS | EPI_RELU | EPI_Y,
-                                      F | EPI_BIAS | EPI_RES | EPI_RELU | EPI_RB | EPI_PP, F | EPI_BIAS | EPI_RES | EPI_RELU | EPI_PP,
-                                      F | EPI_RES | EPI_MB | EPI_Y, F | EPI_MB | EPI_Y, F | EPI_Y>(
-              acc, smem + wid * EpiCfg<4>::BYTES, (float*)(smem + 36864 + wid * 8192), m0 + wm * (FBT * 16), n0 + wn * 64, p, lane);
-          return;
-        }
-      }
-      if constexpr (RM && B1 == 4) {
-        if (pm) {
-          epilogue_rows_bf16_dispatch<4, FBT, false, true, false, EPI_BIAS | EPI_RELU | EPI_Y, EPI_MK | EPI_Y, EPI_Y>(
-              acc, smem + wid * EpiCfg<4>::BYTES, nullptr, wm * (FBT * 16), n0 + wn * 64, p, lane, &pmr);
-          return;
-        }
-      }
-      epilogue_rows_bf16_dispatch<4, FBT, false, false, false, EPI_FULL | EPI_BIAS | EPI_RELU | EPI_Y, EPI_FULL | EPI_BIAS | EPI_Y, EPI_FULL | EPI_Y,
-                                  EPI_FULL | EPI_MK | EPI_Y, EPI_FULL | EPI_RES | EPI_MK | EPI_Y, EPI_BIAS | EPI_RELU | EPI_Y, EPI_MK | EPI_Y>(
-          acc, smem + wid * EpiCfg<4>::BYTES, nullptr, m0 + wm * (FBT * 16), n0 + wn * 64, p, lane, nullptr, stamp ? stamp + 4 : nullptr);
+      lds_epilogue(m0, n0, lane);
       P8_STAMP(13);
       return;
     }
@@ -561,6 +631,22 @@ static int launch256_p8(Conv256Args& a, hipStream_t st) {
     grid = most * 8 * a.tiles_n;
   }
   size_t lds = 8 * 128 * 128;
+  if constexpr (RM && B1 == 4 && sizeof(TO) == 2) {
+    // persistent tiles (PERS): row-major launches of more tiles than CUs whose rows go through the LDS epilogue. UNIT_P8_PERSIST=0: off (A/B)
+    static int pers = -1;
+    if (pers < 0) { const char* e = getenv("UNIT_P8_PERSIST"); pers = e ? atoi(e) : 1; }
+    if (pers && a.pm_ncls == 0 && (a.ldy & 7) == 0 && grid > 256 && a.R == 1 && a.S == 1 && a.stride == 1 && a.pad == 0) {
+      const size_t lds_p = 7 * 128 * 128 + 8 * EpiCfg<4>::BYTES;          // operand slots up to buffer 1's X1 + the epilogue scratch from there on
+      static bool attr_p = false;
+      if (!attr_p) {
+        (void)hipFuncSetAttribute((const void*)conv_igemm256_p8_kernel<TO, RM, B1, X3, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_p);
+        attr_p = true;
+      }
+      conv_igemm256_p8_kernel<TO, RM, B1, X3, false, true><<<256, 512, lds_p, st>>>(a);
+      UNIT_LAUNCH_CHECK();
+      return UNIT_OK;
+    }
+  }
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)conv_igemm256_p8_kernel<TO, RM, B1, X3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
