@@ -1314,6 +1314,59 @@ def test_conv_fused_pool_and_relu_bits(dev, rois, c, k, variant):
     assert torch.equal(o.avgpool_bwd_bits(df[lo:].contiguous(), bits[lo:], 7, 7), want[lo:])
 
 
+@pytest.mark.parametrize("case", ["res_relu_bits", "relu_bits", "pool", "maskbits", "plain_relu", "k2048"])
+def test_conv_persistent_tiles_and_straight_line_epilogue_are_bit_identical(dev, case):
+    """Round 5: (a) the persistent-tile form of the 256x256 kernel (a workgroup walks tiles and issues the next tile's first k-tiles before the
+    current epilogue; csrc/conv_igemm256p8.hip PERS) against one workgroup per tile (UNIT_P8_PERSIST=0, read per launch), and (b) the
+    straight-line epilogue passes of whole tiles against the dynamic form, which a problem with ONE row less takes for its last row tile
+    (conv_epilogue.h epilogue_rows_bf16_dispatch): every output bit for bit."""
+    import os
+    from unit_amd import ops as o
+    g = torch.Generator().manual_seed(11)
+    rois = 768                       # 37 632 rows = 147 row tiles x 8 channel tiles = 1 176 tiles: 4.6 per workgroup
+    c, k = (2048, 512) if case == "k2048" else (512, 2048)
+    x = torch.randn(rois, 7, 7, c, generator=g).to(dev).bfloat16()
+    w = (torch.randn(k, 1, 1, c, generator=g) * (1.0 / c) ** 0.5).to(dev).bfloat16()
+    res = torch.randn(rois, 7, 7, k, generator=g).to(dev).bfloat16()
+    bias = (torch.randn(k, generator=g) * 0.1).to(dev)
+    bits_in = o.conv2d_ex(x, w, k, 1, 1, 0, bias=bias, relu=True, want_bits=True)[1] if case == "maskbits" else None
+
+    def run(xx, rr, mb):
+        if case == "res_relu_bits":
+            return o.conv2d_ex(xx, w, k, 1, 1, 0, bias=bias, residual=rr, relu=True, want_bits=True)
+        if case == "relu_bits":
+            return o.conv2d_ex(xx, w, k, 1, 1, 0, bias=bias, relu=True, want_bits=True)
+        if case == "pool":
+            return o.conv2d_ex(xx, w, k, 1, 1, 0, bias=bias, residual=rr, relu=True, want_bits=True, pool_rows=49, want_y=False)
+        if case == "maskbits":
+            return o.conv2d_ex(xx, w, k, 1, 1, 0, residual=rr, mask_bits=mb)
+        return (o.conv2d(xx, w, k, 1, 1, 1, 0, bias=bias, relu=True), None, None)
+
+    def same(a, b, n=None):
+        for u, v in zip(a, b):
+            if u is None:
+                assert v is None
+                continue
+            u = u.unpack() if isinstance(u, o.ReluBits) else u
+            v = v.unpack() if isinstance(v, o.ReluBits) else v
+            assert torch.equal(u if n is None else u[:n], v if n is None else v[:n])
+
+    got = run(x, res, bits_in)
+    old = os.environ.get("UNIT_P8_PERSIST")
+    os.environ["UNIT_P8_PERSIST"] = "0"
+    try:
+        ref = run(x, res, bits_in)
+    finally:
+        if old is None:
+            del os.environ["UNIT_P8_PERSIST"]
+        else:
+            os.environ["UNIT_P8_PERSIST"] = old
+    same(got, ref)
+    if case != "maskbits":           # (a bit-mask input is laid out for its own row count)
+        part = run(x[:rois - 1].contiguous(), res[:rois - 1].contiguous(), None)      # 49 rows less: the last row tile is partial -> dynamic passes
+        same(part, got, rois - 1)
+
+
 def test_conv_fused_pool_is_reproducible(dev):
     """two launches, one fed from a dirty allocator state: identical pooled features and bit masks (no atomics, no uninitialised reads)"""
     from unit_amd import ops as o

@@ -2,6 +2,7 @@
 # everything the round's evidence needs, at the HEAD that is on the box: tools/gpu_round_end.sh <tag>   (GPU box; ~15 min)
 TAG=${1:-r05}
 bash tools/gpu_final_profiles.sh $TAG > gpurun_out/${TAG}_final.log 2>&1
+cp gpurun_out/pmc_traffic.json profiles/pmc_traffic.json          # (this box's copy: the lines below then carry roofline.traffic of THIS build)
 python bench.py --no-cpu-baseline > gpurun_out/${TAG}_bench_default_2.json 2> gpurun_out/${TAG}_bench_default_2.err
 python bench.py --force-collectives --no-cpu-baseline --no-roofline > gpurun_out/${TAG}_bench_forced.json 2> gpurun_out/${TAG}_bench_forced.err
 python bench.py --shapes voc --no-cpu-baseline --no-roofline --steps 40 > gpurun_out/${TAG}_bench_voc.json 2> gpurun_out/${TAG}_bench_voc.err

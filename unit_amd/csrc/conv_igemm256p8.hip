@@ -633,8 +633,8 @@ static int launch256_p8(Conv256Args& a, hipStream_t st) {
   size_t lds = 8 * 128 * 128;
   if constexpr (RM && B1 == 4 && sizeof(TO) == 2) {
     // persistent tiles (PERS): row-major launches of more tiles than CUs whose rows go through the LDS epilogue. UNIT_P8_PERSIST=0: off (A/B)
-    static int pers = -1;
-    if (pers < 0) { const char* e = getenv("UNIT_P8_PERSIST"); pers = e ? atoi(e) : 1; }
+    const char* pe = getenv("UNIT_P8_PERSIST");          // (read per launch: the bit-identity test flips it inside one process)
+    const int pers = pe ? atoi(pe) : 1;
     if (pers && a.pm_ncls == 0 && (a.ldy & 7) == 0 && grid > 256 && a.R == 1 && a.S == 1 && a.stride == 1 && a.pad == 0) {
       const size_t lds_p = 7 * 128 * 128 + 8 * EpiCfg<4>::BYTES;          // operand slots up to buffer 1's X1 + the epilogue scratch from there on
       static bool attr_p = false;
