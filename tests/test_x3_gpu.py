@@ -115,6 +115,33 @@ def test_conv_x3_kernels(dev, case, tile):
     assert ((y2 - exp).abs() <= 2.0 ** -16 * exp.abs() + 2e-6 * max(scale, exp.abs().max().item())).all()
 
 
+@pytest.mark.parametrize("case", [(4, 38, 63, 1024, 256, 1, 152), (4, 38, 63, 256, 1024, 1, 154), (4, 38, 63, 256, 1024, 1, 142), (2, 75, 125, 512, 1024, 2, 164),
+                                  (1, 20, 20, 64, 128, 1, 182), (4, 38, 63, 1024, 2048, 1, 144)])
+def test_conv_x3_operand_reuse_is_bit_identical(dev, case):
+    """the loader / consumer kernel's operand-reuse form for pointwise bf16x3 layers (csrc/conv_igemm_lc.hip R3: lo / hi / Wh / Wl of a 64-channel
+    block staged once each instead of six tiles per three k-steps) against the plain form (UNIT_X3_REUSE=0, read per launch): same products in
+    the same order, so both planes of the output agree bit for bit -- one tile per workgroup, several (the run crosses tile boundaries),
+    one channel block, sixteen, stride 2, ragged last tiles"""
+    import os
+    o = ops()
+    n, h, w, c, k, stride, tile = case
+    gen = g(5 + c + k + tile)
+    x = o.x3_split((torch.randn(n, h, w, c, generator=gen) * 2).to(dev))
+    wf, _ = o.weight_prep_x3((torch.randn(k, 1, 1, c, generator=gen) / np.sqrt(c)).to(dev), None, k, 1, 1, c, want_dgrad=False)
+    bias = torch.randn(k, generator=gen).to(dev)
+    oh, ow = o.conv_out_size(h, w, 1, 1, stride, 0)
+    res = o.x3_split(torch.randn(n, oh, ow, k, generator=gen).to(dev))
+    got = o.conv2d_x3(x, wf, k, 1, 1, stride, 0, bias=bias, residual=res, relu=True, tile=tile)
+    os.environ["UNIT_X3_REUSE"] = "0"
+    try:
+        ref = o.conv2d_x3(x, wf, k, 1, 1, stride, 0, bias=bias, residual=res, relu=True, tile=tile)
+    finally:
+        del os.environ["UNIT_X3_REUSE"]
+    raw = lambda t: t.as_subclass(torch.Tensor).view(torch.int32)
+    assert torch.equal(raw(got), raw(ref))
+    assert float(o.as_f32(got).abs().max()) > 0
+
+
 def test_conv_x3_policy_and_position_classes(dev):
     """what the step launches (tile=None): the 256x256 kernel with position-class tiles on the Res5 3x3 shape equals the explicit 4-wave
     kernel within fp32 accumulation order, images not a multiple of the tile"""

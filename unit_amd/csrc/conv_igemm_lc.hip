@@ -42,6 +42,18 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() {
 #undef LC_W
 }
 
+// wave-uniform runtime count (the operand-reuse form below issues a different number of pieces per step)
+__device__ __forceinline__ void wait_vmcnt_rt(int n) {
+#define LC_R(v) case v: asm volatile("s_waitcnt vmcnt(" #v ")" ::: "memory"); break
+  switch (n) {
+    LC_R(0); LC_R(1); LC_R(2); LC_R(3); LC_R(4); LC_R(5); LC_R(6); LC_R(7); LC_R(8); LC_R(9); LC_R(10); LC_R(11); LC_R(12); LC_R(13); LC_R(14);
+    LC_R(15); LC_R(16); LC_R(17); LC_R(18); LC_R(19); LC_R(20); LC_R(21); LC_R(22); LC_R(23); LC_R(24); LC_R(25); LC_R(26); LC_R(27); LC_R(28);
+    LC_R(29); LC_R(30); LC_R(31); LC_R(32); LC_R(33); LC_R(34); LC_R(35); LC_R(36);
+    default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+  }
+#undef LC_R
+}
+
 template <int FB, int FA, int NL, int NSMAX = 3> struct LcCfg {
   static constexpr int BM = FB * 16, BN = FA * 64;
   static constexpr int XP = BM / 8, WP = BN / 8, TP = XP + WP;     // LDS-DMA pieces (8 rows x 128 B) per k-step: X, W, all
@@ -61,8 +73,17 @@ template <int FB, int FA, int NL, int NSMAX = 3> struct LcCfg {
 // write split output planes; everything else is the same kernel.
 // PAIR: two problems of one layer in one grid (conv_epilogue.h ConvSecond): tile ids >= second.tiles0 belong to the second problem; the loaders'
 // cursor and the consumers swap the problem's fields in per tile (a workgroup's run of tiles may cross from one problem into the other).
-template <int FB, int FA, int NL, int NSMAX = 3, bool X3 = false, bool PAIR = false>
+// R3 (X3 pointwise layers, round 5): operand reuse inside a 64-channel block. Its three k-steps are lo.Wh, hi.Wh, hi.Wl -- four distinct operand
+// tiles, not six -- and this kernel is bound by what a CU takes in (header), so the loaders stage each tile ONCE: the ring is split into three X
+// slots and three W slots, block b keeps lo(b) in X slot 2b % 3, hi(b) in (2b + 1) % 3, Wh(b) in W slot 2b % 3, Wl(b) in (2b + 1) % 3, and during
+// the steps of block b the loaders issue [lo, Wh](b + 1), then hi(b + 1), then Wl(b + 1) -- each into the slot whose previous tile was last read
+// one step earlier, three steps before its own first use. Same products in the same order: bit-identical to the plain X3 form.
+//   RAW: after issuing in iteration g a loader lets only its pieces of iterations g and g - 1 stay in flight; what step g + 1 reads was issued
+//        in iteration g - 2 or earlier.   WAR: see the slot table above; a slot's last reader retired its reads before the barrier that the
+//        loaders pass before overwriting it.
+template <int FB, int FA, int NL, int NSMAX = 3, bool X3 = false, bool PAIR = false, bool R3 = false>
 __global__ void __launch_bounds__((4 + NL) * 64) conv_igemm_lc_kernel(ConvDmaArgs p) {
+  static_assert(!R3 || (X3 && !PAIR && NSMAX == 3), "operand reuse: bf16x3 operands, one problem, the three-slot ring");
   typedef LcCfg<FB, FA, NL, NSMAX> Cf;
   constexpr int BM = Cf::BM, BN = Cf::BN, BK = 64;
   constexpr int XP = Cf::XP, WP = Cf::WP, TP = Cf::TP, XPL = Cf::XPL, WPL = Cf::WPL, XR = Cf::XR, SLOT = Cf::SLOT, NS = Cf::NS;
@@ -171,10 +192,70 @@ __global__ void __launch_bounds__((4 + NL) * 64) conv_igemm_lc_kernel(ConvDmaArg
         if (++cur_t < t_count) setup_tile(cur_t);
       }
     };
+    if constexpr (R3) {
+      // blocks = (tile, real 64-channel block); NB of them in this workgroup's run; step g = 3 * b + sg
+      const int nb = nk / 3, NB = t_count * nb;
+      int cx = 0, cw = 0;                            // this loader's pieces per X tile / W tile
+#pragma unroll
+      for (int i = 0; i < XPL; ++i) cx += (i * NL + l < XP) ? 1 : 0;
+#pragma unroll
+      for (int i = 0; i < WPL; ++i) cw += (i * NL + lw < WP) ? 1 : 0;
+      char* xring = smem;
+      char* wring = smem + 3 * XR * 128;
+      auto issue_x = [&](int plane_bit, int cbr, int xs) {
+        const int ch0 = plane_bit * p.sk.cr + cbr * BK;
+        char* base = xring + xs * (XR * 128);
+#pragma unroll
+        for (int i = 0; i < XPL; ++i) {
+          if (i * NL + l >= XP) continue;
+          int R0 = (i * NL + l) * 8;
+          bool ok = x_ok[i] && (unsigned)x_ih0[i] < (unsigned)cH && (unsigned)x_iw0[i] < (unsigned)cW;
+          unsigned off = (x_base[i] + (unsigned)((x_ih0[i] * cW + x_iw0[i]) * xpitch + ch0 + x_q[i] * 8)) * 2u;
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX0, (lds_void_lc*)(base + R0 * 128), 16, ok ? off : OOB, 0, 0, 0);
+        }
+      };
+      auto issue_w = [&](int seg, int cbr, int ws) {
+        const int k0 = (cbr * 3 + seg) * BK;          // the weights' layout keeps all three segments ([Wh | Wh | Wl], split.hip)
+        char* base = wring + ws * (BN * 128);
+#pragma unroll
+        for (int i = 0; i < WPL; ++i) {
+          if (i * NL + lw >= WP) continue;
+          int R0 = (i * NL + lw) * 8;
+          unsigned off = w_off[i] + (unsigned)k0 * 2u;
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (lds_void_lc*)(base + R0 * 128), 16, w_ok[i] ? off : OOB, 0, 0, 0);
+        }
+      };
+      const int lo_bit = p.sk.seg_lo & 1, hi_bit = (p.sk.seg_lo >> 1) & 1;      // plane of segment 0 (lo) / segments 1, 2 (hi)
+      int set_t = 0;                                 // tile whose descriptors are loaded
+      setup_tile(0);
+      auto at_block = [&](int b) {                   // descriptors of block b's tile
+        int t = b / nb;
+        if (t != set_t) { setup_tile(t); set_t = t; }
+        return b - t * nb;                           // its real channel block
+      };
+      if (NB > 0) {                                  // block 0 whole
+        int c0 = at_block(0);
+        issue_x(lo_bit, c0, 0); issue_w(0, c0, 0); issue_x(hi_bit, c0, 1); issue_w(2, c0, 1);
+      }
+      wait_vmcnt<0>();
+      for (int g = 0; g < G; ++g) {
+        __builtin_amdgcn_s_barrier();
+        const int b = g / 3, sg = g - b * 3, nx = b + 1;
+        if (nx < NB) {
+          int c1 = at_block(nx);
+          if (sg == 0) { issue_x(lo_bit, c1, (2 * nx) % 3); issue_w(0, c1, (2 * nx) % 3); wait_vmcnt_rt(cx + 2 * cw); }
+          else if (sg == 1) { issue_x(hi_bit, c1, (2 * nx + 1) % 3); wait_vmcnt_rt(2 * cx + cw); }
+          else { issue_w(2, c1, (2 * nx + 1) % 3); wait_vmcnt_rt(cx + cw); }
+        } else {
+          wait_vmcnt<0>();
+        }
+      }
+      return;
+    }
     setup_tile(0);
     int issued = 0, islot = 0;
-    for (; issued < D && issued < G; ++issued) { issue(islot); islot = islot + 1 == NS ? 0 : islot + 1; }
     const bool hi = l < NHI;                        // this loader issues PLO + 1 pieces per k-step
+    for (; issued < D && issued < G; ++issued) { issue(islot); islot = islot + 1 == NS ? 0 : islot + 1; }
     auto wait_ahead = [&]() {                       // all but the youngest D-1 k-steps of this wave's pieces have landed
       if (hi) wait_vmcnt<(PLO + 1) * (D - 1)>(); else wait_vmcnt<PLO * (D - 1)>();
     };
@@ -208,6 +289,7 @@ __global__ void __launch_bounds__((4 + NL) * 64) conv_igemm_lc_kernel(ConvDmaArg
     bool second = false;
     if constexpr (PAIR) { if (id >= p.second.tiles0) { id -= p.second.tiles0; second = true; } }
     int tile_n = id % p.tiles_n, tile_m = id / p.tiles_n;
+    const int blk0 = R3 ? t * (nk / 3) : 0;          // R3: the run's block number of this tile's first block
     f32x4 acc[FA][FB];
 #pragma unroll
     for (int a = 0; a < FA; ++a)
@@ -217,11 +299,17 @@ __global__ void __launch_bounds__((4 + NL) * 64) conv_igemm_lc_kernel(ConvDmaArg
       __builtin_amdgcn_s_barrier();
       __builtin_amdgcn_sched_barrier(0);
       const char* base = smem + slot * SLOT;
+      const char* basew = base;
+      if constexpr (R3) {          // X and W come from their own rings (slot table in the header); offw carries XR * 128, the W ring starts at 3 * XR * 128
+        const int sg = kt % 3, b2 = 2 * (blk0 + kt / 3);
+        base = smem + ((b2 + (sg > 0 ? 1 : 0)) % 3) * (XR * 128);
+        basew = smem + 2 * XR * 128 + ((b2 + (sg == 2 ? 1 : 0)) % 3) * (BN * 128);
+      }
       i32x4 fa[2][FA], fb[2][FB];
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
 #pragma unroll
-        for (int a = 0; a < FA; ++a) fa[ks][a] = *reinterpret_cast<const i32x4*>(base + (offw[a] ^ (ks * 64)));
+        for (int a = 0; a < FA; ++a) fa[ks][a] = *reinterpret_cast<const i32x4*>(basew + (offw[a] ^ (ks * 64)));
 #pragma unroll
         for (int b = 0; b < FB; ++b) fb[ks][b] = *reinterpret_cast<const i32x4*>(base + (offx[b] ^ (ks * 64)));
       }
@@ -273,6 +361,20 @@ static int launch_lc(ConvDmaArgs& a, hipStream_t st) {
   }
   const int slots = NSMAX == 2 ? 512 : 256;          // persistent workgroups: one per CU, two with the two-slot ring
   int grid = total < slots ? total : slots;
+  if constexpr (X3 && NL == 4 && NSMAX == 3) {
+    // operand reuse (R3) for the pointwise layers: lo / hi / Wh / Wl of a block staged once each. UNIT_X3_REUSE=0: off (A/B, bit-identity test)
+    const char* e = getenv("UNIT_X3_REUSE");
+    if ((e ? atoi(e) : 1) && a.R == 1 && a.S == 1 && a.sk.nseg == 3 && (a.Kgemm / 64) % 3 == 0) {
+      static bool attr3 = false;
+      if (!attr3) {
+        (void)hipFuncSetAttribute((const void*)conv_igemm_lc_kernel<FB, FA, NL, NSMAX, true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, Cf::LDS);
+        attr3 = true;
+      }
+      conv_igemm_lc_kernel<FB, FA, NL, NSMAX, true, false, true><<<grid, Cf::THREADS, Cf::LDS, st>>>(a);
+      UNIT_LAUNCH_CHECK();
+      return UNIT_OK;
+    }
+  }
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)conv_igemm_lc_kernel<FB, FA, NL, NSMAX, X3>, hipFuncAttributeMaxDynamicSharedMemorySize, Cf::LDS);
