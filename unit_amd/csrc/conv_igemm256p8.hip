@@ -642,7 +642,13 @@ static int launch256_p8(Conv256Args& a, hipStream_t st) {
         (void)hipFuncSetAttribute((const void*)conv_igemm256_p8_kernel<TO, RM, B1, X3, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_p);
         attr_p = true;
       }
-      conv_igemm256_p8_kernel<TO, RM, B1, X3, false, true><<<256, 512, lds_p, st>>>(a);
+      static int ncu = 0;                    // one workgroup per CU (256 on MI355X); a multiple of 8 so that a workgroup's tiles stay on its XCD's share
+      if (ncu == 0) {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 8) n = 256;
+        ncu = n / 8 * 8;
+      }
+      conv_igemm256_p8_kernel<TO, RM, B1, X3, false, true><<<grid < ncu ? grid : ncu, 512, lds_p, st>>>(a);
       UNIT_LAUNCH_CHECK();
       return UNIT_OK;
     }
