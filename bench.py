@@ -868,6 +868,9 @@ def main():
             traffic_stale = traffic is not None and tdoc.get("_build_hash") != _lib.build_hash()
             if traffic_stale:
                 traffic = None
+            traffic_other_mode = traffic is not None and args.dtype != "bf16"          # the PMC passes run the default (bf16) step: their bytes
+            if traffic_other_mode:                                                     # per launch say nothing about this mode's launches
+                traffic = None
             out["roofline"] = {"kernel": ("conv_igemm256_p8_kernel" if key == "conv_igemm256" else key + "_kernel") +
                                          " (implicit-GEMM conv fwd/dgrad, bf16 MFMA 16x16x32, 256x256x64 LDS-DMA tiles)",
                                "bound": "mfma", "achieved": r["tflops"], "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
@@ -875,7 +878,8 @@ def main():
                                "traffic_source": (f"profiles/pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this command, kernel "
                                                   f"sources {tdoc.get('_build_hash')} = this build (not collected inside this run)") if traffic else
                                                  (f"withheld: profiles/pmc_traffic.json was measured on kernel sources {tdoc.get('_build_hash')}, this build is "
-                                                  f"{_lib.build_hash()} -- re-run tools/pmc_bench.sh") if traffic_stale else None,
+                                                  f"{_lib.build_hash()} -- re-run tools/pmc_bench.sh") if traffic_stale else
+                                                 ("withheld: profiles/pmc_traffic.json holds the bf16 step's launches, not this mode's" if traffic_other_mode else None),
                                "launches_per_step": r["launches_per_step"], "avg_launch_us": r["avg_launch_us"],
                                "algorithmic_gflop_per_launch": r["gflop_per_launch"],
                                "algorithmic_bytes_per_launch": r["algorithmic_bytes_per_launch"],
