@@ -203,6 +203,20 @@ int unit_multi_weight_prep(const void* descs_dev, int n, int total_blocks, const
  * NCCL, reached from engine/defaults.py:256): out[i] = parts[0][i] + ... + parts[nparts-1][i], fp32, in that order; parts = [nparts][n]
  * fp32 or bf16 (received by an all-to-all over all xGMI links at once), out fp32 [n] = this rank's shard of the gradient bucket */
 int unit_shard_sum(const void* parts, int dtype, int nparts, long n, float* out, void* stream);
+/* The gradient exchange from the C ABI (csrc/comm.hip): what DistributedDataParallel's reducer does on NCCL for the reference
+ * (engine/defaults.py:256, scripts/train_VOC.py:67-77), for a host without torch.distributed. RCCL is resolved with dlopen at the first call (the copy
+ * already in the process, else the system's): not a link-time dependency. One process per GPU.
+ *   unit_comm_unique_id          rank 0: 128 bytes (UNIT_COMM_ID_BYTES) that the host hands to the other ranks out of band
+ *   unit_comm_init               every rank, on its device: *comm = opaque communicator
+ *   unit_allreduce_bucket_async  buf[0..count) <- sum over ranks, in place, enqueued on `stream`; dtype 0 = fp32, 1 = bf16
+ *   unit_comm_wait               work enqueued on compute_stream afterwards waits for the collectives enqueued on comm_stream so far (no host wait)
+ *   unit_comm_destroy, unit_comm_rccl_version (major * 10000 + minor * 100 + patch; 0 = RCCL not loadable) */
+int unit_comm_unique_id(void* id, int id_bytes);
+int unit_comm_init(int rank, int world, const void* id, int id_bytes, void** comm);
+int unit_allreduce_bucket_async(void* comm, void* buf, long count, int dtype, void* stream);
+int unit_comm_wait(void* compute_stream, void* comm_stream);
+int unit_comm_destroy(void* comm);
+int unit_comm_rccl_version(void);
 /* FrozenBatchNorm2d fold (detectron2 layers/batch_norm.py, eps 1e-5) and weight re-layout / cast */
 int unit_frozen_bn_fold(const float* w, const float* b, const float* rm, const float* rv, float eps, float* scale, float* shift,
                         int C, void* stream);

@@ -62,6 +62,7 @@ def main():
         assert not b0.active and b0.launched == 0
         os.environ["UNIT_FORCE_COLLECTIVES"] = "1"
         cases = [("allreduce", {}), ("rs_ag", dict(reduce_mode="rs_ag", bucket_bytes=3 << 20)), ("direct", dict(reduce_mode="direct", bucket_bytes=5 << 20)),
+                 ("cabi", dict(reduce_mode="cabi", bucket_bytes=7 << 20)),          # RCCL through the library's own comm exports (csrc/comm.hip)
                  ("direct_bf16_buckets", dict(reduce_mode="direct", bf16_buckets=True)), ("allreduce_bf16_buckets", dict(bf16_buckets=True))]
         if dname == "fp32":
             cases += [("graph_per_bucket", dict(use_graph=True, graph_per_bucket=True)), ("graph_whole", dict(use_graph=True, graph_per_bucket=False)),
@@ -74,6 +75,22 @@ def main():
                 "bit_equal": bool(torch.equal(p, ref_p)), "max_abs_diff": float((p - ref_p).abs().max()),
                 "max_abs_diff_step1": float((first - ref_first).abs().max()), "loss_diff": float((l - ref_l).abs().max()),
                 "launched": b.launched, "describe": d, "graph_segments": nseg, "finite": bool(torch.isfinite(p).all())}
+    # the comm exports on their own: id -> communicator -> in-place sum of a bucket on a side stream -> event hand-off -> destroy
+    from unit_amd import parallel, _lib
+    comm = parallel.CAbiComm(0, 1, parallel.CAbiComm.unique_id())
+    side = torch.cuda.Stream()
+    a = torch.randn(1 << 20, device="cuda")
+    b = a.to(torch.bfloat16)
+    a0, b0c = a.clone(), b.clone()
+    side.wait_stream(torch.cuda.current_stream())
+    comm.all_reduce_(a, side)
+    comm.all_reduce_(b, side)
+    parallel.CAbiComm.wait(torch.cuda.current_stream(), side)
+    a.mul_(2.0)                                       # ordered behind the collective by the hand-off
+    torch.cuda.synchronize()
+    res["cabi"] = {"fp32_identity": bool(torch.equal(a, a0 * 2.0)), "bf16_identity": bool(torch.equal(b, b0c)),
+                   "rccl_version": int(_lib.lib().unit_comm_rccl_version())}
+    comm.close()
     json.dump(res, open(out, "w"))
     dist.destroy_process_group()
 

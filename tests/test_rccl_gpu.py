@@ -36,7 +36,15 @@ def test_rccl_is_the_backend(dev, result):
     assert d["backend"].startswith("rccl") and d["ranks_seen"] == 1 and d["collectives_forced_at_world_1"] and d["rccl_version"]
 
 
-@pytest.mark.parametrize("case", ["allreduce", "rs_ag", "direct", "graph_per_bucket", "graph_whole", "graph_per_bucket_direct", "tail_overlap"])
+def test_comm_exports_of_the_c_abi(dev, result):
+    """unit_comm_unique_id / unit_comm_init / unit_allreduce_bucket_async / unit_comm_wait / unit_comm_destroy (csrc/comm.hip): RCCL
+    resolved by dlopen, a one-rank communicator, an fp32 and a bf16 bucket summed in place on a side stream (= the identity), the compute
+    stream ordered behind them by the event hand-off; and the same binding as the step's exchange (`reduce_mode="cabi"`, below)"""
+    c = result["cabi"]
+    assert c["fp32_identity"] and c["bf16_identity"] and c["rccl_version"] >= 20000, c
+
+
+@pytest.mark.parametrize("case", ["allreduce", "rs_ag", "direct", "cabi", "graph_per_bucket", "graph_whole", "graph_per_bucket_direct", "tail_overlap"])
 def test_forced_collectives_fp32_buckets_are_the_identity(dev, result, case):
     """fp32 buckets through RCCL at world 1: launched from the weight-gradient stream inside the backward, waited for by the optimizer's
     stream -- parameters after 4 steps BIT-equal to the run without any collective (a missing stream dependency would show as a torn
@@ -51,7 +59,7 @@ def test_forced_collectives_fp32_buckets_are_the_identity(dev, result, case):
         if case == "graph_per_bucket":
             assert c["graph_segments"] >= 4
         if case != "allreduce":
-            assert c["describe"]["reduce_mode"] == ("direct" if "direct" in case else "rs_ag" if case == "rs_ag" else "allreduce")
+            assert c["describe"]["reduce_mode"] == ("direct" if "direct" in case else case if case in ("rs_ag", "cabi") else "allreduce")
 
 
 @pytest.mark.parametrize("case", ["allreduce_bf16_buckets", "direct_bf16_buckets"])

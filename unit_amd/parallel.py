@@ -27,7 +27,52 @@ import os
 
 import torch.distributed as dist
 
-MODES = ("allreduce", "rs_ag", "direct")
+MODES = ("allreduce", "rs_ag", "direct", "cabi")
+
+
+class CAbiComm:
+    """RCCL through the library's own comm exports (csrc/comm.hip: unit_comm_unique_id / unit_comm_init / unit_allreduce_bucket_async / unit_comm_wait)
+    -- what a host without torch.distributed binds. `GradBuckets(mode="cabi")` exchanges its buckets through it; the 128-byte id
+    travels from rank 0 to the others over whatever the host has (here: the torch.distributed group that exists anyway, a broadcast of one tensor)."""
+    ID_BYTES = 128
+
+    @staticmethod
+    def unique_id():
+        import ctypes
+        from ._lib import check, lib
+        buf = ctypes.create_string_buffer(CAbiComm.ID_BYTES)
+        check(lib().unit_comm_unique_id(buf, CAbiComm.ID_BYTES), "unit_comm_unique_id")
+        return buf.raw
+
+    def __init__(self, rank, world, uid):
+        import ctypes
+        from ._lib import check, lib
+        assert len(uid) == self.ID_BYTES
+        self.rank, self.world = rank, world
+        h = ctypes.c_void_p()
+        check(lib().unit_comm_init(rank, world, ctypes.create_string_buffer(uid, self.ID_BYTES), self.ID_BYTES, ctypes.byref(h)), "unit_comm_init")
+        self.handle = h
+
+    def all_reduce_(self, t, stream):
+        """t (1-D fp32 / bf16, contiguous) <- sum over the ranks, in place, enqueued on the torch stream `stream`"""
+        import ctypes
+        import torch
+        from ._lib import check, lib
+        assert t.is_contiguous() and t.dtype in (torch.float32, torch.bfloat16)
+        check(lib().unit_allreduce_bucket_async(self.handle, ctypes.c_void_p(t.data_ptr()), t.numel(), 0 if t.dtype == torch.float32 else 1,
+                                                ctypes.c_void_p(stream.cuda_stream)), "unit_allreduce_bucket_async")
+
+    @staticmethod
+    def wait(compute_stream, comm_stream):
+        import ctypes
+        from ._lib import check, lib
+        check(lib().unit_comm_wait(ctypes.c_void_p(compute_stream.cuda_stream), ctypes.c_void_p(comm_stream.cuda_stream)), "unit_comm_wait")
+
+    def close(self):
+        from ._lib import check, lib
+        if self.handle is not None:
+            check(lib().unit_comm_destroy(self.handle), "unit_comm_destroy")
+            self.handle = None
 
 
 class _Widen:
@@ -97,6 +142,7 @@ class GradBuckets:
         self._plan = None
         self._recv = {}                 # "direct": receive buffers of the all-to-all, keyed by (elements, dtype)
         self._comm_stream = None        # the stream a bucket's collectives are enqueued on (see _collective_stream)
+        self._cabi = None               # mode "cabi": the CAbiComm of this process
         # WHERE the RCCL kernels run. torch.distributed's nccl backend enqueues a collective with async_op=False on the caller's CURRENT stream
         # and one with async_op=True on a stream of its own (tools/nccl_stream_probe.py under rocprofv3, torch 2.10). A process's HIP streams
         # share 4 hardware queues, and that internal stream lands on whichever queue the runtime deals it: in the traced
@@ -187,7 +233,10 @@ class GradBuckets:
         cs.wait_stream(torch.cuda.current_stream())          # the bucket's gradients are final where the caller stands
         t.record_stream(cs)
         with torch.cuda.stream(cs):
-            if self.mode == "allreduce" or n < w:
+            if self.mode == "cabi":          # the library's own RCCL binding (CAbiComm above), same stream placement
+                self._cabi_comm(t.device).all_reduce_(t, cs)
+                self.launched += 1
+            elif self.mode == "allreduce" or n < w:
                 dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
                 self.launched += 1
             else:
@@ -220,10 +269,24 @@ class GradBuckets:
             ev.record()
         return _EventWork(ev)
 
+    def _cabi_comm(self, device):
+        """the communicator of mode "cabi", created at the first bucket: rank 0's id goes round as one uint8 tensor over the existing group"""
+        if self._cabi is None:
+            import torch
+            uid = torch.zeros(CAbiComm.ID_BYTES, dtype=torch.uint8, device=device)
+            if self.rank == 0:
+                uid.copy_(torch.frombuffer(bytearray(CAbiComm.unique_id()), dtype=torch.uint8))
+            if self.world > 1:
+                dist.broadcast(uid, 0, group=self.group)
+            self._cabi = CAbiComm(self.rank, self.world, bytes(uid.cpu().numpy().tobytes()))
+        return self._cabi
+
     def _exchange(self, t):
         """launch the exchange of the 1-D tensor `t` (summed over the ranks, in place); -> work handle. Ordered after the CURRENT
         stream; nothing here blocks the host or the current stream."""
         cs = self._collective_stream(t.device)
+        if self.mode == "cabi" and cs is None:
+            raise RuntimeError('GradBuckets mode "cabi" enqueues on a stream of ours: collective_stream "rpn" or "own", device buckets')
         if cs is not None:
             return self._exchange_placed(t, cs)
         n, w, r = t.numel(), self.world, self.rank
