@@ -53,7 +53,7 @@ def parse():
                     "overlap the next step's frozen layers instead of joining the weight-gradient stream first "
                     "(GeneralizedRCNN.overlap_optimizer_tail; measured 119.3 vs 121.4 images/s at N=1: off by default)")
     ap.add_argument("--bucket-mb", type=float, default=None, help="gradient bucket size in MB (parallel.GradBuckets; default 64 / UNIT_BUCKET_MB)")
-    ap.add_argument("--reduce-mode", default=None, choices=["allreduce", "rs_ag", "direct"], help="how a gradient bucket crosses xGMI: one all-reduce "
+    ap.add_argument("--reduce-mode", default=None, choices=["allreduce", "rs_ag", "direct", "cabi"], help="how a gradient bucket crosses xGMI (cabi = one all-reduce through the library's own RCCL binding): one all-reduce "
                     "(default), reduce-scatter + all-gather in place, or all-to-all + ordered owner-side sum + all-gather (all 7 links at once, "
                     "bit-reproducible); parallel.py")
     ap.add_argument("--bf16-buckets", action="store_true", help="exchange bf16 copies of the gradient buckets (half the bytes)")
