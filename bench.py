@@ -44,6 +44,12 @@ def parse():
     ap.add_argument("--graph", action="store_true", help="capture the whole step in a hipGraph and replay it (engine.GraphedStep; "
                     "N > 1: two graphs around one eager all-reduce of the flat gradient buffer). Measured at N=1: host enqueue per step "
                     "drops, the device runs the replay ~2.5 %% slower than the eager four-stream schedule: off by default")
+    ap.add_argument("--launch", default=None, choices=["replay", "eager", "graph"], help="how the step's ~650 launches reach the device: replay "
+                    "(default: engine.ReplayedStep -- the eager step's C-ABI call sequence recorded once per batch key and re-issued by one C call per "
+                    "segment, csrc/replay.hip: the eager four-stream schedule without the interpreter), eager (Python issues every launch), graph "
+                    "(= --graph: hipGraph replay)")
+    ap.add_argument("--sustain-steps", type=int, default=300, help="N=1: after the timed region the same step runs this many more times and the last "
+                    "two thirds are timed (`sustained_images_per_sec`: held clocks next to the burst figure); 0 = skip")
     ap.add_argument("--early-update", action="store_true", help="per-bucket optimizer updates beside the backward instead of one "
                     "update after it (engine.EarlyUpdate; measured 18.56 vs 18.43 ms per step: off by default)")
     ap.add_argument("--high-priority", action="store_true", help="run the steps on a high-priority HIP stream instead of PyTorch's default stream "
@@ -118,6 +124,18 @@ def pick_exchange(table):
         return None
     best = min(ok)
     return table[best[1]]
+
+
+def launch_mode(args):
+    """replay | eager | graph for this run: --graph and the modes that need Python inside the step (early update, tail overlap, the single-stream
+    profiling run) keep their form; everything else replays the recorded call list"""
+    if args.graph:
+        return "graph"
+    if args.launch:
+        return args.launch
+    if args.early_update or args.tail_overlap:
+        return "eager"
+    return "replay"
 
 
 def launch_ranks(args):
@@ -447,9 +465,13 @@ def voc_shapes_run(args, cfg, model, buckets, opt, rank, world, dev):
         weak = [synthetic_batch(0, 1, hw=hw, seed=1000 * rank + 10 * i + 5 + j)[1][0] for j, hw in enumerate(weak_hw)]
         packed.append(model.pack_batch(sup, weak, gt_buckets=(8, 16, 32)))          # resident in HBM before the timed region
     gs = None
-    if args.graph:
+    mode = launch_mode(args)
+    if mode == "graph":
         from unit_amd.engine import GraphedStep
         gs = GraphedStep(model, opt, warmup_steps=2, buckets=buckets)
+    elif mode == "replay":
+        from unit_amd.engine import ReplayedStep
+        gs = ReplayedStep(model, opt, warmup_steps=2, buckets=buckets)
 
     def run(b):
         if gs is not None:
@@ -500,7 +522,7 @@ def voc_shapes_run(args, cfg, model, buckets, opt, rank, world, dev):
         out = {"metric": "images/sec (fwd+bwd+SGD) R101-C4 VOC, multi-scale VOC-shaped batches (SECONDARY line, not BASELINE.json's metric)",
                "headline": False, "value": round(2 * world * steps / dt, 3), "unit": "images/sec", "n_gpus": world, "steps": steps, "warmup": warm,
                "ms_per_step": round(dt / steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype,
-               "data": "synthetic", "launch": "hipGraph replay per batch key" if gs else "eager", "host_enqueue_ms_per_step": round(host_ms, 3),
+               "data": "synthetic", "launch": {"graph": "hipGraph replay per batch key", "replay": "call-list replay per batch key (engine.ReplayedStep)", "eager": "eager"}[mode], "host_enqueue_ms_per_step": round(host_ms, 3),
                "host_enqueue_ms_from_idle_device": round(host_idle_ms, 3),
                "dist": buckets.describe(), "build_hash": _lib.build_hash(),
                "config": {"workload": f"UniT base-training step S1, ResNet-{args.depth}-C4, 2 supervised + 2 weak images per GPU whose sizes change every "
@@ -697,12 +719,20 @@ def main():
         torch.cuda.set_stream(model.high_priority_stream())          # the step's main chain ahead of the side streams it forks (rcnn.py)
 
     timed_step = one_step
-    if args.graph and early is None:
+    mode = launch_mode(args) if early is None else "eager"
+    gs = None
+    if mode == "graph":
         from unit_amd.engine import GraphedStep
         gs = GraphedStep(model, opt, warmup_steps=max(1, args.warmup - 2), buckets=buckets)      # the last warm-up steps already replay the graph
         timed_step = lambda: gs.run(packed=batch)
-    for _ in range(max(args.warmup, 3 if args.graph else 0)):
+    elif mode == "replay":
+        from unit_amd.engine import ReplayedStep
+        gs = ReplayedStep(model, opt, warmup_steps=max(1, args.warmup - 3), buckets=buckets)     # eager steps, one recorded step, then replays
+        timed_step = lambda: gs.run(packed=batch)
+    for _ in range(max(args.warmup, 4 if gs is not None else 0)):
         timed_step()
+    if gs is not None:
+        assert gs.stats["replayed"] > 0 or args.warmup < 4, gs.stats          # the timed region measures the mode the line names
     buckets.exposed_events = [] if buckets.active else None          # two event records per step around the bucket waits
     buckets.exposed_per_bucket = [] if (buckets.active and world > 1) else None
     if world > 1:
@@ -717,6 +747,33 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    # the host's OWN share of a step: the same step enqueued onto an IDLE device (synchronize before, clock stopped before anything is waited
+    # for). `host_enqueue_ms_per_step` below is the timed region's figure and includes queue back-pressure: the runtime's queues hold a few
+    # steps' worth of launches, after that the host enqueues at the pace the device retires them -- whenever the device is the slower side
+    # that figure tends to the device's time per step, whatever the host needs.
+    idle = []
+    for _ in range(8 if world == 1 else 0):
+        torch.cuda.synchronize()
+        ti = time.perf_counter()
+        timed_step()
+        idle.append(time.perf_counter() - ti)
+    torch.cuda.synchronize()
+    host_idle_ms = sorted(idle)[len(idle) // 2] * 1e3 if idle else None
+    # sustained clocks: the timed region is a burst of `steps` x ~15 ms from a cool chip; the same step for a few seconds more, timed over its
+    # tail (the driver line carries both figures). N = 1 only: no collective may differ between ranks' loop counts.
+    sustained = None
+    if world == 1 and args.sustain_steps > 0:
+        k_sus = args.sustain_steps
+        for _ in range(k_sus // 3):
+            timed_step()
+        torch.cuda.synchronize()
+        ts = time.perf_counter()
+        for _ in range(k_sus - k_sus // 3):
+            timed_step()
+        torch.cuda.synchronize()
+        ms_sus = (time.perf_counter() - ts) / (k_sus - k_sus // 3) * 1e3
+        sustained = {"images_per_sec": round(2e3 / ms_sus, 2), "ms_per_step": round(ms_sus, 3), "steps_timed": k_sus - k_sus // 3,
+                     "steps_before": args.warmup + args.steps + len(idle) + k_sus // 3}
     exposed_ms = 0.0
     if buckets.exposed_events:
         exposed_ms = sum(a.elapsed_time(b) for a, b in buckets.exposed_events) / args.steps
@@ -830,9 +887,14 @@ def main():
                       f"SECONDARY images/sec (fwd+bwd+SGD) R{args.depth}-C4 VOC 600x1000 bs=2/GPU" + (" (BASELINE.json config 2)" if args.depth == 50 else ""),
             "value": round(value, 3), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": args.dtype, "data": "synthetic", "launch": ("hipGraph replay" if world == 1 else "hipGraph replay (one graph per gradient-bucket stage, the bucket all-reduces launched between the replays | optimizer graph)") if (args.graph and early is None) else "eager",
+            "dtype": args.dtype, "data": "synthetic", "launch": {"graph": ("hipGraph replay" if world == 1 else "hipGraph replay (one graph per gradient-bucket stage, the bucket all-reduces launched between the replays | optimizer graph)"),
+                                                                     "replay": "call-list replay (engine.ReplayedStep: the eager step's C-ABI calls recorded once, re-issued by unit_replay" + ("" if world == 1 else "; the buckets' collectives launched live between its segments") + ")",
+                                                                     "eager": "eager"}[mode],
+            "launch_stats": (dict(gs.stats) if gs is not None else None),
             "dist": dict(buckets.describe(), tuning=tuning, exposed_ms_per_bucket_tag=per_bucket), "build_hash": _lib.build_hash(),
-            "host_enqueue_ms_per_step": round(host_ms, 3),      # max over ranks
+            "host_enqueue_ms_per_step": round(host_ms, 3),      # max over ranks; timed region, includes queue back-pressure (see host_enqueue_ms_from_idle_device)
+            "host_enqueue_ms_from_idle_device": (round(host_idle_ms, 3) if host_idle_ms is not None else None),      # the host's own cost of one step
+            "sustained_images_per_sec": (sustained["images_per_sec"] if sustained else None), "sustained": sustained,
             "allreduce_exposed_ms": round(exposed_ms, 3),       # max over ranks: compute-stream time inside GradBuckets.finish() per step
             "config": {"workload": f"UniT base-training step {args.variant.upper()} (TrainerNoMeta.run_step): ResNet-{args.depth}-C4, "
                                    f"VOC split1 K=20, 2 supervised + {n_weak} weak 3x600x1000 images per GPU, 512 RoIs/image, "

@@ -423,6 +423,26 @@ int unit_paste_masks(const float* probs, const float* boxes, const unsigned char
 int unit_sgd_momentum(float* p, const float* g, float* buf, long n, float lr, float momentum, float wd, float grad_scale,
                       int first_step, const float* lr_dev, void* stream);
 
+/* ---- the step's launch sequence as a call list walked in C (csrc/replay.hip; unit_amd/_lib.py Recorder, engine.ReplayedStep) ----
+ * The reference's step is `loss_dict = self.model(data, ...); losses.backward(); self.optimizer.step()` (engine/defaults.py:279-284):
+ * ~650 operator launches issued one by one from Python. Here the sequence of C-ABI calls of one eagerly executed step (a constant for
+ * a given batch key: the step has no host sync and no data-dependent host branch) is recorded and re-issued by ONE call per segment:
+ * same launches, same in-order streams, same schedule as eager -- minus the interpreter. calls = [n] records of unit_call_bytes() each:
+ * {void* fn; int n_int, n_flt; long long i[32]; float f[8]} = a function of this header, its integer-class arguments (ints, sizes,
+ * pointers) and its float arguments in declaration order (x86-64 SysV: the two classes travel in separate register files). Every
+ * pointer in the list must stay valid and every shape unchanged between replays (the recorder pins the recorded step's allocations
+ * in a private memory pool and keeps the host structs alive). *failed = index of the first call that did not return 0, or -1. */
+size_t unit_call_bytes(void);
+int unit_replay(const void* calls, int n, int* failed);
+/* hipEventRecord / hipStreamWaitEvent on a caller-owned hipEvent_t: what torch.cuda.Event.record / .wait do, as list entries */
+int unit_event_record_raw(void* event, void* stream);
+int unit_stream_wait_event_raw(void* stream, void* event);
+/* host-only self-test of the generic call (tests/test_replay_cpu.py): out[0] = sum of (i + 1) * i-th integer-class argument,
+ * out[1] = the four floats x 1000, packed in decimal */
+int unit_replay_selftest(int a0, const void* p1, float f0, long a2, int a3, float f1, int a4, int a5, size_t a6, int a7, int a8, float f2,
+                         int a9, int a10, int a11, int a12, int a13, int a14, int a15, int a16, int a17, int a18, int a19, int a20,
+                         int a21, int a22, int a23, int a24, int a25, int a26, float f3, int a27, long long* out);
+
 #ifdef __cplusplus
 }
 #endif

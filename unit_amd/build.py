@@ -18,7 +18,7 @@ CSRC = os.path.join(HERE, "csrc")
 OUT_DIR = os.path.join(HERE, "_build")
 LIB = os.path.join(OUT_DIR, "libunit_hip.so")
 HEADER = os.path.join(os.path.dirname(HERE), "include", "unit_hip.h")
-SOURCES = ["elementwise.hip", "input_pipeline.hip", "boxes.hip", "sort_nms.hip", "roi_align.hip", "losses.hip", "conv_igemm.hip", "conv_igemm256.hip", "conv_igemm256p8.hip", "conv_igemm256p8m.hip", "conv_igemm128.hip", "conv_igemm_lc.hip", "conv_wgrad.hip", "conv_wgrad256.hip", "conv_wgrad256p8.hip", "conv_wgrad256r.hip", "conv_wgrad128r.hip", "linear_wgrad.hip", "stem_pool.hip", "detect.hip", "mask.hip", "multi.hip", "split.hip", "comm.hip"]
+SOURCES = ["elementwise.hip", "input_pipeline.hip", "boxes.hip", "sort_nms.hip", "roi_align.hip", "losses.hip", "conv_igemm.hip", "conv_igemm256.hip", "conv_igemm256p8.hip", "conv_igemm256p8m.hip", "conv_igemm128.hip", "conv_igemm_lc.hip", "conv_wgrad.hip", "conv_wgrad256.hip", "conv_wgrad256p8.hip", "conv_wgrad256r.hip", "conv_wgrad128r.hip", "linear_wgrad.hip", "stem_pool.hip", "detect.hip", "mask.hip", "multi.hip", "split.hip", "comm.hip", "replay.hip"]
 STAMP = "build_stamp.hip"
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-ffp-contract=off", "-std=c++17", "-Wno-unused-value"]
 

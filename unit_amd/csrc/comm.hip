@@ -11,6 +11,8 @@
 // between that stream and the compute stream (the same primitive as unit_stream_wait_stream). No hidden allocation: RCCL's own buffers are its own.
 #include <dlfcn.h>
 
+#include <mutex>
+
 #include "common.h"
 
 extern "C" int unit_stream_wait_stream(void* waiter, void* signaller);          // multi.hip
@@ -32,8 +34,7 @@ struct Rccl {
 };
 Rccl g_rccl;
 
-int rccl_load() {
-  if (g_rccl.h) return UNIT_OK;
+int rccl_load_once() {
   const char* names[] = {"librccl.so", "librccl.so.1"};
   void* h = nullptr;
   for (const char* n : names) { h = dlopen(n, RTLD_NOW | RTLD_NOLOAD); if (h) break; }          // the copy the host process already runs on
@@ -52,8 +53,18 @@ int rccl_load() {
   return UNIT_OK;
 }
 
+// two host threads may make their first comm call at the same time: the table is filled exactly once, later callers read a complete
+// table (a failed load is remembered with its message re-set for every caller) -- ADVICE r05
+int rccl_load() {
+  static std::once_flag once;
+  static int status = UNIT_ERR_UNSUPPORTED;
+  std::call_once(once, [] { status = rccl_load_once(); });
+  if (status != UNIT_OK) unit_set_error("unit_comm: librccl.so could not be loaded (dlopen) or lacks the NCCL entry points");
+  return status;
+}
+
 int rccl_fail(int rc, const char* what) {
-  static char buf[256];
+  thread_local char buf[256];
   snprintf(buf, sizeof(buf), "%s: %s", what, g_rccl.err ? g_rccl.err(rc) : "RCCL error");
   unit_set_error(buf);
   return UNIT_ERR_LAUNCH;

@@ -266,9 +266,74 @@ class GraphedStep:
         return ent[2]
 
 
+class ReplayedStep(GraphedStep):
+    """One whole training step as a CALL LIST walked in C (csrc/replay.hip, _lib.Recorder): the second step of a batch key runs eagerly
+    with every enqueueing C-ABI call and every event record / wait noted down -- function address + argument words -- and every later step
+    of the key re-issues that list: the SAME launches on the SAME four in-order streams as the eager schedule (a hipGraph of the step
+    orders its nodes with barrier packets and takes the device 0.5 - 0.9 ms longer per step), at the host cost of the
+    runtime's launch calls alone. Everything GraphedStep says about what makes the step replayable applies (no host sync or data-dependent
+    host branch, device-resident sampling RNG / learning rate / counts, static input buffers refilled per step, one plan per batch key, a
+    key's first step eager). What a hipGraph's private pool does for a capture, a torch.cuda.MemPool does for the recording: every
+    allocation of the recorded step comes from it, blocks that were handed to other streams (record_stream) are not recycled inside the
+    step, and nothing else allocates from it afterwards -- the addresses in the list stay the step's own.
+    Data parallel: a bucket's collective launch (`model.on_grad_ready` -> GradBuckets.ready) is live Python BETWEEN two segments of the
+    list, issued at the very point of the backward where the eager step issues it (no stream joins at the cuts: nothing is captured), then
+    GradBuckets.finish(), then the optimizer's segment. Ranks may disagree about eager vs replay: both forms issue the same collectives."""
+
+    def __init__(self, model, optimizer, warmup_steps=2, buckets=None):
+        super().__init__(model, optimizer, warmup_steps=warmup_steps, buckets=buckets, per_bucket=True)
+        self.plans = {}          # key -> (CallList, static PackedBatch, losses tensor)
+        self.mempool = None
+
+    def _record(self, static):
+        from ._lib import Recorder
+        torch = self._torch
+        model = self.model
+        if self.mempool is None:
+            self.mempool = torch.cuda.MemPool()
+        hook = model.on_grad_ready
+        with torch.cuda.use_mem_pool(self.mempool), Recorder() as rec:
+            if hook is not None:
+                model.on_grad_ready = lambda tag: rec.py(lambda: hook(tag))
+            try:
+                losses = self._fwd_bwd(static)
+            finally:
+                model.on_grad_ready = hook
+            if self.buckets is not None:
+                rec.py(self.buckets.finish)
+            self.optimizer.step()
+        return rec.finish(), losses
+
+    def run(self, base_data=None, classifier_data=None, packed=None):
+        model, opt = self.model, self.optimizer
+        fresh = packed if packed is not None else model.pack_batch(base_data, classifier_data, gt_buckets=self.GT_BUCKETS)
+        opt._bind()
+        opt.use_device_lr(model.device)
+        key = fresh.key()
+        if self.eager_left > 0 or key not in self.seen:
+            self.eager_left = max(0, self.eager_left - 1)
+            self.seen.add(key)
+            self.stats["eager"] += 1
+            return self._body(fresh)
+        ent = self.plans.get(key)
+        if ent is None:
+            self.stats["captured"] += 1
+            static = fresh.clone()
+            plan, losses = self._record(static)          # the recording IS this iteration's step (it ran for real)
+            self.plans[key] = (plan, static, losses)
+            return losses
+        self.stats["replayed"] += 1
+        self._refill(ent[1], fresh)
+        ent[0].run()
+        opt.iter += 1
+        opt._first = False
+        return ent[2]
+
+
 class TrainerNoMeta:
     def __init__(self, cfg, model, data_iter=None, weak_data_iter=None, group=None, early_update=False, bf16_buckets=False,
-                 use_graph=False, overlap_tail=False, graph_per_bucket=True, high_priority=False, reduce_mode=None, bucket_bytes=None):
+                 use_graph=False, overlap_tail=False, graph_per_bucket=True, high_priority=False, reduce_mode=None, bucket_bytes=None,
+                 use_replay=False):
         """overlap_tail: the end of a step (last weight gradients, all-reduce waits, SGD, weight re-preparation) stays on the model's
         weight-gradient stream and overlaps the next step's preprocessing / frozen layers (GeneralizedRCNN.overlap_optimizer_tail);
         read parameters between steps only after model.join_optimizer_tail() (state_dict() does it)."""
@@ -294,6 +359,9 @@ class TrainerNoMeta:
         self.fixed_permutations = None
         self.early = EarlyUpdate(model, self.buckets, self.optimizer) if early_update else None
         self.graphed = GraphedStep(model, self.optimizer, buckets=self.buckets, per_bucket=graph_per_bucket) if (use_graph and not early_update) else None
+        if use_replay and not early_update and not use_graph and not overlap_tail:
+            # the step's launches from a recorded call list (ReplayedStep): the eager schedule at ~1/6 of its host cost
+            self.graphed = ReplayedStep(model, self.optimizer, buckets=self.buckets)
 
     def run_step(self, base_data=None, classifier_data=None):
         assert self.model.training, "[TrainerNoMeta] model was changed to eval mode!"

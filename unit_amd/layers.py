@@ -568,7 +568,23 @@ class LinearGroup:
         r = x2d.shape[0]
         gw, gb = self._fused_views("grad")
         trainable = any(m.weight.requires_grad for m in self.members)
-        if trainable:
+        if trainable and ops.WGRAD_DIRECT and ops.WGRAD_ACCUMULATE:
+            # module-level training (modeling/train_modules.py): torch semantics -- a second backward before zero_grad(), or the reference's
+            # per-image RPN calls (rcnn.py:601), ADD to .grad like the convs' direct weight gradients do
+            tmp = ops.conv2d_wgrad(x2d.view(r, 1, 1, self.cin), dy2d.view(r, 1, 1, self.kp), self.kp, 1, 1).view(self.kp, self.cin)
+            tb = ops.bias_grad(dy2d, self.k)
+            for m, c in zip(self.members, self.cols):
+                if m.weight.requires_grad:
+                    gw_m = tmp[c:c + m.out_features].reshape(m.weight.shape)
+                    if m.weight.grad is None:
+                        m.weight.grad = gw_m.clone()
+                    else:
+                        m.weight.grad.add_(gw_m)
+                    if m.bias.grad is None:
+                        m.bias.grad = tb[c:c + m.out_features].clone()
+                    else:
+                        m.bias.grad.add_(tb[c:c + m.out_features])
+        elif trainable:
             if gw is not None and _LINEAR_WGRAD and x2d.dtype == torch.bfloat16 and self.kp <= 128 and self.cin % 128 == 0:
                 ops.linear_wgrad(x2d, dy2d, self.k, gw, gb)       # rows [k, kp) of the view belong to other parameters: not written
             elif gw is not None:

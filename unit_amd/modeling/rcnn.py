@@ -918,11 +918,20 @@ class WeaklySupervisedRCNNNoMeta(nn.Module):
         """small host-built constants of the step (image sizes, slot tables) are uploaded once per distinct value: no pageable
         host-to-device copy inside the step -- which a hipGraph capture of the step could not contain"""
         cache = self.__dict__.setdefault("_dev_consts", {})
-        t = cache.get(key)
+        t = cache.pop(key, None)
         if t is None or t.device != self.device:
+            # bounded (ADVICE r05): evaluating a dataset of varied image sizes meets a new (sizes, output sizes) combination per batch.
+            # Least-recently-USED eviction; once captured graphs / recorded call lists may hold an entry's address, an evicted tensor is
+            # parked like an outgrown workspace instead of being freed (the anchor grids: rpn.DefaultAnchorGenerator.grid)
+            if len(cache) >= self.CONST_CACHE_CAP:
+                old = cache.pop(next(iter(cache)))
+                if ops._GRAPHS_ALIVE[0]:
+                    ops._WS_RETIRED.append(old)
             t = make().to(self.device)
-            cache[key] = t
+        cache[key] = t          # (re-)inserted at the back: most recently used
         return t
+
+    CONST_CACHE_CAP = 256          # entries are a few bytes to a few KB each
 
     def _sizes_on_device(self, sizes):
         return self._const_on_device(("hw", tuple(sizes)), lambda: torch.tensor(sizes, dtype=torch.float32))

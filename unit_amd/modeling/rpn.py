@@ -147,6 +147,11 @@ class WSRPN(nn.Module):
 
     # ---- plugin surface (rpn.py:20) on NCHW fp32 features: eval = proposal generation; training = losses + proposals as an autograd node
     def forward(self, images, features, gt_instances=None, loss_weights=None):
+        if loss_weights is not None:
+            # rpn.py:44 / :64: a loss_weights argument switches WSRPN.losses to UNREDUCED per-anchor losses (reduction="none"), consumed by
+            # the meta-attention architectures only (out of scope); TrainerNoMeta / TrainerFineTune never pass it
+            # (rcnn.py:463, :601). Dropping it silently would hand back reduced, unweighted losses.
+            raise NotImplementedError("WSRPN.forward(loss_weights=...): unreduced RPN losses are not part of the C4 training path")
         if self.training:
             # rpn.py:20-53 in training, as ONE autograd node over the RPN's explicit forward / backward (modeling/train_modules.py): losses
             # when gt_instances are given (:41-46), proposals when images are (:48-52; PRE / POST_NMS_TOPK_TRAIN)

@@ -237,11 +237,13 @@ class _HeadsFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, gl):
-        _check_unit_weights(gl, "WSROIHeadNoMeta")
         rh = ctx.rh
         bp, wh = rh.box_predictor, rh.box_predictor.weak_detector_head
         n_sup, n_weak, rs, rw, fshape, fwshape, multi, rows = ctx.geo
         box_feat, wfeat_all, box_ctx, weak_ctx, dy_sup, dy_weak, rois = ctx.saved
+        # only the losses that were handed out carry a weight: without a weak batch (rcnn.py:456-459, :644 -- weak_features None) the caller
+        # got the two supervised losses, the four weak slots of the vector are unused zeros whose incoming gradient is 0
+        _check_unit_weights(gl if dy_weak is not None else gl[:2], "WSROIHeadNoMeta")
         g = gw = None
         with _direct_grads():
             dbox = bp.group.bwd(box_feat, dy_sup, need_dx=True)

@@ -897,7 +897,7 @@ def conv2d_x3(x, w, k, r, s, stride=1, pad=0, bias=None, residual=None, mask_ref
 
 
 def weight_prep_x3(w_krsc, scale, k, r, s, c, want_fwd=True, want_dgrad=True, w_fwd=None, w_dgrad=None):
-    """fp32 [k][r][s][c] storage -> (bf16 [k][r][s][c/64][3][64], bf16 [c][r][s][k/64][3][64]) = the k-segments [Wh | Wl | Wh] of the bf16x3
+    """fp32 [k][r][s][c] storage -> (bf16 [k][r][s][c/64][3][64], bf16 [c][r][s][k/64][3][64]) = the k-segments [Wh | Wh | Wl] of the bf16x3
     convs (forward: c % 64 == 0; dgrad: k % 64 == 0; either may be skipped)"""
     dev = w_krsc.device
     if want_fwd and w_fwd is None:

@@ -409,6 +409,40 @@ class GradBuckets:
         self._work_tags = []
         self._tag_works = {}
 
+    def close(self):
+        """release what this object created outside torch.distributed: the RCCL communicator of mode "cabi" (ncclCommDestroy). Call it
+        before `dist.destroy_process_group()` / at the end of training; harmless to call twice or in the other modes."""
+        if self._cabi is not None:
+            self._cabi.close()
+            self._cabi = None
+
     @property
     def grad_scale(self):
         return 1.0 / self.world
+
+
+def allreduce_module_grads(model, group=None, average=True):
+    """Data parallelism for the MODULE-LEVEL training surface (modeling/train_modules.py) under a trainer that is not this package's:
+    the explicit backward of those nodes writes parameter gradients straight into `.grad`, the parameters themselves never pass through
+    autograd -- so torch's DistributedDataParallel (the reference: engine/defaults.py:256), whose reducer listens to autograd's per-parameter
+    accumulation hooks, never sees them: its buckets are not reduced and the next iteration raises "Expected to have finished reduction"
+    (or, with find_unused_parameters, the ranks silently diverge). Do NOT wrap such a model in DDP: call this after `losses.backward()`
+    and before `optimizer.step()` instead -- one flat all-reduce of every existing `.grad` (coalesced through one buffer per dtype),
+    averaged like DDP's. The fused step (TrainerNoMeta / GradBuckets) does its own overlapped exchange and does not need it."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return 0
+    import torch
+    grads = [p.grad for p in model.parameters() if p.requires_grad and p.grad is not None]
+    n = 0
+    for dtype in {g.dtype for g in grads}:
+        gs = [g for g in grads if g.dtype == dtype]
+        flat = torch.cat([g.reshape(-1) for g in gs])
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+        if average:
+            flat /= dist.get_world_size(group)
+        o = 0
+        for g in gs:
+            g.copy_(flat[o:o + g.numel()].view_as(g))
+            o += g.numel()
+        n += len(gs)
+    return n
