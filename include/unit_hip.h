@@ -124,7 +124,9 @@ int unit_conv2d_fwd_mid(const void* x, const void* w, void* y, const float* bias
  *                                   tile codes (csrc/conv_igemm_lc.hip). C % 64 == 0.
  *   unit_conv2d_wgrad_x3            dW ~ hi^T.hi + hi^T.lo + lo^T.hi: three passes of unit_conv2d_wgrad's bf16 kernels over the planes of split
  *                                   x [N,H,W][2][C] and split dy [M][2][ldy]; 3 * unit_conv2d_wgrad_splits(UNIT_BF16, ...) slabs, workspace
- *                                   3 * unit_conv2d_wgrad_workspace_bytes(UNIT_BF16, ...); dw == NULL leaves the slabs
+ *                                   3 * unit_conv2d_wgrad_workspace_bytes(UNIT_BF16, ...); dw == NULL leaves the slabs. Bits 8-9 of
+ *                                   `variant` = the number of passes to run (0 = all three; 1 = hi^T.hi only: products of the bf16-rounded
+ *                                   operands with fp32 accumulation -- p passes write p * splits slabs)
  *   unit_global_avgpool_x3_fwd      mean over `rows` consecutive rows of a split map [R][rows][2][C] -> fp32 [R][C] (box_head.py:80)
  *   unit_global_avgpool_x3_bwd_relu g = split((y > 0) ? dfeat / rows : 0), y the split forward map */
 int unit_x3_split(const float* x, void* out, long rows, int C, void* stream);
@@ -398,6 +400,13 @@ int unit_deconv2x2_weight_prep(const float* w, int Cin, int Cout, void* w_fwd, v
 int unit_deconv2x2_grad_unpack(const float* dw_gemm, const float* db_gemm, int Cin, int Cout, float* dw, float* db, void* stream);
 int unit_mask_targets(const unsigned char* gt_masks, int Mcap, int Hm, int Wm, const float* rois5, const int* gt_index, const int* cls,
                       int K, int S, int M, unsigned char* out, void* stream);
+/* the same targets from POLYGON ground truth (the reference's COCO-segm yaml leaves INPUT.MASK_FORMAT at "polygon": mask_head.py:34 ->
+ * Detectron2 mask_rcnn_loss -> PolygonMasks.crop_and_resize = rasterize_polygons_within_box -> pycocotools frPyObjects / merge / decode).
+ * poly_xy [V][2] fp64 image coordinates of every polygon vertex; poly_start [P + 1] vertex ranges; inst_start [I + 1] polygon ranges of the
+ * flat instances; image_inst0 [B] flat index of an image's first instance; slot s uses instance image_inst0[rois5[s][0]] + gt_index[s].
+ * Arithmetic = pycocotools' rleFrPoly on the box-relative, M / side scaled vertices (fp64 on the device); cls outside [0, K): zeros. */
+int unit_mask_targets_polygon(const double* poly_xy, const int* poly_start, const int* inst_start, const int* image_inst0,
+                              const float* rois5, const int* gt_index, const int* cls, int K, int S, int M, unsigned char* out, void* stream);
 int unit_mask_bce_loss(const float* logits, int K, int ldk, const int* cls, const unsigned char* targets, int S, int M, float gscale,
                        float* loss, void* dlogits, int d_dtype, void* stream);
 /* training form of the fine-tune mask head (mask_head.py:74-93 with similarity['seg'][fg], roi_heads.py:888-906): gt-class logit =

@@ -201,3 +201,111 @@ int oracle_nms_sorted(const float* boxes, int n, float thresh, int64_t* keep) {
   free(dead);
   return nk;
 }
+
+/* ----------------------------------------------------------------------------------------------
+ * a16 mask targets from POLYGON ground truth. TEST INFRASTRUCTURE ONLY.
+ * /root/reference/modeling/roi_heads/mask_head.py:34 `mask_rcnn_loss(x, instances)` [d2-ext] calls
+ * `instances.gt_masks.crop_and_resize(proposal_boxes, M)`; the reference's COCO-segm yaml sets no INPUT.MASK_FORMAT, so gt_masks are
+ * Detectron2 PolygonMasks (data/dataset_mapper.py:104-106 `annotations_to_instances(..., mask_format=self.mask_format)`), whose
+ * crop_and_resize is `rasterize_polygons_within_box(polygons, box, M)` per instance (detectron2/structures/masks.py):
+ *     w, h = box[2] - box[0], box[3] - box[1]                      (float32, the box is a float32 tensor row)
+ *     p[0::2] -= box[0]; p[1::2] -= box[1]                          (float64 polygons)
+ *     p[0::2] *= M / max(w, 0.1); p[1::2] *= M / max(h, 0.1)        (quotient in float64 of the float32 side: numpy 1.x scalar promotion)
+ *     mask = decode(merge(frPyObjects(polygons, M, M)))             (pycocotools: un-vendored, absent from this image -- "parity unpinned")
+ * pycocotools 2.0.x common/maskApi.c, restated from the published algorithm:
+ *   rleFrPoly: vertices to a 5x finer integer grid (x = (int)(5 * x + .5), C truncation), every edge walked as a dense integer line
+ *   (major axis one step at a time, minor axis rounded half up), the points where the walk changes column give "y-boundary" points
+ *   (column, first row at or below the crossing, on the original grid), their column-major positions are sorted, and consecutive
+ *   differences are the run lengths of an RLE that starts with a run of zeros;   rleMerge(intersect = 0): union;   rleDecode.
+ * This function follows that literally (point lists, qsort, run lengths, decode); the HIP kernel counts crossings per position instead.
+ * xy: all vertices (x, y) of the instance's polygons, poly_start[n_poly + 1] = vertex ranges. out: M x M bytes, row-major [y][x].
+ * ---------------------------------------------------------------------------------------------- */
+static int oracle_uint_cmp(const void* a, const void* b) {
+  unsigned c = *(const unsigned*)a, d = *(const unsigned*)b;
+  return c > d ? 1 : c < d ? -1 : 0;
+}
+
+static void oracle_rle_fr_poly(const double* xy, int k, int h, int w, uint8_t* mask /* column-major h x w, OR-ed into */) {
+  const double scale = 5;
+  int* x = (int*)malloc(sizeof(int) * (k + 1));
+  int* y = (int*)malloc(sizeof(int) * (k + 1));
+  long m = 0;
+  for (int j = 0; j < k; ++j) x[j] = (int)(scale * xy[j * 2 + 0] + .5);
+  x[k] = x[0];
+  for (int j = 0; j < k; ++j) y[j] = (int)(scale * xy[j * 2 + 1] + .5);
+  y[k] = y[0];
+  for (int j = 0; j < k; ++j) {
+    int ax = abs(x[j] - x[j + 1]), ay = abs(y[j] - y[j + 1]);
+    m += (ax > ay ? ax : ay) + 1;
+  }
+  int* u = (int*)malloc(sizeof(int) * (m > 0 ? m : 1));
+  int* v = (int*)malloc(sizeof(int) * (m > 0 ? m : 1));
+  m = 0;
+  for (int j = 0; j < k; ++j) {
+    int xs = x[j], xe = x[j + 1], ys = y[j], ye = y[j + 1], dx, dy, t, d;
+    int flip;
+    double s;
+    dx = abs(xe - xs);
+    dy = abs(ys - ye);
+    flip = (dx >= dy && xs > xe) || (dx < dy && ys > ye);
+    if (flip) { t = xs; xs = xe; xe = t; t = ys; ys = ye; ye = t; }
+    s = dx >= dy ? (double)(ye - ys) / dx : (double)(xe - xs) / dy;
+    if (dx >= dy) for (d = 0; d <= dx; d++) {
+      t = flip ? dx - d : d; u[m] = t + xs; v[m] = (int)(ys + s * t + .5); m++;
+    } else for (d = 0; d <= dy; d++) {
+      t = flip ? dy - d : d; v[m] = t + ys; u[m] = (int)(xs + s * t + .5); m++;
+    }
+  }
+  free(x); free(y);
+  long kk = m;
+  unsigned* a = (unsigned*)malloc(sizeof(unsigned) * (kk + 1));
+  m = 0;
+  for (long j = 1; j < kk; ++j) if (u[j] != u[j - 1]) {
+    double xd = (double)(u[j] < u[j - 1] ? u[j] : u[j] - 1);
+    xd = (xd + .5) / scale - .5;
+    if (floor(xd) != xd || xd < 0 || xd > w - 1) continue;
+    double yd = (double)(v[j] < v[j - 1] ? v[j] : v[j - 1]);
+    yd = (yd + .5) / scale - .5;
+    if (yd < 0) yd = 0; else if (yd > h) yd = h;
+    yd = ceil(yd);
+    a[m++] = (unsigned)((int)xd * h + (int)yd);
+  }
+  free(u); free(v);
+  a[m++] = (unsigned)(h * w);
+  qsort(a, m, sizeof(unsigned), oracle_uint_cmp);
+  unsigned p = 0;
+  for (long j = 0; j < m; ++j) { unsigned t = a[j]; a[j] -= p; p = t; }
+  unsigned* b = (unsigned*)malloc(sizeof(unsigned) * m);
+  long j = 0, nb = 0;
+  b[nb++] = a[j++];
+  while (j < m) if (a[j] > 0) b[nb++] = a[j++]; else { j++; if (j < m) b[nb - 1] += a[j++]; }
+  /* rleDecode: runs alternate 0 / 1 starting with 0, column-major */
+  long pos = 0;
+  uint8_t val = 0;
+  for (long r = 0; r < nb; ++r) {
+    for (unsigned c = 0; c < b[r] && pos < (long)h * w; ++c) { if (val) mask[pos] = 1; pos++; }
+    val = !val;
+  }
+  free(a); free(b);
+}
+
+void oracle_rasterize_polygons_within_box(const double* xy, const int* poly_start, int n_poly, const float* box, int M, uint8_t* out) {
+  float w = box[2] - box[0], h = box[3] - box[1];
+  double ratio_w = (double)M / (double)(w > 0.1f ? w : 0.1f), ratio_h = (double)M / (double)(h > 0.1f ? h : 0.1f);
+  if (!(w >= 0.1f)) ratio_w = (double)M / 0.1;          /* max(w, 0.1) picks the Python float 0.1 (a double) when the side is smaller */
+  if (!(h >= 0.1f)) ratio_h = (double)M / 0.1;
+  uint8_t* cm = (uint8_t*)calloc((size_t)M * M, 1);
+  for (int p = 0; p < n_poly; ++p) {
+    int k = poly_start[p + 1] - poly_start[p];
+    double* q = (double*)malloc(sizeof(double) * 2 * (k > 0 ? k : 1));
+    for (int i = 0; i < k; ++i) {
+      q[2 * i] = (xy[2 * (poly_start[p] + i)] - (double)box[0]) * ratio_w;
+      q[2 * i + 1] = (xy[2 * (poly_start[p] + i) + 1] - (double)box[1]) * ratio_h;
+    }
+    if (k > 0) oracle_rle_fr_poly(q, k, M, M, cm);
+    free(q);
+  }
+  for (int yy = 0; yy < M; ++yy)
+    for (int xx = 0; xx < M; ++xx) out[yy * M + xx] = cm[xx * M + yy];
+  free(cm);
+}

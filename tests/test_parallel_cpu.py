@@ -23,7 +23,7 @@ def _free_port():
 def _worker(rank, world, port, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
-    torch.set_num_threads(2)
+    torch.set_num_threads(2 if world <= 2 else 1)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from unit_amd.modeling import build_model
@@ -37,15 +37,15 @@ def _worker(rank, world, port, q):
         buckets = GradBuckets(model, bucket_bytes=8 << 20)
         # (1) broadcast from rank 0
         ref0 = st.params.clone()
-        lst = [None, None]
+        lst = [None] * world
         dist.all_gather_object(lst, float(ref0.double().sum()))
-        assert lst[0] != lst[1]
+        assert len(set(lst)) == world
         dist.broadcast(st.params, 0)
         dist.all_gather_object(lst, float(st.params.double().sum()))
-        assert lst[0] == lst[1]
+        assert len(set(lst)) == 1
         # (2) bucketed all-reduce in backward order through the hook the backward plan calls
         st.grads.copy_(torch.arange(st.size, dtype=torch.float32) % 97 * (rank + 1))
-        expect = torch.arange(st.size, dtype=torch.float32) % 97 * 3.0     # (1 + 2)
+        expect = torch.arange(st.size, dtype=torch.float32) % 97 * (world * (world + 1) / 2.0)     # (1 + 2 + ... + world): integers, exact in any order
         tags = []
         for tag, _, _ in st.tags:
             if tag not in tags:
@@ -56,7 +56,7 @@ def _worker(rank, world, port, q):
         assert len(buckets._works) >= len(st.tags)          # res4/res5 ranges are split into several buckets
         buckets.finish()
         assert torch.equal(st.grads, expect)
-        assert buckets.grad_scale == 0.5
+        assert buckets.grad_scale == 1.0 / world
         # every gradient element is covered by exactly one bucket
         cover = torch.zeros(st.size, dtype=torch.int32)
         for chunks in buckets._plan.values():
@@ -66,7 +66,7 @@ def _worker(rank, world, port, q):
         # (3) the other exchange forms of a bucket (parallel.MODES): reduce-scatter + all-gather in place, and the "direct" form
         # (all-to-all of shard contributions, owner-side sum in rank order, all-gather) -- same sums, odd bucket sizes included
         # (a tag whose length is not a multiple of the world size leaves a tail that goes through a small all-reduce)
-        for mode, mb in (("rs_ag", 8), ("direct", 8), ("direct", 0.37), ("rs_ag", 1.3)):
+        for mode, mb in ((("rs_ag", 8), ("direct", 8), ("direct", 0.37), ("rs_ag", 1.3)) if world == 2 else (("direct", 25), ("direct", 0.37), ("rs_ag", 1.3))):
             b2 = GradBuckets(model, bucket_bytes=int(mb * (1 << 20)), mode=mode)
             assert b2.bucket_elems % world == 0
             st.grads.copy_(torch.arange(st.size, dtype=torch.float32) % 97 * (rank + 1))
@@ -74,13 +74,55 @@ def _worker(rank, world, port, q):
                 model.on_grad_ready(tag)
             b2.finish()
             assert torch.equal(st.grads, expect), (mode, mb, (st.grads - expect).abs().max())
-            assert b2.launched > len(tags) and b2.describe()["reduce_mode"] == mode and b2.describe()["ranks_seen"] == 2
+            assert b2.launched > len(tags) and b2.describe()["reduce_mode"] == mode and b2.describe()["ranks_seen"] == world
+            if world > 2:          # shards: every bucket a whole number of shards, tails (< world elements at the end of a tag) only at a tag's last bucket
+                tails = 0
+                for tag, chunks in b2._plan.items():
+                    for i, (a, b) in enumerate(chunks):
+                        assert (b - a) % world == 0 or i == len(chunks) - 1, (tag, a, b)
+                        tails += (b - a) % world != 0
+                assert tails == 0          # (the flat store pads every tag to a multiple of 8 elements: the real model has no tails at 8 ranks)
         # reduce_all (one-graph mode of engine.GraphedStep): one exchange of the whole buffer, every mode
         for mode in ("allreduce", "rs_ag", "direct"):
             b3 = GradBuckets(model, mode=mode)
             st.grads.copy_(torch.arange(st.size, dtype=torch.float32) % 97 * (rank + 1))
             b3.reduce_all()
             assert torch.equal(st.grads, expect), mode
+        # (3b) tails: a store whose tags are NOT multiples of the world size (another padding, another world size): the last bucket of a tag
+        # carries < world leftover elements through a small all-reduce, buckets smaller than the world size go through all-reduce whole
+        class _Store:
+            tags = [("a", 0, 1003), ("b", 1003, 1080), ("c", 1080, 1085), ("d", 1085, 1085 + 8 * 40)]
+            size = 1085 + 8 * 40
+            grads = torch.zeros(1085 + 8 * 40)
+
+        class _Model:
+            store = _Store()
+            on_grad_ready = None
+
+        fake = _Model()
+        pat = torch.arange(_Store.size, dtype=torch.float32) % 89
+        for mode in ("allreduce", "rs_ag", "direct"):
+            bf = GradBuckets(fake, bucket_bytes=4 * 128, mode=mode)
+            assert bf.bucket_elems == 128 // world * world
+            _Store.grads.copy_(pat * (rank + 1))
+            for tag, _, _ in _Store.tags:
+                fake.on_grad_ready(tag)
+            bf.finish()
+            assert torch.equal(_Store.grads, pat * (world * (world + 1) / 2.0)), mode
+            n_tail = sum((b - a) % world != 0 for ch in bf._plan.values() for a, b in ch)
+            assert n_tail == (3 if world == 8 else 3), (n_tail, world)          # tags a (1003), b (77), c (5) end off a multiple of 2 and of 8
+        # (4) the module-level training surface under a foreign trainer (parallel.allreduce_module_grads: what replaces DDP there)
+        from unit_amd.parallel import allreduce_module_grads
+        lin = torch.nn.Linear(5, 3)
+        frozen = torch.nn.Linear(2, 2)
+        for prm in frozen.parameters():
+            prm.requires_grad = False
+        mod = torch.nn.Sequential(lin, frozen)
+        lin.weight.grad = torch.full((3, 5), float(rank + 1))
+        lin.bias.grad = torch.full((3,), 2.0 * (rank + 1))
+        assert allreduce_module_grads(mod) == 2
+        mean = (world + 1) / 2.0
+        assert torch.equal(lin.weight.grad, torch.full((3, 5), mean)) and torch.equal(lin.bias.grad, torch.full((3,), 2.0 * mean))
         q.put((rank, "ok"))
     except Exception as e:  # noqa
         import traceback
@@ -97,6 +139,24 @@ def test_grad_buckets_gloo_world2():
     for p in procs:
         p.start()
     res = [q.get(timeout=600) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=60)
+    for rank, msg in res:
+        assert msg == "ok", f"rank {rank}: {msg}"
+
+
+def test_grad_buckets_gloo_world8():
+    """the node's real rank count: eight gloo ranks over the R50 model's flat buffer -- the bucket plan cut into whole shards
+    of eight, tags whose length is not a multiple of eight (tail all-reduce), `direct` (all-to-all + ordered owner-side sum + all-gather) and
+    `rs_ag` on odd bucket sizes, one exchange of the whole buffer, the parameter broadcast from rank 0"""
+    world = 8
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=900) for _ in range(world)]
     for p in procs:
         p.join(timeout=60)
     for rank, msg in res:

@@ -196,8 +196,15 @@ WGRAD_CASES = [
 ]
 
 
+@pytest.fixture(params=[3, 1])
+def wgrad_passes(request, monkeypatch):
+    """plane passes of a bf16x3 weight gradient (ops.X3_WGRAD_PASSES): 3 = hi.hi + hi.lo + lo.hi, 1 = hi.hi only (the round-6 default)"""
+    monkeypatch.setattr(ops(), "X3_WGRAD_PASSES", request.param)
+    return request.param
+
+
 @pytest.mark.parametrize("case", WGRAD_CASES)
-def test_wgrad_x3(dev, case):
+def test_wgrad_x3(dev, case, wgrad_passes):
     o = ops()
     n, h, w, c, k, r, stride, pad = case
     gen = g(4 + c)
@@ -208,16 +215,18 @@ def test_wgrad_x3(dev, case):
     xh, xl = split_cpu(x)
     dh, dl = split_cpu(dy)
     wg = lambda a, b: torch.nn.grad.conv2d_weight(nchw64(a), (k, c, r, r), nchw64(b), stride=stride, padding=pad).permute(0, 2, 3, 1)
-    ref3 = (wg(xh, dh) + wg(xh, dl) + wg(xl, dh)) * scale.double().view(-1, 1, 1, 1)
+    ref3 = ((wg(xh, dh) + wg(xh, dl) + wg(xl, dh)) if wgrad_passes == 3 else wg(xh, dh)) * scale.double().view(-1, 1, 1, 1)      # the passes that run, in fp64
     ref = wg(x, dy) * scale.double().view(-1, 1, 1, 1)
     xs, dys = o.x3_split(x.to(dev)), o.x3_split(dy.to(dev))
     dw = o.conv2d_wgrad(xs, dys, k, r, r, stride, pad, scale=scale.to(dev)).cpu().double()
     s = ref.abs().max().item()
     assert (dw - ref3).abs().max().item() <= 3e-6 * s
-    assert (dw - ref).abs().max().item() <= 3e-5 * s
+    # against the unsplit gradient: 2^-17 per product with three passes; one pass = both operands rounded to bf16 (2^-9 each), which the fp32
+    # sum over the contraction averages down: measured 4e-4 .. 1.2e-3 of the largest entry on these random operands
+    assert (dw - ref).abs().max().item() <= (3e-5 if wgrad_passes == 3 else 3e-3) * s
     # partial slabs (what the training plan folds itself) add up to the same gradient
     slab, splits = o.conv2d_wgrad_partial(xs, dys, k, r, r, stride, pad)
-    assert splits % 3 == 0
+    assert splits % wgrad_passes == 0 and (wgrad_passes == 3 or splits == o.lib().unit_conv2d_wgrad_splits(1, n, oh, ow, k, r, r, c))
     parts = slab.view(torch.float32)[: splits * k * r * r * c].view(splits, k, r, r, c).cpu().double().sum(0) * scale.double().view(-1, 1, 1, 1)
     assert (parts - ref3).abs().max().item() <= 3e-6 * s
     dw2 = o.conv2d_wgrad(xs, dys, k, r, r, stride, pad, scale=scale.to(dev), out=dw.float().to(dev), accumulate=True).cpu().double()
@@ -239,7 +248,7 @@ def test_avgpool_x3(dev):
     assert torch.allclose(o.as_f32(gm).cpu(), exp, rtol=2.0 ** -15, atol=0)
 
 
-def test_wgrad_x3_grouped_launch(dev):
+def test_wgrad_x3_grouped_launch(dev, wgrad_passes):
     """the plan's grouped launches take X3 layers as three bf16 problems each (one per plane pass): same gradients as the per-layer call,
     mixed tile kinds (256x256 and 128x128 grids), more problems than one grid's argument block holds"""
     o = ops()
@@ -258,6 +267,6 @@ def test_wgrad_x3_grouped_launch(dev):
     out = o.conv2d_wgrad_group(items)
     for (slab, splits), (xs, dys, k, r, _, _, _), ref in zip(out, items, refs):
         c = xs.shape[-1]
-        assert splits % 3 == 0
+        assert splits % wgrad_passes == 0
         got = slab.view(torch.float32)[: splits * k * r * r * c].view(splits, k, r, r, c).sum(0).cpu()
         assert torch.allclose(got, ref, rtol=0, atol=3e-6 * ref.abs().max().item()), (got - ref).abs().max()

@@ -12,7 +12,7 @@ HEADER = os.path.join(os.path.dirname(HERE), "include", "unit_hip.h")
 LIB_PATH = os.environ.get("UNIT_HIP_LIB") or os.path.join(HERE, "_build", "libunit_hip.so")   # override: diagnostic builds
 
 _CT = {
-    "int": ctypes.c_int, "long": ctypes.c_long, "float": ctypes.c_float, "size_t": ctypes.c_size_t,
+    "int": ctypes.c_int, "long": ctypes.c_long, "float": ctypes.c_float, "double": ctypes.c_double, "size_t": ctypes.c_size_t,
     "long long": ctypes.c_longlong, "unsigned long long": ctypes.c_ulonglong, "unsigned": ctypes.c_uint,
 }
 

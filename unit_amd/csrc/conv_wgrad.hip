@@ -331,8 +331,11 @@ extern "C" int unit_conv2d_wgrad_x3(const void* x, const void* dy, float* dw, co
   const size_t xt = (size_t)N * H * W * C * 4, dt = (size_t)N * OH * OW * ldy * 4;      // bytes of the split tensors
   const size_t slab = (size_t)K * R * S * C * sizeof(float);
   const int xpl[3] = {0, 0, 1}, dpl[3] = {0, 1, 0};                                    // plane of x / dy per pass: (hi, hi), (hi, lo), (lo, hi)
+  // variant bits 8-9: how many of the three passes run (0 = all; 1 = hi^T.hi only: bf16-grade products of the rounded operands, fp32 sums)
+  const int npass = ((variant >> 8) & 3) ? ((variant >> 8) & 3) : 3;
+  variant &= 0xff;
   int total = 0;
-  for (int ps = 0; ps < 3; ++ps) {
+  for (int ps = 0; ps < npass; ++ps) {
     size_t used = (size_t)total * slab;
     if (workspace_bytes < used) { unit_set_error("wgrad_x3: workspace too small"); return UNIT_ERR_WORKSPACE; }
     const char* xp = (const char*)x + (size_t)xpl[ps] * C * 2;

@@ -320,3 +320,100 @@ extern "C" int unit_paste_masks(const float* probs, const float* boxes, const un
   UNIT_LAUNCH_CHECK();
   return UNIT_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Mask targets from POLYGON ground truth: PolygonMasks.crop_and_resize (mask_head.py:34 -> Detectron2 mask_rcnn_loss ->
+// rasterize_polygons_within_box -> pycocotools frPyObjects / merge / decode; the reference's COCO-segm yaml leaves INPUT.MASK_FORMAT at
+// "polygon"). The arithmetic is pycocotools' (common/maskApi.c rleFrPoly, restated in oracle/oracle_c.c): vertices in box coordinates x
+// M / side (fp64), snapped to a 5x finer integer grid with C truncation, every edge walked as a dense integer line; wherever the walk
+// changes column, a "y-boundary" point (column, first row at or below the crossing) toggles everything behind it in COLUMN-MAJOR order.
+// The reference sorts the points and run-length encodes; a pixel's value is simply the parity of the number of boundary points at or
+// before its column-major position, which is what this kernel counts: one workgroup per foreground slot, per polygon a crossing-count
+// table in LDS (waves take edges, lanes take steps of the walk), a prefix parity over the M*M positions, OR over the polygons (rleMerge).
+// poly_xy [V][2] fp64 image coordinates; poly_start [P + 1]; inst_start [I + 1] = polygon range of flat instance i; image_inst0 [B] = flat
+// index of an image's first instance; slot s -> instance image_inst0[rois5[s][0]] + gt_index[s]. cls outside [0, K): zeros.
+__device__ __forceinline__ int ctrunc(double v) { return (int)v; }          // C conversion: toward zero (the reference's (int) casts)
+
+__global__ void __launch_bounds__(256) mask_targets_polygon_kernel(const double* __restrict__ xy, const int* __restrict__ poly_start,
+                                                                   const int* __restrict__ inst_start, const int* __restrict__ image_inst0,
+                                                                   const float* __restrict__ rois5, const int* __restrict__ gt_index,
+                                                                   const int* __restrict__ cls, int K, int M, unsigned char* __restrict__ out) {
+  __shared__ int cnt[28 * 28 + 1];          // crossings per column-major position 0 .. M*M (position M*M = the end sentinel's)
+  __shared__ unsigned char acc[28 * 28];    // union over the polygons, column-major
+  const int s = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int c = cls[s];
+  const int MM = M * M;
+  if (c < 0 || c >= K) {
+    for (int i = tid; i < MM; i += 256) out[(size_t)s * MM + i] = 0;
+    return;
+  }
+  const float* roi = rois5 + 5 * (size_t)s;
+  const float bx0 = roi[1], by0 = roi[2];
+  const float wf = roi[3] - roi[1], hf = roi[4] - roi[2];          // float32 sides, as box[2] - box[0] on the float32 tensor row
+  const double rw = (double)M / (wf >= 0.1f ? (double)wf : 0.1), rh = (double)M / (hf >= 0.1f ? (double)hf : 0.1);
+  const int inst = image_inst0[(int)roi[0]] + gt_index[s];
+  const int p0 = inst_start[inst], p1 = inst_start[inst + 1];
+  for (int i = tid; i < MM; i += 256) acc[i] = 0;
+  for (int p = p0; p < p1; ++p) {
+    const int v0 = poly_start[p], k = poly_start[p + 1] - v0;
+    for (int i = tid; i <= MM; i += 256) cnt[i] = 0;
+    __syncthreads();
+    for (int e = wid; e < k; e += 4) {          // edge e: vertex e -> vertex (e + 1) % k
+      const int e1 = e + 1 == k ? 0 : e + 1;
+      const int xa = ctrunc(5.0 * ((xy[2 * (size_t)(v0 + e)] - (double)bx0) * rw) + .5), ya = ctrunc(5.0 * ((xy[2 * (size_t)(v0 + e) + 1] - (double)by0) * rh) + .5);
+      const int xb = ctrunc(5.0 * ((xy[2 * (size_t)(v0 + e1)] - (double)bx0) * rw) + .5), yb = ctrunc(5.0 * ((xy[2 * (size_t)(v0 + e1) + 1] - (double)by0) * rh) + .5);
+      int xs = xa, xe = xb, ys = ya, ye = yb;
+      const int dx = abs(xe - xs), dy = abs(ys - ye);
+      const bool flip = (dx >= dy && xs > xe) || (dx < dy && ys > ye);
+      if (flip) { int t = xs; xs = xe; xe = t; t = ys; ys = ye; ye = t; }
+      const bool xmajor = dx >= dy;
+      const int n = xmajor ? dx : dy;          // steps 0 .. n of the walk, from the ORIGINAL first vertex to the second
+      const double sl = n == 0 ? 0.0 : (xmajor ? (double)(ye - ys) / dx : (double)(xe - xs) / dy);
+      auto point = [&](int d, int& u, int& v) {
+        const int t = flip ? n - d : d;
+        if (xmajor) { u = t + xs; v = ctrunc(ys + sl * t + .5); } else { v = t + ys; u = ctrunc(xs + sl * t + .5); }
+      };
+      for (int d = 1 + lane; d <= n; d += 64) {          // (the junction between two edges repeats a vertex: same column, no crossing)
+        int u0, w0, u1, w1;
+        point(d - 1, u0, w0);
+        point(d, u1, w1);
+        if (u1 == u0) continue;
+        double xd = (double)(u1 < u0 ? u1 : u1 - 1);
+        xd = (xd + .5) / 5.0 - .5;
+        if (floor(xd) != xd || xd < 0 || xd > M - 1) continue;
+        double yd = (double)(w1 < w0 ? w1 : w0);
+        yd = (yd + .5) / 5.0 - .5;
+        if (yd < 0) yd = 0; else if (yd > M) yd = M;
+        yd = ceil(yd);
+        atomicAdd(&cnt[(int)xd * M + (int)yd], 1);
+      }
+    }
+    __syncthreads();
+    // pixel i (column-major) = parity of the crossings at positions <= i: wave 0 scans the M*M positions, 64 per round
+    if (wid == 0) {
+      int carry = 0;
+      for (int base = 0; base < MM; base += 64) {
+        const int i = base + lane;
+        int v = i < MM ? cnt[i] : 0;
+        for (int o = 1; o < 64; o <<= 1) { int t = __shfl_up(v, o, 64); if (lane >= o) v += t; }
+        if (i < MM && ((carry + v) & 1)) acc[i] = 1;
+        carry += __shfl(v, 63, 64);
+      }
+    }
+    __syncthreads();
+  }
+  for (int i = tid; i < MM; i += 256) {          // column-major -> row-major [y][x]
+    const int yy = i / M, xx = i - yy * M;
+    out[(size_t)s * MM + i] = acc[xx * M + yy];
+  }
+}
+
+extern "C" int unit_mask_targets_polygon(const double* poly_xy, const int* poly_start, const int* inst_start, const int* image_inst0,
+                                         const float* rois5, const int* gt_index, const int* cls, int K, int S, int M, unsigned char* out,
+                                         void* stream) {
+  UNIT_CHECK_ARG(M >= 1 && M <= 28, "unit_mask_targets_polygon: mask side 1 .. 28");
+  if (S == 0) return UNIT_OK;
+  mask_targets_polygon_kernel<<<S, 256, 0, (hipStream_t)stream>>>(poly_xy, poly_start, inst_start, image_inst0, rois5, gt_index, cls, K, M, out);
+  UNIT_LAUNCH_CHECK();
+  return UNIT_OK;
+}

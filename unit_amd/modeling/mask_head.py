@@ -183,6 +183,17 @@ def mask_targets(gt_masks, rois5, gt_index, cls, num_classes, m=14):
     return out
 
 
+def mask_targets_polygon(polys, rois5, gt_index, cls, num_classes, m=14):
+    """PolygonMasks.crop_and_resize for every slot (the reference's COCO-segm ground truth: mask_head.py:34 -> d2 mask_rcnn_loss ->
+    rasterize_polygons_within_box -> pycocotools): polys = structures.PackedPolygons -> u8 [S,m,m]"""
+    s = rois5.shape[0]
+    out = torch.empty((s, m, m), dtype=torch.uint8, device=rois5.device)
+    check(lib().unit_mask_targets_polygon(ops._p(polys.xy), ops._p(polys.poly_start), ops._p(polys.inst_start), ops._p(polys.image_inst0),
+                                          ops._p(rois5), ops._p(gt_index), ops._p(cls), num_classes, s, m, ops._p(out), ops._s()),
+          "mask_targets_polygon")
+    return out
+
+
 def gather_match_index(sampled_idx, match_idx):
     b, s = sampled_idx.shape
     out = torch.empty((b * s,), dtype=torch.int32, device=sampled_idx.device)

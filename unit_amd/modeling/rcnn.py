@@ -34,7 +34,7 @@ class PackedBatch:
         self.gt_boxes, self.gt_classes, self.gt_count = gt_boxes, gt_classes, gt_count
         self.n_sup = n_sup
         self.multihot = multihot        # [n_weak, K] uint8 or None
-        self.gt_masks = gt_masks        # [n_sup, Mcap, H, W] uint8 bitmasks or None (MASK_ON)
+        self.gt_masks = gt_masks        # [n_sup, Mcap, H, W] uint8 bitmasks, structures.PackedPolygons (MASK_FORMAT "polygon"), or None
 
     @property
     def n_weak(self):
@@ -322,12 +322,18 @@ class WeaklySupervisedRCNNNoMeta(nn.Module):
         gt_masks = None
         if n > 0 and all(x["instances"].has("gt_masks") for x in sup):
             ms = [x["instances"].gt_masks for x in sup]
-            ms = [m.tensor if hasattr(m, "tensor") else m for m in ms]
-            hm, wm = max(m.shape[-2] for m in ms), max(m.shape[-1] for m in ms)
-            gt_masks = torch.zeros((n, mcap, hm, wm), dtype=torch.uint8)
-            for i, m in enumerate(ms):
-                gt_masks[i, : m.shape[0], : m.shape[-2], : m.shape[-1]] = m.to(torch.uint8).cpu() if m.is_cuda else m.to(torch.uint8)
-            gt_masks = gt_masks.to(dev, non_blocking=True)
+            if all(hasattr(m, "polygons") for m in ms):
+                # INPUT.MASK_FORMAT "polygon" -- what the reference's COCO-segm yaml trains on (Detectron2 PolygonMasks): the vertices travel
+                # to the device as they are and are rasterised inside each sampled box there (unit_mask_targets_polygon)
+                from ..structures import PackedPolygons
+                gt_masks = PackedPolygons.pack(ms, dev, mcap)
+            else:
+                ms = [m.tensor if hasattr(m, "tensor") else m for m in ms]
+                hm, wm = max(m.shape[-2] for m in ms), max(m.shape[-1] for m in ms)
+                gt_masks = torch.zeros((n, mcap, hm, wm), dtype=torch.uint8)
+                for i, m in enumerate(ms):
+                    gt_masks[i, : m.shape[0], : m.shape[-2], : m.shape[-1]] = m.to(torch.uint8).cpu() if m.is_cuda else m.to(torch.uint8)
+                gt_masks = gt_masks.to(dev, non_blocking=True)
         return PackedBatch(images, gt_boxes.to(dev, non_blocking=True), gt_classes.to(dev, non_blocking=True),
                            gt_count.to(dev, non_blocking=True), n, multihot, gt_masks)
 
@@ -606,7 +612,11 @@ class WeaklySupervisedRCNNNoMeta(nn.Module):
             x_fg = ops.gather_blocks(ymap, n_sup, s, fgc)
             cls_fg = ops.gather_blocks(c.roi_cls, n_sup, s, fgc)
             rois_fg = ops.gather_blocks(c.rois, n_sup, s, fgc)
-            tgt = mask_targets(batch.gt_masks, rois_fg, ops.gather_blocks(gidx, n_sup, s, fgc), cls_fg, rh.num_classes, mh.mask_size)
+            if hasattr(batch.gt_masks, "poly_start"):          # polygon ground truth (structures.PackedPolygons)
+                from .mask_head import mask_targets_polygon
+                tgt = mask_targets_polygon(batch.gt_masks, rois_fg, ops.gather_blocks(gidx, n_sup, s, fgc), cls_fg, rh.num_classes, mh.mask_size)
+            else:
+                tgt = mask_targets(batch.gt_masks, rois_fg, ops.gather_blocks(gidx, n_sup, s, fgc), cls_fg, rh.num_classes, mh.mask_size)
             kw = {}
             if sim is not None:      # similarity['seg'][fg] (roi_heads.py:893-897): fg slot -> its RoI row
                 rows = self._const_on_device(("fg_rows", n_sup, s, fgc), lambda: torch.cat([torch.arange(sl.start, sl.stop, dtype=torch.int32) for sl in sel]))

@@ -183,3 +183,91 @@ class ImageList:
 
     def __len__(self):
         return len(self.image_sizes)
+
+
+class PolygonMasks:
+    """Detectron2 `structures.masks.PolygonMasks` (the ground-truth mask container the reference's COCO-segm configuration trains on:
+    INPUT.MASK_FORMAT is left at "polygon", data/dataset_mapper.py:104-106): per instance a list of polygons, each a flat float64 array
+    [x0, y0, x1, y1, ...] in image coordinates. Only what the training path touches: len, indexing, `to`, and `crop_and_resize`
+    (mask_head.py:34 -> mask_rcnn_loss), which runs the polygon rasteriser of the HIP library (unit_mask_targets_polygon)."""
+
+    def __init__(self, polygons):
+        import numpy as np
+        self.polygons = [[np.asarray(p, dtype="float64").reshape(-1) for p in inst] for inst in polygons]
+        for inst in self.polygons:
+            for p in inst:
+                if len(p) % 2 != 0 or len(p) < 6:
+                    raise ValueError(f"a polygon needs at least 3 (x, y) points, got {len(p)} numbers")
+
+    def __len__(self):
+        return len(self.polygons)
+
+    def __getitem__(self, item):
+        import torch
+        if isinstance(item, int):
+            return PolygonMasks([self.polygons[item]])
+        if isinstance(item, slice):
+            return PolygonMasks(self.polygons[item])
+        if torch.is_tensor(item):
+            item = item.nonzero().flatten().tolist() if item.dtype == torch.bool else item.tolist()
+        return PolygonMasks([self.polygons[i] for i in item])
+
+    def to(self, *args, **kwargs):
+        return self
+
+    def crop_and_resize(self, boxes, mask_size):
+        """boxes [N, 4] (device tensor, one per instance) -> bool [N, mask_size, mask_size]"""
+        import torch
+        from .modeling.mask_head import mask_targets_polygon
+        n = len(self)
+        assert boxes.shape[0] == n
+        packed = PackedPolygons.pack([self], boxes.device, max(n, 1))
+        rois = torch.cat([torch.zeros((n, 1), dtype=torch.float32, device=boxes.device), boxes.float()], 1).contiguous()
+        idx = torch.arange(n, dtype=torch.int32, device=boxes.device)
+        out = mask_targets_polygon(packed, rois, idx, torch.zeros(n, dtype=torch.int32, device=boxes.device), 1, mask_size)
+        return out.bool()
+
+
+class PackedPolygons:
+    """device form of a batch's polygon ground truth (PackedBatch.gt_masks for MASK_FORMAT "polygon"): xy fp64 [Vcap, 2] every vertex,
+    poly_start int32 [Pcap + 1] vertex ranges, inst_start int32 [B * Mcap + 1] polygon ranges of the flat instances (image b's instance j =
+    b * Mcap + j), image_inst0 int32 [B]. Capacities are rounded up (vertices to 2048, polygons to 128) so that batches share shapes
+    (= batch keys of a captured / recorded step); the padding is empty ranges."""
+
+    def __init__(self, xy, poly_start, inst_start, image_inst0):
+        self.xy, self.poly_start, self.inst_start, self.image_inst0 = xy, poly_start, inst_start, image_inst0
+
+    @staticmethod
+    def pack(per_image, device, mcap):
+        import numpy as np
+        import torch
+        verts, pstart, istart = [], [0], [0]
+        for pm in per_image:
+            assert len(pm) <= mcap
+            for j in range(mcap):
+                if j < len(pm):
+                    for poly in pm.polygons[j]:
+                        verts.append(poly.reshape(-1, 2))
+                        pstart.append(pstart[-1] + len(poly) // 2)
+                istart.append(len(pstart) - 1)
+        v = np.concatenate(verts, 0) if verts else np.zeros((0, 2))
+        vcap = max(2048, (len(v) + 2047) // 2048 * 2048)
+        pcap = max(128, (len(pstart) - 1 + 127) // 128 * 128)
+        xy = torch.zeros((vcap, 2), dtype=torch.float64)
+        xy[: len(v)] = torch.from_numpy(np.ascontiguousarray(v))
+        ps = torch.full((pcap + 1,), pstart[-1], dtype=torch.int32)
+        ps[: len(pstart)] = torch.tensor(pstart, dtype=torch.int32)
+        return PackedPolygons(xy.to(device), ps.to(device), torch.tensor(istart, dtype=torch.int32).to(device),
+                              (torch.arange(len(per_image), dtype=torch.int32) * mcap).to(device))
+
+    @property
+    def shape(self):
+        return ("polygons", self.xy.shape[0], self.poly_start.shape[0], self.inst_start.shape[0])
+
+    def clone(self):
+        return PackedPolygons(self.xy.clone(), self.poly_start.clone(), self.inst_start.clone(), self.image_inst0.clone())
+
+    def copy_(self, other, non_blocking=False):
+        for a, b in zip((self.xy, self.poly_start, self.inst_start, self.image_inst0), (other.xy, other.poly_start, other.inst_start, other.image_inst0)):
+            a.copy_(b, non_blocking=non_blocking)
+        return self
