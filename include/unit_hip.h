@@ -135,6 +135,15 @@ int unit_weight_prep_x3(const float* w_krsc, const float* scale_k, int K, int R,
 int unit_conv2d_fwd_x3(const void* x, const void* w, void* y, const float* bias, const void* residual, const void* mask_ref, int mask_c,
                        int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int OH, int OW, int ldy, int oy_mul, int OHf,
                        int OWf, int relu, int tile, void* stream);
+/* round 6: the dgrad chain of the bf16x3 mode with TWO k-segments per 64-channel block -- w_dgrad [C][R][S][K/64][2][64] = [Wh | Wl]
+ * (unit_weight_prep_x3s dgrad_segs = 2) against the hi plane of the gradient map twice: dx = hi(dy).(Wh + Wl), the weights at 16 bits, dy at
+ * its hi plane (one fresh 2^-9 rounding per element and layer, averaged out by the weight gradients' sums over the pixel rows). segs = 3 is
+ * unit_conv2d_fwd_x3. The forward pass always runs three segments. */
+int unit_weight_prep_x3s(const float* w_krsc, const float* scale_k, int K, int R, int S, int C, void* w_fwd, void* w_dgrad, int dgrad_segs,
+                         void* stream);
+int unit_conv2d_fwd_x3s(const void* x, const void* w, void* y, const float* bias, const void* residual, const void* mask_ref, int mask_c,
+                        int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int OH, int OW, int ldy, int oy_mul, int OHf,
+                        int OWf, int relu, int tile, int segs, void* stream);
 int unit_conv2d_wgrad_x3(const void* x, const void* dy, float* dw, const float* scale_k, int N, int H, int W, int C, int K, int R, int S,
                          int stride, int pad, int OH, int OW, int ldy, int accumulate, int variant, void* workspace, size_t workspace_bytes,
                          void* stream);
@@ -146,7 +155,7 @@ int unit_global_avgpool_x3_bwd_relu(const float* dfeat, const void* y, void* g, 
  * aspect ratio, so the two padded sizes almost never agree). Pointwise stride-1 layers need nothing (concatenate the rows); every other layer
  * takes the second problem here instead of a second, half-empty launch. kernel: 0 = unit_conv2d_fwd (tile = tile_cfg), 1 = unit_conv2d_fwd_mid
  * (tile 0 / 1 / 2 / 4 / 5 or a loader-consumer code 142 .. 182, 144 .. 164), 2 = unit_conv2d_fwd_big (tile = variant 0 / 8 / 12: row-major 256-row
- * tiles), 3 = unit_conv2d_fwd_x3 (mask_c as there). The second problem's OH / OW follow from its H / W; OHf / OWf = its scatter target's map
+ * tiles), 3 = unit_conv2d_fwd_x3 (mask_c as there), 4 = unit_conv2d_fwd_x3s with two segments. The second problem's OH / OW follow from its H / W; OHf / OWf = its scatter target's map
  * size (= OH / OW without scatter). Each problem's result is what the single launch writes, bit for bit. */
 typedef struct UnitConvSecond {
   const void* x; void* y; const void* residual; const void* mask_ref;

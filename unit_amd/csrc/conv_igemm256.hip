@@ -744,22 +744,34 @@ extern "C" int unit_conv2d_fwd_x3(const void* x, const void* w, void* y, const f
                                   int mask_c, int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int OH, int OW, int ldy,
                                   int oy_mul, int OHf, int OWf, int relu, int tile, void* stream) {
   return unit_conv_x3_impl(x, w, y, bias, residual, mask_ref, mask_c, N, H, W, C, K, R, S, stride, pad, OH, OW, ldy, oy_mul, OHf, OWf, relu, tile,
-                           nullptr, stream);
+                           nullptr, stream, 3);
+}
+
+// segs = 3: as unit_conv2d_fwd_x3. segs = 2 (round 6, the dgrad chain of the bf16x3 mode): w = [K][R][S][C / 64][2][64] = [Wh | Wl] against the
+// planes [hi | hi] of x -- y = hi(x).(Wh + Wl): the weights at full 16-bit precision, the input at its hi plane (its lo plane is not read). For a
+// gradient map that is one fresh, unbiased 2^-9 rounding per element and layer, which the weight gradients' sums over >= 2 394 rows average
+// out (weights rounded instead would be the SAME error in every row); the forward pass never uses it.
+extern "C" int unit_conv2d_fwd_x3s(const void* x, const void* w, void* y, const float* bias, const void* residual, const void* mask_ref,
+                                   int mask_c, int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int OH, int OW, int ldy,
+                                   int oy_mul, int OHf, int OWf, int relu, int tile, int segs, void* stream) {
+  UNIT_CHECK_ARG(segs == 2 || segs == 3, "conv_x3s: 2 or 3 k-segments per 64-channel block");
+  return unit_conv_x3_impl(x, w, y, bias, residual, mask_ref, mask_c, N, H, W, C, K, R, S, stride, pad, OH, OW, ldy, oy_mul, OHf, OWf, relu, tile,
+                           nullptr, stream, segs);
 }
 
 int unit_conv_x3_impl(const void* x, const void* w, void* y, const float* bias, const void* residual, const void* mask_ref, int mask_c, int N, int H,
                       int W, int C, int K, int R, int S, int stride, int pad, int OH, int OW, int ldy, int oy_mul, int OHf, int OWf, int relu, int tile,
-                      const UnitConvSecond* second, void* stream) {
+                      const UnitConvSecond* second, void* stream, int segs) {
   UNIT_CHECK_ARG(C % 64 == 0, "conv_x3: C must be a multiple of 64");
   UNIT_CHECK_ARG(ldy % 8 == 0 && ldy >= K, "conv_x3: ldy must be a multiple of 8 and >= K");
   UNIT_CHECK_ARG(OH == (H + 2 * pad - R) / stride + 1 && OW == (W + 2 * pad - S) / stride + 1, "conv_x3: OH/OW mismatch");
   UNIT_CHECK_ARG((OH - 1) * oy_mul < OHf && (OW - 1) * oy_mul < OWf, "conv_x3: output scatter out of range");
   UNIT_CHECK_ARG(((uintptr_t)x % 16 == 0) && ((uintptr_t)w % 16 == 0) && ((uintptr_t)y % 16 == 0), "conv_x3: 16B alignment");
   UNIT_CHECK_ARG(mask_ref == nullptr || (mask_c >= ldy && mask_c % 8 == 0), "conv_x3: mask_c must be the mask tensor's channels per plane");
-  const int NSEG = 3;
+  const int NSEG = segs;
   size_t xb = (size_t)N * H * W * C * 4, wb = (size_t)K * R * S * C * NSEG * 2;
   UNIT_CHECK_ARG(xb < 0xFFFFFFF0ull && wb < 0xFFFFFFF0ull, "conv_x3: operand larger than 4 GiB");
-  SplitK sk{NSEG, 0x1, C, 2 * C};          // segments [lo.Wh, hi.Wh, hi.Wl]
+  SplitK sk{NSEG, NSEG == 3 ? 0x1 : 0x0, C, 2 * C};          // segments [lo.Wh, hi.Wh, hi.Wl] | [hi.Wh, hi.Wl]
   hipStream_t st = (hipStream_t)stream;
   ConvSecond sec;
   { int rc = unit_fill_second(sec, second, R, S, stride, pad, oy_mul, (size_t)C * 4); if (rc != UNIT_OK) return rc; }
@@ -810,9 +822,11 @@ extern "C" int unit_conv2d_fwd_pair(int kernel, const void* x, const void* w, vo
     case 2: return unit_conv_big_impl(x, w, y, bias, residual, mask_ref, out_dtype, N, H, W, C, K, R, S, stride, pad, OH, OW, ldy, oy_mul, OHf, OWf, relu, tile,
                                       second, stream);
     case 3: return unit_conv_x3_impl(x, w, y, bias, residual, mask_ref, mask_c, N, H, W, C, K, R, S, stride, pad, OH, OW, ldy, oy_mul, OHf, OWf, relu, tile,
-                                     second, stream);
+                                     second, stream, 3);
+    case 4: return unit_conv_x3_impl(x, w, y, bias, residual, mask_ref, mask_c, N, H, W, C, K, R, S, stride, pad, OH, OW, ldy, oy_mul, OHf, OWf, relu, tile,
+                                     second, stream, 2);
   }
-  unit_set_error("conv_pair: kernel 0 (generic), 1 (mid), 2 (big), 3 (bf16x3)");
+  unit_set_error("conv_pair: kernel 0 (generic), 1 (mid), 2 (big), 3 (bf16x3), 4 (bf16x3, two segments)");
   return UNIT_ERR_ARG;
 }
 

@@ -44,4 +44,4 @@ int unit_conv_big_impl(const void* x, const void* w, void* y, const float* bias,
                        int variant, const UnitConvSecond* second, void* stream);
 int unit_conv_x3_impl(const void* x, const void* w, void* y, const float* bias, const void* residual, const void* mask_ref, int mask_c, int N, int H,
                       int W, int C, int K, int R, int S, int stride, int pad, int OH, int OW, int ldy, int oy_mul, int OHf, int OWf, int relu, int tile,
-                      const UnitConvSecond* second, void* stream);
+                      const UnitConvSecond* second, void* stream, int segs);

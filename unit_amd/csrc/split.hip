@@ -70,8 +70,9 @@ extern "C" int unit_x3_merge(const void* in, float* out, long rows, int C, void*
 //   w_fwd   [K][R][S][C / 64][3][64]   segments [Wh | Wh | Wl]  (against the planes [lo | hi | hi] of x: consecutive k-tiles share an
 //                                      operand -- Wh, then hi -- which the 256x256 kernel keeps in registers, conv_igemm256p8.hip)
 //   w_dgrad [C][R][S][K / 64][3][64]   taps flipped (dgrad = forward conv of dy with this tensor), same segments over the K axis
+// dseg = 2: the dgrad copy as [C][R][S][K / 64][2][64] = [Wh | Wl] (unit_conv2d_fwd_x3s segs = 2)
 __global__ void weight_prep_x3_kernel(const float* __restrict__ w, const float* __restrict__ scale, int K, int R, int S, int C,
-                                      bf16_t* __restrict__ wf, bf16_t* __restrict__ wd) {
+                                      bf16_t* __restrict__ wf, bf16_t* __restrict__ wd, int dseg) {
   long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
   long total = (long)K * R * S * C;
   if (idx >= total) return;
@@ -86,18 +87,26 @@ __global__ void weight_prep_x3_kernel(const float* __restrict__ w, const float* 
     q[0] = h; q[64] = h; q[128] = l;
   }
   if (wd) {
-    bf16_t* q = wd + (((size_t)c * R + (R - 1 - r)) * S + (S - 1 - s)) * (size_t)(3 * K) + (size_t)(k >> 6) * 192 + (k & 63);
-    q[0] = h; q[64] = h; q[128] = l;
+    bf16_t* q = wd + (((size_t)c * R + (R - 1 - r)) * S + (S - 1 - s)) * (size_t)(dseg * K) + (size_t)(k >> 6) * (64 * dseg) + (k & 63);
+    if (dseg == 3) { q[0] = h; q[64] = h; q[128] = l; } else { q[0] = h; q[64] = l; }
   }
 }
 
+extern "C" int unit_weight_prep_x3s(const float* w_krsc, const float* scale_k, int K, int R, int S, int C, void* w_fwd, void* w_dgrad,
+                                    int dgrad_segs, void* stream);
 extern "C" int unit_weight_prep_x3(const float* w_krsc, const float* scale_k, int K, int R, int S, int C, void* w_fwd, void* w_dgrad,
                                    void* stream) {
+  return unit_weight_prep_x3s(w_krsc, scale_k, K, R, S, C, w_fwd, w_dgrad, 3, stream);
+}
+
+extern "C" int unit_weight_prep_x3s(const float* w_krsc, const float* scale_k, int K, int R, int S, int C, void* w_fwd, void* w_dgrad,
+                                    int dgrad_segs, void* stream) {
+  UNIT_CHECK_ARG(dgrad_segs == 2 || dgrad_segs == 3, "weight_prep_x3s: 2 or 3 segments in the dgrad copy");
   UNIT_CHECK_ARG(w_fwd == nullptr || C % 64 == 0, "weight_prep_x3: C must be a multiple of 64 for the forward copy");
   UNIT_CHECK_ARG(w_dgrad == nullptr || K % 64 == 0, "weight_prep_x3: K must be a multiple of 64 for the dgrad copy");
   long total = (long)K * R * S * C;
   if (total == 0) return UNIT_OK;
-  weight_prep_x3_kernel<<<(unsigned)cdiv(total, 256L), 256, 0, (hipStream_t)stream>>>(w_krsc, scale_k, K, R, S, C, (bf16_t*)w_fwd, (bf16_t*)w_dgrad);
+  weight_prep_x3_kernel<<<(unsigned)cdiv(total, 256L), 256, 0, (hipStream_t)stream>>>(w_krsc, scale_k, K, R, S, C, (bf16_t*)w_fwd, (bf16_t*)w_dgrad, dgrad_segs);
   UNIT_LAUNCH_CHECK();
   return UNIT_OK;
 }

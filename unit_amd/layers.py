@@ -110,7 +110,7 @@ class Conv2d(_EpochOnLoad):
             ok = lambda t, shape: t if (t is not None and t.dtype == torch.bfloat16 and tuple(t.shape) == shape) else None
             self.wf, self.wd = ops.weight_prep_x3(src, self.scale, self.cout, self.k, self.k, self.cin, want_dgrad=need_dgrad,
                                                   w_fwd=ok(self.wf, (self.cout, self.k, self.k, 3 * self.cin)),
-                                                  w_dgrad=ok(self.wd, (self.cin, self.k, self.k, 3 * self.cout)))
+                                                  w_dgrad=ok(self.wd, (self.cin, self.k, self.k, ops.X3_DGRAD_SEGS * self.cout)))
             self._prep_key = key
             return
         if self.wf is not None and self.wf.dim() == 4 and self.wf.shape[-1] != self.cin_pad:

@@ -51,6 +51,21 @@ class PackedBatch:
                 None if self.gt_masks is None else tuple(self.gt_masks.shape))
 
 
+def pack_gt_masks(ms, dev, mcap):
+    """per-image ground-truth mask containers -> their device form: uint8 bitmasks [n, mcap, H, W] (Detectron2 BitMasks / plain tensors), or
+    structures.PackedPolygons for PolygonMasks -- INPUT.MASK_FORMAT "polygon", what the reference's COCO-segm yaml trains on: the vertices
+    travel to the device as they are and are rasterised inside each sampled box there (unit_mask_targets_polygon)"""
+    if all(hasattr(m, "polygons") for m in ms):
+        from ..structures import PackedPolygons
+        return PackedPolygons.pack(ms, dev, mcap)
+    ms = [m.tensor if hasattr(m, "tensor") else m for m in ms]
+    hm, wm = max(m.shape[-2] for m in ms), max(m.shape[-1] for m in ms)
+    gt_masks = torch.zeros((len(ms), mcap, hm, wm), dtype=torch.uint8)
+    for i, m in enumerate(ms):
+        gt_masks[i, : m.shape[0], : m.shape[-2], : m.shape[-1]] = m.to(torch.uint8).cpu() if m.is_cuda else m.to(torch.uint8)
+    return gt_masks.to(dev, non_blocking=True)
+
+
 def _record_tree(obj, streams):
     """record_stream on every tensor inside nested tuples / lists (ops.ReluBits included): memory allocated under one stream's context
     that other streams go on using"""
@@ -321,19 +336,7 @@ class WeaklySupervisedRCNNNoMeta(nn.Module):
             multihot = multihot.to(dev, non_blocking=True)
         gt_masks = None
         if n > 0 and all(x["instances"].has("gt_masks") for x in sup):
-            ms = [x["instances"].gt_masks for x in sup]
-            if all(hasattr(m, "polygons") for m in ms):
-                # INPUT.MASK_FORMAT "polygon" -- what the reference's COCO-segm yaml trains on (Detectron2 PolygonMasks): the vertices travel
-                # to the device as they are and are rasterised inside each sampled box there (unit_mask_targets_polygon)
-                from ..structures import PackedPolygons
-                gt_masks = PackedPolygons.pack(ms, dev, mcap)
-            else:
-                ms = [m.tensor if hasattr(m, "tensor") else m for m in ms]
-                hm, wm = max(m.shape[-2] for m in ms), max(m.shape[-1] for m in ms)
-                gt_masks = torch.zeros((n, mcap, hm, wm), dtype=torch.uint8)
-                for i, m in enumerate(ms):
-                    gt_masks[i, : m.shape[0], : m.shape[-2], : m.shape[-1]] = m.to(torch.uint8).cpu() if m.is_cuda else m.to(torch.uint8)
-                gt_masks = gt_masks.to(dev, non_blocking=True)
+            gt_masks = pack_gt_masks([x["instances"].gt_masks for x in sup], dev, mcap)
         return PackedBatch(images, gt_boxes.to(dev, non_blocking=True), gt_classes.to(dev, non_blocking=True),
                            gt_count.to(dev, non_blocking=True), n, multihot, gt_masks)
 

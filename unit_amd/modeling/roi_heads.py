@@ -235,7 +235,12 @@ class WSROIHeadNoMetaWithMask(WSROIHeadNoMeta):
         `model.inference` makes the same two passes without the host round trip in between)"""
         del images, weak_images
         if self.training:
-            raise RuntimeError("WSROIHead*.forward in training mode: " + _FUSED)
+            # roi_heads.py:783-822 / :909-952 in training under a meta-architecture other than the fused step: one autograd node over the
+            # heads' explicit forward / backward incl. the mask head on the foreground RoIs (modeling/train_modules.py)
+            if tta or return_similarity or train_only_weak:
+                raise NotImplementedError("tta / return_similarity / train_only_weak are outside the hot path (SURVEY.md section 2)")
+            from .train_modules import roi_heads_forward_train
+            return roi_heads_forward_train(self, features, proposals, targets, weak_features, weak_proposals, weak_targets)
         if tta or return_similarity:
             raise NotImplementedError("tta / return_similarity belong to the TTA and visualisation tools, outside the hot path "
                                       "(SURVEY.md section 2)")

@@ -11,8 +11,8 @@ Each call is ONE torch.autograd.Function node over the same explicit forward / b
 the node's forward runs the HIP kernels and keeps the context, its backward runs the segment's explicit backward, ACCUMULATES the
 module's parameter gradients into `.grad` (torch semantics: zero_grad() between steps) and hands d(loss)/d(features) to autograd, which
 sums the RPN's and the ROI heads' contributions before the backbone's node runs. One HIP stream, no plan-level fusions (multi-tensor
-weight-gradient launches, stream overlap): the fused step stays the fast path, these are the drop-in surface. Supported: the VOC / COCO
-base-training heads without the mask branch (WSROIHeadNoMeta); fine-tune and mask heads train through the fused step only.
+weight-gradient launches, stream overlap): the fused step stays the fast path, these are the drop-in surface. All four ROI-head classes of
+the C4 configurations: WSROIHeadNoMeta, WSROIHeadFineTune, WSROIHeadNoMetaWithMask, WSROIHeadWithMaskFineTune (round 6).
 
 Sampling follows the explicit-permutation contract of the fused step: a module draws its permutations from its own device counter unless
 `module.next_perm` (int32 [n_images, capacity]) is set, which is consumed once (tests)."""
@@ -169,14 +169,19 @@ def rpn_forward_train(module, images, features, gt_instances):
     return proposals, losses
 
 
-# ------------------------------------------------------------------------------------------------ WSROIHeadNoMeta (roi_heads.py:496-591)
-HEAD_LOSSES = ["loss_cls", "loss_box_reg", "loss_im_cls", "loss_oicr_1", "loss_oicr_2", "loss_oicr_3"]
+# ------------------------------------------------------------------------------------------------ ROI heads
+# WSROIHeadNoMeta roi_heads.py:496-591, WSROIHeadFineTune :595-644, WSROIHeadNoMetaWithMask :712-822, WSROIHeadWithMaskFineTune :826-952
+HEAD_LOSSES = ["loss_cls", "loss_box_reg", "loss_im_cls", "loss_oicr_1", "loss_oicr_2", "loss_oicr_3", "loss_mask"]
 
 
 class _HeadsFn(torch.autograd.Function):
+    """The four ROI-head classes in training as ONE node: the same forward / backward segments the fused step runs for them
+    (rcnn.forward_train / backward_train: Res5 heads, predictors + loss kernels, the fine-tune heads' similarity transfer with its backward,
+    the mask head on the foreground RoIs' res5 maps), on one stream."""
+
     @staticmethod
     def forward(ctx, f, fw, rh, io):
-        from .inference import pack_proposal_instances
+        from .inference import class_roles, pack_proposal_instances, similarity_dict
         dtype = _dtype(rh)
         rh.prepare(dtype, _pversion(rh))
         bp = rh.box_predictor
@@ -212,49 +217,127 @@ class _HeadsFn(torch.autograd.Function):
         if has_weak:
             rh.pool(feat_w, rois[rs:], out=pooled[rs:], image_offset=n_sup)
         multi = rh.weak_box_head is not None
+        mh = getattr(rh, "mask_head", None)
+        ft = bool(getattr(bp, "finetune", False))
+        mask_on = mh is not None and all(t.has("gt_masks") for t in io["targets"])
+        # a frozen box head (VOC fine-tune yaml) still hands d(loss)/d(features) on when the caller's features want it
         box_trainable = any(p.requires_grad for p in rh.box_head.parameters())
+        save_box = box_trainable or ctx.needs_input_grad[0] or (not multi and has_weak and ctx.needs_input_grad[1])
         if multi:
-            box_feat, box_ctx = rh.box_head.fwd(pooled[:rs], save=box_trainable)
+            box_feat, box_ctx = rh.box_head.fwd(pooled[:rs], save=save_box, keep_map=mask_on)
             wfeat_all, weak_ctx = rh.weak_box_head.fwd(pooled, save=has_weak)          # its supervised rows: the reference's no_grad evaluation
             rows = slice(rs, rs + rw)
         else:
-            wfeat_all, box_ctx = rh.box_head.fwd(pooled, save=box_trainable)
+            wfeat_all, box_ctx = rh.box_head.fwd(pooled, save=save_box, keep_map=mask_on)
             box_feat, weak_ctx, rows = wfeat_all[:rs], None, None
         lin_sup = bp.group.fwd(box_feat)
         lin_weak = wh.group.fwd(wfeat_all)
         losses = ops.zeros(len(HEAD_LOSSES), torch.float32, dev)
-        dy_sup, _ = bp.sup_losses(lin_sup, lin_weak[:rs], roi_cls, rois[:rs], roi_gt, losses[0:2], dtype)
+        st = {"mask_ctx": None, "dsim_mask": None, "sel": None}
+
+        def run_mask(sim=None, roles=None):          # rcnn.forward_train run_mask (roi_heads.py:691-710 / :888-906)
+            from .mask_head import gather_match_index, mask_targets, mask_targets_polygon
+            from .rcnn import pack_gt_masks
+            fgc = rh.max_fg_per_image
+            ymap = box_ctx[1]
+            sidx, midx = rh._last_sampling
+            gidx = ops.gather_blocks(gather_match_index(sidx, midx), n_sup, s, fgc)
+            x_fg = ops.gather_blocks(ymap, n_sup, s, fgc)
+            cls_fg = ops.gather_blocks(roi_cls, n_sup, s, fgc)
+            rois_fg = ops.gather_blocks(rois, n_sup, s, fgc)
+            gtm = pack_gt_masks([t.gt_masks for t in io["targets"]], dev, gt_boxes.shape[1])
+            if hasattr(gtm, "poly_start"):
+                tgt = mask_targets_polygon(gtm, rois_fg, gidx, cls_fg, rh.num_classes, mh.mask_size)
+            else:
+                tgt = mask_targets(gtm, rois_fg, gidx, cls_fg, rh.num_classes, mh.mask_size)
+            kw = {}
+            if sim is not None:
+                sel_rows = torch.cat([torch.arange(i * s, i * s + fgc, dtype=torch.int32) for i in range(n_sup)]).to(dev)
+                st["dsim_mask"] = torch.zeros(sim.shape, dtype=torch.float32, device=dev)
+                kw = dict(sim=sim, sim_rows=sel_rows, roles=roles, dsim=st["dsim_mask"])
+            st["mask_ctx"] = mh.fwd_train(x_fg, cls_fg, tgt, losses[6:7], dtype, **kw)
+            st["sel"] = [slice(i * s, i * s + fgc) for i in range(n_sup)]
+
+        if mask_on and not ft:
+            run_mask()
+        ft_ctx = None
+        if ft:
+            # a14 (roi_heads.py:595-644 / :826-870 + fast_rcnn.py:484-533): the similarity transfer is active in TRAINING too
+            frozen = not any(p.requires_grad for n, p in bp.named_parameters() if not n.split(".")[0].endswith("_ft"))
+            assert frozen, "fine-tune heads: the delta / weak predictors must be frozen (FREEZE_LAYERS.FAST_RCNN of every *-ft.yaml)"
+            lin_ft = bp.group_ft.fwd(box_feat)
+            lin_w_box = wh.group.fwd(box_feat)
+            sims, lingual, keys = similarity_dict(rh, lin_w_box, want_ctx=True)
+            t = class_roles(rh)
+            scores, bbox = ops.transfer_predictions(lin_sup, bp.col_cls, bp.col_bbox, rh.num_classes, lin_weak[:rs], wh.col_oicr[0], wh.oicr_iter,
+                                                    sims["cls"], sims["bbox"], t["base"], t["novel"], t["role"], t["slot"], ft=lin_ft,
+                                                    fccol0=bp.col_cls, fbcol0=bp.col_bbox)
+            dy_sup = bp.ft_losses(scores, bbox, roi_cls, rois[:rs], roi_gt, losses[0:2], dtype)
+            ft_ctx = (lin_sup, sims, lingual, keys, t, lin_w_box)
+            if mask_on:
+                run_mask(sims.get("seg"), t)
+        else:
+            dy_sup, _ = bp.sup_losses(lin_sup, lin_weak[:rs], roi_cls, rois[:rs], roi_gt, losses[0:2], dtype)
         dy_weak = None
         if has_weak:
             multihot = torch.zeros((n_weak, rh.num_classes), dtype=torch.uint8)
             for i, c in enumerate(io["weak_targets"]):
                 multihot[i, c.long().cpu()] = 1          # torch.unique(gt_classes) (weak_detector_fast_rcnn.py:203)
             dy_weak = wh.fused_losses(lin_weak[rs:], rois[rs:], weak_valid, sw, n_weak, multihot.to(dev), losses[2:6], dtype)
-        io["rois"], io["roi_cls"] = rois, roi_cls
-        ctx.rh, ctx.geo = rh, (n_sup, n_weak, rs, rw, feat.shape, feat_w.shape if has_weak else None, multi, rows)
-        ctx.saved = (box_feat, wfeat_all, box_ctx, weak_ctx, dy_sup, dy_weak, rois)
+        io["rois"], io["roi_cls"], io["mask_on"] = rois, roi_cls, st["mask_ctx"] is not None
+        ctx.rh, ctx.geo = rh, (n_sup, n_weak, rs, rw, feat.shape, feat_w.shape if has_weak else None, multi, rows, box_trainable, ft, dtype)
+        ctx.saved = (box_feat, wfeat_all, box_ctx, weak_ctx, dy_sup, dy_weak, rois, ft_ctx, st)
         return losses
 
     @staticmethod
     def backward(ctx, gl):
         rh = ctx.rh
         bp, wh = rh.box_predictor, rh.box_predictor.weak_detector_head
-        n_sup, n_weak, rs, rw, fshape, fwshape, multi, rows = ctx.geo
-        box_feat, wfeat_all, box_ctx, weak_ctx, dy_sup, dy_weak, rois = ctx.saved
+        n_sup, n_weak, rs, rw, fshape, fwshape, multi, rows, box_trainable, ft, dtype = ctx.geo
+        box_feat, wfeat_all, box_ctx, weak_ctx, dy_sup, dy_weak, rois, ft_ctx, st = ctx.saved
         # only the losses that were handed out carry a weight: without a weak batch (rcnn.py:456-459, :644 -- weak_features None) the caller
-        # got the two supervised losses, the four weak slots of the vector are unused zeros whose incoming gradient is 0
-        _check_unit_weights(gl if dy_weak is not None else gl[:2], "WSROIHeadNoMeta")
+        # got the supervised losses, the weak slots of the vector are unused zeros whose incoming gradient is 0
+        used = [0, 1] + ([2, 3, 4, 5] if dy_weak is not None else []) + ([6] if st["mask_ctx"] is not None else [])
+        _check_unit_weights(gl[used], type(rh).__name__)
+        need_dx = box_ctx is not None
         g = gw = None
         with _direct_grads():
-            dbox = bp.group.bwd(box_feat, dy_sup, need_dx=True)
-            dweak = wh.group.bwd(wfeat_all[rs:], dy_weak, need_dx=True) if dy_weak is not None else None
-            if multi:
-                dpool_sup = rh.box_head.bwd(box_ctx, dbox) if box_ctx is not None else None
-                dpool_weak = rh.weak_box_head.bwd(weak_ctx, dweak, row_slice=rows) if dweak is not None else None
+            if ft:
+                dbox = bp.group_ft.bwd(box_feat, dy_sup, need_dx=need_dx)
+                if need_dx:
+                    # ... through the frozen delta heads incl. the base -> novel transfer, and the similarity (computed WITH grad in the
+                    # reference, roi_heads.py:852), into the box head's features (rcnn.backward_train)
+                    lin_sup, sims, lingual, keys, t, lin_w_box = ft_ctx
+                    assert len(set(keys.values())) == 1, "fine-tune backward: one similarity matrix for all heads (equal FINETUNE_TERMS)"
+                    ul, uv = next(iter(keys.values()))
+                    dlin, dsim = ops.transfer_predictions_bwd(dy_sup, bp.col_cls, bp.col_bbox, lin_sup, bp.col_cls, bp.col_bbox, rh.num_classes,
+                                                              sims["cls"], sims["bbox"], t, bp.group.kp)
+                    if st["dsim_mask"] is not None:
+                        dsim += st["dsim_mask"]
+                    dlin_w = ops.similarity_bwd(lin_w_box, wh.col_oicr[0], wh.oicr_iter, rh.num_classes + 1, t["base"], lingual,
+                                                t["novel"].numel(), rh.visual_threshold, ul, uv, dsim, dtype)
+                    dbox = dbox + bp.group.bwd(box_feat, dlin, need_dx=True) + wh.group.bwd(box_feat, dlin_w, need_dx=True)
             else:
+                dbox = bp.group.bwd(box_feat, dy_sup, need_dx=True)
+            dweak = wh.group.bwd(wfeat_all[rs:], dy_weak, need_dx=True) if dy_weak is not None else None
+            mask_hook = None
+            if st["mask_ctx"] is not None:
+                mh = rh.mask_head
+
+                def mask_hook(gmap, y):          # rcnn.backward_train: the mask head's gradient into the fg slots of the res5 map gradient
+                    dy1 = mh.bwd(st["mask_ctx"])
+                    fgc = rh.max_fg_per_image
+                    for i, sl in enumerate(st["sel"]):
+                        mh.deconv.dgrad(dy1[i * fgc:(i + 1) * fgc], residual=gmap[sl], mask_ref=y[sl], out=gmap[sl])
+            if multi:
+                dpool_sup = rh.box_head.bwd(box_ctx, dbox, map_grad_hook=mask_hook) if need_dx else None
+                dpool_weak = rh.weak_box_head.bwd(weak_ctx, dweak, row_slice=rows) if dweak is not None else None
+            elif need_dx:
                 dall = dbox if dweak is None else torch.cat([dbox, dweak], 0)
-                dpool = rh.box_head.bwd(box_ctx, dall)
+                dpool = rh.box_head.bwd(box_ctx, dall, map_grad_hook=mask_hook)
                 dpool_sup, dpool_weak = dpool[:rs], (dpool[rs:] if rw > 0 else None)
+            else:
+                dpool_sup = dpool_weak = None
         dev = rois.device
         if dpool_sup is not None:
             g = torch.empty(fshape, dtype=torch.float32, device=dev)
@@ -266,15 +349,17 @@ class _HeadsFn(torch.autograd.Function):
 
 
 def roi_heads_forward_train(rh, features, proposals, targets, weak_features, weak_proposals, weak_targets):
-    if getattr(rh, "mask_head", None) is not None or getattr(rh, "finetune", False):
-        raise RuntimeError("module-level training forward: the mask / fine-tune ROI heads train through WeaklySupervisedRCNNNoMeta's fused step")
-    assert targets, "WSROIHeadNoMeta.forward in training needs targets (roi_heads.py:562)"
+    assert targets, "WSROIHead*.forward in training needs targets (roi_heads.py:562)"
     f = features["res4"] if isinstance(features, dict) else features
     has_weak = weak_proposals is not None and weak_features is not None
     fw = (weak_features["res4"] if isinstance(weak_features, dict) else weak_features) if has_weak else f.new_zeros(1)
+    if not f.requires_grad:
+        # (a fully frozen backbone: the node must still be part of the graph for its PARAMETERS' sake -- they are updated by the explicit
+        # backward, not by autograd; same device as the backbone node's anchor)
+        f = f + _anchor(rh, f.device) * 0
     io = {"proposals": proposals, "targets": targets, "weak_proposals": weak_proposals if has_weak else None, "weak_targets": weak_targets}
     lv = _HeadsFn.apply(f, fw, rh, io)
-    names = HEAD_LOSSES if has_weak else HEAD_LOSSES[:2]
+    names = HEAD_LOSSES[:2] + (HEAD_LOSSES[2:6] if has_weak else []) + (["loss_mask"] if io["mask_on"] else [])
     rh._last_train_io = io
     s = rh.batch_size_per_image
     sampled = []

@@ -805,7 +805,9 @@ def conv2d_pair(xs, w, k, r, s, stride=1, pad=0, bias=None, residuals=None, mask
     if force is not None:
         kernel, tile = force
     elif x3:
-        kernel, tile = 3, X3_TILE_POLICY(m_tot, k, c, 3 * r * s * c)
+        segs = w.shape[-1] // c          # (conv2d_x3)
+        assert segs in (2, 3) and w.shape[-1] == segs * c
+        kernel, tile = (3 if segs == 3 else 4), X3_TILE_POLICY(m_tot, k, c, segs * r * s * c)
     else:
         big = BIG_TILE_POLICY(x0.dtype, m_tot, k, c, r * s * c) and ldy % 8 == 0
         mid = -1
@@ -822,8 +824,8 @@ def conv2d_pair(xs, w, k, r, s, stride=1, pad=0, bias=None, residuals=None, mask
     sec.residual = residuals[1].data_ptr() if residuals[1] is not None else None
     sec.mask_ref = mask_refs[1].data_ptr() if mask_refs[1] is not None else None
     sec.N, sec.H, sec.W, sec.OHf, sec.OWf = g1[0], g1[1], g1[2], g1[6], g1[7]
-    with _timed("conv_igemm256" if kernel == 2 or (kernel == 3 and tile < 0) else ("conv_igemm_dma" if kernel in (1, 3) else "conv_igemm"),
-                (3 if x3 else 1) * 2.0 * m_tot * k * r * s * c, (sum(x.numel() for x in xs) + m_tot * ldy) * x0.element_size()):
+    with _timed("conv_igemm256" if kernel == 2 or (kernel in (3, 4) and tile < 0) else ("conv_igemm_dma" if kernel in (1, 3, 4) else "conv_igemm"),
+                ((3 if kernel == 3 else 2) if x3 else 1) * 2.0 * m_tot * k * r * s * c, (sum(x.numel() for x in xs) + m_tot * ldy) * x0.element_size()):
         check(lib().unit_conv2d_fwd_pair(kernel, ptr(xs[0]), _p(w), ptr(outs[0]), _p(bias), ptr(residuals[0]), ptr(mask_refs[0]), mask_c,
                                          BF16 if x3 else dt(x0.dtype), BF16 if x3 else dt(x0.dtype), g0[0], g0[1], g0[2], c, k, r, s, stride, pad, g0[3], g0[4],
                                          ldy, g0[5], g0[6], g0[7], int(relu), int(tile), ctypes.byref(sec), _s()), "unit_conv2d_fwd_pair")
@@ -871,17 +873,19 @@ def conv2d_x3(x, w, k, r, s, stride=1, pad=0, bias=None, residual=None, mask_ref
         assert type(mask_ref) is X3 and mask_ref.is_contiguous()
         mask_c = mask_ref.shape[-1]
     m = n * oh * ow
+    segs = w.shape[-1] // c          # 3 = [Wh | Wh | Wl]; 2 = [Wh | Wl], the two-segment dgrad copy (weight_prep_x3 dgrad_segs)
+    assert segs in (2, 3) and w.shape[-1] == segs * c, "conv2d_x3: w is a weight_prep_x3 copy"
     if tile is None:
-        pkey = ("x3", m, k, c, r * s, X3_TILE_POLICY, _NO_LC)
+        pkey = ("x3", m, k, c, r * s, X3_TILE_POLICY, _NO_LC, segs)
         tile = _POLICY_CACHE.get(pkey)
         if tile is None:
-            tile = _POLICY_CACHE[pkey] = X3_TILE_POLICY(m, k, c, 3 * r * s * c)
+            tile = _POLICY_CACHE[pkey] = X3_TILE_POLICY(m, k, c, segs * r * s * c)
     prof = PROFILER
     if prof is not None:
         e0 = torch.cuda.Event(enable_timing=True)
         e0.record()
-    check(lib().unit_conv2d_fwd_x3(_px(x), _p(w), _px(out), _p(bias), _px(residual), _px(mask_ref), mask_c, n, h, wd, c, k, r, s, stride, pad,
-                                   oh, ow, k, oy_mul, ohf, owf, int(relu), int(tile), _s()), "unit_conv2d_fwd_x3")
+    check(lib().unit_conv2d_fwd_x3s(_px(x), _p(w), _px(out), _p(bias), _px(residual), _px(mask_ref), mask_c, n, h, wd, c, k, r, s, stride, pad,
+                                    oh, ow, k, oy_mul, ohf, owf, int(relu), int(tile), segs, _s()), "unit_conv2d_fwd_x3s")
     if prof is not None:
         e1 = torch.cuda.Event(enable_timing=True)
         e1.record()
@@ -890,10 +894,16 @@ def conv2d_x3(x, w, k, r, s, stride=1, pad=0, bias=None, residual=None, mask_ref
         if tile >= 0:
             bm, bn = mid_tile_dims(tile)
             tiles = ((m + bm - 1) // bm) * ((k + bn - 1) // bn)
-            feed = ((tiles + 255) // 256) * (3 * r * s * c // 64) * (bm + bn) * 128.0
-        # flops = the MFMA work issued: three bf16 products per fp32 product
-        prof.setdefault("conv_igemm256" if tile < 0 else "conv_igemm_dma", []).append((e0, e1, 3 * 2.0 * m * k * r * s * c, nbytes, feed))
+            feed = ((tiles + 255) // 256) * (segs * r * s * c // 64) * (bm + bn) * 128.0
+        # flops = the MFMA work issued: three (dgrad with two segments: two) bf16 products per fp32 product
+        prof.setdefault("conv_igemm256" if tile < 0 else "conv_igemm_dma", []).append((e0, e1, segs * 2.0 * m * k * r * s * c, nbytes, feed))
     return out
+
+
+# k-segments of the DGRAD copies of the bf16x3 mode (round 6): 2 = [Wh | Wl] against the gradient map's hi plane (dx = hi(dy).(Wh + Wl)),
+# 3 = the forward's three products. UNIT_X3_DGRAD_SEGS=3 restores round 5 (A/B; profiles/r06_exp_x3_wgrad_passes.txt)
+X3_DGRAD_SEGS = int(os.environ.get("UNIT_X3_DGRAD_SEGS", "2"))
+assert X3_DGRAD_SEGS in (2, 3)
 
 
 def weight_prep_x3(w_krsc, scale, k, r, s, c, want_fwd=True, want_dgrad=True, w_fwd=None, w_dgrad=None):
@@ -902,10 +912,11 @@ def weight_prep_x3(w_krsc, scale, k, r, s, c, want_fwd=True, want_dgrad=True, w_
     dev = w_krsc.device
     if want_fwd and w_fwd is None:
         w_fwd = torch.empty((k, r, s, 3 * c), dtype=torch.bfloat16, device=dev)
-    if want_dgrad and w_dgrad is None:
-        w_dgrad = torch.empty((c, r, s, 3 * k), dtype=torch.bfloat16, device=dev)
-    check(lib().unit_weight_prep_x3(_p(w_krsc), _p(scale), k, r, s, c, _p(w_fwd) if want_fwd else None, _p(w_dgrad) if want_dgrad else None, _s()),
-          "weight_prep_x3")
+    dsegs = X3_DGRAD_SEGS
+    if want_dgrad and (w_dgrad is None or w_dgrad.shape[-1] != dsegs * k):
+        w_dgrad = torch.empty((c, r, s, dsegs * k), dtype=torch.bfloat16, device=dev)
+    check(lib().unit_weight_prep_x3s(_p(w_krsc), _p(scale), k, r, s, c, _p(w_fwd) if want_fwd else None, _p(w_dgrad) if want_dgrad else None,
+                                     dsegs, _s()), "weight_prep_x3s")
     return (w_fwd if want_fwd else None), (w_dgrad if want_dgrad else None)
 
 
