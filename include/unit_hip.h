@@ -334,6 +334,11 @@ size_t unit_rpn_loss_scratch_bytes(int B, int Ncap);
 int unit_rpn_loss(const float* head, int ld, int A, int dcol0, const int8_t* labels, const int64_t* match_idx, const float* gt_boxes,
                   int Mcap, const float* anchors, int B, int Ncap, float normalizer, float gscale, float* loss2, void* dhead,
                   int dhead_dtype, float* scratch, size_t scratch_bytes, void* stream);
+/* unit_rpn_loss with Detectron2's per-loss weights (rpn.py:100 `v * self.loss_weight.get(k, 1.0)`: MODEL.RPN.LOSS_WEIGHT for loss_rpn_cls,
+ * LOSS_WEIGHT * BBOX_REG_LOSS_WEIGHT for loss_rpn_loc): loss values and gradients are scaled */
+int unit_rpn_loss_w(const float* head, int ld, int A, int dcol0, const int8_t* labels, const int64_t* match_idx, const float* gt_boxes,
+                    int Mcap, const float* anchors, int B, int Ncap, float normalizer, float gscale, float w_cls, float w_loc, float* loss2,
+                    void* dhead, int dhead_dtype, float* scratch, size_t scratch_bytes, void* stream);
 int unit_sup_scores(const float* delta, int ldd, int dcol0, const float* weak, int ldw, int wcol0, int n_oicr, int ncls,
                     const unsigned char* novel_mask_dev, const float* extra, int lde, int ecol0, float* out, int ldo, int R,
                     void* stream);

@@ -83,11 +83,15 @@ def test_predictor_forward_losses_inference(dev, ft):
     assert torch.equal(torch.isinf(scores.cpu()), torch.isinf(rs))
     fin = torch.isfinite(rs)
     assert torch.allclose(scores.cpu()[fin], rs[fin], rtol=1e-4, atol=1e-4) and torch.allclose(bbox.cpu(), rb, rtol=1e-4, atol=1e-4)
-    from unit_amd.modeling import fast_rcnn as _fr
-    _fr._WARNED_VALUES_ONLY[0] = False
-    with pytest.warns(RuntimeWarning, match="without an autograd graph"):       # values only: training runs through the fused step
-        losses = bp.losses([scores, bbox], props, weak_predictions=weak_ret, weak_proposals=wprops, weak_targets=wtargets)
-    assert all(not v.requires_grad for v in losses.values())
+    losses = bp.losses([scores, bbox], props, weak_predictions=weak_ret, weak_proposals=wprops, weak_targets=wtargets)
+    assert all(v.requires_grad for v in losses.values())          # training-mode predictions and losses carry a graph (round 6; values only until then)
+    with torch.no_grad():          # ... and under no_grad the same kernels return values
+        (s_ng, b_ng), w_ng = bp(x.to(dev), nov_t, base_t, supervised_branch_x_weak=xw.to(dev), x_weak=xweak.to(dev),
+                                similarity={k: v.to(dev) for k, v in sim.items()} if ft else None)
+        l_ng = bp.losses([s_ng, b_ng], props, weak_predictions=w_ng, weak_proposals=wprops, weak_targets=wtargets)
+    assert not s_ng.requires_grad and all(not v.requires_grad for v in l_ng.values())
+    assert torch.equal(torch.nan_to_num(s_ng, neginf=-1e30), torch.nan_to_num(scores.detach(), neginf=-1e30))
+    assert all(torch.equal(l_ng[k], losses[k].detach()) for k in losses)
     ref = orc.fast_rcnn_losses(rs, rb, torch.cat(flat["b"]), torch.cat(flat["gb"]), torch.cat(flat["gc"]))
     cs, ds, oicr = orc.weak_head_forward_train(xweak, p, "roi_heads.box_predictor.weak_detector_head")
     assert torch.allclose(weak_ret[0].cpu(), cs, rtol=1e-4, atol=1e-4) and torch.allclose(weak_ret[1].cpu(), ds, rtol=1e-4, atol=1e-4)
@@ -95,6 +99,41 @@ def test_predictor_forward_losses_inference(dev, ft):
     assert set(losses) == set(ref) == {"loss_cls", "loss_box_reg", "loss_im_cls", "loss_oicr_1", "loss_oicr_2", "loss_oicr_3"}
     for k, v in ref.items():
         assert abs(losses[k].item() - v.item()) <= 1e-4 * max(1.0, abs(v.item())), (k, losses[k].item(), v.item())
+    # ---- the graph: a WEIGHTED sum of the six losses, backward, against torch autograd over the oracle's forward (fast_rcnn.py:435-453 hands
+    # the reference's trainer differentiable losses; the loss nodes scale the kernels' gradient by whatever weight arrives)
+    wts = dict(loss_cls=1.0, loss_box_reg=0.5, loss_im_cls=2.0, loss_oicr_1=0.25, loss_oicr_2=1.5, loss_oicr_3=1.0)
+    trainable = {n for n, q in model.named_parameters() if q.requires_grad}
+    pg = {k: v.clone().requires_grad_(k in trainable) for k, v in p.items()}
+    xo, xwo = x.clone().requires_grad_(True), xweak.clone().requires_grad_(True)
+    simo = {h: v.clone().requires_grad_(True) for h, v in sim.items()} if ft else None
+    rs2, rb2 = orc.supervised_predictor_forward(xo, xw, pg, "roi_heads.box_predictor", novel, training=True, similarity=simo, base_classes=base,
+                                                finetune=ft)
+    ro = orc.fast_rcnn_losses(rs2, rb2, torch.cat(flat["b"]), torch.cat(flat["gb"]), torch.cat(flat["gc"]))
+    cs2, ds2, oicr2 = orc.weak_head_forward_train(xwo, pg, "roi_heads.box_predictor.weak_detector_head")
+    ro.update(orc.weak_losses(cs2, ds2, oicr2, [w.proposal_boxes.tensor.cpu() for w in wprops], wtargets))
+    sum(wts[k] * v for k, v in ro.items()).backward()
+    for q in model.parameters():
+        q.grad = None
+    xd, xwd = x.to(dev).requires_grad_(True), xweak.to(dev).requires_grad_(True)
+    simd = {h: v.to(dev).requires_grad_(True) for h, v in sim.items()} if ft else None
+    (sc3, bb3), wr3 = bp(xd, nov_t, base_t, supervised_branch_x_weak=xw.to(dev), x_weak=xwd, similarity=simd)
+    l3 = bp.losses([sc3, bb3], props, weak_predictions=wr3, weak_proposals=wprops, weak_targets=wtargets)
+    sum(wts[k] * v for k, v in l3.items()).backward()
+    close = lambda a, b, what: (a.cpu() - b).abs().max().item() <= 2e-4 * b.abs().max().item() + 1e-9 or pytest.fail(f"{what}: {(a.cpu() - b).abs().max().item()} vs max {b.abs().max().item()}")
+    close(xd.grad, xo.grad, "d/dx")
+    named = dict(model.named_parameters())
+    checked = 0
+    for n in sorted(trainable):
+        if not n.startswith("roi_heads.box_predictor.") or n.endswith("embeddings.weight"):
+            continue
+        assert named[n].grad is not None, n
+        close(named[n].grad, pg[n].grad, n)
+        checked += 1
+    assert checked == (4 if ft else 14), checked          # ft yaml: only cls_score_ft / bbox_pred_ft train; base: delta heads + the weak head's five Linears
+    if ft:
+        # one similarity matrix feeds both heads in the reference's heads; handed in as two tensors, its gradient arrives on 'cls'
+        close(simd["cls"].grad, simo["cls"].grad + simo["bbox"].grad, "d/dsimilarity")
+    close(xwd.grad, xwo.grad, "d/dx_weak")
     # ---- eval forward + inference
     bp.eval()
     (se, be), wr = bp(x.to(dev), nov_t, base_t, supervised_branch_x_weak=xw.to(dev), x_weak=None, similarity={k: v.to(dev) for k, v in sim.items()})

@@ -17,6 +17,8 @@ SH = [("res4 1x1 1024->256", 4, 38, 63, 1024, 256, 1, 1, 0, None), ("res4 3x3 25
 CODES = [0, 152, 1152, 1142, 1162, 1172, 1182, 154, 1154, 1144, 0] if len(sys.argv) > 1 else [0, 142, 152, 162, 172, 182, 144, 154, 164, 0]
 if len(sys.argv) > 1 and sys.argv[1] == "two":          # the two-workgroups-per-CU form (two ring slots)
     CODES = [0, 152, 2142, 2152, 2162, 0]
+if len(sys.argv) > 1 and sys.argv[1] == "wd":           # weights fetched straight into the consumers' registers (code + 8000) beside the staged form
+    CODES = [0, 142, 8142, 152, 8152, 162, 8162, 172, 8172, 182, 8182, 144, 8144, 154, 8154, 164, 8164]
 dev = torch.device("cuda:0")
 for name, n, h, w, c, k, r, st, pad, extra in SH:
     x = torch.randn(n, h, w, c, device=dev).bfloat16()

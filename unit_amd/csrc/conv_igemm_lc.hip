@@ -54,12 +54,19 @@ __device__ __forceinline__ void wait_vmcnt_rt(int n) {
 #undef LC_R
 }
 
-template <int FB, int FA, int NL, int NSMAX = 3> struct LcCfg {
+// WD ("weights direct", round 6): the weight fragments do not pass through LDS at all. A consumer wave owns FA*16 channels of the tile
+// exclusively -- nobody else reads its weight rows -- so staging them in LDS buys no sharing and costs the CU's LDS port twice (the
+// LDS-DMA write and the fragment read): of the ~83 KB that cross the port per k-step of an 80 x 128 tile (26.6 KB staged + 4 x 10 KB of
+// pixel fragments + 16 KB of weight fragments) 32 KB are weights, and at 128 B/clk the port, not the MFMA pipe (282 clk) or the L2, is what
+// the ~900 clk k-step waits for. With WD every consumer lane fetches its 16-byte fragment piece straight from L2 into registers
+// (buffer_load_dwordx4: row = its channel, the same k-slice the LDS image would have held -- same MFMA operands, bit-identical results),
+// PD k-steps ahead; the loaders stage pixels only.
+template <int FB, int FA, int NL, int NSMAX = 3, bool WD = false> struct LcCfg {
   static constexpr int BM = FB * 16, BN = FA * 64;
-  static constexpr int XP = BM / 8, WP = BN / 8, TP = XP + WP;     // LDS-DMA pieces (8 rows x 128 B) per k-step: X, W, all
+  static constexpr int XP = BM / 8, WP = WD ? 0 : BN / 8, TP = XP + WP;     // LDS-DMA pieces (8 rows x 128 B) per k-step: X, W, all
   static constexpr int XPL = (XP + NL - 1) / NL, WPL = (WP + NL - 1) / NL;      // at most so many per loader wave
   static constexpr int XR = BM;                                     // X rows of a slot
-  static constexpr int SLOT = (XR + BN) * 128;
+  static constexpr int SLOT = (XR + (WD ? 0 : BN)) * 128;
   static constexpr int THREADS = (4 + NL) * 64;
   static constexpr int SCR = 4 * EpiCfg<FA>::BYTES;
   static constexpr int NS = ((160 * 1024 - SCR) / SLOT >= NSMAX) ? NSMAX : (160 * 1024 - SCR) / SLOT;
@@ -81,10 +88,11 @@ template <int FB, int FA, int NL, int NSMAX = 3> struct LcCfg {
 //   RAW: after issuing in iteration g a loader lets only its pieces of iterations g and g - 1 stay in flight; what step g + 1 reads was issued
 //        in iteration g - 2 or earlier.   WAR: see the slot table above; a slot's last reader retired its reads before the barrier that the
 //        loaders pass before overwriting it.
-template <int FB, int FA, int NL, int NSMAX = 3, bool X3 = false, bool PAIR = false, bool R3 = false>
+template <int FB, int FA, int NL, int NSMAX = 3, bool X3 = false, bool PAIR = false, bool R3 = false, bool WD = false>
 __global__ void __launch_bounds__((4 + NL) * 64) conv_igemm_lc_kernel(ConvDmaArgs p) {
   static_assert(!R3 || (X3 && !PAIR && NSMAX == 3), "operand reuse: bf16x3 operands, one problem, the three-slot ring");
-  typedef LcCfg<FB, FA, NL, NSMAX> Cf;
+  static_assert(!WD || !R3, "weights direct: not with the operand-reuse rings");
+  typedef LcCfg<FB, FA, NL, NSMAX, WD> Cf;
   constexpr int BM = Cf::BM, BN = Cf::BN, BK = 64;
   constexpr int XP = Cf::XP, WP = Cf::WP, TP = Cf::TP, XPL = Cf::XPL, WPL = Cf::WPL, XR = Cf::XR, SLOT = Cf::SLOT, NS = Cf::NS;
   constexpr int D = NS - 1, PLO = TP / NL, NHI = TP % NL;           // loaders 0 .. NHI-1 issue PLO + 1 pieces per k-step, the others PLO
@@ -284,6 +292,11 @@ __global__ void __launch_bounds__((4 + NL) * 64) conv_igemm_lc_kernel(ConvDmaArg
   for (int a = 0; a < FA; ++a) { int row = c * FA * 16 + a * 16 + frow; offw[a] = XR * 128 + row * 128 + ((fq ^ ((row >> 1) & 7)) << 4); }
   char* scr = smem + NS * SLOT + c * EpiCfg<FA>::BYTES;
   int slot = 0;
+  // WD: this lane's piece of every weight fragment comes straight from memory -- row = channel n0 + c*FA*16 + a*16 + frow, bytes
+  // (k0 + ks*32 + fq*8) * 2 .. +16 of it: exactly the 16 bytes the LDS image holds at offw[a] ^ (ks * 64)
+  constexpr int PD = WD ? (FA <= 2 ? 2 : 1) : 0, SETS = PD + 1;      // k-steps of prefetch; register sets of fragments
+  __amdgpu_buffer_rsrc_t rsWc = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>((const bf16_t*)p.w), 0, (int)p.w_bytes, 0x00020000);
+  const int RSc = p.R * p.S;
   for (int t = 0; t < t_count; ++t) {
     int id = t_first + t;
     bool second = false;
@@ -295,6 +308,71 @@ __global__ void __launch_bounds__((4 + NL) * 64) conv_igemm_lc_kernel(ConvDmaArg
     for (int a = 0; a < FA; ++a)
 #pragma unroll
       for (int b = 0; b < FB; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if constexpr (WD) {
+      constexpr unsigned OOBW = 0xFFFFFFF0u;
+      unsigned wrow[FA]; bool wok[FA];
+#pragma unroll
+      for (int a = 0; a < FA; ++a) {
+        int nn = tile_n * BN + c * FA * 16 + a * 16 + frow;
+        wok[a] = nn < p.K;
+        wrow[a] = ((unsigned)(wok[a] ? nn : 0) * (unsigned)p.Kgemm + (unsigned)fq * 8u) * 2u;
+      }
+      i32x4 fw[SETS][2][FA];
+      int w_rs = 0, w_cb = 0;                        // (channel block, tap) of the next k-step to fetch: k order = block outermost, taps innermost
+      auto fetch = [&](i32x4 (&dst)[2][FA]) {
+        const unsigned koff = (unsigned)(w_rs * p.C + w_cb * BK) * 2u;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+          for (int a = 0; a < FA; ++a)
+            dst[ks][a] = __builtin_bit_cast(i32x4, __builtin_amdgcn_raw_buffer_load_b128(rsWc, (int)(wok[a] ? wrow[a] + koff + (unsigned)ks * 64u : OOBW), 0, 0));
+        if (++w_rs == RSc) { w_rs = 0; ++w_cb; }
+      };
+      // one k-step: wait for the slot's pixels (the barrier all eight waves meet at), read the pixel fragments, multiply with the weight
+      // fragments of register set `fwu`
+      auto kstep = [&](const i32x4 (&fwu)[2][FA]) {
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        const char* base = smem + slot * SLOT;
+        i32x4 fb[2][FB];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+          for (int b = 0; b < FB; ++b) fb[ks][b] = *reinterpret_cast<const i32x4*>(base + (offx[b] ^ (ks * 64)));
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+          for (int a = 0; a < FA; ++a)
+#pragma unroll
+            for (int b = 0; b < FB; ++b)
+              acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fwu[ks][a]), __builtin_bit_cast(bf16x8, fb[ks][b]), acc[a][b], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+        slot = slot + 1 == NS ? 0 : slot + 1;
+      };
+      // (nk > PD: unit_conv_lc_launch sends shorter contractions to the staged form.) Prologue and steady state are free of conditional
+      // fetches: hipcc's vmcnt bookkeeping merges the pending loads of both branches at every join and falls back to vmcnt(0) -- no
+      // prefetch at all -- wherever a fetch is conditional; this way the count at the loop header is the same from both of its edges.
+#pragma unroll
+      for (int u = 0; u < PD; ++u) fetch(fw[u]);
+      int kt = 0;
+      for (; kt + SETS - 1 + PD < nk; kt += SETS) {
+#pragma unroll
+        for (int u = 0; u < SETS; ++u) {
+          fetch(fw[(u + PD) % SETS]);
+          kstep(fw[u]);
+        }
+      }
+      const int rem = nk - kt;                       // PD .. SETS + PD - 1 steps left; set of step kt + j = j % SETS
+#pragma unroll
+      for (int j = 0; j < SETS + PD - 1; ++j) {
+        if (j < rem) {
+          if (j + PD < rem) fetch(fw[(j + PD) % SETS]);
+          kstep(fw[j % SETS]);
+        }
+      }
+    } else
     for (int kt = 0; kt < nk; ++kt) {
       __builtin_amdgcn_s_barrier();
       __builtin_amdgcn_sched_barrier(0);
@@ -335,9 +413,9 @@ __global__ void __launch_bounds__((4 + NL) * 64) conv_igemm_lc_kernel(ConvDmaArg
   }
 }
 
-template <int FB, int FA, int NL, int NSMAX = 3, bool X3 = false>
+template <int FB, int FA, int NL, int NSMAX = 3, bool X3 = false, bool WD = false>
 static int launch_lc(ConvDmaArgs& a, hipStream_t st) {
-  typedef LcCfg<FB, FA, NL, NSMAX> Cf;
+  typedef LcCfg<FB, FA, NL, NSMAX, WD> Cf;
   a.tiles_m = cdiv(a.M, Cf::BM); a.tiles_n = cdiv(a.K, Cf::BN);
   int total = a.tiles_m * a.tiles_n;
   if (a.second.on) {          // pair launch (only the default three-slot / four-loader forms carry a PAIR instantiation)
@@ -348,10 +426,10 @@ static int launch_lc(ConvDmaArgs& a, hipStream_t st) {
       int grid = total < 256 ? total : 256;
       static bool attr2 = false;
       if (!attr2) {
-        (void)hipFuncSetAttribute((const void*)conv_igemm_lc_kernel<FB, FA, NL, NSMAX, X3, true>, hipFuncAttributeMaxDynamicSharedMemorySize, Cf::LDS);
+        (void)hipFuncSetAttribute((const void*)conv_igemm_lc_kernel<FB, FA, NL, NSMAX, X3, true, false, WD>, hipFuncAttributeMaxDynamicSharedMemorySize, Cf::LDS);
         attr2 = true;
       }
-      conv_igemm_lc_kernel<FB, FA, NL, NSMAX, X3, true><<<grid, Cf::THREADS, Cf::LDS, st>>>(a);
+      conv_igemm_lc_kernel<FB, FA, NL, NSMAX, X3, true, false, WD><<<grid, Cf::THREADS, Cf::LDS, st>>>(a);
       UNIT_LAUNCH_CHECK();
       return UNIT_OK;
     } else {
@@ -361,7 +439,7 @@ static int launch_lc(ConvDmaArgs& a, hipStream_t st) {
   }
   const int slots = NSMAX == 2 ? 512 : 256;          // persistent workgroups: one per CU, two with the two-slot ring
   int grid = total < slots ? total : slots;
-  if constexpr (X3 && NL == 4 && NSMAX == 3) {
+  if constexpr (X3 && NL == 4 && NSMAX == 3 && !WD) {
     // operand reuse (R3) for the pointwise layers: lo / hi / Wh / Wl of a block staged once each. UNIT_X3_REUSE=0: off (A/B, bit-identity test)
     const char* e = getenv("UNIT_X3_REUSE");
     if ((e ? atoi(e) : 1) && a.R == 1 && a.S == 1 && a.sk.nseg == 3 && (a.Kgemm / 64) % 3 == 0) {
@@ -377,10 +455,10 @@ static int launch_lc(ConvDmaArgs& a, hipStream_t st) {
   }
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)conv_igemm_lc_kernel<FB, FA, NL, NSMAX, X3>, hipFuncAttributeMaxDynamicSharedMemorySize, Cf::LDS);
+    (void)hipFuncSetAttribute((const void*)conv_igemm_lc_kernel<FB, FA, NL, NSMAX, X3, false, false, WD>, hipFuncAttributeMaxDynamicSharedMemorySize, Cf::LDS);
     attr_set = true;
   }
-  conv_igemm_lc_kernel<FB, FA, NL, NSMAX, X3><<<grid, Cf::THREADS, Cf::LDS, st>>>(a);
+  conv_igemm_lc_kernel<FB, FA, NL, NSMAX, X3, false, false, WD><<<grid, Cf::THREADS, Cf::LDS, st>>>(a);
   UNIT_LAUNCH_CHECK();
   return UNIT_OK;
 }
@@ -405,7 +483,16 @@ int unit_conv_lc_launch(ConvDmaArgs& a, int out_dtype, int code, hipStream_t st)
     unit_set_error("conv_lc: bf16x3 operands: tile code 142 .. 182, 144 .. 164");
     return UNIT_ERR_UNSUPPORTED;
   }
-  switch (code) {
+  if (code >= 8000 && a.Kgemm / 64 < 4) code -= 8000;          // (the prefetch pipeline of the WD form wants >= 4 k-steps)
+  switch (code) {          // + 8000: weights direct (WD), the default three-slot / four-loader form of every tile shape
+    case 8142: return launch_lc<4, 2, 4, 3, false, true>(a, st);
+    case 8152: return launch_lc<5, 2, 4, 3, false, true>(a, st);
+    case 8162: return launch_lc<6, 2, 4, 3, false, true>(a, st);
+    case 8172: return launch_lc<7, 2, 4, 3, false, true>(a, st);
+    case 8182: return launch_lc<8, 2, 4, 3, false, true>(a, st);
+    case 8144: return launch_lc<4, 4, 4, 3, false, true>(a, st);
+    case 8154: return launch_lc<5, 4, 4, 3, false, true>(a, st);
+    case 8164: return launch_lc<6, 4, 4, 3, false, true>(a, st);
     case 142: return launch_lc<4, 2, 4>(a, st);
     case 152: return launch_lc<5, 2, 4>(a, st);
     case 162: return launch_lc<6, 2, 4>(a, st);

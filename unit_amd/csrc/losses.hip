@@ -53,7 +53,7 @@ __device__ __forceinline__ f32x4 encode1(f32x4 s, f32x4 t, f32x4 w) {
 template <typename TD>
 __global__ void rpn_loss_kernel(const float* __restrict__ head, int ld, int A, int dcol0, const int8_t* __restrict__ labels,
                                 const int64_t* __restrict__ midx, const float* __restrict__ gt, int Mcap,
-                                const float* __restrict__ anchors, int Ncap, float inv_norm, float gscale,
+                                const float* __restrict__ anchors, int Ncap, float inv_norm, float gscale, float w_cls, float w_loc,
                                 float* __restrict__ loss2, TD* __restrict__ dhead, float* __restrict__ scratch) {
   __shared__ float lds[17];
   __shared__ int s_last;
@@ -70,7 +70,7 @@ __global__ void rpn_loss_kernel(const float* __restrict__ head, int ld, int A, i
       // binary_cross_entropy_with_logits: max(x,0) - x*y + log1p(exp(-|x|))
       lc = fmaxf(x, 0.f) - x * y + log1pf(expf(-fabsf(x)));
       float sg = 1.f / (1.f + expf(-x));
-      dl = (sg - y) * inv_norm * gscale;
+      dl = (sg - y) * inv_norm * gscale * w_cls;
     }
     if (lab == 1) {
       f32x4 an = *reinterpret_cast<const f32x4*>(anchors + 4 * (size_t)i);
@@ -81,7 +81,7 @@ __global__ void rpn_loss_kernel(const float* __restrict__ head, int ld, int A, i
       for (int j = 0; j < 4; ++j) {
         float df = head[row + dcol0 + 4 * a + j] - t[j];
         ll += fabsf(df);
-        dd[j] = (df > 0.f ? 1.f : (df < 0.f ? -1.f : 0.f)) * inv_norm * gscale;
+        dd[j] = (df > 0.f ? 1.f : (df < 0.f ? -1.f : 0.f)) * inv_norm * gscale * w_loc;
       }
     }
     st(dhead + row + a, dl);
@@ -110,16 +110,30 @@ __global__ void rpn_loss_kernel(const float* __restrict__ head, int ld, int A, i
   }
   tc = block_sum(tc, lds);
   tl = block_sum(tl, lds);
-  if (threadIdx.x == 0) { loss2[0] = tc * inv_norm; loss2[1] = tl * inv_norm; }
+  if (threadIdx.x == 0) { loss2[0] = tc * inv_norm * w_cls; loss2[1] = tl * inv_norm * w_loc; }
 }
 
 // two partial sums per workgroup + the arrival counter
 extern "C" size_t unit_rpn_loss_scratch_bytes(int B, int Ncap) { return ((size_t)2 * cdiv(Ncap, 256) * (B > 0 ? B : 1) + 1) * sizeof(float); }
 
+extern "C" int unit_rpn_loss_w(const float* head, int ld, int A, int dcol0, const int8_t* labels, const int64_t* match_idx,
+                               const float* gt_boxes, int Mcap, const float* anchors, int B, int Ncap, float normalizer,
+                               float gscale, float w_cls, float w_loc, float* loss2, void* dhead, int dhead_dtype, float* scratch,
+                               size_t scratch_bytes, void* stream);
 extern "C" int unit_rpn_loss(const float* head, int ld, int A, int dcol0, const int8_t* labels, const int64_t* match_idx,
                              const float* gt_boxes, int Mcap, const float* anchors, int B, int Ncap, float normalizer,
                              float gscale, float* loss2, void* dhead, int dhead_dtype, float* scratch, size_t scratch_bytes,
                              void* stream) {
+  return unit_rpn_loss_w(head, ld, A, dcol0, labels, match_idx, gt_boxes, Mcap, anchors, B, Ncap, normalizer, gscale, 1.0f, 1.0f, loss2, dhead,
+                         dhead_dtype, scratch, scratch_bytes, stream);
+}
+
+// w_cls / w_loc: the `loss_weight` dictionary of Detectron2's RPN (rpn.py:100 `losses = {k: v * self.loss_weight.get(k, 1.0)}`;
+// MODEL.RPN.LOSS_WEIGHT and LOSS_WEIGHT * BBOX_REG_LOSS_WEIGHT): both the loss values and their gradients carry them
+extern "C" int unit_rpn_loss_w(const float* head, int ld, int A, int dcol0, const int8_t* labels, const int64_t* match_idx,
+                               const float* gt_boxes, int Mcap, const float* anchors, int B, int Ncap, float normalizer,
+                               float gscale, float w_cls, float w_loc, float* loss2, void* dhead, int dhead_dtype, float* scratch,
+                               size_t scratch_bytes, void* stream) {
   UNIT_CHECK_ARG(Ncap % A == 0, "rpn_loss: Ncap % A != 0");
   hipStream_t s = (hipStream_t)stream;
   size_t need = unit_rpn_loss_scratch_bytes(B, Ncap);
@@ -132,9 +146,9 @@ extern "C" int unit_rpn_loss(const float* head, int ld, int A, int dcol0, const 
   dim3 grid(cdiv(Ncap, 256), B);
   float inv = 1.0f / normalizer;
   if (dhead_dtype == UNIT_BF16)
-    rpn_loss_kernel<bf16_t><<<grid, 256, 0, s>>>(head, ld, A, dcol0, labels, match_idx, gt_boxes, Mcap, anchors, Ncap, inv, gscale, loss2, (bf16_t*)dhead, scratch);
+    rpn_loss_kernel<bf16_t><<<grid, 256, 0, s>>>(head, ld, A, dcol0, labels, match_idx, gt_boxes, Mcap, anchors, Ncap, inv, gscale, w_cls, w_loc, loss2, (bf16_t*)dhead, scratch);
   else
-    rpn_loss_kernel<float><<<grid, 256, 0, s>>>(head, ld, A, dcol0, labels, match_idx, gt_boxes, Mcap, anchors, Ncap, inv, gscale, loss2, (float*)dhead, scratch);
+    rpn_loss_kernel<float><<<grid, 256, 0, s>>>(head, ld, A, dcol0, labels, match_idx, gt_boxes, Mcap, anchors, Ncap, inv, gscale, w_cls, w_loc, loss2, (float*)dhead, scratch);
   UNIT_LAUNCH_CHECK();
   return UNIT_OK;
 }

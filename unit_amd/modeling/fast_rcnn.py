@@ -7,8 +7,6 @@ Parameter names equal the reference's (`cls_score_delta`, `bbox_pred_delta`, `cl
 All Linear layers that share an input run as one fused GEMM (LinearGroup); the loss kernels emit loss + gradient."""
 import os
 
-import warnings
-
 import torch
 from torch import nn
 
@@ -21,19 +19,6 @@ def _freeze_by_first_component(module, layers):
     for name, p in module.named_parameters():
         if any(layer == name.split(".")[0] for layer in layers):
             p.requires_grad = False
-
-
-_WARNED_VALUES_ONLY = [False]
-
-
-def _warn_values_only(who):
-    """the module-level `forward` / `losses` of the predictors run the HIP kernels under no_grad: in training mode they return VALUES
-    (for monitoring and the module-level parity tests) that carry no autograd graph -- a trainer that composes these modules itself and
-    calls `.backward()` on their losses would update nothing. Training runs through the fused step."""
-    if not _WARNED_VALUES_ONLY[0]:
-        _WARNED_VALUES_ONLY[0] = True
-        warnings.warn(f"{who}.losses in training mode returns loss VALUES without an autograd graph; gradients come from the fused step "
-                      "(WeaklySupervisedRCNNNoMeta.forward / TrainerNoMeta.run_step), see INTEGRATION.md", RuntimeWarning, stacklevel=3)
 
 
 @WEAK_DETECTOR_FAST_RCNN_REGISTRY.register()
@@ -106,13 +91,15 @@ class WeakDetectorOutputsBase(nn.Module):
         self.prepare(dtype, getattr(self, "_version", 0))
         return self.group.fwd(ops.cast(x_weak.contiguous(), dtype))
 
-    @torch.no_grad()
     def forward(self, x_weak):
-        """:148-165 -> ([classifier_stream / T_cls, detection_stream / T_det, [oicr_k], [], None, None], None) in training,
-        `evaluation(x_weak)` otherwise"""
+        """:148-165 -> ([classifier_stream / T_cls, detection_stream / T_det, [oicr_k], [], None, None], None) in training (the outputs
+        carry an autograd graph: one node over the fused Linear, modeling/train_modules.py), `evaluation(x_weak)` otherwise"""
         if not self.training:
             return self.evaluation(x_weak)
-        lin, k = self._lin(x_weak), self.num_classes
+        from .train_modules import _WeakPredictFn, _anchor
+        k = self.num_classes
+        x = x_weak if x_weak.requires_grad else x_weak + _anchor(self, x_weak.device) * 0          # (the node's parameters are updated by its explicit backward)
+        lin = _WeakPredictFn.apply(x, self)
         cs = lin[:, self.col_cls:self.col_cls + k] / self.classifier_temp
         ds = lin[:, self.col_det:self.col_det + k] / self.detector_temp
         return [cs, ds, [lin[:, c:c + k + 1] for c in self.col_oicr], [], None, None], None
@@ -123,13 +110,17 @@ class WeakDetectorOutputsBase(nn.Module):
         lin, k = self._lin(x_weak), self.num_classes
         return [[lin[:, c:c + k + 1] for c in self.col_oicr], torch.zeros((lin.shape[0], 4 * k), device=lin.device)], None
 
-    @torch.no_grad()
     def losses(self, weak_predictions, weak_proposals, weak_targets):
-        """:189-255 -> {'loss_im_cls', 'loss_oicr_1..n'} (values; HIP kernels unit_wsddn_mil / unit_oicr_targets / unit_softmax_ce).
-        weak_predictions = forward()'s list, weak_proposals = list[Instances(proposal_boxes)], weak_targets = list[LongTensor]."""
-        if self.training:
-            _warn_values_only(type(self).__name__)
+        """:189-255 -> {'loss_im_cls', 'loss_oicr_1..n'} (HIP kernels unit_wsddn_mil / unit_oicr_targets / unit_softmax_ce). With predictions
+        that carry a graph (training-mode forward) the losses do too: one autograd node whose backward hands out the gradient the loss kernels
+        emit, scaled by the weight that arrives. weak_predictions = forward()'s list, weak_proposals = list[Instances(proposal_boxes)],
+        weak_targets = list[LongTensor]."""
         cs, ds, oicr = weak_predictions[0], weak_predictions[1], weak_predictions[2]
+        with_graph = torch.is_grad_enabled() and any(t.requires_grad for t in [cs, ds] + list(oicr))
+        with torch.set_grad_enabled(with_graph):
+            return self._losses(cs, ds, oicr, weak_proposals, weak_targets, with_graph)
+
+    def _losses(self, cs, ds, oicr, weak_proposals, weak_targets, with_graph):
         k, dev = self.num_classes, cs.device
         sizes = [len(p) for p in weak_proposals]
         b, s = len(sizes), max(sizes)
@@ -150,8 +141,12 @@ class WeakDetectorOutputsBase(nn.Module):
             valid[rows] = 0
             multihot[i, weak_targets[i].long().to(dev)] = 1
             o += n
-        loss = torch.zeros(1 + self.oicr_iter, dtype=torch.float32, device=dev)
-        self.fused_losses(lin, rois5, valid, s, b, multihot, loss, torch.float32)
+        if with_graph:
+            from .train_modules import _WeakLossFn
+            loss = _WeakLossFn.apply(lin, self, dict(rois5=rois5, valid=valid, s=s, b=b, multihot=multihot))
+        else:
+            loss = torch.zeros(1 + self.oicr_iter, dtype=torch.float32, device=dev)
+            self.fused_losses(lin, rois5, valid, s, b, multihot, loss, torch.float32)
         out = {"loss_im_cls": loss[0]}
         out.update({f"loss_oicr_{i + 1}": loss[1 + i] for i in range(self.oicr_iter)})
         return out
@@ -244,9 +239,26 @@ class SupervisedDetectorOutputsBase(nn.Module):
             self._roles_key = key
         return self._roles_t
 
-    @torch.no_grad()
     def forward(self, x, novel_classes, base_classes, supervised_branch_x_weak=None, x_weak=None, similarity=None):
-        """fast_rcnn.py:384-433 (Base) / :484-533 (FineTune) -> ([scores [R,K+1], bbox [R,4K]], weak_branch_return).
+        """fast_rcnn.py:384-433 (Base) / :484-533 (FineTune) -> ([scores [R,K+1], bbox [R,4K]], weak_branch_return). In TRAINING mode with
+        autograd enabled the predictions carry a graph (one node over the predictor's explicit forward / backward, train_modules._SupPredictFn);
+        otherwise values from the same kernels."""
+        if self.training and torch.is_grad_enabled() and x is not None:
+            from .train_modules import _SupPredictFn, _anchor
+            t = self._roles(novel_classes, base_classes, x.device)
+            sim = similarity if self.finetune else None
+            xg = x if x.requires_grad else x + _anchor(self, x.device) * 0
+            scores, bbox = _SupPredictFn.apply(xg, sim["cls"] if sim is not None else None, sim["bbox"] if sim is not None else None, self,
+                                               dict(roles=t, x_sup_weak=supervised_branch_x_weak))
+            weak_ret = None
+            if x_weak is not None:
+                weak_ret, _ = self.weak_detector_head(x_weak)
+            return [scores, bbox], weak_ret
+        with torch.no_grad():
+            return self._forward_values(x, novel_classes, base_classes, supervised_branch_x_weak, x_weak, similarity)
+
+    def _forward_values(self, x, novel_classes, base_classes, supervised_branch_x_weak=None, x_weak=None, similarity=None):
+        """the forward of fast_rcnn.py:384-433 / :484-533 as values (eval; training under no_grad)
         x: box-head features [R, D]; supervised_branch_x_weak: weak_box_head features of the same RoIs (None: x itself, :389-390);
         similarity: {'cls': [R,n,b] | [n,b], 'bbox': ...} -- applied in eval (Base) / always (FineTune); training (Base) fills the
         novel columns with -inf (:427-428)."""
@@ -281,23 +293,29 @@ class SupervisedDetectorOutputsBase(nn.Module):
             weak_ret, _ = wh(x_weak)
         return [scores, bbox], weak_ret
 
-    @torch.no_grad()
     def losses(self, predictions, proposals, weak_predictions=None, weak_proposals=None, weak_targets=None, train_only_weak=False):
         """fast_rcnn.py:435-453 -> {'loss_cls', 'loss_box_reg'} (+ the weak head's losses); proposals = list[Instances] with
-        proposal_boxes, gt_boxes, gt_classes (label_and_sample_proposals' output). Values; HIP kernels unit_softmax_ce / unit_box_reg_loss."""
-        if self.training:
-            _warn_values_only(type(self).__name__)
+        proposal_boxes, gt_boxes, gt_classes (label_and_sample_proposals' output). HIP kernels unit_softmax_ce / unit_box_reg_loss; with
+        predictions that carry a graph (training-mode forward) the losses do too (train_modules._SupLossFn), and may enter the total with
+        any weight."""
         out = {}
         if not train_only_weak:
             scores, bbox = predictions
             dev, k = scores.device, self.num_classes
             tb = lambda v: (v.tensor if hasattr(v, "tensor") else v)
-            pb = torch.cat([tb(p.proposal_boxes) for p in proposals]).to(dev).float()
-            gb = torch.cat([tb(p.gt_boxes) for p in proposals]).to(dev).float()
-            gc = torch.cat([p.gt_classes for p in proposals]).to(dev).int()
-            rois5 = torch.cat([torch.zeros((pb.shape[0], 1), device=dev), pb], 1)
-            out["loss_cls"] = ops.softmax_ce(scores.float().contiguous(), 0, k + 1, gc)[0]
-            out["loss_box_reg"] = ops.box_reg_loss(bbox.float().contiguous(), 0, k, gc, rois5, gb, self.bbox_reg_weights)[0]
+            with torch.no_grad():
+                pb = torch.cat([tb(p.proposal_boxes) for p in proposals]).to(dev).float()
+                gb = torch.cat([tb(p.gt_boxes) for p in proposals]).to(dev).float()
+                gc = torch.cat([p.gt_classes for p in proposals]).to(dev).int()
+                rois5 = torch.cat([torch.zeros((pb.shape[0], 1), device=dev), pb], 1)
+            if torch.is_grad_enabled() and (scores.requires_grad or bbox.requires_grad):
+                from .train_modules import _SupLossFn
+                lv = _SupLossFn.apply(scores, bbox, self, dict(gc=gc, rois5=rois5, gb=gb))
+                out["loss_cls"], out["loss_box_reg"] = lv[0], lv[1]
+            else:
+                with torch.no_grad():
+                    out["loss_cls"] = ops.softmax_ce(scores.float().contiguous(), 0, k + 1, gc)[0]
+                    out["loss_box_reg"] = ops.box_reg_loss(bbox.float().contiguous(), 0, k, gc, rois5, gb, self.bbox_reg_weights)[0]
         if weak_predictions is not None:
             out.update(self.weak_detector_head.losses(weak_predictions, weak_proposals, weak_targets))
         return out

@@ -477,7 +477,8 @@ class WeaklySupervisedRCNNNoMeta(nn.Module):
         def rpn_branch():
             c.anchor_labels, c.anchor_match, _ = rpn.label_and_sample_anchors(anchors, batch.gt_boxes, batch.gt_count, perms["rpn"])
             _, c.dhead = ops.rpn_loss(head[:n_sup], rpn.num_anchors, rpn.num_anchors, c.anchor_labels, c.anchor_match, batch.gt_boxes,
-                                      anchors, rpn.batch_size_per_image * n_sup, dt, loss_out=c.rpn_losses)
+                                      anchors, rpn.batch_size_per_image * n_sup, dt, loss_out=c.rpn_losses,
+                                      weights=(rpn.loss_weight["loss_rpn_cls"], rpn.loss_weight["loss_rpn_loc"]))
 
         if side_rpn:
             self._reattach_grads()

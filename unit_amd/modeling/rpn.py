@@ -115,12 +115,11 @@ class WSRPN(nn.Module):
         self.pre_nms_topk = {True: r.PRE_NMS_TOPK_TRAIN, False: r.PRE_NMS_TOPK_TEST}
         self.post_nms_topk = {True: r.POST_NMS_TOPK_TRAIN, False: r.POST_NMS_TOPK_TEST}
         self.nms_thresh = r.NMS_THRESH
+        # Detectron2 RPN.from_config: loss_weight = {"loss_rpn_cls": LOSS_WEIGHT, "loss_rpn_loc": BBOX_REG_LOSS_WEIGHT * LOSS_WEIGHT}, applied at
+        # rpn.py:100 -- the loss kernel scales values and gradients (unit_rpn_loss_w). All shipped yaml leave both at 1.0.
+        self.loss_weight = {"loss_rpn_cls": float(r.LOSS_WEIGHT), "loss_rpn_loc": float(r.BBOX_REG_LOSS_WEIGHT) * float(r.LOSS_WEIGHT)}
         self.min_box_size = float(cfg.MODEL.PROPOSAL_GENERATOR.MIN_SIZE)
         assert r.BBOX_REG_LOSS_TYPE == "smooth_l1" and r.SMOOTH_L1_BETA == 0.0 and tuple(r.BBOX_REG_WEIGHTS) == (1.0, 1.0, 1.0, 1.0)
-        self.loss_weight = {"loss_rpn_cls": r.LOSS_WEIGHT, "loss_rpn_loc": r.BBOX_REG_LOSS_WEIGHT * r.LOSS_WEIGHT}
-        # rpn.py:99 multiplies both losses by these weights; every UniT yaml leaves them at Detectron2's 1.0 and unit_rpn_loss has
-        # them baked in -- a config that changes them is refused instead of silently ignored
-        assert r.LOSS_WEIGHT == 1.0 and r.BBOX_REG_LOSS_WEIGHT == 1.0, "MODEL.RPN.LOSS_WEIGHT / BBOX_REG_LOSS_WEIGHT != 1.0 unsupported"
 
     # ---- a4: RPN.label_and_sample_anchors -- IoU + Matcher[0.3,0.7;lowq] + explicit-permutation sampling
     def label_and_sample_anchors(self, anchors, gt_boxes, gt_count, perm):

@@ -191,12 +191,20 @@ _NO_MID = bool(int(__import__("os").environ.get("UNIT_NO_MID_TILE", "0")))   # A
 
 _LC_TWO = bool(int(os.environ.get("UNIT_LC_TWO", "0")))      # A/B switch: 1 = the two-workgroups-per-CU form of the loader / consumer kernel where it won in isolation
 _NO_LC = bool(int(os.environ.get("UNIT_NO_LC", "0")))      # A/B switch: 1 = never the persistent loader / consumer conv kernel (csrc/conv_igemm_lc.hip)
+# 1 = the loader / consumer kernel's weights-direct form (csrc/conv_igemm_lc.hip WD: weight fragments from L2 straight into the consumers'
+# registers, only pixels through LDS); 0 (default) = both operands staged in LDS. Measured SLOWER in round 6 (profiles/r06_exp_weights_direct.txt:
+# res4 1x1 1024 -> 256 12.6 -> 14.0 us, 3x3 20.5 -> 24.2 us, step 15.12 -> 15.69 ms): the k-step is not waiting for the LDS port, it waits for
+# what one CU takes in from L2 (~29 B/clk, the guide's "rows shared by every workgroup" rate), and 64-byte fragment rows are a worse shape for
+# that path than the 128-byte rows of the LDS-DMA pieces. Kept as a bit-identical variant (tile codes + 8000) and as the evidence.
+_LC_WD = int(os.environ.get("UNIT_LC_WD", "0"))
 _MID96 = int(os.environ.get("UNIT_MID96", "0"))      # 0: off; 1: 96x128 tiles where tools/mid_sweep.py found them faster in isolation; 2: only the two-per-CU form
 
 
 def mid_tile_dims(mid):
     """(BM pixels, BN channels) of a `mid` tile code: 0..5 = the 4-wave LDS-DMA tiles, 100 + 10 * (BM / 16) + BN / 64 = loader / consumer tiles
-    (+ 2000: their two-workgroups-per-CU form)"""
+    (+ 2000: their two-workgroups-per-CU form; + 8000: weights fetched straight into registers)"""
+    if mid >= 8000:
+        mid -= 8000
     code = mid - 2000 if mid >= 2000 else mid
     if code >= 100:
         return (code - 100) // 10 * 16, (code % 10) * 64
@@ -244,7 +252,7 @@ def _mid_tile_default(dtype, m, k, c, kgemm, allow_lc=True):
     if lc and _LC_TWO and k % 8 == 0 and kgemm >= 256 and 384 <= t80 <= 1024 and not (kgemm >= 512 and k >= 1024):
         return 2152
     if lc and kgemm >= 512 and tiles <= 640 and k % 8 == 0:
-        return lc_tile_code(m, k, kgemm)
+        return lc_tile_code(m, k, kgemm) + (8000 if _LC_WD else 0)
     if _MID96:
         # 96-row tiles (tools/mid_sweep.py, profiles/r02_exp_mid_sweep_96_row_tiles.txt): the res4 1x1 -> 256 layers become 100 x 2 = 200
         # workgroups, one round with one workgroup per CU (14.9 vs 15.6 us; 3x3: 26.7 vs 27.9); between one and 2.5 rounds of 128x128
@@ -814,7 +822,7 @@ def conv2d_pair(xs, w, k, r, s, stride=1, pad=0, bias=None, residuals=None, mask
         if not big:
             lc_ok = x0.dtype == torch.bfloat16 and ldy % 8 == 0
             mid = MID_TILE_POLICY(x0.dtype, m_tot, k, c, r * s * c, allow_lc=lc_ok)
-            if mid >= 2000 or mid == 3:          # forms without a pair instantiation: the plain 4-wave tile instead
+            if 2000 <= mid < 8000 or mid == 3:          # forms without a pair instantiation: the plain 4-wave tile instead
                 tiles = ((m_tot + 127) // 128) * ((k + 127) // 128)
                 mid = 2 if k <= 64 else (0 if tiles >= 256 else 1)
         kernel, tile = (2, 0) if big else ((1, mid) if mid >= 0 else (0, 0))
@@ -1394,15 +1402,17 @@ def roi_align_bwd_gather(gout, n_images, h, w, rois, out, pooled_size=14, bin_st
 
 
 # ------------------------------------------------------------------------------------------------ losses
-def rpn_loss(head, a, dcol0, labels, match_idx, gt_boxes, anchors, normalizer, grad_dtype, gscale=1.0, loss_out=None):
+def rpn_loss(head, a, dcol0, labels, match_idx, gt_boxes, anchors, normalizer, grad_dtype, gscale=1.0, loss_out=None, weights=(1.0, 1.0)):
+    """weights = (loss_rpn_cls, loss_rpn_loc) factors of Detectron2's RPN `loss_weight` (rpn.py:100)"""
     b, hw, ld = head.shape
     ncap = anchors.shape[0]
     loss2 = loss_out if loss_out is not None else torch.empty(2, dtype=torch.float32, device=head.device)
     dhead = torch.empty((b, hw, ld), dtype=grad_dtype, device=head.device)
     nbytes = lib().unit_rpn_loss_scratch_bytes(b, ncap)
     scratch = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=head.device)
-    check(lib().unit_rpn_loss(_p(head), ld, a, dcol0, _p(labels), _p(match_idx), _p(gt_boxes), gt_boxes.shape[1], _p(anchors), b, ncap,
-                              float(normalizer), float(gscale), _p(loss2), _p(dhead), dt(grad_dtype), _p(scratch), nbytes, _s()), "rpn_loss")
+    check(lib().unit_rpn_loss_w(_p(head), ld, a, dcol0, _p(labels), _p(match_idx), _p(gt_boxes), gt_boxes.shape[1], _p(anchors), b, ncap,
+                                float(normalizer), float(gscale), float(weights[0]), float(weights[1]), _p(loss2), _p(dhead), dt(grad_dtype),
+                                _p(scratch), nbytes, _s()), "rpn_loss")
     return loss2, dhead
 
 
