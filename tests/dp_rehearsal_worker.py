@@ -1,6 +1,7 @@
 """One rank of the 2-rank data-parallel rehearsal (tests/test_dp_gpu.py starts two of these as fresh child processes; both
 share cuda:0 and talk gloo through 127.0.0.1 -- the RCCL run differs only in the backend name).
-usage: python tests/dp_rehearsal_worker.py <rank> <world> <port> <out.pt> [fp32|bf16_buckets|graph|graph_whole|eager][_ragged] [steps]
+usage: python tests/dp_rehearsal_worker.py <rank> <world> <port> <out.pt> [fp32|bf16_buckets|graph|graph_whole|replay|eager][_ragged] [steps]
+(replay = engine.ReplayedStep: the step's recorded C-ABI call list re-issued in C, the buckets' all-reduces launched live between its segments)
 (graph = one graph per gradient-bucket stage with the bucket all-reduces between the replays; graph_whole = one graph + one all-reduce;
 _ragged: rank 1 meets a NEW batch key (another image size) at step 3 and again at step 5 while rank 0 keeps replaying its first key -- the ranks
 then disagree about eager vs replay in those steps and must still issue the same collectives)"""
@@ -47,7 +48,7 @@ def main():
     mode = mode[:-len("_ragged")] if ragged else mode
     steps = int(sys.argv[6]) if len(sys.argv) > 6 else 1
     tr = engine.TrainerNoMeta(cfg, model, bf16_buckets=(mode == "bf16_buckets"), use_graph=mode in ("graph", "graph_whole"),
-                              graph_per_bucket=(mode == "graph"))
+                              graph_per_bucket=(mode == "graph"), use_replay=(mode == "replay"))
     if mode == "eager":          # the graphed trainer's packing capacity and device-resident learning rate, launched eagerly
         tr.optimizer._bind()
     sup, weak = global_batch()
@@ -68,10 +69,14 @@ def main():
             losses = tr.run_step(engine.shard_batch(sup, rank, world), engine.shard_batch(weak, rank, world))
     torch.cuda.synchronize()
     nseg = 0
-    if tr.graphed is not None and tr.graphed.graphs:
+    if tr.graphed is not None and mode != "replay" and tr.graphed.graphs:
         g = next(iter(tr.graphed.graphs.values()))[0]
         nseg = len(g[0]) if (isinstance(g, tuple) and isinstance(g[0], list)) else 1
-    torch.save({"params": model.store.params.cpu(), "losses": losses.cpu(), "graph_segments": nseg}, out)
+    stats, py_items = None, 0
+    if mode == "replay":
+        stats = dict(tr.graphed.stats)
+        py_items = max(sum(1 for it in ent[0].items if it[0] == "py") for ent in tr.graphed.plans.values()) if tr.graphed.plans else 0
+    torch.save({"params": model.store.params.cpu(), "losses": losses.cpu(), "graph_segments": nseg, "replay_stats": stats, "replay_py_items": py_items}, out)
     dist.barrier()
     dist.destroy_process_group()
 

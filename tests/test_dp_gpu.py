@@ -126,3 +126,27 @@ def test_two_ranks_graphed_step_ranks_disagree_about_eager_vs_replay(dev, tmp_pa
     e0, e1 = _run_ranks(tmp_path / "e", extra=("eager_ragged", "7"))
     assert torch.equal(e0["params"], e1["params"])
     assert torch.allclose(g0["params"], e0["params"], rtol=1e-5, atol=1e-7), (g0["params"] - e0["params"]).abs().max()
+
+
+def test_two_ranks_replayed_step(dev, tmp_path):
+    """engine.ReplayedStep under data parallelism (round 6: the default launch mode of bench.py): every rank re-issues its recorded call list,
+    the buckets' all-reduces are launched live BETWEEN the list's segments at the points of the backward where the eager step launches them,
+    then GradBuckets.finish() and the optimizer's segment. The same launches and the same collectives as five eager steps: BIT-identical."""
+    r0, r1 = _run_ranks(tmp_path, extra=("replay", "6"))
+    assert torch.equal(r0["params"], r1["params"]), "ranks diverged"
+    assert r0["replay_stats"] == {"eager": 2, "captured": 1, "replayed": 3} and r0["replay_py_items"] >= 5, (r0["replay_stats"], r0["replay_py_items"])
+    (tmp_path / "e").mkdir()
+    e0, e1 = _run_ranks(tmp_path / "e", extra=("eager", "6"))
+    assert torch.equal(e0["params"], e1["params"])
+    assert torch.equal(r0["losses"], e0["losses"]) and torch.equal(r0["params"], e0["params"])
+
+
+def test_two_ranks_replayed_step_ranks_disagree_about_eager_vs_replay(dev, tmp_path):
+    """rank 1 meets a new image size at steps 3 and 5 (eager, then recorded) while rank 0 replays its first key: an eager step, a recording step
+    and a replayed step all issue the per-bucket collectives of the eager schedule, so the ranks stay matched whatever each of them is doing"""
+    r0, r1 = _run_ranks(tmp_path, extra=("replay_ragged", "7"))
+    assert torch.equal(r0["params"], r1["params"]), "ranks diverged"
+    assert r1["replay_stats"]["eager"] == 3 and r1["replay_stats"]["captured"] == 2, r1["replay_stats"]
+    (tmp_path / "e").mkdir()
+    e0, e1 = _run_ranks(tmp_path / "e", extra=("eager_ragged", "7"))
+    assert torch.equal(r0["params"], e0["params"])

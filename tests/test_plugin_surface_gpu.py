@@ -119,7 +119,7 @@ def test_predictor_forward_losses_inference(dev, ft):
     (sc3, bb3), wr3 = bp(xd, nov_t, base_t, supervised_branch_x_weak=xw.to(dev), x_weak=xwd, similarity=simd)
     l3 = bp.losses([sc3, bb3], props, weak_predictions=wr3, weak_proposals=wprops, weak_targets=wtargets)
     sum(wts[k] * v for k, v in l3.items()).backward()
-    close = lambda a, b, what: (a.cpu() - b).abs().max().item() <= 2e-4 * b.abs().max().item() + 1e-9 or pytest.fail(f"{what}: {(a.cpu() - b).abs().max().item()} vs max {b.abs().max().item()}")
+    close = lambda a, b, what: (a.cpu() - b).abs().max().item() <= 2e-4 * b.abs().max().item() + 1e-7 or pytest.fail(f"{what}: {(a.cpu() - b).abs().max().item()} vs max {b.abs().max().item()}")
     close(xd.grad, xo.grad, "d/dx")
     named = dict(model.named_parameters())
     checked = 0
@@ -198,12 +198,10 @@ def test_roi_heads_forward_eval_equals_meta_arch_inference(dev, mask):
         det = model.roi_heads._forward_box(features, proposals)
         assert model.roi_heads.forward_with_given_boxes(features, det) is det          # no mask head: instances come back unchanged
     model.roi_heads.train()
-    if mask:          # the mask heads train through the fused step only
-        with pytest.raises(RuntimeError, match="fused step"):
-            model.roi_heads(images, features, proposals, targets=[s["instances"] for s in sup])
-    else:             # (the training-mode call itself: test_module_level_training_matches_the_fused_step)
-        _, losses = model.roi_heads(images, features, proposals, targets=[s["instances"] for s in sup])
-        assert set(losses) == {"loss_cls", "loss_box_reg"} and all(torch.isfinite(v) for v in losses.values())
+    # the training-mode call itself (all four ROI-head classes since round 6: test_module_level_training_matches_the_fused_step[_all_roi_heads];
+    # these targets carry no gt_masks, so the mask variant returns the box losses only, as Detectron2's mask_rcnn_loss would have nothing to crop)
+    _, losses = model.roi_heads(images, features, proposals, targets=[s["instances"] for s in sup])
+    assert set(losses) == {"loss_cls", "loss_box_reg"} and all(torch.isfinite(v) for v in losses.values())
     with pytest.raises(RuntimeError, match="inference-only"):
         model.roi_heads.forward_with_given_boxes(features, det)
 

@@ -11,6 +11,14 @@ from .parallel import GradBuckets
 from .solver import FlatSGD
 
 
+import os as _os
+
+# hipStreamBeginCapture mode of every capture below. "thread_local": only the capturing thread's calls are checked against the capture -- a
+# helper thread of the process (gloo's collective workers, a data loader) may keep making HIP calls meanwhile. "global" (PyTorch's default)
+# makes ANY thread's unsafe call invalidate the capture.
+_CAPTURE_MODE = _os.environ.get("UNIT_GRAPH_CAPTURE_MODE", "thread_local")
+
+
 def shard_batch(global_batch, rank, world):
     """rank r takes images [r*k, (r+1)*k) with k = len // world (data/build.py:354-355 images_per_worker)."""
     k = len(global_batch) // world
@@ -157,7 +165,7 @@ class GraphedStep:
 
         def begin():
             g = torch.cuda.CUDAGraph()
-            g.capture_begin(pool=state["pool"])
+            g.capture_begin(pool=state["pool"], capture_error_mode=_CAPTURE_MODE)
             state["g"], state["n0"], state["tags"] = g, LAUNCHES[0], []
 
         def split(tag):
@@ -220,24 +228,24 @@ class GraphedStep:
             it, first = opt.iter, opt._first
             torch.cuda.synchronize()
             if self.buckets is None:
-                with torch.cuda.graph(g, pool=self.pool):
+                with torch.cuda.graph(g, pool=self.pool, capture_error_mode=_CAPTURE_MODE):
                     losses = self._body(static)
             elif self.per_bucket:
                 segs, losses, pool = self._capture_segments(static)          # collectives stay outside the captures, between them
                 g2 = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g2, pool=pool):
+                with torch.cuda.graph(g2, pool=pool, capture_error_mode=_CAPTURE_MODE):
                     opt.step()
                 g = (segs, g2)
             else:
                 hook, model.on_grad_ready = model.on_grad_ready, None          # no collective inside the capture
                 try:
-                    with torch.cuda.graph(g, pool=self.pool):
+                    with torch.cuda.graph(g, pool=self.pool, capture_error_mode=_CAPTURE_MODE):
                         losses = self._fwd_bwd(static)
                         self._join_side_streams()
                 finally:
                     model.on_grad_ready = hook
                 g2 = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g2, pool=g.pool()):
+                with torch.cuda.graph(g2, pool=g.pool(), capture_error_mode=_CAPTURE_MODE):
                     opt.step()
                 g = (g, g2)
             opt.iter, opt._first = it, first            # the capture only recorded the launches: nothing has run yet
