@@ -152,3 +152,39 @@ def test_pack_batch_rejects_a_capacity_that_does_not_hold_the_batch(dev):
     sup, weak = synthetic_batch(1, 1, hw=(96, 128), seed=5, max_gt=40)
     with pytest.raises(ValueError, match="gt_capacity"):
         m.pack_batch(sup, weak, gt_capacity=8)
+
+
+def test_capture_refuses_aliased_stream_roles(dev, monkeypatch):
+    """Root cause of round 5's "1 in 12-24" hipStreamEndCapture SIGSEGV: the weight-gradient and the RPN-branch role of the
+    step on ONE stream object. The stream-placement probe can no longer produce that (distinct objects even when it finds fewer queues); the
+    experiment switch that still can is refused by GraphedStep with an error instead of a crash inside the ROCm runtime; the call-list replay,
+    which captures nothing, runs such a placement and equals the eager step."""
+    from unit_amd import ops
+    st = ops.streams_on_distinct_queues(dev, 3, candidates=1)          # one candidate: at most one distinct queue can be FOUND
+    assert len({s.cuda_stream for s in st}) == 3
+    monkeypatch.setenv("UNIT_STREAM_MERGE", "wr")
+    data = [synthetic_batch(2, 2, hw=(96, 128), seed=60 + i, max_gt=3) for i in range(2)]
+    cfg, m = _setup()
+    o = FlatSGD(m, cfg)
+    gs = engine.GraphedStep(m, o, warmup_steps=1)
+    gs.run(*data[0])
+    assert m._wgrad_stream is m._rpn_stream
+    with pytest.raises(RuntimeError, match="share one HIP stream object"):
+        gs.run(*data[1])
+    cfg, m1 = _setup()
+    o1 = FlatSGD(m1, cfg)
+    ref = []
+    for d in (data[0], data[1], data[0], data[1]):
+        b = m1.pack_batch(*d, gt_buckets=engine.GraphedStep.GT_BUCKETS)
+        o1._bind()
+        o1.use_device_lr(m1.device)
+        step = m1.forward_train(b, early_backward=True)
+        m1.backward_train(step)
+        o1.step()
+        ref.append(step.losses.clone())
+    cfg, m2 = _setup()
+    o2 = FlatSGD(m2, cfg)
+    rs = engine.ReplayedStep(m2, o2, warmup_steps=1)
+    got = [rs.run(*d).clone() for d in (data[0], data[1], data[0], data[1])]
+    torch.cuda.synchronize()
+    assert rs.stats["replayed"] == 1 and all(torch.equal(a, b) for a, b in zip(got, ref)) and torch.equal(m2.store.params, m1.store.params)

@@ -110,6 +110,14 @@ class GraphedStep:
         self.eager_left = max(1, warmup_steps)          # the very first step initialises the momentum buffers (another SGD launch flag)
         self._torch = torch
 
+    def _check_streams(self):
+        """a hipGraph capture of the step needs the weight-gradient and the RPN-branch role on two stream OBJECTS: with both on one (only the
+        experiment switch UNIT_STREAM_MERGE=wr / all does that) hipStreamEndCapture of ROCm 7.2 segfaults -- refuse instead"""
+        m = self.model
+        if m._streams_on() and m._wgrad_stream is m._rpn_stream:
+            raise RuntimeError("GraphedStep: the weight-gradient and RPN-branch roles share one HIP stream object (UNIT_STREAM_MERGE=wr / all); "
+                               "ROCm 7.2's hipStreamEndCapture crashes on that capture -- use distinct streams, or engine.ReplayedStep")
+
     def _fwd_bwd(self, batch):
         step = self.model.forward_train(batch, early_backward=True)
         self.model.backward_train(step)
@@ -223,6 +231,7 @@ class GraphedStep:
         ent = self.graphs.get(key)
         self.stats["replayed" if ent is not None else "captured"] += 1
         if ent is None:
+            self._check_streams()
             static = fresh.clone()
             g = torch.cuda.CUDAGraph()
             it, first = opt.iter, opt._first

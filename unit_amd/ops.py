@@ -161,8 +161,14 @@ def streams_on_distinct_queues(device, n, candidates=12, spin_cycles=200000):
         if share(c, cur) or any(share(c, r) for r in reps):
             continue
         reps.append(c)
-    while len(reps) < n:          # fewer queues than roles: roles share a stream object (explicitly serial)
-        reps.append(reps[len(reps) % max(1, len(reps))] if reps else torch.cuda.Stream(device))
+    while len(reps) < n:
+        # Fewer distinct queues FOUND than roles -- the runtime offers fewer, or the measurement was disturbed (another process on the same
+        # GPU: the two-ranks-one-GPU rehearsals). The roles still get stream OBJECTS of their own (round 6): two of them may then share a
+        # hardware queue and run in turn, which costs time, not correctness. Until round 5 the roles were aliased onto one object here; with
+        # the weight-gradient and the RPN-branch role on ONE stream object the step's capture makes ROCm 7.2's hipStreamEndCapture segfault
+        # (deterministic: UNIT_STREAM_MERGE=wr / all in a single process, profiles/r06_exp_capture_crash_root_cause.txt) -- the "1 in 12-24"
+        # crash of DESIGN section 8 round 5 item 10 was this fallback firing when the spin probe of a rank was disturbed by the other rank.
+        reps.append(torch.cuda.Stream(device))
     return reps
 
 
