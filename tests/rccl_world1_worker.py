@@ -50,7 +50,10 @@ def main():
         model.join_optimizer_tail()
         torch.cuda.synchronize()
         nseg = 0
-        if tr.graphed is not None and tr.graphed.graphs:
+        if isinstance(tr.graphed, engine.ReplayedStep):
+            assert tr.graphed.stats["replayed"] >= 1, tr.graphed.stats
+            nseg = max(sum(1 for it in ent[0].items if it[0] == "calls") for ent in tr.graphed.plans.values())
+        elif tr.graphed is not None and tr.graphed.graphs:
             g = next(iter(tr.graphed.graphs.values()))[0]
             nseg = len(g[0]) if (isinstance(g, tuple) and isinstance(g[0], list)) else 1
         return model.store.params.clone(), losses.clone(), tr.buckets, nseg, first
@@ -64,6 +67,10 @@ def main():
         cases = [("allreduce", {}), ("rs_ag", dict(reduce_mode="rs_ag", bucket_bytes=3 << 20)), ("direct", dict(reduce_mode="direct", bucket_bytes=5 << 20)),
                  ("cabi", dict(reduce_mode="cabi", bucket_bytes=7 << 20)),          # RCCL through the library's own comm exports (csrc/comm.hip)
                  ("direct_bf16_buckets", dict(reduce_mode="direct", bf16_buckets=True)), ("allreduce_bf16_buckets", dict(bf16_buckets=True))]
+        # the call-list replay (engine.ReplayedStep): the recorded step's launches re-issued in C, every bucket's RCCL exchange launched live
+        # between two segments of the list, from the weight-gradient stream, where the eager backward launches it
+        cases += [("replay", dict(use_replay=True)), ("replay_direct", dict(use_replay=True, reduce_mode="direct", bucket_bytes=5 << 20)),
+                  ("replay_cabi", dict(use_replay=True, reduce_mode="cabi", bucket_bytes=7 << 20))]
         if dname == "fp32":
             cases += [("graph_per_bucket", dict(use_graph=True, graph_per_bucket=True)), ("graph_whole", dict(use_graph=True, graph_per_bucket=False)),
                       ("graph_per_bucket_direct", dict(use_graph=True, graph_per_bucket=True, reduce_mode="direct")),

@@ -44,7 +44,8 @@ def test_comm_exports_of_the_c_abi(dev, result):
     assert c["fp32_identity"] and c["bf16_identity"] and c["rccl_version"] >= 20000, c
 
 
-@pytest.mark.parametrize("case", ["allreduce", "rs_ag", "direct", "cabi", "graph_per_bucket", "graph_whole", "graph_per_bucket_direct", "tail_overlap"])
+@pytest.mark.parametrize("case", ["allreduce", "rs_ag", "direct", "cabi", "graph_per_bucket", "graph_whole", "graph_per_bucket_direct", "tail_overlap",
+                                  "replay", "replay_direct", "replay_cabi"])
 def test_forced_collectives_fp32_buckets_are_the_identity(dev, result, case):
     """fp32 buckets through RCCL at world 1: launched from the weight-gradient stream inside the backward, waited for by the optimizer's
     stream -- parameters after 4 steps BIT-equal to the run without any collective (a missing stream dependency would show as a torn
@@ -58,8 +59,10 @@ def test_forced_collectives_fp32_buckets_are_the_identity(dev, result, case):
         assert c["finite"] and c["bit_equal"], (dname, case, c["max_abs_diff"])
         if case == "graph_per_bucket":
             assert c["graph_segments"] >= 4
+        if case.startswith("replay"):
+            assert c["graph_segments"] >= 5, c["graph_segments"]          # the list is cut at every gradient bucket: its RCCL launch sits between two segments
         if case != "allreduce":
-            assert c["describe"]["reduce_mode"] == ("direct" if "direct" in case else case if case in ("rs_ag", "cabi") else "allreduce")
+            assert c["describe"]["reduce_mode"] == ("direct" if "direct" in case else "cabi" if "cabi" in case else case if case == "rs_ag" else "allreduce")
 
 
 @pytest.mark.parametrize("case", ["allreduce_bf16_buckets", "direct_bf16_buckets"])
