@@ -135,6 +135,10 @@ def launch_mode(args):
         return args.launch
     if args.early_update or args.tail_overlap:
         return "eager"
+    if args.shapes == "voc":
+        # multi-scale batches: a batch key (image sizes, GT capacity) almost never comes back inside a run -- 40 eager + 10 recorded + 0 replayed
+        # steps in profiles/r06_bench_voc_shapes_replay_per_key.json -- so recording buys nothing there and costs the recording
+        return "eager"
     return "replay"
 
 
