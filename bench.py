@@ -126,6 +126,22 @@ def pick_exchange(table):
     return table[best[1]]
 
 
+def _thread_cpu():
+    """{tid: (name, CPU seconds)} of this process's threads (Linux /proc): which thread burns the CPU time `host_cpu_ms_per_step` reports"""
+    out = {}
+    try:
+        tck = os.sysconf("SC_CLK_TCK")
+        for tid in os.listdir("/proc/self/task"):
+            with open(f"/proc/self/task/{tid}/stat") as f:
+                st = f.read()
+            name = st[st.index("(") + 1:st.rindex(")")]
+            rest = st[st.rindex(")") + 2:].split()
+            out[tid] = (name, (int(rest[11]) + int(rest[12])) / tck)
+    except (OSError, ValueError):
+        pass
+    return out
+
+
 def launch_mode(args):
     """replay | eager | graph for this run: --graph and the modes that need Python inside the step (early update, tail overlap, the single-stream
     profiling run) keep their form; everything else replays the recorded call list"""
@@ -742,6 +758,8 @@ def main():
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
+    th0 = _thread_cpu()
+    c0 = time.process_time()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         losses = timed_step()
@@ -751,6 +769,9 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    cpu_ms = (time.process_time() - c0) / args.steps * 1e3          # CPU time of this process (all threads) per step over the timed region, waits included
+    th1 = _thread_cpu()
+    cpu_threads = sorted(((round((th1[t][1] - th0.get(t, (None, 0.0))[1]) / args.steps * 1e3, 3), th1[t][0]) for t in th1), reverse=True)[:4]
     # the host's OWN share of a step: the same step enqueued onto an IDLE device (synchronize before, clock stopped before anything is waited
     # for). `host_enqueue_ms_per_step` below is the timed region's figure and includes queue back-pressure: the runtime's queues hold a few
     # steps' worth of launches, after that the host enqueues at the pace the device retires them -- whenever the device is the slower side
@@ -898,6 +919,8 @@ def main():
             "dist": dict(buckets.describe(), tuning=tuning, exposed_ms_per_bucket_tag=per_bucket), "build_hash": _lib.build_hash(),
             "host_enqueue_ms_per_step": round(host_ms, 3),      # max over ranks; timed region, includes queue back-pressure (see host_enqueue_ms_from_idle_device)
             "host_enqueue_ms_from_idle_device": (round(host_idle_ms, 3) if host_idle_ms is not None else None),      # the host's own cost of one step
+            "host_cpu_ms_per_step_by_thread": [{"thread": n, "ms": v} for v, n in cpu_threads if v > 0.05],
+            "host_cpu_ms_per_step": round(cpu_ms, 3),      # process CPU time (user + sys, all threads) per step of the timed region (rank 0): what a rank costs the node's cores
             "sustained_images_per_sec": (sustained["images_per_sec"] if sustained else None), "sustained": sustained,
             "allreduce_exposed_ms": round(exposed_ms, 3),       # max over ranks: compute-stream time inside GradBuckets.finish() per step
             "config": {"workload": f"UniT base-training step {args.variant.upper()} (TrainerNoMeta.run_step): ResNet-{args.depth}-C4, "

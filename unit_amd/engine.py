@@ -297,10 +297,34 @@ class ReplayedStep(GraphedStep):
     list, issued at the very point of the backward where the eager step issues it (no stream joins at the cuts: nothing is captured), then
     GradBuckets.finish(), then the optimizer's segment. Ranks may disagree about eager vs replay: both forms issue the same collectives."""
 
-    def __init__(self, model, optimizer, warmup_steps=2, buckets=None):
+    def __init__(self, model, optimizer, warmup_steps=2, buckets=None, run_ahead=None):
+        """run_ahead: how many steps the host may be ahead of the device (default 2, env UNIT_REPLAY_RUN_AHEAD; 0 = unbounded). At ~1 ms of host
+        time per 15 ms step the host would otherwise fill the runtime's queues within a few steps and then SPIN inside the launch call for a free
+        slot -- a core burnt per rank for nothing (measured: 2 busy threads per process, bench.py `host_cpu_ms_per_step`). With a bound, the host
+        sleeps on a blocking HIP event (hipEventBlockingSync: an interrupt, not a poll) until the step `run_ahead` steps back has finished."""
         super().__init__(model, optimizer, warmup_steps=warmup_steps, buckets=buckets, per_bucket=True)
         self.plans = {}          # key -> (CallList, static PackedBatch, losses tensor)
         self.mempool = None
+        import collections
+        import os
+        self.run_ahead = int(os.environ.get("UNIT_REPLAY_RUN_AHEAD", "2")) if run_ahead is None else int(run_ahead)
+        self._pace = collections.deque()
+        import time
+        self._time, self.poll_s = time, float(os.environ.get("UNIT_REPLAY_POLL_MS", "0.5")) * 1e-3
+
+    def _paced(self):
+        """called after a step's launches are enqueued: bound the host's run-ahead (see __init__)"""
+        if self.run_ahead <= 0:
+            return
+        ev = self._torch.cuda.Event()
+        ev.record()
+        self._pace.append(ev)
+        while len(self._pace) > self.run_ahead:
+            old = self._pace.popleft()
+            # (hipEventSynchronize spins on this runtime even for hipEventBlockingSync events -- measured: the thread stays at 100 % --, so the
+            #  wait is a sleeping poll: two steps of work are queued behind it, half a millisecond of latency costs nothing)
+            while not old.query():
+                self._time.sleep(self.poll_s)
 
     def _record(self, static):
         from ._lib import Recorder
@@ -344,6 +368,7 @@ class ReplayedStep(GraphedStep):
         ent[0].run()
         opt.iter += 1
         opt._first = False
+        self._paced()
         return ent[2]
 
 
