@@ -730,6 +730,7 @@ def main():
 
     if args.shapes == "voc":
         rc = voc_shapes_run(args, cfg, model, buckets, opt, rank, world, dev)
+        buckets.close()          # (mode "cabi": the library's own RCCL communicator goes before the process group does)
         if dist.is_initialized():
             dist.destroy_process_group()
         return rc
@@ -1038,6 +1039,7 @@ def main():
                 out["cpu_baseline"] = {"error": "oracle sample exceeded the 240 s bound on this host"}
         _trace("printing the line")
         emit(json.dumps(out))
+    buckets.close()
     if dist.is_initialized():
         dist.destroy_process_group()
     _trace("done")
