@@ -509,8 +509,28 @@ def _ellipses(sup):
     return masks
 
 
-@pytest.mark.parametrize("depth", [50, 101])
-def test_coco_k80_mask_step_fullsize(dev, depth):
+def _star_polygons(sup, seed=4):
+    """polygon ground truth (Detectron2 PolygonMasks, the format the reference's COCO-segm yaml trains on): a concave 14-gon inside every GT box,
+    every other instance with a second part -> (per-image containers set on the instances, nested lists for the oracle)"""
+    from test_polygon_masks_cpu import _random_polygon
+    from unit_amd.structures import PolygonMasks
+    rng = np.random.default_rng(seed)
+    out = []
+    for x in sup:
+        inst = []
+        for j, bb in enumerate(x["instances"].gt_boxes.tensor.numpy()):
+            cx, cy, rx, ry = (bb[0] + bb[2]) / 2, (bb[1] + bb[3]) / 2, (bb[2] - bb[0]) / 2, (bb[3] - bb[1]) / 2
+            parts = [(_random_polygon(rng, 0, 0, 1.0, 14, concave=True).reshape(-1, 2) * [rx, ry] + [cx, cy]).reshape(-1)]
+            if j % 2:
+                parts.append((_random_polygon(rng, 0, 0, 0.4, 6).reshape(-1, 2) * [rx, ry] + [cx, cy]).reshape(-1))
+            inst.append(parts)
+        x["instances"].gt_masks = PolygonMasks(inst)
+        out.append(inst)
+    return out
+
+
+@pytest.mark.parametrize("depth,fmt", [(50, "bitmask"), (101, "bitmask"), (50, "polygon")])
+def test_coco_k80_mask_step_fullsize(dev, depth, fmt):
     """BASELINE config 5 (the reference ships COCO-RCNN-50-C4-split1-segm.yaml; BASELINE.json names the R101 variant of it): K = 80, 60 base / 20 novel classes, ONE Res5 head serving the
     supervised and the weak RoIs, mask head on the <= 128 fg RoIs per image; 2 + 2 images 600x1000. fp32 teacher-forced:
     RoIs exact, all nine losses (incl. loss_mask) 1e-4, gradients of the mask head / Res5 / backbone 5e-3 of their max;
@@ -519,15 +539,17 @@ def test_coco_k80_mask_step_fullsize(dev, depth):
     model.train()
     model.compute_dtype = torch.float32
     sup, weak = synthetic_batch(2, 2, hw=HW, num_classes=80, base_ids=list(cfg.DATASETS.FEWSHOT.BASE_CLASSES_ID), seed=9)
-    masks = _ellipses(sup)
+    # fmt "polygon": MASK_FORMAT as the reference's yaml leaves it (Detectron2 PolygonMasks -> pycocotools rasterisation inside every sampled box)
+    mask_kw = dict(gt_polygons=_star_polygons(sup)) if fmt == "polygon" else dict(gt_masks=_ellipses(sup))
     batch = model.pack_batch(sup, weak)
+    assert hasattr(batch.gt_masks, "poly_start") == (fmt == "polygon")
     model._ensure_ready()
     perms = model.sampling_permutations(2, 38 * 63 * 15, cfg.MODEL.RPN.POST_NMS_TOPK_TRAIN + batch.gt_boxes.shape[1])
     p = oracle_params(model)
     operms = dict(rpn=[x.long().cpu() for x in perms["rpn"]], roi=[x.long().cpu() for x in perms["roi"]])
     ref, aux = orc.step_losses(p, [x["image"] for x in sup], [x["instances"].gt_boxes.tensor for x in sup],
                                [x["instances"].gt_classes for x in sup], [x["image"] for x in weak], [x["instances"].gt_classes for x in weak],
-                               operms, ocfg_of(cfg, gt_masks=masks))
+                               operms, ocfg_of(cfg, **mask_kw))
     sum(ref.values()).backward()
     props = pack_proposals(aux["proposals"] + aux["weak_proposals"], cfg.MODEL.RPN.POST_NMS_TOPK_TRAIN, dev)
     step = model.forward_train(batch, perms, early_backward=True, proposals=props)
@@ -545,7 +567,7 @@ def test_coco_k80_mask_step_fullsize(dev, depth):
     stepb = model.forward_train(batch, perms, early_backward=True, proposals=props)
     model.backward_train(stepb)
     gotb = dict(zip(LOSS_NAMES, stepb.losses.cpu().tolist()))
-    log_metrics(f"coco_k80_mask_step_r{depth}", dict(loss_rel_dev_fp32=dev_l, grad_rel_to_max=gerr, bf16={k: (gotb[k], v.item()) for k, v in ref.items()}))
+    log_metrics(f"coco_k80_mask_step_r{depth}" + ("_polygon" if fmt == "polygon" else ""), dict(loss_rel_dev_fp32=dev_l, grad_rel_to_max=gerr, bf16={k: (gotb[k], v.item()) for k, v in ref.items()}))
     assert ref["loss_mask"].item() > 0.1
     for k, v in dev_l.items():
         assert v <= 1e-4, (k, got[k], ref[k].item())
