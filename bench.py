@@ -778,13 +778,17 @@ def main():
     # steps' worth of launches, after that the host enqueues at the pace the device retires them -- whenever the device is the slower side
     # that figure tends to the device's time per step, whatever the host needs.
     idle = []
-    for _ in range(8 if world == 1 else 0):
+    for _ in range(8):          # (every rank runs the same eight steps: their collectives match)
         torch.cuda.synchronize()
         ti = time.perf_counter()
         timed_step()
         idle.append(time.perf_counter() - ti)
     torch.cuda.synchronize()
     host_idle_ms = sorted(idle)[len(idle) // 2] * 1e3 if idle else None
+    if world > 1:
+        ti_all = torch.tensor([host_idle_ms], device=dev, dtype=torch.float64)
+        dist.all_reduce(ti_all, op=dist.ReduceOp.MAX)          # the slowest rank's host
+        host_idle_ms = float(ti_all)
     # sustained clocks: the timed region is a burst of `steps` x ~15 ms from a cool chip; the same step for a few seconds more, timed over its
     # tail (the driver line carries both figures). N = 1 only: no collective may differ between ranks' loop counts.
     sustained = None
@@ -918,8 +922,8 @@ def main():
                                                                      "eager": "eager"}[mode],
             "launch_stats": (dict(gs.stats) if gs is not None else None),
             "dist": dict(buckets.describe(), tuning=tuning, exposed_ms_per_bucket_tag=per_bucket), "build_hash": _lib.build_hash(),
-            # what the host needs to enqueue one step: median of eight steps each enqueued onto an IDLE device (N = 1; at N > 1 not measured: the
-            # timed region's figure). Until round 5 this field was the timed region's wall time per step, which includes waiting -- queue
+            # what the host needs to enqueue one step: median of eight steps each enqueued onto an IDLE device (max over ranks; with gloo on
+            # host-synchronous collectives it includes them). Until round 5 this field was the timed region's wall time per step, which includes waiting -- queue
             # back-pressure then, the replay's deliberate run-ahead bound (a sleeping poll, engine.ReplayedStep) now: that figure tends to the
             # DEVICE's time per step whenever the device is the slower side and is kept as host_wall_ms_per_step_timed_region.
             "host_enqueue_ms_per_step": round(host_idle_ms if host_idle_ms is not None else host_ms, 3),
