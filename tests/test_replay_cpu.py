@@ -79,3 +79,23 @@ def test_byref_and_struct_arguments_are_pinned():
     assert keep == [sec] and ints[-2] == ctypes.addressof(sec)
     with pytest.raises(TypeError):
         _lib._words(fn, args[:-2] + ["not a pointer", None], [])
+
+
+def test_only_the_recording_thread_is_recorded():
+    """while a step is being recorded, `_lib.lib()` hands the recording proxy to the recording thread only: a helper thread of the process (a data
+    loader, a collective's worker) keeps talking to the library itself, and a paused recorder steps aside for its own thread too"""
+    import threading
+    real = _lib.lib()
+    seen = {}
+    with _lib.Recorder() as rec:
+        assert _lib.lib() is rec
+        t = threading.Thread(target=lambda: seen.setdefault("other", _lib.lib()))
+        t.start()
+        t.join()
+        with rec.paused():
+            seen["paused"] = _lib.lib()
+        # host-only calls pass through the proxy unrecorded
+        assert rec.unit_call_bytes() == real.unit_call_bytes()
+    assert seen["other"] is real and seen["paused"] is real and _lib.lib() is real
+    plan = rec.finish()
+    assert plan.n_calls == 0 and plan.items == []

@@ -3,6 +3,7 @@ drift from the C ABI. The product path fails loudly if the library is missing: t
 import ctypes
 import os
 import re
+import threading
 
 import torch  # noqa: F401  -- must be imported BEFORE libunit_hip.so is dlopen'ed: the library has to bind to the same
 #                               libamdhip64 runtime instance PyTorch uses (its device pointers / streams are passed in)
@@ -65,8 +66,8 @@ _RECORDER = None          # the active Recorder (below): lib() then hands out it
 def lib():
     """Loads libunit_hip.so (building it is __graft_entry__.build()'s / unit_amd.build's job)."""
     global _lib
-    if _RECORDER is not None and not _RECORDER.paused_depth:
-        return _RECORDER
+    if _RECORDER is not None and not _RECORDER.paused_depth and _RECORDER.tid == threading.get_ident():
+        return _RECORDER          # (only the recording thread's calls belong to the list: a helper thread keeps talking to the library itself)
     if _lib is None:
         if not os.path.exists(LIB_PATH):
             raise UnitLibError(
@@ -210,6 +211,7 @@ class Recorder:
     def __init__(self):
         self.items, self.cur, self.keep = [], [], []
         self.paused_depth = 0
+        self.tid = threading.get_ident()          # the thread whose launches and event edges are the step's
         self._wrapped = {}
         self._patched = None
 
@@ -281,7 +283,7 @@ class Recorder:
             if stream is None:
                 stream = torch.cuda.current_stream()
             orig_record(self_, stream)
-            if not rec.paused_depth:
+            if not rec.paused_depth and threading.get_ident() == rec.tid:
                 rec.keep.append(self_)
                 rec._append("unit_event_record_raw", _lib.unit_event_record_raw, (self_.cuda_event, stream.cuda_stream))
 
@@ -289,7 +291,7 @@ class Recorder:
             if stream is None:
                 stream = torch.cuda.current_stream()
             orig_wait(self_, stream)
-            if not rec.paused_depth:
+            if not rec.paused_depth and threading.get_ident() == rec.tid:
                 rec.keep.append(self_)
                 rec._append("unit_stream_wait_event_raw", _lib.unit_stream_wait_event_raw, (stream.cuda_stream, self_.cuda_event))
 
