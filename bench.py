@@ -986,6 +986,15 @@ def main():
                                                 f"around every launch ({dt_events / args.steps * 1e3:.2f} ms/step in that mode)",
                                "other_conv_kernels": {k2: rate(prof, k2) for k2 in ("conv_igemm_dma", "conv_igemm", "conv_wgrad")
                                                       if k2 != key and prof.get(k2)}}
+            # weight-gradient kernels: bytes past the L2 per STEP over all of their grids against the operands' size per step (x + dy once,
+            # the fp32 result once) -- per step, because the PMC families and the timed regions do not cut the launches the same way
+            wg = out["roofline"]["other_conv_kernels"].get("conv_wgrad")
+            if wg and traffic is not None and tdoc.get(key + "_kernel", {}).get("launches"):
+                pmc_steps = tdoc[key + "_kernel"]["launches"] / r["launches_per_step"]
+                tot = sum(v["launches"] * v["hbm_bytes_per_launch"] for kk, v in tdoc.items() if isinstance(v, dict) and kk.startswith(("conv_wgrad", "void conv_wgrad")))
+                wg["algorithmic_bytes_per_step"] = wg["algorithmic_bytes_per_launch"] * wg["launches_per_step"]
+                wg["pmc_bytes_per_step"] = round(tot / pmc_steps)
+                wg["traffic_ratio"] = round(wg["pmc_bytes_per_step"] / max(1, wg["algorithmic_bytes_per_step"]), 3)
             # the HBM- / latency-bound kernels north_star names: RoIAlign (GB/s on algorithmic bytes = res4 maps once + pooled
             # tensor once, strided 7x7 bins; bytes past the L2 from the same PMC file) and the proposal chain (us per launch)
             def hbm(pr, k2, pmc_key):

@@ -6,13 +6,18 @@ import collections, csv, glob, json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from unit_amd.build import source_hash          # content hash of the kernel sources the profiled library was built from
 
+by_grid = collections.defaultdict(lambda: collections.defaultdict(list))     # the grouped weight-gradient grids one by one (a Res5 head's is the large one)
+
 def collect(d, counter):
     fs = glob.glob(d + "/**/*counter_collection.csv", recursive=True)
     acc = collections.defaultdict(list)
     for f in fs:
         for r in csv.DictReader(open(f)):
             if r["Counter_Name"] == counter:
-                acc[r["Kernel_Name"].split("(")[0].split("<")[0].strip()].append(float(r["Counter_Value"]))
+                name = r["Kernel_Name"].split("(")[0].split("<")[0].strip()
+                acc[name].append(float(r["Counter_Value"]))
+                if "wgrad256_group" in name:
+                    by_grid[int(r["Grid_Size"]) // int(r["Workgroup_Size"])][counter].append(float(r["Counter_Value"]))
     return acc
 
 fetch = collect(sys.argv[1], "FETCH_SIZE")
@@ -40,5 +45,9 @@ for name, (f, w) in groups.items():
     fb = 2.0 * 1024 * sum(f) / max(1, len(f)); wb = 1024.0 * sum(w) / max(1, len(w))
     out[name] = {"launches": max(len(f), len(w)), "fetch_bytes_per_launch": round(fb), "write_bytes_per_launch": round(wb),
                  "hbm_bytes_per_launch": round(fb + wb)}
+out["_conv_wgrad256_group_by_grid"] = {
+    f"{wgs} workgroups": {"launches": len(c["FETCH_SIZE"]), "fetch_bytes_per_launch": round(2.0 * 1024 * sum(c["FETCH_SIZE"]) / max(1, len(c["FETCH_SIZE"]))),
+                          "write_bytes_per_launch": round(1024.0 * sum(c["WRITE_SIZE"]) / max(1, len(c["WRITE_SIZE"])))}
+    for wgs, c in sorted(by_grid.items())}
 json.dump(out, open(sys.argv[3], "w"), indent=1)
 print(json.dumps({k: v for k, v in out.items() if "igemm256" in k or "wgrad" in k}, indent=1))

@@ -515,8 +515,13 @@ extern "C" int unit_conv2d_wgrad_group(const UnitWgradProblem* pr, int n, int in
   UNIT_CHECK_ARG(in_dtype == UNIT_BF16, "wgrad_group: bf16 only");
   UNIT_CHECK_ARG(pr != nullptr && n >= 0, "wgrad_group: no problems");
   static thread_local WgradGroupArgs g;         // 3.8 KB; filled and passed by value
-  struct U { long w; int p, tap, s, tiles, tile0; };
+  struct U { long w; int p, tap, s, tiles, tile0, gang; long gw; };
   static thread_local U us[8 * WG_GROUP_MAX_UNITS];
+  // gangs (UNIT_WGRAD_GANG, profiles/r06_exp_wgrad_gangs.txt): the nine filter-tap units of one split of a valid_only 3x3 layer contract over the
+  // SAME x / dy rows; dealt one by one (0) they land on up to eight XCDs and every one of those L2s fetches the rows for itself.
+  // 1: all nine on one XCD (36 tiles on 32 CUs, and the taps drift apart: 36 / 42 / 49 valid positions per 7x7 image);
+  // 2 (default): the taps that walk at the same pace -- 4 corner, 4 edge, the centre tap -- form a gang: a Res5 head's grid 4.00 -> 2.67 GB past L2
+  static const int use_gangs = [] { const char* e = getenv("UNIT_WGRAD_GANG"); return e ? atoi(e) : 2; }();
   for (int kind = 2; kind >= 1; --kind) {           // the long 256-tile grid first
     int i0 = 0;
     while (i0 < n) {
@@ -535,8 +540,8 @@ extern "C" int unit_conv2d_wgrad_group(const UnitWgradProblem* pr, int n, int in
         break;
       }
       i0 = i;
-      // units, heaviest first, each to the least-loaded XCD that still has a free unit entry
-      int nu = 0;
+      // units (gangs of units), heaviest first, each to the least-loaded XCD that still has free unit entries
+      int nu = 0, ngang = 0;
       for (int p = 0; p < cnt; ++p) {
         const Wgrad256Args& a = g.p[p];
         if (a.valid_only) {
@@ -550,32 +555,54 @@ extern "C" int unit_conv2d_wgrad_group(const UnitWgradProblem* pr, int n, int in
             for (int sp = 0; sp < a.splits; ++sp)
               for (int t0 = 0; t0 < per; t0 += ch) {
                 int nt = per - t0 < ch ? per - t0 : ch;
-                us[nu++] = U{(long)nt * (meff / a.splits + 1), p, tap, sp, nt, t0};
+                int cls = (kr != 1) + (ks != 1);            // 0 centre, 1 edge, 2 corner
+                us[nu++] = U{(long)nt * (meff / a.splits + 1), p, tap, sp, nt, t0,
+                             use_gangs == 1 ? ngang + sp : use_gangs == 2 ? ngang + sp * 3 + cls : -1, 0};
               }
           }
+          ngang += a.splits * 3;
         } else {
           int tiles = a.tiles_k * a.tiles_n, ch = unit_chunk(a.tiles_k, tiles, kind);
           for (int sp = 0; sp < a.splits; ++sp) {
             int mb = sp * a.m_per_split, me = a.M < mb + a.m_per_split ? a.M : mb + a.m_per_split;
             for (int t0 = 0; t0 < tiles; t0 += ch) {
               int nt = tiles - t0 < ch ? tiles - t0 : ch;
-              us[nu++] = U{(long)nt * (me > mb ? me - mb : 0), p, 0, sp, nt, t0};
+              us[nu++] = U{(long)nt * (me > mb ? me - mb : 0), p, 0, sp, nt, t0, -1, 0};
             }
           }
         }
       }
-      for (int a = 1; a < nu; ++a) {           // insertion sort, stable, descending weight (<= 192 entries)
+      for (int a = 0; a < nu; ++a) {           // a gang is dealt as one item of its units' total weight; a lone unit is its own gang
+        if (us[a].gang < 0) { us[a].gang = ngang++; us[a].gw = us[a].w; continue; }
+        long t = 0;
+        for (int b = 0; b < nu; ++b) if (us[b].gang == us[a].gang) t += us[b].w;
+        us[a].gw = t;
+      }
+      // insertion sort, stable (<= 192 entries): gangs by descending weight, inside a gang the heaviest unit first (the centre tap: the units past
+      // an XCD's 32 workgroup slots start late, they should be the short ones)
+      auto before = [](const U& p, const U& q) { return p.gw != q.gw ? p.gw > q.gw : p.gang != q.gang ? p.gang < q.gang : p.w > q.w; };
+      for (int a = 1; a < nu; ++a) {
         U v = us[a]; int b = a - 1;
-        while (b >= 0 && us[b].w < v.w) { us[b + 1] = us[b]; --b; }
+        while (b >= 0 && before(v, us[b])) { us[b + 1] = us[b]; --b; }
         us[b + 1] = v;
       }
       long load[8] = {0, 0, 0, 0, 0, 0, 0, 0};
       int slots[8] = {0, 0, 0, 0, 0, 0, 0, 0};
       for (int x = 0; x < 8; ++x) g.n_units[x] = 0;
+      int bx = -1;
       for (int a = 0; a < nu; ++a) {
-        int bx = -1;
-        for (int x = 0; x < 8; ++x)
-          if (g.n_units[x] < WG_GROUP_MAX_UNITS && (bx < 0 || load[x] < load[bx])) bx = x;
+        if (a == 0 || us[a].gang != us[a - 1].gang) {
+          int need = 1;
+          while (a + need < nu && us[a + need].gang == us[a].gang) ++need;
+          bx = -1;
+          for (int x = 0; x < 8; ++x)
+            if (g.n_units[x] + need <= WG_GROUP_MAX_UNITS && (bx < 0 || load[x] < load[bx])) bx = x;
+        }
+        if (bx < 0 || g.n_units[bx] >= WG_GROUP_MAX_UNITS) {          // no XCD has room for the whole gang: unit by unit
+          bx = -1;
+          for (int x = 0; x < 8; ++x)
+            if (g.n_units[x] < WG_GROUP_MAX_UNITS && (bx < 0 || load[x] < load[bx])) bx = x;
+        }
         int k = g.n_units[bx]++;
         g.unit_start[bx][k] = (unsigned short)slots[bx];
         g.unit_code[bx][k] = (unsigned short)(us[a].p | (us[a].tap << 5) | (us[a].s << 9));
