@@ -203,6 +203,11 @@ size_t unit_wgrad_problem_bytes(void);
 int unit_conv2d_wgrad_group_supported(int in_dtype, int N, int OH, int OW, int K, int R, int S, int C);
 int unit_conv2d_wgrad_group_plan(UnitWgradProblem* pr, int n, int splits_hint);
 int unit_conv2d_wgrad_group(const UnitWgradProblem* pr, int n, int in_dtype, void* stream);
+/* The grid(s) unit_conv2d_wgrad_group would launch for these (planned) problems, without launching (host only; pointers are checked for
+ * alignment, never read): one row of 9 ints per unit -- {launch, tile kind, XCD, first workgroup slot on that XCD, tiles, index into pr,
+ * filter tap, split, first tile of the unit within its (layer [, tap], split)}. Units that contract over the same rows share an XCD's L2:
+ * the tiles of one (layer, split), and for the in-map 3x3 form the filter taps that walk at the same pace (corner / edge / centre). */
+int unit_conv2d_wgrad_group_layout(const UnitWgradProblem* pr, int n, int* layout, int layout_rows, int* rows);
 /* stream fork / join without host-side event objects: everything enqueued on `waiter` after this call waits for everything enqueued on
  * `signaller` before it (the reference reaches this through torch.cuda.Stream.wait_stream / Event; here the step forks ~100 weight-gradient
  * launches per step to a side stream: engine/defaults.py:279-284's backward has no such structure, it is the explicit plan's own). */

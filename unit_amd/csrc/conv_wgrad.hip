@@ -511,17 +511,25 @@ static int units_of(const UnitWgradProblem& q) {
 
 // x / dy / partial as unit_conv2d_wgrad(dw = NULL) takes them, for n layers at once; pr[i].splits / kind from unit_conv2d_wgrad_group_plan.
 // Slab s of layer i at partial + s*K*R*S*C floats, same layout as unit_conv2d_wgrad's (unit_multi_wgrad_reduce folds them).
-extern "C" int unit_conv2d_wgrad_group(const UnitWgradProblem* pr, int n, int in_dtype, void* stream) {
-  UNIT_CHECK_ARG(in_dtype == UNIT_BF16, "wgrad_group: bf16 only");
-  UNIT_CHECK_ARG(pr != nullptr && n >= 0, "wgrad_group: no problems");
+// layout != nullptr: nothing is launched; one row of 9 ints per unit instead -- {launch, tile kind, XCD, first workgroup slot on that XCD, tiles, index
+// into pr, filter tap, split, first tile} (unit_conv2d_wgrad_group_layout: what the CPU tests check the dealing on)
+constexpr int WG_FIXED_STEPS = 6;          // a tile's fixed time in 64-pixel steps (~12 us against ~2.2 us per step, unit_conv2d_wgrad_group_plan)
+static int wgrad_group_run(const UnitWgradProblem* pr, int n, void* stream, int* layout, int layout_rows, int* rows_out) {
   static thread_local WgradGroupArgs g;         // 3.8 KB; filled and passed by value
-  struct U { long w; int p, tap, s, tiles, tile0, gang; long gw; };
+  int launch_no = 0, rows = 0, pidx[WG_GROUP_MAX_PROBLEMS];
+  struct U { long w; int p, tap, s, tiles, tile0, gang; long gw; int d; };
   static thread_local U us[8 * WG_GROUP_MAX_UNITS];
   // gangs (UNIT_WGRAD_GANG, profiles/r06_exp_wgrad_gangs.txt): the nine filter-tap units of one split of a valid_only 3x3 layer contract over the
   // SAME x / dy rows; dealt one by one (0) they land on up to eight XCDs and every one of those L2s fetches the rows for itself.
   // 1: all nine on one XCD (36 tiles on 32 CUs, and the taps drift apart: 36 / 42 / 49 valid positions per 7x7 image);
   // 2 (default): the taps that walk at the same pace -- 4 corner, 4 edge, the centre tap -- form a gang: a Res5 head's grid 4.00 -> 2.67 GB past L2
-  static const int use_gangs = [] { const char* e = getenv("UNIT_WGRAD_GANG"); return e ? atoi(e) : 2; }();
+  const char* gang_env = getenv("UNIT_WGRAD_GANG");          // read per call (a handful per step): the tests switch it in-process
+  const int use_gangs = gang_env ? atoi(gang_env) : 2;
+  // UNIT_WGRAD_DEAL: 0 = by summed weight alone (round 5), 1 = by makespan. Default: makespan for gangs, weight for single units (measured,
+  // isolated Res5-head grid: gangs 1 599 / 1 625 -> 1 564 / 1 588 us; single units 1 534 / 1 495 -> 1 643 / 1 611: the model's equal step time
+  // per tile is only roughly true)
+  const char* deal_env = getenv("UNIT_WGRAD_DEAL");
+  const bool deal_by_makespan = deal_env ? deal_env[0] != '0' : use_gangs != 0;
   for (int kind = 2; kind >= 1; --kind) {           // the long 256-tile grid first
     int i0 = 0;
     while (i0 < n) {
@@ -533,6 +541,7 @@ extern "C" int unit_conv2d_wgrad_group(const UnitWgradProblem* pr, int n, int in
         int rc = wgrad_group_fill(pr[i], g.p[cnt]);
         if (rc != UNIT_OK) return rc;
         units += units_of(pr[i]);
+        pidx[cnt] = i;
         ++cnt;
       }
       if (cnt == 0) {
@@ -557,7 +566,8 @@ extern "C" int unit_conv2d_wgrad_group(const UnitWgradProblem* pr, int n, int in
                 int nt = per - t0 < ch ? per - t0 : ch;
                 int cls = (kr != 1) + (ks != 1);            // 0 centre, 1 edge, 2 corner
                 us[nu++] = U{(long)nt * (meff / a.splits + 1), p, tap, sp, nt, t0,
-                             use_gangs == 1 ? ngang + sp : use_gangs == 2 ? ngang + sp * 3 + cls : -1, 0};
+                             use_gangs == 1 ? ngang + sp : use_gangs == 2 ? ngang + sp * 3 + cls : -1, 0,
+                             (int)(((meff + a.splits - 1) / a.splits + 63) / 64) + WG_FIXED_STEPS};
               }
           }
           ngang += a.splits * 3;
@@ -567,7 +577,7 @@ extern "C" int unit_conv2d_wgrad_group(const UnitWgradProblem* pr, int n, int in
             int mb = sp * a.m_per_split, me = a.M < mb + a.m_per_split ? a.M : mb + a.m_per_split;
             for (int t0 = 0; t0 < tiles; t0 += ch) {
               int nt = tiles - t0 < ch ? tiles - t0 : ch;
-              us[nu++] = U{(long)nt * (me > mb ? me - mb : 0), p, 0, sp, nt, t0, -1, 0};
+              us[nu++] = U{(long)nt * (me > mb ? me - mb : 0), p, 0, sp, nt, t0, -1, 0, (me > mb ? (me - mb + 63) / 64 : 0) + WG_FIXED_STEPS};
             }
           }
         }
@@ -589,6 +599,84 @@ extern "C" int unit_conv2d_wgrad_group(const UnitWgradProblem* pr, int n, int in
       long load[8] = {0, 0, 0, 0, 0, 0, 0, 0};
       int slots[8] = {0, 0, 0, 0, 0, 0, 0, 0};
       for (int x = 0; x < 8; ++x) g.n_units[x] = 0;
+      // the makespan rule costs ~4 ms for a Res5 head's 100 units and depends on shapes only: the last few problem lists' tables are kept
+      struct Dealt { int nkey, key[3 + 12 * WG_GROUP_MAX_PROBLEMS]; unsigned short start[8][WG_GROUP_MAX_UNITS + 1], code[8][WG_GROUP_MAX_UNITS],
+                     tile0[8][WG_GROUP_MAX_UNITS]; int n_units[8]; };
+      static thread_local Dealt dealt[8];
+      static thread_local int dealt_next = 0;
+      int key[3 + 12 * WG_GROUP_MAX_PROBLEMS], nkey = 0;
+      Dealt* hit = nullptr;
+      if (kind == 2 && deal_by_makespan) {
+        key[nkey++] = kind; key[nkey++] = cnt; key[nkey++] = use_gangs;
+        for (int p = 0; p < cnt; ++p) {
+          const Wgrad256Args& a = g.p[p];
+          const int f[12] = {a.N, a.H, a.W, a.C, a.K, a.R, a.S, a.stride, a.pad, a.OH, a.OW, a.splits};
+          for (int v : f) key[nkey++] = v;
+        }
+        for (int e = 0; e < 8 && !hit; ++e)
+          if (dealt[e].nkey == nkey && memcmp(dealt[e].key, key, sizeof(int) * nkey) == 0) hit = &dealt[e];
+      }
+      if (hit) {
+        memcpy(g.unit_start, hit->start, sizeof(g.unit_start)); memcpy(g.unit_code, hit->code, sizeof(g.unit_code));
+        memcpy(g.unit_tile0, hit->tile0, sizeof(g.unit_tile0)); memcpy(g.n_units, hit->n_units, sizeof(g.n_units));
+        for (int x = 0; x < 8; ++x) slots[x] = g.unit_start[x][g.n_units[x]];
+      } else if (kind == 2 && deal_by_makespan) {
+        // 256-tiles, one workgroup per CU: an XCD's 32 CUs take its slots in order, so what ends the grid is the XCD's list-scheduling makespan,
+        // not its summed weight (a Res5 head: 2.7 rounds of tiles that last 265 / 228 / 196 steps -- dealt by weight alone the 16-tile gangs cost
+        // 798 steps on the slowest XCD against 728, profiles/r06_exp_wgrad_gangs.txt). Every gang goes to the XCD whose makespan with it is the
+        // shortest (then the lighter one), an XCD's units run longest-first. Shapes only: cached per problem list.
+        static thread_local int xl[8][WG_GROUP_MAX_UNITS];
+        auto makespan = [&](int x, int a0, int na) {          // XCD x's units + us[a0 .. a0 + na), longest tiles first, on 32 CUs
+          int cu[32] = {0};
+          int ia = 0, ib = 0, nx = g.n_units[x], worst = 0;
+          while (ia < nx || ib < na) {
+            const U& v = (ib >= na || (ia < nx && us[xl[x][ia]].d >= us[a0 + ib].d)) ? us[xl[x][ia++]] : us[a0 + ib++];
+            for (int t = 0; t < v.tiles; ++t) {
+              int m = 0;
+              for (int c = 1; c < 32; ++c) if (cu[c] < cu[m]) m = c;
+              cu[m] += v.d;
+              if (cu[m] > worst) worst = cu[m];
+            }
+          }
+          return worst;
+        };
+        for (int a = 0; a < nu;) {
+          int need = 1;
+          while (a + need < nu && us[a + need].gang == us[a].gang) ++need;
+          for (int b = a + 1; b < a + need; ++b) {             // the gang's units longest first (they are merged into sorted lists)
+            U v = us[b]; int c = b - 1;
+            while (c >= a && us[c].d < v.d) { us[c + 1] = us[c]; --c; }
+            us[c + 1] = v;
+          }
+          int bx = -1, bm = 0, take = need;
+          for (;;) {
+            for (int x = 0; x < 8; ++x) {
+              if (g.n_units[x] + take > WG_GROUP_MAX_UNITS) continue;
+              int m = makespan(x, a, take);
+              if (bx < 0 || m < bm || (m == bm && load[x] < load[bx])) { bx = x; bm = m; }
+            }
+            if (bx >= 0 || take == 1) break;
+            take = 1;                                          // no XCD has entries for the whole gang: unit by unit
+          }
+          UNIT_CHECK_ARG(bx >= 0, "wgrad_group: unit table full");
+          for (int b = a; b < a + take; ++b) {                 // merge into the XCD's list, longest first, a gang's units adjacent
+            int k = g.n_units[bx]++;
+            while (k > 0 && us[xl[bx][k - 1]].d < us[b].d) { xl[bx][k] = xl[bx][k - 1]; --k; }
+            xl[bx][k] = b;
+            load[bx] += us[b].w;
+          }
+          a += take;
+        }
+        for (int x = 0; x < 8; ++x)
+          for (int k = 0; k < g.n_units[x]; ++k) {
+            const U& v = us[xl[x][k]];
+            g.unit_start[x][k] = (unsigned short)slots[x];
+            g.unit_code[x][k] = (unsigned short)(v.p | (v.tap << 5) | (v.s << 9));
+            g.unit_tile0[x][k] = (unsigned short)v.tile0;
+            slots[x] += v.tiles;
+            UNIT_CHECK_ARG(slots[x] < 65536, "wgrad_group: more than 65535 workgroups on one XCD");
+          }
+      } else {
       int bx = -1;
       for (int a = 0; a < nu; ++a) {
         if (a == 0 || us[a].gang != us[a - 1].gang) {
@@ -610,14 +698,45 @@ extern "C" int unit_conv2d_wgrad_group(const UnitWgradProblem* pr, int n, int in
         slots[bx] += us[a].tiles; load[bx] += us[a].w;
         UNIT_CHECK_ARG(slots[bx] < 65536, "wgrad_group: more than 65535 workgroups on one XCD");
       }
+      }
       int most = 0;
       for (int x = 0; x < 8; ++x) {
         g.unit_start[x][g.n_units[x]] = (unsigned short)slots[x];
         if (slots[x] > most) most = slots[x];
       }
+      if (nkey > 0 && !hit) {
+        Dealt& e = dealt[dealt_next++ & 7];
+        e.nkey = nkey; memcpy(e.key, key, sizeof(int) * nkey);
+        memcpy(e.start, g.unit_start, sizeof(g.unit_start)); memcpy(e.code, g.unit_code, sizeof(g.unit_code));
+        memcpy(e.tile0, g.unit_tile0, sizeof(g.unit_tile0)); memcpy(e.n_units, g.n_units, sizeof(g.n_units));
+      }
+      if (layout != nullptr) {
+        for (int x = 0; x < 8; ++x)
+          for (int k = 0; k < g.n_units[x]; ++k) {
+            UNIT_CHECK_ARG(rows < layout_rows, "wgrad_group_layout: more units than rows");
+            int* o = layout + 9 * rows++;
+            unsigned code = g.unit_code[x][k];
+            o[0] = launch_no; o[1] = kind; o[2] = x; o[3] = g.unit_start[x][k]; o[4] = g.unit_start[x][k + 1] - g.unit_start[x][k];
+            o[5] = pidx[code & 31]; o[6] = (code >> 5) & 15; o[7] = code >> 9; o[8] = g.unit_tile0[x][k];
+          }
+        ++launch_no;
+        continue;
+      }
       int rc = kind == 2 ? unit_wgrad256_group_launch(g, most, (hipStream_t)stream) : unit_wgrad128_group_launch(g, most, (hipStream_t)stream);
       if (rc != UNIT_OK) return rc;
     }
   }
+  if (rows_out) *rows_out = rows;
   return UNIT_OK;
+}
+
+extern "C" int unit_conv2d_wgrad_group(const UnitWgradProblem* pr, int n, int in_dtype, void* stream) {
+  UNIT_CHECK_ARG(in_dtype == UNIT_BF16, "wgrad_group: bf16 only");
+  UNIT_CHECK_ARG(pr != nullptr && n >= 0, "wgrad_group: no problems");
+  return wgrad_group_run(pr, n, stream, nullptr, 0, nullptr);
+}
+
+extern "C" int unit_conv2d_wgrad_group_layout(const UnitWgradProblem* pr, int n, int* layout, int layout_rows, int* rows) {
+  UNIT_CHECK_ARG(pr != nullptr && n >= 0 && layout != nullptr && rows != nullptr, "wgrad_group_layout: null argument");
+  return wgrad_group_run(pr, n, nullptr, layout, layout_rows, rows);
 }
